@@ -1,0 +1,125 @@
+"""ctypes binding of libsrbh.so (the C ABI declared in include/srbh.h) and its in-tree build recipe.
+
+The library is plain HIP behind ``extern "C"`` (no torch types); PyTorch only supplies device
+memory and the stream.  There is deliberately NO fallback: if the shared object is missing or a
+call fails, a RuntimeError is raised (SURVEY.md 8b "Errors").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+LIB_PATH = os.path.join(_HERE, "libsrbh.so")
+SOURCES = ["srbh_conv3x3.hip", "srbh_aux.hip", "srbh_rrdbnet.hip", "srbh_head.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into the in-tree libsrbh.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, "srbh_internal.h"), os.path.join(INCLUDE, "srbh.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    objs, procs = [], []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        objs.append(o)
+        cmd = [HIPCC, *HIPFLAGS, "-I", INCLUDE, "-I", CSRC, "-c", s, "-o", o]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out))
+        if verbose and out:
+            print(out)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return LIB_PATH
+
+
+# ---- C structs (mirror include/srbh.h) ------------------------------------------------------------
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("in_", C.c_void_p), ("in_chunks_total", C.c_int), ("in_chunk0", C.c_int), ("in_chunks", C.c_int),
+        ("w", C.c_void_p), ("bias", C.c_void_p), ("cout", C.c_int),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("upsample2x", C.c_int), ("lrelu", C.c_int),
+        ("res_scale", C.c_float), ("res1", C.c_void_p), ("res1_update", C.c_int),
+        ("res2_scale", C.c_float), ("res2", C.c_void_p), ("res2_update", C.c_int),
+        ("skip", C.c_void_p),
+        ("out16", C.c_void_p), ("out16_chunks_total", C.c_int), ("out16_chunk0", C.c_int),
+        ("out32", C.c_void_p), ("out32_c", C.c_int),
+    ]
+
+
+class ConvW(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p)]
+
+
+class RRDBNetDesc(C.Structure):
+    _fields_ = [
+        ("num_in_ch", C.c_int), ("num_block", C.c_int),
+        ("conv_first_w", C.c_void_p), ("conv_first_b", C.c_void_p),
+        ("rdb", C.POINTER(ConvW)),
+        ("conv_body", ConvW), ("conv_up1", ConvW), ("conv_up2", ConvW), ("conv_hr", ConvW),
+        ("conv_last", ConvW), ("num_out_ch", C.c_int),
+    ]
+
+
+# every exported symbol of include/srbh.h: name -> (restype, argtypes)
+_vp, _i, _sz, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+SIGNATURES = {
+    "srbh_version": (_i, []),
+    "srbh_last_error": (C.c_char_p, []),
+    "srbh_act16_bytes": (_sz, [_i, _i, _i, _i]),
+    "srbh_nchw32_to_act16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "srbh_act16_to_nchw32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "srbh_wpack16_bytes": (_sz, [_i, _i]),
+    "srbh_pack_conv3x3_f16": (_i, [_vp, _i, _i, _vp, _vp]),
+    "srbh_conv3x3_f16": (_i, [C.POINTER(ConvArgs), _vp]),
+    "srbh_conv_first_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "srbh_rrdbnet_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "srbh_rrdbnet_forward": (_i, [C.POINTER(RRDBNetDesc), _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib() -> C.CDLL:
+    """Load libsrbh.so (once).  Raises if it has not been built -- there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"libsrbh.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; "
+                        "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP hot path.")
+                l = C.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(l, name)  # AttributeError here == header/library mismatch
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().srbh_last_error().decode(errors="replace")
+        raise RuntimeError(f"libsrbh {what} failed (rc={rc}): {msg}")
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,51 @@
+// Internal helpers shared by the libsrbh translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "srbh.h"
+
+namespace srbh {
+
+constexpr int PIX_B = 64;       // bytes of one ACT16 pixel record (32 fp16 channels)
+constexpr int CHUNK_C = 32;     // channels per chunk plane
+constexpr int TILE_W = 64;      // output columns per workgroup
+constexpr int TILE_H = 8;       // output rows per workgroup
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define SRBH_HIP(call)                                         \
+    do {                                                       \
+        hipError_t e_ = (call);                                \
+        if (e_ != hipSuccess) return srbh::hip_fail(e_, #call); \
+    } while (0)
+
+#define SRBH_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            srbh::set_error(__VA_ARGS__);  \
+            return SRBH_ERR_ARG;           \
+        }                                  \
+    } while (0)
+
+// ACT16 geometry: [B][chunks][H+2][W+2][32] fp16 + read slack so tiled kernels may over-read.
+struct Act16Geo {
+    int row_b;       // bytes per padded row
+    int plane_b;     // bytes per chunk plane
+    long img_b;      // bytes per image
+    size_t total_b;  // bytes including slack
+};
+inline Act16Geo act16_geo(int B, int chunks, int H, int W) {
+    Act16Geo g;
+    g.row_b = (W + 2) * PIX_B;
+    g.plane_b = (H + 2) * g.row_b;
+    g.img_b = (long)chunks * g.plane_b;
+    // slack: a tile may read TILE_H+2 rows and TILE_W+2 columns starting anywhere inside the last plane
+    size_t slack = (size_t)(TILE_H + 4) * (size_t)((W + 2 > TILE_W + 2) ? (W + 2) : (TILE_W + 2)) * PIX_B + 8192;
+    g.total_b = (size_t)B * g.img_b + slack;
+    g.total_b = (g.total_b + 255) & ~(size_t)255;
+    return g;
+}
+
+}  // namespace srbh

@@ -1,0 +1,133 @@
+// srbh_rrdbnet.hip -- host-side driver that runs RRDBNet.forward_feature / forward
+// (reference SR/rrdbnet_arch.py:208-240) as a fixed sequence of libsrbh kernel launches on one stream.
+//
+// Dense-block concat is never materialised: one ACT16 buffer with 6 chunk planes per image holds
+// [x | x1 | x2 | x3 | x4] (SR/rrdbnet_arch.py:137-141); conv_k reads planes 0..k and writes plane k+1;
+// conv5 writes the next block's x into planes 0..1 of the other (ping-pong) buffer.  The fp32
+// residual streams (x5*0.2+x at :143, out*0.2+x at :167, feat+body_feat at :234) live in three RES32 buffers.
+#include "srbh_internal.h"
+
+using namespace srbh;
+
+namespace {
+
+struct WsLayout {
+    size_t d0, d1, feat, xr, xrr, u2, u3, u4, total;
+    size_t dense_b;
+};
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+WsLayout ws_layout(int B, int H, int W, int want_forward) {
+    WsLayout L;
+    size_t off = 0;
+    L.dense_b = act16_geo(B, 6, H, W).total_b;
+    L.d0 = off; off = align256(off + L.dense_b);
+    L.d1 = off; off = align256(off + L.dense_b);
+    size_t res_b = (size_t)B * H * W * 64 * sizeof(float);
+    L.feat = off; off = align256(off + res_b);
+    L.xr = off; off = align256(off + res_b);
+    L.xrr = off; off = align256(off + res_b);
+    L.u2 = off; off = align256(off + act16_geo(B, 2, 2 * H, 2 * W).total_b);
+    L.u3 = off; off = align256(off + act16_geo(B, 2, 4 * H, 4 * W).total_b);
+    L.u4 = off;
+    if (want_forward) off = align256(off + act16_geo(B, 2, 4 * H, 4 * W).total_b);
+    L.total = off;
+    return L;
+}
+
+}  // namespace
+
+extern "C" size_t srbh_rrdbnet_workspace_bytes(int B, int H, int W, int want_forward) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return ws_layout(B, H, W, want_forward).total;
+}
+
+extern "C" int srbh_rrdbnet_forward(const srbh_rrdbnet_desc* d, const float* x, float* out, int B, int H, int W,
+                                    int want_forward, void* ws, size_t ws_bytes, void* stream) {
+    SRBH_REQUIRE(d && x && out && ws, "srbh_rrdbnet_forward: null pointer");
+    SRBH_REQUIRE(B > 0 && H > 0 && W > 0, "srbh_rrdbnet_forward: bad geometry B=%d H=%d W=%d", B, H, W);
+    SRBH_REQUIRE(d->num_block >= 0 && d->rdb != nullptr, "srbh_rrdbnet_forward: bad descriptor");
+    const WsLayout L = ws_layout(B, H, W, want_forward);
+    if (ws_bytes < L.total) {
+        set_error("srbh_rrdbnet_forward: workspace %zu bytes < required %zu", ws_bytes, L.total);
+        return SRBH_ERR_WORKSPACE;
+    }
+    char* base = (char*)ws;
+    void* D[2] = {base + L.d0, base + L.d1};
+    float* feat = (float*)(base + L.feat);
+    float* xr = (float*)(base + L.xr);
+    float* xrr = (float*)(base + L.xrr);
+    void* U2 = base + L.u2;
+    void* U3 = base + L.u3;
+    void* U4 = base + L.u4;
+
+    int rc = srbh_conv_first_f32(x, d->conv_first_w, d->conv_first_b, B, d->num_in_ch, H, W, feat, xr, xrr, D[0], 6,
+                                 stream);
+    if (rc) return rc;
+
+    srbh_conv3x3_args a;
+    int cur = 0;
+    for (int blk = 0; blk < d->num_block; ++blk) {
+        for (int r = 0; r < 3; ++r) {
+            const srbh_conv_w* cw = d->rdb + (blk * 3 + r) * 5;
+            for (int k = 0; k < 4; ++k) {  // conv1..conv4: lrelu(conv(cat(x, x1..xk)))
+                a = srbh_conv3x3_args{};
+                a.in = D[cur]; a.in_chunks_total = 6; a.in_chunk0 = 0; a.in_chunks = 2 + k;
+                a.w = cw[k].w; a.bias = cw[k].bias; a.cout = 32;
+                a.B = B; a.H = H; a.W = W; a.lrelu = 1;
+                a.out16 = D[cur]; a.out16_chunks_total = 6; a.out16_chunk0 = 2 + k;
+                if ((rc = srbh_conv3x3_f16(&a, stream))) return rc;
+            }
+            a = srbh_conv3x3_args{};  // conv5 + x5*0.2 + x (+ out*0.2 + x_rrdb at the end of the RRDB)
+            a.in = D[cur]; a.in_chunks_total = 6; a.in_chunk0 = 0; a.in_chunks = 6;
+            a.w = cw[4].w; a.bias = cw[4].bias; a.cout = 64;
+            a.B = B; a.H = H; a.W = W;
+            a.res_scale = 0.2f; a.res1 = xr; a.res1_update = 1;
+            if (r == 2) { a.res2 = xrr; a.res2_scale = 0.2f; a.res2_update = 1; }
+            a.out16 = D[cur ^ 1]; a.out16_chunks_total = 6; a.out16_chunk0 = 0;
+            if ((rc = srbh_conv3x3_f16(&a, stream))) return rc;
+            cur ^= 1;
+        }
+    }
+    // conv_body + trunk skip
+    a = srbh_conv3x3_args{};
+    a.in = D[cur]; a.in_chunks_total = 6; a.in_chunk0 = 0; a.in_chunks = 2;
+    a.w = d->conv_body.w; a.bias = d->conv_body.bias; a.cout = 64;
+    a.B = B; a.H = H; a.W = W; a.skip = feat;
+    a.out16 = D[cur ^ 1]; a.out16_chunks_total = 6; a.out16_chunk0 = 0;
+    if ((rc = srbh_conv3x3_f16(&a, stream))) return rc;
+    // conv_up1 / conv_up2 read through the nearest-x2 index map
+    a = srbh_conv3x3_args{};
+    a.in = D[cur ^ 1]; a.in_chunks_total = 6; a.in_chunk0 = 0; a.in_chunks = 2;
+    a.w = d->conv_up1.w; a.bias = d->conv_up1.bias; a.cout = 64;
+    a.B = B; a.H = 2 * H; a.W = 2 * W; a.upsample2x = 1; a.lrelu = 1;
+    a.out16 = U2; a.out16_chunks_total = 2; a.out16_chunk0 = 0;
+    if ((rc = srbh_conv3x3_f16(&a, stream))) return rc;
+    a = srbh_conv3x3_args{};
+    a.in = U2; a.in_chunks_total = 2; a.in_chunk0 = 0; a.in_chunks = 2;
+    a.w = d->conv_up2.w; a.bias = d->conv_up2.bias; a.cout = 64;
+    a.B = B; a.H = 4 * H; a.W = 4 * W; a.upsample2x = 1; a.lrelu = 1;
+    a.out16 = U3; a.out16_chunks_total = 2; a.out16_chunk0 = 0;
+    if ((rc = srbh_conv3x3_f16(&a, stream))) return rc;
+    // conv_hr
+    a = srbh_conv3x3_args{};
+    a.in = U3; a.in_chunks_total = 2; a.in_chunk0 = 0; a.in_chunks = 2;
+    a.w = d->conv_hr.w; a.bias = d->conv_hr.bias; a.cout = 64;
+    a.B = B; a.H = 4 * H; a.W = 4 * W;
+    if (!want_forward) {
+        a.out32 = out; a.out32_c = 64;
+        return srbh_conv3x3_f16(&a, stream);
+    }
+    a.lrelu = 1;
+    a.out16 = U4; a.out16_chunks_total = 2; a.out16_chunk0 = 0;
+    if ((rc = srbh_conv3x3_f16(&a, stream))) return rc;
+    SRBH_REQUIRE(d->conv_last.w && d->num_out_ch >= 1 && d->num_out_ch <= 32,
+                 "srbh_rrdbnet_forward: conv_last needs 1..32 output channels (got %d)", d->num_out_ch);
+    a = srbh_conv3x3_args{};
+    a.in = U4; a.in_chunks_total = 2; a.in_chunk0 = 0; a.in_chunks = 2;
+    a.w = d->conv_last.w; a.bias = d->conv_last.bias; a.cout = 32;
+    a.B = B; a.H = 4 * H; a.W = 4 * W;
+    a.out32 = out; a.out32_c = d->num_out_ch;
+    return srbh_conv3x3_f16(&a, stream);
+}

@@ -1,0 +1,266 @@
+"""MI355X-native RRDBNet (Real-ESRGAN x4 generator) behind the reference's nn.Module interface.
+
+Mirror of the reference classes in SR/rrdbnet_arch.py:20-240 (constructor kwargs, ``forward`` /
+``forward_feature`` signatures, ``.scale`` attribute, state_dict keys ``conv_first.*``,
+``body.{i}.rdb{r}.conv{k}.*``, ``conv_body.*``, ``conv_up1.*``, ``conv_up2.*``, ``conv_hr.*``,
+``conv_last.*``).  The nn.Conv2d sub-modules here are *parameter containers only*: the forward
+pass is one call into libsrbh (hand-written gfx950 kernels, see csrc/), never torch conv ops.
+There is no CPU / eager fallback: calling forward on a non-ROCm tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from . import _lib
+
+__all__ = ["default_init_weights", "make_layer", "pixel_unshuffle", "ResidualDenseBlock", "RRDB", "RRDBNet",
+           "RealESRGAN"]
+
+
+@torch.no_grad()
+def default_init_weights(module_list, scale=1, bias_fill=0, **kwargs):
+    """Kaiming-normal x ``scale`` for conv/linear weights, constant bias; BN weight 1
+    (reference SR/rrdbnet_arch.py:20-48)."""
+    mods = module_list if isinstance(module_list, list) else [module_list]
+    for top in mods:
+        for m in top.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.kaiming_normal_(m.weight, **kwargs)
+                m.weight.mul_(scale)
+                if m.bias is not None:
+                    m.bias.fill_(bias_fill)
+            elif isinstance(m, nn.modules.batchnorm._BatchNorm):
+                nn.init.constant_(m.weight, 1)
+                if m.bias is not None:
+                    m.bias.fill_(bias_fill)
+
+
+def make_layer(basic_block, num_basic_block, **kwarg):
+    """nn.Sequential of ``num_basic_block`` fresh blocks (reference SR/rrdbnet_arch.py:51-64)."""
+    return nn.Sequential(*(basic_block(**kwarg) for _ in range(num_basic_block)))
+
+
+def pixel_unshuffle(x, scale):
+    """(b,c,hh,hw) -> (b,c*scale^2,hh/scale,hw/scale) (reference SR/rrdbnet_arch.py:94-110).
+    A pure index permutation; only on the scale 1/2 constructor paths, so it stays a torch view op."""
+    b, c, hh, hw = x.size()
+    assert hh % scale == 0 and hw % scale == 0
+    h, w = hh // scale, hw // scale
+    return x.view(b, c, h, scale, w, scale).permute(0, 1, 3, 5, 2, 4).reshape(b, c * scale * scale, h, w)
+
+
+def _no_eager(name):
+    raise RuntimeError(f"{name}: this module is a parameter container of the HIP RRDBNet; it has no eager forward. "
+                       "Call RRDBNet.forward / forward_feature (libsrbh) instead.")
+
+
+class ResidualDenseBlock(nn.Module):
+    """Parameter layout of the reference ResidualDenseBlock (SR/rrdbnet_arch.py:113-134): conv1..conv5."""
+
+    def __init__(self, num_feat=64, num_grow_ch=32):
+        super().__init__()
+        for k in range(1, 6):
+            cout = num_grow_ch if k < 5 else num_feat
+            setattr(self, f"conv{k}", nn.Conv2d(num_feat + (k - 1) * num_grow_ch, cout, 3, 1, 1))
+        self.lrelu = nn.LeakyReLU(negative_slope=0.2, inplace=True)
+        default_init_weights([getattr(self, f"conv{k}") for k in range(1, 6)], 0.1)
+
+    def forward(self, x):
+        _no_eager("ResidualDenseBlock")
+
+
+class RRDB(nn.Module):
+    """Parameter layout of the reference RRDB (SR/rrdbnet_arch.py:146-160): rdb1..rdb3."""
+
+    def __init__(self, num_feat, num_grow_ch=32):
+        super().__init__()
+        for r in (1, 2, 3):
+            setattr(self, f"rdb{r}", ResidualDenseBlock(num_feat, num_grow_ch))
+
+    def forward(self, x):
+        _no_eager("RRDB")
+
+
+class RRDBNet(nn.Module):
+    """Drop-in for the reference ``RRDBNet`` (SR/rrdbnet_arch.py:170-240) on MI355X."""
+
+    def __init__(self, num_in_ch, num_out_ch, scale=4, num_feat=64, num_block=23, num_grow_ch=32):
+        super().__init__()
+        self.scale = scale
+        if scale == 2:
+            num_in_ch = num_in_ch * 4
+        elif scale == 1:
+            num_in_ch = num_in_ch * 16
+        self.conv_first = nn.Conv2d(num_in_ch, num_feat, 3, 1, 1)
+        self.body = make_layer(RRDB, num_block, num_feat=num_feat, num_grow_ch=num_grow_ch)
+        self.conv_body = nn.Conv2d(num_feat, num_feat, 3, 1, 1)
+        self.conv_up1 = nn.Conv2d(num_feat, num_feat, 3, 1, 1)
+        self.conv_up2 = nn.Conv2d(num_feat, num_feat, 3, 1, 1)
+        self.conv_hr = nn.Conv2d(num_feat, num_feat, 3, 1, 1)
+        self.conv_last = nn.Conv2d(num_feat, num_out_ch, 3, 1, 1)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.2, inplace=True)
+        # geometry the gfx950 kernels are specialised for (explicit error otherwise, no second backend)
+        self._geom = (num_in_ch, num_out_ch, num_feat, num_block, num_grow_ch)
+        self._packed = None        # (key, buffers, desc) -- rebuilt whenever a parameter changes
+        self._workspaces = OrderedDict()
+
+    # ---- packed-weight cache -------------------------------------------------------------------
+    def _conv_list(self):
+        convs = []
+        for blk in self.body:
+            for r in (1, 2, 3):
+                rdb = getattr(blk, f"rdb{r}")
+                convs.extend(getattr(rdb, f"conv{k}") for k in range(1, 6))
+        convs += [self.conv_body, self.conv_up1, self.conv_up2, self.conv_hr, self.conv_last]
+        return convs
+
+    def _weights_key(self):
+        ver, ptr = 0, 0
+        for p in self.parameters():
+            ver += p._version
+            ptr ^= p.data_ptr()
+        return (ver, ptr)
+
+    def _apply(self, fn, *a, **kw):
+        self._packed = None
+        self._workspaces.clear()
+        return super()._apply(fn, *a, **kw)
+
+    def refresh_packed_weights(self):
+        """Force a repack (call after mutating ``.data`` in ways that bypass the version counters)."""
+        self._packed = None
+
+    @torch.no_grad()
+    def _pack(self, device):
+        L = _lib.lib()
+        num_in_ch, num_out_ch, num_feat, num_block, num_grow_ch = self._geom
+        if num_feat != 64 or num_grow_ch != 32:
+            raise NotImplementedError("libsrbh RRDBNet kernels are specialised for num_feat=64, num_grow_ch=32 "
+                                      f"(got {num_feat}, {num_grow_ch})")
+        if not 1 <= num_out_ch <= 32:
+            raise NotImplementedError("num_out_ch must be in 1..32")
+        convs = self._conv_list()
+        sizes = [L.srbh_wpack16_bytes(c.out_channels, c.in_channels) for c in convs]
+        offs, tot = [], 0
+        for s in sizes:
+            offs.append(tot)
+            tot += (s + 255) & ~255
+        wbuf = torch.zeros(tot, dtype=torch.uint8, device=device)
+        bias_pad = [(c.out_channels + 31) // 32 * 32 for c in convs]
+        bbuf = torch.zeros(sum(bias_pad), dtype=torch.float32, device=device)
+        st = _lib.stream_ptr()
+        keep = []
+        boffs, bo = [], 0
+        for c, off, bp in zip(convs, offs, bias_pad):
+            w = c.weight.detach().to(device=device, dtype=torch.float32).contiguous()
+            keep.append(w)
+            _lib.check(L.srbh_pack_conv3x3_f16(w.data_ptr(), c.out_channels, c.in_channels, wbuf.data_ptr() + off, st),
+                       "pack_conv3x3_f16")
+            if c.bias is not None:
+                bbuf[bo:bo + c.out_channels] = c.bias.detach().float()
+            boffs.append(bo)
+            bo += bp
+        n_rdb = num_block * 15
+        rdb_arr = (_lib.ConvW * max(n_rdb, 1))()
+        for i in range(n_rdb):
+            rdb_arr[i].w = wbuf.data_ptr() + offs[i]
+            rdb_arr[i].bias = bbuf.data_ptr() + 4 * boffs[i]
+        d = _lib.RRDBNetDesc()
+        d.num_in_ch = num_in_ch
+        d.num_block = num_block
+        cf_w = self.conv_first.weight.detach().to(device=device, dtype=torch.float32).contiguous()
+        cf_b = self.conv_first.bias.detach().to(device=device, dtype=torch.float32).contiguous()
+        d.conv_first_w = cf_w.data_ptr()
+        d.conv_first_b = cf_b.data_ptr()
+        d.rdb = C.cast(rdb_arr, C.POINTER(_lib.ConvW))
+        for j, name in enumerate(("conv_body", "conv_up1", "conv_up2", "conv_hr", "conv_last")):
+            cw = _lib.ConvW(wbuf.data_ptr() + offs[n_rdb + j], bbuf.data_ptr() + 4 * boffs[n_rdb + j])
+            setattr(d, name, cw)
+        d.num_out_ch = num_out_ch
+        torch.cuda.current_stream().synchronize()  # `keep` temporaries may be freed after this
+        return (wbuf, bbuf, cf_w, cf_b, rdb_arr), d
+
+    def _workspace(self, B, H, W, want_forward, device):
+        key = (B, H, W, int(want_forward), device)
+        ws = self._workspaces.get(key)
+        if ws is None:
+            n = _lib.lib().srbh_rrdbnet_workspace_bytes(B, H, W, int(want_forward))
+            ws = torch.zeros(n, dtype=torch.uint8, device=device)  # zero borders are an invariant of the kernels
+            self._workspaces[key] = ws
+            while len(self._workspaces) > 2:
+                self._workspaces.popitem(last=False)
+        else:
+            self._workspaces.move_to_end(key)
+        return ws
+
+    # ---- forward -------------------------------------------------------------------------------
+    def _run(self, x, want_forward):
+        if not (torch.is_tensor(x) and x.is_cuda):
+            raise RuntimeError("RRDBNet (libsrbh): input must be a ROCm/HIP device tensor; the hot path has no CPU "
+                               "fallback (use oracle/ in tests for a CPU comparison)")
+        if x.dim() != 4:
+            raise ValueError(f"expected a (B,C,H,W) tensor, got shape {tuple(x.shape)}")
+        if self.scale == 2:
+            x = pixel_unshuffle(x, 2)
+        elif self.scale == 1:
+            x = pixel_unshuffle(x, 4)
+        x = x.detach().to(torch.float32).contiguous()
+        B, Cin, H, W = x.shape
+        if Cin != self._geom[0]:
+            raise ValueError(f"expected {self._geom[0]} input channels, got {Cin}")
+        with torch.cuda.device(x.device):
+            key = self._weights_key()
+            if self._packed is None or self._packed[0] != key:
+                bufs, desc = self._pack(x.device)
+                self._packed = (key, bufs, desc)
+            desc = self._packed[2]
+            ws = self._workspace(B, H, W, want_forward, x.device)
+            cout = self._geom[1] if want_forward else 64
+            out = torch.empty((B, cout, 4 * H, 4 * W), dtype=torch.float32, device=x.device,
+                              memory_format=torch.channels_last)
+            L = _lib.lib()
+            _lib.check(L.srbh_rrdbnet_forward(C.byref(desc), x.data_ptr(), out.data_ptr(), B, H, W, int(want_forward),
+                                              ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "rrdbnet_forward")
+        return out
+
+    def forward(self, x):
+        """reference SR/rrdbnet_arch.py:208-223 -> (B,num_out_ch,4H,4W), channels_last strides."""
+        return self._run(x, True)
+
+    def forward_feature(self, x):
+        """reference SR/rrdbnet_arch.py:225-240 -> (B,64,4H,4W) features, NO activation after conv_hr;
+        returned with channels_last strides (logical NCHW shape as in the reference)."""
+        return self._run(x, False)
+
+
+class RealESRGAN:
+    """Minimal stand-in for the reference GAN wrapper (SR/rrdbnet_arch.py:437-633): the height stage only
+    touches ``.net_g`` (train.py:133-140, predict_realesanet_feature_globe.py:95-102).  No cv2 / VGG19 /
+    discriminator side effects; SR-stage GAN training is out of scope."""
+
+    def __init__(self, in_ch=3, out_ch=3, num_block=23, device="cuda", scale=4, ema_decay=0.999,
+                 pretrain_g_path=None, pretrain_d_path=None, is_train=False):
+        if is_train:
+            raise NotImplementedError("SR-stage GAN fine-tuning is outside the MI355X hot path (SURVEY.md 8f-4)")
+        self.device = device
+        self.scale = scale
+        self.ema_decay = ema_decay
+        self.is_train = False
+        self.net_g = RRDBNet(in_ch, out_ch, scale=scale, num_block=num_block).to(device)
+        if pretrain_g_path is not None:
+            ckpt = torch.load(pretrain_g_path, map_location="cpu")
+            for k in ("params_ema", "net_g_ema", "params"):
+                if isinstance(ckpt, dict) and k in ckpt:
+                    ckpt = ckpt[k]
+                    break
+            self.net_g.load_state_dict(ckpt, strict=True)
+        self.net_g.eval()
+
+    @torch.no_grad()
+    def predict(self, lr):
+        return self.net_g(lr.to(self.device))

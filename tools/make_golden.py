@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the *imported reference* and pin the oracle against it.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU box).
+The reference's unrelated import-time dependencies (cv2, torchvision, rasterio) are replaced by
+empty stub modules; nothing from them is used by the hot path.
+
+For every fixture this script (1) instantiates the reference module, (2) loads the deterministic
+synthetic state_dict from oracle/synth.py into it (strict=True -- this is also the state_dict
+layout check), (3) runs the reference, (4) runs oracle/srbh_oracle.py on the same tensors and
+asserts agreement (<=1e-6 rel-L2; bit-exact for index maps), (5) stores inputs-by-seed and
+reference outputs as small arrays.  Weights are never stored: tests regenerate them by seed.
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+for _m in ("cv2", "torchvision", "torchvision.models", "rasterio"):
+    sys.modules.setdefault(_m, types.ModuleType(_m))
+sys.path.insert(0, "/root/reference")
+import SR.rrdbnet_arch as ref_rrdb   # noqa: E402
+import SR.HRfuse as ref_hr           # noqa: E402
+import aggregate_utils as ref_agg    # noqa: E402
+
+from oracle import srbh_oracle as O  # noqa: E402
+from oracle import synth             # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def check(name, got, want, tol=1e-6):
+    e = O.rel_l2(got, want)
+    assert e <= tol, f"{name}: oracle vs reference rel-L2 {e:.3e} > {tol}"
+    print(f"  pinned {name}: rel-L2 {e:.2e}")
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def rand(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+# ---- G1/G2: ResidualDenseBlock, RRDB ---------------------------------------------------------
+def g_rdb():
+    full = synth.rrdbnet_state_dict(num_block=1, seed=11, mode="stress")
+    sd_rdb = {k[len("body.0.rdb1."):]: v for k, v in full.items() if k.startswith("body.0.rdb1.")}
+    m = ref_rrdb.ResidualDenseBlock(64, 32)
+    m.load_state_dict(sd_rdb, strict=True)
+    x = rand((1, 64, 16, 16), 101)
+    with torch.no_grad():
+        y = m(x)
+    check("G1 rdb", O.rdb(full, "body.0.rdb1.", x), y)
+    sd_rrdb = {k[len("body.0."):]: v for k, v in full.items() if k.startswith("body.0.")}
+    m2 = ref_rrdb.RRDB(64, 32)
+    m2.load_state_dict(sd_rrdb, strict=True)
+    x2 = rand((2, 64, 12, 12), 102)
+    with torch.no_grad():
+        y2 = m2(x2)
+    check("G2 rrdb", O.rrdb(full, "body.0.", x2), y2)
+    save("g1_g2_rdb", rdb_out=y, rrdb_out=y2)
+
+
+# ---- G3: 2-block RRDBNet, forward + forward_feature; scale 1/2 ctor paths ----------------------
+def g_small_net():
+    arrs = {}
+    for scale, hw in ((4, 8), (2, 16), (1, 16)):
+        sd = synth.rrdbnet_state_dict(num_block=2, scale=scale, seed=12, mode="stress")
+        m = ref_rrdb.RRDBNet(3, 3, scale=scale, num_block=2)
+        m.load_state_dict(sd, strict=True)
+        m.eval()
+        x = rand((1, 3, hw, hw), 103 + scale, 0.0, 1.0)
+        with torch.no_grad():
+            ff, fw = m.forward_feature(x), m.forward(x)
+        check(f"G3 forward_feature scale{scale}", O.rrdbnet_forward_feature(sd, x, scale), ff)
+        check(f"G3 forward scale{scale}", O.rrdbnet_forward(sd, x, scale), fw)
+        arrs[f"ff_s{scale}"] = ff
+        arrs[f"fw_s{scale}"] = fw
+    save("g3_rrdbnet_small", **arrs)
+
+
+# ---- G4: the full 23-block net on one 64x64 tile (config 1) -----------------------------------
+def g_full_net():
+    for mode in ("init", "stress"):
+        sd = synth.rrdbnet_state_dict(seed=1337, mode=mode)
+        m = ref_rrdb.RRDBNet(3, 3)
+        m.load_state_dict(sd, strict=True)
+        m.eval()
+        assert sum(p.numel() for p in m.parameters()) == 16_697_987
+        assert len(m.state_dict()) == 702
+        x = synth.tiles(1, 8, 64, seed=1337)[:, :3]
+        with torch.no_grad():
+            y = m.forward_feature(x)
+        assert y.shape == (1, 64, 256, 256)
+        check(f"G4 full forward_feature [{mode}]", O.rrdbnet_forward_feature(sd, x), y)
+        crops = {}
+        for name, (r, c) in {"tl": (0, 0), "tr": (0, 248), "bl": (248, 0), "br": (248, 248), "ce": (124, 124)}.items():
+            crops["crop_" + name] = y[0, :, r:r + 8, c:c + 8].clone()
+        save(f"g4_rrdbnet_full_{mode}", ch_mean=y.double().mean((0, 2, 3)), ch_std=y.double().std((0, 2, 3)),
+             checksum=y.double().sum(), abs_max=y.abs().max(), row_sum=y[0].double().sum((0, 2)), **crops)
+
+
+# ---- G5: index maps (bit exact) ------------------------------------------------------------------
+def g_index_maps():
+    x = torch.arange(2 * 64 * 5 * 7, dtype=torch.float32).reshape(2, 64, 5, 7)
+    ps = torch.nn.PixelShuffle(2)(x)
+    assert torch.equal(O.pixel_shuffle(x, 2), ps)
+    nn_up = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
+    assert torch.equal(O.nearest2x(x), nn_up)
+    xu = torch.arange(1 * 3 * 8 * 12, dtype=torch.float32).reshape(1, 3, 8, 12)
+    for s in (2, 4):
+        assert torch.equal(O.pixel_unshuffle(xu, s), ref_rrdb.pixel_unshuffle(xu, s))
+    # Upsampler with identity-like conv is still conv+shuffle: store the exact reference result on arange input
+    sd = synth.hrfuse_residual_state_dict(16, 16, 16, 1, 4, seed=15, mode="stress")
+    up_sd = {k[len("upsampler."):]: v for k, v in sd.items() if k.startswith("upsampler.")}
+    m = ref_hr.Upsampler(scale=4, n_feats=16)
+    m.load_state_dict(up_sd, strict=True)
+    xa = rand((1, 16, 6, 6), 105)
+    with torch.no_grad():
+        ya = m(xa)
+    check("G5 upsampler", O.upsampler(sd, "upsampler.", xa, 4), ya, 1e-7)
+    print("  pinned G5 index maps: bit-exact")
+    save("g5_index_maps", ps2=ps, nearest2=nn_up, unshuffle2=ref_rrdb.pixel_unshuffle(xu, 2),
+         unshuffle4=ref_rrdb.pixel_unshuffle(xu, 4), upsampler_out=ya)
+
+
+# ---- G6/G7: BasicBlock / HRfeature / HRfuse_residual, train (fwd, running stats, grads) + eval -------
+def _train_eval(module, sd, prefix_fn, inputs, oracle_fn, tag, arrs):
+    module.load_state_dict(sd, strict=True)
+    # eval
+    module.eval()
+    with torch.no_grad():
+        ye = module(*inputs)
+    check(f"{tag} eval", oracle_fn(synth.clone_sd(sd), False, *inputs), ye)
+    arrs[tag + "_eval"] = ye
+    # train: forward, backward of sum(y * w) with a fixed pseudo-random w, updated running stats
+    module.train()
+    ins = [t.clone().requires_grad_(True) for t in inputs]
+    yt = module(*ins)
+    wgt = rand(tuple(yt.shape), 777)
+    (yt * wgt).sum().backward()
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    oins = [t.clone().requires_grad_(True) for t in inputs]
+    yo = oracle_fn(osd, True, *oins)
+    (yo * wgt).sum().backward()
+    check(f"{tag} train fwd", yo, yt)
+    arrs[tag + "_train"] = yt.detach()
+    for i, (a, b) in enumerate(zip(oins, ins)):
+        check(f"{tag} dx{i}", a.grad, b.grad, 2e-6)
+        arrs[f"{tag}_dx{i}"] = b.grad
+    msd = module.state_dict()
+    for k, p in module.named_parameters():
+        check(f"{tag} d{k}", osd[k].grad, p.grad, 5e-6)
+        arrs[f"{tag}_grad_{k}"] = p.grad
+    for k, v in msd.items():
+        if "running" in k or "num_batches" in k:
+            assert torch.allclose(osd[k].double(), v.double(), rtol=1e-6, atol=1e-7), k
+            arrs[f"{tag}_stat_{k}"] = v
+
+
+def g_head():
+    arrs = {}
+    sd = {}
+    synth.basicblock_state_dict(sd, "", 32, 16, 16, "stress")
+    _train_eval(ref_hr.BasicBlock(32, 16), sd, None, [rand((2, 32, 12, 12), 106)],
+                lambda s, tr, x: O.basic_block(s, "", x, tr), "g6_bb32_16", arrs)
+    sd = {}
+    synth.basicblock_state_dict(sd, "", 16, 16, 17, "stress")
+    _train_eval(ref_hr.BasicBlock(16, 16), sd, None, [rand((2, 16, 12, 12), 107)],
+                lambda s, tr, x: O.basic_block(s, "", x, tr), "g6_bb16_16", arrs)
+    save("g6_basicblock", **arrs)
+
+    arrs = {}
+    sd = synth.hrfeature_state_dict(64, 16, 16, seed=18, mode="stress")
+    m = ref_hr.HRfeature(64, 16, 16)
+    assert len(m.state_dict()) == 42 and sum(p.numel() for p in m.parameters()) == 21_984
+    _train_eval(m, sd, None, [rand((2, 64, 16, 16), 108)],
+                lambda s, tr, x: O.hrfeature(s, "", x, tr), "g7_hrfeat", arrs)
+    for oc, npar in ((1, 35_569), (7, 36_439)):
+        sd = synth.hrfuse_residual_state_dict(16, 16, 16, oc, 4, seed=19 + oc, mode="stress")
+        m = ref_hr.HRfuse_residual(16, 16, 16, oc, 4)
+        assert len(m.state_dict()) == 48 and sum(p.numel() for p in m.parameters()) == npar
+        _train_eval(m, sd, None, [rand((2, 16, 4, 4), 109), rand((2, 16, 16, 16), 110)],
+                    lambda s, tr, a, b: O.hrfuse_residual(s, "", a, b, tr), f"g7_fuse{oc}", arrs)
+    save("g7_head", **arrs)
+
+
+# ---- G8: aggregate_torch ------------------------------------------------------------------------------
+def g_aggregate():
+    hist = np.loadtxt("/root/reference/datasetglobe/bh_stats_globe.txt") if os.path.exists(
+        "/root/reference/datasetglobe/bh_stats_globe.txt") else None
+    g = torch.Generator()
+    g.manual_seed(120)
+    if hist is not None and hist.size >= 256:
+        p = torch.from_numpy(np.asarray(hist).reshape(-1)[:256]).double()
+        p = p / p.sum()
+        lab = torch.multinomial(p, 256 * 256, replacement=True, generator=g).reshape(1, 1, 256, 256).float()
+    else:
+        lab = torch.randint(0, 256, (1, 1, 256, 256), generator=g).float()
+    lab[0, 0, :8, :8] = -1.0  # exercise the (data>=0) mask branch
+    want = ref_agg.aggregate_torch(lab, 0.25)
+    got = O.aggregate_torch(lab, 0.25)
+    assert torch.equal(got, want), "aggregate_torch must be bit-exact (same op order)"
+    print("  pinned G8 aggregate_torch: bit-exact")
+    save("g8_aggregate", label=lab.to(torch.int16), out=want)
+
+
+if __name__ == "__main__":
+    g_rdb()
+    g_small_net()
+    g_index_maps()
+    g_head()
+    g_aggregate()
+    g_full_net()
+    print("all fixtures written; oracle pinned against the imported reference")
