@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py -- tiles/s of the MI355X-native hot path (BASELINE.json metric) + roofline + CPU baseline.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (default, BASELINE.json configs[1]): RRDBNet x4 (23 RRDB, 64 feat) forward_feature, batch 32
+synthetic 64x64 tiles per GPU, inputs resident in HBM, random-init weights of the reference architecture.
+A "step" is one forward_feature over one batch.  Tiles are independent, so ranks shard the tile stream with
+no data-path collective ("scaling": "weak"); the only collectives are the timing barrier / max.
+
+One JSON line is printed by rank 0 (contract in the task statement); extra keys:
+  roofline     -- MFMA roofline of the conv stack: 146.630 GFLOP per tile (hook-counted on the
+                  reference) x tiles per step / step duration measured with HIP events on the launch stream.
+  cpu_baseline -- the CPU oracle (oracle/srbh_oracle.py, proven equal to the reference) timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+GFLOP_PER_TILE_FEATURE = 146.630   # 2*9*Cin*Cout*H*W over the 350 convs of forward_feature
+PEAK_F16_TFLOPS = 2500.0           # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md), never the sparse figure
+
+
+def cpu_baseline(sd, seconds_budget=25.0):
+    """Oracle forward_feature on the host cores: B=4 tiles per call, median of >=3 calls after one warm-up."""
+    from oracle import srbh_oracle as O, synth
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    x = synth.tiles(4, 8, 64, seed=1)[:, :3].contiguous()
+    sd_cpu = {k: v.float() for k, v in sd.items()}
+    O.rrdbnet_forward_feature(sd_cpu, x[:1])  # warm-up (oneDNN primitive creation)
+    times, t_start = [], time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_start < seconds_budget * 0.5 and len(times) < 7):
+        t0 = time.perf_counter()
+        O.rrdbnet_forward_feature(sd_cpu, x)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(4 / med, 3), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"oracle RRDBNet.forward_feature fp32, B=4 tiles (64x64x3 -> 64x256x256), median of {len(times)} "
+                      f"calls after 1 warm-up ({sum(times):.1f} s of CPU work)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="tiles per GPU per step (configs[1]: 32)")
+    ap.add_argument("--num-block", type=int, default=23)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback for the hot path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from oracle import synth  # synthetic weights/inputs only (the checker itself runs in cpu_baseline)
+    from srbh_amd.rrdbnet import RRDBNet
+
+    sd = synth.rrdbnet_state_dict(num_block=args.num_block, seed=1337, mode="init")
+    net = RRDBNet(3, 3, num_block=args.num_block)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    B = args.batch
+    x = synth.tiles(B, 8, 64, seed=1337 + rank)[:, :3].contiguous().to(dev)  # rgbseq=[0,1,2] (train.py:32,244)
+
+    def step():
+        with torch.no_grad():
+            return net.forward_feature(x)
+
+    for _ in range(args.warmup):
+        y = step()
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    ev0 = torch.cuda.Event(enable_timing=True)   # torch's current stream == the stream libsrbh launches on
+    ev1 = torch.cuda.Event(enable_timing=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        y = step()
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    assert bool(torch.isfinite(y[0, :, ::16, ::16]).all())
+
+    if dist is not None:
+        t = torch.tensor([elapsed, gpu_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, gpu_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        tiles = B * args.steps * world
+        step_s_events = gpu_ms / 1e3 / args.steps
+        achieved = GFLOP_PER_TILE_FEATURE * (args.num_block * 5.8886 + 11.19) / 146.630 if args.num_block != 23 \
+            else GFLOP_PER_TILE_FEATURE
+        tflops = achieved * B / step_s_events / 1e3
+        line = {
+            "metric": "tiles/sec (64x64x8ch->256x256 height)", "value": round(tiles / elapsed, 2), "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16 operands / f32 accumulate (MFMA), f32 residual stream",
+            "data": "synthetic uniform[0,1) tiles, random-init weights (no datasets/checkpoints offline)",
+            "config": {"workload": f"RRDBNet x4 ({args.num_block} RRDB, 64 feat) forward_feature, batch {B} tiles/GPU, "
+                                   "64x64x3 -> 64x256x256 (BASELINE.json configs[1])",
+                       "global_batch": B * world, "parallelism": f"tile-sharded x{world} (no data-path collective)"},
+            "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tflops / PEAK_F16_TFLOPS, 4), "traffic": None,
+                         "kernel": "conv3x3_f16_kernel (all 349 MFMA conv launches of one forward_feature; "
+                                   "HIP-event time of the whole launch sequence / steps)",
+                         "ms_per_launch_sequence": round(step_s_events * 1e3, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

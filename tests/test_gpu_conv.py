@@ -33,13 +33,10 @@ def test_conv_plain_lrelu_out16(B, cin, cout, H, W):
     x, w, b = rnd((B, cin, H, W), 1), rnd((cout, cin, 3, 3), 2, -0.1, 0.1), rnd((cout,), 3)
     xin = G.act16_from_nchw(x.to(DEV))
     out = G.act16_alloc(B, cout // 32, H, W, DEV)
+    wp, bias_dev = G.pack_w(w.to(DEV)), b.to(DEV)
     a = G.conv_args(**{"in": xin.data_ptr()}, in_chunks_total=cin // 32, in_chunk0=0, in_chunks=cin // 32,
-                    w=G.pack_w(w.to(DEV)).data_ptr(), bias=b.to(DEV).data_ptr(), cout=cout, B=B, H=H, W=W, lrelu=1,
+                    w=wp.data_ptr(), bias=bias_dev.data_ptr(), cout=cout, B=B, H=H, W=W, lrelu=1,
                     out16=out.data_ptr(), out16_chunks_total=cout // 32, out16_chunk0=0)
-    bias_dev = b.to(DEV)
-    a.bias = bias_dev.data_ptr()
-    wp = G.pack_w(w.to(DEV))
-    a.w = wp.data_ptr()
     G.run_conv(a)
     got = G.act16_to_nchw(out, B, cout, H, W).cpu()
     want = torch.nn.functional.leaky_relu(G.ref_conv(x, w, b), 0.2)
@@ -119,7 +116,7 @@ def test_conv_dense_chunk_offsets_and_residual_epilogues():
     want = (G.ref_conv(x, w, b) * 0.2 + r1) * 0.2 + r2
     assert O.rel_l2(res1.permute(0, 3, 1, 2).cpu(), want) <= TIGHT
     assert O.rel_l2(res2.permute(0, 3, 1, 2).cpu(), want) <= TIGHT
-    assert O.rel_l2(G.act16_to_nchw(nxt, B, 64, H, W).cpu(), G.h16(want)) <= 3e-4
+    assert O.rel_l2(G.act16_to_nchw(nxt, B, 192, H, W)[:, :64].cpu(), G.h16(want)) <= 3e-4
     # rdb1/rdb2 flavour: only res1, and a middle-plane output (conv3 writes plane 4 of the same buffer it reads)
     res1b = r1.permute(0, 2, 3, 1).contiguous().to(DEV)
     a2 = G.conv_args(**{"in": xin.data_ptr()}, in_chunks_total=6, in_chunk0=0, in_chunks=6, w=wp.data_ptr(),
