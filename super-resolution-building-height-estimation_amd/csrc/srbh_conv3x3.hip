@@ -21,215 +21,15 @@
 // lane-linear) and on the ds_read_b128 address -- same involution on both sides.
 #include "srbh_internal.h"
 
+#include "srbh_conv3x3_kernel.h"
+
 namespace {
 using namespace srbh;
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-#define GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
-#define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
-
-template <int UPS>
-struct TileGeo {
-    static constexpr int ROWS = UPS ? (TILE_H / 2 + 2) : (TILE_H + 2);
-    static constexpr int COLS = UPS ? (TILE_W / 2 + 2) : (TILE_W + 2);
-    static constexpr int ROW_B = COLS * PIX_B;
-    static constexpr int UNITS = ROWS * COLS * 4;           // 16-byte units in the tile
-    static constexpr int NJ = (UNITS + 255) / 256;          // LDS-DMA instructions per thread per chunk
-    static constexpr int IN_B = UNITS * 16;
-    static constexpr int NP = UPS ? 4 : 6;                  // distinct pixel-fragment rows per wave
-};
-
-struct KParams {
-    const char* in;
-    long in_img_b;
-    int in_plane_b;
-    int in_row_b;
-    int nchunk;
-    const char* w;
-    const float* bias;
-    int H, W;
-    int tiles_x, tiles_per_img, nblocks;
-    int lrelu;
-    float res_scale, res2_scale;
-    float* res1;
-    float* res2;
-    const float* skip;
-    int res1_update, res2_update;
-    char* out16;
-    long out16_img_b;
-    int out16_plane_b;
-    int out16_row_b;
-    float* out32;
-    int out32_c;
-};
-
-// XCD-aware bijective remap: hardware places block b on XCD b%8 (speed only, never correctness);
-// give every XCD a contiguous range of tiles so the row-blocks of one image share an L2.
-__device__ __forceinline__ int xcd_remap(int bid, int n) {
-    const int q = n >> 3, r = n & 7;
-    const int xcd = bid & 7, j = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-}
-
-template <int CB, int UPS>
-__global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const KParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    using G = TileGeo<UPS>;
-    constexpr int W_B = 18 * 1024 * CB;  // weight bytes per input chunk
-    constexpr int STAGE_B = G::IN_B + W_B;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;
-
-    const int t = xcd_remap(blockIdx.x, p.nblocks);
-    const int img = t / p.tiles_per_img;
-    const int trem = t - img * p.tiles_per_img;
-    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
-    const int Y0 = ty * TILE_H, X0 = tx * TILE_W;
-
-    // ---- staging set-up: unit u of the LDS tile <- 16 bytes of the padded source plane
-    const char* src0 = p.in + (long)img * p.in_img_b + (long)(UPS ? (Y0 >> 1) : Y0) * p.in_row_b +
-                       (UPS ? (X0 >> 1) : X0) * PIX_B;
-    int goff[G::NJ];
-#pragma unroll
-    for (int j = 0; j < G::NJ; ++j) {
-        const int u = j * 256 + tid;
-        const int trow = u / (G::COLS * 4);
-        const int rem = u - trow * (G::COLS * 4);
-        const int pc = rem >> 2, ps = rem & 3;
-        goff[j] = trow * p.in_row_b + pc * PIX_B + ((ps ^ ((pc >> 2) & 3)) << 4);
-    }
-    const char* wsrc = p.w + lane * 16;
-
-    auto stage = [&](int chunk, int buf) {
-        char* dst = smem + buf * STAGE_B;
-        const char* s = src0 + (long)chunk * p.in_plane_b;
-#pragma unroll
-        for (int j = 0; j < G::NJ; ++j) {
-            if (j * 256 + 255 < G::UNITS || j * 256 + tid < G::UNITS)
-                __builtin_amdgcn_global_load_lds(GPTR(s + goff[j]), LPTR(dst + (j * 256 + wave * 64) * 16), 16, 0, 0);
-        }
-        const char* ws = wsrc + (long)chunk * W_B;
-        char* wdst = dst + G::IN_B;
-        for (int f = wave; f < 18 * CB; f += 4)
-            __builtin_amdgcn_global_load_lds(GPTR(ws + f * 1024), LPTR(wdst + f * 1024), 16, 0, 0);
-    };
-
-    // ---- per-lane operand addresses inside a stage
-    int aoff[3][2];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-        const int pc = UPS ? (((wc * 32 + l31 + dx - 1) >> 1) + 1) : (wc * 32 + l31 + dx);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            aoff[dx][ks] = wr * (UPS ? 2 : 4) * G::ROW_B + pc * PIX_B + (((ks * 2 + hi) ^ ((pc >> 2) & 3)) << 4);
-    }
-    const int woff = G::IN_B + lane * 16;
-
-    floatx16 acc[CB][4];
-#pragma unroll
-    for (int mb = 0; mb < CB; ++mb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
-
-    stage(0, 0);
-    for (int c = 0; c < p.nchunk; ++c) {
-        __syncthreads();  // chunk c landed (the compiler drains the LDS-DMA with vmcnt(0) here); buf (c+1)&1 is free
-        if (c + 1 < p.nchunk) stage(c + 1, (c + 1) & 1);
-        const char* sb = smem + (c & 1) * STAGE_B;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                half8 P[G::NP];
-#pragma unroll
-                for (int r = 0; r < G::NP; ++r) P[r] = *(const half8*)(sb + aoff[dx][ks] + r * G::ROW_B);
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    half8 A[CB];
-#pragma unroll
-                    for (int mb = 0; mb < CB; ++mb)
-                        A[mb] = *(const half8*)(sb + woff + ((((dy * 3 + dx) * 2 + ks) * CB + mb) << 10));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int pr = UPS ? (((i + dy - 1) >> 1) + 1) : (i + dy);
-#pragma unroll
-                        for (int mb = 0; mb < CB; ++mb)
-                            acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[mb], P[pr], acc[mb][i], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    }
-
-    // ---- epilogue.  D layout: lane holds pixel X = l31, channels 8*g + 4*hi + q  (g = reg>>2, q = reg&3)
-    const int X = X0 + wc * 32 + l31;
-    if (X >= p.W) return;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int Y = Y0 + wr * 4 + i;
-        if (Y >= p.H) continue;
-        const long pix = ((long)img * p.H + Y) * p.W + X;
-#pragma unroll
-        for (int mb = 0; mb < CB; ++mb) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int oc = mb * 32 + g * 8 + hi * 4;
-                floatx4 v;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = acc[mb][i][g * 4 + q];
-                if (p.bias) v += *(const floatx4*)(p.bias + oc);
-                if (p.res1) {
-                    float* r1 = p.res1 + pix * 64 + oc;
-                    v = v * p.res_scale + *(const floatx4*)r1;
-                    if (p.res2) {
-                        float* r2 = p.res2 + pix * 64 + oc;
-                        v = v * p.res2_scale + *(const floatx4*)r2;
-                        if (p.res2_update) *(floatx4*)r2 = v;
-                    }
-                    if (p.res1_update) *(floatx4*)r1 = v;
-                }
-                if (p.skip) v += *(const floatx4*)(p.skip + pix * 64 + oc);
-                if (p.lrelu) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = v[q] >= 0.f ? v[q] : v[q] * 0.2f;
-                }
-                if (p.out16) {
-                    half4 hv;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) hv[q] = (_Float16)v[q];
-                    char* o = p.out16 + (long)img * p.out16_img_b + (long)mb * p.out16_plane_b +
-                              (long)(Y + 1) * p.out16_row_b + (X + 1) * PIX_B + (g * 8 + hi * 4) * 2;
-                    *(half4*)o = hv;
-                }
-                if (p.out32) {
-                    float* o = p.out32 + pix * p.out32_c + oc;
-                    if (p.out32_c == 64) {
-                        *(floatx4*)o = v;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (oc + q < p.out32_c) o[q] = v[q];
-                    }
-                }
-            }
-        }
-    }
-}
+using namespace srbh_k;
 
 template <int CB, int UPS>
 int launch(const KParams& p, hipStream_t stream) {
-    using G = TileGeo<UPS>;
-    constexpr int LDS_B = 2 * (G::IN_B + 18 * 1024 * CB);
+    constexpr int LDS_B = lds_bytes<CB, UPS>();
     static bool attr_set = false;
     if (!attr_set) {
         SRBH_HIP(hipFuncSetAttribute((const void*)conv3x3_f16_kernel<CB, UPS>,
@@ -298,6 +98,7 @@ extern "C" int srbh_conv3x3_f16(const srbh_conv3x3_args* a, void* stream_) {
     }
     p.out32 = a->out32;
     p.out32_c = a->out32_c;
+    p.prof = nullptr;
 
     if (a->upsample2x) return a->cout == 64 ? launch<2, 1>(p, stream) : launch<1, 1>(p, stream);
     return a->cout == 64 ? launch<2, 0>(p, stream) : launch<1, 0>(p, stream);

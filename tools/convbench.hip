@@ -1,0 +1,157 @@
+// convbench.hip -- developer micro-benchmark (not part of the product): ablations of the conv kernel and
+// raw streaming bandwidth probes.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I <pkg>/csrc
+//        tools/convbench.hip -o /tmp/convbench ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <functional>
+#include "srbh_conv3x3_kernel.h"
+
+namespace srbh {
+void set_error(const char*, ...) {}
+int hip_fail(hipError_t e, const char* what) { fprintf(stderr, "HIP error %d in %s\n", (int)e, what); exit(1); }
+}  // namespace srbh
+
+using namespace srbh;
+using namespace srbh_k;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__global__ void stream_read(const float4* __restrict__ p, size_t n, float* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        float4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc.x += a.x + b.x + c.x + d.x; acc.y += a.y + b.y + c.y + d.y;
+        acc.z += a.z + b.z + c.z + d.z; acc.w += a.w + b.w + c.w + d.w;
+    }
+    for (; i < n; i += stride) { float4 a = p[i]; acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+    if (acc.x + acc.y + acc.z + acc.w == 1.2345e30f) out[0] = acc.x;
+}
+
+// every workgroup streams `bytes_per_wg` from its own region into LDS with LDS-DMA, `depth` x 16 KiB in flight
+template <int DEPTH>
+__global__ __launch_bounds__(256, 1) void stream_glds(const char* __restrict__ p, size_t bytes_per_wg, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const char* src = p + (size_t)blockIdx.x * bytes_per_wg + tid * 16;
+    const int nstep = (int)(bytes_per_wg / (DEPTH * 4096));
+    for (int it = 0; it < iters; ++it) {
+        for (int s = 0; s < nstep; ++s) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((size_t)s * DEPTH + d) * 4096),
+                                                 (__attribute__((address_space(3))) void*)(smem + d * 4096 + wave * 1024), 16, 0, 0);
+            __syncthreads();
+        }
+    }
+}
+
+static float time_launches(hipStream_t st, int n, const std::function<void()>& f) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) f();
+    CK(hipEventRecord(a, st));
+    for (int i = 0; i < n; ++i) f();
+    CK(hipEventRecord(b, st));
+    CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms * 1e3f / n;  // us per launch
+}
+
+template <int CB, int UPS, int ABL>
+float run_conv(hipStream_t st, KParams p, int reps) {
+    constexpr int LDS_B = lds_bytes<CB, UPS>();
+    CK(hipFuncSetAttribute((const void*)conv3x3_f16_kernel<CB, UPS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
+    return time_launches(st, reps, [&] { hipLaunchKernelGGL((conv3x3_f16_kernel<CB, UPS, ABL>), dim3(p.nblocks), dim3(256), LDS_B, st, p); });
+}
+
+int main(int argc, char** argv) {
+    int B = argc > 1 ? atoi(argv[1]) : 32;
+    hipStream_t st; CK(hipStreamCreate(&st));
+    // ---------------- bandwidth probes
+    {
+        float* out; CK(hipMalloc(&out, 64));
+        for (size_t mb : {32, 64, 128, 512, 2048}) {
+            size_t bytes = mb << 20; char* buf; CK(hipMalloc(&buf, bytes)); CK(hipMemset(buf, 1, bytes));
+            float us = time_launches(st, 20, [&] { hipLaunchKernelGGL(stream_read, dim3(256 * 8), dim3(256), 0, st, (const float4*)buf, bytes / 16, out); });
+            printf("stream_read   %5zu MiB: %8.1f us  %6.2f TB/s\n", mb, us, bytes / us / 1e6);
+            size_t per_wg = bytes / 256;
+            float us2 = time_launches(st, 20, [&] { hipLaunchKernelGGL(stream_glds<4>, dim3(256), dim3(256), 65536, st, buf, per_wg, 1); });
+            float us3 = time_launches(st, 20, [&] { hipLaunchKernelGGL(stream_glds<8>, dim3(256), dim3(256), 65536, st, buf, per_wg, 1); });
+            printf("stream_glds   %5zu MiB: depth16K*4 %8.1f us %6.2f TB/s | depth 8 %8.1f us %6.2f TB/s (1 WG/CU)\n", mb, us2, bytes / us2 / 1e6, us3, bytes / us3 / 1e6);
+            CK(hipFree(buf));
+        }
+    }
+    // ---------------- conv ablations on the trunk geometry
+    const int H = 64, W = 64;
+    Act16Geo g = act16_geo(B, 6, H, W);
+    char *din, *dout; float *r1, *r2, *bias; char* w;
+    CK(hipMalloc(&din, g.total_b)); CK(hipMemset(din, 0, g.total_b));
+    CK(hipMalloc(&dout, g.total_b)); CK(hipMemset(dout, 0, g.total_b));
+    size_t resb = (size_t)B * H * W * 64 * 4;
+    CK(hipMalloc(&r1, resb)); CK(hipMemset(r1, 0, resb));
+    CK(hipMalloc(&r2, resb)); CK(hipMemset(r2, 0, resb));
+    CK(hipMalloc(&bias, 256)); CK(hipMemset(bias, 0, 256));
+    CK(hipMalloc(&w, 6 * 36864)); CK(hipMemset(w, 0, 6 * 36864));
+    {   // non-trivial data so DVFS / data-dependent power is realistic
+        std::vector<unsigned short> h(g.total_b / 2);
+        for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3000 + (rand() & 0x0fff) + ((rand() & 1) << 15);
+        CK(hipMemcpy(din, h.data(), g.total_b, hipMemcpyHostToDevice));
+        std::vector<unsigned short> hw(6 * 36864 / 2);
+        for (size_t i = 0; i < hw.size(); ++i) hw[i] = 0x2800 + (rand() & 0x0fff) + ((rand() & 1) << 15);
+        CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    }
+    KParams p{}; p.prof = nullptr;
+    p.in = din; p.in_img_b = g.img_b; p.in_plane_b = g.plane_b; p.in_row_b = g.row_b;
+    p.w = w; p.bias = bias; p.H = H; p.W = W; p.tiles_x = 1; p.tiles_per_img = 8; p.nblocks = 8 * B;
+    p.lrelu = 1; p.out16 = dout; p.out16_img_b = g.img_b; p.out16_plane_b = g.plane_b; p.out16_row_b = g.row_b;
+    const double clk = 2.4e9;
+    for (int nchunk : {2, 5}) {
+        p.nchunk = nchunk;
+        double flop = (double)B * H * W * nchunk * 32 * 9 * 32 * 2;
+        float t0 = run_conv<1, 0, 0>(st, p, 50), t1 = run_conv<1, 0, 1>(st, p, 50), t2 = run_conv<1, 0, 2>(st, p, 50),
+              t3 = run_conv<1, 0, 3>(st, p, 50), t4 = run_conv<1, 0, 4>(st, p, 50);
+        printf("CB1 nchunk=%d B=%d: full %.1f us (%.0f TF) | no-compute %.1f | no-stage %.1f | no-epilogue %.1f | mfma-only+stage %.1f | ideal@2.4GHz %.1f us\n",
+               nchunk, B, t0, flop / t0 / 1e6, t1, t2, t3, t4, flop / 2.5e15 * 1e6);
+    }
+    {
+        p.nchunk = 6; p.lrelu = 0; p.res1 = r1; p.res1_update = 1; p.res_scale = 0.2f;
+        double flop = (double)B * H * W * 6 * 32 * 9 * 64 * 2;
+        float t0 = run_conv<2, 0, 0>(st, p, 50), t1 = run_conv<2, 0, 1>(st, p, 50), t2 = run_conv<2, 0, 2>(st, p, 50),
+              t3 = run_conv<2, 0, 3>(st, p, 50), t4 = run_conv<2, 0, 4>(st, p, 50);
+        printf("CB2 nchunk=6 (conv5+res1) B=%d: full %.1f us (%.0f TF) | no-compute %.1f | no-stage %.1f | no-epilogue %.1f | mfma-only+stage %.1f | ideal %.1f us\n",
+               B, t0, flop / t0 / 1e6, t1, t2, t3, t4, flop / 2.5e15 * 1e6);
+        p.res1 = nullptr;
+        float t5 = run_conv<2, 0, 0>(st, p, 50);
+        printf("CB2 nchunk=6 plain out16 epilogue: %.1f us\n", t5);
+    }
+    {   // in-kernel timeline (s_memtime, shader-clock cycles) of a few workgroups
+        unsigned long long* prof; CK(hipMalloc(&prof, 8 * B * 8 * 8)); CK(hipMemset(prof, 0, 8 * B * 8 * 8));
+        std::vector<unsigned long long> h(8 * B * 8);
+        for (int cfg = 0; cfg < 3; ++cfg) {
+            KParams q = p; q.prof = prof; q.res1 = nullptr; q.lrelu = 1;
+            float us;
+            if (cfg == 0) { q.nchunk = 2; us = run_conv<1, 0, 9>(st, q, 5); }
+            else if (cfg == 1) { q.nchunk = 5; us = run_conv<1, 0, 9>(st, q, 5); }
+            else { q.nchunk = 6; q.res1 = r1; q.res1_update = 1; q.res_scale = 0.2f; q.lrelu = 0; us = run_conv<2, 0, 9>(st, q, 5); }
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(h.data(), prof, h.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0min = ~0ull, t5max = 0;
+            for (int b = 0; b < 8 * B; ++b) { if (h[b * 8] < t0min) t0min = h[b * 8]; if (h[b * 8 + 5] > t5max) t5max = h[b * 8 + 5]; }
+            double s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, st0 = 0, e1 = 0, e2 = 0;
+            for (int b = 0; b < 8 * B; ++b) {
+                st0 += (double)(h[b * 8] - t0min);
+                s1 += (double)(h[b * 8 + 1] - h[b * 8]); s2 += (double)(h[b * 8 + 2] - h[b * 8 + 1]);
+                s3 += (double)(h[b * 8 + 3] - h[b * 8 + 2]); s4 += (double)(h[b * 8 + 4] - h[b * 8]); s5 += (double)(h[b * 8 + 5] - h[b * 8 + 4]); e1 += (double)(h[b * 8 + 6] - h[b * 8 + 4]); e2 += (double)(h[b * 8 + 7] - h[b * 8 + 6]);
+            }
+            int n = 8 * B;
+            printf("timeline cfg%d (%.1f us/launch): span %llu cyc | avg start skew %.0f | first barrier +%.0f | chunk0 %.0f | chunk1 %.0f | loop end +%.0f (from start) | epilogue %.0f cycles (barrier %.0f, lds-write %.0f)\n",
+                   cfg, us, t5max - t0min, st0 / n, s1 / n, s2 / n, s3 / n, s4 / n, s5 / n, e1 / n, e2 / n);
+        }
+    }
+    (void)clk;
+    return 0;
+}
