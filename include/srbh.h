@@ -127,6 +127,59 @@ size_t srbh_rrdbnet_workspace_bytes(int B, int H, int W, int want_forward);
 int srbh_rrdbnet_forward(const srbh_rrdbnet_desc* d, const float* x, float* out, int B, int H, int W,
                          int want_forward, void* ws, size_t ws_bytes, void* stream);
 
+
+/* ==== head: HR feature / fusion / regression modules (SR/HRfuse.py), fp32 ==========================
+ * Tensors are NHWC fp32 ([B][H][W][C]; a torch channels_last (B,C,H,W) tensor has exactly this memory).
+ * HWPACK32: fp32 weights in v_mfma_f32_16x16x4_f32 A-fragment order [Cin/16][tap][4][Cout/16][lane 64]. */
+size_t srbh_hpack_bytes(int cout, int cin, int ksize);
+/* OIHW fp32 -> HWPACK32 (nn.Conv2d weight of conv3x3/conv1x1/default_conv, SR/HRfuse.py:11-14,95-109).
+ * transpose_flip=1 packs the weight of the data-gradient convolution instead (cout/cin are then the
+ * LOGICAL counts of that gradient conv: cout = original in_channels, cin = original out_channels). */
+int srbh_hpack_conv_f32(const float* w_oihw, int cout, int cin, int ksize, int transpose_flip, float* packed, void* stream);
+
+/* bytes of the per-channel sum / sum-of-squares partial buffer written by srbh_hconv_f32 (C = cout padded to 16) */
+size_t srbh_bn_stats_bytes(int C);
+
+/* y = conv_{ksize}(cat(pre(src0), src1)) + bias, stride 1, zero padding ksize/2
+ *   pre(x) = relu?(x*pre_scale[c] + pre_shift[c])  -- BatchNorm(+ReLU) of the producer folded into this consumer
+ *            (SR/HRfuse.py:146-148); pre_scale NULL = identity
+ *   src1   : optional second source, concatenated after src0's channels (torch.cat, SR/HRfuse.py:187)
+ *   pixelshuffle2: store through nn.PixelShuffle(2) (SR/HRfuse.py:23): out is [B][2H][2W][cout/4]
+ *   stats  : if non-NULL (srbh_bn_stats_bytes), receives per-channel partial sums of y and y^2 over all
+ *            B*H*W pixels (training-mode BatchNorm statistics); it is zeroed by this call */
+typedef struct srbh_hconv_args {
+    const float* src0; int c0;
+    const float* pre_scale; const float* pre_shift; int pre_relu;
+    const float* src1; int c1;
+    const float* w;       /* HWPACK32 for (cout, c0+c1, ksize) */
+    const float* bias;    /* [cout padded to 16] or NULL */
+    int cout;             /* 1..16 or 49..64 */
+    int ksize;            /* 3 or 1 */
+    int B, H, W;
+    int pixelshuffle2;
+    float* out;
+    double* stats;
+} srbh_hconv_args;
+int srbh_hconv_f32(const srbh_hconv_args* a, void* stream);
+
+/* training-mode nn.BatchNorm2d statistics (SR/HRfuse.py:124,132,135): partial sums -> biased batch variance ->
+ * scale = gamma/sqrt(var+eps), shift = beta - mean*scale; running stats updated with `momentum` and the unbiased
+ * variance exactly as torch does; save_mean/save_invstd (optional) are kept for the backward pass. */
+int srbh_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta, float eps,
+                     float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                     float* save_mean, float* save_invstd, void* stream);
+/* eval-mode BatchNorm folded to scale/shift from the running statistics */
+int srbh_bn_eval_scale_shift(int C, const float* gamma, const float* beta, const float* running_mean,
+                             const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* out = relu(a*a_scale + a_shift + (idt*i_scale + i_shift))   (BasicBlock tail, SR/HRfuse.py:150-157);
+ * i_scale NULL = identity path without downsample */
+int srbh_bn_add_relu(const float* a, const float* a_scale, const float* a_shift, const float* idt,
+                     const float* i_scale, const float* i_shift, float* out, long npix, int C, void* stream);
+/* aggregate_torch (aggregate_utils.py:29-41): data [N][H][W] fp32 -> out [N][H/step][W/step] */
+int srbh_aggregate(const float* data, float* out, int N, int H, int W, int step, void* stream);
+/* NCHW fp32 -> NHWC fp32 */
+int srbh_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

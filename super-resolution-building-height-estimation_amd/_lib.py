@@ -61,6 +61,17 @@ class ConvArgs(C.Structure):
     ]
 
 
+class HConvArgs(C.Structure):
+    _fields_ = [
+        ("src0", C.c_void_p), ("c0", C.c_int),
+        ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("pre_relu", C.c_int),
+        ("src1", C.c_void_p), ("c1", C.c_int),
+        ("w", C.c_void_p), ("bias", C.c_void_p), ("cout", C.c_int), ("ksize", C.c_int),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("pixelshuffle2", C.c_int),
+        ("out", C.c_void_p), ("stats", C.c_void_p),
+    ]
+
+
 class ConvW(C.Structure):
     _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p)]
 
@@ -87,6 +98,15 @@ SIGNATURES = {
     "srbh_pack_conv3x3_f16": (_i, [_vp, _i, _i, _vp, _vp]),
     "srbh_conv3x3_f16": (_i, [C.POINTER(ConvArgs), _vp]),
     "srbh_conv_first_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "srbh_hpack_bytes": (_sz, [_i, _i, _i]),
+    "srbh_hpack_conv_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "srbh_bn_stats_bytes": (_sz, [_i]),
+    "srbh_hconv_f32": (_i, [C.POINTER(HConvArgs), _vp]),
+    "srbh_bn_finalize": (_i, [_vp, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "srbh_bn_eval_scale_shift": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "srbh_bn_add_relu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp]),
+    "srbh_aggregate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "srbh_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_rrdbnet_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "srbh_rrdbnet_forward": (_i, [C.POINTER(RRDBNetDesc), _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
 }

@@ -1,0 +1,416 @@
+// srbh_head.hip -- fp32 kernels of the HR feature / fusion / regression head for gfx950 (MI355X).
+//
+// Stands in for the torch ops inside the reference's SR/HRfuse.py modules (Upsampler :17-44, BasicBlock :109-159,
+// HRfeature :164-169, HRfuse_residual :173-190) and aggregate_utils.py:29-41.  The head runs at 256x256 with only
+// 16 channels, i.e. it is HBM-bound; everything stays fp32 (the reference is fp32 and the head is trained).
+//
+//  * hconv_f32_kernel: KSxKS (3 or 1) convolution as implicit GEMM on the fp32 matrix cores
+//    (v_mfma_f32_16x16x4_f32: exact fp32 FMA chain, 157 TF peak).  A = 16 output channels x 4 input channels of
+//    one tap, B = 16 consecutive pixels of one output row x the same 4 channels.  Fused around it:
+//      - input side : channel concat of two NHWC sources (torch.cat at SR/HRfuse.py:187), per-channel
+//                     scale/shift + ReLU applied while staging (= the BatchNorm + ReLU that precede conv2,
+//                     SR/HRfuse.py:146-148, folded into the consumer), zero padding by bounds check;
+//      - output side: bias, PixelShuffle(2) folded into the store index (SR/HRfuse.py:23), per-channel
+//                     sum / sum-of-squares partials for training-mode BatchNorm statistics.
+//  * bn_finalize_kernel : partial sums -> batch mean/var -> scale/shift (+ running-stat update, momentum 0.1).
+//  * bn_add_relu_kernel : out = relu(bn2(c2) + identity) (SR/HRfuse.py:150-157), identity optionally BN'd (downsample).
+//  * aggregate_kernel   : aggregate_torch (aggregate_utils.py:29-41).
+#include "srbh_internal.h"
+
+namespace {
+using namespace srbh;
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int HT_H = 8, HT_W = 64;          // output tile of one workgroup
+constexpr int HC = 16;                      // input channels per LDS chunk
+constexpr int PL = 704;                     // dwords per channel plane (multiple of 32; >= 10*66 + 24 stagger slack)
+constexpr int RS = 66;                      // row stride inside a plane (3x3: 64 + 2 halo)
+constexpr int NSLOT = 64;                   // stat partial slots (spreads atomic contention)
+
+__device__ __forceinline__ int plane_base(int q) {   // bank staggering, see DESIGN.md "head conv LDS layout"
+    return q * PL + (q & 1) * 16 + (q >> 2) * 8;
+}
+constexpr int IN_DW = 16 * PL + 64;
+
+struct HParams {
+    const float* src0; const float* src1;
+    int c0, c1;
+    const float* pre_scale; const float* pre_shift;   // applied to src0 channels (nullptr = identity)
+    int pre_relu;
+    const float* w; const float* bias;
+    int cout, cout_store;                              // padded (multiple of 16) and real output channels
+    int B, H, W;
+    int ps2;
+    float* out;
+    double* stats;                                     // [NSLOT][2][cout] or nullptr
+    int tiles_x, tiles_per_img;
+};
+
+// NOB = cout/16 (1 or 4), KS = 3 or 1
+template <int NOB, int KS>
+__global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    constexpr int TAPS = KS * KS;
+    constexpr int HALO = KS / 2;
+    constexpr int ROWS = HT_H + 2 * HALO, COLS = HT_W + 2 * HALO;
+    constexpr int W_DW = TAPS * 4 * NOB * 64;          // weight floats per 16-channel chunk
+    float* s_in = hsm;
+    float* s_w = hsm + IN_DW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kk = lane >> 4;
+    const int t = blockIdx.x;
+    const int img = t / p.tiles_per_img;
+    const int trem = t - img * p.tiles_per_img;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int Y0 = ty * HT_H, X0 = tx * HT_W;
+    const int cin = p.c0 + p.c1;
+    const int nchunk = (cin + HC - 1) / HC;
+
+    floatx4 acc[NOB][8];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[ob][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < nchunk; ++c) {
+        __syncthreads();
+        // ---- stage the input chunk: channel-major planes, transform + zero padding applied here
+        for (int u = tid; u < ROWS * COLS * 4; u += 256) {
+            const int cg = u & 3, pix = u >> 2;
+            const int r = pix / COLS, col = pix - r * COLS;
+            const int y = Y0 + r - HALO, x = X0 + col - HALO;
+            const int ch = c * HC + cg * 4;                 // first of 4 channels
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (y >= 0 && y < p.H && x >= 0 && x < p.W && ch < cin) {
+                const long pixi = ((long)img * p.H + y) * p.W + x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cc = ch + j;
+                    if (cc < p.c0) {
+                        float a = p.src0[pixi * p.c0 + cc];
+                        if (p.pre_scale) a = a * p.pre_scale[cc] + p.pre_shift[cc];
+                        if (p.pre_relu) a = fmaxf(a, 0.f);
+                        v[j] = a;
+                    } else if (cc < cin) {
+                        v[j] = p.src1[pixi * p.c1 + (cc - p.c0)];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_in[plane_base(cg * 4 + j) + r * RS + col] = v[j];
+        }
+        // ---- weights of this chunk (already in A-fragment order)
+        for (int u = tid; u < W_DW / 4; u += 256)
+            ((floatx4*)s_w)[u] = ((const floatx4*)(p.w + (long)c * W_DW))[u];
+        __syncthreads();
+        // ---- MFMA: wave owns rows 2*wave, 2*wave+1; 4 column tiles of 16 px each
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dy = tap / KS, dx = tap - dy * KS;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float a[NOB];
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) a[ob] = s_w[((tap * 4 + s) * NOB + ob) * 64 + lane];
+                const float* bp = s_in + plane_base(s * 4 + kk) + (wave * 2 + dy) * RS + dx + l15;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float b = bp[(i >> 2) * RS + (i & 3) * 16];
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob)
+                        acc[ob][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob], b, acc[ob][i], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds channels ob*16 + kk*4 + (0..3) of pixel (row, col0 + l15)
+    float ssum[NOB][4], ssq[NOB][4];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ssum[ob][q] = ssq[ob][q] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int Y = Y0 + wave * 2 + (i >> 2), X = X0 + (i & 3) * 16 + l15;
+        const bool ok = Y < p.H && X < p.W;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+            const int oc = ob * 16 + kk * 4;
+            floatx4 v = acc[ob][i];
+            if (p.bias) v += *(const floatx4*)(p.bias + oc);
+            if (ok) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ssum[ob][q] += v[q];
+                    ssq[ob][q] += v[q] * v[q];
+                }
+                if (p.ps2) {
+                    // PixelShuffle(2): out[b, oc>>2, 2Y + ((oc>>1)&1), 2X + (oc&1)] (SR/HRfuse.py:23); lane's 4 channels
+                    // are the 2x2 sub-pixels of output channel oc>>2
+                    const int co = p.cout_store >> 2, cq = oc >> 2;
+                    if (oc < p.cout_store) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const long o = (((long)img * 2 * p.H + 2 * Y + (q >> 1)) * (2 * p.W) + 2 * X + (q & 1)) * co + cq;
+                            p.out[o] = v[q];
+                        }
+                    }
+                } else {
+                    float* o = p.out + (((long)img * p.H + Y) * p.W + X) * p.cout_store + oc;
+                    if ((p.cout_store & 3) == 0) {
+                        if (oc < p.cout_store) *(floatx4*)o = v;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (oc + q < p.cout_store) o[q] = v[q];
+                    }
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        // reduce over the 16 pixel lanes, then one double atomic per (wave, channel) into a slot
+        double* slot = p.stats + (long)(blockIdx.x % NSLOT) * 2 * p.cout;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float a = ssum[ob][q], b = ssq[ob][q];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+                    a += __shfl_xor(a, m);
+                    b += __shfl_xor(b, m);
+                }
+                if (l15 == 0) {
+                    const int oc = ob * 16 + kk * 4 + q;
+                    atomicAdd(slot + oc, (double)a);
+                    atomicAdd(slot + p.cout + oc, (double)b);
+                }
+            }
+    }
+}
+
+// ---- weights: OIHW fp32 -> [chunk][tap][s][ob][lane 64]  (A fragment of v_mfma_f32_16x16x4_f32: row = lane&15, k = lane>>4)
+// transpose_flip: pack the weight of the corresponding data-gradient conv (swap I/O, flip taps) instead
+__global__ void hpack_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int ks, int nchunk,
+                             int nob, int transpose_flip) {
+    const int taps = ks * ks;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)nchunk * taps * 4 * nob * 64;
+    if (idx >= total) return;
+    int lane = idx & 63;
+    long f = idx >> 6;
+    int ob = f % nob; f /= nob;
+    int s = f & 3; f >>= 2;
+    int tap = f % taps;
+    int chunk = f / taps;
+    int oc = ob * 16 + (lane & 15);
+    int ic = chunk * 16 + s * 4 + (lane >> 4);
+    float v = 0.f;
+    if (!transpose_flip) {
+        if (oc < cout && ic < cin) v = w[((long)oc * cin + ic) * taps + tap];
+    } else {
+        // logical conv: out channel `oc` ranges over the ORIGINAL input channels, `ic` over the original outputs
+        // here cout/cin are the logical (already swapped) counts; original tensor is [cin][cout][ks][ks]
+        if (oc < cout && ic < cin) v = w[((long)ic * cout + oc) * taps + (taps - 1 - tap)];
+    }
+    out[idx] = v;
+}
+
+// ---- BatchNorm: partial sums -> scale/shift (+ running stats) ------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, double count, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* running_mean,
+                                   float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, q = 0;
+    for (int k = 0; k < NSLOT; ++k) {
+        s += stats[(long)k * 2 * C + c];
+        q += stats[(long)k * 2 * C + C + c];
+    }
+    double mean = s / count;
+    double var = q / count - mean * mean;   // biased, as used for normalisation
+    if (var < 0) var = 0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale[c] = g * invstd;
+    shift[c] = b - (float)mean * g * invstd;
+    if (save_mean) save_mean[c] = (float)mean;
+    if (save_invstd) save_invstd[c] = invstd;
+    if (running_mean) {
+        double unbiased = count > 1 ? var * count / (count - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// eval mode: scale/shift from running statistics
+__global__ void bn_eval_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                               float* scale, float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float invstd = 1.f / sqrtf(rv[c] + eps);
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale[c] = g * invstd;
+    shift[c] = b - rm[c] * g * invstd;
+}
+
+// out = relu(a*sa + ha + (idt*si + hi))   (C multiple of 4; NHWC fp32)
+__global__ void bn_add_relu_kernel(const floatx4* __restrict__ a, const float* sa, const float* ha,
+                                   const floatx4* __restrict__ idt, const float* si, const float* hi, floatx4* out,
+                                   long n4, int C) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        int c = (int)((i * 4) % C);
+        floatx4 v = a[i] * *(const floatx4*)(sa + c) + *(const floatx4*)(ha + c);
+        floatx4 d = idt[i];
+        if (si) d = d * *(const floatx4*)(si + c) + *(const floatx4*)(hi + c);
+        v += d;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        out[i] = v;
+    }
+}
+
+// aggregate_torch (aggregate_utils.py:29-41): step x step block sums of data and of (data >= 0)
+__global__ void aggregate_kernel(const float* __restrict__ data, float* __restrict__ out, int N, int H, int W, int step) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int oh = H / step, ow = W / step;
+    long total = (long)N * oh * ow;
+    if (idx >= total) return;
+    int ox = idx % ow;
+    long r = idx / ow;
+    int oy = r % oh;
+    int n = r / oh;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < step; ++i)
+        for (int j = 0; j < step; ++j) {
+            float v = data[((long)n * H + oy * step + i) * W + ox * step + j];
+            s1 += v;
+            s2 += (v >= 0.f) ? 1.f : 0.f;
+        }
+    out[idx] = s1 / (s2 + 1e-10f);
+}
+
+// NCHW <-> NHWC fp32 (module boundaries of the head)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int H, int W) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over dst
+    long total = (long)B * C * H * W;
+    if (idx >= total) return;
+    int c = idx % C;
+    long r = idx / C;
+    int x = r % W; r /= W;
+    int y = r % H;
+    int b = r / H;
+    dst[idx] = src[(((long)b * C + c) * H + y) * W + x];
+}
+
+template <int NOB, int KS>
+int launch_hconv(const HParams& p, int nblocks, hipStream_t st) {
+    constexpr int LDS_B = (IN_DW + KS * KS * 4 * NOB * 64) * 4;
+    if (LDS_B > 65536) {
+        static bool set = false;
+        if (!set) {
+            SRBH_HIP(hipFuncSetAttribute((const void*)hconv_f32_kernel<NOB, KS>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
+            set = true;
+        }
+    }
+    hipLaunchKernelGGL((hconv_f32_kernel<NOB, KS>), dim3(nblocks), dim3(256), LDS_B, st, p);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+}  // namespace
+
+extern "C" size_t srbh_hpack_bytes(int cout, int cin, int ksize) {
+    if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    return (size_t)((cin + 15) / 16) * ksize * ksize * 4 * ((cout + 15) / 16) * 64 * sizeof(float);
+}
+
+extern "C" int srbh_hpack_conv_f32(const float* w, int cout, int cin, int ksize, int transpose_flip, float* packed,
+                                   void* stream) {
+    SRBH_REQUIRE(w && packed && cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), "srbh_hpack_conv_f32: bad arguments");
+    int nchunk = (cin + 15) / 16, nob = (cout + 15) / 16;
+    long total = (long)nchunk * ksize * ksize * 4 * nob * 64;
+    hipLaunchKernelGGL(hpack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, packed, cout, cin,
+                       ksize, nchunk, nob, transpose_flip);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" size_t srbh_bn_stats_bytes(int C) { return C > 0 ? (size_t)NSLOT * 2 * C * sizeof(double) : 0; }
+
+extern "C" int srbh_hconv_f32(const srbh_hconv_args* a, void* stream) {
+    SRBH_REQUIRE(a && a->src0 && a->w && a->out, "srbh_hconv_f32: null pointer");
+    SRBH_REQUIRE(a->c0 > 0 && a->c1 >= 0 && (a->c1 == 0 || a->src1), "srbh_hconv_f32: bad channel split %d+%d", a->c0, a->c1);
+    SRBH_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0, "srbh_hconv_f32: bad geometry");
+    SRBH_REQUIRE(a->ksize == 3 || a->ksize == 1, "srbh_hconv_f32: ksize must be 1 or 3 (got %d)", a->ksize);
+    SRBH_REQUIRE(a->cout >= 1 && a->cout <= 64, "srbh_hconv_f32: cout must be in 1..64 (got %d)", a->cout);
+    SRBH_REQUIRE(!a->pixelshuffle2 || a->cout % 4 == 0, "srbh_hconv_f32: PixelShuffle(2) needs cout %% 4 == 0");
+    const int nob = (a->cout + 15) / 16;
+    SRBH_REQUIRE(nob == 1 || nob == 4, "srbh_hconv_f32: cout must be <=16 or in 49..64 (got %d)", a->cout);
+    HParams p;
+    p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1;
+    p.pre_scale = a->pre_scale; p.pre_shift = a->pre_shift; p.pre_relu = a->pre_relu;
+    p.w = a->w; p.bias = a->bias;
+    p.cout = nob * 16; p.cout_store = a->cout;
+    p.B = a->B; p.H = a->H; p.W = a->W; p.ps2 = a->pixelshuffle2;
+    p.out = a->out; p.stats = a->stats;
+    p.tiles_x = (a->W + HT_W - 1) / HT_W;
+    p.tiles_per_img = p.tiles_x * ((a->H + HT_H - 1) / HT_H);
+    const int nblocks = p.tiles_per_img * a->B;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->stats) SRBH_HIP(hipMemsetAsync(a->stats, 0, srbh_bn_stats_bytes(p.cout), st));
+    if (a->ksize == 3) return nob == 1 ? launch_hconv<1, 3>(p, nblocks, st) : launch_hconv<4, 3>(p, nblocks, st);
+    return nob == 1 ? launch_hconv<1, 1>(p, nblocks, st) : launch_hconv<4, 1>(p, nblocks, st);
+}
+
+extern "C" int srbh_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta,
+                                float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                                float* shift, float* save_mean, float* save_invstd, void* stream) {
+    SRBH_REQUIRE(stats && C > 0 && C <= 64 && count > 0 && scale && shift, "srbh_bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_bn_eval_scale_shift(int C, const float* gamma, const float* beta, const float* running_mean,
+                                        const float* running_var, float eps, float* scale, float* shift, void* stream) {
+    SRBH_REQUIRE(C > 0 && running_mean && running_var && scale && shift, "srbh_bn_eval_scale_shift: bad arguments");
+    hipLaunchKernelGGL(bn_eval_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, C, gamma, beta,
+                       running_mean, running_var, eps, scale, shift);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_bn_add_relu(const float* a, const float* a_scale, const float* a_shift, const float* idt,
+                                const float* i_scale, const float* i_shift, float* out, long npix, int C, void* stream) {
+    SRBH_REQUIRE(a && a_scale && a_shift && idt && out && npix > 0 && C > 0 && C % 4 == 0, "srbh_bn_add_relu: bad arguments");
+    long n4 = npix * C / 4;
+    int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(bn_add_relu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const floatx4*)a, a_scale,
+                       a_shift, (const floatx4*)idt, i_scale, i_shift, (floatx4*)out, n4, C);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_aggregate(const float* data, float* out, int N, int H, int W, int step, void* stream) {
+    SRBH_REQUIRE(data && out && N > 0 && step > 0 && H >= step && W >= step, "srbh_aggregate: bad arguments");
+    long total = (long)N * (H / step) * (W / step);
+    hipLaunchKernelGGL(aggregate_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, data, out, N, H, W, step);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, void* stream) {
+    SRBH_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "srbh_nchw_to_nhwc_f32: bad arguments");
+    long total = (long)B * C * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, B, C, H, W);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}

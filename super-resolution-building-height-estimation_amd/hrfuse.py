@@ -1,0 +1,444 @@
+"""MI355X-native HR feature / fusion / regression head behind the reference's SR/HRfuse.py interface.
+
+Mirrors (constructor kwargs, forward signatures, state_dict keys) of the reference classes
+``Upsampler`` (SR/HRfuse.py:17-44), ``BasicBlock`` (:109-159), ``HRfeature`` (:164-169),
+``HRfuse_residual`` (:173-190) and the sibling variants ``HRfuse`` (:47-65), ``HRfuse_x2`` (:68-90),
+``HRupsample`` (:193-202), ``GeoNet`` (:205-214), ``Refine_residual`` (:217-228).
+
+nn.Conv2d / nn.BatchNorm2d sub-modules are parameter containers only; every forward runs libsrbh's
+fp32 matrix-core kernels (csrc/srbh_head.hip) on NHWC (channels_last) tensors:
+  conv (+concat, +producer's BN+ReLU folded into the load, +PixelShuffle folded into the store,
+  +BatchNorm batch statistics in the epilogue) -> bn finalize -> fused bn+add+relu.
+Training-mode forward/backward is provided by the autograd functions in ``hrfuse_autograd``.
+No CPU / eager fallback: a non-ROCm input raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+
+__all__ = ["default_conv", "Upsampler", "conv3x3", "conv1x1", "BasicBlock", "HRfeature", "HRfuse_residual",
+           "HRfuse", "HRfuse_x2", "HRupsample", "GeoNet", "Refine_residual"]
+
+BN_EPS_DEFAULT = 1e-5
+
+
+# ----------------------------------------------------------------------------- low-level ops (NHWC fp32)
+def _require_dev(x, who):
+    if not (torch.is_tensor(x) and x.is_cuda):
+        raise RuntimeError(f"{who} (libsrbh): input must be a ROCm/HIP device tensor; the head has no CPU fallback")
+    if x.dtype != torch.float32:
+        raise TypeError(f"{who}: expected float32, got {x.dtype}")
+
+
+def to_nhwc(x):
+    """(B,C,H,W) tensor -> same logical tensor whose memory is [B][H][W][C] (no copy if it already is)."""
+    if x.dim() != 4:
+        raise ValueError(f"expected a (B,C,H,W) tensor, got {tuple(x.shape)}")
+    B, Cc, H, W = x.shape
+    if x.stride() == (H * W * Cc, 1, W * Cc, Cc):
+        return x
+    if Cc == 1 and x.is_contiguous():
+        return x.as_strided((B, 1, H, W), (H * W, 1, W, 1))
+    src = x.contiguous()
+    out = torch.empty_strided((B, Cc, H, W), (H * W * Cc, 1, W * Cc, Cc), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib().srbh_nchw_to_nhwc_f32(src.data_ptr(), out.data_ptr(), B, Cc, H, W, _lib.stream_ptr()),
+               "nchw_to_nhwc")
+    return out
+
+
+def empty_nhwc(B, Cc, H, W, device):
+    return torch.empty_strided((B, Cc, H, W), (H * W * Cc, 1, W * Cc, Cc), dtype=torch.float32, device=device)
+
+
+class _PackedConv:
+    """HWPACK32 image of one conv weight (+ zero-padded bias), rebuilt when the parameter changes."""
+
+    def __init__(self):
+        self.key = None
+        self.w = None
+        self.b = None
+
+    def get(self, conv: nn.Conv2d):
+        w = conv.weight
+        key = (w._version, w.data_ptr(), None if conv.bias is None else (conv.bias._version, conv.bias.data_ptr()))
+        if key != self.key:
+            L = _lib.lib()
+            cout, cin, ks, _ = w.shape
+            buf = torch.empty(L.srbh_hpack_bytes(cout, cin, ks) // 4, dtype=torch.float32, device=w.device)
+            wc = w.detach().float().contiguous()
+            _lib.check(L.srbh_hpack_conv_f32(wc.data_ptr(), cout, cin, ks, 0, buf.data_ptr(), _lib.stream_ptr()),
+                       "hpack_conv_f32")
+            b = None
+            if conv.bias is not None:
+                b = torch.zeros((cout + 15) // 16 * 16, dtype=torch.float32, device=w.device)
+                b[:cout] = conv.bias.detach().float()
+            torch.cuda.current_stream().synchronize()
+            self.key, self.w, self.b = key, buf, b
+        return self.w, self.b
+
+
+def hconv(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_stats=False):
+    """conv(cat(srcs)) through srbh_hconv_f32.  srcs: list of 1..2 NHWC tensors; pre=(scale, shift, relu) is
+    applied to srcs[0]; returns (out, stats) with out NHWC and stats the partial-sum buffer or None."""
+    L = _lib.lib()
+    x0 = srcs[0]
+    B, c0, H, W = x0.shape
+    c1 = srcs[1].shape[1] if len(srcs) > 1 else 0
+    cout, cin, ks, _ = conv.weight.shape
+    if cin != c0 + c1:
+        raise ValueError(f"conv expects {cin} input channels, got {c0}+{c1}")
+    w, b = packed.get(conv)
+    a = _lib.HConvArgs()
+    a.src0, a.c0 = x0.data_ptr(), c0
+    if pre is not None:
+        a.pre_scale, a.pre_shift, a.pre_relu = pre[0].data_ptr(), pre[1].data_ptr(), int(pre[2])
+    if c1:
+        a.src1, a.c1 = srcs[1].data_ptr(), c1
+    a.w = w.data_ptr()
+    a.bias = b.data_ptr() if b is not None else None
+    a.cout, a.ksize = cout, ks
+    a.B, a.H, a.W = B, H, W
+    a.pixelshuffle2 = int(ps2)
+    out = empty_nhwc(B, cout // 4, 2 * H, 2 * W, x0.device) if ps2 else empty_nhwc(B, cout, H, W, x0.device)
+    a.out = out.data_ptr()
+    stats = None
+    if want_stats:
+        stats = torch.empty(L.srbh_bn_stats_bytes((cout + 15) // 16 * 16) // 8, dtype=torch.float64, device=x0.device)
+        a.stats = stats.data_ptr()
+    _lib.check(L.srbh_hconv_f32(C.byref(a), _lib.stream_ptr()), "hconv_f32")
+    return out, stats
+
+
+def bn_scale_shift(bn: nn.BatchNorm2d, stats, count, training):
+    """BatchNorm folded to per-channel (scale, shift).  training: from the batch statistics in `stats`
+    (running statistics updated in place, as nn.BatchNorm2d does); eval: from the running statistics.
+    Returns (scale, shift, save_mean, save_invstd)."""
+    L = _lib.lib()
+    Cc = bn.num_features
+    dev = bn.weight.device
+    scale = torch.empty(Cc, dtype=torch.float32, device=dev)
+    shift = torch.empty(Cc, dtype=torch.float32, device=dev)
+    g = bn.weight.detach()
+    bta = bn.bias.detach()
+    if training:
+        if Cc % 16:
+            raise NotImplementedError("libsrbh BatchNorm statistics need a channel count that is a multiple of 16")
+        mean = torch.empty(Cc, dtype=torch.float32, device=dev)
+        invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        rm = bn.running_mean.data_ptr() if bn.track_running_stats else None
+        rv = bn.running_var.data_ptr() if bn.track_running_stats else None
+        _lib.check(L.srbh_bn_finalize(stats.data_ptr(), Cc, float(count), g.data_ptr(), bta.data_ptr(), bn.eps, mom,
+                                      rm, rv, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                      _lib.stream_ptr()), "bn_finalize")
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        return scale, shift, mean, invstd
+    _lib.check(L.srbh_bn_eval_scale_shift(Cc, g.data_ptr(), bta.data_ptr(), bn.running_mean.data_ptr(),
+                                          bn.running_var.data_ptr(), bn.eps, scale.data_ptr(), shift.data_ptr(),
+                                          _lib.stream_ptr()), "bn_eval_scale_shift")
+    return scale, shift, None, None
+
+
+def bn_add_relu(a, sa, ha, idt, si=None, hi=None):
+    B, Cc, H, W = a.shape
+    out = empty_nhwc(B, Cc, H, W, a.device)
+    _lib.check(_lib.lib().srbh_bn_add_relu(a.data_ptr(), sa.data_ptr(), ha.data_ptr(), idt.data_ptr(),
+                                           None if si is None else si.data_ptr(), None if hi is None else hi.data_ptr(),
+                                           out.data_ptr(), B * H * W, Cc, _lib.stream_ptr()), "bn_add_relu")
+    return out
+
+
+def _no_eager(name):
+    raise RuntimeError(f"{name}: parameter container of the HIP head; it has no eager forward")
+
+
+# ----------------------------------------------------------------------------- modules
+def default_conv(in_channels, out_channels, kernel_size, bias=True):
+    """reference SR/HRfuse.py:11-14"""
+    return nn.Conv2d(in_channels, out_channels, kernel_size, padding=(kernel_size // 2), bias=bias)
+
+
+def conv3x3(in_planes: int, out_planes: int, stride: int = 1, groups: int = 1, dilation: int = 1) -> nn.Conv2d:
+    """reference SR/HRfuse.py:93-104"""
+    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=dilation, groups=groups, bias=False,
+                     dilation=dilation)
+
+
+def conv1x1(in_planes: int, out_planes: int, stride: int = 1) -> nn.Conv2d:
+    """reference SR/HRfuse.py:106-108"""
+    return nn.Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
+
+
+class Upsampler(nn.Sequential):
+    """[conv3x3 n->4n (bias), PixelShuffle(2)] x log2(scale) (reference SR/HRfuse.py:17-44); Sequential keys
+    0,2,.. hold the convs, odd indices the (parameter-free) PixelShuffle modules, exactly as upstream."""
+
+    def __init__(self, conv=default_conv, scale=4, n_feats=16, bn=False, act=False, bias=True):
+        m = []
+        if (scale & (scale - 1)) == 0:
+            for _ in range(int(math.log(scale, 2))):
+                m.append(conv(n_feats, 4 * n_feats, 3, bias))
+                m.append(nn.PixelShuffle(2))
+                if bn:
+                    m.append(nn.BatchNorm2d(n_feats))
+                if act == "relu":
+                    m.append(nn.ReLU(True))
+                elif act == "prelu":
+                    m.append(nn.PReLU(n_feats))
+        elif scale == 3:
+            m.append(conv(n_feats, 9 * n_feats, 3, bias))
+            m.append(nn.PixelShuffle(3))
+            if bn:
+                m.append(nn.BatchNorm2d(n_feats))
+            if act == "relu":
+                m.append(nn.ReLU(True))
+            elif act == "prelu":
+                m.append(nn.PReLU(n_feats))
+        else:
+            raise NotImplementedError
+        super().__init__(*m)
+        self._hip_ok = (scale & (scale - 1)) == 0 and not bn and not act
+        self._packs = {}
+
+    def forward(self, x):
+        _require_dev(x, "Upsampler")
+        if not self._hip_ok:
+            raise NotImplementedError("libsrbh Upsampler supports power-of-two scales without bn/act "
+                                      "(the only configuration the reference instantiates)")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from . import hrfuse_autograd as AG
+            return AG.upsampler_forward(self, x)
+        x = to_nhwc(x)
+        for i, mod in enumerate(self):
+            if isinstance(mod, nn.Conv2d):
+                x, _ = hconv([x], mod, self._packs.setdefault(i, _PackedConv()), ps2=True)
+        return x
+
+
+class BasicBlock(nn.Module):
+    """ResNet basic block with the reference's constructor (SR/HRfuse.py:109-159)."""
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1, groups: int = 1, base_width: int = 64,
+                 dilation: int = 1, norm_layer: Optional[Callable[..., nn.Module]] = None, expansion: int = 1) -> None:
+        super().__init__()
+        if norm_layer is None:
+            norm_layer = nn.BatchNorm2d
+        if groups != 1 or base_width != 64:
+            raise ValueError("BasicBlock only supports groups=1 and base_width=64")
+        if dilation > 1:
+            raise NotImplementedError("Dilation > 1 not supported in BasicBlock")
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = norm_layer(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = norm_layer(planes)
+        self.downsample = None
+        self.stride = stride
+        if stride != 1 or inplanes != planes * expansion:
+            self.downsample = nn.Sequential(conv1x1(inplanes, planes * expansion, stride), norm_layer(planes * expansion))
+        self._p1, self._p2, self._pd = _PackedConv(), _PackedConv(), _PackedConv()
+
+    def _check(self):
+        if self.stride != 1:
+            raise NotImplementedError("libsrbh BasicBlock supports stride 1 (all the reference's call sites)")
+        for bn in (self.bn1, self.bn2):
+            if not isinstance(bn, nn.BatchNorm2d):
+                raise NotImplementedError("libsrbh BasicBlock supports nn.BatchNorm2d norm layers")
+
+    def forward_nhwc(self, srcs):
+        """srcs: list of 1..2 NHWC tensors whose channel concat is the block input (no autograd)."""
+        self._check()
+        tr = self.training
+        B, _, H, W = srcs[0].shape
+        n = B * H * W
+        c1, st1 = hconv(srcs, self.conv1, self._p1, want_stats=tr)
+        s1, h1, _, _ = bn_scale_shift(self.bn1, st1, n, tr)
+        c2, st2 = hconv([c1], self.conv2, self._p2, pre=(s1, h1, True), want_stats=tr)
+        s2, h2, _, _ = bn_scale_shift(self.bn2, st2, n, tr)
+        if self.downsample is not None:
+            d, std = hconv(srcs, self.downsample[0], self._pd, want_stats=tr)
+            sd, hd, _, _ = bn_scale_shift(self.downsample[1], std, n, tr)
+            return bn_add_relu(c2, s2, h2, d, sd, hd)
+        if len(srcs) != 1:
+            raise ValueError("identity path needs a single source")
+        return bn_add_relu(c2, s2, h2, srcs[0])
+
+    def forward(self, x):
+        _require_dev(x, "BasicBlock")
+        return run_blocks([self], [x])
+
+
+def _needs_grad(mods, tensors):
+    if not torch.is_grad_enabled():
+        return False
+    return any(t.requires_grad for t in tensors) or any(p.requires_grad for m in mods for p in m.parameters())
+
+
+def run_blocks(blocks, inputs):
+    """Run a chain of BasicBlocks on the channel concat of `inputs` ((B,C,H,W) tensors)."""
+    if _needs_grad(blocks, inputs):
+        from . import hrfuse_autograd as AG
+        return AG.blocks_forward(blocks, inputs)
+    x = [to_nhwc(t) for t in inputs]
+    for b in blocks:
+        x = [b.forward_nhwc(x)]
+    return x[0]
+
+
+class HRfeature(nn.Sequential):
+    """Three BasicBlocks in_chans -> mid -> mid -> out (reference SR/HRfuse.py:164-169)."""
+
+    def __init__(self, in_chans, mid_chans=64, out_chans=64):
+        super().__init__(BasicBlock(in_chans, mid_chans, stride=1), BasicBlock(mid_chans, mid_chans, stride=1),
+                         BasicBlock(mid_chans, out_chans, stride=1))
+
+    def forward(self, x):
+        _require_dev(x, "HRfeature")
+        return run_blocks(list(self), [x])
+
+
+class _LastConv:
+    """conv_last helper shared by the fuse heads."""
+
+    @staticmethod
+    def run(mod, conv, x):
+        if _needs_grad([conv], [x]):
+            from . import hrfuse_autograd as AG
+            return AG.conv_forward(conv, mod._plast, x)
+        out, _ = hconv([to_nhwc(x)], conv, mod._plast)
+        return out
+
+
+class HRfuse_residual(nn.Module):
+    """upsample x_lr x4, concat with x_hr, three BasicBlocks, conv_last (reference SR/HRfuse.py:173-190)."""
+
+    def __init__(self, hr_chans=16, lr_chans=16, mid_chans=16, out_chans=3, upscale=4):
+        super().__init__()
+        self.upsampler = Upsampler(scale=upscale, n_feats=lr_chans)
+        self.fuse = nn.Sequential(BasicBlock(hr_chans + lr_chans, mid_chans, stride=1),
+                                  BasicBlock(mid_chans, mid_chans, stride=1),
+                                  BasicBlock(mid_chans, mid_chans, stride=1))
+        self.conv_last = nn.Conv2d(mid_chans, out_chans, 3, 1, 1)
+        self._plast = _PackedConv()
+
+    def forward(self, x_lr, x_hr):
+        _require_dev(x_lr, "HRfuse_residual")
+        _require_dev(x_hr, "HRfuse_residual")
+        x_lr = self.upsampler(x_lr)
+        x = run_blocks(list(self.fuse), [x_lr, x_hr])
+        return _LastConv.run(self, self.conv_last, x)
+
+
+class Refine_residual(nn.Module):
+    """concat, three BasicBlocks, conv_last -- no upsampler (reference SR/HRfuse.py:217-228)."""
+
+    def __init__(self, hr_chans=16, lr_chans=16, mid_chans=16, out_chans=3):
+        super().__init__()
+        self.fuse = nn.Sequential(BasicBlock(hr_chans + lr_chans, mid_chans, stride=1),
+                                  BasicBlock(mid_chans, mid_chans, stride=1),
+                                  BasicBlock(mid_chans, mid_chans, stride=1))
+        self.conv_last = nn.Conv2d(mid_chans, out_chans, 3, 1, 1)
+        self._plast = _PackedConv()
+
+    def forward(self, x_lr, x_hr):
+        _require_dev(x_lr, "Refine_residual")
+        x = run_blocks(list(self.fuse), [x_lr, x_hr])
+        return _LastConv.run(self, self.conv_last, x)
+
+
+class HRupsample(nn.Module):
+    """upsampler + conv_last (reference SR/HRfuse.py:193-202)."""
+
+    def __init__(self, lr_chans=16, out_chans=3, upscale=4):
+        super().__init__()
+        self.upsampler = Upsampler(scale=upscale, n_feats=lr_chans)
+        self.conv_last = nn.Conv2d(lr_chans, out_chans, 3, 1, 1)
+        self._plast = _PackedConv()
+
+    def forward(self, x):
+        _require_dev(x, "HRupsample")
+        return _LastConv.run(self, self.conv_last, self.upsampler(x))
+
+
+class GeoNet(nn.Module):
+    """three BasicBlocks under ``feat`` (reference SR/HRfuse.py:205-214)."""
+
+    def __init__(self, in_chans=4, mid_chans=16):
+        super().__init__()
+        self.feat = nn.Sequential(BasicBlock(in_chans, mid_chans, stride=1), BasicBlock(mid_chans, mid_chans, stride=1),
+                                  BasicBlock(mid_chans, mid_chans, stride=1))
+
+    def forward(self, x):
+        _require_dev(x, "GeoNet")
+        return run_blocks(list(self.feat), [x])
+
+
+class _ConvBnReluFuse(nn.Module):
+    """shared body of HRfuse / HRfuse_x2: conv-BN-ReLU x2 as an nn.Sequential named ``fuse`` with the reference's
+    integer keys (0,1,3,4 hold parameters), an Upsampler and conv_last (reference SR/HRfuse.py:47-90)."""
+
+    def __init__(self, hr_channel, lr_channel, mid_channel, out_channel, upscale):
+        super().__init__()
+        self.fuse = nn.Sequential(
+            nn.Conv2d(hr_channel + lr_channel, mid_channel, 3, 1, 1, bias=False), nn.BatchNorm2d(mid_channel),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(mid_channel, mid_channel, 3, 1, 1, bias=False), nn.BatchNorm2d(mid_channel),
+            nn.ReLU(inplace=True))
+        self.upsampler = Upsampler(scale=upscale, n_feats=mid_channel)
+        self.conv_last = nn.Conv2d(mid_channel, out_channel, 3, 1, 1)
+        self._pf0, self._pf3, self._plast = _PackedConv(), _PackedConv(), _PackedConv()
+
+    def _fuse_nhwc(self, srcs):
+        if _needs_grad([self], srcs):
+            raise NotImplementedError("HRfuse / HRfuse_x2 are inference-only in libsrbh (they are not instantiated by "
+                                      "the reference's train.py / predict scripts)")
+        tr = self.training
+        B, _, H, W = srcs[0].shape
+        c1, st1 = hconv(srcs, self.fuse[0], self._pf0, want_stats=tr)
+        s1, h1, _, _ = bn_scale_shift(self.fuse[1], st1, B * H * W, tr)
+        c2, st2 = hconv([c1], self.fuse[3], self._pf3, pre=(s1, h1, True), want_stats=tr)
+        s2, h2, _, _ = bn_scale_shift(self.fuse[4], st2, B * H * W, tr)
+        return c2, (s2, h2, True)   # the trailing BN+ReLU is folded into whichever conv consumes c2
+
+
+class HRfuse(_ConvBnReluFuse):
+    """fuse at low resolution, then upsample (reference SR/HRfuse.py:47-65)."""
+
+    def __init__(self, hr_channel=16, lr_channel=16, mid_channel=16, out_channel=3, upscale=4):
+        super().__init__(hr_channel, lr_channel, mid_channel, out_channel, upscale)
+
+    def forward(self, x_lr, x_hr):
+        _require_dev(x_lr, "HRfuse")
+        c2, pre = self._fuse_nhwc([to_nhwc(x_lr), to_nhwc(x_hr)])
+        x = c2
+        first = True
+        for i, mod in enumerate(self.upsampler):
+            if isinstance(mod, nn.Conv2d):
+                x, _ = hconv([x], mod, self.upsampler._packs.setdefault(i, _PackedConv()), pre=pre if first else None,
+                             ps2=True)
+                first = False
+        out, _ = hconv([x], self.conv_last, self._plast)
+        return out
+
+
+class HRfuse_x2(_ConvBnReluFuse):
+    """upsample x_lr first, fuse at high resolution (reference SR/HRfuse.py:68-90)."""
+
+    def __init__(self, hr_channel=16, lr_channel=16, mid_channel=16, out_channel=3, upscale=4):
+        super().__init__(hr_channel, lr_channel, mid_channel, out_channel, upscale)
+
+    def forward(self, x_lr, x_hr):
+        _require_dev(x_lr, "HRfuse_x2")
+        with torch.no_grad():
+            up = self.upsampler(x_lr)
+        c2, pre = self._fuse_nhwc([up, to_nhwc(x_hr)])
+        out, _ = hconv([c2], self.conv_last, self._plast, pre=pre)
+        return out

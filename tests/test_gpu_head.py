@@ -1,0 +1,140 @@
+"""GPU parity of the HR feature / fusion head (libsrbh fp32 matrix-core kernels) against the CPU oracle and the
+fixtures captured from the imported reference.  The head is fp32 end to end: tolerance 2e-5 relative."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import srbh_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 2e-5
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def gold(golden_dir, name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, name + ".npz")).items()}
+
+
+def test_pixelshuffle_fold_bit_exact():
+    """Upsampler with a channel-identity centre tap: the output must be the exact PixelShuffle gather."""
+    from srbh_amd.hrfuse import Upsampler
+    up = Upsampler(scale=2, n_feats=16)
+    w = torch.zeros(64, 16, 3, 3)
+    # conv output channel o copies input channel o % 16 scaled by (1 + o//16): values stay exact in fp32
+    for o in range(64):
+        w[o, o % 16, 1, 1] = 1.0 + o // 16
+    up.load_state_dict({"0.weight": w, "0.bias": torch.zeros(64)})
+    up = up.to(DEV).eval()
+    x = torch.randint(-100, 100, (2, 16, 9, 70)).float()
+    with torch.no_grad():
+        y = up(x.to(DEV)).cpu()
+    conv = torch.nn.functional.conv2d(x, w, None, 1, 1)
+    assert torch.equal(y, O.pixel_shuffle(conv, 2))
+    assert torch.equal(y, torch.nn.PixelShuffle(2)(conv))
+
+
+@pytest.mark.parametrize("inp,planes,seed,tag,xseed", [(32, 16, 16, "g6_bb32_16", 106), (16, 16, 17, "g6_bb16_16", 107)])
+def test_basicblock_eval_and_train_forward(inp, planes, seed, tag, xseed, golden_dir):
+    from srbh_amd.hrfuse import BasicBlock
+    g = gold(golden_dir, "g6_basicblock")
+    sd = {}
+    synth.basicblock_state_dict(sd, "", inp, planes, seed, "stress")
+    blk = BasicBlock(inp, planes)
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.to(DEV)
+    x = rnd((2, inp, 12, 12), xseed)
+    with torch.no_grad():
+        ye = blk.eval()(x.to(DEV)).cpu()
+        assert O.rel_l2(ye, g[tag + "_eval"]) <= TOL
+        assert O.rel_l2(ye, O.basic_block(synth.clone_sd(sd), "", x, False)) <= TOL
+        yt = blk.train()(x.to(DEV)).cpu()
+    assert O.rel_l2(yt, g[tag + "_train"]) <= TOL
+    msd = blk.state_dict()
+    for k, v in g.items():
+        if k.startswith(tag + "_stat_"):
+            name = k[len(tag + "_stat_"):]
+            assert torch.allclose(msd[name].cpu().double(), v.double(), rtol=1e-5, atol=1e-6), name
+
+
+def test_hrfeature_and_fuse_heads(golden_dir):
+    from srbh_amd.hrfuse import HRfeature, HRfuse_residual
+    g = gold(golden_dir, "g7_head")
+    sd = synth.hrfeature_state_dict(64, 16, 16, seed=18, mode="stress")
+    m = HRfeature(64, 16, 16)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    x = rnd((2, 64, 16, 16), 108)
+    with torch.no_grad():
+        assert O.rel_l2(m.eval()(x.to(DEV)).cpu(), g["g7_hrfeat_eval"]) <= TOL
+        assert O.rel_l2(m.train()(x.to(DEV)).cpu(), g["g7_hrfeat_train"]) <= TOL
+    for oc in (1, 7):
+        sd = synth.hrfuse_residual_state_dict(16, 16, 16, oc, 4, seed=19 + oc, mode="stress")
+        m = HRfuse_residual(16, 16, 16, oc, 4)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV)
+        a, b = rnd((2, 16, 4, 4), 109), rnd((2, 16, 16, 16), 110)
+        with torch.no_grad():
+            ye = m.eval()(a.to(DEV), b.to(DEV))
+            assert ye.shape == (2, oc, 16, 16)
+            assert O.rel_l2(ye.cpu(), g[f"g7_fuse{oc}_eval"]) <= TOL
+            assert O.rel_l2(m.train()(a.to(DEV), b.to(DEV)).cpu(), g[f"g7_fuse{oc}_train"]) <= TOL
+
+
+def test_head_full_resolution_ragged_and_variants():
+    """256x256 (several tiles per image) and a ragged size; sibling modules against the oracle building blocks."""
+    from srbh_amd.hrfuse import HRfeature, HRupsample, GeoNet, Refine_residual
+    sd = synth.hrfeature_state_dict(64, 16, 16, seed=3, mode="stress")
+    m = HRfeature(64, 16, 16)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    for shape in ((1, 64, 256, 256), (2, 64, 37, 91)):
+        x = rnd(shape, 5)
+        with torch.no_grad():
+            y = m(x.to(DEV).contiguous(memory_format=torch.channels_last))
+        assert O.rel_l2(y.cpu(), O.hrfeature(synth.clone_sd(sd), "", x, False)) <= TOL
+    sdg = synth.hrfeature_state_dict(4, 16, 16, seed=4, mode="stress", prefix="feat.")
+    gnet = GeoNet(4, 16)
+    gnet.load_state_dict(sdg)
+    x = rnd((1, 4, 20, 20), 6)
+    with torch.no_grad():
+        y = gnet.to(DEV).eval()(x.to(DEV))
+    assert O.rel_l2(y.cpu(), O.hrfeature(sdg, "feat.", x, False)) <= TOL
+    sdr = synth.hrfuse_residual_state_dict(16, 16, 16, 3, 4, seed=8, mode="stress")
+    ref = Refine_residual(16, 16, 16, 3)
+    ref.load_state_dict({k: v for k, v in sdr.items() if not k.startswith("upsampler.")})
+    a, b = rnd((1, 16, 24, 24), 7), rnd((1, 16, 24, 24), 8)
+    with torch.no_grad():
+        y = ref.to(DEV).eval()(a.to(DEV), b.to(DEV))
+    xx = torch.cat([a, b], 1)
+    for i in range(3):
+        xx = O.basic_block(sdr, f"fuse.{i}.", xx, False)
+    want = torch.nn.functional.conv2d(xx, sdr["conv_last.weight"], sdr["conv_last.bias"], 1, 1)
+    assert O.rel_l2(y.cpu(), want) <= TOL
+    hup = HRupsample(16, 3, 4)
+    hup.load_state_dict({k: v for k, v in sdr.items() if k.startswith(("upsampler.", "conv_last."))})
+    a = rnd((1, 16, 10, 10), 9)
+    with torch.no_grad():
+        y = hup.to(DEV).eval()(a.to(DEV))
+    want = torch.nn.functional.conv2d(O.upsampler(sdr, "upsampler.", a, 4), sdr["conv_last.weight"], sdr["conv_last.bias"], 1, 1)
+    assert O.rel_l2(y.cpu(), want) <= TOL
+
+
+def test_aggregate_kernel(golden_dir):
+    from srbh_amd.aggregate import aggregate_torch
+    g = gold(golden_dir, "g8_aggregate")
+    lab = g["label"].float()
+    out = aggregate_torch(lab.to(DEV), 0.25)
+    assert out.shape == (64, 64)
+    assert torch.allclose(out.cpu(), g["out"], rtol=1e-6, atol=1e-6)
+    batch = torch.cat([lab, lab.flip(-1)], 0)
+    out2 = aggregate_torch(batch.to(DEV), 0.25)
+    assert out2.shape == (2, 64, 64) and torch.allclose(out2[0].cpu(), g["out"], rtol=1e-6, atol=1e-6)
