@@ -153,7 +153,7 @@ typedef struct srbh_hconv_args {
     const float* src1; int c1;
     const float* w;       /* HWPACK32 for (cout, c0+c1, ksize) */
     const float* bias;    /* [cout padded to 16] or NULL */
-    int cout;             /* 1..16 or 49..64 */
+    int cout;             /* 1..32 or 49..64 */
     int ksize;            /* 3 or 1 */
     int B, H, W;
     int pixelshuffle2;
@@ -179,6 +179,35 @@ int srbh_bn_add_relu(const float* a, const float* a_scale, const float* a_shift,
 int srbh_aggregate(const float* data, float* out, int N, int H, int W, int step, void* stream);
 /* NCHW fp32 -> NHWC fp32 */
 int srbh_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, void* stream);
+
+/* ---- head backward (training; the reference relies on torch autograd over SR/HRfuse.py, train.py:254-256) ---- */
+/* dW[oc][ci][tap] = sum_px dy[px][oc] * X[px+tap][ci] with X = cat(pre(src0), src1) exactly as srbh_hconv_f32 reads it.
+ * dw is OIHW fp32 [cout][c0+c1][ksize][ksize]; it is zeroed by this call. */
+typedef struct srbh_hwgrad_args {
+    const float* src0; int c0;
+    const float* pre_scale; const float* pre_shift; int pre_relu;
+    const float* src1; int c1;
+    const float* dy;      /* NHWC [B][H][W][cout] */
+    int cout; int ksize;
+    int B, H, W;
+    float* dw;
+} srbh_hwgrad_args;
+int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream);
+/* out = g where ref > 0 else 0   (ReLU backward with the saved output, SR/HRfuse.py:157) */
+int srbh_relu_mask_mul(const float* g, const float* ref, float* out, long n, void* stream);
+int srbh_add_inplace(float* a, const float* b, long n, void* stream);
+/* per-channel partial sums (into a srbh_bn_stats_bytes(C) buffer, zeroed here) of dy and dy*xhat,
+ * dy = g * [c*mask_scale + mask_shift > 0] (mask optional), xhat = (c - mean)*invstd (c optional: bias gradients) */
+int srbh_bn_bwd_reduce(const float* g, const float* c, const float* mean, const float* invstd, const float* mask_scale,
+                       const float* mask_shift, long npix, int C, double* stats, void* stream);
+/* dgamma = sum dy*xhat, dbeta = sum dy, and the constants of dc = coef*(dy - k1 - xhat*k2) (coef may be NULL) */
+int srbh_bn_bwd_finalize(const double* stats, int C, double count, const float* gamma, const float* invstd,
+                         float* dgamma, float* dbeta, float* coef, float* k1, float* k2, void* stream);
+int srbh_bn_bwd_apply(const float* g, const float* c, const float* mean, const float* invstd, const float* mask_scale,
+                      const float* mask_shift, const float* coef, const float* k1, const float* k2, float* out, long npix,
+                      int C, void* stream);
+/* inverse of the PixelShuffle(2) store map: g_ps [B][2H][2W][C] -> g [B][H][W][4C] */
+int srbh_ps2_inverse(const float* g_ps, float* g, int B, int H, int W, int C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libsrbh.so")
-SOURCES = ["srbh_conv3x3.hip", "srbh_aux.hip", "srbh_rrdbnet.hip", "srbh_head.hip"]
+SOURCES = ["srbh_conv3x3.hip", "srbh_aux.hip", "srbh_rrdbnet.hip", "srbh_head.hip", "srbh_head_bwd.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
@@ -72,6 +72,16 @@ class HConvArgs(C.Structure):
     ]
 
 
+class HWGradArgs(C.Structure):
+    _fields_ = [
+        ("src0", C.c_void_p), ("c0", C.c_int),
+        ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("pre_relu", C.c_int),
+        ("src1", C.c_void_p), ("c1", C.c_int),
+        ("dy", C.c_void_p), ("cout", C.c_int), ("ksize", C.c_int),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dw", C.c_void_p),
+    ]
+
+
 class ConvW(C.Structure):
     _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p)]
 
@@ -107,6 +117,13 @@ SIGNATURES = {
     "srbh_bn_add_relu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp]),
     "srbh_aggregate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "srbh_hconv_wgrad_f32": (_i, [C.POINTER(HWGradArgs), _vp]),
+    "srbh_relu_mask_mul": (_i, [_vp, _vp, _vp, C.c_long, _vp]),
+    "srbh_add_inplace": (_i, [_vp, _vp, C.c_long, _vp]),
+    "srbh_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp, _vp]),
+    "srbh_bn_bwd_finalize": (_i, [_vp, _i, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "srbh_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp]),
+    "srbh_ps2_inverse": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_rrdbnet_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "srbh_rrdbnet_forward": (_i, [C.POINTER(RRDBNetDesc), _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
 }

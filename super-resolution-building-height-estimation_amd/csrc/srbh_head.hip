@@ -353,7 +353,7 @@ extern "C" int srbh_hconv_f32(const srbh_hconv_args* a, void* stream) {
     SRBH_REQUIRE(a->cout >= 1 && a->cout <= 64, "srbh_hconv_f32: cout must be in 1..64 (got %d)", a->cout);
     SRBH_REQUIRE(!a->pixelshuffle2 || a->cout % 4 == 0, "srbh_hconv_f32: PixelShuffle(2) needs cout %% 4 == 0");
     const int nob = (a->cout + 15) / 16;
-    SRBH_REQUIRE(nob == 1 || nob == 4, "srbh_hconv_f32: cout must be <=16 or in 49..64 (got %d)", a->cout);
+    SRBH_REQUIRE(nob == 1 || nob == 2 || nob == 4, "srbh_hconv_f32: cout must be <=32 or in 49..64 (got %d)", a->cout);
     HParams p;
     p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1;
     p.pre_scale = a->pre_scale; p.pre_shift = a->pre_shift; p.pre_relu = a->pre_relu;
@@ -366,8 +366,11 @@ extern "C" int srbh_hconv_f32(const srbh_hconv_args* a, void* stream) {
     const int nblocks = p.tiles_per_img * a->B;
     hipStream_t st = (hipStream_t)stream;
     if (a->stats) SRBH_HIP(hipMemsetAsync(a->stats, 0, srbh_bn_stats_bytes(p.cout), st));
-    if (a->ksize == 3) return nob == 1 ? launch_hconv<1, 3>(p, nblocks, st) : launch_hconv<4, 3>(p, nblocks, st);
-    return nob == 1 ? launch_hconv<1, 1>(p, nblocks, st) : launch_hconv<4, 1>(p, nblocks, st);
+    if (a->ksize == 3)
+        return nob == 1 ? launch_hconv<1, 3>(p, nblocks, st)
+                        : (nob == 2 ? launch_hconv<2, 3>(p, nblocks, st) : launch_hconv<4, 3>(p, nblocks, st));
+    return nob == 1 ? launch_hconv<1, 1>(p, nblocks, st)
+                    : (nob == 2 ? launch_hconv<2, 1>(p, nblocks, st) : launch_hconv<4, 1>(p, nblocks, st));
 }
 
 extern "C" int srbh_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta,

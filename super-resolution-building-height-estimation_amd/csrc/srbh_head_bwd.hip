@@ -1,0 +1,327 @@
+// srbh_head_bwd.hip -- backward kernels of the HR feature / fusion head (training: SURVEY.md 3.1, train.py:254-256).
+//
+// The reference gets these from torch autograd over SR/HRfuse.py; here each is a hand-written gfx950 kernel:
+//  * hwgrad_f32_kernel : weight gradient of a 3x3 / 1x1 conv as a GEMM over pixels on the fp32 matrix cores
+//                        dW[oc][ci][tap] = sum_px dY[px][oc] * X[px + tap][ci]   (v_mfma_f32_16x16x4_f32, K = 4 pixels),
+//                        X read with the same concat / folded BN+ReLU transform as the forward conv.
+//  * data gradients reuse the forward conv kernel (srbh_hconv_f32) with transposed + flipped weights
+//    (srbh_hpack_conv_f32(transpose_flip=1)).
+//  * BatchNorm backward in three steps: per-channel reductions (sum dy, sum dy*xhat) -> per-channel constants ->
+//    dc = gamma*invstd * (dy - mean(dy) - xhat * mean(dy*xhat)); the ReLU mask of the block is applied on the fly.
+//  * small elementwise helpers: relu mask, in-place add, per-channel sum (bias grad), PixelShuffle(2) inverse.
+#include "srbh_internal.h"
+
+namespace {
+using namespace srbh;
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int HT_H = 8, HT_W = 64;
+constexpr int NSLOT = 64;
+
+struct WGParams {
+    const float* src0; const float* src1;
+    int c0, c1;
+    const float* pre_scale; const float* pre_shift;
+    int pre_relu;
+    const float* dy;      // NHWC [B][H][W][cout_total]
+    int cout_total;
+    float* dw;            // OIHW fp32 [cout_total][cin][KS][KS], accumulated with atomics (caller zeroes it)
+    int B, H, W;
+    int tiles_x, tiles_per_img, ntiles;
+};
+
+// One workgroup walks tiles t = blockIdx.x, +gridDim.x, ... and keeps the 16(oc) x 16(ci) x taps partial sums of
+// one (oc block = blockIdx.y, ci chunk) in registers; flushed once per chunk through LDS with one atomic per value.
+template <int KS>
+__global__ __launch_bounds__(256) void hwgrad_f32_kernel(const WGParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    constexpr int TAPS = KS * KS, HALO = KS / 2;
+    constexpr int ROWS = HT_H + 2 * HALO, COLS = HT_W + 2 * HALO;
+    float* s_x = wsm;                          // [ROWS*COLS][16]
+    float* s_dy = wsm + ROWS * COLS * 16;      // [8*64][16]
+    float* s_red = s_dy;                       // reused for the cross-wave reduction at flush time
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kk = lane >> 4;
+    const int cin = p.c0 + p.c1;
+    const int nchunk = (cin + 15) / 16;
+    const int ob = blockIdx.y;
+
+    for (int c = 0; c < nchunk; ++c) {
+        floatx4 acc[TAPS];
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) acc[tp] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+            const int img = t / p.tiles_per_img;
+            const int trem = t - img * p.tiles_per_img;
+            const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+            const int Y0 = ty * HT_H, X0 = tx * HT_W;
+            __syncthreads();
+            for (int u = tid; u < ROWS * COLS * 4; u += 256) {   // X tile, pixel-major, 4 channels per thread
+                const int cg = u & 3, pix = u >> 2;
+                const int r = pix / COLS, col = pix - r * COLS;
+                const int y = Y0 + r - HALO, x = X0 + col - HALO;
+                const int ch = c * 16 + cg * 4;
+                floatx4 v = {0.f, 0.f, 0.f, 0.f};
+                if (y >= 0 && y < p.H && x >= 0 && x < p.W && ch < cin) {
+                    const long pixi = ((long)img * p.H + y) * p.W + x;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int cc = ch + j;
+                        if (cc < p.c0) {
+                            float a = p.src0[pixi * p.c0 + cc];
+                            if (p.pre_scale) a = a * p.pre_scale[cc] + p.pre_shift[cc];
+                            if (p.pre_relu) a = fmaxf(a, 0.f);
+                            v[j] = a;
+                        } else if (cc < cin) {
+                            v[j] = p.src1[pixi * p.c1 + (cc - p.c0)];
+                        }
+                    }
+                }
+                *(floatx4*)(s_x + pix * 16 + cg * 4) = v;
+            }
+            for (int u = tid; u < HT_H * HT_W * 4; u += 256) {   // dY tile (16 channels of block `ob`)
+                const int cg = u & 3, pix = u >> 2;
+                const int r = pix >> 6, col = pix & 63;
+                const int y = Y0 + r, x = X0 + col;
+                floatx4 v = {0.f, 0.f, 0.f, 0.f};
+                if (y < p.H && x < p.W) {
+                    const float* s = p.dy + (((long)img * p.H + y) * p.W + x) * p.cout_total + ob * 16 + cg * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (ob * 16 + cg * 4 + j < p.cout_total) v[j] = s[j];
+                }
+                *(floatx4*)(s_dy + pix * 16 + cg * 4) = v;
+            }
+            __syncthreads();
+#pragma unroll 2
+            for (int ks = 0; ks < 32; ++ks) {                     // 2 rows x 16 groups of 4 pixels per wave
+                const int row = wave * 2 + (ks >> 4), col = (ks & 15) * 4 + kk;
+                const float a = s_dy[(row * 64 + col) * 16 + l15];          // A[oc = l15][k = kk]
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp) {
+                    const int dy = tp / KS, dx = tp - dy * KS;
+                    const float b = s_x[((row + dy) * COLS + col + dx) * 16 + l15];   // B[k = kk][ci = l15]
+                    acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[tp], 0, 0, 0);
+                }
+            }
+        }
+        // flush: D[row = oc = kk*4 + r][col = ci = l15]
+        __syncthreads();
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_red[((wave * TAPS + tp) * 16 + kk * 4 + r) * 16 + l15] = acc[tp][r];
+        __syncthreads();
+        for (int u = tid; u < TAPS * 256; u += 256) {
+            const float v = s_red[u] + s_red[TAPS * 256 + u] + s_red[2 * TAPS * 256 + u] + s_red[3 * TAPS * 256 + u];
+            const int ci = c * 16 + (u & 15), oc = ob * 16 + ((u >> 4) & 15), tp = u >> 8;
+            if (ci < cin && oc < p.cout_total) atomicAdd(p.dw + ((long)oc * cin + ci) * TAPS + tp, v);
+        }
+    }
+}
+
+// ---- elementwise / reduction helpers (NHWC fp32, C % 4 == 0 unless noted) ------------------------------------------
+__global__ void relu_mask_mul_kernel(const floatx4* __restrict__ g, const floatx4* __restrict__ ref, floatx4* out, long n4) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        floatx4 a = g[i], r = ref[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = r[q] > 0.f ? a[q] : 0.f;
+        out[i] = a;
+    }
+}
+
+__global__ void add_inplace_kernel(floatx4* a, const floatx4* __restrict__ b, long n4) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) a[i] += b[i];
+}
+
+// per-channel sums of dy (and dy*xhat when c != nullptr); dy = g * [c*ms+mh > 0] when ms != nullptr.
+// generic C (scalar loads); block = 256 threads over pixels, thread handles all channels of a pixel subset
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ c, const float* mean,
+                                     const float* invstd, const float* ms, const float* mh, long npix, int C,
+                                     double* stats /* [NSLOT][2][C] */) {
+    extern __shared__ float red[];   // [2][C]
+    for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) red[k] = 0.f;
+    __syncthreads();
+    // thread layout: channel = threadIdx.x % C (C <= 64 divides 256 or not: use modulo walk over flat index)
+    long total = npix * C;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    // stride is a multiple of C when C divides blockDim.x*gridDim.x; otherwise accumulate per element via LDS atomics
+    const bool fixed = (stride % C) == 0;
+    float s = 0.f, q = 0.f;
+    int ch = (int)(i % C);
+    for (; i < total; i += stride) {
+        if (!fixed) ch = (int)(i % C);
+        float dy = g[i];
+        float cv = c ? c[i] : 0.f;
+        if (ms && !(cv * ms[ch] + mh[ch] > 0.f)) dy = 0.f;
+        const float xh = c ? (cv - mean[ch]) * invstd[ch] : 0.f;
+        if (fixed) {
+            s += dy;
+            q += dy * xh;
+        } else {
+            atomicAdd(&red[ch], dy);
+            atomicAdd(&red[C + ch], dy * xh);
+        }
+    }
+    if (fixed) {
+        atomicAdd(&red[ch], s);
+        atomicAdd(&red[C + ch], q);
+    }
+    __syncthreads();
+    double* slot = stats + (long)(blockIdx.x % NSLOT) * 2 * C;
+    for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) atomicAdd(slot + k, (double)red[k]);
+}
+
+// per-channel constants of the BatchNorm backward: dgamma, dbeta and (coef, k1, k2) with
+// dc = coef * (dy - k1 - xhat * k2);   training: coef = gamma*invstd, k1 = sum(dy)/N, k2 = sum(dy*xhat)/N
+__global__ void bn_bwd_finalize_kernel(const double* stats, int C, double count, const float* gamma, const float* invstd,
+                                       float* dgamma, float* dbeta, float* coef, float* k1, float* k2) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, q = 0;
+    for (int k = 0; k < NSLOT; ++k) {
+        s += stats[(long)k * 2 * C + c];
+        q += stats[(long)k * 2 * C + C + c];
+    }
+    if (dgamma) dgamma[c] = (float)q;
+    if (dbeta) dbeta[c] = (float)s;
+    if (coef) {
+        coef[c] = (gamma ? gamma[c] : 1.f) * invstd[c];
+        k1[c] = (float)(s / count);
+        k2[c] = (float)(q / count);
+    }
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ c, const float* mean,
+                                    const float* invstd, const float* ms, const float* mh, const float* coef,
+                                    const float* k1, const float* k2, float* out, long total, int C) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int ch = (int)(i % C);
+        float dy = g[i];
+        const float cv = c[i];
+        if (ms && !(cv * ms[ch] + mh[ch] > 0.f)) dy = 0.f;
+        const float xh = (cv - mean[ch]) * invstd[ch];
+        out[i] = coef[ch] * (dy - k1[ch] - xh * k2[ch]);
+    }
+}
+
+// PixelShuffle(2) inverse: g_ps [B][2H][2W][C] -> g [B][H][W][4C], channel 4c + 2i + j <- (2y+i, 2x+j, c)
+__global__ void ps2_inverse_kernel(const float* __restrict__ gps, float* __restrict__ g, int B, int H, int W, int C) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)B * H * W * 4 * C;
+    if (idx >= total) return;
+    int oc = idx % (4 * C);
+    long r = idx / (4 * C);
+    int x = r % W; r /= W;
+    int y = r % H;
+    int b = r / H;
+    int cc = oc >> 2, i = (oc >> 1) & 1, j = oc & 1;
+    g[idx] = gps[(((long)b * 2 * H + 2 * y + i) * (2 * W) + 2 * x + j) * C + cc];
+}
+
+int grid_for(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
+}
+
+}  // namespace
+
+extern "C" int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream) {
+    SRBH_REQUIRE(a && a->src0 && a->dy && a->dw, "srbh_hconv_wgrad_f32: null pointer");
+    SRBH_REQUIRE(a->c0 > 0 && a->c1 >= 0 && (a->c1 == 0 || a->src1), "srbh_hconv_wgrad_f32: bad channel split");
+    SRBH_REQUIRE(a->ksize == 3 || a->ksize == 1, "srbh_hconv_wgrad_f32: ksize must be 1 or 3");
+    SRBH_REQUIRE(a->cout >= 1 && a->cout <= 64 && a->B > 0 && a->H > 0 && a->W > 0, "srbh_hconv_wgrad_f32: bad shape");
+    WGParams p;
+    p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1;
+    p.pre_scale = a->pre_scale; p.pre_shift = a->pre_shift; p.pre_relu = a->pre_relu;
+    p.dy = a->dy; p.cout_total = a->cout; p.dw = a->dw;
+    p.B = a->B; p.H = a->H; p.W = a->W;
+    p.tiles_x = (a->W + HT_W - 1) / HT_W;
+    p.tiles_per_img = p.tiles_x * ((a->H + HT_H - 1) / HT_H);
+    p.ntiles = p.tiles_per_img * a->B;
+    hipStream_t st = (hipStream_t)stream;
+    const int cin = a->c0 + a->c1;
+    SRBH_HIP(hipMemsetAsync(a->dw, 0, (size_t)a->cout * cin * a->ksize * a->ksize * sizeof(float), st));
+    const int nob = (a->cout + 15) / 16;
+    const int gx = p.ntiles < 512 ? p.ntiles : 512;
+    if (a->ksize == 3) {
+        constexpr int LDS_B = (10 * 66 * 16 + 4 * 9 * 256) * 4;   // X tile + max(dY tile, flush buffer)
+        static bool set = false;
+        if (!set) {
+            SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_f32_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
+            set = true;
+        }
+        hipLaunchKernelGGL(hwgrad_f32_kernel<3>, dim3(gx, nob), dim3(256), LDS_B, st, p);
+    } else {
+        constexpr int LDS_B = (8 * 64 * 16 + 8 * 64 * 16) * 4;
+        static bool set = false;
+        if (!set) {
+            SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_f32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
+            set = true;
+        }
+        hipLaunchKernelGGL(hwgrad_f32_kernel<1>, dim3(gx, nob), dim3(256), LDS_B, st, p);
+    }
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_relu_mask_mul(const float* g, const float* ref, float* out, long n, void* stream) {
+    SRBH_REQUIRE(g && ref && out && n > 0 && n % 4 == 0, "srbh_relu_mask_mul: bad arguments");
+    hipLaunchKernelGGL(relu_mask_mul_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const floatx4*)g,
+                       (const floatx4*)ref, (floatx4*)out, n / 4);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_add_inplace(float* a, const float* b, long n, void* stream) {
+    SRBH_REQUIRE(a && b && n > 0 && n % 4 == 0, "srbh_add_inplace: bad arguments");
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (floatx4*)a,
+                       (const floatx4*)b, n / 4);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_bn_bwd_reduce(const float* g, const float* c, const float* mean, const float* invstd,
+                                  const float* mask_scale, const float* mask_shift, long npix, int C, double* stats,
+                                  void* stream) {
+    SRBH_REQUIRE(g && stats && npix > 0 && C > 0 && C <= 64, "srbh_bn_bwd_reduce: bad arguments");
+    SRBH_REQUIRE(!c || (mean && invstd), "srbh_bn_bwd_reduce: c needs mean/invstd");
+    SRBH_REQUIRE(!mask_scale || (c && mask_shift), "srbh_bn_bwd_reduce: mask needs c and mask_shift");
+    hipStream_t st = (hipStream_t)stream;
+    SRBH_HIP(hipMemsetAsync(stats, 0, (size_t)NSLOT * 2 * C * sizeof(double), st));
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(npix * C)), dim3(256), 2 * C * sizeof(float), st, g, c, mean,
+                       invstd, mask_scale, mask_shift, npix, C, stats);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_bn_bwd_finalize(const double* stats, int C, double count, const float* gamma, const float* invstd,
+                                    float* dgamma, float* dbeta, float* coef, float* k1, float* k2, void* stream) {
+    SRBH_REQUIRE(stats && C > 0 && C <= 64 && count > 0, "srbh_bn_bwd_finalize: bad arguments");
+    SRBH_REQUIRE(!coef || (invstd && k1 && k2), "srbh_bn_bwd_finalize: coef needs invstd, k1, k2");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, C, count, gamma, invstd,
+                       dgamma, dbeta, coef, k1, k2);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_bn_bwd_apply(const float* g, const float* c, const float* mean, const float* invstd,
+                                 const float* mask_scale, const float* mask_shift, const float* coef, const float* k1,
+                                 const float* k2, float* out, long npix, int C, void* stream) {
+    SRBH_REQUIRE(g && c && mean && invstd && coef && k1 && k2 && out && npix > 0 && C > 0, "srbh_bn_bwd_apply: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * C)), dim3(256), 0, (hipStream_t)stream, g, c, mean,
+                       invstd, mask_scale, mask_shift, coef, k1, k2, out, npix * C, C);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_ps2_inverse(const float* g_ps, float* g, int B, int H, int W, int C, void* stream) {
+    SRBH_REQUIRE(g_ps && g && B > 0 && H > 0 && W > 0 && C > 0, "srbh_ps2_inverse: bad arguments");
+    long total = (long)B * H * W * 4 * C;
+    hipLaunchKernelGGL(ps2_inverse_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_ps, g, B, H, W, C);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}

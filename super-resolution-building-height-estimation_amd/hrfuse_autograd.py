@@ -1,0 +1,268 @@
+"""Training path of the HR feature / fusion head: torch.autograd.Function wrappers whose forward AND backward
+are libsrbh kernels (csrc/srbh_head.hip, csrc/srbh_head_bwd.hip).  torch.autograd only carries the graph.
+
+The reference obtains these gradients from torch autograd over SR/HRfuse.py (train.py:254-256); parity is pinned by
+tests/golden/g6_basicblock.npz and g7_head.npz (outputs, input grads, parameter grads, running statistics).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib
+from . import hrfuse as H
+
+
+# ----------------------------------------------------------------------------- raw op wrappers
+class _PackedGrad:
+    """HWPACK32 of the data-gradient conv (transposed + flipped weight), cached per weight version."""
+
+    def __init__(self):
+        self.key = None
+        self.w = None
+
+    def get(self, weight):
+        key = (weight._version, weight.data_ptr())
+        if key != self.key:
+            L = _lib.lib()
+            cout, cin, ks, _ = weight.shape
+            buf = torch.empty(L.srbh_hpack_bytes(cin, cout, ks) // 4, dtype=torch.float32, device=weight.device)
+            wc = weight.detach().float().contiguous()
+            _lib.check(L.srbh_hpack_conv_f32(wc.data_ptr(), cin, cout, ks, 1, buf.data_ptr(), _lib.stream_ptr()),
+                       "hpack_conv_f32(T)")
+            torch.cuda.current_stream().synchronize()
+            self.key, self.w = key, buf
+        return self.w
+
+
+def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False):
+    L = _lib.lib()
+    x0 = srcs[0]
+    B, c0, Hh, Ww = x0.shape
+    a = _lib.HConvArgs()
+    a.src0, a.c0 = x0.data_ptr(), c0
+    if pre is not None:
+        a.pre_scale, a.pre_shift, a.pre_relu = pre[0].data_ptr(), pre[1].data_ptr(), int(pre[2])
+    if len(srcs) > 1:
+        a.src1, a.c1 = srcs[1].data_ptr(), srcs[1].shape[1]
+    a.w = w_packed.data_ptr()
+    a.bias = None if bias is None else bias.data_ptr()
+    a.cout, a.ksize = cout, ks
+    a.B, a.H, a.W = B, Hh, Ww
+    a.pixelshuffle2 = int(ps2)
+    out = H.empty_nhwc(B, cout // 4, 2 * Hh, 2 * Ww, x0.device) if ps2 else H.empty_nhwc(B, cout, Hh, Ww, x0.device)
+    a.out = out.data_ptr()
+    _lib.check(L.srbh_hconv_f32(C.byref(a), _lib.stream_ptr()), "hconv_f32")
+    return out
+
+
+def conv_dgrad(g, weight, cache: _PackedGrad):
+    """dX = conv^T(g, W): the forward kernel with transposed + flipped weights."""
+    cout, cin, ks, _ = weight.shape
+    return _hconv_raw([g], cache.get(weight), None, cin, ks)
+
+
+def conv_wgrad(srcs, pre, g, cout, ks):
+    L = _lib.lib()
+    x0 = srcs[0]
+    B, c0, Hh, Ww = x0.shape
+    c1 = srcs[1].shape[1] if len(srcs) > 1 else 0
+    dw = torch.empty((cout, c0 + c1, ks, ks), dtype=torch.float32, device=x0.device)
+    a = _lib.HWGradArgs()
+    a.src0, a.c0 = x0.data_ptr(), c0
+    if pre is not None:
+        a.pre_scale, a.pre_shift, a.pre_relu = pre[0].data_ptr(), pre[1].data_ptr(), int(pre[2])
+    if c1:
+        a.src1, a.c1 = srcs[1].data_ptr(), c1
+    a.dy, a.cout, a.ksize = g.data_ptr(), cout, ks
+    a.B, a.H, a.W = B, Hh, Ww
+    a.dw = dw.data_ptr()
+    _lib.check(L.srbh_hconv_wgrad_f32(C.byref(a), _lib.stream_ptr()), "hconv_wgrad_f32")
+    return dw
+
+
+def _stats_buf(Cc, dev):
+    return torch.empty(_lib.lib().srbh_bn_stats_bytes(Cc) // 8, dtype=torch.float64, device=dev)
+
+
+def channel_sum(g):
+    """sum over (B,H,W) per channel of an NHWC tensor (bias gradient)."""
+    L = _lib.lib()
+    B, Cc, Hh, Ww = g.shape
+    st = _stats_buf(Cc, g.device)
+    _lib.check(L.srbh_bn_bwd_reduce(g.data_ptr(), None, None, None, None, None, B * Hh * Ww, Cc, st.data_ptr(),
+                                    _lib.stream_ptr()), "bn_bwd_reduce")
+    out = torch.empty(Cc, dtype=torch.float32, device=g.device)
+    _lib.check(L.srbh_bn_bwd_finalize(st.data_ptr(), Cc, 1.0, None, None, None, out.data_ptr(), None, None, None,
+                                      _lib.stream_ptr()), "bn_bwd_finalize")
+    return out
+
+
+def bn_backward(g, c, mean, invstd, gamma, mask, training):
+    """BatchNorm (+ optional ReLU mask [c*ms+mh > 0]) backward.  Returns (dc, dgamma, dbeta)."""
+    L = _lib.lib()
+    B, Cc, Hh, Ww = c.shape
+    n = B * Hh * Ww
+    dev = c.device
+    st = _stats_buf(Cc, dev)
+    ms, mh = (mask[0].data_ptr(), mask[1].data_ptr()) if mask is not None else (None, None)
+    _lib.check(L.srbh_bn_bwd_reduce(g.data_ptr(), c.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ms, mh, n, Cc,
+                                    st.data_ptr(), _lib.stream_ptr()), "bn_bwd_reduce")
+    dgamma = torch.empty(Cc, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(Cc, dtype=torch.float32, device=dev)
+    coef = torch.empty(Cc, dtype=torch.float32, device=dev)
+    k1 = torch.empty(Cc, dtype=torch.float32, device=dev)
+    k2 = torch.empty(Cc, dtype=torch.float32, device=dev)
+    _lib.check(L.srbh_bn_bwd_finalize(st.data_ptr(), Cc, float(n), gamma.data_ptr(), invstd.data_ptr(), dgamma.data_ptr(),
+                                      dbeta.data_ptr(), coef.data_ptr(), k1.data_ptr(), k2.data_ptr(), _lib.stream_ptr()),
+               "bn_bwd_finalize")
+    if not training:       # frozen statistics: the mean terms vanish
+        k1.zero_()
+        k2.zero_()
+    dc = H.empty_nhwc(B, Cc, Hh, Ww, dev)
+    _lib.check(L.srbh_bn_bwd_apply(g.data_ptr(), c.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ms, mh, coef.data_ptr(),
+                                   k1.data_ptr(), k2.data_ptr(), dc.data_ptr(), n, Cc, _lib.stream_ptr()), "bn_bwd_apply")
+    return dc, dgamma, dbeta
+
+
+def relu_mask(g, ref):
+    out = torch.empty_like(ref)
+    _lib.check(_lib.lib().srbh_relu_mask_mul(g.data_ptr(), ref.data_ptr(), out.data_ptr(), ref.numel(), _lib.stream_ptr()),
+               "relu_mask_mul")
+    return out
+
+
+def add_(a, b):
+    _lib.check(_lib.lib().srbh_add_inplace(a.data_ptr(), b.data_ptr(), a.numel(), _lib.stream_ptr()), "add_inplace")
+    return a
+
+
+def ps2_inverse(g_ps):
+    B, Cc, H2, W2 = g_ps.shape
+    out = H.empty_nhwc(B, 4 * Cc, H2 // 2, W2 // 2, g_ps.device)
+    _lib.check(_lib.lib().srbh_ps2_inverse(g_ps.data_ptr(), out.data_ptr(), B, H2 // 2, W2 // 2, Cc, _lib.stream_ptr()),
+               "ps2_inverse")
+    return out
+
+
+def _bn_eval_stats(bn):
+    return bn.running_mean.detach(), torch.rsqrt(bn.running_var.detach() + bn.eps)
+
+
+# ----------------------------------------------------------------------------- conv (+bias, +PixelShuffle)
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, conv, packed, gcache, ps2):
+        xn = H.to_nhwc(x.detach())
+        out, _ = H.hconv([xn], conv, packed, ps2=ps2)
+        ctx.save_for_backward(xn, weight)
+        ctx.ps2, ctx.gcache, ctx.has_bias = ps2, gcache, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xn, weight = ctx.saved_tensors
+        g = H.to_nhwc(g)
+        if ctx.ps2:
+            g = ps2_inverse(g)
+        cout, cin, ks, _ = weight.shape
+        dx = conv_dgrad(g, weight, ctx.gcache) if ctx.needs_input_grad[0] else None
+        dw = conv_wgrad([xn], None, g, cout, ks) if ctx.needs_input_grad[1] else None
+        db = channel_sum(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None, None, None, None
+
+
+def conv_forward(conv: nn.Conv2d, packed, x, ps2=False):
+    cache = conv.__dict__.setdefault("_srbh_gcache", _PackedGrad())
+    return _ConvFn.apply(x, conv.weight, conv.bias, conv, packed, cache, ps2)
+
+
+def upsampler_forward(up, x):
+    for i, mod in enumerate(up):
+        if isinstance(mod, nn.Conv2d):
+            x = conv_forward(mod, up._packs.setdefault(i, H._PackedConv()), x, ps2=True)
+    return x
+
+
+# ----------------------------------------------------------------------------- BasicBlock
+class _BasicBlockFn(torch.autograd.Function):
+    """out = relu(bn2(conv2(relu(bn1(conv1(x))))) + idt(x)), x = cat(x0, x1)  (SR/HRfuse.py:142-159)."""
+
+    @staticmethod
+    def forward(ctx, blk, x0, x1, w1, g1, b1, w2, g2, b2, wd, gd, bd):
+        blk._check()
+        tr = blk.training
+        srcs = [H.to_nhwc(x0.detach())] + ([H.to_nhwc(x1.detach())] if x1 is not None else [])
+        B, _, Hh, Ww = srcs[0].shape
+        n = B * Hh * Ww
+        c1, st1 = H.hconv(srcs, blk.conv1, blk._p1, want_stats=tr)
+        s1, h1, m1, i1 = H.bn_scale_shift(blk.bn1, st1, n, tr)
+        c2, st2 = H.hconv([c1], blk.conv2, blk._p2, pre=(s1, h1, True), want_stats=tr)
+        s2, h2, m2, i2 = H.bn_scale_shift(blk.bn2, st2, n, tr)
+        if not tr:
+            (m1, i1), (m2, i2) = _bn_eval_stats(blk.bn1), _bn_eval_stats(blk.bn2)
+        d = md = idd = None
+        if blk.downsample is not None:
+            d, std = H.hconv(srcs, blk.downsample[0], blk._pd, want_stats=tr)
+            sd, hd, md, idd = H.bn_scale_shift(blk.downsample[1], std, n, tr)
+            if not tr:
+                md, idd = _bn_eval_stats(blk.downsample[1])
+            out = H.bn_add_relu(c2, s2, h2, d, sd, hd)
+        else:
+            out = H.bn_add_relu(c2, s2, h2, srcs[0])
+        ctx.blk, ctx.tr, ctx.nsrc = blk, tr, len(srcs)
+        ctx.save_for_backward(*srcs, c1, c2, out, s1, h1, m1, i1, m2, i2, w1, g1, w2, g2,
+                              *([d, md, idd, wd, gd] if d is not None else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        blk, tr, nsrc = ctx.blk, ctx.tr, ctx.nsrc
+        sv = ctx.saved_tensors
+        srcs = list(sv[:nsrc])
+        c1, c2, out, s1, h1, m1, i1, m2, i2, w1, g1, w2, g2 = sv[nsrc:nsrc + 13]
+        has_ds = len(sv) > nsrc + 13
+        if has_ds:
+            d, md, idd, wd, gd = sv[nsrc + 13:]
+        caches = blk.__dict__.setdefault("_srbh_gcaches", [_PackedGrad(), _PackedGrad(), _PackedGrad()])
+        dz = relu_mask(H.to_nhwc(g), out)                                   # through the final ReLU
+        # bn2 -> conv2
+        dc2, dg2, db2 = bn_backward(dz, c2, m2, i2, g2, None, tr)
+        dw2 = conv_wgrad([c1], (s1, h1, True), dc2, w2.shape[0], 3)
+        da1 = conv_dgrad(dc2, w2, caches[1])
+        # relu -> bn1 -> conv1   (mask: bn1(c1) > 0)
+        dc1, dg1, db1 = bn_backward(da1, c1, m1, i1, g1, (s1, h1), tr)
+        dw1 = conv_wgrad(srcs, None, dc1, w1.shape[0], 3)
+        need_dx = ctx.needs_input_grad[1] or (nsrc > 1 and ctx.needs_input_grad[2])
+        dx = conv_dgrad(dc1, w1, caches[0]) if need_dx else None
+        dwd = dgd = dbd = None
+        if has_ds:
+            dd, dgd, dbd = bn_backward(dz, d, md, idd, gd, None, tr)
+            dwd = conv_wgrad(srcs, None, dd, wd.shape[0], 1)
+            if need_dx:
+                add_(dx, conv_dgrad(dd, wd, caches[2]))
+        elif need_dx:
+            add_(dx, dz)
+        dx0 = dx1 = None
+        if need_dx:
+            if nsrc == 1:
+                dx0 = dx
+            else:
+                c0 = srcs[0].shape[1]
+                dx0, dx1 = dx[:, :c0], dx[:, c0:]
+        return (None, dx0, dx1, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd)
+
+
+def blocks_forward(blocks, inputs):
+    x0 = inputs[0]
+    x1 = inputs[1] if len(inputs) > 1 else None
+    for blk in blocks:
+        ds = blk.downsample
+        x0 = _BasicBlockFn.apply(blk, x0, x1, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight,
+                                 blk.bn2.weight, blk.bn2.bias,
+                                 None if ds is None else ds[0].weight, None if ds is None else ds[1].weight,
+                                 None if ds is None else ds[1].bias)
+        x1 = None
+    return x0

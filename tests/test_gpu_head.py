@@ -138,3 +138,71 @@ def test_aggregate_kernel(golden_dir):
     batch = torch.cat([lab, lab.flip(-1)], 0)
     out2 = aggregate_torch(batch.to(DEV), 0.25)
     assert out2.shape == (2, 64, 64) and torch.allclose(out2[0].cpu(), g["out"], rtol=1e-6, atol=1e-6)
+
+
+def _train_check(g, tag, module, inputs, tol_grad=5e-5):
+    """forward in train mode with autograd, backward of sum(y*w): outputs, input grads, parameter grads and the
+    updated running statistics must match what the reference produced (tools/make_golden.py::_train_eval)."""
+    module = module.to(DEV).train()
+    ins = [t.clone().to(DEV).requires_grad_(True) for t in inputs]
+    y = module(*ins)
+    assert O.rel_l2(y.detach().cpu(), g[tag + "_train"]) <= TOL
+    wgt = rnd(tuple(y.shape), 777).to(DEV)
+    (y * wgt).sum().backward()
+    for i, t in enumerate(ins):
+        e = O.rel_l2(t.grad.cpu(), g[f"{tag}_dx{i}"])
+        assert e <= tol_grad, (f"dx{i}", e)
+    for k, p in module.named_parameters():
+        e = O.rel_l2(p.grad.cpu(), g[f"{tag}_grad_{k}"])
+        assert e <= tol_grad, (k, e)
+    msd = module.state_dict()
+    for k, v in g.items():
+        if k.startswith(tag + "_stat_"):
+            name = k[len(tag + "_stat_"):]
+            assert torch.allclose(msd[name].cpu().double(), v.double(), rtol=1e-5, atol=1e-6), name
+
+
+@pytest.mark.parametrize("inp,planes,seed,tag,xseed", [(32, 16, 16, "g6_bb32_16", 106), (16, 16, 17, "g6_bb16_16", 107)])
+def test_basicblock_backward(inp, planes, seed, tag, xseed, golden_dir):
+    from srbh_amd.hrfuse import BasicBlock
+    g = gold(golden_dir, "g6_basicblock")
+    sd = {}
+    synth.basicblock_state_dict(sd, "", inp, planes, seed, "stress")
+    blk = BasicBlock(inp, planes)
+    blk.load_state_dict(sd, strict=True)
+    _train_check(g, tag, blk, [rnd((2, inp, 12, 12), xseed)])
+
+
+def test_head_backward(golden_dir):
+    from srbh_amd.hrfuse import HRfeature, HRfuse_residual
+    g = gold(golden_dir, "g7_head")
+    m = HRfeature(64, 16, 16)
+    m.load_state_dict(synth.hrfeature_state_dict(64, 16, 16, seed=18, mode="stress"), strict=True)
+    _train_check(g, "g7_hrfeat", m, [rnd((2, 64, 16, 16), 108)])
+    for oc in (1, 7):
+        m = HRfuse_residual(16, 16, 16, oc, 4)
+        m.load_state_dict(synth.hrfuse_residual_state_dict(16, 16, 16, oc, 4, seed=19 + oc, mode="stress"), strict=True)
+        _train_check(g, f"g7_fuse{oc}", m, [rnd((2, 16, 4, 4), 109), rnd((2, 16, 16, 16), 110)])
+
+
+def test_backward_larger_ragged_vs_oracle_autograd():
+    """several tiles per image + ragged edges: compare with torch autograd over the CPU oracle."""
+    from srbh_amd.hrfuse import HRfuse_residual
+    sd = synth.hrfuse_residual_state_dict(16, 16, 16, 7, 4, seed=31, mode="stress")
+    m = HRfuse_residual(16, 16, 16, 7, 4)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).train()
+    a, b = rnd((2, 16, 19, 23), 1), rnd((2, 16, 76, 92), 2)
+    ins = [a.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)]
+    y = m(*ins)
+    wgt = rnd(tuple(y.shape), 3)
+    (y * wgt.to(DEV)).sum().backward()
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    oa, ob = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yo = O.hrfuse_residual(osd, "", oa, ob, True)
+    (yo * wgt).sum().backward()
+    assert O.rel_l2(y.detach().cpu(), yo.detach()) <= TOL
+    assert O.rel_l2(ins[0].grad.cpu(), oa.grad) <= 1e-4 and O.rel_l2(ins[1].grad.cpu(), ob.grad) <= 1e-4
+    for k, p in m.named_parameters():
+        assert O.rel_l2(p.grad.cpu(), osd[k].grad) <= 1e-4, k
