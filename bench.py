@@ -70,6 +70,57 @@ def cpu_baseline(sd, seconds_budget=20.0):
                       f"calls after 1 warm-up ({sum(times) + t_first:.1f} s of CPU work)"}
 
 
+def bench_train(args, rank, world, dev, dist):
+    """BASELINE configs[2]/[3]: RRDBNet forward (no grad) + SRRegress_Cls_feature forward/backward + Adam, batch 64 per
+    GPU, gradients averaged over ranks by one bucketed RCCL all-reduce per step."""
+    from oracle import synth
+    from srbh_amd.harness import TrainStep, synthetic_batch
+    from srbh_amd.models import SRRegress_Cls_feature
+    from srbh_amd.rrdbnet import RRDBNet
+    B = args.batch if args.batch != 32 else 64
+    net_hr = RRDBNet(3, 3, num_block=args.num_block)
+    net_hr.load_state_dict(synth.rrdbnet_state_dict(num_block=args.num_block, seed=1337, mode="init"))
+    torch.manual_seed(1337)
+    net = SRRegress_Cls_feature("efficientnet-b4", in_channels=8, super_in=64, super_mid=16, upscale=4, isaggre=True,
+                                chans_build=7)
+    ts = TrainStep(net_hr.to(dev), net.to(dev), dev, world=world)
+    batch = synthetic_batch(B, 1337 + rank, dev)
+    for _ in range(args.warmup):
+        ts(batch)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = ts(batch)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    if rank == 0:
+        gf_tile = 146.63 + 8.12 * 3 + 0.9 * 3      # RRDB fwd + head fwd/bwd (~3x fwd) + encoder/decoders (SURVEY 8d)
+        tf = gf_tile * B * world * args.steps / elapsed / 1e3
+        print(json.dumps({
+            "metric": "tiles/sec (64x64x8ch->256x256 height) fwd+bwd", "value": round(B * world * args.steps / elapsed, 2),
+            "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16 operands/f32 acc (RRDB), f32 (head fwd+bwd)", "data": "synthetic",
+            "config": {"workload": f"full train step: RRDBNet fwd (no grad) + SRRegress_Cls_feature fwd/bwd + Adam, batch {B}/GPU "
+                                   "(BASELINE.json configs[2])", "global_batch": B * world,
+                       "parallelism": f"dp{world} (bucketed RCCL grad all-reduce)"},
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / PEAK_F16_TFLOPS, 4), "traffic": None,
+                         "kernel": "whole step (RRDB f16 MFMA stack dominates the FLOPs)"},
+            "final_loss": float(loss)}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +129,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="tiles per GPU per step (configs[1]: 32)")
     ap.add_argument("--num-block", type=int, default=23)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["feature", "train"], default="feature",
+                    help="feature = BASELINE configs[1] (default); train = configs[2]: full training step, batch 64")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,6 +151,9 @@ def main():
 
     from oracle import synth  # synthetic weights/inputs only (the checker itself runs in cpu_baseline)
     from srbh_amd.rrdbnet import RRDBNet
+
+    if args.workload == "train":
+        return bench_train(args, rank, world, dev, dist)
 
     sd = synth.rrdbnet_state_dict(num_block=args.num_block, seed=1337, mode="init")
     net = RRDBNet(3, 3, num_block=args.num_block)

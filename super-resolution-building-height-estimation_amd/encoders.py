@@ -1,0 +1,245 @@
+"""Third-party parts of the height model, restated in stock PyTorch(-ROCm) ops.
+
+The reference builds its encoder / decoders from ``segmentation_models_pytorch`` (unpinned in requirements.txt:14;
+call sites mymodels.py:242-258,276,279,287), which is not in the reference tree and not installable offline.
+SURVEY.md 8(a) a18 scopes these < 1 GFLOP/tile parts as "stock PyTorch-ROCm ops acceptable"; this file restates
+the published architectures from their papers / documented layouts:
+
+* ``EfficientNetEncoder``  -- EfficientNet (Tan & Le 2019) B0-B7 feature extractor with the module/parameter naming
+  of efficientnet_pytorch 0.7.1 as wrapped by smp <0.5 (``_conv_stem``, ``_bn0``, ``_blocks.{i}._expand_conv`` ...,
+  ``_conv_head``/``_bn1`` present but unused, ``_fc`` removed), TF-style "same" padding computed statically for the
+  model's nominal resolution, BatchNorm eps 1e-3 / momentum 0.01, swish, squeeze-excite 0.25, drop-connect.
+* ``UnetDecoder``          -- U-Net decoder of smp <0.5: n_blocks x [nearest x2, concat skip, (conv3x3+BN+ReLU) x2],
+  keys ``blocks.{i}.conv{1,2}.{0,1}.*``.
+
+PARITY UNPINNED: the reference holds no fixture at this boundary and the dependency is absent; the anchors are the
+author's recorded parameter counts (mymodels.py:765: encoder 17.55 M, decoder 2.68 M), asserted in tests.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+# (width, depth, resolution, dropout) -- EfficientNet paper table / efficientnet_pytorch.utils.efficientnet_params
+_EFFNET_PARAMS = {
+    "efficientnet-b0": (1.0, 1.0, 224, 0.2), "efficientnet-b1": (1.0, 1.1, 240, 0.2),
+    "efficientnet-b2": (1.1, 1.2, 260, 0.3), "efficientnet-b3": (1.2, 1.4, 300, 0.3),
+    "efficientnet-b4": (1.4, 1.8, 380, 0.4), "efficientnet-b5": (1.6, 2.2, 456, 0.4),
+    "efficientnet-b6": (1.8, 2.6, 528, 0.5), "efficientnet-b7": (2.0, 3.1, 600, 0.5),
+}
+# (repeats, kernel, stride, expand, in, out) of the B0 baseline; SE ratio 0.25 everywhere
+_BASE_BLOCKS = [(1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
+                (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320)]
+# smp encoder registry: stage boundaries (block indices) and feature channels
+_SMP_STAGES = {
+    "efficientnet-b0": ((3, 5, 9, 16), (3, 32, 24, 40, 112, 320)), "efficientnet-b1": ((5, 8, 16, 23), (3, 32, 24, 40, 112, 320)),
+    "efficientnet-b2": ((5, 8, 16, 23), (3, 32, 24, 48, 120, 352)), "efficientnet-b3": ((5, 8, 18, 26), (3, 40, 32, 48, 136, 384)),
+    "efficientnet-b4": ((6, 10, 22, 32), (3, 48, 32, 56, 160, 448)), "efficientnet-b5": ((8, 13, 27, 39), (3, 48, 40, 64, 176, 512)),
+    "efficientnet-b6": ((9, 15, 31, 45), (3, 56, 40, 72, 200, 576)), "efficientnet-b7": ((11, 18, 38, 55), (3, 64, 48, 80, 224, 640)),
+}
+BN_MOM, BN_EPS = 0.01, 1e-3
+DROP_CONNECT = 0.2
+
+
+def _round_filters(f, width, divisor=8):
+    f *= width
+    new = max(divisor, int(f + divisor / 2) // divisor * divisor)
+    if new < 0.9 * f:
+        new += divisor
+    return int(new)
+
+
+def _round_repeats(r, depth):
+    return int(math.ceil(depth * r))
+
+
+class SamePadConv2d(nn.Conv2d):
+    """Conv2d with TensorFlow "same" padding fixed at construction for a nominal input size (the padding is a
+    parameter-free ``static_padding`` sub-module, so state_dict keys are just weight/bias)."""
+
+    def __init__(self, in_ch, out_ch, kernel_size, image_size, stride=1, groups=1, bias=True):
+        super().__init__(in_ch, out_ch, kernel_size, stride=stride, groups=groups, bias=bias)
+        ih = iw = image_size
+        kh, kw = self.weight.shape[-2:]
+        sh, sw = self.stride
+        oh, ow = math.ceil(ih / sh), math.ceil(iw / sw)
+        pad_h = max((oh - 1) * sh + (kh - 1) + 1 - ih, 0)
+        pad_w = max((ow - 1) * sw + (kw - 1) + 1 - iw, 0)
+        if pad_h > 0 or pad_w > 0:
+            self.static_padding = nn.ZeroPad2d((pad_w // 2, pad_w - pad_w // 2, pad_h // 2, pad_h - pad_h // 2))
+        else:
+            self.static_padding = nn.Identity()
+
+    def forward(self, x):
+        return F.conv2d(self.static_padding(x), self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)
+
+
+def _drop_connect(x, p, training):
+    if not training or p <= 0:
+        return x
+    keep = 1.0 - p
+    mask = torch.floor(keep + torch.rand([x.shape[0], 1, 1, 1], dtype=x.dtype, device=x.device))
+    return x / keep * mask
+
+
+class MBConvBlock(nn.Module):
+    def __init__(self, inp, out, kernel, stride, expand, image_size, se_ratio=0.25):
+        super().__init__()
+        self.inp, self.out, self.stride, self.expand = inp, out, stride, expand
+        mid = inp * expand
+        if expand != 1:
+            self._expand_conv = SamePadConv2d(inp, mid, 1, image_size, bias=False)
+            self._bn0 = nn.BatchNorm2d(mid, momentum=BN_MOM, eps=BN_EPS)
+        self._depthwise_conv = SamePadConv2d(mid, mid, kernel, image_size, stride=stride, groups=mid, bias=False)
+        self._bn1 = nn.BatchNorm2d(mid, momentum=BN_MOM, eps=BN_EPS)
+        sq = max(1, int(inp * se_ratio))
+        self._se_reduce = SamePadConv2d(mid, sq, 1, 1)
+        self._se_expand = SamePadConv2d(sq, mid, 1, 1)
+        self._project_conv = SamePadConv2d(mid, out, 1, math.ceil(image_size / stride), bias=False)
+        self._bn2 = nn.BatchNorm2d(out, momentum=BN_MOM, eps=BN_EPS)
+
+    def forward(self, x, drop_connect_rate=None):
+        inputs = x
+        if self.expand != 1:
+            x = _swish(self._bn0(self._expand_conv(x)))
+        x = _swish(self._bn1(self._depthwise_conv(x)))
+        s = F.adaptive_avg_pool2d(x, 1)
+        s = self._se_expand(_swish(self._se_reduce(s)))
+        x = torch.sigmoid(s) * x
+        x = self._bn2(self._project_conv(x))
+        if self.stride == 1 and self.inp == self.out:
+            if drop_connect_rate:
+                x = _drop_connect(x, drop_connect_rate, self.training)
+            x = x + inputs
+        return x
+
+
+class EfficientNetEncoder(nn.Module):
+    """features = [x, stem, stage2, stage3, stage4, stage5] at strides (1,2,4,8,16,32); ``out_channels`` as in smp."""
+
+    def __init__(self, name="efficientnet-b4", in_channels=3, depth=5):
+        super().__init__()
+        if name not in _EFFNET_PARAMS:
+            raise NotImplementedError(f"encoder {name!r}: only the EfficientNet family used by the reference is restated "
+                                      "(train.py:143 uses 'efficientnet-b4')")
+        width, dmult, res, _ = _EFFNET_PARAMS[name]
+        self._stage_idxs, chans = _SMP_STAGES[name]
+        self._depth = depth
+        self._in_channels = in_channels
+        self.out_channels = tuple([in_channels] + list(chans[1:]))[:depth + 1]
+        size = res
+        stem = _round_filters(32, width)
+        self._conv_stem = SamePadConv2d(in_channels, stem, 3, size, stride=2, bias=False)
+        self._bn0 = nn.BatchNorm2d(stem, momentum=BN_MOM, eps=BN_EPS)
+        size = math.ceil(size / 2)
+        blocks = []
+        for (rep, k, s, e, i, o) in _BASE_BLOCKS:
+            i, o, rep = _round_filters(i, width), _round_filters(o, width), _round_repeats(rep, dmult)
+            blocks.append(MBConvBlock(i, o, k, s, e, size))
+            size = math.ceil(size / s)
+            for _ in range(rep - 1):
+                blocks.append(MBConvBlock(o, o, k, 1, e, size))
+        self._blocks = nn.ModuleList(blocks)
+        head = _round_filters(1280, width)
+        self._conv_head = SamePadConv2d(blocks[-1].out, head, 1, size, bias=False)   # present but unused (as in smp)
+        self._bn1 = nn.BatchNorm2d(head, momentum=BN_MOM, eps=BN_EPS)
+
+    def forward(self, x):
+        feats = [x]
+        x = _swish(self._bn0(self._conv_stem(x)))
+        feats.append(x)
+        n = len(self._blocks)
+        bounds = list(self._stage_idxs[:3]) + [n]
+        for idx, blk in enumerate(self._blocks):
+            x = blk(x, DROP_CONNECT * idx / n)
+            if idx + 1 in bounds:
+                feats.append(x)
+        return feats[:self._depth + 1]
+
+
+def get_encoder(name, in_channels=3, depth=5, weights=None, **kwargs):
+    """smp.encoders.get_encoder stand-in.  ``weights='imagenet'`` would download a checkpoint upstream; there is no
+    network here, so the kwarg is accepted and the encoder stays randomly initialised unless SRBH_ENCODER_WEIGHTS
+    points at a local efficientnet_pytorch state_dict (then smp's first-conv patch w[:, i] = w[:, i % 3] * 3/in_ch is
+    applied for in_channels != 3)."""
+    import os
+    enc = EfficientNetEncoder(name, in_channels=in_channels, depth=depth)
+    path = os.environ.get("SRBH_ENCODER_WEIGHTS")
+    if weights is not None and path and os.path.isfile(path):
+        sd = torch.load(path, map_location="cpu")
+        sd = {k: v for k, v in sd.items() if not k.startswith("_fc.")}
+        w = sd["_conv_stem.weight"]
+        if in_channels != w.shape[1]:
+            new = torch.empty(w.shape[0], in_channels, *w.shape[2:])
+            for i in range(in_channels):
+                new[:, i] = w[:, i % w.shape[1]]
+            sd["_conv_stem.weight"] = new * (w.shape[1] / in_channels)
+        enc.load_state_dict(sd, strict=True)
+    return enc
+
+
+class _ConvBnRelu(nn.Sequential):
+    def __init__(self, cin, cout, use_batchnorm=True):
+        mods = [nn.Conv2d(cin, cout, 3, padding=1, bias=not use_batchnorm)]
+        if use_batchnorm:
+            mods.append(nn.BatchNorm2d(cout))
+        mods.append(nn.ReLU(inplace=True))
+        super().__init__(*mods)
+
+
+class _Attention(nn.Module):
+    def __init__(self, name):
+        super().__init__()
+        if name is not None:
+            raise NotImplementedError("only attention_type=None is used by the reference (mymodels.py:251,258)")
+        self.attention = nn.Identity()
+
+    def forward(self, x):
+        return self.attention(x)
+
+
+class DecoderBlock(nn.Module):
+    def __init__(self, in_channels, skip_channels, out_channels, use_batchnorm=True, attention_type=None):
+        super().__init__()
+        self.conv1 = _ConvBnRelu(in_channels + skip_channels, out_channels, use_batchnorm)
+        self.attention1 = _Attention(attention_type)
+        self.conv2 = _ConvBnRelu(out_channels, out_channels, use_batchnorm)
+        self.attention2 = _Attention(attention_type)
+
+    def forward(self, x, skip=None):
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        if skip is not None:
+            x = self.attention1(torch.cat([x, skip], dim=1))
+        return self.attention2(self.conv2(self.conv1(x)))
+
+
+class UnetDecoder(nn.Module):
+    def __init__(self, encoder_channels, decoder_channels, n_blocks=5, use_batchnorm=True, attention_type=None,
+                 center=False):
+        super().__init__()
+        if n_blocks != len(decoder_channels):
+            raise ValueError(f"Model depth is {n_blocks}, but you provide `decoder_channels` for "
+                             f"{len(decoder_channels)} blocks.")
+        if center:
+            raise NotImplementedError("center block is only used with VGG encoders (mymodels.py:250)")
+        enc = list(encoder_channels[1:])[::-1]
+        ins = [enc[0]] + list(decoder_channels[:-1])
+        skips = enc[1:] + [0]
+        self.center = nn.Identity()
+        self.blocks = nn.ModuleList(DecoderBlock(i, s, o, use_batchnorm, attention_type)
+                                    for i, s, o in zip(ins, skips, decoder_channels))
+
+    def forward(self, *features):
+        feats = features[1:][::-1]
+        x = self.center(feats[0])
+        skips = feats[1:]
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, skips[i] if i < len(skips) else None)
+        return x

@@ -1,0 +1,79 @@
+"""``SRRegress_Cls_feature`` -- the height / building-hierarchy model that train.py:143-148 and
+predict_realesanet_feature_globe.py:90-93 instantiate (reference mymodels.py:233-337), on MI355X.
+
+Same constructor kwargs, ``forward`` / ``forward_unsup`` / ``forward_nobuild`` signatures, returned tuples (no
+squeeze, callers squeeze: train.py:248-249) and state_dict prefixes (``encoder.``, ``decoder1.``, ``decoder2.``,
+``reg.``, ``seg.``, ``hrfeat.``, ``aggre_height.``).  The 256x256 part -- ``hrfeat`` (HRfeature) and ``reg`` / ``seg``
+(HRfuse_residual) -- and ``aggre_height`` run on libsrbh kernels with hand-written backward; the < 1 GFLOP/tile
+EfficientNet-B4 encoder and the two U-Net decoders use stock PyTorch-ROCm ops.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import hrfuse as H
+from .encoders import UnetDecoder, get_encoder
+from .hrfuse import HRfeature, HRfuse_residual
+
+__all__ = ["SRRegress_Cls_feature"]
+
+
+class SRRegress_Cls_feature(torch.nn.Module):
+    def __init__(self, encoder_name="resnet50", encoder_weights="imagenet", encoder_depth=5, in_channels=7, classes=1,
+                 super_in=4, super_mid=64, upscale=4, isaggre=False, chans_build=2, uniform_range=0.3, isunsup=False):
+        super().__init__()
+        # classes / uniform_range / isunsup are accepted and ignored, as upstream (mymodels.py:234-268)
+        self.encoder = get_encoder(encoder_name, in_channels=in_channels, depth=encoder_depth, weights=encoder_weights)
+        dec_in = (256, 128, 64, 32, 16)
+        center = encoder_name.startswith("vgg")
+        self.decoder1 = UnetDecoder(encoder_channels=self.encoder.out_channels, decoder_channels=dec_in,
+                                    n_blocks=encoder_depth, use_batchnorm=True, center=center, attention_type=None)
+        self.decoder2 = UnetDecoder(encoder_channels=self.encoder.out_channels, decoder_channels=dec_in,
+                                    n_blocks=encoder_depth, use_batchnorm=True, center=center, attention_type=None)
+        self.reg = HRfuse_residual(hr_chans=super_mid, lr_chans=dec_in[-1], mid_chans=dec_in[-1], out_chans=1,
+                                   upscale=upscale)
+        self.seg = HRfuse_residual(hr_chans=super_mid, lr_chans=dec_in[-1], mid_chans=dec_in[-1], out_chans=chans_build,
+                                   upscale=upscale)
+        self.hrfeat = HRfeature(in_chans=super_in, mid_chans=super_mid, out_chans=super_mid)
+        self.isaggre = isaggre
+        if self.isaggre:
+            self.aggre_height = nn.Conv2d(super_mid, 1, 3, 1, 1)
+            self._plast = H._PackedConv()
+
+    def _aggre(self, height_fea):
+        return H._LastConv.run(self, self.aggre_height, height_fea)
+
+    def forward(self, x, super_fea):
+        """x: (B,in_channels,64,64) Sentinel-2+1 tile; super_fea: (B,super_in,256,256) RRDBNet.forward_feature output.
+        Order of ops as upstream (mymodels.py:270-293)."""
+        encode_fea = self.encoder(x)
+        super_fea = self.hrfeat(super_fea)
+        height_fea = self.decoder1(*encode_fea)
+        if self.isaggre:
+            height_aggre = self._aggre(height_fea)
+        height = self.reg(height_fea, super_fea)
+        build = self.decoder2(*encode_fea)
+        build = self.seg(build, super_fea)
+        if self.isaggre:
+            return height, build, height_aggre
+        return height, build
+
+    def forward_unsup(self, x, super_fea):
+        """mymodels.py:295-313: height only, squeezed."""
+        encode_fea = self.encoder(x)
+        super_fea = self.hrfeat(super_fea)
+        height_fea = self.decoder1(*encode_fea)
+        return self.reg(height_fea, super_fea).squeeze()
+
+    def forward_nobuild(self, x, super_fea):
+        """mymodels.py:315-337: skips decoder2 / seg."""
+        encode_fea = self.encoder(x)
+        super_fea = self.hrfeat(super_fea)
+        height_fea = self.decoder1(*encode_fea)
+        if self.isaggre:
+            height_aggre = self._aggre(height_fea)
+        height = self.reg(height_fea, super_fea)
+        if self.isaggre:
+            return height, height_aggre
+        return height

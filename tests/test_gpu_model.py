@@ -1,0 +1,101 @@
+"""GPU: the whole height model (stock-op encoder/decoders + libsrbh head) and one training step of the harness."""
+import copy
+
+import pytest
+import torch
+
+from oracle import srbh_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_model(seed=0, isaggre=True):
+    from srbh_amd.models import SRRegress_Cls_feature
+    torch.manual_seed(seed)
+    m = SRRegress_Cls_feature("efficientnet-b4", in_channels=8, super_in=64, super_mid=16, upscale=4, isaggre=isaggre,
+                              chans_build=7)
+    # non-trivial BN statistics everywhere so eval mode is a real test
+    g = torch.Generator()
+    g.manual_seed(seed + 1)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_((torch.rand(mod.num_features, generator=g) - 0.5) * 0.2)
+            mod.running_var.copy_(0.5 + torch.rand(mod.num_features, generator=g))
+    return m
+
+
+def cpu_reference(m_cpu, x, fea, training):
+    """stock-op encoder/decoders on CPU + the oracle's functional head on the same state_dict (autograd-capable)."""
+    sd = {k: v for k, v in m_cpu.state_dict(keep_vars=True).items()}
+    feats = m_cpu.encoder(x)
+    sup = O.hrfeature(sd, "hrfeat.", fea, training)
+    hfea = m_cpu.decoder1(*feats)
+    aggre = torch.nn.functional.conv2d(hfea, sd["aggre_height.weight"], sd["aggre_height.bias"], 1, 1)
+    height = O.hrfuse_residual(sd, "reg.", hfea, sup, training)
+    build = O.hrfuse_residual(sd, "seg.", m_cpu.decoder2(*feats), sup, training)
+    return height, build, aggre
+
+
+def test_model_eval_forward_matches_cpu():
+    m = make_model().eval()
+    x = synth.tiles(2, 8, 64, seed=3)
+    fea = torch.randn(2, 64, 256, 256, generator=torch.Generator().manual_seed(4)) * 0.5
+    with torch.no_grad():
+        want = cpu_reference(copy.deepcopy(m), x, fea, False)
+        got = m.to(DEV)(x.to(DEV), fea.to(DEV))
+    assert got[0].shape == (2, 1, 256, 256) and got[1].shape == (2, 7, 256, 256) and got[2].shape == (2, 1, 64, 64)
+    for a, b, name in zip(got, want, ("height", "build", "aggre")):
+        assert O.rel_l2(a.cpu(), b) <= 2e-4, name
+    p = make_model(isaggre=False).eval().to(DEV)
+    with torch.no_grad():
+        out = p(x.to(DEV), fea.to(DEV))
+        assert len(out) == 2
+        assert p.forward_unsup(x.to(DEV), fea.to(DEV)).shape == (2, 256, 256)
+        assert p.forward_nobuild(x.to(DEV), fea.to(DEV)).shape == (2, 1, 256, 256)
+
+
+def test_model_train_step_gradients_match_cpu_autograd(monkeypatch):
+    from srbh_amd import encoders
+    monkeypatch.setattr(encoders, "DROP_CONNECT", 0.0)          # the only RNG in the model
+    m = make_model(seed=5).train()
+    mc = copy.deepcopy(m)
+    x = synth.tiles(2, 8, 64, seed=6)
+    fea = torch.randn(2, 64, 256, 256, generator=torch.Generator().manual_seed(7)) * 0.5
+    w = [torch.randn(2, 1, 256, 256), torch.randn(2, 7, 256, 256), torch.randn(2, 1, 64, 64)]
+    outs = cpu_reference(mc, x, fea, True)
+    sum((o * ww).sum() for o, ww in zip(outs, w)).backward()
+    m = m.to(DEV)
+    got = m(x.to(DEV), fea.to(DEV))
+    sum((o * ww.to(DEV)).sum() for o, ww in zip(got, w)).backward()
+    for a, b in zip(got, outs):
+        assert O.rel_l2(a.detach().cpu(), b.detach()) <= 2e-4
+    cpu_grads = dict(mc.named_parameters())
+    checked = 0
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            assert cpu_grads[k].grad is None, k
+            continue
+        e = O.rel_l2(p.grad.cpu(), cpu_grads[k].grad)
+        assert e <= 5e-3, (k, e)
+        checked += 1
+    assert checked > 600
+    assert m.encoder._conv_head.weight.grad is None               # unused parameter, as upstream
+    # BN running statistics moved identically
+    for (k, a), (_, b) in zip(m.named_buffers(), mc.named_buffers()):
+        if "running" in k and k.split(".")[0] in ("hrfeat", "reg", "seg"):
+            assert torch.allclose(a.cpu(), b, rtol=1e-4, atol=1e-5), k
+
+
+def test_train_harness_step_reduces_loss():
+    from srbh_amd.harness import TrainStep, synthetic_batch
+    from srbh_amd.rrdbnet import RRDBNet
+    net_hr = RRDBNet(3, 3, num_block=2)
+    net_hr.load_state_dict(synth.rrdbnet_state_dict(num_block=2, seed=2, mode="stress"))
+    ts = TrainStep(net_hr.to(DEV), make_model(seed=9).to(DEV), DEV)
+    batch = synthetic_batch(4, 11, DEV)
+    assert batch[0].shape == (4, 8, 64, 64) and batch[1].shape == (4, 256, 256) and batch[2].shape == (4, 64, 64)
+    assert batch[3].dtype == torch.long and int(batch[3].max()) <= 6
+    losses = [float(ts(batch)[0]) for _ in range(6)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
