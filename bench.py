@@ -200,6 +200,12 @@ def main():
         achieved = GFLOP_PER_TILE_FEATURE * (args.num_block * 5.8886 + 11.19) / 146.630 if args.num_block != 23 \
             else GFLOP_PER_TILE_FEATURE
         tflops = achieved * B / step_s_events / 1e3
+        traffic = None   # HBM bytes per launch sequence from the PMC passes recorded under profiles/ (same command, B=32)
+        try:
+            if B == 32 and args.num_block == 23:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["per_forward_B32"]["total_bytes"]
+        except Exception:
+            pass
         line = {
             "metric": "tiles/sec (64x64x8ch->256x256 height)", "value": round(tiles / elapsed, 2), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -210,7 +216,7 @@ def main():
                                    "64x64x3 -> 64x256x256 (BASELINE.json configs[1])",
                        "global_batch": B * world, "parallelism": f"tile-sharded x{world} (no data-path collective)"},
             "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tflops / PEAK_F16_TFLOPS, 4), "traffic": None,
+                         "frac": round(tflops / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                          "kernel": "conv3x3_f16_kernel (all 349 MFMA conv launches of one forward_feature; "
                                    "HIP-event time of the whole launch sequence / steps)",
                          "ms_per_launch_sequence": round(step_s_events * 1e3, 4)},
