@@ -188,6 +188,7 @@ def main():
     elapsed = time.perf_counter() - t0
     gpu_ms = ev0.elapsed_time(ev1)
     assert bool(torch.isfinite(y[0, :, ::16, ::16]).all())
+    net.check_status()   # persistent-kernel error word (outside the timed region)
 
     if dist is not None:
         t = torch.tensor([elapsed, gpu_ms], dtype=torch.float64, device=dev)

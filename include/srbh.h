@@ -128,6 +128,11 @@ int srbh_rrdbnet_forward(const srbh_rrdbnet_desc* d, const float* x, float* out,
                          int want_forward, void* ws, size_t ws_bytes, void* stream);
 
 
+/* Synchronises `stream` and returns 0 if the last srbh_rrdbnet_forward on this workspace completed normally, or a
+ * negative code if the persistent trunk kernel gave up waiting for a neighbour workgroup (its spins are bounded so a
+ * scheduling problem shows up as an error here instead of a hung GPU).  Set SRBH_PERSISTENT=0 to force per-layer launches. */
+int srbh_rrdbnet_last_status(const void* ws, int B, int H, int W, int want_forward, void* stream);
+
 /* ==== head: HR feature / fusion / regression modules (SR/HRfuse.py), fp32 ==========================
  * Tensors are NHWC fp32 ([B][H][W][C]; a torch channels_last (B,C,H,W) tensor has exactly this memory).
  * HWPACK32: fp32 weights in v_mfma_f32_16x16x4_f32 A-fragment order [Cin/16][tap][4][Cout/16][lane 64]. */

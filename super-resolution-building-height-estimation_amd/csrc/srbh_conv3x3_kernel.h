@@ -71,10 +71,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 }
 
 // ABL (bench-only ablations, 0 in the library): 1 = no MFMA/ds_read, 2 = no LDS-DMA after the first chunk,
-// 3 = no epilogue stores, 4 = MFMA only (no ds_read)
-template <int CB, int UPS, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const KParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// 3 = no epilogue stores, 4 = MFMA only (no ds_read), 9 = s_memtime stamps.
+// PERSIST = 1 (persistent trunk kernel): activations are read with sc1 LDS-DMA (L1 bypass) and written with
+// write-through (sc1) stores so that a neighbouring workgroup can consume them inside the same launch.
+template <int CB, int UPS, int ABL, int PERSIST>
+__device__ __forceinline__ void conv_tile(const KParams& p, char* smem, const int img, const int Y0, const int X0,
+                                          unsigned long long* tstamp) {
     using G = TileGeo<UPS>;
     constexpr int W_B = 18 * 1024 * CB;  // weight bytes per input chunk
     constexpr int STAGE_B = G::IN_B + W_B;
@@ -84,14 +86,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const KParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
-
-    unsigned long long tstamp[8];
-    if (ABL == 9) tstamp[0] = __builtin_amdgcn_s_memtime();
-    const int t = xcd_remap(blockIdx.x, p.nblocks);
-    const int img = t / p.tiles_per_img;
-    const int trem = t - img * p.tiles_per_img;
-    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
-    const int Y0 = ty * TILE_H, X0 = tx * TILE_W;
 
     // ---- staging set-up: unit u of the LDS tile <- 16 bytes of the padded source plane
     const char* src0 = p.in + (long)img * p.in_img_b + (long)(UPS ? (Y0 >> 1) : Y0) * p.in_row_b +
@@ -122,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const KParams p) {
             const int j = part * JPP + jj;
             if (j < G::NJ)
                 __builtin_amdgcn_global_load_lds(GPTR(s + goff[j < G::NJ ? j : 0]),
-                                                 LPTR(dst + (j * 256 + wave * 64) * 16), 16, 0, 0);
+                                                 LPTR(dst + (j * 256 + wave * 64) * 16), 16, 0, PERSIST ? 16 : 0);
         }
         const char* ws = wsrc + (long)chunk * W_B;
         char* wdst = dst + G::IN_B;
@@ -335,7 +329,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const KParams p) {
                         }
                         char* o = p.out16 + (long)img * p.out16_img_b + (long)(c8 >> 2) * p.out16_plane_b +
                                   (long)(Y + 1) * p.out16_row_b + (X + 1) * PIX_B + (c8 & 3) * 16;
-                        *(half8*)o = hv;
+                        if (PERSIST) {
+                            floatx4 raw = __builtin_bit_cast(floatx4, hv);
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
+                        } else {
+                            *(half8*)o = hv;
+                        }
                     }
                     if (p.out32) {
                         float* o = p.out32 + pix * p.out32_c + c8 * 8;
@@ -354,9 +353,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const KParams p) {
             }
         }
     }
+}
+
+template <int CB, int UPS, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long tstamp[8];
+    if (ABL == 9) tstamp[0] = __builtin_amdgcn_s_memtime();
+    const int t = xcd_remap(blockIdx.x, p.nblocks);
+    const int img = t / p.tiles_per_img;
+    const int trem = t - img * p.tiles_per_img;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    conv_tile<CB, UPS, ABL, 0>(p, smem, img, ty * TILE_H, tx * TILE_W, tstamp);
     if (ABL == 9 && p.prof) {
         tstamp[5] = __builtin_amdgcn_s_memtime();
-        if (tid == 0)
+        if (threadIdx.x == 0)
             for (int k = 0; k < 8; ++k) p.prof[blockIdx.x * 8 + k] = tstamp[k];
     }
 }

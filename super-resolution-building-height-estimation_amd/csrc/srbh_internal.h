@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <vector>
 #include "srbh.h"
 
 namespace srbh {
@@ -47,5 +48,12 @@ inline Act16Geo act16_geo(int B, int chunks, int H, int W) {
     g.total_b = (g.total_b + 255) & ~(size_t)255;
     return g;
 }
+
+
+// persistent trunk (srbh_ptrunk.hip)
+size_t ptrunk_aux_bytes(int B, int tiles_per_img);
+size_t ptrunk_err_offset(int B, int tiles_per_img);
+int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr, float* xrr, int B, int H, int W,
+               void* aux, hipStream_t stream, int* used, int* final_cur);
 
 }  // namespace srbh

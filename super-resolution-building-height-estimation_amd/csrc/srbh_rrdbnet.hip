@@ -5,6 +5,7 @@
 // [x | x1 | x2 | x3 | x4] (SR/rrdbnet_arch.py:137-141); conv_k reads planes 0..k and writes plane k+1;
 // conv5 writes the next block's x into planes 0..1 of the other (ping-pong) buffer.  The fp32
 // residual streams (x5*0.2+x at :143, out*0.2+x at :167, feat+body_feat at :234) live in three RES32 buffers.
+#include <stdlib.h>
 #include "srbh_internal.h"
 
 using namespace srbh;
@@ -12,7 +13,7 @@ using namespace srbh;
 namespace {
 
 struct WsLayout {
-    size_t d0, d1, feat, xr, xrr, u2, u3, u4, total;
+    size_t d0, d1, feat, xr, xrr, u2, u3, u4, aux, total;
     size_t dense_b;
 };
 
@@ -32,6 +33,8 @@ WsLayout ws_layout(int B, int H, int W, int want_forward) {
     L.u3 = off; off = align256(off + act16_geo(B, 2, 4 * H, 4 * W).total_b);
     L.u4 = off;
     if (want_forward) off = align256(off + act16_geo(B, 2, 4 * H, 4 * W).total_b);
+    L.aux = off;   // persistent-trunk layer table, progress counters, error word
+    off = align256(off + ptrunk_aux_bytes(B, (H + TILE_H - 1) / TILE_H));
     L.total = off;
     return L;
 }
@@ -68,7 +71,16 @@ extern "C" int srbh_rrdbnet_forward(const srbh_rrdbnet_desc* d, const float* x, 
 
     srbh_conv3x3_args a;
     int cur = 0;
-    for (int blk = 0; blk < d->num_block; ++blk) {
+    int used_persistent = 0;
+    {
+        const char* env = getenv("SRBH_PERSISTENT");
+        const bool want = !(env && env[0] == '0');
+        if (want) {
+            rc = ptrunk_run(d, D[0], D[1], xr, xrr, B, H, W, base + L.aux, (hipStream_t)stream, &used_persistent, &cur);
+            if (rc) return rc;
+        }
+    }
+    for (int blk = 0; !used_persistent && blk < d->num_block; ++blk) {
         for (int r = 0; r < 3; ++r) {
             const srbh_conv_w* cw = d->rdb + (blk * 3 + r) * 5;
             for (int k = 0; k < 4; ++k) {  // conv1..conv4: lrelu(conv(cat(x, x1..xk)))
@@ -130,4 +142,16 @@ extern "C" int srbh_rrdbnet_forward(const srbh_rrdbnet_desc* d, const float* x, 
     a.B = B; a.H = 4 * H; a.W = 4 * W;
     a.out32 = out; a.out32_c = d->num_out_ch;
     return srbh_conv3x3_f16(&a, stream);
+}
+
+extern "C" int srbh_rrdbnet_last_status(const void* ws, int B, int H, int W, int want_forward, void* stream) {
+    SRBH_REQUIRE(ws && B > 0 && H > 0 && W > 0, "srbh_rrdbnet_last_status: bad arguments");
+    const WsLayout L = ws_layout(B, H, W, want_forward);
+    const int tpi = (H + TILE_H - 1) / TILE_H;
+    SRBH_HIP(hipStreamSynchronize((hipStream_t)stream));
+    int err = 0;
+    const size_t eoff = ptrunk_err_offset(B, tpi);
+    SRBH_HIP(hipMemcpy(&err, (const char*)ws + L.aux + eoff, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) set_error("persistent trunk kernel timed out waiting for a neighbour workgroup (err=%d)", err);
+    return err ? -3 : SRBH_OK;
 }

@@ -228,6 +228,14 @@ class RRDBNet(nn.Module):
                                               ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "rrdbnet_forward")
         return out
 
+    def check_status(self):
+        """Synchronise and raise if the last forward's persistent trunk kernel reported a timeout (tests / smoke / bench
+        call this outside timed regions; the kernels themselves never hang: every spin is bounded)."""
+        L = _lib.lib()
+        for (B, H, W, wf, dev), ws in self._workspaces.items():
+            with torch.cuda.device(dev):
+                _lib.check(L.srbh_rrdbnet_last_status(ws.data_ptr(), B, H, W, wf, _lib.stream_ptr()), "rrdbnet_last_status")
+
     def forward(self, x):
         """reference SR/rrdbnet_arch.py:208-223 -> (B,num_out_ch,4H,4W), channels_last strides."""
         return self._run(x, True)

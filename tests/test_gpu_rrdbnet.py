@@ -35,6 +35,7 @@ def test_small_net_forward_and_feature(scale, hw, B, golden_dir):
     with torch.no_grad():
         ff = net.forward_feature(x.to(DEV))
         fw = net(x.to(DEV))
+    net.check_status()
     s = 4 * hw // {4: 1, 2: 2, 1: 4}[scale]
     assert ff.shape == (B, 64, s, s) and fw.shape == (B, 3, s, s)
     assert O.rel_l2(ff.cpu(), O.rrdbnet_forward_feature(sd, x, scale)) <= REL_TOL
@@ -54,6 +55,7 @@ def test_full_net_config1_against_reference_fixture(mode, golden_dir):
     x = synth.tiles(1, 8, 64, seed=1337)[:, :3].contiguous()
     with torch.no_grad():
         y = net.forward_feature(x.to(DEV)).cpu()
+    net.check_status()
     assert y.shape == (1, 64, 256, 256)
     for name, (r, c) in {"tl": (0, 0), "tr": (0, 248), "bl": (248, 0), "br": (248, 248), "ce": (124, 124)}.items():
         assert O.rel_l2(y[0, :, r:r + 8, c:c + 8], g["crop_" + name]) <= REL_TOL, name
@@ -77,6 +79,7 @@ def test_batch_independence_and_determinism():
         y2 = net.forward_feature(x)
         y_single = net.forward_feature(x[3:4])
         y_perm = net.forward_feature(x.flip(0))
+    net.check_status()
     assert torch.equal(y, y2)
     assert torch.equal(y[3:4], y_single)
     assert torch.equal(y_perm.flip(0), y)
@@ -109,3 +112,20 @@ def test_full_size_batch32_properties():
         assert y.shape == (32, 64, 256, 256) and bool(torch.isfinite(y).all())
         for i in (0, 17, 31):
             assert torch.equal(net.forward_feature(x[i:i + 1]), y[i:i + 1])
+    net.check_status()
+
+
+def test_persistent_and_per_layer_paths_agree(monkeypatch):
+    """the persistent trunk kernel (default) and the per-layer launch sequence (SRBH_PERSISTENT=0) are the same
+    arithmetic in the same order: bit-identical outputs, incl. a batch that needs several persistent sub-launches."""
+    sd = synth.rrdbnet_state_dict(num_block=3, seed=21, mode="stress")
+    net = build(sd, num_block=3)
+    for B, hw in ((3, 64), (40, 64), (2, 40)):
+        x = synth.tiles(B, 3, hw, seed=22).to(DEV)
+        with torch.no_grad():
+            monkeypatch.setenv("SRBH_PERSISTENT", "1")
+            y1 = net.forward_feature(x)
+            net.check_status()
+            monkeypatch.setenv("SRBH_PERSISTENT", "0")
+            y0 = net.forward_feature(x)
+        assert torch.equal(y0, y1), (B, hw)
