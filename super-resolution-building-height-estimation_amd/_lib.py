@@ -18,7 +18,12 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libsrbh.so")
 SOURCES = ["srbh_conv3x3.hip", "srbh_aux.hip", "srbh_rrdbnet.hip", "srbh_ptrunk.hip", "srbh_head.hip", "srbh_head_bwd.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# NOTE: `-mllvm -amdgpu-mfma-vgpr-form=1` removes the AGPR<->VGPR accumulator copies hipcc emits at every K-loop
+# back-edge (~20 % of the loop), but the persistent trunk kernel then produced non-deterministic garbage on MI355X
+# (ROCm 7.2); until that is understood the flag stays off.
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+if os.environ.get("SRBH_HIPFLAGS_OVERRIDE"):      # developer bisecting only
+    HIPFLAGS = os.environ["SRBH_HIPFLAGS_OVERRIDE"].split()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

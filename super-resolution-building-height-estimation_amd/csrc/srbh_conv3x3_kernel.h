@@ -176,15 +176,15 @@ __device__ __forceinline__ void conv_tile(const KParams& p, char* smem, const in
 
     constexpr int NREAD = G::NP + 3 * CB;   // ds_read_b128 per group
     constexpr int NMFMA = 12 * CB;          // MFMAs per group
-    constexpr int NDMA = JPP + WPP;         // LDS-DMA per pipeline part (upper bound)
-    auto chunk_body = [&](auto more_tag, int c) {
-        constexpr bool MORE = decltype(more_tag)::value;
+    // ONE code path for every chunk: per-variant copies of this body made the compiler shuffle all accumulators at the
+    // join.  The LDS-DMA slices of chunk c+1 sit behind a wave-uniform branch at the head of each MFMA group.
+    auto chunk_body = [&](const bool more, int c) {
         const char* sb = smem + (c & 1) * STAGE_B;
         load_group(sb, 0, 0);
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
+            if (more && ABL != 2) stage_part(c + 1, (c + 1) & 1, g);
             if (g + 1 < 6) load_group(sb, g + 1, (g + 1) & 1);   // next group's LDS reads fly under this group's MFMAs
-            if (MORE && ABL != 2) stage_part(c + 1, (c + 1) & 1, g);
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
@@ -196,7 +196,7 @@ __device__ __forceinline__ void conv_tile(const KParams& p, char* smem, const in
                 }
             }
 #if SRBH_SCHED_HINTS
-            // pin the interleave: one ds_read behind each of the first NREAD MFMAs, then the LDS-DMA, then the rest
+            // pin the interleave: one ds_read behind each of the first NREAD MFMAs, then the rest
             if (g == 0) __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
             if (g + 1 < 6) {
 #pragma unroll
@@ -204,10 +204,8 @@ __device__ __forceinline__ void conv_tile(const KParams& p, char* smem, const in
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                if (MORE && ABL != 2) __builtin_amdgcn_sched_group_barrier(0x020, NDMA, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NREAD, 0);
             } else {
-                if (MORE && ABL != 2) __builtin_amdgcn_sched_group_barrier(0x020, NDMA, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
             }
 #endif
@@ -225,10 +223,7 @@ __device__ __forceinline__ void conv_tile(const KParams& p, char* smem, const in
                 for (int part = 0; part < 6; ++part) stage_part(c + 1, (c + 1) & 1, part);
             continue;
         }
-        if (c + 1 < p.nchunk)
-            chunk_body(std::true_type{}, c);
-        else
-            chunk_body(std::false_type{}, c);
+        chunk_body(c + 1 < p.nchunk, c);
     }
 
     if (ABL == 9) tstamp[4] = __builtin_amdgcn_s_memtime();

@@ -16,6 +16,10 @@
 // sets an error word and drains instead of hanging.
 #include "srbh_conv3x3_kernel.h"
 
+#ifndef PT_EPI_BARRIER
+#define PT_EPI_BARRIER 0
+#endif
+
 namespace {
 using namespace srbh;
 using namespace srbh_k;
@@ -37,84 +41,364 @@ struct PParams {
     int H, W, tiles_per_img, nblocks;
     int* prog;
     int* err;
+    unsigned long long* prof;   // debug (tools/convbench): [block][layer][4] s_memtime stamps, nullptr in production
 };
 
 constexpr unsigned SPIN_LIMIT = 4u << 20;
+using G = TileGeo<0>;
+constexpr int P_STAGE_B = G::IN_B + 36 * 1024;      // one pipeline stage: input tile + weight chunk sized for cout 64
+constexpr int JPP = (G::NJ + 5) / 6;
+static_assert(2 * P_STAGE_B <= 163840, "two stages must fit the 160 KiB LDS");
+
+// PLayer.flags bit 3 is set by the host when the layer's FIRST input chunk is produced by the previous layer
+// (conv1 of an RDB reads the x written by the previous conv5): it can be neither prefetched nor published lazily.
+__device__ __forceinline__ int first_new_chunk(const PLayer& l) { return (l.flags & 8) ? 0 : l.nchunk - 1; }
 
 __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
     const int t = xcd_remap(blockIdx.x, pp.nblocks);
     const int img = t / pp.tiles_per_img;
     const int ty = t - img * pp.tiles_per_img;
+    const int Y0 = ty * TILE_H;
     const int up = ty > 0 ? t - 1 : -1, dn = ty + 1 < pp.tiles_per_img ? t + 1 : -1;
-    for (int L = 0; L < pp.nlayers; ++L) {
-        const PLayer lay = pp.layers[L];
-        if (L > 0) {
-            if (threadIdx.x == 0) {
-                int bad = 0;
+
+    // ---- geometry that is identical for every layer
+    int goff[G::NJ];
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int nb = k ? dn : up;
-                    if (nb < 0) continue;
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(pp.prog + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < L) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > SPIN_LIMIT || __hip_atomic_load(pp.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                            bad = 1;
-                            break;
-                        }
+    for (int j = 0; j < G::NJ; ++j) {
+        const int u0 = j * 256 + tid;
+        const int u = u0 < G::UNITS ? u0 : 0;
+        const int trow = u / (G::COLS * 4);
+        const int rem = u - trow * (G::COLS * 4);
+        const int pc = rem >> 2, ps = rem & 3;
+        goff[j] = trow * pp.row_b + pc * PIX_B + ((ps ^ ((pc >> 2) & 3)) << 4);
+    }
+    int aoff[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int pc = wc * 32 + l31 + dx;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            aoff[dx][ks] = wr * 4 * G::ROW_B + pc * PIX_B + (((ks * 2 + hi) ^ ((pc >> 2) & 3)) << 4);
+    }
+    const int woff = G::IN_B + lane * 16;
+    const long tile_off = (long)img * pp.img_b + (long)Y0 * pp.row_b;
+
+    // ---- staging of one (layer, chunk) step into stage `buf`; NCB = cout/32 of the layer that owns the chunk
+    auto stage_part = [&](auto ncb_tag, const char* src, const char* wsrc, int buf, int part) {
+        constexpr int NCB = decltype(ncb_tag)::value;
+        constexpr int WFR = (18 * NCB + 3) / 4, WPP = (WFR + 5) / 6;
+        char* dst = smem + buf * P_STAGE_B;
+#pragma unroll
+        for (int jj = 0; jj < JPP; ++jj) {
+            const int j = part * JPP + jj;
+            if (j < G::NJ)   // activations: sc1 = bypass this CU's L1 (they were written by other CUs inside this launch)
+                __builtin_amdgcn_global_load_lds(GPTR(src + goff[j < G::NJ ? j : 0]),
+                                                 LPTR(dst + (j * 256 + wave * 64) * 16), 16, 0, 16);
+        }
+        const char* ws = wsrc + lane * 16;
+        char* wdst = dst + G::IN_B;
+#pragma unroll
+        for (int kk = 0; kk < WPP; ++kk) {
+            const int f = wave + 4 * (part * WPP + kk);
+            // cout 32: fragments 18,19 over-read 2 KiB of the following packed weights into the unused half of the
+            // 36 KiB weight area -- keeps this loop free of a wave-dependent branch
+            if (part * WPP + kk < WFR)
+                __builtin_amdgcn_global_load_lds(GPTR(ws + f * 1024), LPTR(wdst + f * 1024), 16, 0, 0);
+        }
+    };
+    auto chunk_src = [&](const PLayer& l, int c) { return pp.dense[l.in_sel] + tile_off + (long)c * pp.plane_b; };
+    auto chunk_w = [&](const PLayer& l, int c) { return l.w + (long)c * (18 * 1024 * l.cb); };
+
+    // ---- neighbour progress: thread 0 keeps the last values it loaded; a blocking (bounded) poll only if they are stale
+    int f_up = up < 0 ? 0x7fffffff : 0, f_dn = dn < 0 ? 0x7fffffff : 0;
+    int gs = 0;                  // global step counter: stage buffer = gs & 1
+    bool aborted = false;
+    auto ensure_flags = [&](int need) {
+        // that stage is free while we decide (explicit LDS address space: a generic pointer would become flat_*)
+#ifdef PT_FLAT_WORD
+        volatile int* word = (volatile int*)(smem + ((gs + 1) & 1) * P_STAGE_B);
+#else
+        auto* word = (__attribute__((address_space(3))) int*)(smem + ((gs + 1) & 1) * P_STAGE_B);
+#endif
+        if (tid == 0) {
+            int bad = 0;
+            unsigned spins = 0;
+            while (f_up < need || f_dn < need) {
+                if (up >= 0) f_up = __hip_atomic_load(pp.prog + up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dn >= 0) f_dn = __hip_atomic_load(pp.prog + dn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (f_up >= need && f_dn >= need) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > SPIN_LIMIT || __hip_atomic_load(pp.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    bad = 1;
+                    break;
+                }
+            }
+            if (bad) __hip_atomic_store(pp.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *word = bad;
+        }
+        __syncthreads();
+        const int bad = *word;
+        __syncthreads();
+        if (bad) aborted = true;
+    };
+    auto peek_flags = [&]() {   // non-blocking refresh; the values are consumed after the next barrier
+        if (tid == 0) {
+            if (up >= 0) f_up = __hip_atomic_load(pp.prog + up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (dn >= 0) f_dn = __hip_atomic_load(pp.prog + dn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+
+    bool pending_pub = false;
+    int pub_val = 0;
+
+    // ---- one layer: CB = cout/32
+    auto run_layer = [&](auto cb_tag, const int L, const PLayer& lay) {
+        constexpr int CB = decltype(cb_tag)::value;
+        constexpr int NREAD = G::NP + 3 * CB, NMFMA = 12 * CB;
+        floatx16 acc[CB][4];
+#pragma unroll
+        for (int mb = 0; mb < CB; ++mb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
+        half8 P[2][G::NP];
+        half8 A[2][3][CB];
+        auto load_group = [&](const char* sb, int g, int set) {
+            const int ks = g / 3, dx = g - ks * 3;
+#pragma unroll
+            for (int r = 0; r < G::NP; ++r) P[set][r] = *(const half8*)(sb + aoff[dx][ks] + r * G::ROW_B);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int mb = 0; mb < CB; ++mb)
+                    A[set][dy][mb] = *(const half8*)(sb + woff + ((((dy * 3 + dx) * 2 + ks) * CB + mb) << 10));
+        };
+        // One code path for every chunk (duplicating it per staging variant made the compiler shuffle all accumulators
+        // through VGPRs at the join): the LDS-DMA slices of the next step sit behind tiny wave-uniform branches at the
+        // head of each MFMA group.  next_cb = cout/32 of the layer that owns the staged step, 0 = nothing to stage.
+        auto compute = [&](const int next_cb, const char* nsrc, const char* nw) {
+            const char* sb = smem + (gs & 1) * P_STAGE_B;
+            char* dst = smem + ((gs + 1) & 1) * P_STAGE_B;
+            const char* ws = nw + lane * 16;
+            load_group(sb, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                if (next_cb) {
+#pragma unroll
+                    for (int jj = 0; jj < JPP; ++jj) {
+                        const int j = g * JPP + jj;
+                        if (j < G::NJ)
+                            __builtin_amdgcn_global_load_lds(GPTR(nsrc + goff[j < G::NJ ? j : 0]),
+                                                             LPTR(dst + (j * 256 + wave * 64) * 16), 16, 0, 16);
+                    }
+                    // weights: 20 (cout 32, incl. 2 KiB over-read into the unused half) or 36 fragments
+                    if (g < 5) {
+                        const int f = wave + 4 * g;
+                        __builtin_amdgcn_global_load_lds(GPTR(ws + f * 1024), LPTR(dst + G::IN_B + f * 1024), 16, 0, 0);
+                    }
+                    if (next_cb == 2 && g < 4) {
+                        const int f = 20 + wave + 4 * g;
+                        __builtin_amdgcn_global_load_lds(GPTR(ws + f * 1024), LPTR(dst + G::IN_B + f * 1024), 16, 0, 0);
                     }
                 }
-                if (bad) __hip_atomic_store(pp.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *(volatile int*)smem = bad;
+                if (g + 1 < 6) load_group(sb, g + 1, (g + 1) & 1);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int mb = 0; mb < CB; ++mb)
+                            acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g & 1][dy][mb], P[g & 1][i + dy], acc[mb][i], 0, 0, 0);
+                if (g == 0) __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
+                if (g + 1 < 6) {
+#pragma unroll
+                    for (int k = 0; k < NREAD; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NREAD, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
+                }
             }
-            __syncthreads();
-            const int bad = *(volatile int*)smem;
-            __syncthreads();
-            if (bad) return;   // uniform: the whole launch drains, the host sees err != 0
+        };
+
+        const int n = lay.nchunk;
+        const int fnew = first_new_chunk(lay);
+        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tw = 0, tb = 0;
+        if (pp.prof) ts0 = __builtin_amdgcn_s_memtime();
+        for (int c = 0; c < n && !aborted; ++c) {
+            unsigned long long b0 = 0;
+            if (pp.prof) b0 = __builtin_amdgcn_s_memtime();
+            __syncthreads();   // step gs landed (vmcnt(0)); every wave is past step gs-1 and past the previous epilogue
+            if (pp.prof) tb += __builtin_amdgcn_s_memtime() - b0;
+            if (pending_pub) {  // the previous layer's write-through stores are complete now -> move the counter
+                if (tid == 0) __hip_atomic_store(pp.prog + t, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pending_pub = false;
+            }
+            int next_cb = 0;
+            const char* nsrc = nullptr;
+            const char* nw = nullptr;
+            if (c + 1 < n) {
+                if (c + 1 >= fnew && L > 0) {   // the newest plane: neighbours must have finished layer L-1
+                    unsigned long long a0 = 0;
+                    if (pp.prof) a0 = __builtin_amdgcn_s_memtime();
+                    ensure_flags(L);
+                    if (pp.prof) tw += __builtin_amdgcn_s_memtime() - a0;
+                }
+                next_cb = lay.cb;
+                nsrc = chunk_src(lay, c + 1);
+                nw = chunk_w(lay, c + 1);
+            } else if (L + 1 < pp.nlayers) {
+                const PLayer& nl = pp.layers[L + 1];
+                if (!(nl.flags & 8)) {                          // its first chunk is old data: prefetch across the layer seam
+                    next_cb = nl.cb;
+                    nsrc = chunk_src(nl, 0);
+                    nw = chunk_w(nl, 0);
+                }
+            }
+            if (aborted) break;
+            peek_flags();
+            compute(next_cb, nsrc, nw);
+            ++gs;
         }
-        KParams p;
-        p.in = pp.dense[lay.in_sel];
-        p.in_img_b = pp.img_b;
-        p.in_plane_b = pp.plane_b;
-        p.in_row_b = pp.row_b;
-        p.nchunk = lay.nchunk;
-        p.w = lay.w;
-        p.bias = lay.bias;
-        p.H = pp.H;
-        p.W = pp.W;
-        p.tiles_x = 1;
-        p.tiles_per_img = pp.tiles_per_img;
-        p.nblocks = pp.nblocks;
-        p.lrelu = lay.flags & 1;
-        p.res_scale = 0.2f;
-        p.res2_scale = 0.2f;
-        p.res1 = (lay.flags & 2) ? pp.xr : nullptr;
-        p.res2 = (lay.flags & 4) ? pp.xrr : nullptr;
-        p.skip = nullptr;
-        p.res1_update = 1;
-        p.res2_update = 1;
-        p.out16 = pp.dense[lay.out_sel] + (long)lay.out_chunk0 * pp.plane_b;
-        p.out16_img_b = pp.img_b;
-        p.out16_plane_b = pp.plane_b;
-        p.out16_row_b = pp.row_b;
-        p.out32 = nullptr;
-        p.out32_c = 0;
-        p.prof = nullptr;
-        if (lay.cb == 1)
-            conv_tile<1, 0, 0, 1>(p, smem, img, ty * TILE_H, 0, nullptr);
-        else
-            conv_tile<2, 0, 0, 1>(p, smem, img, ty * TILE_H, 0, nullptr);
-        // publish: all of this workgroup's stores are complete (write-through) before the counter moves
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (aborted) return;
+        if (pp.prof) ts1 = __builtin_amdgcn_s_memtime();
+
+        // ---- epilogue (per output row through this wave's LDS slice inside the stage that was just consumed)
+#if PT_EPI_BARRIER == 1
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(pp.prog + t, L + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif PT_EPI_BARRIER == 2
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all ds_reads of that stage done; DMA keeps flying
+#endif
+        constexpr int NCH = 32 * CB, EP_STRIDE = NCH * 4 + 16, LPP = NCH / 8, PPP = 64 / LPP, NPASS = 32 / PPP;
+        char* ep = smem + ((gs - 1) & 1) * P_STAGE_B + wave * (32 * EP_STRIDE);
+        const int c8 = lane % LPP, pxl = lane / LPP;
+        const floatx4 bias_lo = *(const floatx4*)(lay.bias + c8 * 8);
+        const floatx4 bias_hi = *(const floatx4*)(lay.bias + c8 * 8 + 4);
+        const bool lrelu = lay.flags & 1, r1 = lay.flags & 2, r2 = lay.flags & 4;
+        char* obase = pp.dense[lay.out_sel] + (long)img * pp.img_b + (long)lay.out_chunk0 * pp.plane_b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int Y = Y0 + wr * 4 + i;
+#pragma unroll
+            for (int mb = 0; mb < CB; ++mb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    floatx4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = acc[mb][i][g * 4 + q];
+                    *(floatx4*)(ep + l31 * EP_STRIDE + (mb * 32 + g * 8 + hi * 4) * 4) = v;
+                }
+            if (Y < pp.H) {
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int px = ps * PPP + pxl;
+                    const int X = wc * 32 + px;
+                    floatx4 v0 = *(const floatx4*)(ep + px * EP_STRIDE + c8 * 32) + bias_lo;
+                    floatx4 v1 = *(const floatx4*)(ep + px * EP_STRIDE + c8 * 32 + 16) + bias_hi;
+                    if (X < pp.W) {
+                        const long pix = ((long)img * pp.H + Y) * pp.W + X;
+                        if (r1) {
+                            float* q1 = pp.xr + pix * 64 + c8 * 8;
+                            v0 = v0 * 0.2f + *(const floatx4*)q1;
+                            v1 = v1 * 0.2f + *(const floatx4*)(q1 + 4);
+                            if (r2) {
+                                float* q2 = pp.xrr + pix * 64 + c8 * 8;
+                                v0 = v0 * 0.2f + *(const floatx4*)q2;
+                                v1 = v1 * 0.2f + *(const floatx4*)(q2 + 4);
+                                *(floatx4*)q2 = v0;
+                                *(floatx4*)(q2 + 4) = v1;
+                            }
+                            *(floatx4*)q1 = v0;
+                            *(floatx4*)(q1 + 4) = v1;
+                        }
+                        if (lrelu) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                v0[q] = v0[q] >= 0.f ? v0[q] : v0[q] * 0.2f;
+                                v1[q] = v1[q] >= 0.f ? v1[q] : v1[q] * 0.2f;
+                            }
+                        }
+                        half8 hv;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            hv[q] = (_Float16)v0[q];
+                            hv[4 + q] = (_Float16)v1[q];
+                        }
+                        char* o = obase + (long)(c8 >> 2) * pp.plane_b + (long)(Y + 1) * pp.row_b + (X + 1) * PIX_B + (c8 & 3) * 16;
+                        floatx4 raw = __builtin_bit_cast(floatx4, hv);
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
+                    }
+                }
+            }
+        }
+        if (pp.prof) ts2 = __builtin_amdgcn_s_memtime();
+        // ---- publication of "layer L complete"
+        const bool seam = (L + 1 == pp.nlayers) || (pp.layers[L + 1 < pp.nlayers ? L + 1 : L].flags & 8);
+        if (seam) {
+            // the next layer's first chunk is THIS layer's output on the neighbours: publish now, then wait for them
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(pp.prog + t, L + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (L + 1 < pp.nlayers) {
+                const PLayer& nl = pp.layers[L + 1];
+                ensure_flags(L + 1);
+                if (aborted) return;
+#pragma unroll
+                for (int part = 0; part < 6; ++part) {
+                    if (nl.cb == 1)
+                        stage_part(std::integral_constant<int, 1>{}, chunk_src(nl, 0), chunk_w(nl, 0), gs & 1, part);
+                    else
+                        stage_part(std::integral_constant<int, 2>{}, chunk_src(nl, 0), chunk_w(nl, 0), gs & 1, part);
+                }
+            }
+        } else {
+            pending_pub = true;   // published behind the next top-of-step barrier (whose vmcnt(0) covers these stores)
+            pub_val = L + 1;
+        }
+        if (pp.prof && tid == 0) {
+            unsigned long long* q = pp.prof + ((long)blockIdx.x * pp.nlayers + L) * 6;
+            q[0] = ts0; q[1] = ts1; q[2] = ts2; q[3] = tw | ((unsigned long long)(__builtin_amdgcn_s_memtime() - ts2) << 32);
+            q[4] = tb;
+        }
+    };
+
+    // ---- prologue: layer 0's inputs were written by the previous kernel (conv_first): no flag needed
+    {
+        const PLayer& l0 = pp.layers[0];
+#pragma unroll
+        for (int part = 0; part < 6; ++part) {
+            if (l0.cb == 1)
+                stage_part(std::integral_constant<int, 1>{}, chunk_src(l0, 0), chunk_w(l0, 0), 0, part);
+            else
+                stage_part(std::integral_constant<int, 2>{}, chunk_src(l0, 0), chunk_w(l0, 0), 0, part);
+        }
+    }
+    for (int L = 0; L < pp.nlayers && !aborted; ++L) {
+        const PLayer lay = pp.layers[L];
+        if (lay.cb == 1)
+            run_layer(std::integral_constant<int, 1>{}, L, lay);
+        else
+            run_layer(std::integral_constant<int, 2>{}, L, lay);
     }
 }
 
 }  // namespace
 
 namespace srbh {
+
+unsigned long long* g_ptrunk_prof = nullptr;   // set by tools/convbench only
 
 constexpr int MAX_BLOCKS = 64;   // layer-table capacity (RRDB blocks)
 static size_t table_bytes() { return ((size_t)MAX_BLOCKS * 15 * sizeof(PLayer) + 255) & ~(size_t)255; }
@@ -134,7 +418,7 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
     SRBH_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     const int tpi = (H + TILE_H - 1) / TILE_H;
     if (tpi > ncu) return SRBH_OK;
-    constexpr int LDS_B = lds_bytes<2, 0>() > lds_bytes<1, 0>() ? lds_bytes<2, 0>() : lds_bytes<1, 0>();
+    constexpr int LDS_B = 2 * P_STAGE_B;
     static bool attr_set = false;
     if (!attr_set) {
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
@@ -150,7 +434,8 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
     for (int blk = 0; blk < d->num_block; ++blk)
         for (int r = 0; r < 3; ++r) {
             const srbh_conv_w* cw = d->rdb + (blk * 3 + r) * 5;
-            for (int k = 0; k < 4; ++k) tab[li++] = PLayer{(const char*)cw[k].w, cw[k].bias, 2 + k, 1, cur, cur, 2 + k, 1};
+            for (int k = 0; k < 4; ++k)
+                tab[li++] = PLayer{(const char*)cw[k].w, cw[k].bias, 2 + k, 1, cur, cur, 2 + k, 1 | (k == 0 ? 8 : 0)};
             tab[li++] = PLayer{(const char*)cw[4].w, cw[4].bias, 6, 2, cur, cur ^ 1, 0, 2 | (r == 2 ? 4 : 0)};
             cur ^= 1;
         }
@@ -182,6 +467,7 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
         pp.nblocks = nb * tpi;
         pp.prog = d_prog + b0 * tpi;
         pp.err = d_err;
+        pp.prof = g_ptrunk_prof;
         hipLaunchKernelGGL(ptrunk_kernel, dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
         SRBH_HIP(hipGetLastError());
     }

@@ -8,8 +8,10 @@
 #include <vector>
 #include <functional>
 #include "srbh_conv3x3_kernel.h"
+#include "srbh_ptrunk.hip"
 
 namespace srbh {
+extern unsigned long long* g_ptrunk_prof;
 void set_error(const char*, ...) {}
 int hip_fail(hipError_t e, const char* what) { fprintf(stderr, "HIP error %d in %s\n", (int)e, what); exit(1); }
 }  // namespace srbh
@@ -151,6 +153,40 @@ int main(int argc, char** argv) {
             printf("timeline cfg%d (%.1f us/launch): span %llu cyc | avg start skew %.0f | first barrier +%.0f | chunk0 %.0f | chunk1 %.0f | loop end +%.0f (from start) | epilogue %.0f cycles (barrier %.0f, lds-write %.0f)\n",
                    cfg, us, t5max - t0min, st0 / n, s1 / n, s2 / n, s3 / n, s4 / n, s5 / n, e1 / n, e2 / n);
         }
+    }
+    {   // ---- persistent trunk: per-layer in-kernel timeline
+        const int NB = argc > 2 ? atoi(argv[2]) : 23;
+        std::vector<srbh_conv_w> cw(NB * 15);
+        for (auto& c : cw) { c.w = w; c.bias = bias; }
+        srbh_rrdbnet_desc d{}; d.num_block = NB; d.rdb = cw.data();
+        char* aux; CK(hipMalloc(&aux, ptrunk_aux_bytes(B, 8)));
+        unsigned long long* prof; size_t pbytes = (size_t)8 * B * NB * 15 * 6 * 8; CK(hipMalloc(&prof, pbytes)); CK(hipMemset(prof, 0, pbytes));
+        int used = 0, cur = 0;
+        for (int rep = 0; rep < 3; ++rep) {
+            g_ptrunk_prof = rep == 2 ? prof : nullptr;
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            CK(hipEventRecord(e0, st));
+            ptrunk_run(&d, din, dout, r1, r2, B, H, W, aux, st, &used, &cur);
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("ptrunk run %d: used=%d %.3f ms for %d layers (%.2f us/layer)\n", rep, used, ms, NB * 15, ms * 1e3 / (NB * 15));
+        }
+        std::vector<unsigned long long> h(pbytes / 8);
+        CK(hipMemcpy(h.data(), prof, pbytes, hipMemcpyDeviceToHost));
+        const int NL = NB * 15, nblk = 8 * B;
+        double loop[5] = {0}, epi[5] = {0}, pub[5] = {0}, wait[5] = {0}, total[5] = {0}, bar[5] = {0};
+        for (int b = 0; b < nblk; ++b)
+            for (int L = 1; L + 1 < NL; ++L) {
+                const unsigned long long* q = &h[((size_t)b * NL + L) * 6];
+                const unsigned long long* qn = &h[((size_t)b * NL + L + 1) * 6];
+                int k = L % 5;
+                loop[k] += (double)(q[1] - q[0]); epi[k] += (double)(q[2] - q[1]); pub[k] += (double)(q[3] >> 32);
+                wait[k] += (double)(q[3] & 0xffffffffu); total[k] += (double)(qn[0] - q[0]); bar[k] += (double)q[4];
+            }
+        double cnt = (double)nblk * (NL - 2) / 5.0;
+        for (int k = 0; k < 5; ++k)
+            printf("  conv%d: loop %.0f cyc (of which flag-wait %.0f, top-barrier wait %.0f) | epilogue %.0f | publish/seam %.0f | layer start-to-start %.0f\n",
+                   k + 1, loop[k] / cnt, wait[k] / cnt, bar[k] / cnt, epi[k] / cnt, pub[k] / cnt, total[k] / cnt);
     }
     (void)clk;
     return 0;
