@@ -3,6 +3,9 @@
 #include <type_traits>
 #include "srbh_internal.h"
 
+#ifndef SRBH_PIN_ACC
+#define SRBH_PIN_ACC 0
+#endif
 #ifndef SRBH_SCHED_HINTS
 #define SRBH_SCHED_HINTS 1
 #endif
@@ -215,7 +218,9 @@ __device__ __forceinline__ void conv_tile(const KParams& p, char* smem, const in
 #pragma unroll
     for (int part = 0; part < 6; ++part) stage_part(0, 0, part);
     for (int c = 0; c < p.nchunk; ++c) {
-        __syncthreads();  // chunk c landed (the compiler drains the LDS-DMA with vmcnt(0) here); buf (c+1)&1 is free
+        // explicit drain: hipcc usually emits vmcnt(0) for pending LDS-DMA before a barrier, but not in every loop shape
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // chunk c landed on every wave; buf (c+1)&1 is free
         if (ABL == 9 && c < 3) tstamp[1 + c] = __builtin_amdgcn_s_memtime();
         if (ABL == 1) {
             if (c + 1 < p.nchunk)
@@ -223,7 +228,19 @@ __device__ __forceinline__ void conv_tile(const KParams& p, char* smem, const in
                 for (int part = 0; part < 6; ++part) stage_part(c + 1, (c + 1) & 1, part);
             continue;
         }
+#if SRBH_PIN_ACC
+#pragma unroll
+        for (int mb = 0; mb < CB; ++mb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+a"(acc[mb][i]));
+#endif
         chunk_body(c + 1 < p.nchunk, c);
+#if SRBH_PIN_ACC
+#pragma unroll
+        for (int mb = 0; mb < CB; ++mb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+a"(acc[mb][i]));
+#endif
     }
 
     if (ABL == 9) tstamp[4] = __builtin_amdgcn_s_memtime();

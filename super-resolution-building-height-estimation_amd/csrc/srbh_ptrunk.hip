@@ -161,6 +161,23 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
     auto run_layer = [&](auto cb_tag, const int L, const PLayer& lay) {
         constexpr int CB = decltype(cb_tag)::value;
         constexpr int NREAD = G::NP + 3 * CB, NMFMA = 12 * CB;
+        // ---- layer prologue (no accumulator is live here)
+        unsigned long long p0 = 0;
+        if (pp.prof) p0 = __builtin_amdgcn_s_memtime();
+        // LDS-DMA completion is NOT reliably waited for by hipcc before a barrier (seen: no vmcnt at all in this loop
+        // shape) -> always drain explicitly.  vmcnt(0) also covers this workgroup's write-through stores of layer L-1.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // step (L,0) landed on every wave
+        if (pending_pub) {
+            if (tid == 0) __hip_atomic_store(pp.prog + t, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pending_pub = false;
+        }
+        if (L > 0) ensure_flags(L);   // every input plane of layer L is complete on both neighbours from here on
+        if (aborted) return;
+        const bool has_next_prefetch = (L + 1 < pp.nlayers) && !(pp.layers[L + 1 < pp.nlayers ? L + 1 : L].flags & 8);
+        const PLayer nlay = pp.layers[L + 1 < pp.nlayers ? L + 1 : L];
+        unsigned long long p1 = 0;
+        if (pp.prof) p1 = __builtin_amdgcn_s_memtime();
         floatx16 acc[CB][4];
 #pragma unroll
         for (int mb = 0; mb < CB; ++mb)
@@ -231,41 +248,27 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         };
 
         const int n = lay.nchunk;
-        const int fnew = first_new_chunk(lay);
-        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, tw = 0, tb = 0;
-        if (pp.prof) ts0 = __builtin_amdgcn_s_memtime();
-        for (int c = 0; c < n && !aborted; ++c) {
-            unsigned long long b0 = 0;
-            if (pp.prof) b0 = __builtin_amdgcn_s_memtime();
-            __syncthreads();   // step gs landed (vmcnt(0)); every wave is past step gs-1 and past the previous epilogue
-            if (pp.prof) tb += __builtin_amdgcn_s_memtime() - b0;
-            if (pending_pub) {  // the previous layer's write-through stores are complete now -> move the counter
-                if (tid == 0) __hip_atomic_store(pp.prog + t, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pending_pub = false;
+        unsigned long long ts0 = p1, ts1 = 0, ts2 = 0, tw = p1 - p0, tb = 0;
+        // The chunk loop below must stay as plain as the per-layer kernel's (barrier + one compute body): with any
+        // extra control flow inside it hipcc parks the loop-carried accumulators in VGPRs and copies all of them back
+        // into AGPRs at the top of every chunk.  So everything protocol-related happened in the layer prologue.
+        for (int c = 0; c < n; ++c) {
+            if (c > 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of step gs has landed ...
+                __syncthreads();                                   // ... and everybody else's; all waves are past step gs-1
             }
             int next_cb = 0;
             const char* nsrc = nullptr;
             const char* nw = nullptr;
             if (c + 1 < n) {
-                if (c + 1 >= fnew && L > 0) {   // the newest plane: neighbours must have finished layer L-1
-                    unsigned long long a0 = 0;
-                    if (pp.prof) a0 = __builtin_amdgcn_s_memtime();
-                    ensure_flags(L);
-                    if (pp.prof) tw += __builtin_amdgcn_s_memtime() - a0;
-                }
                 next_cb = lay.cb;
                 nsrc = chunk_src(lay, c + 1);
                 nw = chunk_w(lay, c + 1);
-            } else if (L + 1 < pp.nlayers) {
-                const PLayer& nl = pp.layers[L + 1];
-                if (!(nl.flags & 8)) {                          // its first chunk is old data: prefetch across the layer seam
-                    next_cb = nl.cb;
-                    nsrc = chunk_src(nl, 0);
-                    nw = chunk_w(nl, 0);
-                }
+            } else if (has_next_prefetch) {
+                next_cb = nlay.cb;
+                nsrc = chunk_src(nlay, 0);
+                nw = chunk_w(nlay, 0);
             }
-            if (aborted) break;
-            peek_flags();
             compute(next_cb, nsrc, nw);
             ++gs;
         }
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
             if (tid == 0) __hip_atomic_store(pp.prog + t, L + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (L + 1 < pp.nlayers) {
                 const PLayer& nl = pp.layers[L + 1];
-                ensure_flags(L + 1);
+                ensure_flags(L + 1);   // its first chunk is this layer's output on the neighbours: wait before staging it
                 if (aborted) return;
 #pragma unroll
                 for (int part = 0; part < 6; ++part) {
