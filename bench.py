@@ -204,7 +204,7 @@ def main():
         traffic = None   # HBM bytes per launch sequence from the PMC passes recorded under profiles/ (same command, B=32)
         try:
             if B == 32 and args.num_block == 23:
-                traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["per_forward_B32"]["total_bytes"]
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_hbm_traffic.json")))["per_forward_B32"]["total_bytes"]
         except Exception:
             pass
         line = {

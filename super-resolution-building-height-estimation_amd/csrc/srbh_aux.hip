@@ -95,42 +95,76 @@ __global__ void pack_w_kernel(const float* __restrict__ w, _Float16* __restrict_
 }
 
 // ---- conv_first: fp32 direct conv, few input channels ------------------------------------------------
-// One thread per (pixel, group of 4 output channels); input taps are re-read through L1/L2 (tiny op).
-__global__ void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                  const float* __restrict__ bias, int B, int cin, int H, int W, float* ra, float* rb,
-                                  float* rc, char* out16, int row_b, int plane_b, long img_b) {
-    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long total = (long)B * H * W * 16;
+// Thread = (4 consecutive pixels of a row, 4 consecutive output channels); 16 lanes cover the 64 channels of a pixel
+// group so every store instruction writes whole 256-byte pixel records.  Weights sit in LDS as [ic*9+tap][64] and are
+// read as float4 broadcasts; each input value is loaded once and reused for the 4 channels x up to 3 pixels it touches.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, int B, int cin_rt, int H, int W,
+                                                         float* ra, float* rb, float* rc, char* out16, int row_b,
+                                                         int plane_b, long img_b) {
+    extern __shared__ float s_w[];   // [cin*9][64]
+    const int cin = CIN > 0 ? CIN : cin_rt;
+    for (int u = threadIdx.x; u < cin * 9 * 64; u += 256) {
+        const int oc = u & 63, k = u >> 6;            // k = ic*9 + tap
+        s_w[u] = w[(long)oc * cin * 9 + k];
+    }
+    __syncthreads();
+    const int wq = (W + 3) >> 2;                      // pixel groups per row
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * H * wq * 16;
     if (idx >= total) return;
-    int og = idx & 15;  // output channels og*4 .. +3
-    long pix = idx >> 4;
-    int xx = pix % W;
-    long r = pix / W;
-    int yy = r % H;
-    int b = r / H;
-    float acc[4];
-    for (int q = 0; q < 4; ++q) acc[q] = bias ? bias[og * 4 + q] : 0.f;
+    const int og = idx & 15;
+    long r = idx >> 4;
+    const int xg = r % wq; r /= wq;
+    const int yy = r % H;
+    const int b = r / H;
+    const int x0 = xg * 4;
+    float acc[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[p][q] = bias ? bias[og * 4 + q] : 0.f;
     for (int ic = 0; ic < cin; ++ic) {
         const float* xp = x + ((long)b * cin + ic) * H * W;
+#pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            int sy = yy + ky - 1;
-            if (sy < 0 || sy >= H) continue;
+            const int sy = yy + ky - 1;
+            float in[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int sx = x0 + j - 1;
+                in[j] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? xp[(long)sy * W + sx] : 0.f;
+            }
+#pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                int sx = xx + kx - 1;
-                if (sx < 0 || sx >= W) continue;
-                float v = xp[(long)sy * W + sx];
-                for (int q = 0; q < 4; ++q) acc[q] = fmaf(v, w[((long)(og * 4 + q) * cin + ic) * 9 + ky * 3 + kx], acc[q]);
+                const float4 wv = *(const float4*)(s_w + (ic * 9 + ky * 3 + kx) * 64 + og * 4);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float v = in[p + kx];
+                    acc[p][0] = fmaf(v, wv.x, acc[p][0]);
+                    acc[p][1] = fmaf(v, wv.y, acc[p][1]);
+                    acc[p][2] = fmaf(v, wv.z, acc[p][2]);
+                    acc[p][3] = fmaf(v, wv.w, acc[p][3]);
+                }
             }
         }
     }
-    float4 v4 = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    if (ra) *(float4*)(ra + pix * 64 + og * 4) = v4;
-    if (rb) *(float4*)(rb + pix * 64 + og * 4) = v4;
-    if (rc) *(float4*)(rc + pix * 64 + og * 4) = v4;
-    if (out16) {
-        _Float16* o = (_Float16*)(out16 + b * img_b + (long)(og >> 3) * plane_b + (long)(yy + 1) * row_b +
-                                  (xx + 1) * PIX_B + (og & 7) * 8);
-        for (int q = 0; q < 4; ++q) o[q] = (_Float16)acc[q];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int xx = x0 + p;
+        if (xx >= W) break;
+        const long pix = ((long)b * H + yy) * W + xx;
+        const float4 v4 = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
+        if (ra) *(float4*)(ra + pix * 64 + og * 4) = v4;
+        if (rb) *(float4*)(rb + pix * 64 + og * 4) = v4;
+        if (rc) *(float4*)(rc + pix * 64 + og * 4) = v4;
+        if (out16) {
+            _Float16* o = (_Float16*)(out16 + b * img_b + (long)(og >> 3) * plane_b + (long)(yy + 1) * row_b +
+                                      (xx + 1) * PIX_B + (og & 7) * 8);
+            typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+            *(half4*)o = half4{(_Float16)acc[p][0], (_Float16)acc[p][1], (_Float16)acc[p][2], (_Float16)acc[p][3]};
+        }
     }
 }
 
@@ -173,9 +207,21 @@ extern "C" int srbh_conv_first_f32(const float* x, const float* w, const float* 
     SRBH_REQUIRE(x && w && B > 0 && cin > 0 && H > 0 && W > 0, "srbh_conv_first_f32: bad arguments");
     SRBH_REQUIRE(!out16 || out16_chunks_total >= 2, "srbh_conv_first_f32: out16 needs >= 2 chunk planes");
     Act16Geo g = act16_geo(B, out16_chunks_total > 0 ? out16_chunks_total : 2, H, W);
-    long total = (long)B * H * W * 16;
-    hipLaunchKernelGGL(conv_first_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, w, bias, B,
-                       cin, H, W, ra, rb, rc, (char*)out16, g.row_b, g.plane_b, g.img_b);
+    SRBH_REQUIRE(cin <= 56, "srbh_conv_first_f32: at most 56 input channels (got %d)", cin);
+    long total = (long)B * H * ((W + 3) / 4) * 16;
+    const size_t lds = (size_t)cin * 9 * 64 * sizeof(float);
+    if (cin == 3)
+        hipLaunchKernelGGL(conv_first_kernel<3>, dim3((total + 255) / 256), dim3(256), lds, (hipStream_t)stream, x, w, bias,
+                           B, cin, H, W, ra, rb, rc, (char*)out16, g.row_b, g.plane_b, g.img_b);
+    else {
+        static bool set = false;
+        if (lds > 65536 && !set) {
+            SRBH_HIP(hipFuncSetAttribute((const void*)conv_first_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 56 * 9 * 64 * 4));
+            set = true;
+        }
+        hipLaunchKernelGGL(conv_first_kernel<0>, dim3((total + 255) / 256), dim3(256), lds, (hipStream_t)stream, x, w, bias,
+                           B, cin, H, W, ra, rb, rc, (char*)out16, g.row_b, g.plane_b, g.img_b);
+    }
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }

@@ -14,6 +14,7 @@
 // All workgroups must be co-resident (1 per CU: the kernel uses the whole 160 KiB LDS): the host launches at most
 // multiProcessorCount workgroups per call (sub-batches of images) and every spin is bounded -- on timeout the launch
 // sets an error word and drains instead of hanging.
+#include <stdlib.h>
 #include "srbh_conv3x3_kernel.h"
 
 #ifndef PT_EPI_BARRIER
@@ -41,6 +42,7 @@ struct PParams {
     int H, W, tiles_per_img, nblocks;
     int* prog;
     int* err;
+    int stagger;                // odd images start this many s_sleep(127) periods late (de-phases the HBM bursts)
     unsigned long long* prof;   // debug (tools/convbench): [block][layer][4] s_memtime stamps, nullptr in production
 };
 
@@ -275,72 +277,90 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         if (aborted) return;
         if (pp.prof) ts1 = __builtin_amdgcn_s_memtime();
 
-        // ---- epilogue (per output row through this wave's LDS slice inside the stage that was just consumed)
-#if PT_EPI_BARRIER == 1
-        __syncthreads();
-#elif PT_EPI_BARRIER == 2
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#else
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all ds_reads of that stage done; DMA keeps flying
-#endif
-        constexpr int NCH = 32 * CB, EP_STRIDE = NCH * 4 + 16, LPP = NCH / 8, PPP = 64 / LPP, NPASS = 32 / PPP;
-        char* ep = smem + ((gs - 1) & 1) * P_STAGE_B + wave * (32 * EP_STRIDE);
-        const int c8 = lane % LPP, pxl = lane / LPP;
-        const floatx4 bias_lo = *(const floatx4*)(lay.bias + c8 * 8);
-        const floatx4 bias_hi = *(const floatx4*)(lay.bias + c8 * 8 + 4);
+        // ---- epilogue, straight from the MFMA D layout (no LDS round trip): lane (l31, hi) holds, for every row i and
+        // channel group g, the 4 consecutive channels 8g + 4hi + (0..3) of pixel l31.  fp32 residual traffic is already
+        // 16 B per lane; the fp16 output is widened from 8 to 16 B per lane with v_permlane32_swap (the two half-waves
+        // exchange one 4-channel packet so that each ends up with 8 consecutive channels).
         const bool lrelu = lay.flags & 1, r1 = lay.flags & 2, r2 = lay.flags & 4;
         char* obase = pp.dense[lay.out_sel] + (long)img * pp.img_b + (long)lay.out_chunk0 * pp.plane_b;
+        floatx4 bias4[CB][4];
+#pragma unroll
+        for (int mb = 0; mb < CB; ++mb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias4[mb][g] = *(const floatx4*)(lay.bias + mb * 32 + g * 8 + hi * 4);
+        const int X = wc * 32 + l31;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int Y = Y0 + wr * 4 + i;
+            const bool valid = (Y < pp.H) && (X < pp.W);
+            const long pix = ((long)img * pp.H + Y) * pp.W + X;
+            floatx4 v[CB][4];
 #pragma unroll
             for (int mb = 0; mb < CB; ++mb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    floatx4 v;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = acc[mb][i][g * 4 + q];
-                    *(floatx4*)(ep + l31 * EP_STRIDE + (mb * 32 + g * 8 + hi * 4) * 4) = v;
+                    for (int q = 0; q < 4; ++q) v[mb][g][q] = acc[mb][i][g * 4 + q];
+                    v[mb][g] += bias4[mb][g];
                 }
-            if (Y < pp.H) {
+            if (r1 && valid) {
+                float* q1 = pp.xr + pix * 64 + hi * 4;
+                floatx4 a1[CB][4];
 #pragma unroll
-                for (int ps = 0; ps < NPASS; ++ps) {
-                    const int px = ps * PPP + pxl;
-                    const int X = wc * 32 + px;
-                    floatx4 v0 = *(const floatx4*)(ep + px * EP_STRIDE + c8 * 32) + bias_lo;
-                    floatx4 v1 = *(const floatx4*)(ep + px * EP_STRIDE + c8 * 32 + 16) + bias_hi;
-                    if (X < pp.W) {
-                        const long pix = ((long)img * pp.H + Y) * pp.W + X;
-                        if (r1) {
-                            float* q1 = pp.xr + pix * 64 + c8 * 8;
-                            v0 = v0 * 0.2f + *(const floatx4*)q1;
-                            v1 = v1 * 0.2f + *(const floatx4*)(q1 + 4);
-                            if (r2) {
-                                float* q2 = pp.xrr + pix * 64 + c8 * 8;
-                                v0 = v0 * 0.2f + *(const floatx4*)q2;
-                                v1 = v1 * 0.2f + *(const floatx4*)(q2 + 4);
-                                *(floatx4*)q2 = v0;
-                                *(floatx4*)(q2 + 4) = v1;
-                            }
-                            *(floatx4*)q1 = v0;
-                            *(floatx4*)(q1 + 4) = v1;
-                        }
-                        if (lrelu) {
+                for (int mb = 0; mb < CB; ++mb)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                v0[q] = v0[q] >= 0.f ? v0[q] : v0[q] * 0.2f;
-                                v1[q] = v1[q] >= 0.f ? v1[q] : v1[q] * 0.2f;
-                            }
-                        }
-                        half8 hv;
+                    for (int g = 0; g < 4; ++g) a1[mb][g] = *(const floatx4*)(q1 + mb * 32 + g * 8);
+                if (r2) {
+                    float* q2 = pp.xrr + pix * 64 + hi * 4;
+                    floatx4 a2[CB][4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            hv[q] = (_Float16)v0[q];
-                            hv[4 + q] = (_Float16)v1[q];
+                    for (int mb = 0; mb < CB; ++mb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) a2[mb][g] = *(const floatx4*)(q2 + mb * 32 + g * 8);
+#pragma unroll
+                    for (int mb = 0; mb < CB; ++mb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            v[mb][g] = (v[mb][g] * 0.2f + a1[mb][g]) * 0.2f + a2[mb][g];
+                            *(floatx4*)(q2 + mb * 32 + g * 8) = v[mb][g];
+                            *(floatx4*)(q1 + mb * 32 + g * 8) = v[mb][g];
                         }
-                        char* o = obase + (long)(c8 >> 2) * pp.plane_b + (long)(Y + 1) * pp.row_b + (X + 1) * PIX_B + (c8 & 3) * 16;
-                        floatx4 raw = __builtin_bit_cast(floatx4, hv);
+                } else {
+#pragma unroll
+                    for (int mb = 0; mb < CB; ++mb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            v[mb][g] = v[mb][g] * 0.2f + a1[mb][g];
+                            *(floatx4*)(q1 + mb * 32 + g * 8) = v[mb][g];
+                        }
+                }
+            }
+#pragma unroll
+            for (int mb = 0; mb < CB; ++mb) {
+                unsigned hp[4][2];   // packed fp16 pairs of the 4 channel groups
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    floatx4 w = v[mb][g];
+                    if (lrelu) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) w[q] = fmaxf(w[q], w[q] * 0.2f);   // == x>=0 ? x : 0.2x
+                    }
+                    half4 h4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) h4[q] = (_Float16)w[q];
+                    const uint2 u = __builtin_bit_cast(uint2, h4);
+                    hp[g][0] = u.x;
+                    hp[g][1] = u.y;
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    // lower half-wave ends with channels 16m + 0..7, upper half-wave with 16m + 8..15
+                    auto s0 = __builtin_amdgcn_permlane32_swap(hp[2 * m][0], hp[2 * m + 1][0], false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(hp[2 * m][1], hp[2 * m + 1][1], false, false);
+                    typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+                    const uintx4 raw = {s0[0], s1[0], s0[1], s1[1]};
+                    if (valid) {
+                        char* o = obase + (long)mb * pp.plane_b + (long)(Y + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16;
                         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
                     }
                 }
@@ -377,6 +397,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         }
     };
 
+    if ((img & 1) && pp.stagger > 0)
+        for (int k = 0; k < pp.stagger; ++k) __builtin_amdgcn_s_sleep(127);
     // ---- prologue: layer 0's inputs were written by the previous kernel (conv_first): no flag needed
     {
         const PLayer& l0 = pp.layers[0];
@@ -471,6 +493,10 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
         pp.prog = d_prog + b0 * tpi;
         pp.err = d_err;
         pp.prof = g_ptrunk_prof;
+        {
+            const char* e = getenv("SRBH_PT_STAGGER");
+            pp.stagger = e ? atoi(e) : 0;
+        }
         hipLaunchKernelGGL(ptrunk_kernel, dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
         SRBH_HIP(hipGetLastError());
     }

@@ -157,7 +157,13 @@ int main(int argc, char** argv) {
     {   // ---- persistent trunk: per-layer in-kernel timeline
         const int NB = argc > 2 ? atoi(argv[2]) : 23;
         std::vector<srbh_conv_w> cw(NB * 15);
-        for (auto& c : cw) { c.w = w; c.bias = bias; }
+        const bool distinct_w = argc > 3 && atoi(argv[3]) != 0;   // every layer gets its own (L2-cold) weight image
+        char* wall = nullptr;
+        if (distinct_w) {
+            CK(hipMalloc(&wall, (size_t)NB * 15 * 6 * 36864));
+            for (size_t i = 0; i < (size_t)NB * 15; ++i) CK(hipMemcpy(wall + i * 6 * 36864, w, 6 * 36864, hipMemcpyDeviceToDevice));
+        }
+        for (size_t i = 0; i < cw.size(); ++i) { cw[i].w = distinct_w ? wall + i * 6 * 36864 : w; cw[i].bias = bias; }
         srbh_rrdbnet_desc d{}; d.num_block = NB; d.rdb = cw.data();
         char* aux; CK(hipMalloc(&aux, ptrunk_aux_bytes(B, 8)));
         unsigned long long* prof; size_t pbytes = (size_t)8 * B * NB * 15 * 6 * 8; CK(hipMalloc(&prof, pbytes)); CK(hipMemset(prof, 0, pbytes));
