@@ -159,6 +159,7 @@ class _ConvFn(torch.autograd.Function):
         out, _ = H.hconv([xn], conv, packed, ps2=ps2)
         ctx.save_for_backward(xn, weight)
         ctx.ps2, ctx.gcache, ctx.has_bias = ps2, gcache, bias is not None
+        ctx.pack_dx = xn.data_ptr() != x.data_ptr()   # producer was a stock (NCHW) op: hand it a packed gradient
         return out
 
     @staticmethod
@@ -169,6 +170,8 @@ class _ConvFn(torch.autograd.Function):
             g = ps2_inverse(g)
         cout, cin, ks, _ = weight.shape
         dx = conv_dgrad(g, weight, ctx.gcache) if ctx.needs_input_grad[0] else None
+        if dx is not None and ctx.pack_dx:
+            dx = dx.contiguous()
         dw = conv_wgrad([xn], None, g, cout, ks) if ctx.needs_input_grad[1] else None
         db = channel_sum(g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None, None, None, None
