@@ -214,6 +214,18 @@ int srbh_bn_bwd_apply(const float* g, const float* c, const float* mean, const f
 /* inverse of the PixelShuffle(2) store map: g_ps [B][2H][2W][C] -> g [B][H][W][4C] */
 int srbh_ps2_inverse(const float* g_ps, float* g, int B, int H, int W, int C, void* stream);
 
+/* ---- inference epilogue: quantise + integer mosaic (predict_realesanet_feature_globe.py:172-204) ------------------
+ * accumulate: height [B][th][tw] fp32 (model output, C=1), build logits NHWC [B][th][tw][C] fp32, pos [B][4] int32
+ *   = (xoff, yoff, xcount, ycount) already multiplied by 4 (predict...py:182); adds round(max(h,0)*10) and
+ *   round(softmax*255) (both round-half-even, uint16 range) into uint32 mosaics [H][W], [C][H][W] and 1 into the
+ *   weight mosaic, with atomics.  finalize: build class = argmax of the class sums (mod 2^16), height =
+ *   round(sum/weight) where weight (mod 2^8) > 0 -- bit-identical to the reference's uint16/uint8 numpy arrays for any
+ *   tile order or sharding (mosaics of different ranks add). */
+int srbh_mosaic_accumulate(const float* height, const float* build, int C, int B, int th, int tw, const int* pos,
+                           unsigned* res_height, unsigned* res_build, unsigned* res_weight, int H, int W, void* stream);
+int srbh_mosaic_finalize(const unsigned* res_height, const unsigned* res_build, const unsigned* res_weight, int C, int H,
+                         int W, unsigned short* height_out, unsigned char* build_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

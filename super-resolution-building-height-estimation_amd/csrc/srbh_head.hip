@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
     const int Y0 = ty * HT_H, X0 = tx * HT_W;
     const int cin = p.c0 + p.c1;
     const int nchunk = (cin + HC - 1) / HC;
+    const bool vec0 = (p.c0 & 3) == 0, vec1 = p.c1 > 0 && (p.c1 & 3) == 0 && (p.c0 & 3) == 0;
 
     floatx4 acc[NOB][8];
 #pragma unroll
@@ -85,6 +86,16 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (y >= 0 && y < p.H && x >= 0 && x < p.W && ch < cin) {
                 const long pixi = ((long)img * p.H + y) * p.W + x;
+                if (vec0 && ch + 3 < p.c0) {            // 16-byte path: the 4 channels sit in src0
+                    floatx4 a = *(const floatx4*)(p.src0 + pixi * p.c0 + ch);
+                    if (p.pre_scale) a = a * *(const floatx4*)(p.pre_scale + ch) + *(const floatx4*)(p.pre_shift + ch);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = p.pre_relu ? fmaxf(a[j], 0.f) : a[j];
+                } else if (vec1 && ch >= p.c0 && ch + 3 < cin) {   // ... or in src1
+                    const floatx4 a = *(const floatx4*)(p.src1 + pixi * p.c1 + (ch - p.c0));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = a[j];
+                } else
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int cc = ch + j;

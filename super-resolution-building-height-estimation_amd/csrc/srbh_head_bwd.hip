@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void hwgrad_f32_kernel(const WGParams p) {
     const int cin = p.c0 + p.c1;
     const int nchunk = (cin + 15) / 16;
     const int ob = blockIdx.y;
+    const bool vec0 = (p.c0 & 3) == 0, vec1 = p.c1 > 0 && (p.c1 & 3) == 0 && (p.c0 & 3) == 0;
 
     for (int c = 0; c < nchunk; ++c) {
         floatx4 acc[TAPS];
@@ -64,6 +65,14 @@ __global__ __launch_bounds__(256) void hwgrad_f32_kernel(const WGParams p) {
                 floatx4 v = {0.f, 0.f, 0.f, 0.f};
                 if (y >= 0 && y < p.H && x >= 0 && x < p.W && ch < cin) {
                     const long pixi = ((long)img * p.H + y) * p.W + x;
+                    if (vec0 && ch + 3 < p.c0) {
+                        floatx4 a = *(const floatx4*)(p.src0 + pixi * p.c0 + ch);
+                        if (p.pre_scale) a = a * *(const floatx4*)(p.pre_scale + ch) + *(const floatx4*)(p.pre_shift + ch);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = p.pre_relu ? fmaxf(a[j], 0.f) : a[j];
+                    } else if (vec1 && ch >= p.c0 && ch + 3 < cin) {
+                        v = *(const floatx4*)(p.src1 + pixi * p.c1 + (ch - p.c0));
+                    } else
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int cc = ch + j;
@@ -86,9 +95,13 @@ __global__ __launch_bounds__(256) void hwgrad_f32_kernel(const WGParams p) {
                 floatx4 v = {0.f, 0.f, 0.f, 0.f};
                 if (y < p.H && x < p.W) {
                     const float* s = p.dy + (((long)img * p.H + y) * p.W + x) * p.cout_total + ob * 16 + cg * 4;
+                    if ((p.cout_total & 3) == 0 && ob * 16 + cg * 4 + 3 < p.cout_total) {
+                        v = *(const floatx4*)s;
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (ob * 16 + cg * 4 + j < p.cout_total) v[j] = s[j];
+                        for (int j = 0; j < 4; ++j)
+                            if (ob * 16 + cg * 4 + j < p.cout_total) v[j] = s[j];
+                    }
                 }
                 *(floatx4*)(s_dy + pix * 16 + cg * 4) = v;
             }

@@ -1,0 +1,88 @@
+// srbh_mosaic.hip -- inference epilogue of the urban-centre predict path, on the device.
+//
+// Stands in for the per-batch numpy code of reference predict_realesanet_feature_globe.py:172-185 (clamp, x10,
+// round-half-even -> uint16; softmax x255 round -> uint16; per-tile scatter-ADD into city mosaics, weight += 1) and the
+// per-city finalisation :195-204 (argmax over class sums; height = round(sum / weight) where weight > 0).
+// Integer work is exact.  Device mosaics are uint32 (atomic adds need 32 bits); the reference's uint16 / uint8
+// wrap-around is reproduced at finalisation by reducing modulo 2^16 / 2^8 (addition commutes with the modulus), so the
+// result is bit-identical for ANY sharding or order of the tiles -- ranks can simply sum their mosaics.
+#include "srbh_internal.h"
+
+namespace {
+using namespace srbh;
+
+__global__ void mosaic_accumulate_kernel(const float* __restrict__ height, const float* __restrict__ build, int C, int B,
+                                         int th, int tw, const int* __restrict__ pos, unsigned* res_h, unsigned* res_b,
+                                         unsigned* res_w, int H, int W) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)B * th * tw;
+    if (idx >= total) return;
+    const int x = idx % tw;
+    long r = idx / tw;
+    const int y = r % th;
+    const int b = r / th;
+    const int xoff = pos[b * 4 + 0], yoff = pos[b * 4 + 1], xcount = pos[b * 4 + 2], ycount = pos[b * 4 + 3];
+    if (x >= xcount || y >= ycount) return;
+    const int X = xoff + x, Y = yoff + y;
+    if (X < 0 || X >= W || Y < 0 || Y >= H) return;   // (the reference would raise on such a tile)
+    float hv = height[idx];
+    hv = hv < 0.f ? 0.f : hv;                                            // ypred[ypred<0] = 0
+    const unsigned hq = ((unsigned)rintf(hv * 10.f)) & 0xffffu;          // np.round(.*10).astype(uint16)
+    const long o = (long)Y * W + X;
+    atomicAdd(res_h + o, hq);
+    atomicAdd(res_w + o, 1u);
+    const float* lg = build + idx * C;
+    float m = lg[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, lg[c]);
+    float e[16], s = 0.f;
+    for (int c = 0; c < C; ++c) {
+        e[c] = expf(lg[c] - m);
+        s += e[c];
+    }
+    for (int c = 0; c < C; ++c) {
+        const unsigned q = ((unsigned)rintf(e[c] / s * 255.f)) & 0xffffu;  // np.round(softmax*255).astype(uint16)
+        atomicAdd(res_b + (long)c * H * W + o, q);
+    }
+}
+
+__global__ void mosaic_finalize_kernel(const unsigned* __restrict__ res_h, const unsigned* __restrict__ res_b,
+                                       const unsigned* __restrict__ res_w, int C, long HW, unsigned short* height_out,
+                                       unsigned char* build_out) {
+    long o = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= HW) return;
+    unsigned best = res_b[o] & 0xffffu;
+    int arg = 0;
+    for (int c = 1; c < C; ++c) {                          // np.argmax: first maximum
+        const unsigned v = res_b[(long)c * HW + o] & 0xffffu;
+        if (v > best) { best = v; arg = c; }
+    }
+    build_out[o] = (unsigned char)arg;
+    const unsigned h16 = res_h[o] & 0xffffu, w8 = res_w[o] & 0xffu;
+    // res_height[mask] = np.round(res_height[mask] / res_weight[mask]).astype(uint16): float64 division, half-even
+    height_out[o] = w8 > 0 ? (unsigned short)(unsigned)rint((double)h16 / (double)w8) : (unsigned short)h16;
+}
+
+}  // namespace
+
+extern "C" int srbh_mosaic_accumulate(const float* height, const float* build, int C, int B, int th, int tw,
+                                      const int* pos, unsigned* res_height, unsigned* res_build, unsigned* res_weight,
+                                      int H, int W, void* stream) {
+    SRBH_REQUIRE(height && build && pos && res_height && res_build && res_weight, "srbh_mosaic_accumulate: null pointer");
+    SRBH_REQUIRE(C >= 1 && C <= 16 && B > 0 && th > 0 && tw > 0 && H > 0 && W > 0, "srbh_mosaic_accumulate: bad shape");
+    long total = (long)B * th * tw;
+    hipLaunchKernelGGL(mosaic_accumulate_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, height, build,
+                       C, B, th, tw, pos, res_height, res_build, res_weight, H, W);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_mosaic_finalize(const unsigned* res_height, const unsigned* res_build, const unsigned* res_weight, int C,
+                                    int H, int W, unsigned short* height_out, unsigned char* build_out, void* stream) {
+    SRBH_REQUIRE(res_height && res_build && res_weight && height_out && build_out && C >= 1 && H > 0 && W > 0,
+                 "srbh_mosaic_finalize: bad arguments");
+    long HW = (long)H * W;
+    hipLaunchKernelGGL(mosaic_finalize_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, res_height,
+                       res_build, res_weight, C, HW, height_out, build_out);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}

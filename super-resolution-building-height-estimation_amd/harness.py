@@ -134,3 +134,22 @@ class TrainStep:
         allreduce_grads(self.params(), self.world)
         self.optimizer.step()
         return loss.detach(), height_pred.detach()
+
+
+@torch.no_grad()
+def predict_tiles(net_hr, model, tiles, posall, mosaic, batch=32, rank=0, world=1):
+    """predict_whole_image_grid's inner loop (predict_realesanet_feature_globe.py:167-185) for this rank's shard of a
+    city's grid cells: RRDBNet feature extraction -> height / building heads -> quantise + integer mosaic on the
+    device.  ``tiles`` (N,8,64,64) fp32, ``posall`` (N,4) LR-cell windows.  Merge shards with ``mosaic.all_reduce_``
+    (or ``merge_``) before ``mosaic.finalize()``; integer sums make the result independent of the sharding."""
+    model.eval()
+    net_hr.eval()
+    lo, hi = shard_range(tiles.shape[0], rank, world)
+    dev = mosaic.res_height.device
+    for s in range(lo, hi, batch):
+        e = min(s + batch, hi)
+        x = tiles[s:e].to(dev, non_blocking=True)
+        hr_fea = net_hr.forward_feature(x[:, :3])
+        out = model(x, hr_fea)
+        mosaic.add(out[0], out[1], posall[s:e])
+    return hi - lo

@@ -110,3 +110,32 @@ def test_train_harness_step_reduces_loss():
     assert batch[3].dtype == torch.long and int(batch[3].max()) <= 6
     losses = [float(ts(batch)[0]) for _ in range(6)]
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+
+
+def test_predict_path_sharded_mosaic():
+    """config 5 shape: grid cells -> both nets -> device mosaic; two 'ranks' merged == one rank (integer sums)."""
+    from srbh_amd.harness import predict_tiles
+    from srbh_amd.mosaic import Mosaic
+    from srbh_amd.rrdbnet import RRDBNet
+    net_hr = RRDBNet(3, 3, num_block=1)
+    net_hr.load_state_dict(synth.rrdbnet_state_dict(num_block=1, seed=4, mode="stress"))
+    net_hr = net_hr.to(DEV).eval()
+    model = make_model(seed=12, isaggre=False).to(DEV).eval()
+    tiles = synth.tiles(6, 8, 64, seed=13, kind="grid")
+    pos = [[0, 0, 64, 64], [64, 0, 64, 64], [128, 0, 32, 64], [0, 64, 64, 16], [64, 64, 64, 16], [32, 32, 64, 48]]
+    H, W = 80 * 4, 160 * 4
+    one = Mosaic(H, W, 7, DEV)
+    assert predict_tiles(net_hr, model, tiles, pos, one, batch=6) == 6
+    a, b = Mosaic(H, W, 7, DEV), Mosaic(H, W, 7, DEV)
+    predict_tiles(net_hr, model, tiles, pos, a, batch=2, rank=0, world=2)
+    predict_tiles(net_hr, model, tiles, pos, b, batch=2, rank=1, world=2)
+    a.merge_(b)
+    assert torch.equal(a.res_weight, one.res_weight)
+    # heights are quantised model outputs: batch-size dependent stock-op algorithms may move a value across a rounding
+    # boundary, so compare the final rasters with a 1-LSB allowance on a vanishing fraction
+    h1, c1 = one.finalize()
+    h2, c2 = a.finalize()
+    dh = (h1.int() - h2.int()).abs()
+    assert int(dh.max()) <= 1 and float((dh > 0).float().mean()) < 1e-3
+    assert float((c1 != c2).float().mean()) < 1e-3
+    assert int(one.res_weight.max()) == 2          # the overlapping window really overlapped
