@@ -17,6 +17,9 @@
 #include <stdlib.h>
 #include "srbh_conv3x3_kernel.h"
 
+#ifndef PT_LATE_FLAGS
+#define PT_LATE_FLAGS 0   // measured slower: the peel re-introduces accumulator copies
+#endif
 #ifndef PT_EPI_BARRIER
 #define PT_EPI_BARRIER 0
 #endif
@@ -174,8 +177,15 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
             if (tid == 0) __hip_atomic_store(pp.prog + t, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             pending_pub = false;
         }
-        if (L > 0) ensure_flags(L);   // every input plane of layer L is complete on both neighbours from here on
+        // Non-seam layers with >= 3 chunks read the neighbours' newest plane only in their LAST chunk (staged during
+        // chunk n-2 >= 1): issue the flag loads now, compute chunk 0 (old data) under their latency, check after it.
+        const bool late_check = PT_LATE_FLAGS && L > 0 && !(lay.flags & 8) && lay.nchunk >= 3;
+        if (L > 0 && !late_check) ensure_flags(L);   // every input plane of layer L is complete on both neighbours
         if (aborted) return;
+        if (late_check && tid == 0) {
+            if (up >= 0) f_up = __hip_atomic_load(pp.prog + up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (dn >= 0) f_dn = __hip_atomic_load(pp.prog + dn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         const bool has_next_prefetch = (L + 1 < pp.nlayers) && !(pp.layers[L + 1 < pp.nlayers ? L + 1 : L].flags & 8);
         const PLayer nlay = pp.layers[L + 1 < pp.nlayers ? L + 1 : L];
         unsigned long long p1 = 0;
@@ -254,11 +264,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         // The chunk loop below must stay as plain as the per-layer kernel's (barrier + one compute body): with any
         // extra control flow inside it hipcc parks the loop-carried accumulators in VGPRs and copies all of them back
         // into AGPRs at the top of every chunk.  So everything protocol-related happened in the layer prologue.
-        for (int c = 0; c < n; ++c) {
-            if (c > 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of step gs has landed ...
-                __syncthreads();                                   // ... and everybody else's; all waves are past step gs-1
-            }
+        auto step = [&](const int c) {
             int next_cb = 0;
             const char* nsrc = nullptr;
             const char* nw = nullptr;
@@ -273,6 +279,24 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
             }
             compute(next_cb, nsrc, nw);
             ++gs;
+        };
+        int c0 = 0;
+        if (late_check) {            // peeled chunk 0: runs under the latency of the flag loads issued in the prologue
+            step(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            ensure_flags(L);
+            if (aborted) return;
+            c0 = 1;
+            step(1);                 // (its barrier was the one above)
+            c0 = 2;
+        }
+        for (int c = c0; c < n; ++c) {
+            if (c > 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of step gs has landed ...
+                __syncthreads();                                   // ... and everybody else's; all waves are past step gs-1
+            }
+            step(c);
         }
         if (aborted) return;
         if (pp.prof) ts1 = __builtin_amdgcn_s_memtime();
