@@ -60,7 +60,10 @@ def cpu_baseline(sd, seconds_budget=20.0):
                 "sample": f"oracle RRDBNet.forward_feature fp32, ONE B=1 call incl. warm-up ({t_first:.1f} s of CPU work)"}
     bs = 4 if t_first * 4 * 3 < seconds_budget else 1
     times, t_start = [], time.perf_counter()
-    while len(times) < 3 and time.perf_counter() - t_start < seconds_budget:
+    # at least 3 calls; keep sampling until ~10 s of CPU work (bounded by the budget) so fast hosts are not under-sampled
+    while len(times) < 3 or (time.perf_counter() - t_start < min(10.0, seconds_budget) and len(times) < 64):
+        if len(times) >= 3 and time.perf_counter() - t_start >= seconds_budget:
+            break
         t0 = time.perf_counter()
         O.rrdbnet_forward_feature(sd_cpu, x[:bs])
         times.append(time.perf_counter() - t0)

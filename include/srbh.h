@@ -164,6 +164,13 @@ typedef struct srbh_hconv_args {
     int pixelshuffle2;
     float* out;
     double* stats;
+    /* optional extensions (0 / NULL = off), used by the strict fp32 trunk: strided views into wider NHWC buffers,
+     * LeakyReLU(0.2) and the two residual forms y*s1 + res1, (..)*s2 + res2 (SR/rrdbnet_arch.py:143,167) */
+    int src0_ld, src1_ld;      /* floats between consecutive pixels of src0 / src1 (default c0 / c1) */
+    int out_ld, out_coff;      /* pixel stride and first channel of the output view (default cout, 0) */
+    int post_lrelu;
+    const float* res1; int res1_ld; float res1_scale;
+    const float* res2; int res2_ld; float res2_scale;
 } srbh_hconv_args;
 int srbh_hconv_f32(const srbh_hconv_args* a, void* stream);
 
@@ -182,6 +189,8 @@ int srbh_bn_add_relu(const float* a, const float* a_scale, const float* a_shift,
                      const float* i_scale, const float* i_shift, float* out, long npix, int C, void* stream);
 /* aggregate_torch (aggregate_utils.py:29-41): data [N][H][W] fp32 -> out [N][H/step][W/step] */
 int srbh_aggregate(const float* data, float* out, int N, int H, int W, int step, void* stream);
+/* F.interpolate(scale_factor=2, mode='nearest') on NHWC fp32 (SR/rrdbnet_arch.py:236-237); H, W = output size */
+int srbh_nearest2x_f32(const float* src, float* dst, int B, int H, int W, int C, void* stream);
 /* NCHW fp32 -> NHWC fp32 */
 int srbh_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, void* stream);
 

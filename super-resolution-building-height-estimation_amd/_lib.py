@@ -74,6 +74,9 @@ class HConvArgs(C.Structure):
         ("w", C.c_void_p), ("bias", C.c_void_p), ("cout", C.c_int), ("ksize", C.c_int),
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("pixelshuffle2", C.c_int),
         ("out", C.c_void_p), ("stats", C.c_void_p),
+        ("src0_ld", C.c_int), ("src1_ld", C.c_int), ("out_ld", C.c_int), ("out_coff", C.c_int), ("post_lrelu", C.c_int),
+        ("res1", C.c_void_p), ("res1_ld", C.c_int), ("res1_scale", C.c_float),
+        ("res2", C.c_void_p), ("res2_ld", C.c_int), ("res2_scale", C.c_float),
     ]
 
 
@@ -121,6 +124,7 @@ SIGNATURES = {
     "srbh_bn_eval_scale_shift": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "srbh_bn_add_relu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp]),
     "srbh_aggregate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "srbh_nearest2x_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_hconv_wgrad_f32": (_i, [C.POINTER(HWGradArgs), _vp]),
     "srbh_relu_mask_mul": (_i, [_vp, _vp, _vp, C.c_long, _vp]),

@@ -45,6 +45,10 @@ struct HParams {
     float* out;
     double* stats;                                     // [NSLOT][2][cout] or nullptr
     int tiles_x, tiles_per_img;
+    int ld0, ld1, out_ld, out_coff;                    // pixel strides (floats) of src0 / src1 / out, channel offset of out
+    int post_lrelu;
+    const float* res1; int res1_ld; float res1_scale;  // y = y*res1_scale + res1 ; then y = y*res2_scale + res2
+    const float* res2; int res2_ld; float res2_scale;
 };
 
 // NOB = cout/16 (1 or 4), KS = 3 or 1
@@ -67,7 +71,8 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
     const int Y0 = ty * HT_H, X0 = tx * HT_W;
     const int cin = p.c0 + p.c1;
     const int nchunk = (cin + HC - 1) / HC;
-    const bool vec0 = (p.c0 & 3) == 0, vec1 = p.c1 > 0 && (p.c1 & 3) == 0 && (p.c0 & 3) == 0;
+    const bool vec0 = (p.c0 & 3) == 0 && (p.ld0 & 3) == 0,
+               vec1 = p.c1 > 0 && (p.c1 & 3) == 0 && (p.c0 & 3) == 0 && (p.ld1 & 3) == 0;
 
     floatx4 acc[NOB][8];
 #pragma unroll
@@ -87,12 +92,12 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
             if (y >= 0 && y < p.H && x >= 0 && x < p.W && ch < cin) {
                 const long pixi = ((long)img * p.H + y) * p.W + x;
                 if (vec0 && ch + 3 < p.c0) {            // 16-byte path: the 4 channels sit in src0
-                    floatx4 a = *(const floatx4*)(p.src0 + pixi * p.c0 + ch);
+                    floatx4 a = *(const floatx4*)(p.src0 + pixi * p.ld0 + ch);
                     if (p.pre_scale) a = a * *(const floatx4*)(p.pre_scale + ch) + *(const floatx4*)(p.pre_shift + ch);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = p.pre_relu ? fmaxf(a[j], 0.f) : a[j];
                 } else if (vec1 && ch >= p.c0 && ch + 3 < cin) {   // ... or in src1
-                    const floatx4 a = *(const floatx4*)(p.src1 + pixi * p.c1 + (ch - p.c0));
+                    const floatx4 a = *(const floatx4*)(p.src1 + pixi * p.ld1 + (ch - p.c0));
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = a[j];
                 } else
@@ -100,12 +105,12 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                 for (int j = 0; j < 4; ++j) {
                     const int cc = ch + j;
                     if (cc < p.c0) {
-                        float a = p.src0[pixi * p.c0 + cc];
+                        float a = p.src0[pixi * p.ld0 + cc];
                         if (p.pre_scale) a = a * p.pre_scale[cc] + p.pre_shift[cc];
                         if (p.pre_relu) a = fmaxf(a, 0.f);
                         v[j] = a;
                     } else if (cc < cin) {
-                        v[j] = p.src1[pixi * p.c1 + (cc - p.c0)];
+                        v[j] = p.src1[pixi * p.ld1 + (cc - p.c0)];
                     }
                 }
             }
@@ -152,6 +157,15 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
             const int oc = ob * 16 + kk * 4;
             floatx4 v = acc[ob][i];
             if (p.bias) v += *(const floatx4*)(p.bias + oc);
+            if (ok && p.res1) {      // residual epilogues of the strict fp32 trunk (x5*0.2 + x, out*0.2 + x)
+                const long pixr = ((long)img * p.H + Y) * p.W + X;
+                v = v * p.res1_scale + *(const floatx4*)(p.res1 + pixr * p.res1_ld + oc);
+                if (p.res2) v = v * p.res2_scale + *(const floatx4*)(p.res2 + pixr * p.res2_ld + oc);
+            }
+            if (p.post_lrelu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = v[q] >= 0.f ? v[q] : v[q] * 0.2f;
+            }
             if (ok) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -170,8 +184,8 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                         }
                     }
                 } else {
-                    float* o = p.out + (((long)img * p.H + Y) * p.W + X) * p.cout_store + oc;
-                    if ((p.cout_store & 3) == 0) {
+                    float* o = p.out + (((long)img * p.H + Y) * p.W + X) * p.out_ld + p.out_coff + oc;
+                    if ((p.cout_store & 3) == 0 && (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0) {
                         if (oc < p.cout_store) *(floatx4*)o = v;
                     } else {
 #pragma unroll
@@ -320,6 +334,19 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __rest
     dst[idx] = src[(((long)b * C + c) * H + y) * W + x];
 }
 
+// F.interpolate(scale_factor=2, mode='nearest') on NHWC fp32: out[y][x] = in[y>>1][x>>1] (SR/rrdbnet_arch.py:236-237)
+__global__ void nearest2x_kernel(const floatx4* __restrict__ src, floatx4* __restrict__ dst, int B, int H, int W, int C4) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over dst float4s, H,W = OUTPUT size
+    long total = (long)B * H * W * C4;
+    if (idx >= total) return;
+    int c = idx % C4;
+    long r = idx / C4;
+    int x = r % W; r /= W;
+    int y = r % H;
+    int b = r / H;
+    dst[idx] = src[(((long)b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * C4 + c];
+}
+
 template <int NOB, int KS>
 int launch_hconv(const HParams& p, int nblocks, hipStream_t st) {
     constexpr int LDS_B = (IN_DW + KS * KS * 4 * NOB * 64) * 4;
@@ -370,6 +397,16 @@ extern "C" int srbh_hconv_f32(const srbh_hconv_args* a, void* stream) {
     p.pre_scale = a->pre_scale; p.pre_shift = a->pre_shift; p.pre_relu = a->pre_relu;
     p.w = a->w; p.bias = a->bias;
     p.cout = nob * 16; p.cout_store = a->cout;
+    p.ld0 = a->src0_ld > 0 ? a->src0_ld : a->c0;
+    p.ld1 = a->src1_ld > 0 ? a->src1_ld : a->c1;
+    p.out_ld = a->out_ld > 0 ? a->out_ld : a->cout;
+    p.out_coff = a->out_coff;
+    p.post_lrelu = a->post_lrelu;
+    p.res1 = a->res1; p.res1_ld = a->res1_ld; p.res1_scale = a->res1_scale;
+    p.res2 = a->res2; p.res2_ld = a->res2_ld; p.res2_scale = a->res2_scale;
+    SRBH_REQUIRE(!a->pixelshuffle2 || (a->out_ld <= 0 && a->out_coff == 0), "srbh_hconv_f32: PixelShuffle store needs a dense output");
+    SRBH_REQUIRE(!a->res1 || (a->cout % 4 == 0 && a->res1_ld % 4 == 0), "srbh_hconv_f32: residual epilogue needs 4-aligned channels");
+    SRBH_REQUIRE(!a->res2 || a->res1, "srbh_hconv_f32: res2 requires res1");
     p.B = a->B; p.H = a->H; p.W = a->W; p.ps2 = a->pixelshuffle2;
     p.out = a->out; p.stats = a->stats;
     p.tiles_x = (a->W + HT_W - 1) / HT_W;
@@ -425,6 +462,16 @@ extern "C" int srbh_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C,
     SRBH_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "srbh_nchw_to_nhwc_f32: bad arguments");
     long total = (long)B * C * H * W;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, B, C, H, W);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_nearest2x_f32(const float* src, float* dst, int B, int H, int W, int C, void* stream) {
+    SRBH_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && H % 2 == 0 && W % 2 == 0,
+                 "srbh_nearest2x_f32: bad arguments (H, W are the OUTPUT size, C %% 4 == 0)");
+    long total = (long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(nearest2x_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const floatx4*)src,
+                       (floatx4*)dst, B, H, W, C / 4);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }

@@ -205,6 +205,11 @@ class RRDBNet(nn.Module):
                                "fallback (use oracle/ in tests for a CPU comparison)")
         if x.dim() != 4:
             raise ValueError(f"expected a (B,C,H,W) tensor, got shape {tuple(x.shape)}")
+        if self._use_strict():
+            if self._geom[2] != 64 or self._geom[4] != 32:
+                raise NotImplementedError("libsrbh RRDBNet kernels are specialised for num_feat=64, num_grow_ch=32")
+            with torch.cuda.device(x.device):
+                return self._run_strict(x, want_forward)
         if self.scale == 2:
             x = pixel_unshuffle(x, 2)
         elif self.scale == 1:
@@ -235,6 +240,81 @@ class RRDBNet(nn.Module):
         for (B, H, W, wf, dev), ws in self._workspaces.items():
             with torch.cuda.device(dev):
                 _lib.check(L.srbh_rrdbnet_last_status(ws.data_ptr(), B, H, W, wf, _lib.stream_ptr()), "rrdbnet_last_status")
+
+    # ---- strict fp32 path -------------------------------------------------------------------------------------
+    def _run_strict(self, x, want_forward):
+        """The same network on libsrbh's exact-fp32 matrix-core conv (v_mfma_f32_16x16x4_f32, csrc/srbh_head.hip):
+        every conv, residual and activation in fp32, one kernel launch per conv.  ~20x slower than the fp16-operand
+        path; it is the strict-parity mode (agrees with the fp32 reference to ~1e-6) and the on-device yardstick the
+        fast path is reported against.  Select with ``net.precision = "f32"`` or SRBH_TRUNK_PRECISION=f32."""
+        from . import hrfuse as H
+        L = _lib.lib()
+        if self.scale == 2:
+            x = pixel_unshuffle(x, 2)
+        elif self.scale == 1:
+            x = pixel_unshuffle(x, 4)
+        x = H.to_nhwc(x.detach().to(torch.float32))
+        B, _, Hh, Ww = x.shape
+        dev = x.device
+        packs = self.__dict__.setdefault("_strict_packs", {})
+
+        def conv(mod, src, c0, ld0, out, out_ld=0, out_coff=0, lrelu=False, res1=None, res2=None):
+            w, b = packs.setdefault(id(mod), H._PackedConv()).get(mod)
+            a = _lib.HConvArgs()
+            a.src0, a.c0, a.src0_ld = src.data_ptr(), c0, ld0
+            a.w, a.bias = w.data_ptr(), (b.data_ptr() if b is not None else None)
+            a.cout, a.ksize = mod.out_channels, 3
+            a.B, a.H, a.W = src.shape[0], src.shape[1], src.shape[2]
+            a.out, a.out_ld, a.out_coff, a.post_lrelu = out.data_ptr(), out_ld, out_coff, int(lrelu)
+            if res1 is not None:
+                a.res1, a.res1_ld, a.res1_scale = res1[0].data_ptr(), res1[1], res1[2]
+            if res2 is not None:
+                a.res2, a.res2_ld, a.res2_scale = res2[0].data_ptr(), res2[1], res2[2]
+            _lib.check(L.srbh_hconv_f32(C.byref(a), _lib.stream_ptr()), "hconv_f32(strict trunk)")
+
+        def up2(t):
+            Bn, Hn, Wn, Cn = t.shape
+            o = torch.empty((Bn, 2 * Hn, 2 * Wn, Cn), dtype=torch.float32, device=dev)
+            _lib.check(L.srbh_nearest2x_f32(t.data_ptr(), o.data_ptr(), Bn, 2 * Hn, 2 * Wn, Cn, _lib.stream_ptr()), "nearest2x")
+            return o
+
+        xs = x.permute(0, 2, 3, 1)                      # (B,H,W,C) view of the NHWC memory
+        assert xs.is_contiguous()
+        feat = torch.empty((B, Hh, Ww, 64), dtype=torch.float32, device=dev)
+        conv(self.conv_first, xs, xs.shape[3], xs.shape[3], feat)
+        D = [torch.zeros((B, Hh, Ww, 192), dtype=torch.float32, device=dev) for _ in range(2)]
+        D[0][..., :64].copy_(feat)
+        xrr = feat.clone()
+        cur = 0
+        for blk in self.body:
+            for r in (1, 2, 3):
+                rdb = getattr(blk, f"rdb{r}")
+                for k in range(1, 5):                  # lrelu(conv_k(cat(x, x1..x_{k-1}))) -> channels 64+32(k-1)..
+                    c0 = 64 + 32 * (k - 1)
+                    conv(getattr(rdb, f"conv{k}"), D[cur], c0, 192, D[cur], 192, c0, lrelu=True)
+                conv(rdb.conv5, D[cur], 192, 192, D[cur ^ 1], 192, 0, res1=(D[cur], 192, 0.2),
+                     res2=(xrr, 64, 0.2) if r == 3 else None)
+                cur ^= 1
+            xrr.copy_(D[cur][..., :64])
+        body = torch.empty((B, Hh, Ww, 64), dtype=torch.float32, device=dev)
+        conv(self.conv_body, D[cur], 64, 192, body, res1=(feat, 64, 1.0))          # feat + conv_body(body_out)
+        t = up2(body)
+        u1 = torch.empty_like(t)
+        conv(self.conv_up1, t, 64, 64, u1, lrelu=True)
+        t = up2(u1)
+        u2 = torch.empty_like(t)
+        conv(self.conv_up2, t, 64, 64, u2, lrelu=True)
+        hr = torch.empty_like(u2)
+        conv(self.conv_hr, u2, 64, 64, hr, lrelu=want_forward)
+        if not want_forward:
+            return hr.permute(0, 3, 1, 2)
+        out = torch.empty((B, 4 * Hh, 4 * Ww, self._geom[1]), dtype=torch.float32, device=dev)
+        conv(self.conv_last, hr, 64, 64, out)
+        return out.permute(0, 3, 1, 2)
+
+    def _use_strict(self):
+        import os
+        return getattr(self, "precision", os.environ.get("SRBH_TRUNK_PRECISION", "f16")) in ("f32", "fp32", "strict")
 
     def forward(self, x):
         """reference SR/rrdbnet_arch.py:208-223 -> (B,num_out_ch,4H,4W), channels_last strides."""

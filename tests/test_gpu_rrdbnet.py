@@ -129,3 +129,32 @@ def test_persistent_and_per_layer_paths_agree(monkeypatch):
             monkeypatch.setenv("SRBH_PERSISTENT", "0")
             y0 = net.forward_feature(x)
         assert torch.equal(y0, y1), (B, hw)
+
+
+def test_strict_fp32_path_matches_reference_and_bounds_the_fast_path(golden_dir):
+    """precision='f32': exact-fp32 matrix-core convs -> agrees with the fp32 reference to rounding (1e-5), and is the
+    on-device yardstick for the default fp16-operand path (<= 1e-3)."""
+    g = np.load(os.path.join(golden_dir, "g3_rrdbnet_small.npz"))
+    for scale, hw in ((4, 8), (2, 16)):
+        sd = synth.rrdbnet_state_dict(num_block=2, scale=scale, seed=12, mode="stress")
+        net = build(sd, scale=scale, num_block=2)
+        net.precision = "f32"
+        x = rnd((1, 3, hw, hw), 103 + scale)
+        with torch.no_grad():
+            ff, fw = net.forward_feature(x.to(DEV)), net(x.to(DEV))
+        assert O.rel_l2(ff.cpu(), torch.from_numpy(g[f"ff_s{scale}"])) <= 1e-5
+        assert O.rel_l2(fw.cpu(), torch.from_numpy(g[f"fw_s{scale}"])) <= 1e-5
+    gg = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, "g4_rrdbnet_full_stress.npz")).items()}
+    sd = synth.rrdbnet_state_dict(seed=1337, mode="stress")
+    net = build(sd)
+    x = synth.tiles(2, 8, 64, seed=1337)[:, :3].contiguous().to(DEV)
+    with torch.no_grad():
+        fast = net.forward_feature(x)
+        net.precision = "f32"
+        strict = net.forward_feature(x)
+    assert strict.shape == fast.shape == (2, 64, 256, 256)
+    assert O.rel_l2(strict[0, :, 124:132, 124:132].cpu(), gg["crop_ce"]) <= 2e-5      # vs the reference itself
+    assert O.rel_l2(strict[:1].double().mean((0, 2, 3)).cpu(), gg["ch_mean"]) <= 2e-5
+    e = O.rel_l2(fast.cpu(), strict.cpu())
+    print(f"fp16-operand path vs strict fp32 path: rel-L2 {e:.3e}")
+    assert e <= REL_TOL
