@@ -516,6 +516,8 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
         pp.nblocks = nb * tpi;
         pp.prog = d_prog + b0 * tpi;
         pp.err = d_err;
+        if (getenv("SRBH_PT_PROF") && !g_ptrunk_prof)
+            SRBH_HIP(hipMalloc(&g_ptrunk_prof, (size_t)ncu * MAX_BLOCKS * 15 * 6 * 8));
         pp.prof = g_ptrunk_prof;
         {
             const char* e = getenv("SRBH_PT_STAGGER");
@@ -523,6 +525,28 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
         }
         hipLaunchKernelGGL(ptrunk_kernel, dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
         SRBH_HIP(hipGetLastError());
+    }
+    if (getenv("SRBH_PT_PROF") && g_ptrunk_prof) {   // developer aid: cycles vs wall clock of the real forward
+        SRBH_HIP(hipStreamSynchronize(stream));
+        const int nblk = (B < imgs_per_launch ? B : imgs_per_launch) * tpi;
+        std::vector<unsigned long long> h((size_t)nblk * nl * 6);
+        SRBH_HIP(hipMemcpy(h.data(), g_ptrunk_prof, h.size() * 8, hipMemcpyDeviceToHost));
+        double cyc = 0;
+        for (int b = 0; b < nblk; ++b) cyc += (double)(h[((size_t)b * nl + nl - 1) * 6 + 2] - h[(size_t)b * nl * 6]);
+        fprintf(stderr, "[srbh] ptrunk: avg %.0f shader cycles per workgroup (first layer start -> last epilogue)\n", cyc / nblk);
+        double loop[5] = {0}, epi[5] = {0}, pub[5] = {0}, wait[5] = {0}, tot5[5] = {0};
+        for (int b = 0; b < nblk; ++b)
+            for (int L = 1; L + 1 < nl; ++L) {
+                const unsigned long long* q = &h[((size_t)b * nl + L) * 6];
+                const unsigned long long* qn = &h[((size_t)b * nl + L + 1) * 6];
+                const int k = L % 5;
+                loop[k] += (double)(q[1] - q[0]); epi[k] += (double)(q[2] - q[1]); pub[k] += (double)(q[3] >> 32);
+                wait[k] += (double)(q[3] & 0xffffffffu); tot5[k] += (double)(qn[0] - q[0]);
+            }
+        const double cnt = (double)nblk * (nl - 2) / 5.0;
+        for (int k = 0; k < 5; ++k)
+            fprintf(stderr, "[srbh]   conv%d: loop %.0f (flag-wait %.0f) | epilogue %.0f | publish/seam %.0f | start-to-start %.0f\n",
+                    k + 1, loop[k] / cnt, wait[k] / cnt, epi[k] / cnt, pub[k] / cnt, tot5[k] / cnt);
     }
     *used = 1;
     return SRBH_OK;
