@@ -235,6 +235,17 @@ int srbh_mosaic_accumulate(const float* height, const float* build, int C, int B
 int srbh_mosaic_finalize(const unsigned* res_height, const unsigned* res_build, const unsigned* res_weight, int C, int H,
                          int W, unsigned short* height_out, unsigned char* build_out, void* stream);
 
+/* ---- loader-side tensor math (BH_loader.py:30-61,326-329,361-392) --------------------------------
+ * label_prep: height uint8 [B][H][W] -> build (int64 class = buildhir_lut[height]), height as float,
+ *   weight = class_weight[build], and per 4x4 cell height_aggre = aggregate_torch(height, 0.25),
+ *   weight_aggre = class_weight[buildhir_lut[(long)height_aggre]]  ([B][H/4][W/4]).
+ * normalize_clamp: dst = clip((src - mins[c]) / ranges[c], lo, hi) on NCHW fp32 (clip only when clamp != 0). */
+int srbh_label_prep(const unsigned char* height, int B, int H, int W, const unsigned char* buildhir_lut,
+                    const float* class_weight, long long* build, float* height_f, float* weight, float* height_aggre,
+                    float* weight_aggre, void* stream);
+int srbh_normalize_clamp(const float* src, float* dst, int B, int C, int H, int W, const float* mins, const float* ranges,
+                         float lo, float hi, int clamp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -222,7 +222,31 @@ def g_aggregate():
     save("g8_aggregate", label=lab.to(torch.int16), out=want)
 
 
+# ---- G9: hierweight known answers (BH_loader.py:30-55; the author's expected vectors are at :1122-1129) ----------------
+def g_hierweight():
+    class _Dummy(types.ModuleType):        # BH_loader imports GIS / augmentation libs at module level; none is used here
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return lambda *a, **k: None
+    for m in ("tifffile", "albumentations", "osgeo", "osgeo.gdal", "geopandas", "matplotlib", "matplotlib.pyplot"):
+        sys.modules[m] = _Dummy(m)
+    sys.modules["cv2"] = _Dummy("cv2")
+    sys.modules["osgeo"].gdal = sys.modules["osgeo.gdal"]
+    import BH_loader as ref_loader
+    stats = np.loadtxt("/root/reference/datasetglobe/bh_stats_globe.txt")
+    h255, h256 = (0, 3, 12, 21, 30, 60, 90, 255), (0, 3, 12, 21, 30, 60, 90, 256)
+    out = dict(stats=stats, sqrt255=ref_loader.hierweight(stats, h255), simple255=ref_loader.hierweight_simple(stats, h255),
+               sqrt256=ref_loader.hierweight(stats, h256), simple256=ref_loader.hierweight_simple(stats, h256))
+    assert np.allclose(out["sqrt255"], [0.08743518, 0.26821995, 0.32067124, 0.73515255, 0.98135007, 1.60267172, 3.0044993], atol=1e-7)
+    assert np.allclose(out["simple255"], [4.02924542e-03, 3.79169577e-02, 5.41965148e-02, 2.84843482e-01, 5.07573877e-01,
+                                          1.35375631e+00, 4.75768362e+00], rtol=1e-7)
+    print("  pinned G9 hierweight: reference functions reproduce the author's comment vectors")
+    save("g9_hierweight", **out)
+
+
 if __name__ == "__main__":
+    g_hierweight()
     g_rdb()
     g_small_net()
     g_index_maps()
