@@ -17,6 +17,9 @@
 #include <stdlib.h>
 #include "srbh_conv3x3_kernel.h"
 
+#ifndef PT_SPLIT_DRAIN
+#define PT_SPLIT_DRAIN 0
+#endif
 #ifndef PT_LATE_FLAGS
 #define PT_LATE_FLAGS 0   // measured slower: the peel re-introduces accumulator copies
 #endif
@@ -54,6 +57,10 @@ using G = TileGeo<0>;
 constexpr int P_STAGE_B = G::IN_B + 36 * 1024;      // one pipeline stage: input tile + weight chunk sized for cout 64
 constexpr int JPP = (G::NJ + 5) / 6;
 static_assert(2 * P_STAGE_B <= 163840, "two stages must fit the 160 KiB LDS");
+// The input area of a stage is padded to whole LDS-DMA instructions; the tail lanes are masked off, which frees the pad
+// of stage 0 for the double-buffered per-layer bias vector.
+constexpr int P_BIAS_OFF = G::UNITS * 16;
+static_assert(P_BIAS_OFF + 2 * 64 * 4 <= G::IN_B, "bias slots must fit the stage-0 pad");
 
 // PLayer.flags bit 3 is set by the host when the layer's FIRST input chunk is produced by the previous layer
 // (conv1 of an RDB reads the x written by the previous conv5): it can be neither prefetched nor published lazily.
@@ -83,6 +90,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         const int pc = rem >> 2, ps = rem & 3;
         goff[j] = trow * pp.row_b + pc * PIX_B + ((ps ^ ((pc >> 2) & 3)) << 4);
     }
+    const bool tail_ok = (G::NJ - 1) * 256 + tid < G::UNITS;   // lanes of the last DMA instruction that carry tile data
     int aoff[3][2];
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
 #pragma unroll
         for (int jj = 0; jj < JPP; ++jj) {
             const int j = part * JPP + jj;
-            if (j < G::NJ)   // activations: sc1 = bypass this CU's L1 (they were written by other CUs inside this launch)
+            if (j < G::NJ && (j < G::NJ - 1 || tail_ok))   // activations: sc1 = bypass this CU's L1 (written by other CUs in this launch)
                 __builtin_amdgcn_global_load_lds(GPTR(src + goff[j < G::NJ ? j : 0]),
                                                  LPTR(dst + (j * 256 + wave * 64) * 16), 16, 0, 16);
         }
@@ -171,7 +179,12 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         if (pp.prof) p0 = __builtin_amdgcn_s_memtime();
         // LDS-DMA completion is NOT reliably waited for by hipcc before a barrier (seen: no vmcnt at all in this loop
         // shape) -> always drain explicitly.  vmcnt(0) also covers this workgroup's write-through stores of layer L-1.
+        // The layer's bias goes through LDS (slot L&1): its global-load latency hides under the drain below instead of
+        // opening the epilogue, and no registers are held across the chunk loop.
+        float bias_v = 0.f;
+        if (tid < lay.cb * 32) bias_v = lay.bias[tid];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid < lay.cb * 32) ((float*)(smem + P_BIAS_OFF))[(L & 1) * 64 + tid] = bias_v;
         __syncthreads();   // step (L,0) landed on every wave
         if (pending_pub) {
             if (tid == 0) __hip_atomic_store(pp.prog + t, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
 #pragma unroll
                     for (int jj = 0; jj < JPP; ++jj) {
                         const int j = g * JPP + jj;
-                        if (j < G::NJ)
+                        if (j < G::NJ && (j < G::NJ - 1 || tail_ok))
                             __builtin_amdgcn_global_load_lds(GPTR(nsrc + goff[j < G::NJ ? j : 0]),
                                                              LPTR(dst + (j * 256 + wave * 64) * 16), 16, 0, 16);
                     }
@@ -305,97 +318,136 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         // channel group g, the 4 consecutive channels 8g + 4hi + (0..3) of pixel l31.  fp32 residual traffic is already
         // 16 B per lane; the fp16 output is widened from 8 to 16 B per lane with v_permlane32_swap (the two half-waves
         // exchange one 4-channel packet so that each ends up with 8 consecutive channels).
-        const bool lrelu = lay.flags & 1, r1 = lay.flags & 2, r2 = lay.flags & 4;
+        // The trunk has exactly two layer shapes and ptrunk_run() builds nothing else: cout 32 + leaky ReLU (conv1-4) and
+        // cout 64 + residual(s) (conv5).  Tying the epilogue variant to CB at compile time keeps selects out of a
+        // VALU-bound epilogue (flags 1 and 2 of the table are implied; flag 4 stays a run-time property).
+        constexpr bool lrelu = (CB == 1), r1 = (CB == 2);
+        const bool r2 = r1 && (lay.flags & 4);
         char* obase = pp.dense[lay.out_sel] + (long)img * pp.img_b + (long)lay.out_chunk0 * pp.plane_b;
         floatx4 bias4[CB][4];
 #pragma unroll
         for (int mb = 0; mb < CB; ++mb)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bias4[mb][g] = *(const floatx4*)(lay.bias + mb * 32 + g * 8 + hi * 4);
+            for (int g = 0; g < 4; ++g)
+                bias4[mb][g] = *(const floatx4*)((const float*)(smem + P_BIAS_OFF) + (L & 1) * 64 + mb * 32 + g * 8 + hi * 4);
         const int X = wc * 32 + l31;
+        // rows are processed NR at a time: all residual loads of the group are issued before any of them is consumed
+        // (per-row processing left only 8-16 loads in flight per wave and made the fp32 residual RMW latency-bound)
+        auto process_rows = [&](auto nr_tag, const int i0) {
+            constexpr int NR = decltype(nr_tag)::value;
+            floatx4 a1[NR][CB][4], a2[NR][CB][4];
+            bool valid[NR];
+            long pix[NR];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int Y = Y0 + wr * 4 + i;
-            const bool valid = (Y < pp.H) && (X < pp.W);
-            const long pix = ((long)img * pp.H + Y) * pp.W + X;
-            floatx4 v[CB][4];
+            for (int k = 0; k < NR; ++k) {
+                const int Y = Y0 + wr * 4 + i0 + k;
+                valid[k] = (Y < pp.H) && (X < pp.W);
+                pix[k] = ((long)img * pp.H + Y) * pp.W + X;
+                if (r1 && valid[k]) {
+                    const float* q1 = pp.xr + pix[k] * 64 + hi * 4;
 #pragma unroll
-            for (int mb = 0; mb < CB; ++mb)
+                    for (int mb = 0; mb < CB; ++mb)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                        for (int g = 0; g < 4; ++g) a1[k][mb][g] = *(const floatx4*)(q1 + mb * 32 + g * 8);
+                    if (r2) {
+                        const float* q2 = pp.xrr + pix[k] * 64 + hi * 4;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[mb][g][q] = acc[mb][i][g * 4 + q];
-                    v[mb][g] += bias4[mb][g];
+                        for (int mb = 0; mb < CB; ++mb)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) a2[k][mb][g] = *(const floatx4*)(q2 + mb * 32 + g * 8);
+                    }
                 }
-            if (r1 && valid) {
-                float* q1 = pp.xr + pix * 64 + hi * 4;
-                floatx4 a1[CB][4];
+            }
+            floatx4 vv[NR][CB][4];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                const int i = i0 + k;
+                const int Y = Y0 + wr * 4 + i;
 #pragma unroll
                 for (int mb = 0; mb < CB; ++mb)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) a1[mb][g] = *(const floatx4*)(q1 + mb * 32 + g * 8);
-                if (r2) {
-                    float* q2 = pp.xrr + pix * 64 + hi * 4;
-                    floatx4 a2[CB][4];
+                    for (int g = 0; g < 4; ++g) {
+                        floatx4 t;
 #pragma unroll
-                    for (int mb = 0; mb < CB; ++mb)
+                        for (int q = 0; q < 4; ++q) t[q] = acc[mb][i][g * 4 + q];
+                        t += bias4[mb][g];
+                        if (r1) {
+                            t = t * 0.2f + a1[k][mb][g];
+                            if (r2) t = t * 0.2f + a2[k][mb][g];
+                        }
+                        vv[k][mb][g] = t;
+                    }
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) a2[mb][g] = *(const floatx4*)(q2 + mb * 32 + g * 8);
+                for (int mb = 0; mb < CB; ++mb) {
+                    unsigned hp[4][2];   // packed fp16 pairs of the 4 channel groups
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        floatx4 w = vv[k][mb][g];
+                        // leaky ReLU as max(x, 0.2x) with a bare v_max_f32: fmaxf() costs two extra canonicalising
+                        // v_max per value and this epilogue is VALU-bound
+                        if (lrelu) {
+                            const floatx4 ws = w * 0.2f;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) asm("v_max_f32 %0, %1, %2" : "=v"(w[q]) : "v"(w[q]), "v"(ws[q]));
+                        }
+                        half4 h4;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) h4[q] = (_Float16)w[q];
+                        const uint2 u = __builtin_bit_cast(uint2, h4);
+                        hp[g][0] = u.x;
+                        hp[g][1] = u.y;
+                    }
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        // lower half-wave ends with channels 16m + 0..7, upper half-wave with 16m + 8..15
+                        auto s0 = __builtin_amdgcn_permlane32_swap(hp[2 * m][0], hp[2 * m + 1][0], false, false);
+                        auto s1 = __builtin_amdgcn_permlane32_swap(hp[2 * m][1], hp[2 * m + 1][1], false, false);
+                        typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+                        const uintx4 raw = {s0[0], s1[0], s0[1], s1[1]};
+                        if (valid[k]) {
+                            char* o = obase + (long)mb * pp.plane_b + (long)(Y + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16;
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
+                        }
+                    }
+                }
+            }
+            // the private fp32 residual streams go out LAST: at an RDB seam only the write-through fp16 stores above have
+            // to be complete before the progress counter moves (see `seam` below), these may still be in flight
+            if (r1) {
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    if (!valid[k]) continue;
+                    float* q1 = pp.xr + pix[k] * 64 + hi * 4;
+                    float* q2 = pp.xrr + pix[k] * 64 + hi * 4;
 #pragma unroll
                     for (int mb = 0; mb < CB; ++mb)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            v[mb][g] = (v[mb][g] * 0.2f + a1[mb][g]) * 0.2f + a2[mb][g];
-                            *(floatx4*)(q2 + mb * 32 + g * 8) = v[mb][g];
-                            *(floatx4*)(q1 + mb * 32 + g * 8) = v[mb][g];
-                        }
-                } else {
-#pragma unroll
-                    for (int mb = 0; mb < CB; ++mb)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            v[mb][g] = v[mb][g] * 0.2f + a1[mb][g];
-                            *(floatx4*)(q1 + mb * 32 + g * 8) = v[mb][g];
+                            if (r2) *(floatx4*)(q2 + mb * 32 + g * 8) = vv[k][mb][g];
+                            *(floatx4*)(q1 + mb * 32 + g * 8) = vv[k][mb][g];
                         }
                 }
             }
-#pragma unroll
-            for (int mb = 0; mb < CB; ++mb) {
-                unsigned hp[4][2];   // packed fp16 pairs of the 4 channel groups
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    floatx4 w = v[mb][g];
-                    if (lrelu) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) w[q] = fmaxf(w[q], w[q] * 0.2f);   // == x>=0 ? x : 0.2x
-                    }
-                    half4 h4;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) h4[q] = (_Float16)w[q];
-                    const uint2 u = __builtin_bit_cast(uint2, h4);
-                    hp[g][0] = u.x;
-                    hp[g][1] = u.y;
-                }
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    // lower half-wave ends with channels 16m + 0..7, upper half-wave with 16m + 8..15
-                    auto s0 = __builtin_amdgcn_permlane32_swap(hp[2 * m][0], hp[2 * m + 1][0], false, false);
-                    auto s1 = __builtin_amdgcn_permlane32_swap(hp[2 * m][1], hp[2 * m + 1][1], false, false);
-                    typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
-                    const uintx4 raw = {s0[0], s1[0], s0[1], s1[1]};
-                    if (valid) {
-                        char* o = obase + (long)mb * pp.plane_b + (long)(Y + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16;
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
-                    }
-                }
-            }
+        };
+        if (r2) {
+            process_rows(std::integral_constant<int, 2>{}, 0);
+            process_rows(std::integral_constant<int, 2>{}, 2);
+        } else {
+            process_rows(std::integral_constant<int, 4>{}, 0);
         }
         if (pp.prof) ts2 = __builtin_amdgcn_s_memtime();
         // ---- publication of "layer L complete"
         const bool seam = (L + 1 == pp.nlayers) || (pp.layers[L + 1 < pp.nlayers ? L + 1 : L].flags & 8);
         if (seam) {
             // the next layer's first chunk is THIS layer's output on the neighbours: publish now, then wait for them
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // vmcnt counts this wave's outstanding VMEM ops and (no loads are pending here) stores retire in issue order:
+            // leaving the trailing 32 fp32 residual stores in flight still guarantees every write-through fp16 store.
+            // Only when all 4 rows of this wave were stored (the trailing count is then exact); else drain everything.
+            const bool full = PT_SPLIT_DRAIN && CB == 2 && r1 && (Y0 + wr * 4 + 3 < pp.H) && (pp.W >= TILE_W);
+            if (full)
+                asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) __hip_atomic_store(pp.prog + t, L + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (L + 1 < pp.nlayers) {
