@@ -4,11 +4,14 @@
 // One launch runs every layer: a workgroup owns (image, 8 output rows) for the whole trunk and walks a device-side
 // layer table.  What a per-layer launch pays on every conv (launch gap, cold prologue, store-drain tail) is paid once.
 // Row-block neighbours exchange their 1-row halos INSIDE the launch:
-//   producer : activations are stored write-through (global_store ... sc1), every wave drains vmcnt(0), barrier,
-//              one lane publishes prog[tile] = layers completed (relaxed, agent scope);
+//   producer : activations are stored, every wave drains vmcnt(0), barrier, one lane publishes
+//              prog[tile] = layers completed (relaxed atomic);
 //   consumer : one lane polls the two neighbours' prog words (relaxed agent loads + s_sleep, bounded), barrier,
-//              then reads the activations with sc1 LDS-DMA (L1 bypass) -- placement independent (no reliance on
-//              which XCD a workgroup landed on; the XCD-aware tile map only helps L2 locality).
+//              then reads the activations with sc1 LDS-DMA (L1 bypass).
+// The tile map (xcd_remap) puts the row blocks of one image on one XCD, so the exchange normally stays inside that
+// XCD's L2: plain stores, complete once they are in L2.  Placement is verified at kernel start (XCC_ID handshake with
+// both neighbours); a workgroup whose neighbour sits on another XCD falls back to write-through (sc1) stores and
+// agent-scope publishes, which are placement independent (measured: +6 % whole-forward for the in-L2 exchange).
 // Skew between neighbours is <= 1 layer (a layer cannot start before both neighbours finished the previous one),
 // while any plane is re-written no earlier than 5 layers after its last read, so there is no WAR hazard.
 // All workgroups must be co-resident (1 per CU: the kernel uses the whole 160 KiB LDS): the host launches at most
@@ -48,6 +51,9 @@ struct PParams {
     int H, W, tiles_per_img, nblocks;
     int* prog;
     int* err;
+    int* xcc;                   // [nblocks] XCC_ID + 1 of every workgroup (placement handshake)
+    int force_wt;               // 1: always use write-through stores (debugging aid, env SRBH_PT_WT=1)
+    int frag_res;               // 1: fp32 residual streams in fragment order inside the launch (W == TILE_W)
     int stagger;                // odd images start this many s_sleep(127) periods late (de-phases the HBM bursts)
     unsigned long long* prof;   // debug (tools/convbench): [block][layer][4] s_memtime stamps, nullptr in production
 };
@@ -167,6 +173,46 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         }
     };
 
+    // ---- where do my halo partners run?  Workgroups are dealt round-robin to the 8 XCDs and xcd_remap() puts the tiles
+    // of one image on one XCD, so normally both neighbours share this workgroup's L2 and the exchange never has to leave
+    // it: plain stores are complete (vmcnt) once they are in L2, and the neighbours' L1-bypassing reads find them there.
+    // That placement is a dispatcher habit, not a contract, so it is verified: every workgroup posts its XCC_ID and
+    // compares it with its neighbours'; any mismatch (or a neighbour that never answers) selects write-through (sc1)
+    // stores, which are placement independent.
+    bool wt = true;
+    {
+        int my_xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(my_xcc));
+        auto* word = (__attribute__((address_space(3))) int*)(smem);
+        if (tid == 0) {
+            __hip_atomic_store(pp.xcc + t, my_xcc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int diff = pp.force_wt;
+            for (int s = 0; s < 2 && !diff; ++s) {
+                const int nb = s ? dn : up;
+                if (nb < 0) continue;
+                int v = 0;
+                for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+                    v = __hip_atomic_load(pp.xcc + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (v != my_xcc + 1) diff = 1;
+            }
+            *word = diff;
+        }
+        __syncthreads();
+        wt = __builtin_amdgcn_readfirstlane(*word) != 0;
+        __syncthreads();
+    }
+    auto publish = [&](int v) {
+        if (tid == 0) {
+            if (wt)
+                __hip_atomic_store(pp.prog + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                __hip_atomic_store(pp.prog + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // reaches L2, no further
+        }
+    };
+
     bool pending_pub = false;
     int pub_val = 0;
 
@@ -187,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         if (tid < lay.cb * 32) ((float*)(smem + P_BIAS_OFF))[(L & 1) * 64 + tid] = bias_v;
         __syncthreads();   // step (L,0) landed on every wave
         if (pending_pub) {
-            if (tid == 0) __hip_atomic_store(pp.prog + t, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            publish(pub_val);
             pending_pub = false;
         }
         // Non-seam layers with >= 3 chunks read the neighbours' newest plane only in their LAST chunk (staged during
@@ -331,30 +377,41 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
             for (int g = 0; g < 4; ++g)
                 bias4[mb][g] = *(const floatx4*)((const float*)(smem + P_BIAS_OFF) + (L & 1) * 64 + mb * 32 + g * 8 + hi * 4);
         const int X = wc * 32 + l31;
+        // fp32 residual streams.  They are private to this workgroup -- each lane re-reads exactly the values it wrote one
+        // RDB earlier -- so inside the launch they live in "fragment order": within the wave's 32-pixel segment of a
+        // row, instruction (mb, g) owns 1 KiB and lane l its 16 B at l*16 (whole cache lines per instruction instead of
+        // 32 B pieces of 32 different lines).  Only the first read of each stream (written by conv_first) is in pixel
+        // order (flags 16 / 32); widths other than TILE_W keep pixel order throughout.  Float offsets:
+        struct ResForm { int lane, sm, sg; };
+        const ResForm pixel_form{X * 64 + hi * 4, 32, 8}, frag_form{wc * 2048 + lane * 4, 1024, 256};
+        const ResForm s1 = (!pp.frag_res || (lay.flags & 16)) ? pixel_form : frag_form;
+        const ResForm s2 = (!pp.frag_res || (lay.flags & 32)) ? pixel_form : frag_form;
+        const ResForm sd = pp.frag_res ? frag_form : pixel_form;
+        const float* res1_src = (lay.flags & 64) ? pp.xrr : pp.xr;
         // rows are processed NR at a time: all residual loads of the group are issued before any of them is consumed
         // (per-row processing left only 8-16 loads in flight per wave and made the fp32 residual RMW latency-bound)
         auto process_rows = [&](auto nr_tag, const int i0) {
             constexpr int NR = decltype(nr_tag)::value;
             floatx4 a1[NR][CB][4], a2[NR][CB][4];
             bool valid[NR];
-            long pix[NR];
+            long rowb[NR];   // float offset of image row Y in the RES32 streams
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
                 const int Y = Y0 + wr * 4 + i0 + k;
                 valid[k] = (Y < pp.H) && (X < pp.W);
-                pix[k] = ((long)img * pp.H + Y) * pp.W + X;
+                rowb[k] = ((long)img * pp.H + Y) * pp.W * 64;
                 if (r1 && valid[k]) {
-                    const float* q1 = pp.xr + pix[k] * 64 + hi * 4;
+                    const float* q1 = res1_src + rowb[k] + s1.lane;
 #pragma unroll
                     for (int mb = 0; mb < CB; ++mb)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) a1[k][mb][g] = *(const floatx4*)(q1 + mb * 32 + g * 8);
+                        for (int g = 0; g < 4; ++g) a1[k][mb][g] = *(const floatx4*)(q1 + mb * s1.sm + g * s1.sg);
                     if (r2) {
-                        const float* q2 = pp.xrr + pix[k] * 64 + hi * 4;
+                        const float* q2 = pp.xrr + rowb[k] + s2.lane;
 #pragma unroll
                         for (int mb = 0; mb < CB; ++mb)
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) a2[k][mb][g] = *(const floatx4*)(q2 + mb * 32 + g * 8);
+                            for (int g = 0; g < 4; ++g) a2[k][mb][g] = *(const floatx4*)(q2 + mb * s2.sm + g * s2.sg);
                     }
                 }
             }
@@ -406,7 +463,10 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
                         const uintx4 raw = {s0[0], s1[0], s0[1], s1[1]};
                         if (valid[k]) {
                             char* o = obase + (long)mb * pp.plane_b + (long)(Y + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16;
-                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
+                            if (wt)
+                                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
+                            else
+                                asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
                         }
                     }
                 }
@@ -417,15 +477,12 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
 #pragma unroll
                 for (int k = 0; k < NR; ++k) {
                     if (!valid[k]) continue;
-                    float* q1 = pp.xr + pix[k] * 64 + hi * 4;
-                    float* q2 = pp.xrr + pix[k] * 64 + hi * 4;
+                    // an RRDB-closing layer leaves xr == xrr: only xrr is written, the next RDB reads its res1 from there
+                    float* q = (r2 ? pp.xrr : pp.xr) + rowb[k] + sd.lane;
 #pragma unroll
                     for (int mb = 0; mb < CB; ++mb)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            if (r2) *(floatx4*)(q2 + mb * 32 + g * 8) = vv[k][mb][g];
-                            *(floatx4*)(q1 + mb * 32 + g * 8) = vv[k][mb][g];
-                        }
+                        for (int g = 0; g < 4; ++g) *(floatx4*)(q + mb * sd.sm + g * sd.sg) = vv[k][mb][g];
                 }
             }
         };
@@ -449,7 +506,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(pp.prog + t, L + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            publish(L + 1);
             if (L + 1 < pp.nlayers) {
                 const PLayer& nl = pp.layers[L + 1];
                 ensure_flags(L + 1);   // its first chunk is this layer's output on the neighbours: wait before staging it
@@ -505,7 +562,7 @@ constexpr int MAX_BLOCKS = 64;   // layer-table capacity (RRDB blocks)
 static size_t table_bytes() { return ((size_t)MAX_BLOCKS * 15 * sizeof(PLayer) + 255) & ~(size_t)255; }
 static size_t prog_bytes(int B, int tpi) { return ((size_t)B * tpi * sizeof(int) + 255) & ~(size_t)255; }
 
-size_t ptrunk_aux_bytes(int B, int tiles_per_img) { return table_bytes() + prog_bytes(B, tiles_per_img) + 256; }
+size_t ptrunk_aux_bytes(int B, int tiles_per_img) { return table_bytes() + 2 * prog_bytes(B, tiles_per_img) + 256; }
 size_t ptrunk_err_offset(int B, int tiles_per_img) { return table_bytes() + prog_bytes(B, tiles_per_img); }
 
 // returns SRBH_OK and sets *used = 1 when the persistent path ran, *used = 0 when the shape is not eligible
@@ -537,7 +594,10 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
             const srbh_conv_w* cw = d->rdb + (blk * 3 + r) * 5;
             for (int k = 0; k < 4; ++k)
                 tab[li++] = PLayer{(const char*)cw[k].w, cw[k].bias, 2 + k, 1, cur, cur, 2 + k, 1 | (k == 0 ? 8 : 0)};
-            tab[li++] = PLayer{(const char*)cw[4].w, cw[4].bias, 6, 2, cur, cur ^ 1, 0, 2 | (r == 2 ? 4 : 0)};
+            // conv5: 64 = res1 comes from the xrr stream (first RDB of a block: xr == xrr there and the closing layer of
+            // the previous block wrote only xrr); 16 / 32 = that stream still holds conv_first's pixel-order data
+            tab[li++] = PLayer{(const char*)cw[4].w, cw[4].bias, 6, 2, cur, cur ^ 1, 0,
+                               2 | (r == 2 ? 4 : 0) | (r == 0 ? 64 : 0) | (blk == 0 && r == 0 ? 16 : 0) | (blk == 0 && r == 2 ? 32 : 0)};
             cur ^= 1;
         }
     *final_cur = cur;
@@ -548,6 +608,8 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
     SRBH_HIP(hipMemcpyAsync(d_tab, tab.data(), (size_t)nl * sizeof(PLayer), hipMemcpyHostToDevice, stream));
     SRBH_HIP(hipMemsetAsync(d_prog, 0, (size_t)B * tpi * sizeof(int) , stream));
     SRBH_HIP(hipMemsetAsync(d_err, 0, sizeof(int), stream));
+    int* d_xcc = (int*)(a + ptrunk_err_offset(B, tpi) + 256);
+    SRBH_HIP(hipMemsetAsync(d_xcc, 0, (size_t)B * tpi * sizeof(int), stream));
     const Act16Geo g = act16_geo(B, 6, H, W);
     const int imgs_per_launch = ncu / tpi;
     for (int b0 = 0; b0 < B; b0 += imgs_per_launch) {
@@ -568,9 +630,18 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
         pp.nblocks = nb * tpi;
         pp.prog = d_prog + b0 * tpi;
         pp.err = d_err;
+        pp.xcc = d_xcc + b0 * tpi;
+        {
+            const char* e = getenv("SRBH_PT_WT");
+            pp.force_wt = (e && atoi(e) == 1) ? 1 : 0;
+        }
         if (getenv("SRBH_PT_PROF") && !g_ptrunk_prof)
             SRBH_HIP(hipMalloc(&g_ptrunk_prof, (size_t)ncu * MAX_BLOCKS * 15 * 6 * 8));
         pp.prof = g_ptrunk_prof;
+        {
+            const char* e = getenv("SRBH_PT_FRAGRES");   // debugging aid: 0 keeps the residual streams in pixel order
+            pp.frag_res = (W == TILE_W) && !(e && atoi(e) == 0);
+        }
         {
             const char* e = getenv("SRBH_PT_STAGGER");
             pp.stagger = e ? atoi(e) : 0;
