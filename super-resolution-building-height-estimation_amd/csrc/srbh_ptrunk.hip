@@ -23,8 +23,8 @@
 #ifndef PT_SPLIT_DRAIN
 #define PT_SPLIT_DRAIN 0
 #endif
-#ifndef PT_LATE_FLAGS
-#define PT_LATE_FLAGS 0   // measured slower: the peel re-introduces accumulator copies
+#ifndef PT_INLOOP_FLAGS
+#define PT_INLOOP_FLAGS 0   // 1: check the neighbour flags of conv2..5 inside the chunk loop (measured 5 % SLOWER)
 #endif
 #ifndef PT_EPI_BARRIER
 #define PT_EPI_BARRIER 0
@@ -54,6 +54,7 @@ struct PParams {
     int* xcc;                   // [nblocks] XCC_ID + 1 of every workgroup (placement handshake)
     int force_wt;               // 1: always use write-through stores (debugging aid, env SRBH_PT_WT=1)
     int frag_res;               // 1: fp32 residual streams in fragment order inside the launch (W == TILE_W)
+    int stagger_ways;
     int stagger;                // odd images start this many s_sleep(127) periods late (de-phases the HBM bursts)
     unsigned long long* prof;   // debug (tools/convbench): [block][layer][4] s_memtime stamps, nullptr in production
 };
@@ -166,12 +167,6 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         __syncthreads();
         if (bad) aborted = true;
     };
-    auto peek_flags = [&]() {   // non-blocking refresh; the values are consumed after the next barrier
-        if (tid == 0) {
-            if (up >= 0) f_up = __hip_atomic_load(pp.prog + up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (dn >= 0) f_dn = __hip_atomic_load(pp.prog + dn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
 
     // ---- where do my halo partners run?  Workgroups are dealt round-robin to the 8 XCDs and xcd_remap() puts the tiles
     // of one image on one XCD, so normally both neighbours share this workgroup's L2 and the exchange never has to leave
@@ -216,6 +211,38 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
     bool pending_pub = false;
     int pub_val = 0;
 
+    // Per-wave flag check used inside the chunk loop: scalar loads (glc: straight from L2), no barrier, no vector
+    // registers -- anything heavier in the loop makes hipcc shuffle the accumulators.  Bounded: on timeout the error
+    // word is set and the wave carries on (the host reports the forward as failed).
+    int poll_ok = 1;
+    auto wave_poll = [&](const int need) {
+        // the whole spin is ONE asm statement: to the compiler this is straight-line code
+        const int* pu = pp.prog + (up >= 0 ? up : t);
+        const int* pd = pp.prog + (dn >= 0 ? dn : t);
+        const int need_u = up >= 0 ? need : 0, need_d = dn >= 0 ? need : 0;   // own word when there is no neighbour
+        int a, b, left = (int)SPIN_LIMIT, ok;
+        asm volatile(
+            "Lsrbh_poll_%=:\n\t"
+            "s_load_dword %0, %5, 0x0 glc\n\t"
+            "s_load_dword %1, %6, 0x0 glc\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_cmp_ge_i32 %0, %7\n\t"
+            "s_cselect_b32 %3, 1, 0\n\t"
+            "s_cmp_ge_i32 %1, %8\n\t"
+            "s_cselect_b32 %3, %3, 0\n\t"
+            "s_cmp_lg_u32 %3, 0\n\t"
+            "s_cbranch_scc1 Lsrbh_done_%=\n\t"
+            "s_sleep 1\n\t"
+            "s_sub_u32 %2, %2, 1\n\t"
+            "s_cmp_lg_u32 %2, 0\n\t"
+            "s_cbranch_scc1 Lsrbh_poll_%=\n"
+            "Lsrbh_done_%=:"
+            : "=&s"(a), "=&s"(b), "+s"(left), "=&s"(ok)
+            : "0"(0), "s"(pu), "s"(pd), "s"(need_u), "s"(need_d)
+            : "memory", "scc");
+        poll_ok &= ok;
+    };
+
     // ---- one layer: CB = cout/32
     auto run_layer = [&](auto cb_tag, const int L, const PLayer& lay) {
         constexpr int CB = decltype(cb_tag)::value;
@@ -236,15 +263,16 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
             publish(pub_val);
             pending_pub = false;
         }
-        // Non-seam layers with >= 3 chunks read the neighbours' newest plane only in their LAST chunk (staged during
-        // chunk n-2 >= 1): issue the flag loads now, compute chunk 0 (old data) under their latency, check after it.
-        const bool late_check = PT_LATE_FLAGS && L > 0 && !(lay.flags & 8) && lay.nchunk >= 3;
-        if (L > 0 && !late_check) ensure_flags(L);   // every input plane of layer L is complete on both neighbours
-        if (aborted) return;
-        if (late_check && tid == 0) {
-            if (up >= 0) f_up = __hip_atomic_load(pp.prog + up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (dn >= 0) f_dn = __hip_atomic_load(pp.prog + dn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Non-seam layers read the neighbours' newest plane only in their LAST chunk, staged during chunk n-2 >= 1: their
+        // flag check sits inside that chunk (see compute()), one or more chunks of MFMA work after the publish above, so
+        // the L2 round trip of the flags is off the critical path.  Seam layers (conv1) and layer 0 check here.
+        if (!poll_ok) {   // an in-loop flag check of the previous layer timed out
+            if (tid == 0) __hip_atomic_store(pp.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            aborted = true;
         }
+        const bool inloop_check = PT_INLOOP_FLAGS && L > 0 && !(lay.flags & 8) && lay.nchunk >= 3;
+        if (L > 0 && !inloop_check) ensure_flags(L);   // every input plane of layer L is complete on both neighbours
+        if (aborted) return;
         const bool has_next_prefetch = (L + 1 < pp.nlayers) && !(pp.layers[L + 1 < pp.nlayers ? L + 1 : L].flags & 8);
         const PLayer nlay = pp.layers[L + 1 < pp.nlayers ? L + 1 : L];
         unsigned long long p1 = 0;
@@ -271,17 +299,22 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         // One code path for every chunk (duplicating it per staging variant made the compiler shuffle all accumulators
         // through VGPRs at the join): the LDS-DMA slices of the next step sit behind tiny wave-uniform branches at the
         // head of each MFMA group.  next_cb = cout/32 of the layer that owns the staged step, 0 = nothing to stage.
-        auto compute = [&](const int next_cb, const char* nsrc, const char* nw) {
+        auto compute = [&](const int next_cb, const char* nsrc, const char* nw, const int poll_need) {
             const char* sb = smem + (gs & 1) * P_STAGE_B;
             char* dst = smem + ((gs + 1) & 1) * P_STAGE_B;
             const char* ws = nw + lane * 16;
             load_group(sb, 0, 0);
+            // LDS-DMA issue order: the instructions that carry the two halo rows (tile rows 0 and 9: j = 0, 1, 9, 10) go
+            // last, behind the neighbour-flag check of the chunk that stages a freshly produced plane.
+            constexpr int JORD[12] = {2, 3, 4, 5, 6, 7, 8, 0, 1, 9, 10, 11};
+            static_assert(G::NJ == 11 && JPP == 2, "DMA issue order is written for 11 instructions, 2 per group");
 #pragma unroll
             for (int g = 0; g < 6; ++g) {
                 if (next_cb) {
 #pragma unroll
                     for (int jj = 0; jj < JPP; ++jj) {
-                        const int j = g * JPP + jj;
+                        const int j = JORD[g * JPP + jj];
+                        if (j == 0 && poll_need) wave_poll(poll_need);
                         if (j < G::NJ && (j < G::NJ - 1 || tail_ok))
                             __builtin_amdgcn_global_load_lds(GPTR(nsrc + goff[j < G::NJ ? j : 0]),
                                                              LPTR(dst + (j * 256 + wave * 64) * 16), 16, 0, 16);
@@ -336,21 +369,10 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
                 nsrc = chunk_src(nlay, 0);
                 nw = chunk_w(nlay, 0);
             }
-            compute(next_cb, nsrc, nw);
+            compute(next_cb, nsrc, nw, (inloop_check && c == n - 2) ? L : 0);
             ++gs;
         };
-        int c0 = 0;
-        if (late_check) {            // peeled chunk 0: runs under the latency of the flag loads issued in the prologue
-            step(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            ensure_flags(L);
-            if (aborted) return;
-            c0 = 1;
-            step(1);                 // (its barrier was the one above)
-            c0 = 2;
-        }
-        for (int c = c0; c < n; ++c) {
+        for (int c = 0; c < n; ++c) {
             if (c > 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of step gs has landed ...
                 __syncthreads();                                   // ... and everybody else's; all waves are past step gs-1
@@ -530,8 +552,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         }
     };
 
-    if ((img & 1) && pp.stagger > 0)
-        for (int k = 0; k < pp.stagger; ++k) __builtin_amdgcn_s_sleep(127);
+    if (pp.stagger > 0)   // image i starts (i mod ways) * stagger sleep periods late: de-phases the HBM bursts of conv5
+        for (int k = 0; k < (img % pp.stagger_ways) * pp.stagger; ++k) __builtin_amdgcn_s_sleep(127);
     // ---- prologue: layer 0's inputs were written by the previous kernel (conv_first): no flag needed
     {
         const PLayer& l0 = pp.layers[0];
@@ -645,6 +667,8 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
         {
             const char* e = getenv("SRBH_PT_STAGGER");
             pp.stagger = e ? atoi(e) : 0;
+            const char* w = getenv("SRBH_PT_STAGGER_WAYS");
+            pp.stagger_ways = w && atoi(w) > 0 ? atoi(w) : 2;
         }
         hipLaunchKernelGGL(ptrunk_kernel, dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
         SRBH_HIP(hipGetLastError());
