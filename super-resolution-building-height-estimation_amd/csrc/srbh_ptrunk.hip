@@ -23,9 +23,6 @@
 #ifndef PT_SPLIT_DRAIN
 #define PT_SPLIT_DRAIN 0
 #endif
-#ifndef PT_INLOOP_FLAGS
-#define PT_INLOOP_FLAGS 0   // 1: check the neighbour flags of conv2..5 inside the chunk loop (measured 5 % SLOWER)
-#endif
 #ifndef PT_EPI_BARRIER
 #define PT_EPI_BARRIER 0
 #endif
@@ -61,13 +58,22 @@ struct PParams {
 
 constexpr unsigned SPIN_LIMIT = 4u << 20;
 using G = TileGeo<0>;
-constexpr int P_STAGE_B = G::IN_B + 36 * 1024;      // one pipeline stage: input tile + weight chunk sized for cout 64
 constexpr int JPP = (G::NJ + 5) / 6;
-static_assert(2 * P_STAGE_B <= 163840, "two stages must fit the 160 KiB LDS");
-// The input area of a stage is padded to whole LDS-DMA instructions; the tail lanes are masked off, which frees the pad
-// of stage 0 for the double-buffered per-layer bias vector.
-constexpr int P_BIAS_OFF = G::UNITS * 16;
-static_assert(P_BIAS_OFF + 2 * 64 * 4 <= G::IN_B, "bias slots must fit the stage-0 pad");
+// LDS map (160 KiB).  The cout-32 layers of an RDB (conv1-4, "phase A") are bound by the L2-miss bandwidth of their input
+// staging, not by the matrix cores, so they keep plane 0 of the dense buffer RESIDENT for the whole RDB (it is read by
+// every conv) and stage only planes 1..k: 10 instead of 14 plane reads per RDB in those layers.
+//   phase A (cout 32):  [R: plane 0][stage 0: input + 18 KiB weights][stage 1][bias 128 B][flag word]
+//   phase B (cout 64):  [stage 0: input + 36 KiB weights][stage 1][bias 256 B] ... [flag word]
+// Input areas are exact (the tail lanes of the last DMA instruction are masked off), weight areas too (no over-read).
+constexpr int IN_EX = G::UNITS * 16;
+constexpr int A_STAGE_B = IN_EX + 18 * 1024, B_STAGE_B = IN_EX + 36 * 1024;
+constexpr int A_BASE = IN_EX;
+constexpr int A_BIAS_OFF = A_BASE + 2 * A_STAGE_B, B_BIAS_OFF = 2 * B_STAGE_B;
+constexpr int P_WORD_OFF = A_BIAS_OFF + 128;
+constexpr int P_LDS_B = 163840;
+static_assert(P_WORD_OFF + 4 <= P_LDS_B && B_BIAS_OFF + 256 <= P_WORD_OFF, "LDS map must fit 160 KiB");
+__device__ __forceinline__ int stage_off(int cb, int idx) { return cb == 1 ? A_BASE + idx * A_STAGE_B : idx * B_STAGE_B; }
+__device__ __forceinline__ int bias_off(int cb) { return cb == 1 ? A_BIAS_OFF : B_BIAS_OFF; }
 
 // PLayer.flags bit 3 is set by the host when the layer's FIRST input chunk is produced by the previous layer
 // (conv1 of an RDB reads the x written by the previous conv5): it can be neither prefetched nor published lazily.
@@ -106,30 +112,23 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         for (int ks = 0; ks < 2; ++ks)
             aoff[dx][ks] = wr * 4 * G::ROW_B + pc * PIX_B + (((ks * 2 + hi) ^ ((pc >> 2) & 3)) << 4);
     }
-    const int woff = G::IN_B + lane * 16;
+    const int woff = lane * 16;
     const long tile_off = (long)img * pp.img_b + (long)Y0 * pp.row_b;
 
-    // ---- staging of one (layer, chunk) step into stage `buf`; NCB = cout/32 of the layer that owns the chunk
-    auto stage_part = [&](auto ncb_tag, const char* src, const char* wsrc, int buf, int part) {
-        constexpr int NCB = decltype(ncb_tag)::value;
-        constexpr int WFR = (18 * NCB + 3) / 4, WPP = (WFR + 5) / 6;
-        char* dst = smem + buf * P_STAGE_B;
+    // ---- cold staging of one step (used where nothing could be prefetched): input plane (if any) to `din`, the
+    // 18 * ncb weight fragments to `dw`
+    auto stage_cold = [&](const char* src, char* din, const char* wsrc, char* dw, const int ncb) {
+        if (src) {
 #pragma unroll
-        for (int jj = 0; jj < JPP; ++jj) {
-            const int j = part * JPP + jj;
-            if (j < G::NJ && (j < G::NJ - 1 || tail_ok))   // activations: sc1 = bypass this CU's L1 (written by other CUs in this launch)
-                __builtin_amdgcn_global_load_lds(GPTR(src + goff[j < G::NJ ? j : 0]),
-                                                 LPTR(dst + (j * 256 + wave * 64) * 16), 16, 0, 16);
+            for (int j = 0; j < G::NJ; ++j)
+                if (j < G::NJ - 1 || tail_ok)   // activations: sc1 = bypass this CU's L1 (written by other CUs in this launch)
+                    __builtin_amdgcn_global_load_lds(GPTR(src + goff[j]), LPTR(din + (j * 256 + wave * 64) * 16), 16, 0, 16);
         }
         const char* ws = wsrc + lane * 16;
-        char* wdst = dst + G::IN_B;
 #pragma unroll
-        for (int kk = 0; kk < WPP; ++kk) {
-            const int f = wave + 4 * (part * WPP + kk);
-            // cout 32: fragments 18,19 over-read 2 KiB of the following packed weights into the unused half of the
-            // 36 KiB weight area -- keeps this loop free of a wave-dependent branch
-            if (part * WPP + kk < WFR)
-                __builtin_amdgcn_global_load_lds(GPTR(ws + f * 1024), LPTR(wdst + f * 1024), 16, 0, 0);
+        for (int k = 0; k < 9; ++k) {
+            const int f = wave + 4 * k;
+            if (f < 18 * ncb) __builtin_amdgcn_global_load_lds(GPTR(ws + f * 1024), LPTR(dw + f * 1024), 16, 0, 0);
         }
     };
     auto chunk_src = [&](const PLayer& l, int c) { return pp.dense[l.in_sel] + tile_off + (long)c * pp.plane_b; };
@@ -140,12 +139,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
     int gs = 0;                  // global step counter: stage buffer = gs & 1
     bool aborted = false;
     auto ensure_flags = [&](int need) {
-        // that stage is free while we decide (explicit LDS address space: a generic pointer would become flat_*)
-#ifdef PT_FLAT_WORD
-        volatile int* word = (volatile int*)(smem + ((gs + 1) & 1) * P_STAGE_B);
-#else
-        auto* word = (__attribute__((address_space(3))) int*)(smem + ((gs + 1) & 1) * P_STAGE_B);
-#endif
+        auto* word = (__attribute__((address_space(3))) int*)(smem + P_WORD_OFF);   // (a generic pointer would become flat_*)
         if (tid == 0) {
             int bad = 0;
             unsigned spins = 0;
@@ -211,38 +205,6 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
     bool pending_pub = false;
     int pub_val = 0;
 
-    // Per-wave flag check used inside the chunk loop: scalar loads (glc: straight from L2), no barrier, no vector
-    // registers -- anything heavier in the loop makes hipcc shuffle the accumulators.  Bounded: on timeout the error
-    // word is set and the wave carries on (the host reports the forward as failed).
-    int poll_ok = 1;
-    auto wave_poll = [&](const int need) {
-        // the whole spin is ONE asm statement: to the compiler this is straight-line code
-        const int* pu = pp.prog + (up >= 0 ? up : t);
-        const int* pd = pp.prog + (dn >= 0 ? dn : t);
-        const int need_u = up >= 0 ? need : 0, need_d = dn >= 0 ? need : 0;   // own word when there is no neighbour
-        int a, b, left = (int)SPIN_LIMIT, ok;
-        asm volatile(
-            "Lsrbh_poll_%=:\n\t"
-            "s_load_dword %0, %5, 0x0 glc\n\t"
-            "s_load_dword %1, %6, 0x0 glc\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "s_cmp_ge_i32 %0, %7\n\t"
-            "s_cselect_b32 %3, 1, 0\n\t"
-            "s_cmp_ge_i32 %1, %8\n\t"
-            "s_cselect_b32 %3, %3, 0\n\t"
-            "s_cmp_lg_u32 %3, 0\n\t"
-            "s_cbranch_scc1 Lsrbh_done_%=\n\t"
-            "s_sleep 1\n\t"
-            "s_sub_u32 %2, %2, 1\n\t"
-            "s_cmp_lg_u32 %2, 0\n\t"
-            "s_cbranch_scc1 Lsrbh_poll_%=\n"
-            "Lsrbh_done_%=:"
-            : "=&s"(a), "=&s"(b), "+s"(left), "=&s"(ok)
-            : "0"(0), "s"(pu), "s"(pd), "s"(need_u), "s"(need_d)
-            : "memory", "scc");
-        poll_ok &= ok;
-    };
-
     // ---- one layer: CB = cout/32
     auto run_layer = [&](auto cb_tag, const int L, const PLayer& lay) {
         constexpr int CB = decltype(cb_tag)::value;
@@ -252,26 +214,18 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         if (pp.prof) p0 = __builtin_amdgcn_s_memtime();
         // LDS-DMA completion is NOT reliably waited for by hipcc before a barrier (seen: no vmcnt at all in this loop
         // shape) -> always drain explicitly.  vmcnt(0) also covers this workgroup's write-through stores of layer L-1.
-        // The layer's bias goes through LDS (slot L&1): its global-load latency hides under the drain below instead of
+        // The layer's bias goes through LDS: its global-load latency hides under the drain below instead of
         // opening the epilogue, and no registers are held across the chunk loop.
         float bias_v = 0.f;
         if (tid < lay.cb * 32) bias_v = lay.bias[tid];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid < lay.cb * 32) ((float*)(smem + P_BIAS_OFF))[(L & 1) * 64 + tid] = bias_v;
-        __syncthreads();   // step (L,0) landed on every wave
+        __syncthreads();   // step (L,0) landed on every wave, and every wave is past the previous epilogue (bias slot free)
+        if (tid < lay.cb * 32) ((float*)(smem + bias_off(lay.cb)))[tid] = bias_v;   // read after >= 1 more barrier
         if (pending_pub) {
             publish(pub_val);
             pending_pub = false;
         }
-        // Non-seam layers read the neighbours' newest plane only in their LAST chunk, staged during chunk n-2 >= 1: their
-        // flag check sits inside that chunk (see compute()), one or more chunks of MFMA work after the publish above, so
-        // the L2 round trip of the flags is off the critical path.  Seam layers (conv1) and layer 0 check here.
-        if (!poll_ok) {   // an in-loop flag check of the previous layer timed out
-            if (tid == 0) __hip_atomic_store(pp.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            aborted = true;
-        }
-        const bool inloop_check = PT_INLOOP_FLAGS && L > 0 && !(lay.flags & 8) && lay.nchunk >= 3;
-        if (L > 0 && !inloop_check) ensure_flags(L);   // every input plane of layer L is complete on both neighbours
+        if (L > 0) ensure_flags(L);   // every input plane of layer L is complete on both neighbours
         if (aborted) return;
         const bool has_next_prefetch = (L + 1 < pp.nlayers) && !(pp.layers[L + 1 < pp.nlayers ? L + 1 : L].flags & 8);
         const PLayer nlay = pp.layers[L + 1 < pp.nlayers ? L + 1 : L];
@@ -286,50 +240,48 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
                 for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
         half8 P[2][G::NP];
         half8 A[2][3][CB];
-        auto load_group = [&](const char* sb, int g, int set) {
+        auto load_group = [&](const char* sbi, const char* sbw, int g, int set) {
             const int ks = g / 3, dx = g - ks * 3;
 #pragma unroll
-            for (int r = 0; r < G::NP; ++r) P[set][r] = *(const half8*)(sb + aoff[dx][ks] + r * G::ROW_B);
+            for (int r = 0; r < G::NP; ++r) P[set][r] = *(const half8*)(sbi + aoff[dx][ks] + r * G::ROW_B);
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int mb = 0; mb < CB; ++mb)
-                    A[set][dy][mb] = *(const half8*)(sb + woff + ((((dy * 3 + dx) * 2 + ks) * CB + mb) << 10));
+                    A[set][dy][mb] = *(const half8*)(sbw + woff + ((((dy * 3 + dx) * 2 + ks) * CB + mb) << 10));
         };
         // One code path for every chunk (duplicating it per staging variant made the compiler shuffle all accumulators
         // through VGPRs at the join): the LDS-DMA slices of the next step sit behind tiny wave-uniform branches at the
         // head of each MFMA group.  next_cb = cout/32 of the layer that owns the staged step, 0 = nothing to stage.
-        auto compute = [&](const int next_cb, const char* nsrc, const char* nw, const int poll_need) {
-            const char* sb = smem + (gs & 1) * P_STAGE_B;
-            char* dst = smem + ((gs + 1) & 1) * P_STAGE_B;
+        auto compute = [&](const char* sbi, const char* sbw, const int next_cb, const char* nsrc, const char* nw, char* dst) {
             const char* ws = nw + lane * 16;
-            load_group(sb, 0, 0);
-            // LDS-DMA issue order: the instructions that carry the two halo rows (tile rows 0 and 9: j = 0, 1, 9, 10) go
-            // last, behind the neighbour-flag check of the chunk that stages a freshly produced plane.
+            load_group(sbi, sbw, 0, 0);
+            // LDS-DMA issue order: the instructions that carry the two halo rows (tile rows 0 and 9: j = 0, 1, 9, 10) go last
             constexpr int JORD[12] = {2, 3, 4, 5, 6, 7, 8, 0, 1, 9, 10, 11};
             static_assert(G::NJ == 11 && JPP == 2, "DMA issue order is written for 11 instructions, 2 per group");
 #pragma unroll
             for (int g = 0; g < 6; ++g) {
                 if (next_cb) {
+                    if (nsrc) {   // nullptr: the step reads the resident plane
 #pragma unroll
-                    for (int jj = 0; jj < JPP; ++jj) {
-                        const int j = JORD[g * JPP + jj];
-                        if (j == 0 && poll_need) wave_poll(poll_need);
-                        if (j < G::NJ && (j < G::NJ - 1 || tail_ok))
-                            __builtin_amdgcn_global_load_lds(GPTR(nsrc + goff[j < G::NJ ? j : 0]),
-                                                             LPTR(dst + (j * 256 + wave * 64) * 16), 16, 0, 16);
+                        for (int jj = 0; jj < JPP; ++jj) {
+                            const int j = JORD[g * JPP + jj];
+                            if (j < G::NJ && (j < G::NJ - 1 || tail_ok))
+                                __builtin_amdgcn_global_load_lds(GPTR(nsrc + goff[j < G::NJ ? j : 0]),
+                                                                 LPTR(dst + (j * 256 + wave * 64) * 16), 16, 0, 16);
+                        }
                     }
-                    // weights: 20 (cout 32, incl. 2 KiB over-read into the unused half) or 36 fragments
-                    if (g < 5) {
+                    // weights: 18 (cout 32) or 36 fragments
+                    if (g < 4 || (g == 4 && (wave < 2 || next_cb == 2))) {
                         const int f = wave + 4 * g;
-                        __builtin_amdgcn_global_load_lds(GPTR(ws + f * 1024), LPTR(dst + G::IN_B + f * 1024), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds(GPTR(ws + f * 1024), LPTR(dst + IN_EX + f * 1024), 16, 0, 0);
                     }
                     if (next_cb == 2 && g < 4) {
                         const int f = 20 + wave + 4 * g;
-                        __builtin_amdgcn_global_load_lds(GPTR(ws + f * 1024), LPTR(dst + G::IN_B + f * 1024), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds(GPTR(ws + f * 1024), LPTR(dst + IN_EX + f * 1024), 16, 0, 0);
                     }
                 }
-                if (g + 1 < 6) load_group(sb, g + 1, (g + 1) & 1);
+                if (g + 1 < 6) load_group(sbi, sbw, g + 1, (g + 1) & 1);
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -357,19 +309,21 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         // extra control flow inside it hipcc parks the loop-carried accumulators in VGPRs and copies all of them back
         // into AGPRs at the top of every chunk.  So everything protocol-related happened in the layer prologue.
         auto step = [&](const int c) {
+            const char* st = smem + stage_off(CB, gs & 1);
+            const char* sbi = (CB == 1 && c == 0) ? smem : st;   // phase A: plane 0 is resident
             int next_cb = 0;
             const char* nsrc = nullptr;
             const char* nw = nullptr;
             if (c + 1 < n) {
-                next_cb = lay.cb;
+                next_cb = CB;
                 nsrc = chunk_src(lay, c + 1);
                 nw = chunk_w(lay, c + 1);
             } else if (has_next_prefetch) {
                 next_cb = nlay.cb;
-                nsrc = chunk_src(nlay, 0);
+                nsrc = nlay.cb == 1 ? nullptr : chunk_src(nlay, 0);   // a cout-32 layer's step 0 reads the resident plane
                 nw = chunk_w(nlay, 0);
             }
-            compute(next_cb, nsrc, nw, (inloop_check && c == n - 2) ? L : 0);
+            compute(sbi, st + IN_EX, next_cb, nsrc, nw, smem + stage_off(next_cb ? next_cb : CB, (gs + 1) & 1));
             ++gs;
         };
         for (int c = 0; c < n; ++c) {
@@ -397,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         for (int mb = 0; mb < CB; ++mb)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                bias4[mb][g] = *(const floatx4*)((const float*)(smem + P_BIAS_OFF) + (L & 1) * 64 + mb * 32 + g * 8 + hi * 4);
+                bias4[mb][g] = *(const floatx4*)((const float*)(smem + bias_off(CB)) + mb * 32 + g * 8 + hi * 4);
         const int X = wc * 32 + l31;
         // fp32 residual streams.  They are private to this workgroup -- each lane re-reads exactly the values it wrote one
         // RDB earlier -- so inside the launch they live in "fragment order": within the wave's 32-pixel segment of a
@@ -533,13 +487,13 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
                 const PLayer& nl = pp.layers[L + 1];
                 ensure_flags(L + 1);   // its first chunk is this layer's output on the neighbours: wait before staging it
                 if (aborted) return;
-#pragma unroll
-                for (int part = 0; part < 6; ++part) {
-                    if (nl.cb == 1)
-                        stage_part(std::integral_constant<int, 1>{}, chunk_src(nl, 0), chunk_w(nl, 0), gs & 1, part);
-                    else
-                        stage_part(std::integral_constant<int, 2>{}, chunk_src(nl, 0), chunk_w(nl, 0), gs & 1, part);
-                }
+                // ring restart: the seam layer's step 0 reads the resident plane + the weights in stage 0; with 14 phase-A
+                // steps per RDB the last one then sits in stage 1, clear of the phase-B stage 0 it prefetches into
+                gs = 0;
+                if (nl.cb == 1)
+                    stage_cold(chunk_src(nl, 0), smem, chunk_w(nl, 0), smem + stage_off(1, 0) + IN_EX, 1);
+                else
+                    stage_cold(chunk_src(nl, 0), smem + stage_off(2, 0), chunk_w(nl, 0), smem + stage_off(2, 0) + IN_EX, 2);
             }
         } else {
             pending_pub = true;   // published behind the next top-of-step barrier (whose vmcnt(0) covers these stores)
@@ -557,13 +511,10 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
     // ---- prologue: layer 0's inputs were written by the previous kernel (conv_first): no flag needed
     {
         const PLayer& l0 = pp.layers[0];
-#pragma unroll
-        for (int part = 0; part < 6; ++part) {
-            if (l0.cb == 1)
-                stage_part(std::integral_constant<int, 1>{}, chunk_src(l0, 0), chunk_w(l0, 0), 0, part);
-            else
-                stage_part(std::integral_constant<int, 2>{}, chunk_src(l0, 0), chunk_w(l0, 0), 0, part);
-        }
+        if (l0.cb == 1)
+            stage_cold(chunk_src(l0, 0), smem, chunk_w(l0, 0), smem + stage_off(1, 0) + IN_EX, 1);
+        else
+            stage_cold(chunk_src(l0, 0), smem + stage_off(2, 0), chunk_w(l0, 0), smem + stage_off(2, 0) + IN_EX, 2);
     }
     for (int L = 0; L < pp.nlayers && !aborted; ++L) {
         const PLayer lay = pp.layers[L];
@@ -598,7 +549,7 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
     SRBH_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     const int tpi = (H + TILE_H - 1) / TILE_H;
     if (tpi > ncu) return SRBH_OK;
-    constexpr int LDS_B = 2 * P_STAGE_B;
+    constexpr int LDS_B = P_LDS_B;
     static bool attr_set = false;
     if (!attr_set) {
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
