@@ -133,6 +133,12 @@ int srbh_rrdbnet_forward(const srbh_rrdbnet_desc* d, const float* x, float* out,
  * scheduling problem shows up as an error here instead of a hung GPU).  Set SRBH_PERSISTENT=0 to force per-layer launches. */
 int srbh_rrdbnet_last_status(const void* ws, int B, int H, int W, int want_forward, void* stream);
 
+/* Measurement hook used by bench.py: when on, srbh_rrdbnet_forward() brackets the persistent trunk kernel (the dominant
+ * kernel: the 345 dense-block convs, reference SR/rrdbnet_arch.py:136-167) with HIP events on `stream`;
+ * srbh_trunk_last_ms() synchronises on the closing event and returns that launch's duration in milliseconds. */
+int srbh_trunk_timing(int on);
+int srbh_trunk_last_ms(float* ms);
+
 /* ==== head: HR feature / fusion / regression modules (SR/HRfuse.py), fp32 ==========================
  * Tensors are NHWC fp32 ([B][H][W][C]; a torch channels_last (B,C,H,W) tensor has exactly this memory).
  * HWPACK32: fp32 weights in v_mfma_f32_16x16x4_f32 A-fragment order [Cin/16][tap][4][Cout/16][lane 64]. */

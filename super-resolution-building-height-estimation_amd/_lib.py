@@ -139,6 +139,8 @@ SIGNATURES = {
     "srbh_normalize_clamp": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _i, _vp]),
     "srbh_rrdbnet_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "srbh_rrdbnet_last_status": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "srbh_trunk_timing": (_i, [_i]),
+    "srbh_trunk_last_ms": (_i, [C.POINTER(C.c_float)]),
     "srbh_rrdbnet_forward": (_i, [C.POINTER(RRDBNetDesc), _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 

@@ -530,6 +530,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
 namespace srbh {
 
 unsigned long long* g_ptrunk_prof = nullptr;   // set by tools/convbench only
+static int g_trunk_timing = 0;                 // srbh_trunk_timing(): HIP events around the trunk launch(es), on their stream
+static hipEvent_t g_trunk_ev[2];
 
 constexpr int MAX_BLOCKS = 64;   // layer-table capacity (RRDB blocks)
 static size_t table_bytes() { return ((size_t)MAX_BLOCKS * 15 * sizeof(PLayer) + 255) & ~(size_t)255; }
@@ -621,9 +623,11 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
             const char* w = getenv("SRBH_PT_STAGGER_WAYS");
             pp.stagger_ways = w && atoi(w) > 0 ? atoi(w) : 2;
         }
+        if (g_trunk_timing && b0 == 0) SRBH_HIP(hipEventRecord(g_trunk_ev[0], stream));
         hipLaunchKernelGGL(ptrunk_kernel, dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
         SRBH_HIP(hipGetLastError());
     }
+    if (g_trunk_timing) SRBH_HIP(hipEventRecord(g_trunk_ev[1], stream));
     if (getenv("SRBH_PT_PROF") && g_ptrunk_prof) {   // developer aid: cycles vs wall clock of the real forward
         SRBH_HIP(hipStreamSynchronize(stream));
         const int nblk = (B < imgs_per_launch ? B : imgs_per_launch) * tpi;
@@ -651,3 +655,26 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
 }
 
 }  // namespace srbh
+
+// ---- measurement hook (bench.py): duration of the persistent trunk kernel itself, taken with HIP events recorded on the
+// stream it is launched on.  Off by default; not thread safe (one forward at a time while it is on).
+extern "C" int srbh_trunk_timing(int on) {
+    using namespace srbh;
+    if (on && !g_trunk_timing) {
+        SRBH_HIP(hipEventCreate(&g_trunk_ev[0]));
+        SRBH_HIP(hipEventCreate(&g_trunk_ev[1]));
+    } else if (!on && g_trunk_timing) {
+        SRBH_HIP(hipEventDestroy(g_trunk_ev[0]));
+        SRBH_HIP(hipEventDestroy(g_trunk_ev[1]));
+    }
+    g_trunk_timing = on ? 1 : 0;
+    return SRBH_OK;
+}
+
+extern "C" int srbh_trunk_last_ms(float* ms) {
+    using namespace srbh;
+    SRBH_REQUIRE(ms && g_trunk_timing, "srbh_trunk_last_ms: timing is off (srbh_trunk_timing(1) first)");
+    SRBH_HIP(hipEventSynchronize(g_trunk_ev[1]));
+    SRBH_HIP(hipEventElapsedTime(ms, g_trunk_ev[0], g_trunk_ev[1]));
+    return SRBH_OK;
+}

@@ -1,0 +1,82 @@
+// ldsbench.hip -- developer micro-benchmark: LDS read throughput of the access patterns used by the conv kernels.
+// hipcc --offload-arch=gfx950 -O3 tools/ldsbench.hip -o tools/ldsbench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// mode 0: conflict-free linear (lane*16); 1: the pixel-fragment pattern (64-B pixel records, XOR-swizzled k-slot);
+// 2: same without the swizzle; 3: ds_read_b64 x2 of the pixel pattern
+template <int MODE, int WITH_MFMA>
+__global__ __launch_bounds__(256, 1) void lds_read_kernel(unsigned long long* out, int iters, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 160 * 1024 / 4; i += 256) ((float*)smem)[i] = (float)i;
+    __syncthreads();
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    int off[6];
+    for (int r = 0; r < 6; ++r) {
+        const int pc = wc * 32 + l31;
+        if (MODE == 0) off[r] = (wave * 6 + r) * 1024 + lane * 16;
+        else if (MODE == 2) off[r] = (wr * 4 + r) * 66 * 64 + pc * 64 + hi * 16;
+        else off[r] = (wr * 4 + r) * 66 * 64 + pc * 64 + ((hi ^ ((pc >> 2) & 3)) << 4);
+    }
+    half8 acc = {0, 0, 0, 0, 0, 0, 0, 0};
+    floatx16 c = {0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            half8 v[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) v[r] = *(const half8*)(smem + off[r] + ((it + u) & 1) * 32);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                if (WITH_MFMA) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(v[r], v[(r + 1) % 6], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(v[(r + 2) % 6], v[r], c, 0, 0, 0);
+                } else {
+                    acc += v[r];
+                }
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) out[blockIdx.x] = t1 - t0;
+    float s = 0;
+    for (int q = 0; q < 8; ++q) s += (float)acc[q];
+    for (int q = 0; q < 16; ++q) s += c[q];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+template <int MODE, int WITH_MFMA>
+static void run(const char* name) {
+    unsigned long long* d;
+    float* sink;
+    hipMalloc(&d, 256 * 8);
+    hipMalloc(&sink, 4);
+    hipFuncSetAttribute((const void*)lds_read_kernel<MODE, WITH_MFMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int iters = 2000;
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((lds_read_kernel<MODE, WITH_MFMA>), dim3(256), dim3(256), 160 * 1024, 0, d, iters, sink);
+    hipDeviceSynchronize();
+    unsigned long long h[256];
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    double avg = 0;
+    for (int i = 0; i < 256; ++i) avg += (double)h[i];
+    avg /= 256;
+    const double reads_per_wave = (double)iters * 4 * 6;
+    printf("%-44s %8.1f cycles per ds_read_b128 per wave  (CU: %.1f B/clk)%s\n", name, avg / reads_per_wave,
+           4.0 * 1024.0 / (avg / reads_per_wave), WITH_MFMA ? "  [2 MFMA 32x32x16 per read]" : "");
+    hipFree(d);
+    hipFree(sink);
+}
+
+int main() {
+    run<0, 0>("linear lane*16");
+    run<1, 0>("pixel records, swizzled");
+    run<2, 0>("pixel records, unswizzled");
+    run<0, 1>("linear + MFMA");
+    run<1, 1>("pixel records swizzled + MFMA");
+    return 0;
+}
