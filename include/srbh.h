@@ -252,6 +252,31 @@ int srbh_label_prep(const unsigned char* height, int B, int H, int W, const unsi
 int srbh_normalize_clamp(const float* src, float* dst, int B, int C, int H, int W, const float* mins, const float* ranges,
                          float lo, float hi, int clamp, void* stream);
 
+/* ---- loss and metric reductions ------------------------------------------------------------
+ * Replace the elementwise / reduction passes of reference losses_pytorch/selfloss.py and metrics.py.  All outputs are
+ * ACCUMULATED into caller-zeroed device buffers; fp64 accumulation.
+ *
+ * srbh_wmse_sum:  *out_sum += sum_i w_i (pred_i - target_i)^2      (selfloss.py:87-88; weight may be NULL, :75)
+ * srbh_wmse_grad: grad_i = gscale[0] * 2 w_i (pred_i - target_i)   (gscale: device scalar, d loss / d sum)          */
+int srbh_wmse_sum(const float* pred, const float* target, const float* weight, long n, double* out_sum, void* stream);
+int srbh_wmse_grad(const float* pred, const float* target, const float* weight, long n, const float* gscale,
+                   float* grad, void* stream);
+/* srbh_cedice_sums: logits (B,C,HW) fp32 with element strides (b,c,p) -- NCHW and channels_last both work --,
+ * labels (B*HW) int64 in [0,C), weight (B*HW) fp32 or NULL.  out4 += [ sum w*CE, sum pb*tb, sum pb, sum tb ] with
+ * CE = -log softmax_y (selfloss.py:149,157), pb = softmax[1:].sum (:160-161), tb = (y > 0) (:162).
+ * srbh_cedice_grad: dlogits (same strides) = g3[0]*d(sum w*CE) + g3[1]*d(sum pb*tb) + g3[2]*d(sum pb).              */
+int srbh_cedice_sums(const float* logits, int B, int C, long HW, long b_stride, long c_stride, long p_stride,
+                     const long long* labels, const float* weight, double* out4, void* stream);
+int srbh_cedice_grad(const float* logits, int B, int C, long HW, long b_stride, long c_stride, long p_stride,
+                     const long long* labels, const float* weight, const float* g3, float* dlogits, void* stream);
+/* srbh_height_metric_sums: out[k*4 + {0,1,2,3}] += { sum d^2, sum |d|, sum d, count } over the pixels with cls == k,
+ * d = pred - ref (metrics.py:186-200 computes rmse/mae/me per class from exactly these).
+ * srbh_confusion_add: cm[label*num_class + pred] += 1 (metrics.py:71-73); *bad_flag = 1 if any value is out of range. */
+int srbh_height_metric_sums(const float* pred, const float* ref, const long long* cls, long n, int num_class,
+                            double* out, void* stream);
+int srbh_confusion_add(const long long* pred, const long long* label, long n, int num_class,
+                       unsigned long long* cm, int* bad_flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

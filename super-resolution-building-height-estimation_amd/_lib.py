@@ -16,7 +16,7 @@ ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libsrbh.so")
-SOURCES = ["srbh_conv3x3.hip", "srbh_aux.hip", "srbh_rrdbnet.hip", "srbh_ptrunk.hip", "srbh_head.hip", "srbh_head_bwd.hip", "srbh_mosaic.hip", "srbh_loader.hip"]
+SOURCES = ["srbh_conv3x3.hip", "srbh_aux.hip", "srbh_rrdbnet.hip", "srbh_ptrunk.hip", "srbh_head.hip", "srbh_head_bwd.hip", "srbh_mosaic.hip", "srbh_loader.hip", "srbh_loss.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # NOTE: `-mllvm -amdgpu-mfma-vgpr-form=1` removes the AGPR<->VGPR accumulator copies hipcc emits at every K-loop
 # back-edge (~20 % of the loop), but the persistent trunk kernel then produced non-deterministic garbage on MI355X
@@ -139,6 +139,12 @@ SIGNATURES = {
     "srbh_normalize_clamp": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _i, _vp]),
     "srbh_rrdbnet_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "srbh_rrdbnet_last_status": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "srbh_wmse_sum": (_i, [_vp, _vp, _vp, C.c_long, _vp, _vp]),
+    "srbh_wmse_grad": (_i, [_vp, _vp, _vp, C.c_long, _vp, _vp, _vp]),
+    "srbh_cedice_sums": (_i, [_vp, _i, _i, C.c_long, C.c_long, C.c_long, C.c_long, _vp, _vp, _vp, _vp]),
+    "srbh_cedice_grad": (_i, [_vp, _i, _i, C.c_long, C.c_long, C.c_long, C.c_long, _vp, _vp, _vp, _vp, _vp]),
+    "srbh_height_metric_sums": (_i, [_vp, _vp, _vp, C.c_long, _i, _vp, _vp]),
+    "srbh_confusion_add": (_i, [_vp, _vp, C.c_long, _i, _vp, _vp, _vp]),
     "srbh_trunk_timing": (_i, [_i]),
     "srbh_trunk_last_ms": (_i, [C.POINTER(C.c_float)]),
     "srbh_rrdbnet_forward": (_i, [C.POINTER(RRDBNetDesc), _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

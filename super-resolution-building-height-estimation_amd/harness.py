@@ -17,32 +17,7 @@ HIR = (0, 3, 12, 21, 30, 60, 90, 256)                       # train.py:55
 CLASS_WEIGHT = (0.08878965, 0.272375, 0.32563883, 0.74654097, 0.99655239, 1.62749907, 2.94260409)
 
 
-class MSE_adapt_weight(nn.Module):
-    """selfloss.py:81-91 (without the hard-coded device="cuda")."""
-
-    def __init__(self, log_var=0.0, device=None):
-        super().__init__()
-        self.log_var = nn.Parameter(torch.tensor(float(log_var), device=device))
-
-    def forward(self, inputs, targets, weight):
-        loss = (F.mse_loss(inputs, targets, reduction="none") * weight).mean()
-        return loss * torch.exp(-self.log_var) + self.log_var
-
-
-class CE_DICE_adapt_weight(nn.Module):
-    """selfloss.py:145-168 + Dice (selfloss.py:6-17)."""
-
-    def __init__(self, log_var=0.0, device=None):
-        super().__init__()
-        self.log_var = nn.Parameter(torch.tensor(float(log_var), device=device))
-
-    def forward(self, pmask, rmask, weight):
-        loss_ce = (F.cross_entropy(pmask, rmask, reduction="none") * weight).mean()
-        fg = pmask.softmax(dim=1)[:, 1:].sum(dim=1)
-        n = fg.size(0)
-        m1, m2 = fg.reshape(n, -1), (rmask > 0).reshape(n, -1)
-        dice = 1 - (2.0 * (m1 * m2).sum() + 1.0) / (m1.sum() + m2.sum() + 1.0)
-        return (loss_ce + dice) * torch.exp(-self.log_var) + self.log_var
+from .losses import MSE_adapt_weight, CE_DICE_adapt_weight   # noqa: E402  (libsrbh reductions, losses.py)
 
 
 def synthetic_batch(batch, seed, device, aggregate=None):

@@ -245,7 +245,102 @@ def g_hierweight():
     save("g9_hierweight", **out)
 
 
+# ---- G10 / G11: losses and metrics (selfloss.py, metrics.py) ------------------------------------------------------
+def g_losses_metrics():
+    from oracle import loss_oracle as LO
+    _real_tensor = torch.tensor
+    torch.tensor = lambda *a, **k: _real_tensor(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})   # selfloss.py:74,84,128,151 hard-code device="cuda"
+    try:
+        import losses_pytorch.selfloss as ref_loss
+        arrs = {}
+        B, C, H = 2, 7, 24
+        hp = rand((B, H, H), 201, 0.0, 40.0).requires_grad_(True)
+        ht = torch.where(rand((B, H, H), 202, 0, 1) > 0.7, rand((B, H, H), 203, 0, 90.0), torch.zeros(B, H, H)).round()
+        cls = torch.bucketize(ht, torch.tensor([3., 12., 21., 30., 60., 90.]), right=True)
+        cls = torch.where(ht <= 0, torch.zeros_like(cls), cls).long()
+        wt = torch.tensor([0.0888, 0.2724, 0.3256, 0.7465, 0.9966, 1.6275, 2.9426])[cls]
+        logits = (rand((B, C, H, H), 204, -3.0, 3.0)).requires_grad_(True)
+        for lv in (0.0, 0.37):
+            m = ref_loss.MSE_adapt_weight(lv)
+            want = m(hp, ht, wt)
+            g_in, g_lv = torch.autograd.grad(want, [hp, m.log_var])
+            lvt = torch.tensor(lv, requires_grad=True)
+            got = LO.mse_adapt_weight(hp, ht, wt, lvt)
+            og_in, og_lv = torch.autograd.grad(got, [hp, lvt])
+            check(f"G10 mse_adapt_weight lv={lv}", got, want)
+            check(f"G10 mse_adapt_weight grad lv={lv}", og_in, g_in)
+            check(f"G10 mse_adapt_weight dlogvar lv={lv}", og_lv, g_lv)
+            arrs[f"mse_lv{lv}"] = want.detach(); arrs[f"mse_grad_lv{lv}"] = g_in; arrs[f"mse_dlv_lv{lv}"] = g_lv
+            m2 = ref_loss.CE_DICE_adapt_weight(lv)
+            want = m2(logits, cls, wt)
+            g_in, g_lv = torch.autograd.grad(want, [logits, m2.log_var])
+            lvt = torch.tensor(lv, requires_grad=True)
+            got = LO.ce_dice_adapt_weight(logits, cls, wt, lvt)
+            og_in, og_lv = torch.autograd.grad(got, [logits, lvt])
+            check(f"G10 ce_dice_adapt_weight lv={lv}", got, want)
+            check(f"G10 ce_dice_adapt_weight grad lv={lv}", og_in, g_in)
+            arrs[f"cedice_lv{lv}"] = want.detach(); arrs[f"cedice_grad_lv{lv}"] = g_in; arrs[f"cedice_dlv_lv{lv}"] = g_lv
+        m3 = ref_loss.MSE_adapt(0.1)
+        want = m3(hp, ht)
+        check("G10 mse_adapt (unweighted)", LO.mse_adapt_weight(hp, ht, None, m3.log_var), want)
+        arrs["mse_unw"] = want.detach()
+        m4 = ref_loss.CE_DICE_adapt(0.1)
+        want = m4(logits, cls)
+        check("G10 ce_dice_adapt (unweighted)", LO.ce_dice_adapt_weight(logits, cls, None, m4.log_var), want)
+        arrs["cedice_unw"] = want.detach()
+        d = ref_loss.Dice()
+        pr, tg = rand((B, H, H), 205, 0, 1), (cls > 0)
+        check("G10 dice", LO.dice(pr, tg), d(pr, tg))
+        arrs["dice"] = d(pr, tg)
+        save("g10_losses", height_pred=hp.detach(), height=ht, cls=cls.to(torch.int16), weight=wt, logits=logits.detach(),
+             dice_pred=pr, **arrs)
+    finally:
+        torch.tensor = _real_tensor
+
+    sys.modules.setdefault("pandas", __import__("pandas"))
+    import metrics as ref_metrics
+    out = {}
+    m = ref_metrics.SegmentationMetric(3, device="cpu")
+    ref = torch.tensor([0, 0, 1, 1, 2, 2, 2, 2, 2])                # the reference's own toy vectors (metrics.py:466-469)
+    pred = torch.tensor([0, 1, 0, 1, 0, 2, 0, 0, 0])
+    m.addBatch(pred, ref)
+    assert torch.equal(LO.confusion_matrix(pred, ref, 3).double(), m.confusionMatrix)
+    out.update(toy_ref=ref, toy_pred=pred, toy_cm=m.confusionMatrix, toy_fwiou=m.Frequency_Weighted_Intersection_over_Union(),
+               toy_oa=m.OverallAccuracy(), toy_precision=m.Precision(), toy_recall=m.Recall(), toy_f1=m.F1score(),
+               toy_iou=m.IntersectionOverUnion(), toy_miou=m.meanIntersectionOverUnion(), toy_mfwiou=m.mFWIoU())
+    g = torch.Generator(); g.manual_seed(301)
+    lab = torch.randint(0, 7, (2, 40, 40), generator=g)
+    prd = torch.where(torch.rand(2, 40, 40, generator=g) > 0.4, lab, torch.randint(0, 7, (2, 40, 40), generator=g))
+    m7 = ref_metrics.SegmentationMetric(7, device="cpu")
+    m7.addBatch(prd, lab)
+    assert torch.equal(LO.confusion_matrix(prd, lab, 7).double(), m7.confusionMatrix)
+    out.update(seg_label=lab.to(torch.int16), seg_pred=prd.to(torch.int16), seg_cm=m7.confusionMatrix)
+    hm = ref_metrics.HeightMetric(numClass=7, device="cpu")
+    tref = torch.tensor([0, 0, 3, 6, 5, 1]).float()                # metrics.py:482-484 (commented toy case)
+    tpred = torch.tensor([0, 1, 0, 1, 0, 2]).float()
+    hm.addBatch(tpred, tref, tref)
+    st, ct = LO.height_metric_batch(tpred, tref, tref, 7)
+    check("G11 height metric toy stats", st, hm.stats); assert torch.equal(ct, hm.count)
+    out.update(hm_toy_stats=hm.stats, hm_toy_count=hm.count, hm_toy_each=hm.getAvgEach(), hm_toy_all=hm.getAvgAll(),
+               hm_toy_balance=hm.getAvgBalance())
+    hm2 = ref_metrics.HeightMetric(numClass=7, device="cpu")
+    hp2 = torch.rand(2, 40, 40, generator=g) * 50
+    hr2 = torch.rand(2, 40, 40, generator=g) * 50
+    for b in range(2):      # two addBatch calls: per-batch rmse * count accumulates (not a global rmse)
+        hm2.addBatch(hp2[b], hr2[b], lab[b])
+    st = torch.zeros(7, 3, dtype=torch.float64); ct = torch.zeros(7, 1, dtype=torch.float64)
+    for b in range(2):
+        s_, c_ = LO.height_metric_batch(hp2[b], hr2[b], lab[b], 7)
+        st += s_; ct += c_
+    check("G11 height metric stats", st, hm2.stats); assert torch.equal(ct, hm2.count)
+    out.update(hm_pred=hp2, hm_ref=hr2, hm_stats=hm2.stats, hm_count=hm2.count, hm_each=hm2.getAvgEach(),
+               hm_all=hm2.getAvgAll(), hm_balance=hm2.getAvgBalance())
+    print("  pinned G11 metrics: confusion matrices bit-exact, height statistics <=1e-6")
+    save("g11_metrics", **out)
+
+
 if __name__ == "__main__":
+    g_losses_metrics()
     g_hierweight()
     g_rdb()
     g_small_net()
