@@ -27,6 +27,10 @@
 #define PT_EPI_BARRIER 0
 #endif
 
+#ifndef PT_DMA_GROUPS
+#define PT_DMA_GROUPS 3
+#endif
+
 namespace {
 using namespace srbh;
 using namespace srbh_k;
@@ -115,20 +119,41 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
     const int woff = lane * 16;
     const long tile_off = (long)img * pp.img_b + (long)Y0 * pp.row_b;
 
+    // ---- one 16-B-per-lane LDS-DMA under an explicit EXEC mask (all-ones, none, or the tail lanes): predication without a
+    // branch.  SC1 = bypass this CU's L1 (activations written by other CUs inside this launch); weights may hit L1.
+    const unsigned long long tail_mask = __builtin_amdgcn_ballot_w64(tail_ok);
+    auto lds_addr = [](const char* p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p; };
+    auto uni64 = [](unsigned long long m) {   // make uniformity visible to the compiler ("s" operands must be SGPRs)
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)m), hi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    auto dma16 = [&](auto sc1_tag, const char* gaddr, const unsigned lds_off_v, const unsigned long long mask) {
+        unsigned long long sv;
+        const unsigned lds_off = __builtin_amdgcn_readfirstlane(lds_off_v);
+        if constexpr (decltype(sc1_tag)::value)
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %3, off sc1\n\ts_mov_b64 exec, %0"
+                         : "=&s"(sv) : "s"(mask), "s"(lds_off), "v"(gaddr) : "memory", "m0");
+        else
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %3, off\n\ts_mov_b64 exec, %0"
+                         : "=&s"(sv) : "s"(mask), "s"(lds_off), "v"(gaddr) : "memory", "m0");
+    };
+
     // ---- cold staging of one step (used where nothing could be prefetched): input plane (if any) to `din`, the
     // 18 * ncb weight fragments to `dw`
     auto stage_cold = [&](const char* src, char* din, const char* wsrc, char* dw, const int ncb) {
+        const unsigned din_l = lds_addr(din), dw_l = lds_addr(dw);
         if (src) {
 #pragma unroll
             for (int j = 0; j < G::NJ; ++j)
-                if (j < G::NJ - 1 || tail_ok)   // activations: sc1 = bypass this CU's L1 (written by other CUs in this launch)
-                    __builtin_amdgcn_global_load_lds(GPTR(src + goff[j]), LPTR(din + (j * 256 + wave * 64) * 16), 16, 0, 16);
+                dma16(std::true_type{}, src + goff[j], din_l + (j * 256 + wave * 64) * 16, j < G::NJ - 1 ? ~0ull : tail_mask);
         }
         const char* ws = wsrc + lane * 16;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             const int f = wave + 4 * k;
-            if (f < 18 * ncb) __builtin_amdgcn_global_load_lds(GPTR(ws + f * 1024), LPTR(dw + f * 1024), 16, 0, 0);
+            dma16(std::false_type{}, ws + f * 1024, dw_l + f * 1024, uni64(f < 18 * ncb ? ~0ull : 0ull));
         }
     };
     auto chunk_src = [&](const PLayer& l, int c) { return pp.dense[l.in_sel] + tile_off + (long)c * pp.plane_b; };
@@ -259,28 +284,36 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
             // LDS-DMA issue order: the instructions that carry the two halo rows (tile rows 0 and 9: j = 0, 1, 9, 10) go last
             constexpr int JORD[12] = {2, 3, 4, 5, 6, 7, 8, 0, 1, 9, 10, 11};
             static_assert(G::NJ == 11 && JPP == 2, "DMA issue order is written for 11 instructions, 2 per group");
+            // Every staging decision is an EXEC mask, not a branch (dma16): the whole step is one basic block, so the
+            // DMA set-up (address, M0) is scheduled into the shadow of the MFMAs instead of idling the matrix core between
+            // groups (a one-wave-per-SIMD kernel has nobody else to fill that gap).
+            const unsigned long long m_all = ~0ull;
+            const unsigned long long m_in = uni64((next_cb && nsrc) ? m_all : 0ull);      // nullptr: the step reads the resident plane
+            const unsigned long long m_tail = uni64((next_cb && nsrc) ? tail_mask : 0ull);
+            const unsigned long long m_w = uni64(next_cb ? m_all : 0ull);
+            const unsigned long long m_w4 = uni64((next_cb == 2 || (next_cb == 1 && wave < 2)) ? m_all : 0ull);   // fragments 16..19: 18 or 36 in total
+            const unsigned long long m_w2 = uni64(next_cb == 2 ? m_all : 0ull);
+            const unsigned dst_l = lds_addr(dst);
+            // The 20 DMA instructions of the next step are issued in the first PT_DMA_GROUPS MFMA groups: a step cannot end
+            // before its LAST DMA has landed (issue time + ~1.4 k cycles of L2 latency), so spreading them over all six
+            // groups made every step latency-bound (3.3 k cycles for 2.3 k of MFMA work).
+            auto issue = [&](const int i) {
+                if (i < 11) {
+                    const int j = JORD[i];
+                    dma16(std::true_type{}, nsrc + goff[j], dst_l + (j * 256 + wave * 64) * 16, j < G::NJ - 1 ? m_in : m_tail);
+                } else if (i < 16) {
+                    const int f = wave + 4 * (i - 11);
+                    dma16(std::false_type{}, ws + f * 1024, dst_l + IN_EX + f * 1024, i < 15 ? m_w : m_w4);
+                } else {
+                    const int f = 20 + wave + 4 * (i - 16);
+                    dma16(std::false_type{}, ws + f * 1024, dst_l + IN_EX + f * 1024, m_w2);
+                }
+            };
 #pragma unroll
             for (int g = 0; g < 6; ++g) {
-                if (next_cb) {
-                    if (nsrc) {   // nullptr: the step reads the resident plane
 #pragma unroll
-                        for (int jj = 0; jj < JPP; ++jj) {
-                            const int j = JORD[g * JPP + jj];
-                            if (j < G::NJ && (j < G::NJ - 1 || tail_ok))
-                                __builtin_amdgcn_global_load_lds(GPTR(nsrc + goff[j < G::NJ ? j : 0]),
-                                                                 LPTR(dst + (j * 256 + wave * 64) * 16), 16, 0, 16);
-                        }
-                    }
-                    // weights: 18 (cout 32) or 36 fragments
-                    if (g < 4 || (g == 4 && (wave < 2 || next_cb == 2))) {
-                        const int f = wave + 4 * g;
-                        __builtin_amdgcn_global_load_lds(GPTR(ws + f * 1024), LPTR(dst + IN_EX + f * 1024), 16, 0, 0);
-                    }
-                    if (next_cb == 2 && g < 4) {
-                        const int f = 20 + wave + 4 * g;
-                        __builtin_amdgcn_global_load_lds(GPTR(ws + f * 1024), LPTR(dst + IN_EX + f * 1024), 16, 0, 0);
-                    }
-                }
+                for (int i = 0; i < 20; ++i)
+                    if (i * PT_DMA_GROUPS / 20 == g) issue(i);
                 if (g + 1 < 6) load_group(sbi, sbw, g + 1, (g + 1) & 1);
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
