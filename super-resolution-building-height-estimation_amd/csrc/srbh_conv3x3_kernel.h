@@ -186,7 +186,13 @@ __device__ __forceinline__ void conv_tile(const KParams& p, char* smem, const in
         load_group(sb, 0, 0);
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
-            if (more && ABL != 2) stage_part(c + 1, (c + 1) & 1, g);
+            // all six DMA slices of chunk c+1 go out in the first two MFMA groups: a chunk cannot end before its LAST
+            // slice has landed (issue time + L2 latency), spreading them over all six groups made every chunk latency-bound
+            if (more && ABL != 2 && g < 2) {
+                stage_part(c + 1, (c + 1) & 1, 3 * g);
+                stage_part(c + 1, (c + 1) & 1, 3 * g + 1);
+                stage_part(c + 1, (c + 1) & 1, 3 * g + 2);
+            }
             if (g + 1 < 6) load_group(sb, g + 1, (g + 1) & 1);   // next group's LDS reads fly under this group's MFMAs
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
