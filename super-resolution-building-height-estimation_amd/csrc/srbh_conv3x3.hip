@@ -62,6 +62,12 @@ extern "C" int srbh_conv3x3_f16(const srbh_conv3x3_args* a, void* stream_) {
     SRBH_REQUIRE(!(a->res1 || a->res2 || a->skip) || a->cout == 64,
                  "srbh_conv3x3_f16: residual/skip epilogues need cout == 64");
 
+    {   // many-tile 64 -> 64 convs (the up-sampler tail) have a persistent form, see srbh_ptail.hip
+        int used = 0;
+        const int rc = ptail_run(a, stream, &used);
+        if (rc != SRBH_OK || used) return rc;
+    }
+
     const int inH = a->upsample2x ? a->H / 2 : a->H, inW = a->upsample2x ? a->W / 2 : a->W;
     const Act16Geo gi = act16_geo(a->B, a->in_chunks_total, inH, inW);
     KParams p;

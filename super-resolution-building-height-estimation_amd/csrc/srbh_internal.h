@@ -53,6 +53,7 @@ inline Act16Geo act16_geo(int B, int chunks, int H, int W) {
 // persistent trunk (srbh_ptrunk.hip)
 size_t ptrunk_aux_bytes(int B, int tiles_per_img);
 size_t ptrunk_err_offset(int B, int tiles_per_img);
+int ptail_run(const srbh_conv3x3_args* a, hipStream_t stream, int* used);
 int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr, float* xrr, int B, int H, int W,
                void* aux, hipStream_t stream, int* used, int* final_cur);
 

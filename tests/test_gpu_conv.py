@@ -151,3 +151,30 @@ def test_argument_errors_are_loud():
     with pytest.raises(RuntimeError, match="chunk range"):
         G.run_conv(a)
     assert b"chunk" in _lib.lib().srbh_last_error()
+
+
+@pytest.mark.parametrize("ups,H,W", [(1, 256, 256), (0, 256, 256), (0, 250, 200)])
+def test_persistent_tail_form_is_bit_identical(ups, H, W, monkeypatch):
+    """>= 512 tiles of a 64 -> 64 conv take the persistent form (srbh_ptail.hip): same bits as the per-tile kernel, for
+    the nearest-x2 + lrelu + fp16 output (conv_up*) and the plain fp32 NHWC output (conv_hr), incl. ragged edges."""
+    B, cin, cout = 5, 64, 64
+    hin, win = (H // 2, W // 2) if ups else (H, W)
+    x, w, b = rnd((B, cin, hin, win), 21), rnd((cout, cin, 3, 3), 22, -0.1, 0.1), rnd((cout,), 23)
+    xin = G.act16_from_nchw(x.to(DEV))
+    wp, bp = G.pack_w(w.to(DEV)), b.to(DEV)
+    res = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SRBH_PTAIL", mode)
+        o16 = G.act16_alloc(B, 2, H, W, DEV)
+        o32 = torch.zeros((B, H, W, cout), device=DEV)
+        a = G.conv_args(**{"in": xin.data_ptr()}, in_chunks_total=2, in_chunk0=0, in_chunks=2, w=wp.data_ptr(),
+                        bias=bp.data_ptr(), cout=cout, B=B, H=H, W=W, upsample2x=ups, lrelu=ups,
+                        out16=o16.data_ptr(), out16_chunks_total=2, out16_chunk0=0, out32=o32.data_ptr(), out32_c=64)
+        G.run_conv(a)
+        torch.cuda.synchronize()
+        res.append((o16.clone(), o32.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    want = G.ref_conv(x[:1], w, b, ups=bool(ups))
+    if ups:
+        want = torch.nn.functional.leaky_relu(want, 0.2)
+    assert O.rel_l2(res[0][1][:1].permute(0, 3, 1, 2).cpu(), want) <= TIGHT
