@@ -1,9 +1,10 @@
 """CPU oracle of the loader-side tensor math  --  TEST INFRASTRUCTURE ONLY.
 
 numpy/torch restatement of reference BH_loader.py:326-329 (buildhir LUT), :361-369 (normalise + clip), :373-392 (label
-branch of myImageFloder_S12_globe.__getitem__).  ``hierweight`` itself is pinned against the imported reference
-functions and the author's comment vectors (tests/golden/g9_hierweight.npz); the per-sample label code lives inside a
-Dataset that needs GeoTIFF IO and cannot be run, so for it this is a line-by-line restatement (parity unpinned)."""
+branch of myImageFloder_S12_globe.__getitem__).  Pinned: ``hierweight`` against the imported reference functions and
+the author's comment vectors (tests/golden/g9_hierweight.npz); the per-sample code by executing the reference's own
+Dataset class with fake tifffile / cv2 IO (tools/make_golden.py::g_loader, fixture g13_loader.npz: labels, weights and
+aggregates bit-exact, normalised tiles to fp32 rounding)."""
 import numpy as np
 import torch
 

@@ -1,8 +1,10 @@
 """CPU oracle of the inference epilogue  --  TEST INFRASTRUCTURE ONLY.
 
 Literal numpy restatement of reference predict_realesanet_feature_globe.py:156-158,172-185,195-204 (same dtypes, same
-operation order).  PARITY UNPINNED: that script imports gdal/rasterio/geopandas at module level and cannot be imported
-here, and the reference holds no fixture for it; the integer steps are nevertheless the reference's own numpy calls."""
+operation order).  Pinned: tools/make_golden.py executes the reference's own ``predict_whole_image_grid`` (module
+imported with stub GIS / IO modules, grid loader + raster writers + the two networks replaced by fakes that feed the
+synthetic city below) and stores what it hands to the raster writers (tests/golden/g12_mosaic.npz); this oracle and the
+HIP kernels must reproduce those arrays bit for bit."""
 import numpy as np
 import torch
 
@@ -31,3 +33,26 @@ class MosaicOracle:
         mask = self.res_weight > 0                                                  # :201
         h[mask] = np.round(h[mask] / self.res_weight[mask]).astype(np.uint16)       # :203
         return h, build
+
+
+def synthetic_city(seed=2024, lr_w=24, lr_h=20, tile=8, n_extra=14, chans_build=7):
+    """A small 'city' for the mosaic fixtures: LR raster lr_h x lr_w, tiles of `tile` LR cells (4x that in HR), a regular
+    grid of windows plus `n_extra` random overlapping ones; windows at the right/bottom edge are clipped (xcount/ycount <
+    tile) as the reference's grid index does.  Returns per-tile predictions (N,1,4t,4t) / logits (N,C,4t,4t) and the
+    (N,4) int64 LR windows [xoff, yoff, xcount, ycount]."""
+    g = torch.Generator()
+    g.manual_seed(seed)
+    pos = []
+    for y in range(0, lr_h, tile):
+        for x in range(0, lr_w, tile):
+            pos.append([x, y, min(tile, lr_w - x), min(tile, lr_h - y)])
+    for _ in range(n_extra):
+        x = int(torch.randint(0, lr_w - 1, (1,), generator=g))
+        y = int(torch.randint(0, lr_h - 1, (1,), generator=g))
+        pos.append([x, y, min(tile, lr_w - x), min(tile, lr_h - y)])
+    pos = torch.tensor(pos, dtype=torch.int64)
+    n, hr = pos.shape[0], 4 * tile
+    ypred = torch.rand(n, 1, hr, hr, generator=g) * 70.0 - 5.0         # some negatives: exercises the clamp (:173)
+    ypred[:, :, ::5, ::7] = (torch.randint(0, 600, (n, 1, (hr + 4) // 5, (hr + 6) // 7), generator=g).float() + 0.5) / 10.0   # exact .5 ties after *10
+    logits = torch.randn(n, chans_build, hr, hr, generator=g) * 3.0
+    return ypred, logits, pos, lr_w, lr_h

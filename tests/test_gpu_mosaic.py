@@ -53,3 +53,20 @@ def test_mosaic_matches_reference_numpy_semantics_and_is_shard_invariant():
     assert torch.equal(a.res_weight, full.res_weight)
     h2, b2 = a.finalize()
     assert torch.equal(h2.view(torch.int16), got_h.view(torch.int16)) and torch.equal(b2, got_b)
+
+
+def test_mosaic_matches_reference_predict_outputs(golden_dir):
+    """g12_mosaic.npz holds what the reference's own predict_whole_image_grid wrote for the synthetic city (tools/
+    make_golden.py ran it with fake networks / loader / raster writers): heights bit-exact; the class map may differ
+    only where the GPU softmax's exp rounding flips a x255 rounding or an argmax tie."""
+    import os
+    from oracle.mosaic_oracle import synthetic_city
+    from srbh_amd.mosaic import Mosaic
+    g = np.load(os.path.join(golden_dir, "g12_mosaic.npz"))
+    ypred, logits, pos, lr_w, lr_h = synthetic_city()
+    assert np.array_equal(pos.numpy(), g["pos"]) and lr_w == int(g["lr_w"]) and lr_h == int(g["lr_h"])
+    m = Mosaic(lr_h * 4, lr_w * 4, 7, DEV)
+    m.add(ypred.to(DEV), logits.to(DEV), pos.tolist())
+    h, b = m.finalize()
+    assert np.array_equal(h.cpu().numpy().astype(np.uint16), g["height"])
+    assert (b.cpu().numpy() != g["build"]).mean() < 1e-3

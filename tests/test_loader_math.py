@@ -52,3 +52,37 @@ def test_label_prep_and_normalize_kernels(golden_dir):
     assert float(out.min()) == 0.0 and float(out.max()) == 1.0
     out2 = LM.normalize_tiles(img.to("cuda:0"), mins, maxs, None)     # grid loader: no clip (BH_loader.py:984-986)
     assert float(out2.min()) < 0.0
+
+
+def _g13(golden_dir):
+    return np.load(os.path.join(golden_dir, "g13_loader.npz"))
+
+
+def test_loader_oracle_matches_reference_dataset_outputs(golden_dir):
+    """g13_loader.npz = outputs of the reference's own myImageFloder_S12_globe.__getitem__ (tools/make_golden.py ran it
+    with fake tifffile / cv2 IO): the oracle's restatement must reproduce them (labels bit-exact)."""
+    from oracle import loader_oracle as LO
+    g = _g13(golden_dir)
+    for i in range(g["s2"].shape[0]):
+        raw = torch.from_numpy(np.concatenate([g["s2"][i], g["s1"][i]], axis=-1)).permute(2, 0, 1)
+        img = LO.normalize(raw, g["mins"], g["maxs"], (0, 1))
+        assert torch.allclose(img, torch.from_numpy(g[f"img{i}"]), rtol=1e-6, atol=1e-7)
+        hf, ha, b, w, wa = LO.label_prep(g["height_u8"][i], HIR, g["heightweight"])
+        assert np.array_equal(ha.numpy(), g[f"height_aggre{i}"]) and np.array_equal(b.numpy(), g[f"build{i}"])
+        assert np.array_equal(w.numpy(), g[f"weight{i}"]) and np.array_equal(wa.numpy(), g[f"weight_aggre{i}"])
+
+
+@pytest.mark.gpu
+def test_loader_kernels_match_reference_dataset_outputs(golden_dir):
+    from srbh_amd import loader_math as LM
+    g = _g13(golden_dir)
+    n = g["s2"].shape[0]
+    raw = torch.from_numpy(np.concatenate([g["s2"], g["s1"]], axis=-1)).permute(0, 3, 1, 2).contiguous()
+    img = LM.normalize_tiles(raw.to("cuda:0"), g["mins"], g["maxs"], (0, 1)).cpu()
+    prep = LM.LabelPrep(HIR, g["heightweight"], "cuda:0")
+    hf, ha, build, wt, wa = prep(torch.from_numpy(g["height_u8"]).to("cuda:0"))
+    for i in range(n):
+        assert torch.allclose(img[i], torch.from_numpy(g[f"img{i}"]), rtol=1e-6, atol=1e-7)
+        assert np.array_equal(build[i].cpu().numpy(), g[f"build{i}"]) and np.array_equal(wt[i].cpu().numpy(), g[f"weight{i}"])
+        assert np.allclose(ha[i].cpu().numpy(), g[f"height_aggre{i}"], rtol=1e-6, atol=1e-6)
+        assert float((wa[i].cpu().numpy() != g[f"weight_aggre{i}"]).mean()) < 1e-2

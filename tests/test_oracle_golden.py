@@ -126,3 +126,16 @@ def test_g8_aggregate(golden_dir):
     # for non-negative labels it is a 4x4 mean pool
     pos = lab.clamp_min(0)
     assert torch.allclose(O.aggregate_torch(pos, 0.25), torch.nn.functional.avg_pool2d(pos, 4).squeeze(), atol=1e-4)
+
+
+def test_mosaic_oracle_matches_reference_predict_outputs(golden_dir):
+    """The reference's predict_whole_image_grid itself produced g12_mosaic.npz (see tools/make_golden.py::g_mosaic)."""
+    import os
+    import numpy as np
+    from oracle.mosaic_oracle import MosaicOracle, synthetic_city
+    g = np.load(os.path.join(golden_dir, "g12_mosaic.npz"))
+    ypred, logits, pos, lr_w, lr_h = synthetic_city()
+    o = MosaicOracle(lr_h * 4, lr_w * 4, 7)
+    o.add(ypred, logits, pos)
+    h, b = o.finalize()
+    assert np.array_equal(h, g["height"]) and np.array_equal(b, g["build"])

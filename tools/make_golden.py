@@ -339,7 +339,145 @@ def g_losses_metrics():
     save("g11_metrics", **out)
 
 
+# ---- G12: inference epilogue + mosaic, by running the reference's own predict_whole_image_grid -----------------
+class _FakeGrid(torch.utils.data.Dataset):            # stands in for BH_loader.gridimgLoader (GeoTIFF IO)
+    def __init__(self, **kw):
+        from oracle.mosaic_oracle import synthetic_city
+        _, _, self.pos, self.width, self.height = synthetic_city()
+        self.s2path, self.geotrans = "fake_s2.tif", (0.0, 10.0, 0.0, 0.0, 0.0, -10.0)
+
+    def __len__(self):
+        return self.pos.shape[0]
+
+    def __getitem__(self, i):
+        x = torch.zeros(8, 8, 8)
+        x[0, 0, 0] = float(i)                          # the fake networks look the tile up by this id
+        return x, np.array(self.pos[i])
+
+
+def g_mosaic():
+    from types import SimpleNamespace
+    from oracle import mosaic_oracle as MO
+
+    class _Dummy(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return lambda *a, **k: None
+    for m in ("tensorboardX", "tifffile", "albumentations", "osgeo", "osgeo.gdal", "geopandas", "matplotlib",
+              "matplotlib.pyplot", "segmentation_models_pytorch", "segmentation_models_pytorch.base",
+              "segmentation_models_pytorch.encoders", "segmentation_models_pytorch.unet",
+              "segmentation_models_pytorch.unet.decoder", "segmentation_models_pytorch.base.heads", "rasterio", "cv2",
+              "skimage", "skimage.transform", "skimage.measure", "shapely", "shapely.geometry", "fiona", "ttach",
+              "mymodels"):     # (the reference's mymodels.py does not even parse: IndentationError at :467)
+        if not isinstance(sys.modules.get(m), _Dummy):
+            sys.modules[m] = _Dummy(m)
+    sys.modules["osgeo"].gdal = sys.modules["osgeo.gdal"]
+    _real_tensor = torch.tensor
+    torch.tensor = lambda *a, **k: _real_tensor(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+    try:
+        import predict_realesanet_feature_globe as ref_pred
+    finally:
+        torch.tensor = _real_tensor
+    ypred, logits, pos, lr_w, lr_h = MO.synthetic_city()
+    captured = {}
+    ref_pred.gridimgLoader = _FakeGrid
+    ref_pred.array2raster_rio = lambda path, arr, *a, **k: captured.__setitem__("build", np.array(arr))
+    ref_pred.array2raster = lambda path, arr, *a, **k: captured.__setitem__("height", np.array(arr))
+
+    class _FakeHR:
+        def eval(self):
+            return self
+
+        def forward_feature(self, x):
+            return None
+
+    class _FakeModel:
+        def eval(self):
+            return self
+
+        def forward(self, x, hr_fea):
+            idx = x[:, 0, 0, 0].long()
+            return ypred[idx], logits[idx]
+    args = SimpleNamespace(wholeimgpath="", datastats="", s1dir="s1", s2dir="s2", nchanss2=6, chans_build=7)
+    ref_pred.predict_whole_image_grid(args, "fakecity", _FakeModel(), _FakeHR(), "cpu", 0, respath="/tmp", gridvalid="isv")
+    assert captured["height"].dtype == np.uint16 and captured["build"].dtype == np.uint8
+    o = MO.MosaicOracle(lr_h * 4, lr_w * 4, 7)
+    o.add(ypred, logits, pos)
+    h, b = o.finalize()
+    assert np.array_equal(h, captured["height"]) and np.array_equal(b, captured["build"]), "mosaic oracle != reference"
+    print("  pinned G12 mosaic: oracle == reference predict_whole_image_grid outputs (bit-exact, %d tiles)" % pos.shape[0])
+    save("g12_mosaic", height=captured["height"], build=captured["build"], pos=pos, lr_w=lr_w, lr_h=lr_h)
+
+
+# ---- G13: loader tensor math, by running the reference's own myImageFloder_S12_globe.__getitem__ ---------------
+def g_loader():
+    import tempfile
+    import BH_loader as ref_loader            # (imported by g_mosaic with the stub GIS / augmentation modules)
+    from oracle import loader_oracle as LO
+    rs = np.random.RandomState(77)
+    n, h = 3, 16
+    stats = np.loadtxt("/root/reference/datasetglobe/bh_stats_globe.txt")
+    p = stats / stats.sum()
+    s2 = rs.randint(0, 6000, size=(n, h, h, 6)).astype(np.float32)
+    s1 = (rs.rand(n, h, h, 2) * 40 - 30).astype(np.float32)
+    height = rs.choice(256, size=(n, 4 * h, 4 * h), p=p).astype(np.uint8)
+    height[:, :8, :8] = rs.randint(1, 200, size=(n, 8, 8))            # make sure every hierarchy class occurs
+    mins2, maxs2 = np.full(6, 100.0), np.linspace(3000, 5000, 6)        # values outside [min,max] exercise the clip
+    mins1, maxs1 = np.array([-25.0, -28.0]), np.array([5.0, 2.0])
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "bh"))
+    names = [f"t{i}.tif" for i in range(n)]
+    with open(os.path.join(tmp, "list.csv"), "w") as f:
+        f.write("\n".join(names) + "\n")
+    for nm in names:
+        open(os.path.join(tmp, "bh", nm), "w").close()                  # os.path.exists(height_path) must hold
+    np.savetxt(os.path.join(tmp, "s2_minmax.txt"), np.stack([mins2, maxs2]))
+    np.savetxt(os.path.join(tmp, "s1_minmax.txt"), np.stack([mins1, maxs1]))
+    idx = {nm: i for i, nm in enumerate(names)}
+
+    class _Tif:                                                         # tifffile.imread
+        @staticmethod
+        def imread(path):
+            i = idx[os.path.basename(path)]
+            return s2[i] if os.sep + "s2" + os.sep in path else s1[i]
+
+    class _Cv2:                                                         # the two cv2 calls of __getitem__
+        IMREAD_UNCHANGED, INTER_NEAREST = -1, 0
+
+        @staticmethod
+        def imread(path, flag):
+            return height[idx[os.path.basename(path)]].copy()
+
+        @staticmethod
+        def resize(img, dsize, interpolation):                          # exact x4 nearest: dst[i] = src[i // 4]
+            assert dsize == (4 * img.shape[0], 4 * img.shape[1])
+            return np.repeat(np.repeat(img, 4, axis=0), 4, axis=1)
+    ref_loader.tif, ref_loader.cv2 = _Tif, _Cv2
+    ref_loader.image_transform = lambda image, mask: {"image": image, "mask": mask}     # identity "augmentation"
+    hir = (0, 3, 12, 21, 30, 60, 90, 256)
+    ds = ref_loader.myImageFloder_S12_globe(os.path.join(tmp, "list.csv"), tmp, datastats=tmp, normmethod="minmax",
+                                            datarange=(0, 1), aug=True, preweight="/root/reference/datasetglobe/bh_stats_globe.txt",
+                                            isaggre=True, ishir=True, hir=hir, nchans=6)
+    out = dict(s2=s2, s1=s1, height_u8=height, mins=np.concatenate([mins2, mins1]), maxs=np.concatenate([maxs2, maxs1]),
+               heightweight=ds.heightweight)
+    for i in range(n):
+        img, (hf, ha), build, (wt, wa) = ds[i]
+        raw = torch.from_numpy(np.concatenate([s2[i], s1[i]], axis=-1)).permute(2, 0, 1)
+        o_img = LO.normalize(raw, out["mins"], out["maxs"], (0, 1))
+        o_hf, o_ha, o_b, o_w, o_wa = LO.label_prep(height[i], hir, ds.heightweight)
+        check(f"G13 loader img {i}", o_img, img)
+        assert torch.equal(o_hf, hf) and torch.equal(o_ha, ha) and torch.equal(o_b, build)
+        assert torch.equal(o_w, wt) and torch.equal(o_wa, wa)
+        out.update({f"img{i}": img, f"height_aggre{i}": ha, f"build{i}": build.to(torch.uint8), f"weight{i}": wt,
+                    f"weight_aggre{i}": wa})
+    print("  pinned G13 loader: oracle == reference myImageFloder_S12_globe.__getitem__ (labels bit-exact)")
+    save("g13_loader", **out)
+
+
 if __name__ == "__main__":
+    g_mosaic()
+    g_loader()
     g_losses_metrics()
     g_hierweight()
     g_rdb()
