@@ -82,7 +82,51 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
 
     for (int c = 0; c < nchunk; ++c) {
         __syncthreads();
-        // ---- stage the input chunk: channel-major planes, transform + zero padding applied here
+        // ---- stage the input chunk: channel-major planes, transform + zero padding applied here.
+        // Fast path (every 4-channel group is one aligned 16-byte load from src0 or src1): ALL global loads of the chunk
+        // are issued before the first LDS store -- the one-load-per-iteration loop below exposes a full memory latency
+        // per iteration (11 of them per chunk) and made the kernel staging-latency bound.
+        constexpr int NIT = (ROWS * COLS * 4 + 255) / 256;
+        const bool fast = vec0 && (p.c1 == 0 || vec1) && (cin & 3) == 0;
+        if (fast) {
+            floatx4 ld[NIT];
+            int where[NIT];   // LDS dword offset of the unit's first channel plane entry, -1 = no unit
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int u = tid + it * 256;
+                ld[it] = floatx4{0.f, 0.f, 0.f, 0.f};
+                where[it] = -1;
+                if (u < ROWS * COLS * 4) {
+                    const int cg = u & 3, pix = u >> 2;
+                    const int r = pix / COLS, col = pix - r * COLS;
+                    const int y = Y0 + r - HALO, x = X0 + col - HALO;
+                    const int ch = c * HC + cg * 4;
+                    where[it] = (cg << 16) | (r * RS + col);
+                    if (y >= 0 && y < p.H && x >= 0 && x < p.W && ch < cin) {
+                        const long pixi = ((long)img * p.H + y) * p.W + x;
+                        if (ch < p.c0) {
+                            floatx4 a = *(const floatx4*)(p.src0 + pixi * p.ld0 + ch);
+                            if (p.pre_scale) a = a * *(const floatx4*)(p.pre_scale + ch) + *(const floatx4*)(p.pre_shift + ch);
+                            if (p.pre_relu) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) a[j] = fmaxf(a[j], 0.f);
+                            }
+                            ld[it] = a;
+                        } else {
+                            ld[it] = *(const floatx4*)(p.src1 + pixi * p.ld1 + (ch - p.c0));
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (where[it] >= 0) {
+                    const int cg = where[it] >> 16, off = where[it] & 0xffff;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s_in[plane_base(cg * 4 + j) + off] = ld[it][j];
+                }
+            }
+        } else
         for (int u = tid; u < ROWS * COLS * 4; u += 256) {
             const int cg = u & 3, pix = u >> 2;
             const int r = pix / COLS, col = pix - r * COLS;

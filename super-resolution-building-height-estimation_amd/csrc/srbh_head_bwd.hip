@@ -57,6 +57,59 @@ __global__ __launch_bounds__(256) void hwgrad_f32_kernel(const WGParams p) {
             const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
             const int Y0 = ty * HT_H, X0 = tx * HT_W;
             __syncthreads();
+            // Fast path (all 4-channel groups are aligned 16-byte loads): every global load of the tile pair is issued
+            // before the first LDS store; the one-load-per-iteration loops below expose one memory latency per
+            // iteration (19 per tile) and made the kernel staging-latency bound.
+            constexpr int NIX = (ROWS * COLS * 4 + 255) / 256, NID = HT_H * HT_W * 4 / 256;
+            const bool fast = vec0 && (p.c1 == 0 || vec1) && (cin & 3) == 0 && (p.cout_total & 3) == 0 &&
+                              ob * 16 + 15 < p.cout_total;
+            if (fast) {
+                floatx4 lx[NIX], ld[NID];
+#pragma unroll
+                for (int it = 0; it < NIX; ++it) {
+                    const int u = tid + it * 256;
+                    lx[it] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    if (u < ROWS * COLS * 4) {
+                        const int cg = u & 3, pix = u >> 2;
+                        const int r = pix / COLS, col = pix - r * COLS;
+                        const int y = Y0 + r - HALO, x = X0 + col - HALO;
+                        const int ch = c * 16 + cg * 4;
+                        if (y >= 0 && y < p.H && x >= 0 && x < p.W && ch < cin) {
+                            const long pixi = ((long)img * p.H + y) * p.W + x;
+                            if (ch < p.c0) {
+                                floatx4 a = *(const floatx4*)(p.src0 + pixi * p.c0 + ch);
+                                if (p.pre_scale) a = a * *(const floatx4*)(p.pre_scale + ch) + *(const floatx4*)(p.pre_shift + ch);
+                                if (p.pre_relu) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) a[j] = fmaxf(a[j], 0.f);
+                                }
+                                lx[it] = a;
+                            } else {
+                                lx[it] = *(const floatx4*)(p.src1 + pixi * p.c1 + (ch - p.c0));
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < NID; ++it) {
+                    const int u = tid + it * 256;
+                    const int cg = u & 3, pix = u >> 2;
+                    const int y = Y0 + (pix >> 6), x = X0 + (pix & 63);
+                    ld[it] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    if (y < p.H && x < p.W)
+                        ld[it] = *(const floatx4*)(p.dy + (((long)img * p.H + y) * p.W + x) * p.cout_total + ob * 16 + cg * 4);
+                }
+#pragma unroll
+                for (int it = 0; it < NIX; ++it) {
+                    const int u = tid + it * 256;
+                    if (u < ROWS * COLS * 4) *(floatx4*)(s_x + (u >> 2) * 16 + (u & 3) * 4) = lx[it];
+                }
+#pragma unroll
+                for (int it = 0; it < NID; ++it) {
+                    const int u = tid + it * 256;
+                    *(floatx4*)(s_dy + (u >> 2) * 16 + (u & 3) * 4) = ld[it];
+                }
+            } else {
             for (int u = tid; u < ROWS * COLS * 4; u += 256) {   // X tile, pixel-major, 4 channels per thread
                 const int cg = u & 3, pix = u >> 2;
                 const int r = pix / COLS, col = pix - r * COLS;
@@ -104,6 +157,7 @@ __global__ __launch_bounds__(256) void hwgrad_f32_kernel(const WGParams p) {
                     }
                 }
                 *(floatx4*)(s_dy + pix * 16 + cg * 4) = v;
+            }
             }
             __syncthreads();
 #pragma unroll 2
