@@ -79,7 +79,7 @@ class _PackedConv:
             if conv.bias is not None:
                 b = torch.zeros((cout + 15) // 16 * 16, dtype=torch.float32, device=w.device)
                 b[:cout] = conv.bias.detach().float()
-            torch.cuda.current_stream().synchronize()
+            # (no host sync: `wc` is recycled by torch's stream-ordered allocator, and the pack kernel runs on that stream)
             self.key, self.w, self.b = key, buf, b
         return self.w, self.b
 

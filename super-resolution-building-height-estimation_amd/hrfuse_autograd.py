@@ -32,7 +32,7 @@ class _PackedGrad:
             wc = weight.detach().float().contiguous()
             _lib.check(L.srbh_hpack_conv_f32(wc.data_ptr(), cin, cout, ks, 1, buf.data_ptr(), _lib.stream_ptr()),
                        "hpack_conv_f32(T)")
-            torch.cuda.current_stream().synchronize()
+            # (no host sync: `wc` is recycled by torch's stream-ordered allocator, and the pack kernel runs on that stream)
             self.key, self.w = key, buf
         return self.w
 
