@@ -199,7 +199,7 @@ class RRDBNet(nn.Module):
         return ws
 
     # ---- forward -------------------------------------------------------------------------------
-    def _run(self, x, want_forward):
+    def _run(self, x, want_forward, out=None):
         if not (torch.is_tensor(x) and x.is_cuda):
             raise RuntimeError("RRDBNet (libsrbh): input must be a ROCm/HIP device tensor; the hot path has no CPU "
                                "fallback (use oracle/ in tests for a CPU comparison)")
@@ -209,7 +209,11 @@ class RRDBNet(nn.Module):
             if self._geom[2] != 64 or self._geom[4] != 32:
                 raise NotImplementedError("libsrbh RRDBNet kernels are specialised for num_feat=64, num_grow_ch=32")
             with torch.cuda.device(x.device):
-                return self._run_strict(x, want_forward)
+                r = self._run_strict(x, want_forward)
+                if out is not None:
+                    out.copy_(r)
+                    return out
+                return r
         if self.scale == 2:
             x = pixel_unshuffle(x, 2)
         elif self.scale == 1:
@@ -226,8 +230,12 @@ class RRDBNet(nn.Module):
             desc = self._packed[2]
             ws = self._workspace(B, H, W, want_forward, x.device)
             cout = self._geom[1] if want_forward else 64
-            out = torch.empty((B, cout, 4 * H, 4 * W), dtype=torch.float32, device=x.device,
-                              memory_format=torch.channels_last)
+            if out is None:
+                out = torch.empty((B, cout, 4 * H, 4 * W), dtype=torch.float32, device=x.device,
+                                  memory_format=torch.channels_last)
+            elif (tuple(out.shape) != (B, cout, 4 * H, 4 * W) or out.dtype != torch.float32 or out.device != x.device
+                  or not out.is_contiguous(memory_format=torch.channels_last)):
+                raise ValueError("out= must be a channels_last fp32 (B,%d,%d,%d) tensor on the input's device" % (cout, 4 * H, 4 * W))
             L = _lib.lib()
             _lib.check(L.srbh_rrdbnet_forward(C.byref(desc), x.data_ptr(), out.data_ptr(), B, H, W, int(want_forward),
                                               ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "rrdbnet_forward")
@@ -320,10 +328,11 @@ class RRDBNet(nn.Module):
         """reference SR/rrdbnet_arch.py:208-223 -> (B,num_out_ch,4H,4W), channels_last strides."""
         return self._run(x, True)
 
-    def forward_feature(self, x):
+    def forward_feature(self, x, out=None):
         """reference SR/rrdbnet_arch.py:225-240 -> (B,64,4H,4W) features, NO activation after conv_hr;
-        returned with channels_last strides (logical NCHW shape as in the reference)."""
-        return self._run(x, False)
+        returned with channels_last strides (logical NCHW shape as in the reference).  ``out`` (extension): write into
+        a caller-owned channels_last buffer (static input of a captured training graph, harness.TrainStep)."""
+        return self._run(x, False, out)
 
 
 class RealESRGAN:
