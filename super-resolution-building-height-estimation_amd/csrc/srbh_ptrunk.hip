@@ -27,6 +27,9 @@
 #define PT_EPI_BARRIER 0
 #endif
 
+#ifndef PT_DEFAULT_VARIANT
+#define PT_DEFAULT_VARIANT 1
+#endif
 #ifndef PT_DMA_GROUPS
 #define PT_DMA_GROUPS 3
 #endif
@@ -558,6 +561,384 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
     }
 }
 
+
+// =====================================================================================================================
+// Variant 2: TWO workgroups per CU.
+//
+// With one 4-wave workgroup per CU every SIMD runs a single wave: nothing fills the matrix core while that wave sits in
+// an epilogue, a barrier, a flag round trip or the first LDS reads of a step (~40 % of the time in variant 1).  Here a
+// workgroup owns (image, FOUR rows), keeps at most 256 registers per wave and ~61 KiB of LDS, so two workgroups --
+// normally in different phases of the layer sequence -- share a CU and fill each other's gaps.  To fit:
+//   * the K pipeline advances in HALF chunks (16 input channels = one MFMA K step): a stage is a 6 x 66 pixel tile with
+//     32 B per pixel (12.4 KiB, stored as two 16-B planes so that ds_read_b128 is lane-linear) + the 9 * cb weight
+//     fragments of that k-step (<= 18 KiB);
+//   * a wave owns 2 rows x 32 pixels (32 * cb accumulator registers), 4 pixel fragments + 3 * cb weight fragments feed
+//     6 * cb MFMAs per (dx) group.
+// Everything else (layer table, progress counters, in-L2 exchange with XCC handshake, fragment-order residual streams,
+// exec-masked DMA issued at the head of a step) is the protocol of variant 1; results are bit-identical to it.
+constexpr int T2_H = 4;
+constexpr int T2_ROWS = T2_H + 2, T2_COLS = TILE_W + 2;
+constexpr int T2_PIX = T2_ROWS * T2_COLS;                  // 396 pixels
+constexpr int T2_UNITS = 2 * T2_PIX;                       // 16-B units, [k-half][row][col]
+constexpr int T2_IN_B = T2_UNITS * 16;                     // 12 672 B
+constexpr int T2_NJ = (T2_UNITS + 255) / 256;              // 4 DMA instructions (the last one: 24 lanes)
+constexpr int T2_STAGE_B = T2_IN_B + 18 * 1024;
+constexpr int T2_BIAS_OFF = 2 * T2_STAGE_B;
+constexpr int T2_WORD_OFF = T2_BIAS_OFF + 256;
+constexpr int T2_LDS_B = T2_WORD_OFF + 64;
+static_assert(2 * T2_LDS_B <= 163840, "two workgroups must fit one CU's LDS");
+
+struct Step2 {
+    const char* src;   // input plane, tile origin (nullptr: nothing to stage)
+    const char* w;     // packed weights of the chunk
+    int ks, cb;
+};
+
+__global__ __launch_bounds__(256, 2) void ptrunk2_kernel(const PParams pp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int t = xcd_remap(blockIdx.x, pp.nblocks);
+    const int img = t / pp.tiles_per_img;
+    const int ty = t - img * pp.tiles_per_img;
+    const int Y0 = ty * T2_H;
+    const int up = ty > 0 ? t - 1 : -1, dn = ty + 1 < pp.tiles_per_img ? t + 1 : -1;
+    const int X = wc * 32 + l31;
+
+    // ---- DMA geometry: unit u -> (k-half h, tile row, column); source = k-slot 2*ks + h of the 64-B pixel record
+    int goff0[T2_NJ], goff1[T2_NJ];
+    unsigned long long jmask[T2_NJ];
+#pragma unroll
+    for (int j = 0; j < T2_NJ; ++j) {
+        const int u0 = j * 256 + tid;
+        const int u = u0 < T2_UNITS ? u0 : 0;
+        const int h = u / T2_PIX, pix = u - h * T2_PIX;
+        const int trow = pix / T2_COLS, pc = pix - trow * T2_COLS;
+        const int base = trow * pp.row_b + pc * PIX_B;   // (the XOR swizzle of variant 1 is an LDS-side trick only)
+        goff0[j] = base + ((0 + h) << 4);
+        goff1[j] = base + ((2 + h) << 4);
+        jmask[j] = __builtin_amdgcn_ballot_w64(u0 < T2_UNITS);
+    }
+    int poff[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) poff[dx] = (hi * T2_PIX + (wr * 2) * T2_COLS + wc * 32 + l31 + dx) * 16;
+    const int woff = T2_IN_B + lane * 16;
+    const long tile_off = (long)img * pp.img_b + (long)Y0 * pp.row_b;
+
+    auto uni64 = [](unsigned long long m) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)m), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
+        return ((unsigned long long)hi32 << 32) | lo;
+    };
+    auto lds_addr = [](const char* p) { return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p; };
+    auto dma16 = [&](auto sc1_tag, const char* gaddr, const unsigned lds_off_v, const unsigned long long mask) {
+        unsigned long long sv;
+        const unsigned lds_off = __builtin_amdgcn_readfirstlane(lds_off_v);
+        if constexpr (decltype(sc1_tag)::value)
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %3, off sc1\n\ts_mov_b64 exec, %0"
+                         : "=&s"(sv) : "s"(mask), "s"(lds_off), "v"(gaddr) : "memory", "m0");
+        else
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %3, off\n\ts_mov_b64 exec, %0"
+                         : "=&s"(sv) : "s"(mask), "s"(lds_off), "v"(gaddr) : "memory", "m0");
+    };
+    // the 4 + 5 DMA instructions of one half step (input tile; weight fragment f' = tap * cb + mb of k-step ks)
+    auto stage = [&](const Step2& d, const unsigned dst_l) {
+        const unsigned long long on = uni64(d.src ? ~0ull : 0ull);
+#pragma unroll
+        for (int j = 0; j < T2_NJ; ++j)
+            dma16(std::true_type{}, d.src + (d.ks ? goff1[j] : goff0[j]), dst_l + (j * 256 + wave * 64) * 16, uni64(jmask[j]) & on);
+        const int sh = d.cb - 1;   // cb is 1 or 2
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int f = wave + 4 * k;
+            const int tap = f >> sh, mb = f & sh;
+            const char* src = d.w + ((((tap * 2 + d.ks) << sh) + mb) << 10) + lane * 16;
+            dma16(std::false_type{}, src, dst_l + T2_IN_B + f * 1024, uni64((d.src && f < 9 * d.cb) ? ~0ull : 0ull));
+        }
+    };
+    auto step_of = [&](const PLayer& l, int s) {
+        Step2 d;
+        const int c = s >> 1;
+        d.src = pp.dense[l.in_sel] + tile_off + (long)c * pp.plane_b;
+        d.w = l.w + (long)c * (18 * 1024 * l.cb);
+        d.ks = s & 1;
+        d.cb = l.cb;
+        return d;
+    };
+
+    int f_up = up < 0 ? 0x7fffffff : 0, f_dn = dn < 0 ? 0x7fffffff : 0;
+    int gs = 0;
+    bool aborted = false;
+    auto ensure_flags = [&](int need) {
+        auto* word = (__attribute__((address_space(3))) int*)(smem + T2_WORD_OFF);
+        if (tid == 0) {
+            int bad = 0;
+            unsigned spins = 0;
+            while (f_up < need || f_dn < need) {
+                if (up >= 0) f_up = __hip_atomic_load(pp.prog + up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dn >= 0) f_dn = __hip_atomic_load(pp.prog + dn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (f_up >= need && f_dn >= need) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > SPIN_LIMIT || __hip_atomic_load(pp.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    bad = 1;
+                    break;
+                }
+            }
+            if (bad) __hip_atomic_store(pp.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *word = bad;
+        }
+        __syncthreads();
+        const int bad = *word;
+        __syncthreads();
+        if (bad) aborted = true;
+    };
+    bool wt = true;
+    {
+        int my_xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(my_xcc));
+        auto* word = (__attribute__((address_space(3))) int*)(smem + T2_WORD_OFF);
+        if (tid == 0) {
+            __hip_atomic_store(pp.xcc + t, my_xcc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int diff = pp.force_wt;
+            for (int s = 0; s < 2 && !diff; ++s) {
+                const int nb = s ? dn : up;
+                if (nb < 0) continue;
+                int v = 0;
+                for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+                    v = __hip_atomic_load(pp.xcc + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (v != my_xcc + 1) diff = 1;
+            }
+            *word = diff;
+        }
+        __syncthreads();
+        wt = __builtin_amdgcn_readfirstlane(*word) != 0;
+        __syncthreads();
+    }
+    auto publish = [&](int v) {
+        if (tid == 0) {
+            if (wt)
+                __hip_atomic_store(pp.prog + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                __hip_atomic_store(pp.prog + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    bool pending_pub = false;
+    int pub_val = 0;
+
+    auto run_layer = [&](auto cb_tag, const int L, const PLayer& lay) {
+        constexpr int CB = decltype(cb_tag)::value;
+        constexpr int NREAD = 4 + 3 * CB, NMFMA = 6 * CB;
+        unsigned long long p0 = 0;
+        if (pp.prof) p0 = __builtin_amdgcn_s_memtime();
+        float bias_v = 0.f;
+        if (tid < CB * 32) bias_v = lay.bias[tid];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid < CB * 32) ((float*)(smem + T2_BIAS_OFF))[tid] = bias_v;
+        if (pending_pub) {
+            publish(pub_val);
+            pending_pub = false;
+        }
+        if (L > 0) ensure_flags(L);
+        if (aborted) return;
+        const bool last_layer = L + 1 >= pp.nlayers;
+        const PLayer nlay = pp.layers[last_layer ? L : L + 1];
+        const bool has_next_prefetch = !last_layer && !(nlay.flags & 8);
+        unsigned long long p1 = 0;
+        if (pp.prof) p1 = __builtin_amdgcn_s_memtime();
+        floatx16 acc[CB][2];
+#pragma unroll
+        for (int mb = 0; mb < CB; ++mb)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
+        half8 P[2][4];
+        half8 A[2][3][CB];
+        auto load_group = [&](const char* sb, int dx, int set) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[set][r] = *(const half8*)(sb + poff[dx] + r * (T2_COLS * 16));
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int mb = 0; mb < CB; ++mb) A[set][dy][mb] = *(const half8*)(sb + woff + (((dy * 3 + dx) * CB + mb) << 10));
+        };
+        auto compute = [&](const Step2& nx) {
+            const char* sb = smem + (gs & 1) * T2_STAGE_B;
+            load_group(sb, 0, 0);
+            stage(nx, lds_addr(smem + ((gs + 1) & 1) * T2_STAGE_B));   // everything up front: see variant 1
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                if (dx + 1 < 3) load_group(sb, dx + 1, (dx + 1) & 1);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int mb = 0; mb < CB; ++mb)
+                            acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[dx & 1][dy][mb], P[dx & 1][i + dy], acc[mb][i], 0, 0, 0);
+                if (dx == 0) __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);
+                if (dx + 1 < 3) {
+#pragma unroll
+                    for (int k = 0; k < NMFMA; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (k < NREAD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    if (NREAD > NMFMA) __builtin_amdgcn_sched_group_barrier(0x100, NREAD - NMFMA, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
+                }
+            }
+            ++gs;
+        };
+        const int ns = 2 * lay.nchunk;
+        unsigned long long ts0 = p1, ts1 = 0, ts2 = 0, tw = p1 - p0;
+        for (int s = 0; s < ns; ++s) {
+            if (s > 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            Step2 nx;
+            if (s + 1 < ns) {
+                nx = step_of(lay, s + 1);
+            } else {
+                nx = step_of(nlay, 0);
+                if (!has_next_prefetch) nx.src = nullptr;
+            }
+            compute(nx);
+        }
+        if (pp.prof) ts1 = __builtin_amdgcn_s_memtime();
+
+        // ---- epilogue (D layout: lane (l31, hi) holds channels 8g + 4hi + (0..3) of pixel l31 for row i, group g)
+        char* obase = pp.dense[lay.out_sel] + (long)img * pp.img_b + (long)lay.out_chunk0 * pp.plane_b;
+        floatx4 bias4[CB][4];
+#pragma unroll
+        for (int mb = 0; mb < CB; ++mb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias4[mb][g] = *(const floatx4*)((const float*)(smem + T2_BIAS_OFF) + mb * 32 + g * 8 + hi * 4);
+        constexpr bool lrelu = (CB == 1), r1 = (CB == 2);
+        const bool r2 = r1 && (lay.flags & 4);
+        struct ResForm { int lane, sm, sg; };
+        const ResForm pixel_form{X * 64 + hi * 4, 32, 8}, frag_form{wc * 2048 + lane * 4, 1024, 256};
+        const ResForm s1 = (!pp.frag_res || (lay.flags & 16)) ? pixel_form : frag_form;
+        const ResForm s2 = (!pp.frag_res || (lay.flags & 32)) ? pixel_form : frag_form;
+        const ResForm sd = pp.frag_res ? frag_form : pixel_form;
+        const float* res1_src = (lay.flags & 64) ? pp.xrr : pp.xr;
+        // one row at a time: the register budget is 256 per wave here (two waves per SIMD hide the load latency instead)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int Y = Y0 + wr * 2 + k;
+            const bool valid = (Y < pp.H) && (X < pp.W);
+            const long rowb = ((long)img * pp.H + Y) * pp.W * 64;
+            floatx4 a1[CB][4], a2[CB][4], vv[CB][4];
+            if (r1 && valid) {
+                const float* q1 = res1_src + rowb + s1.lane;
+#pragma unroll
+                for (int mb = 0; mb < CB; ++mb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) a1[mb][g] = *(const floatx4*)(q1 + mb * s1.sm + g * s1.sg);
+                if (r2) {
+                    const float* q2 = pp.xrr + rowb + s2.lane;
+#pragma unroll
+                    for (int mb = 0; mb < CB; ++mb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) a2[mb][g] = *(const floatx4*)(q2 + mb * s2.sm + g * s2.sg);
+                }
+            }
+#pragma unroll
+            for (int mb = 0; mb < CB; ++mb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    floatx4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = acc[mb][k][g * 4 + q];
+                    v += bias4[mb][g];
+                    if (r1) {
+                        v = v * 0.2f + a1[mb][g];
+                        if (r2) v = v * 0.2f + a2[mb][g];
+                    }
+                    vv[mb][g] = v;
+                }
+#pragma unroll
+            for (int mb = 0; mb < CB; ++mb) {
+                unsigned hp[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    floatx4 w = vv[mb][g];
+                    if (lrelu) {
+                        const floatx4 ws = w * 0.2f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) asm("v_max_f32 %0, %1, %2" : "=v"(w[q]) : "v"(w[q]), "v"(ws[q]));
+                    }
+                    half4 h4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) h4[q] = (_Float16)w[q];
+                    const uint2 u = __builtin_bit_cast(uint2, h4);
+                    hp[g][0] = u.x;
+                    hp[g][1] = u.y;
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    auto s0 = __builtin_amdgcn_permlane32_swap(hp[2 * m][0], hp[2 * m + 1][0], false, false);
+                    auto s1v = __builtin_amdgcn_permlane32_swap(hp[2 * m][1], hp[2 * m + 1][1], false, false);
+                    typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+                    const uintx4 raw = {s0[0], s1v[0], s0[1], s1v[1]};
+                    if (valid) {
+                        char* o = obase + (long)mb * pp.plane_b + (long)(Y + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16;
+                        if (wt)
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
+                        else
+                            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
+                    }
+                }
+            }
+            if (r1 && valid) {
+                float* q = (r2 ? pp.xrr : pp.xr) + rowb + sd.lane;
+#pragma unroll
+                for (int mb = 0; mb < CB; ++mb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) *(floatx4*)(q + mb * sd.sm + g * sd.sg) = vv[mb][g];
+            }
+        }
+        if (pp.prof) ts2 = __builtin_amdgcn_s_memtime();
+        const bool seam = last_layer || (nlay.flags & 8);
+        if (seam) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            publish(L + 1);
+            if (!last_layer) {
+                ensure_flags(L + 1);
+                if (aborted) return;
+                stage(step_of(nlay, 0), lds_addr(smem + (gs & 1) * T2_STAGE_B));
+            }
+        } else {
+            pending_pub = true;
+            pub_val = L + 1;
+        }
+        if (pp.prof && tid == 0) {
+            unsigned long long* q = pp.prof + ((long)blockIdx.x * pp.nlayers + L) * 6;
+            q[0] = ts0; q[1] = ts1; q[2] = ts2; q[3] = tw | ((unsigned long long)(__builtin_amdgcn_s_memtime() - ts2) << 32);
+            q[4] = 0;
+        }
+    };
+
+    stage(step_of(pp.layers[0], 0), lds_addr(smem));
+    for (int L = 0; L < pp.nlayers && !aborted; ++L) {
+        const PLayer lay = pp.layers[L];
+        if (lay.cb == 1)
+            run_layer(std::integral_constant<int, 1>{}, L, lay);
+        else
+            run_layer(std::integral_constant<int, 2>{}, L, lay);
+    }
+}
+
 }  // namespace
 
 namespace srbh {
@@ -568,10 +949,115 @@ static hipEvent_t g_trunk_ev[2];
 
 constexpr int MAX_BLOCKS = 64;   // layer-table capacity (RRDB blocks)
 static size_t table_bytes() { return ((size_t)MAX_BLOCKS * 15 * sizeof(PLayer) + 255) & ~(size_t)255; }
-static size_t prog_bytes(int B, int tpi) { return ((size_t)B * tpi * sizeof(int) + 255) & ~(size_t)255; }
+static size_t prog_bytes(int B, int tpi) { return ((size_t)B * 2 * tpi * sizeof(int) + 255) & ~(size_t)255; }   // (x2: 4-row tiles of variant 2)
 
 size_t ptrunk_aux_bytes(int B, int tiles_per_img) { return table_bytes() + 2 * prog_bytes(B, tiles_per_img) + 256; }
 size_t ptrunk_err_offset(int B, int tiles_per_img) { return table_bytes() + prog_bytes(B, tiles_per_img); }
+
+static void build_table(const srbh_rrdbnet_desc* d, std::vector<PLayer>& tab, int* final_cur) {
+    int cur = 0, li = 0;
+    for (int blk = 0; blk < d->num_block; ++blk)
+        for (int r = 0; r < 3; ++r) {
+            const srbh_conv_w* cw = d->rdb + (blk * 3 + r) * 5;
+            for (int k = 0; k < 4; ++k)
+                tab[li++] = PLayer{(const char*)cw[k].w, cw[k].bias, 2 + k, 1, cur, cur, 2 + k, 1 | (k == 0 ? 8 : 0)};
+            // conv5: 64 = res1 comes from the xrr stream (first RDB of a block: xr == xrr there and the closing layer of
+            // the previous block wrote only xrr); 16 / 32 = that stream still holds conv_first's pixel-order data
+            tab[li++] = PLayer{(const char*)cw[4].w, cw[4].bias, 6, 2, cur, cur ^ 1, 0,
+                               2 | (r == 2 ? 4 : 0) | (r == 0 ? 64 : 0) | (blk == 0 && r == 0 ? 16 : 0) | (blk == 0 && r == 2 ? 32 : 0)};
+            cur ^= 1;
+        }
+    *final_cur = cur;
+}
+
+static int ptrunk2_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr, float* xrr, int B, int H, int W,
+                       void* aux, hipStream_t stream, int* used, int* final_cur) {
+    *used = 0;
+    if (W > TILE_W || d->num_block <= 0 || d->num_block > MAX_BLOCKS) return SRBH_OK;
+    int dev = 0;
+    SRBH_HIP(hipGetDevice(&dev));
+    int ncu = 0;
+    SRBH_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int tpi = (H + T2_H - 1) / T2_H;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_B));
+        attr_set = true;
+    }
+    int per_cu = 0;
+    SRBH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ptrunk2_kernel, 256, T2_LDS_B));
+    if (per_cu < 2 || tpi > per_cu * ncu) return SRBH_OK;
+    const int slots = 2 * ncu;   // co-resident workgroups the protocol may rely on
+    const int nl = d->num_block * 15;
+    std::vector<PLayer> tab(nl);
+    build_table(d, tab, final_cur);
+    const int tpi8 = (H + TILE_H - 1) / TILE_H;
+    char* a = (char*)aux;
+    PLayer* d_tab = (PLayer*)a;
+    int* d_prog = (int*)(a + table_bytes());
+    int* d_err = (int*)(a + ptrunk_err_offset(B, tpi8));
+    int* d_xcc = (int*)(a + ptrunk_err_offset(B, tpi8) + 256);
+    SRBH_HIP(hipMemcpyAsync(d_tab, tab.data(), (size_t)nl * sizeof(PLayer), hipMemcpyHostToDevice, stream));
+    SRBH_HIP(hipMemsetAsync(d_prog, 0, (size_t)B * tpi * sizeof(int), stream));
+    SRBH_HIP(hipMemsetAsync(d_err, 0, sizeof(int), stream));
+    SRBH_HIP(hipMemsetAsync(d_xcc, 0, (size_t)B * tpi * sizeof(int), stream));
+    const Act16Geo g = act16_geo(B, 6, H, W);
+    const int imgs_per_launch = slots / tpi;
+    for (int b0 = 0; b0 < B; b0 += imgs_per_launch) {
+        const int nb = (B - b0) < imgs_per_launch ? (B - b0) : imgs_per_launch;
+        PParams pp{};
+        pp.dense[0] = (char*)dense0 + (long)b0 * g.img_b;
+        pp.dense[1] = (char*)dense1 + (long)b0 * g.img_b;
+        pp.img_b = g.img_b;
+        pp.plane_b = g.plane_b;
+        pp.row_b = g.row_b;
+        pp.xr = xr + (long)b0 * H * W * 64;
+        pp.xrr = xrr + (long)b0 * H * W * 64;
+        pp.layers = d_tab;
+        pp.nlayers = nl;
+        pp.H = H;
+        pp.W = W;
+        pp.tiles_per_img = tpi;
+        pp.nblocks = nb * tpi;
+        pp.prog = d_prog + b0 * tpi;
+        pp.err = d_err;
+        pp.xcc = d_xcc + b0 * tpi;
+        const char* e = getenv("SRBH_PT_WT");
+        pp.force_wt = (e && atoi(e) == 1) ? 1 : 0;
+        if (getenv("SRBH_PT_PROF") && !g_ptrunk_prof)
+            SRBH_HIP(hipMalloc(&g_ptrunk_prof, (size_t)slots * MAX_BLOCKS * 15 * 6 * 8));
+        pp.prof = g_ptrunk_prof;
+        const char* fr = getenv("SRBH_PT_FRAGRES");
+        pp.frag_res = (W == TILE_W) && !(fr && atoi(fr) == 0);
+        if (g_trunk_timing && b0 == 0) SRBH_HIP(hipEventRecord(g_trunk_ev[0], stream));
+        hipLaunchKernelGGL(ptrunk2_kernel, dim3(pp.nblocks), dim3(256), T2_LDS_B, stream, pp);
+        SRBH_HIP(hipGetLastError());
+    }
+    if (g_trunk_timing) SRBH_HIP(hipEventRecord(g_trunk_ev[1], stream));
+    if (getenv("SRBH_PT_PROF") && g_ptrunk_prof) {
+        SRBH_HIP(hipStreamSynchronize(stream));
+        const int nblk = (B < imgs_per_launch ? B : imgs_per_launch) * tpi;
+        std::vector<unsigned long long> h((size_t)nblk * nl * 6);
+        SRBH_HIP(hipMemcpy(h.data(), g_ptrunk_prof, h.size() * 8, hipMemcpyDeviceToHost));
+        double cyc = 0, loop[5] = {0}, epi[5] = {0}, pub[5] = {0}, wait[5] = {0}, tot5[5] = {0};
+        for (int b = 0; b < nblk; ++b) cyc += (double)(h[((size_t)b * nl + nl - 1) * 6 + 2] - h[(size_t)b * nl * 6]);
+        fprintf(stderr, "[srbh] ptrunk2: avg %.0f shader cycles per workgroup (2 workgroups per CU)\n", cyc / nblk);
+        for (int b = 0; b < nblk; ++b)
+            for (int L = 1; L + 1 < nl; ++L) {
+                const unsigned long long* q = &h[((size_t)b * nl + L) * 6];
+                const unsigned long long* qn = &h[((size_t)b * nl + L + 1) * 6];
+                const int k = L % 5;
+                loop[k] += (double)(q[1] - q[0]); epi[k] += (double)(q[2] - q[1]); pub[k] += (double)(q[3] >> 32);
+                wait[k] += (double)(q[3] & 0xffffffffu); tot5[k] += (double)(qn[0] - q[0]);
+            }
+        const double cnt = (double)nblk * (nl - 2) / 5.0;
+        for (int k = 0; k < 5; ++k)
+            fprintf(stderr, "[srbh]   conv%d: loop %.0f (flag-wait %.0f) | epilogue %.0f | publish/seam %.0f | start-to-start %.0f\n",
+                    k + 1, loop[k] / cnt, wait[k] / cnt, epi[k] / cnt, pub[k] / cnt, tot5[k] / cnt);
+    }
+    *used = 1;
+    return SRBH_OK;
+}
 
 // returns SRBH_OK and sets *used = 1 when the persistent path ran, *used = 0 when the shape is not eligible
 int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr, float* xrr, int B, int H, int W,
@@ -582,6 +1068,13 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
     SRBH_HIP(hipGetDevice(&dev));
     int ncu = 0;
     SRBH_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    // variant 2 (two 4-row workgroups per CU, see ptrunk2_kernel) or variant 1 (one 8-row workgroup per CU)
+    const char* ve = getenv("SRBH_PT_VARIANT");
+    const int variant = ve ? atoi(ve) : PT_DEFAULT_VARIANT;
+    if (variant == 2) {
+        const int rc2 = ptrunk2_run(d, dense0, dense1, xr, xrr, B, H, W, aux, stream, used, final_cur);
+        if (rc2 != SRBH_OK || *used) return rc2;
+    }
     const int tpi = (H + TILE_H - 1) / TILE_H;
     if (tpi > ncu) return SRBH_OK;
     constexpr int LDS_B = P_LDS_B;
