@@ -27,6 +27,9 @@
 #define PT_EPI_BARRIER 0
 #endif
 
+#ifndef PT_LOAD_SCOPE
+#define PT_LOAD_SCOPE " sc1"   // cache-coherence bits of the activation LDS-DMA loads
+#endif
 #ifndef PT_DEFAULT_VARIANT
 #define PT_DEFAULT_VARIANT 1
 #endif
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         const unsigned lds_off = __builtin_amdgcn_readfirstlane(lds_off_v);
         if constexpr (decltype(sc1_tag)::value)
             asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                         "global_load_lds_dwordx4 %3, off sc1\n\ts_mov_b64 exec, %0"
+                         "global_load_lds_dwordx4 %3, off" PT_LOAD_SCOPE "\n\ts_mov_b64 exec, %0"
                          : "=&s"(sv) : "s"(mask), "s"(lds_off), "v"(gaddr) : "memory", "m0");
         else
             asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
@@ -638,7 +641,7 @@ __global__ __launch_bounds__(256, 2) void ptrunk2_kernel(const PParams pp) {
         const unsigned lds_off = __builtin_amdgcn_readfirstlane(lds_off_v);
         if constexpr (decltype(sc1_tag)::value)
             asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                         "global_load_lds_dwordx4 %3, off sc1\n\ts_mov_b64 exec, %0"
+                         "global_load_lds_dwordx4 %3, off" PT_LOAD_SCOPE "\n\ts_mov_b64 exec, %0"
                          : "=&s"(sv) : "s"(mask), "s"(lds_off), "v"(gaddr) : "memory", "m0");
         else
             asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
