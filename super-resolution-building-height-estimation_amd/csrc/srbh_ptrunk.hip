@@ -299,20 +299,38 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
             const unsigned long long m_w = uni64(next_cb ? m_all : 0ull);
             const unsigned long long m_w4 = uni64((next_cb == 2 || (next_cb == 1 && wave < 2)) ? m_all : 0ull);   // fragments 16..19: 18 or 36 in total
             const unsigned long long m_w2 = uni64(next_cb == 2 ? m_all : 0ull);
-            const unsigned dst_l = lds_addr(dst);
-            // The 20 DMA instructions of the next step are issued in the first PT_DMA_GROUPS MFMA groups: a step cannot end
-            // before its LAST DMA has landed (issue time + ~1.4 k cycles of L2 latency), so spreading them over all six
-            // groups made every step latency-bound (3.3 k cycles for 2.3 k of MFMA work).
+            // The 20 DMA instructions of the next step are issued in the first MFMA groups: a step cannot end before its
+            // LAST DMA has landed (issue time + ~1.5 us of L2-miss latency), so spreading them over all six groups made
+            // every step latency-bound.
+            const unsigned dst_w = __builtin_amdgcn_readfirstlane(lds_addr(dst) + wave * 1024);       // inputs: + j * 4096
+            const unsigned wdst_w = dst_w + IN_EX;                                                      // weights: + k * 4096
+            const unsigned long long ibase = uni64((unsigned long long)nsrc);
+            const unsigned long long wbase = uni64((unsigned long long)(nw + wave * 1024));
+            const unsigned wl = lane * 16;
+            // one asm statement per DMA (the scheduler interleaves them with the MFMAs: blocks of 5 back-to-back DMAs stall
+            // the wave on the VMEM issue queue and measured 5 % slower), scalar base + 32-bit VGPR offset addressing
+            auto dma_s = [&](auto sc1_tag, const unsigned long long base, const unsigned voff, const unsigned lds_off,
+                             const unsigned long long mask) {
+                unsigned long long sv;
+                if constexpr (decltype(sc1_tag)::value)
+                    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                                 "global_load_lds_dwordx4 %3, %4 sc1\n\ts_mov_b64 exec, %0"
+                                 : "=&s"(sv) : "s"(mask), "s"(lds_off), "v"(voff), "s"(base) : "memory", "m0");
+                else
+                    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                                 "global_load_lds_dwordx4 %3, %4\n\ts_mov_b64 exec, %0"
+                                 : "=&s"(sv) : "s"(mask), "s"(lds_off), "v"(voff), "s"(base) : "memory", "m0");
+            };
             auto issue = [&](const int i) {
                 if (i < 11) {
                     const int j = JORD[i];
-                    dma16(std::true_type{}, nsrc + goff[j], dst_l + (j * 256 + wave * 64) * 16, j < G::NJ - 1 ? m_in : m_tail);
+                    dma_s(std::true_type{}, ibase, goff[j], dst_w + j * 4096, j < G::NJ - 1 ? m_in : m_tail);
                 } else if (i < 16) {
-                    const int f = wave + 4 * (i - 11);
-                    dma16(std::false_type{}, ws + f * 1024, dst_l + IN_EX + f * 1024, i < 15 ? m_w : m_w4);
+                    const int k = i - 11;
+                    dma_s(std::false_type{}, wbase + k * 4096, wl, wdst_w + k * 4096, k < 4 ? m_w : m_w4);
                 } else {
-                    const int f = 20 + wave + 4 * (i - 16);
-                    dma16(std::false_type{}, ws + f * 1024, dst_l + IN_EX + f * 1024, m_w2);
+                    const int k = i - 16;
+                    dma_s(std::false_type{}, wbase + 20 * 1024 + k * 4096, wl, wdst_w + 20 * 1024 + k * 4096, m_w2);
                 }
             };
 #pragma unroll

@@ -72,7 +72,75 @@ static void run(const char* name) {
     hipFree(sink);
 }
 
+// the conv kernels' group shape: NR reads (6 pixel-fragment rows + 3*CB weight fragments) and NM = 12*CB MFMAs per group,
+// operands double-buffered (the reads of group g+1 fly under the MFMAs of group g), ACC independent accumulators
+template <int NR, int NM, int ACC>
+__global__ __launch_bounds__(256, 1) void group_kernel(unsigned long long* out, int iters, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 160 * 1024 / 4; i += 256) ((float*)smem)[i] = (float)(i & 1023) * 1e-3f;
+    __syncthreads();
+    const int l31 = lane & 31, hi = lane >> 5, wr = wave >> 1, wc = wave & 1;
+    int off[NR];
+    for (int r = 0; r < NR; ++r) {
+        const int pc = wc * 32 + l31;
+        off[r] = r < 6 ? (wr * 4 + r) * 66 * 64 + pc * 64 + ((hi ^ ((pc >> 2) & 3)) << 4) : 45056 + (r - 6) * 1024 + lane * 16;
+    }
+    floatx16 c[ACC];
+    for (int a = 0; a < ACC; ++a) c[a] = floatx16{0};
+    half8 v[2][NR];
+    for (int r = 0; r < NR; ++r) v[0][r] = *(const half8*)(smem + off[r]);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) v[(u + 1) & 1][r] = *(const half8*)(smem + off[r] + ((it + u) & 1) * 64);
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+                c[m % ACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v[u][6 + m % (NR - 6)], v[u][m % 6], c[m % ACC], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) out[blockIdx.x] = t1 - t0;
+    float s = 0;
+    for (int a = 0; a < ACC; ++a)
+        for (int q = 0; q < 16; ++q) s += c[a][q];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+template <int NR, int NM, int ACC>
+static void run_group(const char* name) {
+    unsigned long long* d;
+    float* sink;
+    hipMalloc(&d, 256 * 8);
+    hipMalloc(&sink, 4);
+    hipFuncSetAttribute((const void*)group_kernel<NR, NM, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int iters = 1000;
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((group_kernel<NR, NM, ACC>), dim3(256), dim3(256), 160 * 1024, 0, d, iters, sink);
+    hipDeviceSynchronize();
+    unsigned long long h[256];
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    double avg = 0;
+    for (int i = 0; i < 256; ++i) avg += (double)h[i];
+    avg /= 256;
+    printf("%-44s %8.1f cycles per group of %d MFMA (issue floor %d) -> %.0f %% of the MFMA rate\n", name, avg / (iters * 2.0), NM, NM * 32,
+           100.0 * NM * 32 / (avg / (iters * 2.0)));
+    hipFree(d);
+    hipFree(sink);
+}
+
 int main() {
+    run_group<9, 12, 4>("cout 32 group: 9 reads + 12 MFMA, 4 acc");
+    run_group<12, 24, 8>("cout 64 group: 12 reads + 24 MFMA, 8 acc");
+    run_group<7, 6, 2>("variant 2 cout 32: 7 reads + 6 MFMA");
     run<0, 0>("linear lane*16");
     run<1, 0>("pixel records, swizzled");
     run<2, 0>("pixel records, unswizzled");
