@@ -87,7 +87,8 @@ def bench_train(args, rank, world, dev, dist):
     torch.manual_seed(1337)
     net = SRRegress_Cls_feature("efficientnet-b4", in_channels=8, super_in=64, super_mid=16, upscale=4, isaggre=True,
                                 chans_build=7)
-    ts = TrainStep(net_hr.to(dev), net.to(dev), dev, world=world)
+    sync_bn = os.environ.get("SRBH_SYNC_BN", "0") == "1"        # default: per-rank BatchNorm statistics
+    ts = TrainStep(net_hr.to(dev), net.to(dev), dev, world=world, sync_bn=sync_bn)
     batch = synthetic_batch(B, 1337 + rank, dev)
     for _ in range(args.warmup):
         ts(batch)

@@ -83,7 +83,15 @@ class TrainStep:
     """train.py:133-179,243-256: frozen RRDBNet feature extractor + trainable SRRegress_Cls_feature, three
     uncertainty-weighted losses, Adam(lr 1e-3, wd 1e-4) with the log_vars as an extra param group."""
 
-    def __init__(self, net_hr, net, device, world=1, lr=1e-3):
+    def __init__(self, net_hr, net, device, world=1, lr=1e-3, sync_bn=False):
+        if sync_bn and world > 1:
+            # global-batch BatchNorm statistics (what the reference computes on one device): libsrbh BatchNorms all-reduce
+            # their partial sums (hrfuse.set_bn_sync), the stock-op encoder / decoders become torch SyncBatchNorm
+            from . import hrfuse
+            hrfuse.set_bn_sync(world)
+            for name in ("encoder", "decoder1", "decoder2"):
+                if hasattr(net, name):
+                    setattr(net, name, nn.SyncBatchNorm.convert_sync_batchnorm(getattr(net, name)))
         self.net_hr, self.net, self.world = net_hr.eval(), net.train(), world
         for p in self.net_hr.parameters():
             p.requires_grad_(False)

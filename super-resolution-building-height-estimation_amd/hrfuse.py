@@ -116,6 +116,28 @@ def hconv(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_
     return out, stats
 
 
+# ---- synchronised BatchNorm statistics for data-parallel training -------------------------------------------------------
+# Off by default ("local-BN DP": statistics per rank).  set_bn_sync(world, group) makes every training-mode BatchNorm of
+# this module all-reduce its per-channel partial sums (sum, sum of squares; backward: sum dy, sum dy*xhat) over the
+# ranks, i.e. the statistics of the GLOBAL batch as on one device (reference semantics): one small
+# all-reduce (NSLOT x 2 x C doubles) per BatchNorm and direction.
+_BN_SYNC = {"world": 1, "group": None}
+
+
+def set_bn_sync(world=1, group=None):
+    _BN_SYNC["world"], _BN_SYNC["group"] = int(world), group
+
+
+def bn_sync_world():
+    return _BN_SYNC["world"]
+
+
+def bn_allreduce_(buf):
+    import torch.distributed as dist
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=_BN_SYNC["group"])
+    return buf
+
+
 def bn_scale_shift(bn: nn.BatchNorm2d, stats, count, training):
     """BatchNorm folded to per-channel (scale, shift).  training: from the batch statistics in `stats`
     (running statistics updated in place, as nn.BatchNorm2d does); eval: from the running statistics.
@@ -133,6 +155,9 @@ def bn_scale_shift(bn: nn.BatchNorm2d, stats, count, training):
         mean = torch.empty(Cc, dtype=torch.float32, device=dev)
         invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
         mom = 0.1 if bn.momentum is None else bn.momentum
+        if _BN_SYNC["world"] > 1:
+            bn_allreduce_(stats)
+            count = count * _BN_SYNC["world"]
         rm = bn.running_mean.data_ptr() if bn.track_running_stats else None
         rv = bn.running_var.data_ptr() if bn.track_running_stats else None
         _lib.check(L.srbh_bn_finalize(stats.data_ptr(), Cc, float(count), g.data_ptr(), bta.data_ptr(), bn.eps, mom,

@@ -118,6 +118,14 @@ def bn_backward(g, c, mean, invstd, gamma, mask, training):
     _lib.check(L.srbh_bn_bwd_finalize(st.data_ptr(), Cc, float(n), gamma.data_ptr(), invstd.data_ptr(), dgamma.data_ptr(),
                                       dbeta.data_ptr(), coef.data_ptr(), k1.data_ptr(), k2.data_ptr(), _lib.stream_ptr()),
                "bn_bwd_finalize")
+    if training and H.bn_sync_world() > 1:
+        # synchronised statistics: dgamma / dbeta above stay the LOCAL sums (they are averaged with the other gradients),
+        # the mean terms of dx are those of the global batch
+        H.bn_allreduce_(st)
+        scratch = torch.empty(2 * Cc, dtype=torch.float32, device=dev)
+        _lib.check(L.srbh_bn_bwd_finalize(st.data_ptr(), Cc, float(n * H.bn_sync_world()), gamma.data_ptr(), invstd.data_ptr(),
+                                          scratch.data_ptr(), scratch.data_ptr() + 4 * Cc, coef.data_ptr(), k1.data_ptr(),
+                                          k2.data_ptr(), _lib.stream_ptr()), "bn_bwd_finalize(sync)")
     if not training:       # frozen statistics: the mean terms vanish
         k1.zero_()
         k2.zero_()
