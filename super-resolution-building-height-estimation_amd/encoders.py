@@ -78,7 +78,9 @@ class SamePadConv2d(nn.Conv2d):
 
 
 def _swish(x):
-    return x * torch.sigmoid(x)
+    # x * sigmoid(x) (efficientnet_pytorch's MemoryEfficientSwish) as ONE kernel forward and one backward: at 64x64 the
+    # encoder is bound by the number of tiny launches, not by their work
+    return F.silu(x)
 
 
 def _drop_connect(x, p, training):
