@@ -37,7 +37,7 @@ class _PackedGrad:
         return self.w
 
 
-def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False):
+def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None):
     L = _lib.lib()
     x0 = srcs[0]
     B, c0, Hh, Ww = x0.shape
@@ -54,14 +54,17 @@ def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False):
     a.pixelshuffle2 = int(ps2)
     out = H.empty_nhwc(B, cout // 4, 2 * Hh, 2 * Ww, x0.device) if ps2 else H.empty_nhwc(B, cout, Hh, Ww, x0.device)
     a.out = out.data_ptr()
+    if res is not None:          # out = conv + res in the conv's epilogue (exact: fma(y, 1, res))
+        a.res1, a.res1_ld, a.res1_scale = res.data_ptr(), res.shape[1], 1.0
     _lib.check(L.srbh_hconv_f32(C.byref(a), _lib.stream_ptr()), "hconv_f32")
     return out
 
 
-def conv_dgrad(g, weight, cache: _PackedGrad):
-    """dX = conv^T(g, W): the forward kernel with transposed + flipped weights."""
+def conv_dgrad(g, weight, cache: _PackedGrad, res=None):
+    """dX = conv^T(g, W) (+ res): the forward kernel with transposed + flipped weights; `res` (NHWC, same shape as dX) is the
+    gradient arriving over a skip connection, added in the epilogue instead of by a separate pass."""
     cout, cin, ks, _ = weight.shape
-    return _hconv_raw([g], cache.get(weight), None, cin, ks)
+    return _hconv_raw([g], cache.get(weight), None, cin, ks, res=res)
 
 
 def conv_wgrad(srcs, pre, g, cout, ks):
@@ -247,15 +250,13 @@ class _BasicBlockFn(torch.autograd.Function):
         dc1, dg1, db1 = bn_backward(da1, c1, m1, i1, g1, (s1, h1), tr)
         dw1 = conv_wgrad(srcs, None, dc1, w1.shape[0], 3)
         need_dx = ctx.needs_input_grad[1] or (nsrc > 1 and ctx.needs_input_grad[2])
-        dx = conv_dgrad(dc1, w1, caches[0]) if need_dx else None
         dwd = dgd = dbd = None
+        skip = dz if need_dx else None          # gradient arriving over the identity / downsample path
         if has_ds:
             dd, dgd, dbd = bn_backward(dz, d, md, idd, gd, None, tr)
             dwd = conv_wgrad(srcs, None, dd, wd.shape[0], 1)
-            if need_dx:
-                add_(dx, conv_dgrad(dd, wd, caches[2]))
-        elif need_dx:
-            add_(dx, dz)
+            skip = conv_dgrad(dd, wd, caches[2]) if need_dx else None
+        dx = conv_dgrad(dc1, w1, caches[0], res=skip) if need_dx else None
         dx0 = dx1 = None
         if need_dx:
             if nsrc == 1:
