@@ -309,17 +309,17 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
             const unsigned wl = lane * 16;
             // one asm statement per DMA (the scheduler interleaves them with the MFMAs: blocks of 5 back-to-back DMAs stall
             // the wave on the VMEM issue queue and measured 5 % slower), scalar base + 32-bit VGPR offset addressing
+            // (EXEC is all-ones everywhere in this kernel's compute region: restored with the constant, no save; the EXEC
+            // write doubles as the wait state the M0 write needs before an LDS-DMA.  The cout-32 steps carry ~4 non-MFMA
+            // instructions per MFMA, about what one wave per SIMD can hide: every instruction less in here is time.)
             auto dma_s = [&](auto sc1_tag, const unsigned long long base, const unsigned voff, const unsigned lds_off,
                              const unsigned long long mask) {
-                unsigned long long sv;
                 if constexpr (decltype(sc1_tag)::value)
-                    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                                 "global_load_lds_dwordx4 %3, %4 sc1\n\ts_mov_b64 exec, %0"
-                                 : "=&s"(sv) : "s"(mask), "s"(lds_off), "v"(voff), "s"(base) : "memory", "m0");
+                    asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 exec, %0\n\tglobal_load_lds_dwordx4 %2, %3 sc1\n\ts_mov_b64 exec, -1"
+                                 :: "s"(mask), "s"(lds_off), "v"(voff), "s"(base) : "memory", "m0");
                 else
-                    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                                 "global_load_lds_dwordx4 %3, %4\n\ts_mov_b64 exec, %0"
-                                 : "=&s"(sv) : "s"(mask), "s"(lds_off), "v"(voff), "s"(base) : "memory", "m0");
+                    asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 exec, %0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1"
+                                 :: "s"(mask), "s"(lds_off), "v"(voff), "s"(base) : "memory", "m0");
             };
             auto issue = [&](const int i) {
                 if (i < 11) {
