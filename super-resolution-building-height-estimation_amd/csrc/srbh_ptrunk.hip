@@ -89,6 +89,9 @@ __device__ __forceinline__ int bias_off(int cb) { return cb == 1 ? A_BIAS_OFF : 
 // (conv1 of an RDB reads the x written by the previous conv5): it can be neither prefetched nor published lazily.
 __device__ __forceinline__ int first_new_chunk(const PLayer& l) { return (l.flags & 8) ? 0 : l.nchunk - 1; }
 
+// PROF (developer builds of the timeline only): s_memtime stamps per layer; compiled out of the production kernel -- the
+// stamps and their pointer cost ~16 SGPRs in a kernel that already spills scalars
+template <bool PROF>
 __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         constexpr int NREAD = G::NP + 3 * CB, NMFMA = 12 * CB;
         // ---- layer prologue (no accumulator is live here)
         unsigned long long p0 = 0;
-        if (pp.prof) p0 = __builtin_amdgcn_s_memtime();
+        if (PROF) p0 = __builtin_amdgcn_s_memtime();
         // LDS-DMA completion is NOT reliably waited for by hipcc before a barrier (seen: no vmcnt at all in this loop
         // shape) -> always drain explicitly.  vmcnt(0) also covers this workgroup's write-through stores of layer L-1.
         // The layer's bias goes through LDS: its global-load latency hides under the drain below instead of
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         const bool has_next_prefetch = (L + 1 < pp.nlayers) && !(pp.layers[L + 1 < pp.nlayers ? L + 1 : L].flags & 8);
         const PLayer nlay = pp.layers[L + 1 < pp.nlayers ? L + 1 : L];
         unsigned long long p1 = 0;
-        if (pp.prof) p1 = __builtin_amdgcn_s_memtime();
+        if (PROF) p1 = __builtin_amdgcn_s_memtime();
         floatx16 acc[CB][4];
 #pragma unroll
         for (int mb = 0; mb < CB; ++mb)
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
             step(c);
         }
         if (aborted) return;
-        if (pp.prof) ts1 = __builtin_amdgcn_s_memtime();
+        if (PROF) ts1 = __builtin_amdgcn_s_memtime();
 
         // ---- epilogue, straight from the MFMA D layout (no LDS round trip): lane (l31, hi) holds, for every row i and
         // channel group g, the 4 consecutive channels 8g + 4hi + (0..3) of pixel l31.  fp32 residual traffic is already
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         } else {
             process_rows(std::integral_constant<int, 4>{}, 0);
         }
-        if (pp.prof) ts2 = __builtin_amdgcn_s_memtime();
+        if (PROF) ts2 = __builtin_amdgcn_s_memtime();
         // ---- publication of "layer L complete"
         const bool seam = (L + 1 == pp.nlayers) || (pp.layers[L + 1 < pp.nlayers ? L + 1 : L].flags & 8);
         if (seam) {
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
             pending_pub = true;   // published behind the next top-of-step barrier (whose vmcnt(0) covers these stores)
             pub_val = L + 1;
         }
-        if (pp.prof && tid == 0) {
+        if (PROF && tid == 0) {
             unsigned long long* q = pp.prof + ((long)blockIdx.x * pp.nlayers + L) * 6;
             q[0] = ts0; q[1] = ts1; q[2] = ts2; q[3] = tw | ((unsigned long long)(__builtin_amdgcn_s_memtime() - ts2) << 32);
             q[4] = tb;
@@ -1101,11 +1104,12 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
     constexpr int LDS_B = P_LDS_B;
     static bool attr_set = false;
     if (!attr_set) {
-        SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
+        SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
+        SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
         attr_set = true;
     }
     int per_cu = 0;
-    SRBH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ptrunk_kernel, 256, LDS_B));
+    SRBH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ptrunk_kernel<false>, 256, LDS_B));
     if (per_cu < 1) return SRBH_OK;
 
     const int nl = d->num_block * 15;
@@ -1171,7 +1175,10 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
             pp.stagger_ways = w && atoi(w) > 0 ? atoi(w) : 2;
         }
         if (g_trunk_timing && b0 == 0) SRBH_HIP(hipEventRecord(g_trunk_ev[0], stream));
-        hipLaunchKernelGGL(ptrunk_kernel, dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
+        if (pp.prof)
+            hipLaunchKernelGGL(ptrunk_kernel<true>, dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
+        else
+            hipLaunchKernelGGL(ptrunk_kernel<false>, dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
         SRBH_HIP(hipGetLastError());
     }
     if (g_trunk_timing) SRBH_HIP(hipEventRecord(g_trunk_ev[1], stream));
