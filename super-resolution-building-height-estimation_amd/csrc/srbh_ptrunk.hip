@@ -61,8 +61,6 @@ struct PParams {
     int* xcc;                   // [nblocks] XCC_ID + 1 of every workgroup (placement handshake)
     int force_wt;               // 1: always use write-through stores (debugging aid, env SRBH_PT_WT=1)
     int frag_res;               // 1: fp32 residual streams in fragment order inside the launch (W == TILE_W)
-    int stagger_ways;
-    int stagger;                // odd images start this many s_sleep(127) periods late (de-phases the HBM bursts)
     unsigned long long* prof;   // debug (tools/convbench): [block][layer][4] s_memtime stamps, nullptr in production
 };
 
@@ -566,8 +564,6 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         }
     };
 
-    if (pp.stagger > 0)   // image i starts (i mod ways) * stagger sleep periods late: de-phases the HBM bursts of conv5
-        for (int k = 0; k < (img % pp.stagger_ways) * pp.stagger; ++k) __builtin_amdgcn_s_sleep(127);
     // ---- prologue: layer 0's inputs were written by the previous kernel (conv_first): no flag needed
     {
         const PLayer& l0 = pp.layers[0];
@@ -1167,12 +1163,6 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
         {
             const char* e = getenv("SRBH_PT_FRAGRES");   // debugging aid: 0 keeps the residual streams in pixel order
             pp.frag_res = (W == TILE_W) && !(e && atoi(e) == 0);
-        }
-        {
-            const char* e = getenv("SRBH_PT_STAGGER");
-            pp.stagger = e ? atoi(e) : 0;
-            const char* w = getenv("SRBH_PT_STAGGER_WAYS");
-            pp.stagger_ways = w && atoi(w) > 0 ? atoi(w) : 2;
         }
         if (g_trunk_timing && b0 == 0) SRBH_HIP(hipEventRecord(g_trunk_ev[0], stream));
         if (pp.prof)
