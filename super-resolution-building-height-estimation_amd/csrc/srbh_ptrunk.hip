@@ -329,8 +329,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
                 } else if (i < 16) {
                     const int k = i - 11;
                     dma_s(std::false_type{}, wbase + k * 4096, wl, wdst_w + k * 4096, k < 4 ? m_w : m_w4);
-                } else {
-                    const int k = i - 16;
+                } else if (CB == 2) {        // fragments 20..35 only exist for a cout-64 step; a cout-32 layer stages one
+                    const int k = i - 16;    // only in its very last step (conv4 -> conv5), see below the group loop
                     dma_s(std::false_type{}, wbase + 20 * 1024 + k * 4096, wl, wdst_w + 20 * 1024 + k * 4096, m_w2);
                 }
             };
@@ -358,6 +358,11 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
                 } else {
                     __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
                 }
+            }
+            if (CB == 1 && next_cb == 2) {   // (behind the MFMAs: one step per RDB)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    dma_s(std::false_type{}, wbase + 20 * 1024 + k * 4096, wl, wdst_w + 20 * 1024 + k * 4096, ~0ull);
             }
         };
 
