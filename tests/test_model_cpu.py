@@ -67,8 +67,11 @@ def test_dropin_import_paths_resolve_to_the_build():
             "from SR.HRfuse import HRfuse, HRfuse_x2, HRfeature, HRfuse_residual, Refine_residual, GeoNet, HRupsample;"
             "from mymodels import SRRegress_Cls_feature;"
             "from aggregate_utils import aggregate_torch;"
-            "import srbh_amd.rrdbnet as r, srbh_amd.hrfuse as h;"
-            "assert RRDBNet is r.RRDBNet and HRfeature is h.HRfeature; print('ok')") % os.path.join(PKG, "dropin")
+            "from losses_pytorch.selfloss import CE_DICE_adapt, MSE_adapt, MSE_adapt_weight, CE_DICE_adapt_weight;"   # train.py:20
+            "from metrics import AverageMeter, SegmentationMetric, HeightMetric;"                                     # train.py:13
+            "import srbh_amd.rrdbnet as r, srbh_amd.hrfuse as h, srbh_amd.losses as l, srbh_amd.metrics as m;"
+            "assert RRDBNet is r.RRDBNet and HRfeature is h.HRfeature;"
+            "assert MSE_adapt_weight is l.MSE_adapt_weight and HeightMetric is m.HeightMetric; print('ok')") % os.path.join(PKG, "dropin")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
 
