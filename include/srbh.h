@@ -177,6 +177,10 @@ typedef struct srbh_hconv_args {
     int post_lrelu;
     const float* res1; int res1_ld; float res1_scale;
     const float* res2; int res2_ld; float res2_scale;
+    /* inference-mode BasicBlock fusion (SR/HRfuse.py:146-157 with BatchNorm in eval mode): per-output-channel affine
+     * y = y*post_scale[c] + post_shift[c] (applied after the bias, before res1) and a plain ReLU at the very end */
+    const float* post_scale; const float* post_shift;   /* [cout padded to 16] or NULL */
+    int post_relu;
 } srbh_hconv_args;
 int srbh_hconv_f32(const srbh_hconv_args* a, void* stream);
 

@@ -77,6 +77,7 @@ class HConvArgs(C.Structure):
         ("src0_ld", C.c_int), ("src1_ld", C.c_int), ("out_ld", C.c_int), ("out_coff", C.c_int), ("post_lrelu", C.c_int),
         ("res1", C.c_void_p), ("res1_ld", C.c_int), ("res1_scale", C.c_float),
         ("res2", C.c_void_p), ("res2_ld", C.c_int), ("res2_scale", C.c_float),
+        ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("post_relu", C.c_int),
     ]
 
 

@@ -49,6 +49,7 @@ struct HParams {
     int post_lrelu;
     const float* res1; int res1_ld; float res1_scale;  // y = y*res1_scale + res1 ; then y = y*res2_scale + res2
     const float* res2; int res2_ld; float res2_scale;
+    const float* post_scale; const float* post_shift; int post_relu;
 };
 
 // NOB = cout/16 (1 or 4), KS = 3 or 1
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
             const int oc = ob * 16 + kk * 4;
             floatx4 v = acc[ob][i];
             if (p.bias) v += *(const floatx4*)(p.bias + oc);
+            if (p.post_scale) v = v * *(const floatx4*)(p.post_scale + oc) + *(const floatx4*)(p.post_shift + oc);   // eval-mode BatchNorm
             if (ok && p.res1) {      // residual epilogues of the strict fp32 trunk (x5*0.2 + x, out*0.2 + x)
                 const long pixr = ((long)img * p.H + Y) * p.W + X;
                 v = v * p.res1_scale + *(const floatx4*)(p.res1 + pixr * p.res1_ld + oc);
@@ -209,6 +211,10 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
             if (p.post_lrelu) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = v[q] >= 0.f ? v[q] : v[q] * 0.2f;
+            }
+            if (p.post_relu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
             }
             if (ok) {
 #pragma unroll
@@ -448,6 +454,8 @@ extern "C" int srbh_hconv_f32(const srbh_hconv_args* a, void* stream) {
     p.post_lrelu = a->post_lrelu;
     p.res1 = a->res1; p.res1_ld = a->res1_ld; p.res1_scale = a->res1_scale;
     p.res2 = a->res2; p.res2_ld = a->res2_ld; p.res2_scale = a->res2_scale;
+    p.post_scale = a->post_scale; p.post_shift = a->post_shift; p.post_relu = a->post_relu;
+    SRBH_REQUIRE(!a->post_scale || a->post_shift, "srbh_hconv_f32: post_scale needs post_shift");
     SRBH_REQUIRE(!a->pixelshuffle2 || (a->out_ld <= 0 && a->out_coff == 0), "srbh_hconv_f32: PixelShuffle store needs a dense output");
     SRBH_REQUIRE(!a->res1 || (a->cout % 4 == 0 && a->res1_ld % 4 == 0), "srbh_hconv_f32: residual epilogue needs 4-aligned channels");
     SRBH_REQUIRE(!a->res2 || a->res1, "srbh_hconv_f32: res2 requires res1");

@@ -84,9 +84,11 @@ class _PackedConv:
         return self.w, self.b
 
 
-def hconv(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_stats=False):
+def hconv(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_stats=False, post=None, res=None,
+          post_relu=False):
     """conv(cat(srcs)) through srbh_hconv_f32.  srcs: list of 1..2 NHWC tensors; pre=(scale, shift, relu) is
-    applied to srcs[0]; returns (out, stats) with out NHWC and stats the partial-sum buffer or None."""
+    applied to srcs[0]; returns (out, stats) with out NHWC and stats the partial-sum buffer or None.
+    Epilogue extras (inference fusion): post=(scale, shift) per output channel, res = NHWC tensor added, post_relu."""
     L = _lib.lib()
     x0 = srcs[0]
     B, c0, H, W = x0.shape
@@ -108,6 +110,11 @@ def hconv(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_
     a.pixelshuffle2 = int(ps2)
     out = empty_nhwc(B, cout // 4, 2 * H, 2 * W, x0.device) if ps2 else empty_nhwc(B, cout, H, W, x0.device)
     a.out = out.data_ptr()
+    if post is not None:
+        a.post_scale, a.post_shift = post[0].data_ptr(), post[1].data_ptr()
+    if res is not None:
+        a.res1, a.res1_ld, a.res1_scale = res.data_ptr(), res.shape[1], 1.0
+    a.post_relu = int(post_relu)
     stats = None
     if want_stats:
         stats = torch.empty(L.srbh_bn_stats_bytes((cout + 15) // 16 * 16) // 8, dtype=torch.float64, device=x0.device)
@@ -286,6 +293,19 @@ class BasicBlock(nn.Module):
         n = B * H * W
         c1, st1 = hconv(srcs, self.conv1, self._p1, want_stats=tr)
         s1, h1, _, _ = bn_scale_shift(self.bn1, st1, n, tr)
+        if not tr and self.bn2.num_features % 16 == 0:
+            # inference: BatchNorm is a per-channel affine -> bn2, the skip connection and the final ReLU run in conv2's
+            # epilogue (and the downsample BatchNorm in the 1x1 conv's): no c2 round trip, no separate elementwise pass
+            s2, h2, _, _ = bn_scale_shift(self.bn2, None, n, False)
+            if self.downsample is not None:
+                sd, hd, _, _ = bn_scale_shift(self.downsample[1], None, n, False)
+                idt, _ = hconv(srcs, self.downsample[0], self._pd, post=(sd, hd))
+            else:
+                if len(srcs) != 1:
+                    raise ValueError("identity path needs a single source")
+                idt = srcs[0]
+            out, _ = hconv([c1], self.conv2, self._p2, pre=(s1, h1, True), post=(s2, h2), res=idt, post_relu=True)
+            return out
         c2, st2 = hconv([c1], self.conv2, self._p2, pre=(s1, h1, True), want_stats=tr)
         s2, h2, _, _ = bn_scale_shift(self.bn2, st2, n, tr)
         if self.downsample is not None:
