@@ -89,7 +89,7 @@ __device__ __forceinline__ int first_new_chunk(const PLayer& l) { return (l.flag
 
 // PROF (developer builds of the timeline only): s_memtime stamps per layer; compiled out of the production kernel -- the
 // stamps and their pointer cost ~16 SGPRs in a kernel that already spills scalars
-template <bool PROF>
+template <bool PROF, bool REGRES>
 __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -236,6 +236,25 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
 
     bool pending_pub = false;
     int pub_val = 0;
+
+    // The RDB-level residual stream (the fp32 input x of the current RDB) of this wave's 4 rows x 32 pixels x 64 channels
+    // lives in 128 REGISTERS per lane, in exactly the accumulator layout of conv5 ([mb][row][channel group]): with one
+    // wave per SIMD half of the 512-entry register file is otherwise idle, and conv5's epilogue stops being an fp32
+    // read-modify-write of 128 KiB per workgroup through HBM.  Only the RRDB-level stream (every third RDB) stays in memory.
+    floatx4 xres[2][4][4];
+    if (REGRES) {   // the launch's input x, written by conv_first in pixel order
+        const int X = wc * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int Y = Y0 + wr * 4 + i;
+            const bool ok = (Y < pp.H) && (X < pp.W);
+            const float* q = pp.xrr + (((long)img * pp.H + (ok ? Y : 0)) * pp.W + (ok ? X : 0)) * 64 + hi * 4;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xres[mb][i][g] = *(const floatx4*)(q + mb * 32 + g * 8);
+        }
+    }
 
     // ---- one layer: CB = cout/32
     auto run_layer = [&](auto cb_tag, const int L, const PLayer& lay) {
@@ -429,8 +448,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         const float* res1_src = (lay.flags & 64) ? pp.xrr : pp.xr;
         // rows are processed NR at a time: all residual loads of the group are issued before any of them is consumed
         // (per-row processing left only 8-16 loads in flight per wave and made the fp32 residual RMW latency-bound)
-        auto process_rows = [&](auto nr_tag, const int i0) {
-            constexpr int NR = decltype(nr_tag)::value;
+        auto process_rows = [&](auto nr_tag, auto i0_tag) {
+            constexpr int NR = decltype(nr_tag)::value, i0 = decltype(i0_tag)::value;
             floatx4 a1[NR][CB][4], a2[NR][CB][4];
             bool valid[NR];
             long rowb[NR];   // float offset of image row Y in the RES32 streams
@@ -440,11 +459,13 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
                 valid[k] = (Y < pp.H) && (X < pp.W);
                 rowb[k] = ((long)img * pp.H + Y) * pp.W * 64;
                 if (r1 && valid[k]) {
-                    const float* q1 = res1_src + rowb[k] + s1.lane;
+                    if (!REGRES) {
+                        const float* q1 = res1_src + rowb[k] + s1.lane;
 #pragma unroll
-                    for (int mb = 0; mb < CB; ++mb)
+                        for (int mb = 0; mb < CB; ++mb)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) a1[k][mb][g] = *(const floatx4*)(q1 + mb * s1.sm + g * s1.sg);
+                            for (int g = 0; g < 4; ++g) a1[k][mb][g] = *(const floatx4*)(q1 + mb * s1.sm + g * s1.sg);
+                    }
                     if (r2) {
                         const float* q2 = pp.xrr + rowb[k] + s2.lane;
 #pragma unroll
@@ -468,8 +489,12 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
                         for (int q = 0; q < 4; ++q) t[q] = acc[mb][i][g * 4 + q];
                         t += bias4[mb][g];
                         if (r1) {
-                            t = t * 0.2f + a1[k][mb][g];
+                            if (REGRES)
+                                t = t * 0.2f + xres[mb][i][g];
+                            else
+                                t = t * 0.2f + a1[k][mb][g];
                             if (r2) t = t * 0.2f + a2[k][mb][g];
+                            if (REGRES) xres[mb][i][g] = t;
                         }
                         vv[k][mb][g] = t;
                     }
@@ -512,24 +537,43 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
             }
             // the private fp32 residual streams go out LAST: at an RDB seam only the write-through fp16 stores above have
             // to be complete before the progress counter moves (see `seam` below), these may still be in flight
-            if (r1) {
+            if (r1 && (r2 || !REGRES)) {   // REGRES: the RDB-level stream stays in registers, nothing to store
 #pragma unroll
                 for (int k = 0; k < NR; ++k) {
                     if (!valid[k]) continue;
                     // an RRDB-closing layer leaves xr == xrr: only xrr is written, the next RDB reads its res1 from there
-                    float* q = (r2 ? pp.xrr : pp.xr) + rowb[k] + sd.lane;
+                    // scalar base + 32-bit lane offset, formed at the point of use: left to the compiler, the 32 64-bit
+                    // store addresses are computed early, spilled, and every store then waits for its address reload
+                    const float* q = (r2 ? pp.xrr : pp.xr) + rowb[k];
+                    const unsigned vo = (unsigned)sd.lane * 4u;
 #pragma unroll
                     for (int mb = 0; mb < CB; ++mb)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) *(floatx4*)(q + mb * sd.sm + g * sd.sg) = vv[k][mb][g];
+                        for (int g = 0; g < 4; ++g) {
+                            const unsigned long long sb = uni64((unsigned long long)(q + mb * sd.sm + g * sd.sg));
+                            // Hazards the compiler cannot see through inline asm: the scalar base is typically a fresh
+                            // v_readlane (SGPR spill reload) and a VALU-written SGPR needs 5 wait states before VMEM reads
+                            // it; a >8-byte store needs wait states before a VALU write of its data registers.
+                            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(vo), "v"(vv[k][mb][g]), "s"(sb) : "memory");
+                        }
                 }
             }
         };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        using I4 = std::integral_constant<int, 4>;
         if (r2) {
-            process_rows(std::integral_constant<int, 2>{}, 0);
-            process_rows(std::integral_constant<int, 2>{}, 2);
+            process_rows(I2{}, I0{});
+            process_rows(I2{}, I2{});
+        } else if (REGRES && r1) {   // no residual loads to batch: row by row keeps the register pressure down
+            process_rows(I1{}, I0{});
+            process_rows(I1{}, I1{});
+            process_rows(I1{}, I2{});
+            process_rows(I1{}, I3{});
         } else {
-            process_rows(std::integral_constant<int, 4>{}, 0);
+            process_rows(I4{}, I0{});
         }
         if (PROF) ts2 = __builtin_amdgcn_s_memtime();
         // ---- publication of "layer L complete"
@@ -1105,17 +1149,22 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
     constexpr int LDS_B = P_LDS_B;
     static bool attr_set = false;
     if (!attr_set) {
-        SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
-        SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
+        SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
+        SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
+        SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
         attr_set = true;
     }
     int per_cu = 0;
-    SRBH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ptrunk_kernel<false>, 256, LDS_B));
+    SRBH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ptrunk_kernel<false, true>, 256, LDS_B));
     if (per_cu < 1) return SRBH_OK;
 
     const int nl = d->num_block * 15;
     std::vector<PLayer> tab(nl);
     int cur = 0, li = 0;
+    // The RDB-level fp32 residual stream lives in registers (ptrunk_kernel<., true>); SRBH_PT_REGRES=0 selects the
+    // instantiation that keeps it in memory (A/B aid).
+    const char* rr = getenv("SRBH_PT_REGRES");
+    const bool reg_res = !(rr && atoi(rr) == 0);
     for (int blk = 0; blk < d->num_block; ++blk)
         for (int r = 0; r < 3; ++r) {
             const srbh_conv_w* cw = d->rdb + (blk * 3 + r) * 5;
@@ -1171,9 +1220,11 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
         }
         if (g_trunk_timing && b0 == 0) SRBH_HIP(hipEventRecord(g_trunk_ev[0], stream));
         if (pp.prof)
-            hipLaunchKernelGGL(ptrunk_kernel<true>, dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
+            hipLaunchKernelGGL((ptrunk_kernel<true, true>), dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
+        else if (reg_res)
+            hipLaunchKernelGGL((ptrunk_kernel<false, true>), dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
         else
-            hipLaunchKernelGGL(ptrunk_kernel<false>, dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
+            hipLaunchKernelGGL((ptrunk_kernel<false, false>), dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
         SRBH_HIP(hipGetLastError());
     }
     if (g_trunk_timing) SRBH_HIP(hipEventRecord(g_trunk_ev[1], stream));
