@@ -36,6 +36,9 @@
 #ifndef PT_DMA_GROUPS
 #define PT_DMA_GROUPS 3
 #endif
+#ifndef PT_DEFER_FLAGS
+#define PT_DEFER_FLAGS 1
+#endif
 
 namespace {
 using namespace srbh;
@@ -276,7 +279,11 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
             publish(pub_val);
             pending_pub = false;
         }
-        if (L > 0) ensure_flags(L);   // every input plane of layer L is complete on both neighbours
+        // Layer L's only NEW input plane is its last chunk (except at an RDB seam, flag 8, whose wait happened in the
+        // previous epilogue): the neighbour-flag wait (one L2 round trip, ~2.5 k cycles when taken here) is deferred
+        // behind step 0, which reads planes verified layers ago and stages another such plane.
+        const bool defer_flags = PT_DEFER_FLAGS && !(lay.flags & 8) && lay.nchunk >= 3;
+        if (L > 0 && !defer_flags) ensure_flags(L);   // every input plane of layer L is complete on both neighbours
         if (aborted) return;
         const bool has_next_prefetch = (L + 1 < pp.nlayers) && !(pp.layers[L + 1 < pp.nlayers ? L + 1 : L].flags & 8);
         const PLayer nlay = pp.layers[L + 1 < pp.nlayers ? L + 1 : L];
@@ -408,14 +415,14 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
             compute(sbi, st + IN_EX, next_cb, nsrc, nw, smem + stage_off(next_cb ? next_cb : CB, (gs + 1) & 1));
             ++gs;
         };
-        for (int c = 0; c < n; ++c) {
-            if (c > 0) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of step gs has landed ...
-                __syncthreads();                                   // ... and everybody else's; all waves are past step gs-1
-            }
+        step(0);
+        if (defer_flags) ensure_flags(L);   // (once per layer, outside the chunk loop: see the note on control flow above)
+        if (aborted) return;
+        for (int c = 1; c < n; ++c) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of step gs has landed ...
+            __syncthreads();                                   // ... and everybody else's; all waves are past step gs-1
             step(c);
         }
-        if (aborted) return;
         if (PROF) ts1 = __builtin_amdgcn_s_memtime();
 
         // ---- epilogue, straight from the MFMA D layout (no LDS round trip): lane (l31, hi) holds, for every row i and
