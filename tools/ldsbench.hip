@@ -205,6 +205,101 @@ static void run_step(const char* name, unsigned long long dmask) {
     hipFree(sink);
 }
 
+
+// 8 waves per workgroup (2 per SIMD), each owning 2 rows x 32 pixels: NP = 4 pixel-fragment rows + 3*CB weight fragments
+// feed 6*CB MFMAs per group; same staging volume per step as step_kernel (ND DMA per wave)
+template <int CB, int ND>
+__global__ __launch_bounds__(512, 1) void step8_kernel(unsigned long long* out, int iters, float* sink, const char* gsrc, unsigned long long dmask) {
+    constexpr int NP = 4, NR = NP + 3 * CB, NM = 6 * CB, ACC = 2 * CB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 160 * 1024 / 4; i += 512) ((float*)smem)[i] = (float)(i & 1023) * 1e-3f;
+    __syncthreads();
+    const int l31 = lane & 31, hi = lane >> 5, wr = wave >> 1, wc = wave & 1;
+    int off[NR];
+    for (int r = 0; r < NR; ++r) {
+        const int pc = wc * 32 + l31;
+        off[r] = r < NP ? (wr * 2 + r) * 66 * 64 + pc * 64 + ((hi ^ ((pc >> 2) & 3)) << 4) : 45056 + (r - NP) * 1024 + lane * 16;
+    }
+    floatx16 c[ACC];
+    for (int a = 0; a < ACC; ++a) c[a] = floatx16{0};
+    half8 v[2][NR];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* sb = smem + (it & 1) * 81920;
+        const unsigned dstl = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)(smem + ((it + 1) & 1) * 81920) + wave * 1024;
+        const unsigned long long gb = (unsigned long long)gsrc + (unsigned long long)blockIdx.x * 81920 + (it & 3) * 20480;
+        const unsigned dl = __builtin_amdgcn_readfirstlane(dstl);
+        const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gb), ghi = __builtin_amdgcn_readfirstlane((unsigned)(gb >> 32));
+        const unsigned long long gbu = ((unsigned long long)ghi << 32) | glo;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) v[0][r] = *(const half8*)(sb + off[r]);
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+#pragma unroll
+            for (int i = 0; i < ND; ++i)
+                if (i * 3 / ND == u) {
+                    unsigned long long sv;
+                    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                                 "global_load_lds_dwordx4 %3, %4 sc1\n\ts_mov_b64 exec, %0"
+                                 : "=&s"(sv) : "s"(dmask), "s"(dl + i * 8192), "v"(lane * 16 + wave * 1024 + i * 8192), "s"(gbu) : "memory", "m0");
+                }
+            if (u + 1 < 6) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) v[(u + 1) & 1][r] = *(const half8*)(sb + off[r] + (u + 1) * 16);
+            }
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+                c[m % ACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v[u & 1][NP + m % (NR - NP)], v[u & 1][m % NP], c[m % ACC], 0, 0, 0);
+            if (u == 0) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+            if (u + 1 < 6) {
+                constexpr int K = NR < NM ? NR : NM;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                if constexpr (NM > NR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+                if constexpr (NR > NM) __builtin_amdgcn_sched_group_barrier(0x100, NR - NM, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) out[blockIdx.x] = t1 - t0;
+    float s = 0;
+    for (int a = 0; a < ACC; ++a)
+        for (int q = 0; q < 16; ++q) s += c[a][q];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+template <int CB, int ND>
+static void run_step8(const char* name, unsigned long long dmask) {
+    unsigned long long* d;
+    float* sink;
+    hipMalloc(&d, 256 * 8);
+    hipMalloc(&sink, 4);
+    hipFuncSetAttribute((const void*)step8_kernel<CB, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int iters = 400;
+    char* gsrc;
+    hipMalloc(&gsrc, 256 * 81920 + (1 << 20));
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((step8_kernel<CB, ND>), dim3(256), dim3(512), 160 * 1024, 0, d, iters, sink, gsrc, dmask);
+    hipDeviceSynchronize();
+    unsigned long long h[256];
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    double avg = 0;
+    for (int i = 0; i < 256; ++i) avg += (double)h[i];
+    avg /= 256;
+    printf("%-52s %8.1f cycles per step (per-SIMD MFMA issue floor %d) -> %.0f %%\n", name, avg / iters, 2 * 6 * 6 * CB * 32,
+           100.0 * 2 * 6 * 6 * CB * 32 / (avg / iters));
+    hipFree(d);
+    hipFree(sink);
+    hipFree(gsrc);
+}
+
 template <int NR, int NM, int ACC>
 static void run_group(const char* name) {
     unsigned long long* d;
@@ -227,6 +322,10 @@ static void run_group(const char* name) {
 }
 
 int main() {
+    run_step8<1, 1>("8 waves, cout 32 STEP: barrier + 6 groups, ~no DMA", 0ull);
+    run_step8<1, 8>("8 waves, cout 32 STEP + 8 DMA/wave (64 KiB/step)", ~0ull);
+    run_step8<2, 1>("8 waves, cout 64 STEP: barrier + 6 groups, ~no DMA", 0ull);
+    run_step8<2, 10>("8 waves, cout 64 STEP + 10 DMA/wave (80 KiB/step)", ~0ull);
     run_step<9, 12, 4, 1>("cout 32 STEP: barrier + 6 groups, ~no DMA", 0ull);
     run_step<9, 12, 4, 16>("cout 32 STEP + 16 DMA slots masked off", 0ull);
     run_step<9, 12, 4, 16>("cout 32 STEP + 16 DMA (64 KiB/step)", ~0ull);

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Refresh the judged measurement artefacts of one round on the GPU box:  bash tools/profile_round.sh r01e
+# Writes gpurun_out/<tag>_*; copy what should be judged into profiles/ afterwards.
+# (counter passes carry --kernel-trace + --pmc only, one pass per counter set, as MI355X_MICROARCH.md prescribes)
+TAG=${1:-rXX}
+export TMPDIR=/tmp
+O=gpurun_out
+mkdir -p $O
+timeout 600 python bench.py > $O/${TAG}_bench_feature_b32.json.log 2> $O/${TAG}_bench.err
+timeout 600 python bench.py --workload train --no-cpu-baseline > $O/${TAG}_bench_train_b64.json.log 2>> $O/${TAG}_bench.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- python bench.py --no-cpu-baseline > $O/${TAG}_stats.log 2>&1
+cp $(find $O/${TAG}_stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_feature_b32_kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_pmc_write.log 2>&1
+python tools/pmc_traffic.py $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_hbm_traffic.json
+bash tools/pmc_sq.sh > /dev/null 2>&1
+cp $O/sq/summary.txt $O/${TAG}_sq_counters_ptrunk.txt
+find $O -name "*.csv" -size +1M -delete
+find $O -name "*.db" -delete
+tail -1 $O/${TAG}_bench_feature_b32.json.log; tail -1 $O/${TAG}_bench_train_b64.json.log; head -4 $O/${TAG}_bench_feature_b32_kernel_stats.csv; cat $O/${TAG}_sq_counters_ptrunk.txt
