@@ -20,12 +20,6 @@
 #include <stdlib.h>
 #include "srbh_conv3x3_kernel.h"
 
-#ifndef PT_SPLIT_DRAIN
-#define PT_SPLIT_DRAIN 0
-#endif
-#ifndef PT_EPI_BARRIER
-#define PT_EPI_BARRIER 0
-#endif
 
 #ifndef PT_LOAD_SCOPE
 #define PT_LOAD_SCOPE " sc1"   // cache-coherence bits of the activation LDS-DMA loads
@@ -587,14 +581,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         const bool seam = (L + 1 == pp.nlayers) || (pp.layers[L + 1 < pp.nlayers ? L + 1 : L].flags & 8);
         if (seam) {
             // the next layer's first chunk is THIS layer's output on the neighbours: publish now, then wait for them
-            // vmcnt counts this wave's outstanding VMEM ops and (no loads are pending here) stores retire in issue order:
-            // leaving the trailing 32 fp32 residual stores in flight still guarantees every write-through fp16 store.
-            // Only when all 4 rows of this wave were stored (the trailing count is then exact); else drain everything.
-            const bool full = PT_SPLIT_DRAIN && CB == 2 && r1 && (Y0 + wr * 4 + 3 < pp.H) && (pp.W >= TILE_W);
-            if (full)
-                asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             publish(L + 1);
             if (L + 1 < pp.nlayers) {

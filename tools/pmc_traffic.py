@@ -29,7 +29,7 @@ def main():
     tot = 0.0
     launches_ref = None
     for k in sorted(set(fe) | set(wr)):
-        if not ("srbh" in k or "ptrunk" in k or "conv_first" in k):
+        if not ("srbh" in k or "ptrunk" in k or "ptail" in k or "conv_first" in k):
             continue
         e = {"launches": max(len(fe.get(k, [])), len(wr.get(k, [])))}
         if k in fe:
