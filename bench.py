@@ -126,6 +126,76 @@ def bench_train(args, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
+def bench_predict(args, rank, world, dev, dist):
+    """BASELINE configs[4]: urban-centre tiled inference.  A "step" is ONE synthetic city: its grid cells (64x64x8 LR tiles,
+    stride 48 as in the reference's grid loader) are sharded over the ranks, each rank runs RRDBNet features -> eval head ->
+    quantise + integer mosaic on the device, the integer mosaics are summed over ranks (bit-identical to the serial
+    result) and finalised (argmax / normalise).  City sizes: the first --steps (+ warm-up) of 301 cell counts drawn
+    log-uniform in [200, 20000] (numpy default_rng(2024)); no per-city grid counts ship with the reference.
+    GeoTIFF IO is outside the path."""
+    import numpy as np
+    from oracle import synth
+    from srbh_amd.harness import predict_tiles
+    from srbh_amd.models import SRRegress_Cls_feature
+    from srbh_amd.mosaic import Mosaic
+    from srbh_amd.rrdbnet import RRDBNet
+    net_hr = RRDBNet(3, 3, num_block=args.num_block)
+    net_hr.load_state_dict(synth.rrdbnet_state_dict(num_block=args.num_block, seed=1337, mode="init"))
+    net_hr = net_hr.to(dev).eval()
+    torch.manual_seed(1337)
+    model = SRRegress_Cls_feature("efficientnet-b4", in_channels=8, super_in=64, super_mid=16, upscale=4, isaggre=False,
+                                  chans_build=7).to(dev).eval()
+    counts = np.exp(np.random.default_rng(2024).uniform(np.log(200.0), np.log(20000.0), 301)).astype(int)
+    batch = args.batch if args.batch != 32 else 128     # 288 GB of HBM: larger batches amortise the stock-op encoder's small launches
+    n_warm = min(args.warmup, 2)
+    todo = [int(c) for c in counts[:args.steps]]
+    warm = [min(int(c), 256) for c in counts[-n_warm:]] if n_warm else []
+
+    def city(n, seed):
+        gw = int(np.ceil(np.sqrt(n)))
+        gh = (n + gw - 1) // gw
+        pos = [[(i % gw) * 48, (i // gw) * 48, 64, 64] for i in range(n)]
+        g = torch.Generator(device=dev).manual_seed(seed)        # inference tiles: N(0.35, 0.25), not clipped (SURVEY 8d)
+        tiles = torch.randn((n, 8, 64, 64), generator=g, device=dev) * 0.25 + 0.35
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        m = Mosaic((gh * 48 + 16) * 4, (gw * 48 + 16) * 4, 7, dev)
+        predict_tiles(net_hr, model, tiles, pos, m, batch=batch, rank=rank, world=world)
+        if dist is not None:
+            m.all_reduce_(dist)
+        out = m.finalize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        del m, out, tiles
+        return dt
+
+    for i, n in enumerate(warm):
+        city(n, 99 + i)
+    lat = [city(n, 2024 + i) for i, n in enumerate(todo)]
+    if rank == 0:
+        total, elapsed = sum(todo), sum(lat)
+        order = sorted(range(len(lat)), key=lambda i: lat[i])
+        mid = order[len(order) // 2]
+        print(json.dumps({
+            "metric": "tiles/sec (64x64x8ch->256x256 height) tiled inference incl. quantise + mosaic", "value": round(total / elapsed, 2),
+            "unit": "tiles/s", "n_gpus": world, "steps": len(todo), "warmup": len(warm), "ms_per_step": round(elapsed / len(todo) * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f16 operands/f32 acc (RRDB), f32 (head), integer mosaic", "data": "synthetic cities, random-init weights",
+            "config": {"workload": f"sliding-window predict path, {len(todo)} of 301 synthetic cities (cells log-uniform 200..20000, "
+                                   f"seed 2024), batch {batch}/GPU (BASELINE.json configs[4])",
+                       "cities": len(todo), "tiles": total, "parallelism": f"each city's cells sharded x{world}, integer mosaic all-reduce"},
+            "p50_city_latency_ms": round(lat[mid] * 1e3, 2), "p50_city_tiles": todo[mid],
+            "max_city_latency_ms": round(max(lat) * 1e3, 2), "max_city_tiles": max(todo)}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,8 +204,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="tiles per GPU per step (configs[1]: 32)")
     ap.add_argument("--num-block", type=int, default=23)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["feature", "train"], default="feature",
-                    help="feature = BASELINE configs[1] (default); train = configs[2]: full training step, batch 64")
+    ap.add_argument("--workload", choices=["feature", "train", "predict"], default="feature",
+                    help="feature = BASELINE configs[1] (default); train = configs[2]: full training step, batch 64; "
+                         "predict = configs[4]: tiled city inference incl. mosaic, one city per step (try --steps 12)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,6 +230,8 @@ def main():
 
     if args.workload == "train":
         return bench_train(args, rank, world, dev, dist)
+    if args.workload == "predict":
+        return bench_predict(args, rank, world, dev, dist)
 
     sd = synth.rrdbnet_state_dict(num_block=args.num_block, seed=1337, mode="init")
     net = RRDBNet(3, 3, num_block=args.num_block)

@@ -233,6 +233,17 @@ int srbh_bn_bwd_apply(const float* g, const float* c, const float* mean, const f
 /* inverse of the PixelShuffle(2) store map: g_ps [B][2H][2W][C] -> g [B][H][W][4C] */
 int srbh_ps2_inverse(const float* g_ps, float* g, int B, int H, int W, int C, void* stream);
 
+/* ---- depthwise KxK convolution (K = 3|5, stride 1|2), fp32 NCHW, zero padding folded in (pad_t / pad_l given, bottom /
+ * right implied by OH / OW): the EfficientNet encoder's `_depthwise_conv` (third-party efficientnet_pytorch called from
+ * mymodels.py:242-248), for which MIOpen only has its naive fp32 kernels.  x [B][C][H][W], w [C][1][K][K],
+ * y / dy [B][C][OH][OW]; bwd_weight sums in a fixed order (deterministic). */
+int srbh_dwconv_fwd(const float* x, const float* w, float* y, int B, int C, int H, int W, int K, int stride, int pad_t,
+                    int pad_l, int OH, int OW, void* stream);
+int srbh_dwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int C, int H, int W, int K, int stride,
+                         int pad_t, int pad_l, int OH, int OW, void* stream);
+int srbh_dwconv_bwd_weight(const float* x, const float* dy, float* dw, int B, int C, int H, int W, int K, int stride,
+                           int pad_t, int pad_l, int OH, int OW, void* stream);
+
 /* ---- inference epilogue: quantise + integer mosaic (predict_realesanet_feature_globe.py:172-204) ------------------
  * accumulate: height [B][th][tw] fp32 (model output, C=1), build logits NHWC [B][th][tw][C] fp32, pos [B][4] int32
  *   = (xoff, yoff, xcount, ycount) already multiplied by 4 (predict...py:182); adds round(max(h,0)*10) and

@@ -1,0 +1,178 @@
+// srbh_dwconv.hip -- depthwise KxK convolution (K = 3 or 5, stride 1 or 2), fp32 NCHW, forward / input gradient / weight
+// gradient, with the zero padding folded in (top/left pad given; bottom/right implied by the output size).
+//
+// Why it exists: the EfficientNet-B4 encoder the reference instantiates (mymodels.py:242-248) is stock PyTorch ops in
+// this build, but MIOpen has no fp32 solver for its 5x5 / strided depthwise convolutions and falls back
+// to `naive_conv_ab_nonpacked_{fwd,bwd,wrw}` -- 10.7 % of the tiled-inference path and 5.6 ms of the 81 ms training step
+// (profiles/r01e_*).  These are HBM-bound element-wise kernels: planes are at most 32x32, every tap re-read hits L1/L2.
+#include <hip/hip_runtime.h>
+#include "srbh.h"
+#include "srbh_internal.h"
+
+namespace {
+using namespace srbh;
+
+struct DWParams {
+    const float* x;     // [B][C][H][W]
+    const float* w;     // [C][1][K][K]
+    const float* dy;    // [B][C][OH][OW]
+    float* out;         // y, dx or dw
+    int B, C, H, W, OH, OW, stride, pad_t, pad_l;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const DWParams p) {
+    const long total = (long)p.B * p.C * p.OH * p.OW;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ox = idx % p.OW;
+        long r = idx / p.OW;
+        const int oy = r % p.OH;
+        r /= p.OH;                                  // r = b * C + c
+        const int c = r % p.C;
+        const float* xp = p.x + r * p.H * p.W;
+        const float* wp = p.w + (long)c * K * K;
+        const int y0 = oy * p.stride - p.pad_t, x0 = ox * p.stride - p.pad_l;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int y = y0 + i;
+            if (y < 0 || y >= p.H) continue;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int x = x0 + j;
+                if (x >= 0 && x < p.W) acc = fmaf(xp[y * p.W + x], wp[i * K + j], acc);
+            }
+        }
+        p.out[idx] = acc;
+    }
+}
+
+// dx[y][x] = sum over taps (i, j) with (y + pad_t - i) = s * oy, (x + pad_l - j) = s * ox of dy[oy][ox] * w[i][j]
+template <int K>
+__global__ __launch_bounds__(256) void dw_bwd_data_kernel(const DWParams p) {
+    const long total = (long)p.B * p.C * p.H * p.W;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int x = idx % p.W;
+        long r = idx / p.W;
+        const int y = r % p.H;
+        r /= p.H;
+        const int c = r % p.C;
+        const float* gp = p.dy + r * p.OH * p.OW;
+        const float* wp = p.w + (long)c * K * K;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int ty = y + p.pad_t - i;
+            if (ty < 0 || ty % p.stride) continue;
+            const int oy = ty / p.stride;
+            if (oy >= p.OH) continue;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int tx = x + p.pad_l - j;
+                if (tx < 0 || tx % p.stride) continue;
+                const int ox = tx / p.stride;
+                if (ox < p.OW) acc = fmaf(gp[oy * p.OW + ox], wp[i * K + j], acc);
+            }
+        }
+        p.out[idx] = acc;
+    }
+}
+
+// dw[c][i][j] = sum over (b, oy, ox) of dy[b][c][oy][ox] * x[b][c][oy*s - pad_t + i][ox*s - pad_l + j]: one workgroup per
+// channel, a fixed summation tree (thread-strided partial sums -> wave shuffles -> LDS across the 4 waves): deterministic
+template <int K>
+__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const DWParams p) {
+    const int c = blockIdx.x;
+    const int per_img = p.OH * p.OW;
+    const long n = (long)p.B * per_img;
+    float acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = 0.f;
+    for (long e = threadIdx.x; e < n; e += 256) {
+        const int b = e / per_img;
+        const int q = e - (long)b * per_img;
+        const int oy = q / p.OW, ox = q - oy * p.OW;
+        const float g = p.dy[((long)b * p.C + c) * per_img + q];
+        const float* xp = p.x + ((long)b * p.C + c) * p.H * p.W;
+        const int y0 = oy * p.stride - p.pad_t, x0 = ox * p.stride - p.pad_l;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int y = y0 + i;
+            if (y < 0 || y >= p.H) continue;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int x = x0 + j;
+                if (x >= 0 && x < p.W) acc[i * K + j] = fmaf(g, xp[y * p.W + x], acc[i * K + j]);
+            }
+        }
+    }
+    __shared__ float red[4][K * K];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+        float v = acc[t];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) red[wave][t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < K * K) p.out[(long)c * K * K + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+int check(const DWParams& p, int K, const char* what) {
+    SRBH_REQUIRE(K == 3 || K == 5, "%s: kernel size must be 3 or 5", what);
+    SRBH_REQUIRE(p.stride == 1 || p.stride == 2, "%s: stride must be 1 or 2", what);
+    SRBH_REQUIRE(p.B > 0 && p.C > 0 && p.H > 0 && p.W > 0 && p.OH > 0 && p.OW > 0, "%s: bad shape", what);
+    SRBH_REQUIRE(p.pad_t >= 0 && p.pad_l >= 0 && p.pad_t < K && p.pad_l < K, "%s: bad padding", what);
+    // bottom/right padding implied by the output size must be a zero pad, not a crop
+    SRBH_REQUIRE((p.OH - 1) * p.stride - p.pad_t + K >= p.H - (p.stride - 1) && (p.OW - 1) * p.stride - p.pad_l + K >= p.W - (p.stride - 1),
+                 "%s: output size does not cover the input", what);
+    return SRBH_OK;
+}
+
+int grid_for(long n) {
+    const long b = (n + 255) / 256;
+    return (int)(b < 8192 ? (b > 0 ? b : 1) : 8192);
+}
+}  // namespace
+
+extern "C" int srbh_dwconv_fwd(const float* x, const float* w, float* y, int B, int C, int H, int W, int K, int stride, int pad_t,
+                               int pad_l, int OH, int OW, void* stream) {
+    SRBH_REQUIRE(x && w && y, "srbh_dwconv_fwd: null pointer");
+    DWParams p{x, w, nullptr, y, B, C, H, W, OH, OW, stride, pad_t, pad_l};
+    if (int rc = check(p, K, "srbh_dwconv_fwd")) return rc;
+    const int g = grid_for((long)B * C * OH * OW);
+    if (K == 3)
+        hipLaunchKernelGGL(dw_fwd_kernel<3>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(dw_fwd_kernel<5>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_dwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int C, int H, int W, int K, int stride,
+                                    int pad_t, int pad_l, int OH, int OW, void* stream) {
+    SRBH_REQUIRE(dy && w && dx, "srbh_dwconv_bwd_data: null pointer");
+    DWParams p{nullptr, w, dy, dx, B, C, H, W, OH, OW, stride, pad_t, pad_l};
+    if (int rc = check(p, K, "srbh_dwconv_bwd_data")) return rc;
+    const int g = grid_for((long)B * C * H * W);
+    if (K == 3)
+        hipLaunchKernelGGL(dw_bwd_data_kernel<3>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(dw_bwd_data_kernel<5>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_dwconv_bwd_weight(const float* x, const float* dy, float* dw, int B, int C, int H, int W, int K, int stride,
+                                      int pad_t, int pad_l, int OH, int OW, void* stream) {
+    SRBH_REQUIRE(x && dy && dw, "srbh_dwconv_bwd_weight: null pointer");
+    DWParams p{x, nullptr, dy, dw, B, C, H, W, OH, OW, stride, pad_t, pad_l};
+    if (int rc = check(p, K, "srbh_dwconv_bwd_weight")) return rc;
+    if (K == 3)
+        hipLaunchKernelGGL(dw_bwd_weight_kernel<3>, dim3(C), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(dw_bwd_weight_kernel<5>, dim3(C), dim3(256), 0, (hipStream_t)stream, p);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}

@@ -56,6 +56,45 @@ def _round_repeats(r, depth):
     return int(math.ceil(depth * r))
 
 
+class _DepthwiseConvFn(torch.autograd.Function):
+    """Depthwise KxK conv (K 3|5, stride 1|2) with the static "same" zero padding folded in, on libsrbh (csrc/srbh_dwconv.hip):
+    MIOpen serves these fp32 shapes with its naive kernels.  Device fp32 NCHW tensors only (the CPU path of the encoder
+    stays on stock ops)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        from . import _lib
+        pl, pr, pt, pb = pad
+        x = x.contiguous()
+        weight = weight.contiguous()
+        B, C, H, W = x.shape
+        K = weight.shape[-1]
+        OH, OW = (H + pt + pb - K) // stride + 1, (W + pl + pr - K) // stride + 1
+        y = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().srbh_dwconv_fwd(x.data_ptr(), weight.data_ptr(), y.data_ptr(), B, C, H, W, K, stride, pt, pl, OH, OW,
+                                              _lib.stream_ptr()), "dwconv_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.geo = (B, C, H, W, K, stride, pt, pl, OH, OW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        x, weight = ctx.saved_tensors
+        B, C, H, W, K, stride, pt, pl, OH, OW = ctx.geo
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(_lib.lib().srbh_dwconv_bwd_data(dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), B, C, H, W, K, stride, pt, pl,
+                                                       OH, OW, _lib.stream_ptr()), "dwconv_bwd_data")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            _lib.check(_lib.lib().srbh_dwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, C, H, W, K, stride, pt, pl,
+                                                         OH, OW, _lib.stream_ptr()), "dwconv_bwd_weight")
+        return dx, dw, None, None
+
+
 class SamePadConv2d(nn.Conv2d):
     """Conv2d with TensorFlow "same" padding fixed at construction for a nominal input size (the padding is a
     parameter-free ``static_padding`` sub-module, so state_dict keys are just weight/bias)."""
@@ -68,12 +107,17 @@ class SamePadConv2d(nn.Conv2d):
         oh, ow = math.ceil(ih / sh), math.ceil(iw / sw)
         pad_h = max((oh - 1) * sh + (kh - 1) + 1 - ih, 0)
         pad_w = max((ow - 1) * sw + (kw - 1) + 1 - iw, 0)
+        self._pad = (pad_w // 2, pad_w - pad_w // 2, pad_h // 2, pad_h - pad_h // 2)   # (left, right, top, bottom)
         if pad_h > 0 or pad_w > 0:
-            self.static_padding = nn.ZeroPad2d((pad_w // 2, pad_w - pad_w // 2, pad_h // 2, pad_h - pad_h // 2))
+            self.static_padding = nn.ZeroPad2d(self._pad)
         else:
             self.static_padding = nn.Identity()
+        self._depthwise = (groups == in_ch == out_ch and groups > 1 and kh == kw and kh in (3, 5) and sh == sw and sh in (1, 2)
+                           and not bias)
 
     def forward(self, x):
+        if self._depthwise and x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32:
+            return _DepthwiseConvFn.apply(x, self.weight, self.stride[0], self._pad)
         return F.conv2d(self.static_padding(x), self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
 
 

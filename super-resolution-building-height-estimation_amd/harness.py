@@ -124,7 +124,9 @@ def predict_tiles(net_hr, model, tiles, posall, mosaic, batch=32, rank=0, world=
     """predict_whole_image_grid's inner loop (predict_realesanet_feature_globe.py:167-185) for this rank's shard of a
     city's grid cells: RRDBNet feature extraction -> height / building heads -> quantise + integer mosaic on the
     device.  ``tiles`` (N,8,64,64) fp32, ``posall`` (N,4) LR-cell windows.  Merge shards with ``mosaic.all_reduce_``
-    (or ``merge_``) before ``mosaic.finalize()``; integer sums make the result independent of the sharding."""
+    (or ``merge_``) before ``mosaic.finalize()``; integer sums make the result independent of the sharding.
+    (Producing batch i+1's features on a second stream while batch i's heads run measured no gain: the persistent trunk
+    kernel owns every CU while it runs, the launches simply serialise.)"""
     model.eval()
     net_hr.eval()
     lo, hi = shard_range(tiles.shape[0], rank, world)
@@ -132,7 +134,12 @@ def predict_tiles(net_hr, model, tiles, posall, mosaic, batch=32, rank=0, world=
     for s in range(lo, hi, batch):
         e = min(s + batch, hi)
         x = tiles[s:e].to(dev, non_blocking=True)
+        k = e - s
+        if k < batch:
+            # ragged tail: run a full batch (eval mode: tiles are independent) instead of a new tensor shape, for which the
+            # stock-op encoder would first search / compile kernels (0.5 s per new shape, more than a small city's work)
+            x = torch.cat([x, x.new_zeros((batch - k,) + tuple(x.shape[1:]))], 0)
         hr_fea = net_hr.forward_feature(x[:, :3])
         out = model(x, hr_fea)
-        mosaic.add(out[0], out[1], posall[s:e])
+        mosaic.add(out[0][:k], out[1][:k], posall[s:e])
     return hi - lo

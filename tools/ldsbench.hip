@@ -4,6 +4,21 @@
 #include <cstdio>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+// data patterns: 0 = the original smooth ramp, 1 = pseudo-random fp16 pairs in [-0.5, 0.5) (matrix-core power depends on
+// operand toggling: the real kernels see the second kind)
+__device__ __forceinline__ float pattern(int i, int rnd) {
+    if (!rnd) return (float)(i & 1023) * 1e-3f;
+    unsigned h = (unsigned)i * 2654435761u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    const _Float16 a = (_Float16)(((h & 0xffff) / 65536.f) - 0.5f), b = (_Float16)(((h >> 16) / 65536.f) - 0.5f);
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    const half2_t v = {a, b};
+    return __builtin_bit_cast(float, v);
+}
+__global__ void fill_kernel(float* p, long n, int rnd) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = pattern((int)i, rnd);
+}
+static int g_rnd = 0;
 
 // mode 0: conflict-free linear (lane*16); 1: the pixel-fragment pattern (64-B pixel records, XOR-swizzled k-slot);
 // 2: same without the swizzle; 3: ds_read_b64 x2 of the pixel pattern
@@ -118,10 +133,10 @@ __global__ __launch_bounds__(256, 1) void group_kernel(unsigned long long* out, 
 
 // the same groups arranged as the kernels' K steps: barrier, first group's reads exposed, 6 groups, (no DMA)
 template <int NR, int NM, int ACC, int ND>
-__global__ __launch_bounds__(256, 1) void step_kernel(unsigned long long* out, int iters, float* sink, const char* gsrc, unsigned long long dmask) {
+__global__ __launch_bounds__(256, 1) void step_kernel(unsigned long long* out, int iters, float* sink, const char* gsrc, unsigned long long dmask, int rnd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 160 * 1024 / 4; i += 256) ((float*)smem)[i] = (float)(i & 1023) * 1e-3f;
+    for (int i = tid; i < 160 * 1024 / 4; i += 256) ((float*)smem)[i] = pattern(i, rnd);
     __syncthreads();
     const int l31 = lane & 31, hi = lane >> 5, wr = wave >> 1, wc = wave & 1;
     int off[NR];
@@ -192,7 +207,8 @@ static void run_step(const char* name, unsigned long long dmask) {
     const int iters = 400;
     char* gsrc;
     hipMalloc(&gsrc, 256 * 81920 + (1 << 20));
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((step_kernel<NR, NM, ACC, ND>), dim3(256), dim3(256), 160 * 1024, 0, d, iters, sink, gsrc, dmask);
+    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, (float*)gsrc, (long)(256 * 81920 + (1 << 20)) / 4, g_rnd);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((step_kernel<NR, NM, ACC, ND>), dim3(256), dim3(256), 160 * 1024, 0, d, iters, sink, gsrc, dmask, g_rnd);
     hipDeviceSynchronize();
     unsigned long long h[256];
     hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
@@ -209,11 +225,11 @@ static void run_step(const char* name, unsigned long long dmask) {
 // 8 waves per workgroup (2 per SIMD), each owning 2 rows x 32 pixels: NP = 4 pixel-fragment rows + 3*CB weight fragments
 // feed 6*CB MFMAs per group; same staging volume per step as step_kernel (ND DMA per wave)
 template <int CB, int ND>
-__global__ __launch_bounds__(512, 1) void step8_kernel(unsigned long long* out, int iters, float* sink, const char* gsrc, unsigned long long dmask) {
+__global__ __launch_bounds__(512, 1) void step8_kernel(unsigned long long* out, int iters, float* sink, const char* gsrc, unsigned long long dmask, int rnd) {
     constexpr int NP = 4, NR = NP + 3 * CB, NM = 6 * CB, ACC = 2 * CB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 160 * 1024 / 4; i += 512) ((float*)smem)[i] = (float)(i & 1023) * 1e-3f;
+    for (int i = tid; i < 160 * 1024 / 4; i += 512) ((float*)smem)[i] = pattern(i, rnd);
     __syncthreads();
     const int l31 = lane & 31, hi = lane >> 5, wr = wave >> 1, wc = wave & 1;
     int off[NR];
@@ -286,7 +302,8 @@ static void run_step8(const char* name, unsigned long long dmask) {
     const int iters = 400;
     char* gsrc;
     hipMalloc(&gsrc, 256 * 81920 + (1 << 20));
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((step8_kernel<CB, ND>), dim3(256), dim3(512), 160 * 1024, 0, d, iters, sink, gsrc, dmask);
+    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, (float*)gsrc, (long)(256 * 81920 + (1 << 20)) / 4, g_rnd);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((step8_kernel<CB, ND>), dim3(256), dim3(512), 160 * 1024, 0, d, iters, sink, gsrc, dmask, g_rnd);
     hipDeviceSynchronize();
     unsigned long long h[256];
     hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
@@ -321,16 +338,21 @@ static void run_group(const char* name) {
     hipFree(sink);
 }
 
-int main() {
-    run_step8<1, 1>("8 waves, cout 32 STEP: barrier + 6 groups, ~no DMA", 0ull);
-    run_step8<1, 8>("8 waves, cout 32 STEP + 8 DMA/wave (64 KiB/step)", ~0ull);
-    run_step8<2, 1>("8 waves, cout 64 STEP: barrier + 6 groups, ~no DMA", 0ull);
-    run_step8<2, 10>("8 waves, cout 64 STEP + 10 DMA/wave (80 KiB/step)", ~0ull);
-    run_step<9, 12, 4, 1>("cout 32 STEP: barrier + 6 groups, ~no DMA", 0ull);
-    run_step<9, 12, 4, 16>("cout 32 STEP + 16 DMA slots masked off", 0ull);
-    run_step<9, 12, 4, 16>("cout 32 STEP + 16 DMA (64 KiB/step)", ~0ull);
-    run_step<12, 24, 8, 1>("cout 64 STEP: barrier + 6 groups, ~no DMA", 0ull);
-    run_step<12, 24, 8, 20>("cout 64 STEP + 20 DMA (80 KiB/step)", ~0ull);
+int main(int argc, char** argv) {
+    for (g_rnd = 0; g_rnd < 2; ++g_rnd) {
+        printf("---- operand data: %s\n", g_rnd ? "pseudo-random fp16 in [-0.5, 0.5)" : "smooth ramp");
+        run_step8<1, 1>("8 waves, cout 32 STEP: barrier + 6 groups, ~no DMA", 0ull);
+        run_step8<1, 8>("8 waves, cout 32 STEP + 8 DMA/wave (64 KiB/step)", ~0ull);
+        run_step8<2, 1>("8 waves, cout 64 STEP: barrier + 6 groups, ~no DMA", 0ull);
+        run_step8<2, 10>("8 waves, cout 64 STEP + 10 DMA/wave (80 KiB/step)", ~0ull);
+        run_step<9, 12, 4, 1>("cout 32 STEP: barrier + 6 groups, ~no DMA", 0ull);
+        run_step<9, 12, 4, 16>("cout 32 STEP + 16 DMA slots masked off", 0ull);
+        run_step<9, 12, 4, 16>("cout 32 STEP + 16 DMA (64 KiB/step)", ~0ull);
+        run_step<12, 24, 8, 1>("cout 64 STEP: barrier + 6 groups, ~no DMA", 0ull);
+        run_step<12, 24, 8, 20>("cout 64 STEP + 20 DMA (80 KiB/step)", ~0ull);
+    }
+    g_rnd = 0;
+    if (argc > 1) return 0;
     run_group<9, 12, 4>("cout 32 group: 9 reads + 12 MFMA, 4 acc");
     run_group<12, 24, 8>("cout 64 group: 12 reads + 24 MFMA, 8 acc");
     run_group<7, 6, 2>("variant 2 cout 32: 7 reads + 6 MFMA");
