@@ -241,7 +241,9 @@ int srbh_dwconv_fwd(const float* x, const float* w, float* y, int B, int C, int 
                     int pad_l, int OH, int OW, void* stream);
 int srbh_dwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int C, int H, int W, int K, int stride,
                          int pad_t, int pad_l, int OH, int OW, void* stream);
-int srbh_dwconv_bwd_weight(const float* x, const float* dy, float* dw, int B, int C, int H, int W, int K, int stride,
+/* ws: caller-provided scratch of srbh_dwconv_bwd_weight_splits(B, C) * C * K * K floats (per-batch-slice partial sums) */
+int srbh_dwconv_bwd_weight_splits(int B, int C);
+int srbh_dwconv_bwd_weight(const float* x, const float* dy, float* dw, float* ws, int B, int C, int H, int W, int K, int stride,
                            int pad_t, int pad_l, int OH, int OW, void* stream);
 
 /* ---- inference epilogue: quantise + integer mosaic (predict_realesanet_feature_globe.py:172-204) ------------------

@@ -136,7 +136,8 @@ SIGNATURES = {
     "srbh_ps2_inverse": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_dwconv_fwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "srbh_dwconv_bwd_data": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
-    "srbh_dwconv_bwd_weight": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
+    "srbh_dwconv_bwd_weight_splits": (_i, [_i, _i]),
+    "srbh_dwconv_bwd_weight": (_i, [_vp, _vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "srbh_mosaic_accumulate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "srbh_mosaic_finalize": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "srbh_label_prep": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

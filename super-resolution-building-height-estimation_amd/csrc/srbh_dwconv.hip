@@ -78,19 +78,22 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const DWParams p) {
     }
 }
 
-// dw[c][i][j] = sum over (b, oy, ox) of dy[b][c][oy][ox] * x[b][c][oy*s - pad_t + i][ox*s - pad_l + j]: one workgroup per
-// channel, a fixed summation tree (thread-strided partial sums -> wave shuffles -> LDS across the 4 waves): deterministic
+// dw[c][i][j] = sum over (b, oy, ox) of dy[b][c][oy][ox] * x[b][c][oy*s - pad_t + i][ox*s - pad_l + j]: workgroup (c, s)
+// sums the images of batch slice s in a fixed tree (thread-strided partial sums -> wave shuffles -> LDS across the 4
+// waves) into ws[s][c][..]; dw_reduce_kernel adds the slices in order: deterministic, and >= ~1000 workgroups even for the
+// 144-channel layers
 template <int K>
-__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const DWParams p) {
-    const int c = blockIdx.x;
+__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const DWParams p, float* __restrict__ ws, int splits) {
+    const int c = blockIdx.x, sp = blockIdx.y;
     const int per_img = p.OH * p.OW;
-    const long n = (long)p.B * per_img;
+    const int b0 = (int)((long)p.B * sp / splits), b1 = (int)((long)p.B * (sp + 1) / splits);
+    const long n = (long)(b1 - b0) * per_img;
     float acc[K * K];
 #pragma unroll
     for (int t = 0; t < K * K; ++t) acc[t] = 0.f;
     for (long e = threadIdx.x; e < n; e += 256) {
-        const int b = e / per_img;
-        const int q = e - (long)b * per_img;
+        const int b = b0 + (int)(e / per_img);
+        const int q = (int)(e % per_img);
         const int oy = q / p.OW, ox = q - oy * p.OW;
         const float g = p.dy[((long)b * p.C + c) * per_img + q];
         const float* xp = p.x + ((long)b * p.C + c) * p.H * p.W;
@@ -116,7 +119,16 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const DWParams p) {
         if (lane == 0) red[wave][t] = v;
     }
     __syncthreads();
-    if (threadIdx.x < K * K) p.out[(long)c * K * K + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x < K * K)
+        ws[((long)sp * p.C + c) * K * K + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void dw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int n, int splits) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += ws[(long)s * n + i];
+    dw[i] = v;
 }
 
 int check(const DWParams& p, int K, const char* what) {
@@ -164,15 +176,25 @@ extern "C" int srbh_dwconv_bwd_data(const float* dy, const float* w, float* dx, 
     return SRBH_OK;
 }
 
-extern "C" int srbh_dwconv_bwd_weight(const float* x, const float* dy, float* dw, int B, int C, int H, int W, int K, int stride,
-                                      int pad_t, int pad_l, int OH, int OW, void* stream) {
-    SRBH_REQUIRE(x && dy && dw, "srbh_dwconv_bwd_weight: null pointer");
+extern "C" int srbh_dwconv_bwd_weight_splits(int B, int C) {
+    int s = (1024 + C - 1) / (C > 0 ? C : 1);
+    if (s > B) s = B;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" int srbh_dwconv_bwd_weight(const float* x, const float* dy, float* dw, float* ws, int B, int C, int H, int W, int K,
+                                      int stride, int pad_t, int pad_l, int OH, int OW, void* stream) {
+    SRBH_REQUIRE(x && dy && dw && ws, "srbh_dwconv_bwd_weight: null pointer");
     DWParams p{x, nullptr, dy, dw, B, C, H, W, OH, OW, stride, pad_t, pad_l};
     if (int rc = check(p, K, "srbh_dwconv_bwd_weight")) return rc;
+    const int splits = srbh_dwconv_bwd_weight_splits(B, C);
     if (K == 3)
-        hipLaunchKernelGGL(dw_bwd_weight_kernel<3>, dim3(C), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(dw_bwd_weight_kernel<3>, dim3(C, splits), dim3(256), 0, (hipStream_t)stream, p, ws, splits);
     else
-        hipLaunchKernelGGL(dw_bwd_weight_kernel<5>, dim3(C), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(dw_bwd_weight_kernel<5>, dim3(C, splits), dim3(256), 0, (hipStream_t)stream, p, ws, splits);
+    SRBH_HIP(hipGetLastError());
+    const int n = C * K * K;
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, dw, n, splits);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }

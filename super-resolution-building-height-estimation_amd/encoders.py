@@ -90,8 +90,9 @@ class _DepthwiseConvFn(torch.autograd.Function):
                                                        OH, OW, _lib.stream_ptr()), "dwconv_bwd_data")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
-            _lib.check(_lib.lib().srbh_dwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, C, H, W, K, stride, pt, pl,
-                                                         OH, OW, _lib.stream_ptr()), "dwconv_bwd_weight")
+            ws = torch.empty(_lib.lib().srbh_dwconv_bwd_weight_splits(B, C) * C * K * K, dtype=torch.float32, device=x.device)
+            _lib.check(_lib.lib().srbh_dwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, C, H, W, K,
+                                                         stride, pt, pl, OH, OW, _lib.stream_ptr()), "dwconv_bwd_weight")
         return dx, dw, None, None
 
 
