@@ -246,6 +246,11 @@ int srbh_dwconv_bwd_weight_splits(int B, int C);
 int srbh_dwconv_bwd_weight(const float* x, const float* dy, float* dw, float* ws, int B, int C, int H, int W, int K, int stride,
                            int pad_t, int pad_l, int OH, int OW, void* stream);
 
+/* inference BatchNorm folded to a per-channel affine (srbh_bn_eval_scale_shift) + activation on NCHW fp32:
+ * y = act(x * scale[c] + shift[c]), act 0 none | 1 SiLU | 2 ReLU; y may alias x. */
+int srbh_affine_act_nchw(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW, int act,
+                         void* stream);
+
 /* ---- inference epilogue: quantise + integer mosaic (predict_realesanet_feature_globe.py:172-204) ------------------
  * accumulate: height [B][th][tw] fp32 (model output, C=1), build logits NHWC [B][th][tw][C] fp32, pos [B][4] int32
  *   = (xoff, yoff, xcount, ycount) already multiplied by 4 (predict...py:182); adds round(max(h,0)*10) and

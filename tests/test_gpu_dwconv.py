@@ -60,3 +60,36 @@ def test_bad_arguments_are_errors():
     assert rc != 0
     with pytest.raises(RuntimeError):
         _lib.check(rc, "dwconv_fwd")
+
+
+def test_fused_inference_batchnorm_agrees_with_the_stock_path():
+    """encoder + U-Net decoder in eval mode: BatchNorm(+SiLU/ReLU) as one libsrbh affine pass vs MIOpen's inference BN"""
+    from srbh_amd import encoders
+    torch.manual_seed(5)
+    enc = encoders.get_encoder("efficientnet-b4", in_channels=8, depth=5, weights=None).to(DEV)
+    dec = encoders.UnetDecoder(enc.out_channels, (256, 128, 64, 32, 16), n_blocks=5, use_batchnorm=True, center=False,
+                               attention_type=None).to(DEV)
+    x = torch.rand((4, 8, 64, 64), device=DEV)
+    enc.train(); dec.train()
+    with torch.no_grad():
+        for _ in range(2):
+            dec(*enc(x))          # non-trivial running statistics
+    enc.eval(); dec.eval()
+    with torch.no_grad():
+        a = dec(*enc(x))
+        encoders.FUSED_BN_EVAL = False
+        try:
+            b = dec(*enc(x))
+        finally:
+            encoders.FUSED_BN_EVAL = True
+    assert rel(a, b) <= 1e-5
+    # a parameter update invalidates the cached affine
+    with torch.no_grad():
+        enc._bn0.weight.mul_(1.5)
+        a2 = enc(x)[1]
+        encoders.FUSED_BN_EVAL = False
+        try:
+            b2 = enc(x)[1]
+        finally:
+            encoders.FUSED_BN_EVAL = True
+    assert rel(a2, b2) <= 1e-5
