@@ -160,16 +160,30 @@ __global__ __launch_bounds__(256) void hwgrad_f32_kernel(const WGParams p) {
             }
             }
             __syncthreads();
-#pragma unroll 2
-            for (int ks = 0; ks < 32; ++ks) {                     // 2 rows x 16 groups of 4 pixels per wave
+            // 2 rows x 16 groups of 4 pixels per wave; the operands of k-step ks+1 are read while the MFMAs of ks run
+            float a_cur, b_cur[TAPS];
+            auto fetch = [&](const int ks, float& a, float (&b)[TAPS]) {
                 const int row = wave * 2 + (ks >> 4), col = (ks & 15) * 4 + kk;
-                const float a = s_dy[(row * 64 + col) * 16 + l15];          // A[oc = l15][k = kk]
+                a = s_dy[(row * 64 + col) * 16 + l15];                     // A[oc = l15][k = kk]
+                // one base address per k-step, the taps are immediate offsets of the LDS reads (left to the compiler, every
+                // tap's address was rebuilt with 3 VALU instructions: 25 per 9 MFMAs)
+                const float* bp = s_x + (row * COLS + col) * 16 + l15;
 #pragma unroll
                 for (int tp = 0; tp < TAPS; ++tp) {
                     const int dy = tp / KS, dx = tp - dy * KS;
-                    const float b = s_x[((row + dy) * COLS + col + dx) * 16 + l15];   // B[k = kk][ci = l15]
-                    acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[tp], 0, 0, 0);
+                    b[tp] = bp[(dy * COLS + dx) * 16];                     // B[k = kk][ci = l15]
                 }
+            };
+            fetch(0, a_cur, b_cur);
+#pragma unroll 2
+            for (int ks = 0; ks < 32; ++ks) {
+                float a_nxt, b_nxt[TAPS];
+                fetch(ks + 1 < 32 ? ks + 1 : ks, a_nxt, b_nxt);
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp) acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur[tp], acc[tp], 0, 0, 0);
+                a_cur = a_nxt;
+#pragma unroll
+                for (int tp = 0; tp < TAPS; ++tp) b_cur[tp] = b_nxt[tp];
             }
         }
         // flush: D[row = oc = kk*4 + r][col = ci = l15]
