@@ -412,9 +412,17 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
         step(0);
         if (defer_flags) ensure_flags(L);   // (once per layer, outside the chunk loop: see the note on control flow above)
         if (aborted) return;
+        unsigned long long t_dma = 0;   // PROF: cycles wave 0 waits for its own LDS-DMA / at the barrier, summed over the steps
         for (int c = 1; c < n; ++c) {
+            unsigned long long w0 = 0, w1 = 0;
+            if (PROF) w0 = __builtin_amdgcn_s_memtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of step gs has landed ...
+            if (PROF) w1 = __builtin_amdgcn_s_memtime();
             __syncthreads();                                   // ... and everybody else's; all waves are past step gs-1
+            if (PROF) {
+                t_dma += w1 - w0;
+                tb += __builtin_amdgcn_s_memtime() - w1;
+            }
             step(c);
         }
         if (PROF) ts1 = __builtin_amdgcn_s_memtime();
@@ -604,6 +612,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
             unsigned long long* q = pp.prof + ((long)blockIdx.x * pp.nlayers + L) * 6;
             q[0] = ts0; q[1] = ts1; q[2] = ts2; q[3] = tw | ((unsigned long long)(__builtin_amdgcn_s_memtime() - ts2) << 32);
             q[4] = tb;
+            q[5] = t_dma;
         }
     };
 
@@ -1230,7 +1239,7 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
         double cyc = 0;
         for (int b = 0; b < nblk; ++b) cyc += (double)(h[((size_t)b * nl + nl - 1) * 6 + 2] - h[(size_t)b * nl * 6]);
         fprintf(stderr, "[srbh] ptrunk: avg %.0f shader cycles per workgroup (first layer start -> last epilogue)\n", cyc / nblk);
-        double loop[5] = {0}, epi[5] = {0}, pub[5] = {0}, wait[5] = {0}, tot5[5] = {0};
+        double loop[5] = {0}, epi[5] = {0}, pub[5] = {0}, wait[5] = {0}, tot5[5] = {0}, dma[5] = {0}, bar[5] = {0};
         for (int b = 0; b < nblk; ++b)
             for (int L = 1; L + 1 < nl; ++L) {
                 const unsigned long long* q = &h[((size_t)b * nl + L) * 6];
@@ -1238,11 +1247,13 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
                 const int k = L % 5;
                 loop[k] += (double)(q[1] - q[0]); epi[k] += (double)(q[2] - q[1]); pub[k] += (double)(q[3] >> 32);
                 wait[k] += (double)(q[3] & 0xffffffffu); tot5[k] += (double)(qn[0] - q[0]);
+                bar[k] += (double)q[4]; dma[k] += (double)q[5];
             }
         const double cnt = (double)nblk * (nl - 2) / 5.0;
         for (int k = 0; k < 5; ++k)
-            fprintf(stderr, "[srbh]   conv%d: loop %.0f (flag-wait %.0f) | epilogue %.0f | publish/seam %.0f | start-to-start %.0f\n",
-                    k + 1, loop[k] / cnt, wait[k] / cnt, epi[k] / cnt, pub[k] / cnt, tot5[k] / cnt);
+            fprintf(stderr, "[srbh]   conv%d: loop %.0f (of which: waiting for the own LDS-DMA %.0f, at the step barriers %.0f; prologue %.0f) | "
+                    "epilogue %.0f | publish/seam %.0f | start-to-start %.0f\n",
+                    k + 1, loop[k] / cnt, dma[k] / cnt, bar[k] / cnt, wait[k] / cnt, epi[k] / cnt, pub[k] / cnt, tot5[k] / cnt);
     }
     *used = 1;
     return SRBH_OK;
