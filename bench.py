@@ -146,6 +146,10 @@ def bench_predict(args, rank, world, dev, dist):
     model = SRRegress_Cls_feature("efficientnet-b4", in_channels=8, super_in=64, super_mid=16, upscale=4, isaggre=False,
                                   chans_build=7).to(dev).eval()
     counts = np.exp(np.random.default_rng(2024).uniform(np.log(200.0), np.log(20000.0), 301)).astype(int)
+    # MIOpen solver search for the stock-op encoder / decoders: without it a few forward convolutions run on MIOpen's naive
+    # kernels (immediate-mode fallback).  One-time cost in the warm-up cities; every batch has the same shape.  (Not used
+    # for the training workload: the backward searches take minutes.)
+    torch.backends.cudnn.benchmark = os.environ.get("SRBH_MIOPEN_FIND", "1") == "1"
     batch = args.batch if args.batch != 32 else 128     # 288 GB of HBM: larger batches amortise the stock-op encoder's small launches
     n_warm = min(args.warmup, 2)
     todo = [int(c) for c in counts[:args.steps]]
