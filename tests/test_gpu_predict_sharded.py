@@ -1,0 +1,84 @@
+"""GPU: the N>1 form of the tiled-inference path (BASELINE config 5) -- two processes share the one GPU of the
+test box (gloo carries the collective): each runs harness.predict_tiles on its shard of a city's grid cells (ragged tail
+batches included), the integer mosaics are summed with Mosaic.all_reduce_ and finalised.  The result must be
+BIT-IDENTICAL to the single-process result (integer sums commute)."""
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _city(n, gw):
+    g = torch.Generator().manual_seed(11)
+    tiles = torch.randn((n, 8, 64, 64), generator=g) * 0.25 + 0.35
+    pos = [[(i % gw) * 48, (i // gw) * 48, 64, 64] for i in range(n)]
+    gh = (n + gw - 1) // gw
+    return tiles, pos, (gh * 48 + 16) * 4, (gw * 48 + 16) * 4
+
+
+def _nets():
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import synth
+    from srbh_amd.models import SRRegress_Cls_feature
+    from srbh_amd.rrdbnet import RRDBNet
+    net_hr = RRDBNet(3, 3, num_block=1)
+    net_hr.load_state_dict(synth.rrdbnet_state_dict(num_block=1, seed=5, mode="init"))
+    torch.manual_seed(9)
+    model = SRRegress_Cls_feature("efficientnet-b4", in_channels=8, super_in=64, super_mid=16, upscale=4, isaggre=False,
+                                  chans_build=7)
+    return net_hr.cuda().eval(), model.cuda().eval()
+
+
+def _run(rank, world, dist):
+    from srbh_amd.harness import predict_tiles
+    from srbh_amd.mosaic import Mosaic
+    tiles, pos, H, W = _city(13, 4)
+    net_hr, model = _nets()
+    m = Mosaic(H, W, 7, "cuda:0")
+    n = predict_tiles(net_hr, model, tiles.cuda(), pos, m, batch=4, rank=rank, world=world)
+    if dist is not None:
+        m.all_reduce_(dist)
+    h, b = m.finalize()
+    return n, h.cpu().to(torch.int32), b.cpu()
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    n, h, b = _run(rank, world, dist)
+    if rank == 0:
+        n1, h1, b1 = _run(0, 1, None)
+        q.put({"n": n, "n1": n1, "h": h.numpy(), "b": b.numpy(), "h1": h1.numpy(), "b1": b1.numpy()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_city_is_bit_identical_to_one_rank():
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res["n"] == 7 and res["n1"] == 13          # balanced shard of 13 cells; ragged tails on both sides
+    assert np.array_equal(res["h"], res["h1"])
+    assert np.array_equal(res["b"], res["b1"])
+    assert res["b1"].max() <= 6 and (res["h1"].any() or np.unique(res["b1"]).size > 1)   # (not a trivially empty mosaic)
