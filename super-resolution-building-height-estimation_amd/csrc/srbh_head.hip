@@ -15,6 +15,7 @@
 //  * bn_finalize_kernel : partial sums -> batch mean/var -> scale/shift (+ running-stat update, momentum 0.1).
 //  * bn_add_relu_kernel : out = relu(bn2(c2) + identity) (SR/HRfuse.py:150-157), identity optionally BN'd (downsample).
 //  * aggregate_kernel   : aggregate_torch (aggregate_utils.py:29-41).
+#include <stdlib.h>
 #include "srbh_internal.h"
 
 namespace {
@@ -22,16 +23,18 @@ using namespace srbh;
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-constexpr int HT_H = 8, HT_W = 64;          // output tile of one workgroup
+constexpr int HT_W = 64;                    // output tile of one workgroup: (4 * RPW) rows x 64 columns, RPW rows per wave
 constexpr int HC = 16;                      // input channels per LDS chunk
-constexpr int PL = 704;                     // dwords per channel plane (multiple of 32; >= 10*66 + 24 stagger slack)
+// dwords per channel plane (multiple of 32; >= rows*66 + 24 stagger slack): 10 rows (RPW 2) / 6 rows (RPW 1)
+constexpr int plane_dw(int rpw) { return rpw == 2 ? 704 : 448; }
 constexpr int RS = 66;                      // row stride inside a plane (3x3: 64 + 2 halo)
 constexpr int NSLOT = 64;                   // stat partial slots (spreads atomic contention)
 
+template <int RPW>
 __device__ __forceinline__ int plane_base(int q) {   // bank staggering, see DESIGN.md "head conv LDS layout"
-    return q * PL + (q & 1) * 16 + (q >> 2) * 8;
+    return q * plane_dw(RPW) + (q & 1) * 16 + (q >> 2) * 8;
 }
-constexpr int IN_DW = 16 * PL + 64;
+constexpr int in_dw(int rpw) { return 16 * plane_dw(rpw) + 64; }
 
 struct HParams {
     const float* src0; const float* src1;
@@ -52,9 +55,12 @@ struct HParams {
     const float* post_scale; const float* post_shift; int post_relu;
 };
 
-// NOB = cout/16 (1 or 4), KS = 3 or 1
-template <int NOB, int KS>
+// NOB = cout/16 (1, 2 or 4), KS = 3 or 1, RPW = output rows per wave (2: 8-row tiles, 54 KiB of LDS, 2 workgroups per CU;
+// 1: 4-row tiles, 38 KiB, ~half the registers -> 4 workgroups per CU: more tiles in flight to hide the staging latency
+// of a one-tile-per-workgroup kernel, for 20 % more halo reads)
+template <int NOB, int KS, int RPW>
 __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
+    constexpr int HT_H = 4 * RPW, IN_DW = in_dw(RPW), NI = 4 * RPW;
     extern __shared__ __attribute__((aligned(16))) float hsm[];
     constexpr int TAPS = KS * KS;
     constexpr int HALO = KS / 2;
@@ -75,11 +81,11 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
     const bool vec0 = (p.c0 & 3) == 0 && (p.ld0 & 3) == 0,
                vec1 = p.c1 > 0 && (p.c1 & 3) == 0 && (p.c0 & 3) == 0 && (p.ld1 & 3) == 0;
 
-    floatx4 acc[NOB][8];
+    floatx4 acc[NOB][NI];
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[ob][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NI; ++i) acc[ob][i] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     for (int c = 0; c < nchunk; ++c) {
         __syncthreads();
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                 if (where[it] >= 0) {
                     const int cg = where[it] >> 16, off = where[it] & 0xffff;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) s_in[plane_base(cg * 4 + j) + off] = ld[it][j];
+                    for (int j = 0; j < 4; ++j) s_in[plane_base<RPW>(cg * 4 + j) + off] = ld[it][j];
                 }
             }
         } else
@@ -160,13 +166,13 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s_in[plane_base(cg * 4 + j) + r * RS + col] = v[j];
+            for (int j = 0; j < 4; ++j) s_in[plane_base<RPW>(cg * 4 + j) + r * RS + col] = v[j];
         }
         // ---- weights of this chunk (already in A-fragment order)
         for (int u = tid; u < W_DW / 4; u += 256)
             ((floatx4*)s_w)[u] = ((const floatx4*)(p.w + (long)c * W_DW))[u];
         __syncthreads();
-        // ---- MFMA: wave owns rows 2*wave, 2*wave+1; 4 column tiles of 16 px each
+        // ---- MFMA: wave owns RPW rows; 4 column tiles of 16 px each
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int dy = tap / KS, dx = tap - dy * KS;
@@ -175,9 +181,9 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                 float a[NOB];
 #pragma unroll
                 for (int ob = 0; ob < NOB; ++ob) a[ob] = s_w[((tap * 4 + s) * NOB + ob) * 64 + lane];
-                const float* bp = s_in + plane_base(s * 4 + kk) + (wave * 2 + dy) * RS + dx + l15;
+                const float* bp = s_in + plane_base<RPW>(s * 4 + kk) + (wave * RPW + dy) * RS + dx + l15;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < NI; ++i) {
                     const float b = bp[(i >> 2) * RS + (i & 3) * 16];
 #pragma unroll
                     for (int ob = 0; ob < NOB; ++ob)
@@ -194,8 +200,8 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) ssum[ob][q] = ssq[ob][q] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int Y = Y0 + wave * 2 + (i >> 2), X = X0 + (i & 3) * 16 + l15;
+    for (int i = 0; i < NI; ++i) {
+        const int Y = Y0 + wave * RPW + (i >> 2), X = X0 + (i & 3) * 16 + l15;
         const bool ok = Y < p.H && X < p.W;
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
@@ -397,20 +403,33 @@ __global__ void nearest2x_kernel(const floatx4* __restrict__ src, floatx4* __res
     dst[idx] = src[(((long)b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * C4 + c];
 }
 
-template <int NOB, int KS>
-int launch_hconv(const HParams& p, int nblocks, hipStream_t st) {
-    constexpr int LDS_B = (IN_DW + KS * KS * 4 * NOB * 64) * 4;
+template <int NOB, int KS, int RPW>
+int launch_hconv(HParams& p, int B, int H, int W, hipStream_t st) {
+    constexpr int LDS_B = (in_dw(RPW) + KS * KS * 4 * NOB * 64) * 4;
+    p.tiles_x = (W + HT_W - 1) / HT_W;
+    p.tiles_per_img = p.tiles_x * ((H + 4 * RPW - 1) / (4 * RPW));
+    const int nblocks = p.tiles_per_img * B;
     if (LDS_B > 65536) {
         static bool set = false;
         if (!set) {
-            SRBH_HIP(hipFuncSetAttribute((const void*)hconv_f32_kernel<NOB, KS>,
+            SRBH_HIP(hipFuncSetAttribute((const void*)hconv_f32_kernel<NOB, KS, RPW>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
             set = true;
         }
     }
-    hipLaunchKernelGGL((hconv_f32_kernel<NOB, KS>), dim3(nblocks), dim3(256), LDS_B, st, p);
+    hipLaunchKernelGGL((hconv_f32_kernel<NOB, KS, RPW>), dim3(nblocks), dim3(256), LDS_B, st, p);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
+}
+
+// tile height: 4-row tiles (RPW 1) by default; SRBH_HCONV_RPW=2 selects the 8-row tiles (A/B aid)
+int hconv_rpw_small() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SRBH_HCONV_RPW");
+        v = (e && atoi(e) == 2) ? 2 : 1;
+    }
+    return v;
 }
 
 }  // namespace
@@ -461,16 +480,21 @@ extern "C" int srbh_hconv_f32(const srbh_hconv_args* a, void* stream) {
     SRBH_REQUIRE(!a->res2 || a->res1, "srbh_hconv_f32: res2 requires res1");
     p.B = a->B; p.H = a->H; p.W = a->W; p.ps2 = a->pixelshuffle2;
     p.out = a->out; p.stats = a->stats;
-    p.tiles_x = (a->W + HT_W - 1) / HT_W;
-    p.tiles_per_img = p.tiles_x * ((a->H + HT_H - 1) / HT_H);
-    const int nblocks = p.tiles_per_img * a->B;
     hipStream_t st = (hipStream_t)stream;
     if (a->stats) SRBH_HIP(hipMemsetAsync(a->stats, 0, srbh_bn_stats_bytes(p.cout), st));
+    const int B = a->B, H = a->H, W = a->W;
+    if (hconv_rpw_small() == 1) {
+        if (a->ksize == 3)
+            return nob == 1 ? launch_hconv<1, 3, 1>(p, B, H, W, st)
+                            : (nob == 2 ? launch_hconv<2, 3, 1>(p, B, H, W, st) : launch_hconv<4, 3, 1>(p, B, H, W, st));
+        return nob == 1 ? launch_hconv<1, 1, 1>(p, B, H, W, st)
+                        : (nob == 2 ? launch_hconv<2, 1, 1>(p, B, H, W, st) : launch_hconv<4, 1, 1>(p, B, H, W, st));
+    }
     if (a->ksize == 3)
-        return nob == 1 ? launch_hconv<1, 3>(p, nblocks, st)
-                        : (nob == 2 ? launch_hconv<2, 3>(p, nblocks, st) : launch_hconv<4, 3>(p, nblocks, st));
-    return nob == 1 ? launch_hconv<1, 1>(p, nblocks, st)
-                    : (nob == 2 ? launch_hconv<2, 1>(p, nblocks, st) : launch_hconv<4, 1>(p, nblocks, st));
+        return nob == 1 ? launch_hconv<1, 3, 2>(p, B, H, W, st)
+                        : (nob == 2 ? launch_hconv<2, 3, 2>(p, B, H, W, st) : launch_hconv<4, 3, 2>(p, B, H, W, st));
+    return nob == 1 ? launch_hconv<1, 1, 2>(p, B, H, W, st)
+                    : (nob == 2 ? launch_hconv<2, 1, 2>(p, B, H, W, st) : launch_hconv<4, 1, 2>(p, B, H, W, st));
 }
 
 extern "C" int srbh_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta,
