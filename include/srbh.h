@@ -251,6 +251,15 @@ int srbh_dwconv_bwd_weight(const float* x, const float* dy, float* dw, float* ws
 int srbh_affine_act_nchw(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW, int act,
                          void* stream);
 
+/* squeeze-and-excitation of an MBConv block at inference (efficientnet_pytorch MBConvBlock.forward, called through
+ * mymodels.py:242-248): (1) affine + activation as above, also writing the per-plane mean pooled [B][C];
+ * (2) hidden [B][SQ] = swish(b1 + w1 [SQ][C] . pooled); (3) y[plane (b,c)] *= sigmoid(b2[c] + w2 [C][SQ] . hidden[b]), in place. */
+int srbh_affine_act_pool_nchw(const float* x, const float* scale, const float* shift, float* y, float* pooled, int B, int C,
+                              int HW, int act, void* stream);
+int srbh_se_hidden(const float* pooled, const float* w1, const float* b1, float* hidden, int B, int C, int SQ, void* stream);
+int srbh_se_gate_scale(float* y, const float* hidden, const float* w2, const float* b2, int B, int C, int SQ, int HW,
+                       void* stream);
+
 /* ---- inference epilogue: quantise + integer mosaic (predict_realesanet_feature_globe.py:172-204) ------------------
  * accumulate: height [B][th][tw] fp32 (model output, C=1), build logits NHWC [B][th][tw][C] fp32, pos [B][4] int32
  *   = (xoff, yoff, xcount, ycount) already multiplied by 4 (predict...py:182); adds round(max(h,0)*10) and

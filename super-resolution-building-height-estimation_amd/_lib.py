@@ -135,6 +135,9 @@ SIGNATURES = {
     "srbh_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp]),
     "srbh_ps2_inverse": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_affine_act_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "srbh_affine_act_pool_nchw": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "srbh_se_hidden": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "srbh_se_gate_scale": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_dwconv_fwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "srbh_dwconv_bwd_data": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "srbh_dwconv_bwd_weight_splits": (_i, [_i, _i]),

@@ -169,6 +169,80 @@ __global__ __launch_bounds__(256) void affine_act_nchw_kernel(const float* __res
     }
 }
 
+// ---- squeeze-and-excitation of an MBConv block at inference (efficientnet_pytorch MBConvBlock.forward: avg-pool -> 1x1
+// reduce -> swish -> 1x1 expand -> sigmoid -> scale), three launches instead of ~11 stock-op ones per block:
+//  (1) inference BatchNorm + SiLU of the depthwise output WITH the per-plane mean (one wave per (b, c) plane, <= 1024 px)
+__global__ __launch_bounds__(256) void affine_act_pool_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, float* __restrict__ y,
+                                                             float* __restrict__ pooled, long planes, int C, int hw, int act) {
+    const int lane = threadIdx.x & 63;
+    const long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pl >= planes) return;
+    const int c = (int)(pl % C);
+    const float s = scale[c], h = shift[c];
+    const float* xp = x + pl * hw;
+    float* yp = y + pl * hw;
+    float sum = 0.f;
+    for (int i = lane; i < hw; i += 64) {
+        float u = fmaf(xp[i], s, h);
+        if (act == 1) u = u / (1.f + __expf(-u));
+        else if (act == 2) u = fmaxf(u, 0.f);
+        yp[i] = u;
+        sum += u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+    if (lane == 0) pooled[pl] = sum / (float)hw;
+}
+
+//  (2) hidden[b][j] = swish(b1[j] + sum_c w1[j][c] * pooled[b][c]): one WAVE per (b, j) dot product (grid = B x SQ/4
+//      workgroups: a per-b workgroup looping over j ran 63 us -- a serial chain of dependent global loads)
+__global__ __launch_bounds__(256) void se_hidden_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, float* __restrict__ hidden, int C, int SQ) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (j >= SQ) return;
+    const float* wr = w1 + (long)j * C;
+    const float* pr = pooled + (long)b * C;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int c = lane;
+    for (; c + 192 < C; c += 256) {
+        a0 = fmaf(wr[c], pr[c], a0);
+        a1 = fmaf(wr[c + 64], pr[c + 64], a1);
+        a2 = fmaf(wr[c + 128], pr[c + 128], a2);
+        a3 = fmaf(wr[c + 192], pr[c + 192], a3);
+    }
+    for (; c < C; c += 64) a0 = fmaf(wr[c], pr[c], a0);
+    float acc = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) {
+        const float u = acc + b1[j];
+        hidden[(long)b * SQ + j] = u / (1.f + __expf(-u));
+    }
+}
+
+//  (3) y[plane] *= sigmoid(b2[c] + sum_j w2[c][j] * hidden[b][j]): one wave per (b, c) plane computes its own gate (row c of
+//      the expand weight is read coalesced by the wave) and scales the plane in place
+__global__ __launch_bounds__(256) void se_gate_scale_kernel(float* __restrict__ y, const float* __restrict__ hidden,
+                                                           const float* __restrict__ w2, const float* __restrict__ b2, long planes,
+                                                           int C, int SQ, int hw) {
+    const int lane = threadIdx.x & 63;
+    const long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pl >= planes) return;
+    const int c = (int)(pl % C);
+    const long b = pl / C;
+    const float* wr = w2 + (long)c * SQ;
+    const float* hr = hidden + b * SQ;
+    float acc = 0.f;
+    for (int j = lane; j < SQ; j += 64) acc = fmaf(wr[j], hr[j], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    const float g = 1.f / (1.f + __expf(-(acc + b2[c])));
+    float* yp = y + pl * hw;
+    for (int i = lane; i < hw; i += 64) yp[i] *= g;
+}
+
 int check(const DWParams& p, int K, const char* what) {
     SRBH_REQUIRE(K == 3 || K == 5, "%s: kernel size must be 3 or 5", what);
     SRBH_REQUIRE(p.stride == 1 || p.stride == 2, "%s: stride must be 1 or 2", what);
@@ -248,6 +322,37 @@ extern "C" int srbh_affine_act_nchw(const float* x, const float* scale, const fl
         hipLaunchKernelGGL(affine_act_nchw_kernel<4>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, planes, C, HW, act);
     else
         hipLaunchKernelGGL(affine_act_nchw_kernel<1>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, planes, C, HW, act);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_affine_act_pool_nchw(const float* x, const float* scale, const float* shift, float* y, float* pooled, int B, int C,
+                                         int HW, int act, void* stream) {
+    SRBH_REQUIRE(x && scale && shift && y && pooled, "srbh_affine_act_pool_nchw: null pointer");
+    SRBH_REQUIRE(B > 0 && C > 0 && HW > 0 && act >= 0 && act <= 2, "srbh_affine_act_pool_nchw: bad arguments");
+    const long planes = (long)B * C;
+    hipLaunchKernelGGL(affine_act_pool_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y,
+                       pooled, planes, C, HW, act);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_se_hidden(const float* pooled, const float* w1, const float* b1, float* hidden, int B, int C, int SQ,
+                              void* stream) {
+    SRBH_REQUIRE(pooled && w1 && b1 && hidden, "srbh_se_hidden: null pointer");
+    SRBH_REQUIRE(B > 0 && C > 0 && SQ > 0 && SQ <= 65535 * 4, "srbh_se_hidden: bad shape");
+    hipLaunchKernelGGL(se_hidden_kernel, dim3(B, (SQ + 3) / 4), dim3(256), 0, (hipStream_t)stream, pooled, w1, b1, hidden, C, SQ);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_se_gate_scale(float* y, const float* hidden, const float* w2, const float* b2, int B, int C, int SQ, int HW,
+                                  void* stream) {
+    SRBH_REQUIRE(y && hidden && w2 && b2, "srbh_se_gate_scale: null pointer");
+    SRBH_REQUIRE(B > 0 && C > 0 && SQ > 0 && HW > 0, "srbh_se_gate_scale: bad shape");
+    const long planes = (long)B * C;
+    hipLaunchKernelGGL(se_gate_scale_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y, hidden, w2, b2,
+                       planes, C, SQ, HW);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }

@@ -97,6 +97,7 @@ class _DepthwiseConvFn(torch.autograd.Function):
 
 
 _ACT = {None: 0, "silu": 1, "relu": 2}
+FUSED_SE_EVAL = True       # squeeze-and-excitation of the MBConv blocks as three libsrbh launches at inference
 FUSED_BN_EVAL = True      # tests switch it off to compare with the stock inference-BatchNorm path
 
 
@@ -104,24 +105,13 @@ def bn_act(bn, x, act=None):
     """BatchNorm2d followed by an activation.  Inference on the device: ONE libsrbh pass y = act(x * scale + shift) with the
     running statistics folded into (scale, shift) (csrc/srbh_dwconv.hip) -- MIOpen's inference-BatchNorm kernel costs
     ~39 us per call whatever the size, 8.6 % of the tiled-inference path.  Training / CPU: the stock ops."""
-    if (FUSED_BN_EVAL and (not bn.training) and x.is_cuda and x.dtype == torch.float32 and bn.track_running_stats
-            and not torch.is_grad_enabled()):
+    if _fused_eval_ok(bn, x):
         from . import _lib
-        C = bn.num_features
-        key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.data_ptr())
-        cache = bn.__dict__.get("_srbh_affine")
-        if cache is None or cache[0] != key:
-            scale = torch.empty(C, dtype=torch.float32, device=x.device)
-            shift = torch.empty(C, dtype=torch.float32, device=x.device)
-            _lib.check(_lib.lib().srbh_bn_eval_scale_shift(C, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
-                                                           bn.running_var.data_ptr(), bn.eps, scale.data_ptr(), shift.data_ptr(),
-                                                           _lib.stream_ptr()), "bn_eval_scale_shift")
-            cache = (key, scale, shift)
-            bn.__dict__["_srbh_affine"] = cache
+        scale, shift = _bn_affine(bn, x.device)
         x = x.contiguous()
-        B, _, H, W = x.shape
+        B, C, H, W = x.shape
         y = torch.empty_like(x)
-        _lib.check(_lib.lib().srbh_affine_act_nchw(x.data_ptr(), cache[1].data_ptr(), cache[2].data_ptr(), y.data_ptr(), B, C, H * W,
+        _lib.check(_lib.lib().srbh_affine_act_nchw(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, C, H * W,
                                                    _ACT[act], _lib.stream_ptr()), "affine_act_nchw")
         return y
     x = bn(x)
@@ -130,6 +120,49 @@ def bn_act(bn, x, act=None):
     if act == "relu":
         return F.relu(x)
     return x
+
+
+def _bn_affine(bn, device):
+    """(scale, shift) of an inference BatchNorm, cached on the module and invalidated by parameter / buffer versions"""
+    from . import _lib
+    C = bn.num_features
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.data_ptr())
+    cache = bn.__dict__.get("_srbh_affine")
+    if cache is None or cache[0] != key:
+        scale = torch.empty(C, dtype=torch.float32, device=device)
+        shift = torch.empty(C, dtype=torch.float32, device=device)
+        _lib.check(_lib.lib().srbh_bn_eval_scale_shift(C, bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                                                       bn.running_var.data_ptr(), bn.eps, scale.data_ptr(), shift.data_ptr(),
+                                                       _lib.stream_ptr()), "bn_eval_scale_shift")
+        cache = (key, scale, shift)
+        bn.__dict__["_srbh_affine"] = cache
+    return cache[1], cache[2]
+
+
+def _fused_eval_ok(bn, x):
+    return (FUSED_BN_EVAL and (not bn.training) and x.is_cuda and x.dtype == torch.float32 and bn.track_running_stats
+            and not torch.is_grad_enabled())
+
+
+def bn_swish_se(bn, x, se_reduce, se_expand):
+    """MBConv middle at inference: swish(bn(x)) followed by squeeze-and-excitation, as THREE libsrbh launches
+    (csrc/srbh_dwconv.hip) instead of ~11 stock-op ones per block: the encoder is bound by its launch count."""
+    from . import _lib
+    L = _lib.lib()
+    scale, shift = _bn_affine(bn, x.device)
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    SQ = se_reduce.out_channels
+    y = torch.empty_like(x)
+    pooled = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    _lib.check(L.srbh_affine_act_pool_nchw(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), pooled.data_ptr(), B, C,
+                                           H * W, 1, _lib.stream_ptr()), "affine_act_pool_nchw")
+    hidden = torch.empty((B, SQ), dtype=torch.float32, device=x.device)
+    _lib.check(L.srbh_se_hidden(pooled.data_ptr(), se_reduce.weight.data_ptr(), se_reduce.bias.data_ptr(), hidden.data_ptr(), B, C, SQ,
+                                _lib.stream_ptr()), "se_hidden")
+    _lib.check(L.srbh_se_gate_scale(y.data_ptr(), hidden.data_ptr(), se_expand.weight.data_ptr(), se_expand.bias.data_ptr(), B, C, SQ,
+                                    H * W, _lib.stream_ptr()), "se_gate_scale")
+    return y
 
 
 class SamePadConv2d(nn.Conv2d):
@@ -192,10 +225,14 @@ class MBConvBlock(nn.Module):
         inputs = x
         if self.expand != 1:
             x = bn_act(self._bn0, self._expand_conv(x), "silu")
-        x = bn_act(self._bn1, self._depthwise_conv(x), "silu")
-        s = F.adaptive_avg_pool2d(x, 1)
-        s = self._se_expand(_swish(self._se_reduce(s)))
-        x = torch.sigmoid(s) * x
+        x = self._depthwise_conv(x)
+        if FUSED_SE_EVAL and _fused_eval_ok(self._bn1, x) and self._se_reduce.weight.is_contiguous() and self._se_expand.weight.is_contiguous():
+            x = bn_swish_se(self._bn1, x, self._se_reduce, self._se_expand)
+        else:
+            x = bn_act(self._bn1, x, "silu")
+            s = F.adaptive_avg_pool2d(x, 1)
+            s = self._se_expand(_swish(self._se_reduce(s)))
+            x = torch.sigmoid(s) * x
         x = bn_act(self._bn2, self._project_conv(x))
         if self.stride == 1 and self.inp == self.out:
             if drop_connect_rate:
