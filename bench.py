@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 GFLOP_PER_TILE_FEATURE = 146.630   # 2*9*Cin*Cout*H*W over the 350 convs of forward_feature
-PMC_JSON = "r01e_pmc_hbm_traffic.json"   # written by tools/pmc_traffic.py from the rocprofv3 --pmc passes
+PMC_JSON = "r01f_pmc_hbm_traffic.json"   # written by tools/pmc_traffic.py from the rocprofv3 --pmc passes
 PEAK_F16_TFLOPS = 2500.0           # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md), never the sparse figure
 
 
