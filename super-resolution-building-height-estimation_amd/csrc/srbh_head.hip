@@ -253,8 +253,11 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
         }
     }
     if (p.stats) {
-        // reduce over the 16 pixel lanes, then one double atomic per (wave, channel) into a slot
-        double* slot = p.stats + (long)(blockIdx.x % NSLOT) * 2 * p.cout;
+        // reduce over the 16 pixel lanes, then over the 4 waves through LDS (the input tile is dead by now), then ONE double
+        // atomic per (workgroup, channel, moment) into a slot: 4x fewer atomics than one per wave -- with 4-row tiles there
+        // are twice as many workgroups, and the atomics had grown to 60 us of a 335 us conv
+        __syncthreads();                       // every wave is past its last LDS read of the tile
+        float* red = hsm;                      // [4 waves][2 moments][NOB * 16 channels]
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
@@ -267,10 +270,19 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                 }
                 if (l15 == 0) {
                     const int oc = ob * 16 + kk * 4 + q;
-                    atomicAdd(slot + oc, (double)a);
-                    atomicAdd(slot + p.cout + oc, (double)b);
+                    red[(wave * 2 + 0) * (NOB * 16) + oc] = a;
+                    red[(wave * 2 + 1) * (NOB * 16) + oc] = b;
                 }
             }
+        __syncthreads();
+        if (tid < 2 * NOB * 16) {
+            const int mom = tid / (NOB * 16), oc = tid - mom * (NOB * 16);
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += (double)red[(w * 2 + mom) * (NOB * 16) + oc];
+            double* slot = p.stats + (long)(blockIdx.x % NSLOT) * 2 * p.cout;
+            atomicAdd(slot + mom * p.cout + oc, v);
+        }
     }
 }
 
