@@ -214,8 +214,10 @@ typedef struct srbh_hwgrad_args {
     const float* dy;      /* NHWC [B][H][W][cout] */
     int cout; int ksize;
     int B, H, W;
-    float* dw;
+    float* dw;            /* OIHW [cout][c0+c1][k][k], fully written (deterministic: fixed summation order) */
+    float* ws;            /* scratch of srbh_hwgrad_ws_bytes(cout, c0 + c1, ksize) bytes: per-workgroup partial sums */
 } srbh_hwgrad_args;
+size_t srbh_hwgrad_ws_bytes(int cout, int cin, int ksize);
 int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream);
 /* out = g where ref > 0 else 0   (ReLU backward with the saved output, SR/HRfuse.py:157) */
 int srbh_relu_mask_mul(const float* g, const float* ref, float* out, long n, void* stream);

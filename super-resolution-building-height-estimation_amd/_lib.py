@@ -87,7 +87,7 @@ class HWGradArgs(C.Structure):
         ("pre_scale", C.c_void_p), ("pre_shift", C.c_void_p), ("pre_relu", C.c_int),
         ("src1", C.c_void_p), ("c1", C.c_int),
         ("dy", C.c_void_p), ("cout", C.c_int), ("ksize", C.c_int),
-        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dw", C.c_void_p),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dw", C.c_void_p), ("ws", C.c_void_p),
     ]
 
 
@@ -133,6 +133,7 @@ SIGNATURES = {
     "srbh_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp, _vp]),
     "srbh_bn_bwd_finalize": (_i, [_vp, _i, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srbh_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp]),
+    "srbh_hwgrad_ws_bytes": (_sz, [_i, _i, _i]),
     "srbh_ps2_inverse": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_affine_act_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_affine_act_pool_nchw": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -25,7 +25,8 @@ struct WGParams {
     int pre_relu;
     const float* dy;      // NHWC [B][H][W][cout_total]
     int cout_total;
-    float* dw;            // OIHW fp32 [cout_total][cin][KS][KS], accumulated with atomics (caller zeroes it)
+    float* dw;            // OIHW fp32 [cout_total][cin][KS][KS]
+    float* ws;            // [gridDim.x][nob][nchunk][TAPS*256] per-workgroup partial sums (hwgrad_reduce_kernel adds them)
     int B, H, W;
     int tiles_x, tiles_per_img, ntiles;
 };
@@ -195,10 +196,45 @@ __global__ __launch_bounds__(256) void hwgrad_f32_kernel(const WGParams p) {
         __syncthreads();
         for (int u = tid; u < TAPS * 256; u += 256) {
             const float v = s_red[u] + s_red[TAPS * 256 + u] + s_red[2 * TAPS * 256 + u] + s_red[3 * TAPS * 256 + u];
-            const int ci = c * 16 + (u & 15), oc = ob * 16 + ((u >> 4) & 15), tp = u >> 8;
-            if (ci < cin && oc < p.cout_total) atomicAdd(p.dw + ((long)oc * cin + ci) * TAPS + tp, v);
+            // no atomics: 512 workgroups adding into the same 2 304 addresses cost 60 us of a 318 us layer (and made the
+            // gradient order-dependent); every workgroup stores its partial, a second tiny kernel adds them in order
+            p.ws[(((long)blockIdx.x * gridDim.y + ob) * nchunk + c) * (TAPS * 256) + u] = v;
         }
     }
+}
+
+// Sum of the workgroups' partials in a fixed order (deterministic), two stages so that enough loads are in flight:
+//   stage 1: tmp[s][u] = sum of the partials x in slice s (x = s*per .. s*per+per-1), grid (U/256, slices);
+//   stage 2: dw[oc][ci][tap] = sum over s of tmp[s][u(oc, ci, tap)]
+__global__ __launch_bounds__(256) void hwgrad_reduce1_kernel(const float* __restrict__ ws, float* __restrict__ tmp, long U, int gx, int per) {
+    const long u = (long)blockIdx.x * 256 + threadIdx.x;
+    if (u >= U) return;
+    const int x0 = blockIdx.y * per;
+    const int x1 = x0 + per < gx ? x0 + per : gx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int x = x0;
+    for (; x + 3 < x1; x += 4) {
+        a0 += ws[(long)x * U + u];
+        a1 += ws[(long)(x + 1) * U + u];
+        a2 += ws[(long)(x + 2) * U + u];
+        a3 += ws[(long)(x + 3) * U + u];
+    }
+    for (; x < x1; ++x) a0 += ws[(long)x * U + u];
+    tmp[(long)blockIdx.y * U + u] = (a0 + a1) + (a2 + a3);
+}
+
+__global__ void hwgrad_reduce2_kernel(const float* __restrict__ tmp, float* __restrict__ dw, long U, int slices, int nchunk, int taps,
+                                      int cout, int cin) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = cout * cin * taps;
+    if (idx >= total) return;
+    const int tp = idx % taps;
+    const int ci = (idx / taps) % cin;
+    const int oc = idx / (taps * cin);
+    const long u = ((long)(oc >> 4) * nchunk + (ci >> 4)) * (taps * 256) + tp * 256 + (oc & 15) * 16 + (ci & 15);
+    float v = 0.f;
+    for (int sidx = 0; sidx < slices; ++sidx) v += tmp[(long)sidx * U + u];
+    dw[idx] = v;
 }
 
 // ---- elementwise / reduction helpers (NHWC fp32, C % 4 == 0 unless noted) ------------------------------------------
@@ -318,14 +354,14 @@ extern "C" int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream) {
     WGParams p;
     p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1;
     p.pre_scale = a->pre_scale; p.pre_shift = a->pre_shift; p.pre_relu = a->pre_relu;
-    p.dy = a->dy; p.cout_total = a->cout; p.dw = a->dw;
+    p.dy = a->dy; p.cout_total = a->cout; p.dw = a->dw; p.ws = a->ws;
+    SRBH_REQUIRE(a->ws, "srbh_hconv_wgrad_f32: workspace missing (srbh_hwgrad_ws_bytes)");
     p.B = a->B; p.H = a->H; p.W = a->W;
     p.tiles_x = (a->W + HT_W - 1) / HT_W;
     p.tiles_per_img = p.tiles_x * ((a->H + HT_H - 1) / HT_H);
     p.ntiles = p.tiles_per_img * a->B;
     hipStream_t st = (hipStream_t)stream;
     const int cin = a->c0 + a->c1;
-    SRBH_HIP(hipMemsetAsync(a->dw, 0, (size_t)a->cout * cin * a->ksize * a->ksize * sizeof(float), st));
     const int nob = (a->cout + 15) / 16;
     const int gx = p.ntiles < 512 ? p.ntiles : 512;
     if (a->ksize == 3) {
@@ -346,7 +382,22 @@ extern "C" int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream) {
         hipLaunchKernelGGL(hwgrad_f32_kernel<1>, dim3(gx, nob), dim3(256), LDS_B, st, p);
     }
     SRBH_HIP(hipGetLastError());
+    constexpr int SLICES = 16;
+    const int taps = a->ksize * a->ksize, nchunk = (cin + 15) / 16;
+    const long U = (long)nob * nchunk * taps * 256;
+    float* tmp = a->ws + (long)512 * U;
+    const int per = (gx + SLICES - 1) / SLICES;
+    hipLaunchKernelGGL(hwgrad_reduce1_kernel, dim3((unsigned)((U + 255) / 256), SLICES), dim3(256), 0, st, a->ws, tmp, U, gx, per);
+    SRBH_HIP(hipGetLastError());
+    const int total = a->cout * cin * taps;
+    hipLaunchKernelGGL(hwgrad_reduce2_kernel, dim3((total + 255) / 256), dim3(256), 0, st, tmp, a->dw, U, SLICES, nchunk, taps, a->cout, cin);
+    SRBH_HIP(hipGetLastError());
     return SRBH_OK;
+}
+
+extern "C" size_t srbh_hwgrad_ws_bytes(int cout, int cin, int ksize) {
+    if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    return (size_t)(512 + 16) * ((cout + 15) / 16) * ((cin + 15) / 16) * ksize * ksize * 256 * sizeof(float);
 }
 
 extern "C" int srbh_relu_mask_mul(const float* g, const float* ref, float* out, long n, void* stream) {

@@ -82,6 +82,8 @@ def conv_wgrad(srcs, pre, g, cout, ks):
     a.dy, a.cout, a.ksize = g.data_ptr(), cout, ks
     a.B, a.H, a.W = B, Hh, Ww
     a.dw = dw.data_ptr()
+    ws = torch.empty(L.srbh_hwgrad_ws_bytes(cout, c0 + c1, ks) // 4, dtype=torch.float32, device=x0.device)
+    a.ws = ws.data_ptr()
     _lib.check(L.srbh_hconv_wgrad_f32(C.byref(a), _lib.stream_ptr()), "hconv_wgrad_f32")
     return dw
 
