@@ -153,7 +153,15 @@ def bench_predict(args, rank, world, dev, dist):
     batch = args.batch if args.batch != 32 else 128     # 288 GB of HBM: larger batches amortise the stock-op encoder's small launches
     n_warm = min(args.warmup, 2)
     todo = [int(c) for c in counts[:args.steps]]
+    pad_to = 32 if batch % 32 == 0 and batch > 32 else None          # ragged tails run as 32/64/96/... tiles, not the full batch
     warm = [min(int(c), 256) for c in counts[-n_warm:]] if n_warm else []
+    if pad_to and args.warmup:
+        # every padded tail shape once on every rank (MIOpen searches per tensor shape; outside the timed region)
+        with torch.no_grad():
+            xw = torch.randn((batch, 8, 64, 64), device=dev) * 0.25 + 0.35
+            for q in range(pad_to, batch + 1, pad_to):
+                model(xw[:q], net_hr.forward_feature(xw[:q, :3]))
+        torch.cuda.synchronize()
 
     def city(n, seed):
         gw = int(np.ceil(np.sqrt(n)))
@@ -166,7 +174,7 @@ def bench_predict(args, rank, world, dev, dist):
             dist.barrier()
         t0 = time.perf_counter()
         m = Mosaic((gh * 48 + 16) * 4, (gw * 48 + 16) * 4, 7, dev)
-        predict_tiles(net_hr, model, tiles, pos, m, batch=batch, rank=rank, world=world)
+        predict_tiles(net_hr, model, tiles, pos, m, batch=batch, rank=rank, world=world, pad_to=pad_to)
         if dist is not None:
             m.all_reduce_(dist)
         out = m.finalize()
@@ -188,7 +196,7 @@ def bench_predict(args, rank, world, dev, dist):
         mid = order[len(order) // 2]
         print(json.dumps({
             "metric": "tiles/sec (64x64x8ch->256x256 height) tiled inference incl. quantise + mosaic", "value": round(total / elapsed, 2),
-            "unit": "tiles/s", "n_gpus": world, "steps": len(todo), "warmup": len(warm), "ms_per_step": round(elapsed / len(todo) * 1e3, 3),
+            "unit": "tiles/s", "n_gpus": world, "steps": len(todo), "warmup": args.warmup, "ms_per_step": round(elapsed / len(todo) * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f16 operands/f32 acc (RRDB), f32 (head), integer mosaic", "data": "synthetic cities, random-init weights",
             "config": {"workload": f"sliding-window predict path, {len(todo)} of 301 synthetic cities (cells log-uniform 200..20000, "

@@ -120,7 +120,7 @@ class TrainStep:
 
 
 @torch.no_grad()
-def predict_tiles(net_hr, model, tiles, posall, mosaic, batch=32, rank=0, world=1):
+def predict_tiles(net_hr, model, tiles, posall, mosaic, batch=32, rank=0, world=1, pad_to=None):
     """predict_whole_image_grid's inner loop (predict_realesanet_feature_globe.py:167-185) for this rank's shard of a
     city's grid cells: RRDBNet feature extraction -> height / building heads -> quantise + integer mosaic on the
     device.  ``tiles`` (N,8,64,64) fp32, ``posall`` (N,4) LR-cell windows.  Merge shards with ``mosaic.all_reduce_``
@@ -136,9 +136,13 @@ def predict_tiles(net_hr, model, tiles, posall, mosaic, batch=32, rank=0, world=
         x = tiles[s:e].to(dev, non_blocking=True)
         k = e - s
         if k < batch:
-            # ragged tail: run a full batch (eval mode: tiles are independent) instead of a new tensor shape, for which the
-            # stock-op encoder would first search / compile kernels (0.5 s per new shape, more than a small city's work)
-            x = torch.cat([x, x.new_zeros((batch - k,) + tuple(x.shape[1:]))], 0)
+            # ragged tail: run a padded batch (eval mode: tiles are independent) instead of a new tensor shape, for which the
+            # stock-op encoder would first search / compile kernels (0.5 s per new shape, more than a small city's work).
+            # pad_to = granularity of the padded sizes (None: always the full batch; e.g. 32 with batch 128 -> four shapes,
+            # which the caller should have warmed up once)
+            q = batch if not pad_to else min(batch, (k + pad_to - 1) // pad_to * pad_to)
+            if q > k:
+                x = torch.cat([x, x.new_zeros((q - k,) + tuple(x.shape[1:]))], 0)
         hr_fea = net_hr.forward_feature(x[:, :3])
         out = model(x, hr_fea)
         mosaic.add(out[0][:k], out[1][:k], posall[s:e])
