@@ -176,8 +176,8 @@ def bench_predict(args, rank, world, dev, dist):
         m = Mosaic((gh * 48 + 16) * 4, (gw * 48 + 16) * 4, 7, dev)
         predict_tiles(net_hr, model, tiles, pos, m, batch=batch, rank=rank, world=world, pad_to=pad_to)
         if dist is not None:
-            m.all_reduce_(dist)
-        out = m.finalize()
+            m.reduce_to_(dist, dst=0)      # each rank ships only the row band it wrote; rank 0 holds the city
+        out = m.finalize() if rank == 0 else None
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None:
@@ -201,7 +201,7 @@ def bench_predict(args, rank, world, dev, dist):
             "dtype": "f16 operands/f32 acc (RRDB), f32 (head), integer mosaic", "data": "synthetic cities, random-init weights",
             "config": {"workload": f"sliding-window predict path, {len(todo)} of 301 synthetic cities (cells log-uniform 200..20000, "
                                    f"seed 2024), batch {batch}/GPU (BASELINE.json configs[4])",
-                       "cities": len(todo), "tiles": total, "parallelism": f"each city's cells sharded x{world}, integer mosaic all-reduce"},
+                       "cities": len(todo), "tiles": total, "parallelism": f"each city's cells sharded x{world}, integer mosaic row bands gathered on rank 0"},
             "p50_city_latency_ms": round(lat[mid] * 1e3, 2), "p50_city_tiles": todo[mid],
             "max_city_latency_ms": round(max(lat) * 1e3, 2), "max_city_tiles": max(todo)}), flush=True)
     if dist is not None:

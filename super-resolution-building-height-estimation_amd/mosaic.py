@@ -17,6 +17,7 @@ class Mosaic:
         self.res_height = torch.zeros((self.H, self.W), dtype=torch.int32, device=device)     # uint32 bit patterns
         self.res_build = torch.zeros((self.C, self.H, self.W), dtype=torch.int32, device=device)
         self.res_weight = torch.zeros((self.H, self.W), dtype=torch.int32, device=device)
+        self._rows = [self.H, 0]     # [first, last+1) mosaic rows this instance has written (for reduce_to_)
 
     def add(self, ypred, build_pred, posall):
         """ypred (N,1,h,w), build_pred (N,C,h,w) raw logits, posall (N,4) = (xoff,yoff,xcount,ycount) in LR cells
@@ -26,7 +27,11 @@ class Mosaic:
         n, _, th, tw = ypred.shape
         hv = ypred.detach().float().contiguous()
         bl = H.to_nhwc(build_pred.detach().float())
-        pos = (torch.as_tensor(posall, dtype=torch.int32).reshape(n, 4) * 4).to(ypred.device).contiguous()
+        pos_h = torch.as_tensor(posall, dtype=torch.int32).reshape(n, 4) * 4
+        if n:
+            self._rows[0] = min(self._rows[0], max(0, int(pos_h[:, 1].min())))
+            self._rows[1] = max(self._rows[1], min(self.H, int((pos_h[:, 1] + pos_h[:, 3]).max())))
+        pos = pos_h.to(ypred.device).contiguous()
         _lib.check(_lib.lib().srbh_mosaic_accumulate(hv.data_ptr(), bl.data_ptr(), self.C, n, th, tw, pos.data_ptr(),
                                                      self.res_height.data_ptr(), self.res_build.data_ptr(),
                                                      self.res_weight.data_ptr(), self.H, self.W, _lib.stream_ptr()),
@@ -42,6 +47,39 @@ class Mosaic:
     def all_reduce_(self, dist):
         for t in (self.res_height, self.res_build, self.res_weight):
             dist.all_reduce(t)
+        return self
+
+    def reduce_to_(self, dist, dst=0):
+        """Sum the ranks' mosaics into rank `dst` moving only the ROW BAND each rank has written (contiguous shards of a
+        row-major grid touch contiguous bands: an 8-way shard of a 27k x 27k city gathers 27 GB / 8 per rank instead of
+        all-reducing 27 GB on every rank).  One gather of equally padded bands; afterwards only `dst` holds the city."""
+        world, rank = dist.get_world_size(), dist.get_rank()
+        dev = self.res_height.device
+        y0, y1 = (self._rows[0], self._rows[1]) if self._rows[1] > self._rows[0] else (0, 0)
+        mine = torch.tensor([y0, y1], dtype=torch.int64, device=dev)
+        ranges = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(ranges, mine)
+        ranges = [(int(r[0]), int(r[1])) for r in ranges]
+        rows = max(1, max(b - a for a, b in ranges))
+        pack = torch.zeros((self.C + 2, rows, self.W), dtype=torch.int32, device=dev)
+        n = y1 - y0
+        if n:
+            pack[0, :n] = self.res_height[y0:y1]
+            pack[1, :n] = self.res_weight[y0:y1]
+            pack[2:, :n] = self.res_build[:, y0:y1]
+        on_host = dist.get_backend() == "gloo"          # (gloo gathers host tensors; RCCL gathers device tensors)
+        send = pack.cpu() if on_host else pack
+        bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+        dist.gather(send, bufs, dst=dst)
+        if rank == dst:
+            for r, (a, b) in enumerate(ranges):
+                if r == dst or b <= a:
+                    continue
+                band = bufs[r].to(dev) if on_host else bufs[r]
+                self.res_height[a:b] += band[0, :b - a]
+                self.res_weight[a:b] += band[1, :b - a]
+                self.res_build[:, a:b] += band[2:, :b - a]
+            self._rows = [min([a for a, b in ranges if b > a] or [self.H]), max([b for a, b in ranges] or [0])]
         return self
 
     def finalize(self):

@@ -40,7 +40,7 @@ def _nets():
     return net_hr.cuda().eval(), model.cuda().eval()
 
 
-def _run(rank, world, dist):
+def _run(rank, world, dist, how="all_reduce"):
     from srbh_amd.harness import predict_tiles
     from srbh_amd.mosaic import Mosaic
     tiles, pos, H, W = _city(13, 4)
@@ -48,7 +48,10 @@ def _run(rank, world, dist):
     m = Mosaic(H, W, 7, "cuda:0")
     n = predict_tiles(net_hr, model, tiles.cuda(), pos, m, batch=4, rank=rank, world=world)
     if dist is not None:
-        m.all_reduce_(dist)
+        if how == "all_reduce":
+            m.all_reduce_(dist)
+        else:
+            m.reduce_to_(dist, dst=0)      # row bands gathered on rank 0 only
     h, b = m.finalize()
     return n, h.cpu().to(torch.int32), b.cpu()
 
@@ -58,9 +61,11 @@ def _worker(rank, world, port, q):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     n, h, b = _run(rank, world, dist)
+    _, hb, bb = _run(rank, world, dist, how="bands")
     if rank == 0:
         n1, h1, b1 = _run(0, 1, None)
-        q.put({"n": n, "n1": n1, "h": h.numpy(), "b": b.numpy(), "h1": h1.numpy(), "b1": b1.numpy()})
+        q.put({"n": n, "n1": n1, "h": h.numpy(), "b": b.numpy(), "h1": h1.numpy(), "b1": b1.numpy(), "hb": hb.numpy(),
+               "bb": bb.numpy()})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -81,4 +86,5 @@ def test_two_rank_sharded_city_is_bit_identical_to_one_rank():
     assert res["n"] == 7 and res["n1"] == 13          # balanced shard of 13 cells; ragged tails on both sides
     assert np.array_equal(res["h"], res["h1"])
     assert np.array_equal(res["b"], res["b1"])
+    assert np.array_equal(res["hb"], res["h1"]) and np.array_equal(res["bb"], res["b1"])   # Mosaic.reduce_to_ (row bands)
     assert res["b1"].max() <= 6 and (res["h1"].any() or np.unique(res["b1"]).size > 1)   # (not a trivially empty mosaic)
