@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- tiles/s of the MI355X-native hot path (BASELINE.json metric) + roofline + CPU baseline.
+"""bench.py -- tiles/s of the MI355X-native hot path (BASELINE.json metric) + rooflines + CPU baselines.
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
-Workload (default, BASELINE.json configs[1]): RRDBNet x4 (23 RRDB, 64 feat) forward_feature, batch 32
+Headline workload (default, BASELINE.json configs[1]): RRDBNet x4 (23 RRDB, 64 feat) forward_feature, batch 32
 synthetic 64x64 tiles per GPU, inputs resident in HBM, random-init weights of the reference architecture.
 A "step" is one forward_feature over one batch.  Tiles are independent, so ranks shard the tile stream with
 no data-path collective ("scaling": "weak"); the only collectives are the timing barrier / max.
 
-One JSON line is printed by rank 0 (contract in the task statement); extra keys:
-  roofline     -- MFMA roofline of the conv stack: 146.630 GFLOP per tile (hook-counted on the
-                  reference) x tiles per step / step duration measured with HIP events on the launch stream.
-  cpu_baseline -- the CPU oracle (oracle/srbh_oracle.py, proven equal to the reference) timed on this host.
+One JSON line is printed by rank 0 (contract in the task statement).  Extra keys of the default run:
+  roofline     -- MFMA roofline of the dominant kernel (persistent trunk), launch duration measured live with HIP events
+                  on the launch stream; `traffic` is the PMC figure RECORDED under profiles/ (`traffic_source` says so).
+  cpu_baseline -- the CPU oracle (oracle/srbh_oracle.py, proven equal to the reference) timed on this host (N=1 only).
+  train_step   -- BASELINE configs[2] (N=1) / configs[3] (N>1): the full training step at batch 64 per GPU, a few timed
+                  steps, with per-kernel rooflines of its dominant kernels (trunk: MFMA; head convs: HBM), the gradient
+                  all-reduce's isolated and exposed time (N>1) and a CPU baseline at B=4 (N=1).
+  predict      -- BASELINE configs[4]: tiled city inference incl. quantise + integer mosaic, a few synthetic cities,
+                  tiles/s and p50 per-city latency.
+`--workload train|predict|epoch` run one of those as the headline instead (longer, all cities / a whole epoch).
+`--no-extras` drops the two sub-objects from the default run.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -25,8 +33,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 GFLOP_PER_TILE_FEATURE = 146.630   # 2*9*Cin*Cout*H*W over the 350 convs of forward_feature
-PMC_JSON = "r01f_pmc_hbm_traffic.json"   # written by tools/pmc_traffic.py from the rocprofv3 --pmc passes
 PEAK_F16_TFLOPS = 2500.0           # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md), never the sparse figure
+PEAK_F32_MFMA_TFLOPS = 157.3       # dense fp32 matrix rate
+PEAK_HBM_GBS = 8000.0              # HBM3E
 
 
 def _host_cores():
@@ -44,11 +53,24 @@ def _host_cores():
     return cores
 
 
+def _recorded_traffic():
+    """HBM bytes per trunk launch from the newest PMC summary under profiles/ (tools/pmc_traffic.py: separate rocprofv3
+    --pmc passes of this very command, FETCH_SIZE doubled per the guide).  A recorded constant, NOT measured in this run."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    for f in reversed(files):
+        try:
+            return json.load(open(f))["dominant_kernel_hbm_bytes_per_launch"], "profiles/" + os.path.basename(f)
+        except Exception:
+            continue
+    return None, None
+
+
 def cpu_baseline(sd, seconds_budget=20.0):
     """Oracle forward_feature on the host cores, bounded to ~seconds_budget of wall time.
     oneDNN scales badly past a few dozen threads on these small convs, so the thread count is capped at 32
     (`cores` reports the threads actually used).  Protocol: one timed B=1 call decides the sample size."""
-    from oracle import srbh_oracle as O, synth
+    from oracle import srbh_oracle as O  # the checker: cpu_baseline leg only
+    from srbh_amd import synth
     cores = min(_host_cores(), 32)
     torch.set_num_threads(cores)
     x = synth.tiles(4, 8, 64, seed=1)[:, :3].contiguous()
@@ -74,88 +96,207 @@ def cpu_baseline(sd, seconds_budget=20.0):
                       f"calls after 1 warm-up ({sum(times) + t_first:.1f} s of CPU work)"}
 
 
-def bench_train(args, rank, world, dev, dist):
-    """BASELINE configs[2]/[3]: RRDBNet forward (no grad) + SRRegress_Cls_feature forward/backward + Adam, batch 64 per
-    GPU, gradients averaged over ranks by one bucketed RCCL all-reduce per step."""
-    from oracle import synth
-    from srbh_amd.harness import TrainStep, synthetic_batch
+def cpu_baseline_train(rrdb_sd, seconds_budget=30.0):
+    """the full training step at B=4 on the host cores (oracle/train_oracle.py: oracle RRDBNet forward under
+    no_grad + stock-op encoder/decoders + oracle head forward/backward + oracle losses + Adam), bounded to
+    ~seconds_budget: one warm-up step, then up to 3 timed steps."""
+    from oracle import srbh_oracle as O
+    from oracle.train_oracle import CpuTrainStep
+    from srbh_amd.harness import synthetic_batch
+    from srbh_amd.models import SRRegress_Cls_feature
+    cores = min(_host_cores(), 32)
+    torch.set_num_threads(cores)
+    torch.manual_seed(1337)
+    model = SRRegress_Cls_feature("efficientnet-b4", in_channels=8, super_in=64, super_mid=16, upscale=4, isaggre=True,
+                                  chans_build=7)
+    ts = CpuTrainStep(rrdb_sd, model)
+    B = 4
+    batch = synthetic_batch(B, 1337, "cpu", aggregate=O.aggregate_torch)
+    t0 = time.perf_counter()
+    ts(batch)
+    t_first = time.perf_counter() - t0
+    times = []
+    while len(times) < 3 and (not times or time.perf_counter() - t0 + times[-1] < seconds_budget):
+        t1 = time.perf_counter()
+        ts(batch)
+        times.append(time.perf_counter() - t1)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(B / med, 3), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"oracle training step fp32 at B={B} (RRDBNet fwd no-grad + encoder/decoders/head fwd+bwd + losses + Adam), "
+                      f"median of {len(times)} steps after 1 warm-up ({sum(times) + t_first:.1f} s of CPU work)"}
+
+
+def _timed(fn, n, dev):
+    """average duration (ms) of fn() over n calls, HIP events on the current stream (= the stream libsrbh launches on)."""
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def head_kernel_rooflines(dev, B):
+    """The training step's dominant HEAD kernels timed on their own at the step's batch size (16-channel 256x256 maps:
+    SURVEY 8d bounds the head by HBM).  Algorithmic bytes per launch: fp32 NHWC input + output (+ both operands for the
+    weight gradient); the fp32 matrix rate is reported next to it because an exact-fp32 3x3 conv at 36 FLOP/B is not far
+    from that second roof."""
+    from srbh_amd import hrfuse as H, hrfuse_autograd as HA
+    px = B * 256 * 256
+    out = []
+    conv = torch.nn.Conv2d(16, 16, 3, 1, 1, bias=False).to(dev)
+    x = H.to_nhwc(torch.randn(B, 16, 256, 256, device=dev))
+    g = H.to_nhwc(torch.randn(B, 16, 256, 256, device=dev))
+    pk, pg = H._PackedConv(), HA._PackedGrad()
+    gflop = 2 * 9 * 16 * 16 * px / 1e9
+    for name, fn, nbytes in (
+            ("hconv_f32_kernel 16->16 3x3 fwd + BN statistics", lambda: H.hconv([x], conv, pk, want_stats=True), px * (64 + 64)),
+            ("hconv_f32_kernel 16->16 3x3 data gradient", lambda: HA.conv_dgrad(g, conv.weight, pg), px * (64 + 64)),
+            ("hwgrad_f32_kernel 16->16 3x3 weight gradient", lambda: HA.conv_wgrad([x], None, g, 16, 3), px * (64 + 64))):
+        ms = _timed(fn, 10, dev)
+        out.append({"kernel": f"{name} @256x256, B={B}", "bound": "hbm", "avg_launch_ms": round(ms, 4),
+                    "algorithmic_bytes_per_launch": nbytes, "achieved": round(nbytes / ms / 1e6, 1), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / PEAK_HBM_GBS, 4),
+                    "f32_mfma_tflops": round(gflop / ms, 2), "f32_mfma_frac": round(gflop / ms / PEAK_F32_MFMA_TFLOPS, 4)})
+    return out
+
+
+def _make_nets(args, dev, isaggre):
+    from srbh_amd import synth
     from srbh_amd.models import SRRegress_Cls_feature
     from srbh_amd.rrdbnet import RRDBNet
-    B = args.batch if args.batch != 32 else 64
+    sd = synth.rrdbnet_state_dict(num_block=args.num_block, seed=1337, mode="init")
     net_hr = RRDBNet(3, 3, num_block=args.num_block)
-    net_hr.load_state_dict(synth.rrdbnet_state_dict(num_block=args.num_block, seed=1337, mode="init"))
+    net_hr.load_state_dict(sd)
     torch.manual_seed(1337)
-    net = SRRegress_Cls_feature("efficientnet-b4", in_channels=8, super_in=64, super_mid=16, upscale=4, isaggre=True,
+    net = SRRegress_Cls_feature("efficientnet-b4", in_channels=8, super_in=64, super_mid=16, upscale=4, isaggre=isaggre,
                                 chans_build=7)
+    return sd, net_hr.to(dev), net.to(dev)
+
+
+def _max_over_ranks(vals, dev, dist):
+    if dist is None:
+        return vals
+    t = torch.tensor(vals, dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t]
+
+
+def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_tiles=None, with_cpu=True, with_kernels=True):
+    """BASELINE configs[2]/[3]: RRDBNet forward (no grad) + SRRegress_Cls_feature forward/backward + Adam, `batch` tiles
+    per GPU, gradients averaged over ranks by bucketed RCCL all-reduces launched from autograd hooks (overlapped with
+    backward).  `epoch_tiles`: run one data-parallel pass over that many synthetic tiles (batches drawn on the device)
+    instead of `steps` repeats of one fixed batch."""
+    from srbh_amd.harness import TrainStep, synthetic_batch, train_epoch
+    sd, net_hr, net = _make_nets(args, dev, True)
     sync_bn = os.environ.get("SRBH_SYNC_BN", "0") == "1"        # default: per-rank BatchNorm statistics (DESIGN.md 6)
-    ts = TrainStep(net_hr.to(dev), net.to(dev), dev, world=world, sync_bn=sync_bn)
-    batch = synthetic_batch(B, 1337 + rank, dev)
-    for _ in range(args.warmup):
-        ts(batch)
+    ts = TrainStep(net_hr, net, dev, world=world, sync_bn=sync_bn, timing=True, status_every=0)
+    fixed = synthetic_batch(batch, 1337 + rank, dev)
+    for _ in range(max(warmup, 2 if world > 1 else 1)):          # (world > 1: step 1 records the bucket plan)
+        ts(fixed)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    exposed = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = ts(batch)
+    if epoch_tiles:
+        steps, tiles, loss = train_epoch(ts, epoch_tiles, batch, rank, world, dev)
+    else:
+        for _ in range(steps):
+            loss, _ = ts(fixed)
+            if ts.reducer is not None:
+                exposed.append(ts.reducer._last_events)
+        tiles = batch * world * steps
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-    if rank == 0:
-        gf_tile = 146.63 + 8.12 * 3 + 0.9 * 3      # RRDB fwd + head fwd/bwd (~3x fwd) + encoder/decoders (SURVEY 8d)
-        tf = gf_tile * B * world * args.steps / elapsed / 1e3
-        print(json.dumps({
-            "metric": "tiles/sec (64x64x8ch->256x256 height) fwd+bwd", "value": round(B * world * args.steps / elapsed, 2),
-            "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16 operands/f32 acc (RRDB), f32 (head fwd+bwd)", "data": "synthetic",
-            "config": {"workload": f"full train step: RRDBNet fwd (no grad) + SRRegress_Cls_feature fwd/bwd + Adam, batch {B}/GPU "
-                                   "(BASELINE.json configs[2])", "global_batch": B * world,
-                       "parallelism": f"dp{world} (bucketed RCCL grad all-reduce)"},
-            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tf / PEAK_F16_TFLOPS, 4), "traffic": None,
-                         "kernel": "whole step (RRDB f16 MFMA stack dominates the FLOPs)"},
-            "final_loss": float(loss)}), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    (elapsed,) = _max_over_ranks([elapsed], dev, dist)
+    net_hr.check_status()
+    comm = None
+    if ts.reducer is not None:
+        ex = [a.elapsed_time(b) for a, b in exposed] or [0.0]
+        iso = ts.reducer.isolated_comm_ms()
+        ex_max, iso_max = _max_over_ranks([sum(ex) / len(ex), iso], dev, dist)
+        comm = {"buckets": ts.reducer.n_buckets, "grad_bytes": int(sum(b["flat"].numel() * 4 for b in ts.reducer.plan)),
+                "comm_ms": round(iso_max, 3), "exposed_comm_ms": round(ex_max, 3),
+                "note": "comm_ms = the step's bucketed all-reduces on their own; exposed_comm_ms = device time between the "
+                        "end of backward and the last bucket landing (max over ranks)"}
+    if rank != 0:
+        return None
+    ms_step = elapsed / steps * 1e3
+    gf_tile = 146.63 + 8.12 * 3 + 0.9 * 3      # RRDB fwd + head fwd/bwd (~3x fwd) + encoder/decoders (SURVEY 8d)
+    line = {
+        "metric": "tiles/sec (64x64x8ch->256x256 height) fwd+bwd", "value": round(tiles / elapsed, 2), "unit": "tiles/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16 operands/f32 acc (RRDB), f32 (head fwd+bwd)",
+        "data": "synthetic" + (" (batches drawn on the device each step)" if epoch_tiles else " (one fixed batch)"),
+        "config": {"workload": (f"one data-parallel pass over {epoch_tiles} synthetic train tiles (BASELINE.json configs[3]), " if epoch_tiles else "")
+                               + f"full train step: RRDBNet fwd (no grad) + SRRegress_Cls_feature fwd/bwd + Adam, batch {batch}/GPU "
+                               "(BASELINE.json configs[2])", "batch": batch, "global_batch": batch * world,
+                   "parallelism": f"dp{world} (bucketed RCCL grad all-reduce launched from autograd hooks)" if world > 1 else "1 GPU"},
+        "whole_step": {"gflop_per_tile": gf_tile, "achieved_tflops": round(gf_tile * tiles / elapsed / 1e3, 2),
+                       "note": "mixes the MFMA-bound trunk with the HBM-bound head: not a roofline, see `kernels`"},
+        "final_loss": float(loss)}
+    if comm:
+        line["comm"] = comm
+    if with_kernels:
+        # per-kernel rooflines: the trunk launch inside THIS step (HIP events via libsrbh's hook), the head kernels on their own
+        import ctypes
+        from srbh_amd import _lib
+        L = _lib.lib()
+        ks = []
+        if L.srbh_trunk_timing(1) == 0:
+            acc = 0.0
+            for _ in range(3):
+                with torch.no_grad():
+                    net_hr.forward_feature(fixed[0][:, :3])
+                ms = ctypes.c_float(0.0)
+                _lib.check(L.srbh_trunk_last_ms(ctypes.byref(ms)), "srbh_trunk_last_ms")
+                acc += ms.value
+            L.srbh_trunk_timing(0)
+            tg = args.num_block * 3 * 4096 * 18 * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64) / 1e9 * batch
+            ks.append({"kernel": f"persistent trunk (345 dense-block convs), B={batch}", "bound": "mfma", "avg_launch_ms": round(acc / 3, 4),
+                       "algorithmic_gflop_per_launch": round(tg, 1), "achieved": round(tg / (acc / 3), 2), "peak": PEAK_F16_TFLOPS,
+                       "unit": "TFLOP/s", "frac": round(tg / (acc / 3) / PEAK_F16_TFLOPS, 4)})
+        ks += head_kernel_rooflines(dev, batch)
+        line["kernels"] = ks
+    if with_cpu and world == 1:
+        line["cpu_baseline"] = cpu_baseline_train(sd)
+    return line
 
 
-def bench_predict(args, rank, world, dev, dist):
+def bench_predict(args, rank, world, dev, dist, n_cities, warmup, batch=128, small=False):
     """BASELINE configs[4]: urban-centre tiled inference.  A "step" is ONE synthetic city: its grid cells (64x64x8 LR tiles,
     stride 48 as in the reference's grid loader) are sharded over the ranks, each rank runs RRDBNet features -> eval head ->
     quantise + integer mosaic on the device, the integer mosaics are summed over ranks (bit-identical to the serial
-    result) and finalised (argmax / normalise).  City sizes: the first --steps (+ warm-up) of 301 cell counts drawn
-    log-uniform in [200, 20000] (numpy default_rng(2024)); no per-city grid counts ship with the reference.
-    GeoTIFF IO is outside the path."""
+    result) and finalised (argmax / normalise).  City sizes: 301 cell counts drawn log-uniform in [200, 20000] (numpy
+    default_rng(2024)); no per-city grid counts ship with the reference.  `small`: the n_cities cities closest
+    to the median size (the default run's bounded sample) instead of the first n_cities.  GeoTIFF IO is outside the path."""
     import numpy as np
-    from oracle import synth
     from srbh_amd.harness import predict_tiles
-    from srbh_amd.models import SRRegress_Cls_feature
     from srbh_amd.mosaic import Mosaic
-    from srbh_amd.rrdbnet import RRDBNet
-    net_hr = RRDBNet(3, 3, num_block=args.num_block)
-    net_hr.load_state_dict(synth.rrdbnet_state_dict(num_block=args.num_block, seed=1337, mode="init"))
-    net_hr = net_hr.to(dev).eval()
-    torch.manual_seed(1337)
-    model = SRRegress_Cls_feature("efficientnet-b4", in_channels=8, super_in=64, super_mid=16, upscale=4, isaggre=False,
-                                  chans_build=7).to(dev).eval()
+    _, net_hr, model = _make_nets(args, dev, False)
+    net_hr.eval()
+    model.eval()
     counts = np.exp(np.random.default_rng(2024).uniform(np.log(200.0), np.log(20000.0), 301)).astype(int)
     # MIOpen solver search for the stock-op encoder / decoders: without it a few forward convolutions run on MIOpen's naive
-    # kernels (immediate-mode fallback).  One-time cost in the warm-up cities; every batch has the same shape.  (Not used
+    # kernels (immediate-mode fallback).  One-time cost in the warm-up; every batch has one of four shapes.  (Not used
     # for the training workload: the backward searches take minutes.)
     torch.backends.cudnn.benchmark = os.environ.get("SRBH_MIOPEN_FIND", "1") == "1"
-    batch = args.batch if args.batch != 32 else 128     # 288 GB of HBM: larger batches amortise the stock-op encoder's small launches
-    n_warm = min(args.warmup, 2)
-    todo = [int(c) for c in counts[:args.steps]]
+    if small:
+        order = np.argsort(np.abs(np.log(counts) - np.log(np.median(counts))))
+        todo = [int(counts[i]) for i in sorted(order[:n_cities])]
+    else:
+        todo = [int(c) for c in counts[:n_cities]]
     pad_to = 32 if batch % 32 == 0 and batch > 32 else None          # ragged tails run as 32/64/96/... tiles, not the full batch
+    n_warm = min(warmup, 2)
     warm = [min(int(c), 256) for c in counts[-n_warm:]] if n_warm else []
-    if pad_to and args.warmup:
+    if pad_to:
         # every padded tail shape once on every rank (MIOpen searches per tensor shape; outside the timed region)
         with torch.no_grad():
             xw = torch.randn((batch, 8, 64, 64), device=dev) * 0.25 + 0.35
@@ -180,71 +321,34 @@ def bench_predict(args, rank, world, dev, dist):
         out = m.finalize() if rank == 0 else None
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t[0])
+        (dt,) = _max_over_ranks([dt], dev, dist)
         del m, out, tiles
         return dt
 
     for i, n in enumerate(warm):
         city(n, 99 + i)
     lat = [city(n, 2024 + i) for i, n in enumerate(todo)]
-    if rank == 0:
-        total, elapsed = sum(todo), sum(lat)
-        order = sorted(range(len(lat)), key=lambda i: lat[i])
-        mid = order[len(order) // 2]
-        print(json.dumps({
-            "metric": "tiles/sec (64x64x8ch->256x256 height) tiled inference incl. quantise + mosaic", "value": round(total / elapsed, 2),
-            "unit": "tiles/s", "n_gpus": world, "steps": len(todo), "warmup": args.warmup, "ms_per_step": round(elapsed / len(todo) * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f16 operands/f32 acc (RRDB), f32 (head), integer mosaic", "data": "synthetic cities, random-init weights",
-            "config": {"workload": f"sliding-window predict path, {len(todo)} of 301 synthetic cities (cells log-uniform 200..20000, "
-                                   f"seed 2024), batch {batch}/GPU (BASELINE.json configs[4])",
-                       "cities": len(todo), "tiles": total, "parallelism": f"each city's cells sharded x{world}, integer mosaic row bands gathered on rank 0"},
-            "p50_city_latency_ms": round(lat[mid] * 1e3, 2), "p50_city_tiles": todo[mid],
-            "max_city_latency_ms": round(max(lat) * 1e3, 2), "max_city_tiles": max(todo)}), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    torch.backends.cudnn.benchmark = False
+    if rank != 0:
+        return None
+    total, elapsed = sum(todo), sum(lat)
+    order = sorted(range(len(lat)), key=lambda i: lat[i])
+    mid = order[len(order) // 2]
+    return {
+        "metric": "tiles/sec (64x64x8ch->256x256 height) tiled inference incl. quantise + mosaic", "value": round(total / elapsed, 2),
+        "unit": "tiles/s", "n_gpus": world, "steps": len(todo), "warmup": warmup, "ms_per_step": round(elapsed / len(todo) * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f16 operands/f32 acc (RRDB), f32 (head), integer mosaic", "data": "synthetic cities, random-init weights",
+        "config": {"workload": f"sliding-window predict path, {len(todo)} of 301 synthetic cities (cells log-uniform 200..20000, "
+                               f"seed 2024{', the ones closest to the median size' if small else ''}), batch {batch}/GPU (BASELINE.json configs[4])",
+                   "cities": len(todo), "tiles": total, "parallelism": f"each city's cells sharded x{world}, integer mosaic row bands sent to rank 0"},
+        "p50_city_latency_ms": round(lat[mid] * 1e3, 2), "p50_city_tiles": todo[mid],
+        "max_city_latency_ms": round(max(lat) * 1e3, 2), "max_city_tiles": max(todo)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="tiles per GPU per step (configs[1]: 32)")
-    ap.add_argument("--num-block", type=int, default=23)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["feature", "train", "predict"], default="feature",
-                    help="feature = BASELINE configs[1] (default); train = configs[2]: full training step, batch 64; "
-                         "predict = configs[4]: tiled city inference incl. mosaic, one city per step (try --steps 12)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback for the hot path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    from oracle import synth  # synthetic weights/inputs only (the checker itself runs in cpu_baseline)
+def bench_feature(args, rank, world, dev, dist):
+    from srbh_amd import synth
     from srbh_amd.rrdbnet import RRDBNet
-
-    if args.workload == "train":
-        return bench_train(args, rank, world, dev, dist)
-    if args.workload == "predict":
-        return bench_predict(args, rank, world, dev, dist)
-
     sd = synth.rrdbnet_state_dict(num_block=args.num_block, seed=1337, mode="init")
     net = RRDBNet(3, 3, num_block=args.num_block)
     net.load_state_dict(sd, strict=True)
@@ -279,63 +383,123 @@ def main():
     gpu_ms = ev0.elapsed_time(ev1)
     assert bool(torch.isfinite(y[0, :, ::16, ::16]).all())
     net.check_status()   # persistent-kernel error word (outside the timed region)
+    elapsed, gpu_ms = _max_over_ranks([elapsed, gpu_ms], dev, dist)
+    if rank != 0:
+        return None
+    tiles = B * args.steps * world
+    step_s_events = gpu_ms / 1e3 / args.steps
+    achieved = GFLOP_PER_TILE_FEATURE * (args.num_block * 5.8886 + 11.19) / 146.630 if args.num_block != 23 \
+        else GFLOP_PER_TILE_FEATURE
+    tflops = achieved * B / step_s_events / 1e3
+    # ---- roofline of the dominant kernel: the persistent trunk (the 345 dense-block convs = 92 % of the FLOPs, ~90 % of
+    # the time).  Its launch duration is measured live with HIP events recorded on the stream it is launched on
+    # (libsrbh's srbh_trunk_timing hook), over extra forwards outside the timed region.
+    import ctypes
+    from srbh_amd import _lib
+    L = _lib.lib()
+    trunk_gflop_tile = args.num_block * 3 * 4096 * 18 * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64) / 1e9
+    trunk_ms = None
+    if L.srbh_trunk_timing(1) == 0:
+        acc, nrep = 0.0, max(5, min(20, args.steps))
+        for _ in range(nrep):
+            step()
+            ms = ctypes.c_float(0.0)
+            _lib.check(L.srbh_trunk_last_ms(ctypes.byref(ms)), "srbh_trunk_last_ms")
+            acc += ms.value
+        L.srbh_trunk_timing(0)
+        trunk_ms = acc / nrep
+    trunk_tflops = trunk_gflop_tile * B / (trunk_ms / 1e3) / 1e3 if trunk_ms else None
+    traffic, traffic_src = (None, None)
+    if B == 32 and args.num_block == 23:
+        traffic, traffic_src = _recorded_traffic()
+    kname = "unknown"
+    try:
+        kname = L.srbh_trunk_kernel_name().decode()
+    except Exception:
+        pass
+    line = {
+        "metric": "tiles/sec (64x64x8ch->256x256 height)", "value": round(tiles / elapsed, 2), "unit": "tiles/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f16 operands / f32 accumulate (MFMA), f32 residual stream",
+        "data": "synthetic uniform[0,1) tiles, random-init weights (no datasets/checkpoints offline)",
+        "config": {"workload": f"RRDBNet x4 ({args.num_block} RRDB, 64 feat) forward_feature, batch {B} tiles/GPU, "
+                               "64x64x3 -> 64x256x256 (BASELINE.json configs[1])",
+                   "global_batch": B * world, "parallelism": f"tile-sharded x{world} (no data-path collective)"},
+        "roofline": {"bound": "mfma", "achieved": round(trunk_tflops, 2) if trunk_tflops else None, "peak": PEAK_F16_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(trunk_tflops / PEAK_F16_TFLOPS, 4) if trunk_tflops else None,
+                     "traffic": traffic,
+                     "traffic_source": (f"{traffic_src} (RECORDED: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                        "command, FETCH doubled per the guide; not measured in this run)") if traffic_src else None,
+                     "kernel": f"{kname} (persistent trunk: 345 dense-block 3x3 convs in one launch)",
+                     "avg_launch_ms": round(trunk_ms, 4) if trunk_ms else None,
+                     "algorithmic_gflop_per_launch": round(trunk_gflop_tile * B, 1),
+                     "whole_forward": {"achieved": round(tflops, 2), "frac": round(tflops / PEAK_F16_TFLOPS, 4),
+                                       "gflop": round(achieved * B, 1), "ms": round(step_s_events * 1e3, 4)}},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(sd)
+    return line
 
-    if dist is not None:
-        t = torch.tensor([elapsed, gpu_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, gpu_ms = float(t[0]), float(t[1])
 
+def _compact(d, drop=("higher_is_better", "vs_baseline", "warmup", "unit", "scaling")):
+    return {k: v for k, v in d.items() if k not in drop} if d else d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="tiles per GPU per step (configs[1]: 32)")
+    ap.add_argument("--num-block", type=int, default=23)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="default run: skip the train_step / predict sub-objects")
+    ap.add_argument("--workload", choices=["feature", "train", "predict", "epoch"], default="feature",
+                    help="feature = BASELINE configs[1] (default; carries bounded train_step / predict sub-objects); train = "
+                         "configs[2]: full training step, batch 64; epoch = configs[3]: one DP pass over 31 500 synthetic tiles; "
+                         "predict = configs[4]: tiled city inference incl. mosaic, one city per step (try --steps 12)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback for the hot path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    tb = args.batch if args.batch != 32 else 64
+    pb = args.batch if args.batch != 32 else 128
+    if args.workload == "train":
+        line = bench_train(args, rank, world, dev, dist, args.steps, args.warmup, batch=tb)
+    elif args.workload == "epoch":
+        line = bench_train(args, rank, world, dev, dist, 0, args.warmup, batch=tb, epoch_tiles=31500, with_kernels=False)
+    elif args.workload == "predict":
+        line = bench_predict(args, rank, world, dev, dist, args.steps, args.warmup, batch=pb)
+    else:
+        line = bench_feature(args, rank, world, dev, dist)
+        if not args.no_extras and args.num_block == 23 and args.batch == 32:
+            extras = {}
+            for key, fn in (("train_step", lambda: bench_train(args, rank, world, dev, dist, 5, 2, batch=64,
+                                                                with_cpu=not args.no_cpu_baseline)),
+                            ("predict", lambda: bench_predict(args, rank, world, dev, dist, 5, 1, batch=128, small=True))):
+                try:
+                    extras[key] = _compact(fn())
+                except Exception as e:          # the headline must survive a failing extra (and say so)
+                    extras[key] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
+            if line is not None:
+                line.update(extras)
     if rank == 0:
-        tiles = B * args.steps * world
-        step_s_events = gpu_ms / 1e3 / args.steps
-        achieved = GFLOP_PER_TILE_FEATURE * (args.num_block * 5.8886 + 11.19) / 146.630 if args.num_block != 23 \
-            else GFLOP_PER_TILE_FEATURE
-        tflops = achieved * B / step_s_events / 1e3
-        # ---- roofline of the dominant kernel: ptrunk_kernel (the 345 dense-block convs = 92 % of the FLOPs, ~90 % of the
-        # time).  Its launch duration is measured live with HIP events recorded on the stream it is launched on
-        # (libsrbh's srbh_trunk_timing hook), over extra forwards outside the timed region.
-        from importlib import import_module
-        _lib = import_module("srbh_amd._lib")
-        L = _lib.lib()
-        trunk_gflop_tile = args.num_block * 3 * 4096 * 18 * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64) / 1e9
-        trunk_ms = None
-        if L.srbh_trunk_timing(1) == 0:
-            import ctypes
-            acc, nrep = 0.0, max(5, min(20, args.steps))
-            for _ in range(nrep):
-                step()
-                ms = ctypes.c_float(0.0)
-                _lib.check(L.srbh_trunk_last_ms(ctypes.byref(ms)), "srbh_trunk_last_ms")
-                acc += ms.value
-            L.srbh_trunk_timing(0)
-            trunk_ms = acc / nrep
-        trunk_tflops = trunk_gflop_tile * B / (trunk_ms / 1e3) / 1e3 if trunk_ms else None
-        traffic = None   # HBM bytes per ptrunk launch from the PMC passes recorded under profiles/ (same command, B=32)
-        try:
-            if B == 32 and args.num_block == 23:
-                traffic = json.load(open(os.path.join(ROOT, "profiles", PMC_JSON)))["dominant_kernel_hbm_bytes_per_launch"]
-        except Exception:
-            pass
-        line = {
-            "metric": "tiles/sec (64x64x8ch->256x256 height)", "value": round(tiles / elapsed, 2), "unit": "tiles/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16 operands / f32 accumulate (MFMA), f32 residual stream",
-            "data": "synthetic uniform[0,1) tiles, random-init weights (no datasets/checkpoints offline)",
-            "config": {"workload": f"RRDBNet x4 ({args.num_block} RRDB, 64 feat) forward_feature, batch {B} tiles/GPU, "
-                                   "64x64x3 -> 64x256x256 (BASELINE.json configs[1])",
-                       "global_batch": B * world, "parallelism": f"tile-sharded x{world} (no data-path collective)"},
-            "roofline": {"bound": "mfma", "achieved": round(trunk_tflops, 2) if trunk_tflops else None, "peak": PEAK_F16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(trunk_tflops / PEAK_F16_TFLOPS, 4) if trunk_tflops else None,
-                         "traffic": traffic,
-                         "kernel": "ptrunk_kernel (persistent trunk: 345 dense-block 3x3 convs in one launch)",
-                         "avg_launch_ms": round(trunk_ms, 4) if trunk_ms else None,
-                         "algorithmic_gflop_per_launch": round(trunk_gflop_tile * B, 1),
-                         "whole_forward": {"achieved": round(tflops, 2), "frac": round(tflops / PEAK_F16_TFLOPS, 4),
-                                           "gflop": round(achieved * B, 1), "ms": round(step_s_events * 1e3, 4)}},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -138,6 +138,9 @@ int srbh_rrdbnet_last_status(const void* ws, int B, int H, int W, int want_forwa
  * srbh_trunk_last_ms() synchronises on the closing event and returns that launch's duration in milliseconds. */
 int srbh_trunk_timing(int on);
 int srbh_trunk_last_ms(float* ms);
+/* Name of the device kernel the last persistent-trunk launch of this process used ("none" before the first one):
+ * lets bench.py label its roofline with the kernel that actually ran (it is what rocprofv3 lists). */
+const char* srbh_trunk_kernel_name(void);
 
 /* ==== head: HR feature / fusion / regression modules (SR/HRfuse.py), fp32 ==========================
  * Tensors are NHWC fp32 ([B][H][W][C]; a torch channels_last (B,C,H,W) tensor has exactly this memory).

@@ -157,6 +157,7 @@ SIGNATURES = {
     "srbh_confusion_add": (_i, [_vp, _vp, C.c_long, _i, _vp, _vp, _vp]),
     "srbh_trunk_timing": (_i, [_i]),
     "srbh_trunk_last_ms": (_i, [C.POINTER(C.c_float)]),
+    "srbh_trunk_kernel_name": (C.c_char_p, []),
     "srbh_rrdbnet_forward": (_i, [C.POINTER(RRDBNetDesc), _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 

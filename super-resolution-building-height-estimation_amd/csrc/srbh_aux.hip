@@ -214,11 +214,8 @@ extern "C" int srbh_conv_first_f32(const float* x, const float* w, const float* 
         hipLaunchKernelGGL(conv_first_kernel<3>, dim3((total + 255) / 256), dim3(256), lds, (hipStream_t)stream, x, w, bias,
                            B, cin, H, W, ra, rb, rc, (char*)out16, g.row_b, g.plane_b, g.img_b);
     else {
-        static bool set = false;
-        if (lds > 65536 && !set) {
-            SRBH_HIP(hipFuncSetAttribute((const void*)conv_first_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 56 * 9 * 64 * 4));
-            set = true;
-        }
+        if (lds > 65536)
+            SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)conv_first_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 56 * 9 * 64 * 4)));
         hipLaunchKernelGGL(conv_first_kernel<0>, dim3((total + 255) / 256), dim3(256), lds, (hipStream_t)stream, x, w, bias,
                            B, cin, H, W, ra, rb, rc, (char*)out16, g.row_b, g.plane_b, g.img_b);
     }

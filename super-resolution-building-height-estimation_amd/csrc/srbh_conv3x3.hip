@@ -30,12 +30,8 @@ using namespace srbh_k;
 template <int CB, int UPS>
 int launch(const KParams& p, hipStream_t stream) {
     constexpr int LDS_B = lds_bytes<CB, UPS>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        SRBH_HIP(hipFuncSetAttribute((const void*)conv3x3_f16_kernel<CB, UPS>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
-        attr_set = true;
-    }
+    SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)conv3x3_f16_kernel<CB, UPS>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)));
     hipLaunchKernelGGL((conv3x3_f16_kernel<CB, UPS>), dim3(p.nblocks), dim3(256), LDS_B, stream, p);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;

@@ -422,12 +422,8 @@ int launch_hconv(HParams& p, int B, int H, int W, hipStream_t st) {
     p.tiles_per_img = p.tiles_x * ((H + 4 * RPW - 1) / (4 * RPW));
     const int nblocks = p.tiles_per_img * B;
     if (LDS_B > 65536) {
-        static bool set = false;
-        if (!set) {
-            SRBH_HIP(hipFuncSetAttribute((const void*)hconv_f32_kernel<NOB, KS, RPW>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
-            set = true;
-        }
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hconv_f32_kernel<NOB, KS, RPW>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)));
     }
     hipLaunchKernelGGL((hconv_f32_kernel<NOB, KS, RPW>), dim3(nblocks), dim3(256), LDS_B, st, p);
     SRBH_HIP(hipGetLastError());

@@ -366,19 +366,11 @@ extern "C" int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream) {
     const int gx = p.ntiles < 512 ? p.ntiles : 512;
     if (a->ksize == 3) {
         constexpr int LDS_B = (10 * 66 * 16 + 4 * 9 * 256) * 4;   // X tile + max(dY tile, flush buffer)
-        static bool set = false;
-        if (!set) {
-            SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_f32_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
-            set = true;
-        }
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_f32_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)));
         hipLaunchKernelGGL(hwgrad_f32_kernel<3>, dim3(gx, nob), dim3(256), LDS_B, st, p);
     } else {
         constexpr int LDS_B = (8 * 64 * 16 + 8 * 64 * 16) * 4;
-        static bool set = false;
-        if (!set) {
-            SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_f32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
-            set = true;
-        }
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_f32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)));
         hipLaunchKernelGGL(hwgrad_f32_kernel<1>, dim3(gx, nob), dim3(256), LDS_B, st, p);
     }
     SRBH_HIP(hipGetLastError());

@@ -30,6 +30,19 @@ int hip_fail(hipError_t e, const char* what);
         }                                  \
     } while (0)
 
+// hipFuncSetAttribute applies to the CURRENT device only (one process may drive several GPUs): run `stmt` the first
+// time this call site is reached on each device.
+#define SRBH_ONCE_PER_DEVICE(stmt)                        \
+    do {                                                  \
+        static unsigned long long done_ = 0;              \
+        int dev_ = 0;                                     \
+        SRBH_HIP(hipGetDevice(&dev_));                    \
+        if (!((done_ >> (dev_ & 63)) & 1ull)) {           \
+            stmt;                                         \
+            done_ |= 1ull << (dev_ & 63);                 \
+        }                                                 \
+    } while (0)
+
 // ACT16 geometry: [B][chunks][H+2][W+2][32] fp16 + read slack so tiled kernels may over-read.
 struct Act16Geo {
     int row_b;       // bytes per padded row

@@ -81,22 +81,27 @@ __global__ __launch_bounds__(256) void cedice_kernel(const float* __restrict__ z
 #pragma unroll
         for (int c = 0; c < MAXC; ++c)
             if (c < g.C) { v[c] = zp[c * g.cs]; m = fmaxf(m, v[c]); }
+        const int yy = (int)y[i];
+        // nll = log(sum exp(z - m)) - (z_y - m): the log-softmax form (what nn.CrossEntropyLoss computes); taking
+        // -log(exp(z_y - m) / sum) instead underflows to +inf once the target logit is ~87 below the maximum.
+        // A label outside [0, C) raises in the reference; a kernel cannot, so it poisons the CE sum with NaN (loud).
+        float zy = __builtin_nanf("");
         float se = 0.f;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c)
-            if (c < g.C) { v[c] = expf(v[c] - m); se += v[c]; }
+            if (c < g.C) {
+                const float d = v[c] - m;
+                if (c == yy) zy = d;
+                v[c] = expf(d);
+                se += v[c];
+            }
         const float inv = 1.f / se;
-        const int yy = (int)y[i];
         const float wi = w ? w[i] : 1.f;
         const float s0 = v[0] * inv;
         const float tb = yy > 0 ? 1.f : 0.f;
         if (!GRAD) {
-            float sy = 0.f;
-#pragma unroll
-            for (int c = 0; c < MAXC; ++c)
-                if (c == yy) sy = v[c] * inv;
             const float pb = 1.f - s0;
-            acc[0] += (double)(-wi * logf(sy));
+            acc[0] += (double)(wi * (logf(se) - zy));
             acc[1] += (double)(pb * tb);
             acc[2] += (double)pb;
             acc[3] += (double)tb;

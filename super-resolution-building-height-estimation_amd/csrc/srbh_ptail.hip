@@ -213,15 +213,12 @@ template <int UPS>
 int launch(const TParams& p0, hipStream_t stream) {
     constexpr int LDS_B = W_RES_B + 2 * TileGeo<UPS>::UNITS * 16;
     static_assert(LDS_B <= 163840, "resident weights + both input chunks must fit the 160 KiB LDS");
-    static bool attr_set = false;
-    static int ncu = 0;
-    if (!attr_set) {
-        SRBH_HIP(hipFuncSetAttribute((const void*)ptail_kernel<UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
-        int dev = 0;
-        SRBH_HIP(hipGetDevice(&dev));
-        SRBH_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        attr_set = true;
-    }
+    SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)ptail_kernel<UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)));
+    static int ncu_of[64] = {0};   // CU count per device (queried once each)
+    int dev = 0;
+    SRBH_HIP(hipGetDevice(&dev));
+    if (!ncu_of[dev & 63]) SRBH_HIP(hipDeviceGetAttribute(&ncu_of[dev & 63], hipDeviceAttributeMultiprocessorCount, dev));
+    const int ncu = ncu_of[dev & 63];
     TParams p = p0;
     const int nwg = p.ntiles < ncu ? p.ntiles : ncu;
     p.tiles_per_wg = (p.ntiles + nwg - 1) / nwg;

@@ -18,6 +18,8 @@
 // multiProcessorCount workgroups per call (sub-batches of images) and every spin is bounded -- on timeout the launch
 // sets an error word and drains instead of hanging.
 #include <stdlib.h>
+#include <string.h>
+#include <mutex>
 #include "srbh_conv3x3_kernel.h"
 
 
@@ -1018,6 +1020,7 @@ namespace srbh {
 unsigned long long* g_ptrunk_prof = nullptr;   // set by tools/convbench only
 static int g_trunk_timing = 0;                 // srbh_trunk_timing(): HIP events around the trunk launch(es), on their stream
 static hipEvent_t g_trunk_ev[2];
+static const char* g_trunk_kernel = "none";    // srbh_trunk_kernel_name()
 
 constexpr int MAX_BLOCKS = 64;   // layer-table capacity (RRDB blocks)
 static size_t table_bytes() { return ((size_t)MAX_BLOCKS * 15 * sizeof(PLayer) + 255) & ~(size_t)255; }
@@ -1025,6 +1028,42 @@ static size_t prog_bytes(int B, int tpi) { return ((size_t)B * 2 * tpi * sizeof(
 
 size_t ptrunk_aux_bytes(int B, int tiles_per_img) { return table_bytes() + 2 * prog_bytes(B, tiles_per_img) + 256; }
 size_t ptrunk_err_offset(int B, int tiles_per_img) { return table_bytes() + prog_bytes(B, tiles_per_img); }
+
+// The layer table depends only on the packed-weight pointers and num_block: it is uploaded ONCE per (device, contents)
+// into a library-owned buffer and reused by every later forward (the per-call hipMemcpyAsync from pageable memory
+// stalled the host on every forward and made forward_feature uncapturable in a HIP graph).  A handful of entries
+// (several nets alive at once); a miss uploads synchronously.
+struct TabEntry {
+    int dev;
+    std::vector<char> host;
+    PLayer* dptr;
+};
+static std::mutex g_tab_mu;
+static std::vector<TabEntry> g_tabs;
+
+static int device_table(const std::vector<PLayer>& tab, PLayer** out) {
+    int dev = 0;
+    SRBH_HIP(hipGetDevice(&dev));
+    const size_t nb = tab.size() * sizeof(PLayer);
+    std::lock_guard<std::mutex> lock(g_tab_mu);
+    for (size_t i = 0; i < g_tabs.size(); ++i)
+        if (g_tabs[i].dev == dev && g_tabs[i].host.size() == nb && memcmp(g_tabs[i].host.data(), tab.data(), nb) == 0) {
+            *out = g_tabs[i].dptr;
+            return SRBH_OK;
+        }
+    if (g_tabs.size() >= 16) {   // evict the oldest (hipFree synchronises the device: nobody still reads it)
+        SRBH_HIP(hipFree(g_tabs.front().dptr));
+        g_tabs.erase(g_tabs.begin());
+    }
+    TabEntry e;
+    e.dev = dev;
+    e.host.assign((const char*)tab.data(), (const char*)tab.data() + nb);
+    SRBH_HIP(hipMalloc(&e.dptr, nb));
+    SRBH_HIP(hipMemcpy(e.dptr, tab.data(), nb, hipMemcpyHostToDevice));
+    *out = e.dptr;
+    g_tabs.push_back(std::move(e));
+    return SRBH_OK;
+}
 
 static void build_table(const srbh_rrdbnet_desc* d, std::vector<PLayer>& tab, int* final_cur) {
     int cur = 0, li = 0;
@@ -1051,11 +1090,7 @@ static int ptrunk2_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, f
     int ncu = 0;
     SRBH_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     const int tpi = (H + T2_H - 1) / T2_H;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_B));
-        attr_set = true;
-    }
+    SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_B)));
     int per_cu = 0;
     SRBH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ptrunk2_kernel, 256, T2_LDS_B));
     if (per_cu < 2 || tpi > per_cu * ncu) return SRBH_OK;
@@ -1065,11 +1100,11 @@ static int ptrunk2_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, f
     build_table(d, tab, final_cur);
     const int tpi8 = (H + TILE_H - 1) / TILE_H;
     char* a = (char*)aux;
-    PLayer* d_tab = (PLayer*)a;
+    PLayer* d_tab = nullptr;
+    if (int rc = device_table(tab, &d_tab)) return rc;
     int* d_prog = (int*)(a + table_bytes());
     int* d_err = (int*)(a + ptrunk_err_offset(B, tpi8));
     int* d_xcc = (int*)(a + ptrunk_err_offset(B, tpi8) + 256);
-    SRBH_HIP(hipMemcpyAsync(d_tab, tab.data(), (size_t)nl * sizeof(PLayer), hipMemcpyHostToDevice, stream));
     SRBH_HIP(hipMemsetAsync(d_prog, 0, (size_t)B * tpi * sizeof(int), stream));
     SRBH_HIP(hipMemsetAsync(d_err, 0, sizeof(int), stream));
     SRBH_HIP(hipMemsetAsync(d_xcc, 0, (size_t)B * tpi * sizeof(int), stream));
@@ -1102,6 +1137,7 @@ static int ptrunk2_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, f
         const char* fr = getenv("SRBH_PT_FRAGRES");
         pp.frag_res = (W == TILE_W) && !(fr && atoi(fr) == 0);
         if (g_trunk_timing && b0 == 0) SRBH_HIP(hipEventRecord(g_trunk_ev[0], stream));
+        g_trunk_kernel = "ptrunk2_kernel";
         hipLaunchKernelGGL(ptrunk2_kernel, dim3(pp.nblocks), dim3(256), T2_LDS_B, stream, pp);
         SRBH_HIP(hipGetLastError());
     }
@@ -1150,13 +1186,11 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
     const int tpi = (H + TILE_H - 1) / TILE_H;
     if (tpi > ncu) return SRBH_OK;
     constexpr int LDS_B = P_LDS_B;
-    static bool attr_set = false;
-    if (!attr_set) {
+    SRBH_ONCE_PER_DEVICE({
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
-        attr_set = true;
-    }
+    });
     int per_cu = 0;
     SRBH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ptrunk_kernel<false, true>, 256, LDS_B));
     if (per_cu < 1) return SRBH_OK;
@@ -1181,10 +1215,10 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
         }
     *final_cur = cur;
     char* a = (char*)aux;
-    PLayer* d_tab = (PLayer*)a;
+    PLayer* d_tab = nullptr;
+    if (int rc = device_table(tab, &d_tab)) return rc;
     int* d_prog = (int*)(a + table_bytes());
     int* d_err = (int*)(a + ptrunk_err_offset(B, tpi));
-    SRBH_HIP(hipMemcpyAsync(d_tab, tab.data(), (size_t)nl * sizeof(PLayer), hipMemcpyHostToDevice, stream));
     SRBH_HIP(hipMemsetAsync(d_prog, 0, (size_t)B * tpi * sizeof(int) , stream));
     SRBH_HIP(hipMemsetAsync(d_err, 0, sizeof(int), stream));
     int* d_xcc = (int*)(a + ptrunk_err_offset(B, tpi) + 256);
@@ -1222,6 +1256,7 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
             pp.frag_res = (W == TILE_W) && !(e && atoi(e) == 0);
         }
         if (g_trunk_timing && b0 == 0) SRBH_HIP(hipEventRecord(g_trunk_ev[0], stream));
+        g_trunk_kernel = "ptrunk_kernel";
         if (pp.prof)
             hipLaunchKernelGGL((ptrunk_kernel<true, true>), dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
         else if (reg_res)
@@ -1275,6 +1310,8 @@ extern "C" int srbh_trunk_timing(int on) {
     g_trunk_timing = on ? 1 : 0;
     return SRBH_OK;
 }
+
+extern "C" const char* srbh_trunk_kernel_name(void) { return srbh::g_trunk_kernel; }
 
 extern "C" int srbh_trunk_last_ms(float* ms) {
     using namespace srbh;

@@ -19,6 +19,17 @@ struct WsLayout {
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// The persistent trunk kernel needs every workgroup co-resident; if something else holds CUs / LDS its bounded spins
+// time out, it sets an error word and drains, and the kernels behind it would run on stale activations.  This guard
+// runs last in the forward: error word clear -> every workgroup returns at once; set -> the whole output becomes NaN,
+// so a timed-out launch can never be mistaken for a result (features, mosaics and losses all turn NaN).  The host-side
+// check (srbh_rrdbnet_last_status) stays the way to get the reason.
+__global__ __launch_bounds__(256) void poison_on_error_kernel(const int* __restrict__ err, float* __restrict__ out, size_t n) {
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+    const float nan = __builtin_nanf("");
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = nan;
+}
+
 WsLayout ws_layout(int B, int H, int W, int want_forward) {
     WsLayout L;
     size_t off = 0;
@@ -127,9 +138,18 @@ extern "C" int srbh_rrdbnet_forward(const srbh_rrdbnet_desc* d, const float* x, 
     a.in = U3; a.in_chunks_total = 2; a.in_chunk0 = 0; a.in_chunks = 2;
     a.w = d->conv_hr.w; a.bias = d->conv_hr.bias; a.cout = 64;
     a.B = B; a.H = 4 * H; a.W = 4 * W;
+    const int* err_word = (const int*)(base + L.aux + ptrunk_err_offset(B, (H + TILE_H - 1) / TILE_H));
+    auto guard = [&](int out_c) -> int {
+        if (!used_persistent) return SRBH_OK;
+        hipLaunchKernelGGL(poison_on_error_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, err_word, out,
+                           (size_t)B * 16 * H * W * out_c);
+        SRBH_HIP(hipGetLastError());
+        return SRBH_OK;
+    };
     if (!want_forward) {
         a.out32 = out; a.out32_c = 64;
-        return srbh_conv3x3_f16(&a, stream);
+        if ((rc = srbh_conv3x3_f16(&a, stream))) return rc;
+        return guard(64);
     }
     a.lrelu = 1;
     a.out16 = U4; a.out16_chunks_total = 2; a.out16_chunk0 = 0;
@@ -141,7 +161,8 @@ extern "C" int srbh_rrdbnet_forward(const srbh_rrdbnet_desc* d, const float* x, 
     a.w = d->conv_last.w; a.bias = d->conv_last.bias; a.cout = 32;
     a.B = B; a.H = 4 * H; a.W = 4 * W;
     a.out32 = out; a.out32_c = d->num_out_ch;
-    return srbh_conv3x3_f16(&a, stream);
+    if ((rc = srbh_conv3x3_f16(&a, stream))) return rc;
+    return guard(d->num_out_ch);
 }
 
 extern "C" int srbh_rrdbnet_last_status(const void* ws, int B, int H, int W, int want_forward, void* stream) {

@@ -51,8 +51,9 @@ def shard_range(n_items, rank, world):
 
 
 def allreduce_grads(params, world, dist=None, bucket_bytes=64 << 20):
-    """Average gradients over ranks with few large all-reduces (RCCL over xGMI is per-link bound: prefer big buckets).
-    Parameters without a gradient (e.g. the unused encoder._conv_head) are skipped on every rank alike."""
+    """Average gradients over ranks with few large all-reduces AFTER backward (RCCL over xGMI is per-link bound: prefer big
+    buckets).  Parameters without a gradient (e.g. the unused encoder._conv_head) are skipped on every rank alike.
+    This is the simple post-backward sweep; `GradReducer` below overlaps the same reduction with backward."""
     if world <= 1:
         return 0
     if dist is None:
@@ -79,11 +80,148 @@ def allreduce_grads(params, world, dist=None, bucket_bytes=64 << 20):
     return len(buckets)
 
 
+class GradReducer:
+    """Gradient all-reduce overlapped with backward (one process per GPU, RCCL over xGMI).
+
+    Step 1 runs the post-backward sweep and RECORDS the order in which gradients became ready (autograd
+    post-accumulate hooks); from it a static bucket plan is built -- parameters grouped in ready order into buckets of
+    ~`bucket_bytes`, parameters that never receive a gradient (encoder._conv_head / _bn1) left out on every
+    rank alike.  From step 2 on, the hook of a bucket's LAST parameter copies that bucket's gradients into its
+    persistent flat buffer and launches ONE asynchronous all-reduce, so the early buckets (heads, decoders: the first
+    gradients backward produces) travel while the encoder's backward still runs; `finish()` waits, divides by the
+    world size and scatters the averages back into `.grad`.  xGMI is point-to-point (ring collectives are per-link
+    bound), so buckets are tens of MB: large enough to run at link rate, small enough that only the last one is
+    exposed.  `exposed_ms` (timing=True) is the device time between the end of backward and the last bucket landing."""
+
+    def __init__(self, params, world, dist=None, bucket_bytes=24 << 20, timing=False):
+        self.params = [p for p in params if p.requires_grad]
+        self.world = world
+        if dist is None and world > 1:
+            import torch.distributed as dist
+        self.dist = dist
+        self.bucket_bytes = bucket_bytes
+        self.timing = timing
+        self.plan = None             # list of buckets: [(param, offset, numel)], flat buffer, trigger param id
+        self._order = []
+        self._ready = {}
+        self._work = []
+        self._hooks = []
+        self.exposed_ms = []
+        self.n_buckets = 0
+        if world > 1:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    # ---- autograd hook: runs as soon as p.grad is final for this backward
+    def _on_grad(self, p):
+        if self.plan is None:
+            self._order.append(p)
+            return
+        b = self._bucket_of.get(id(p))
+        if b is None:
+            return
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        flat = b["flat"]
+        torch._foreach_copy_([flat[o:o + n].view_as(q.grad) for q, o, n in b["items"]], [q.grad for q, _, _ in b["items"]])
+        self._work.append((b, self.dist.all_reduce(flat, async_op=True)))
+
+    def _build_plan(self):
+        buckets, cur, size = [], [], 0
+        for p in self._order:
+            cur.append(p)
+            size += p.numel() * p.element_size()
+            if size >= self.bucket_bytes:
+                buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            buckets.append(cur)
+        self.plan, self._bucket_of = [], {}
+        for ps in buckets:
+            items, off = [], 0
+            for q in ps:
+                items.append((q, off, q.numel()))
+                off += q.numel()
+            b = {"items": items, "flat": torch.empty(off, dtype=ps[0].dtype, device=ps[0].device), "pending": len(ps), "n": len(ps)}
+            self.plan.append(b)
+            for q in ps:
+                self._bucket_of[id(q)] = b
+        self.n_buckets = len(self.plan)
+
+    def finish(self):
+        """Call after backward, before optimizer.step()."""
+        if self.world <= 1:
+            return 0
+        if self.plan is None:        # first step: plain sweep in ready order, then freeze the bucket plan
+            seen = set()
+            self._order = [p for p in self._order if p.grad is not None and not (id(p) in seen or seen.add(id(p)))]
+            allreduce_grads(self._order, self.world, self.dist, self.bucket_bytes)
+            self._build_plan()
+            return self.n_buckets
+        ev0 = ev1 = None
+        if self.timing and self.plan[0]["flat"].is_cuda:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        for b in self.plan:          # a bucket whose parameters did not all fire (should not happen: static graph)
+            if b["pending"] != 0:
+                if b["pending"] != b["n"] or any(q.grad is None for q, _, _ in b["items"]):
+                    raise RuntimeError("GradReducer: the set of parameters receiving gradients changed between steps")
+                self._launch(b)
+        for b, w in self._work:
+            w.wait()                 # (device tensors: the current stream waits for the collective; gloo: host wait)
+            b["flat"].div_(self.world)
+            torch._foreach_copy_([q.grad for q, _, _ in b["items"]], [b["flat"][o:o + n].view_as(q.grad) for q, o, n in b["items"]])
+            b["pending"] = b["n"]
+        self._work = []
+        if ev0 is not None:
+            ev1.record()
+            self._last_events = (ev0, ev1)
+        return self.n_buckets
+
+    def pop_exposed_ms(self):
+        """device time finish() spent behind backward in the last step (timing=True; synchronises)."""
+        ev = getattr(self, "_last_events", None)
+        if ev is None:
+            return None
+        ev[1].synchronize()
+        return ev[0].elapsed_time(ev[1])
+
+    def isolated_comm_ms(self, reps=3):
+        """the all-reduces of one step on their own (nothing to overlap with): what the overlap has to hide."""
+        if self.world <= 1 or not self.plan:
+            return 0.0
+        import time
+        cuda = self.plan[0]["flat"].is_cuda
+        best = None
+        for _ in range(reps):
+            if cuda:
+                torch.cuda.synchronize()
+            self.dist.barrier()
+            t0 = time.perf_counter()
+            for b in self.plan:
+                self.dist.all_reduce(b["flat"])
+            if cuda:
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) * 1e3
+            best = dt if best is None else min(best, dt)
+        return best
+
+
 class TrainStep:
     """train.py:133-179,243-256: frozen RRDBNet feature extractor + trainable SRRegress_Cls_feature, three
-    uncertainty-weighted losses, Adam(lr 1e-3, wd 1e-4) with the log_vars as an extra param group."""
+    uncertainty-weighted losses, Adam(lr 1e-3, wd 1e-4) with the log_vars as an extra param group.
+    world > 1: gradients are averaged by `GradReducer` (bucketed all-reduce launched from autograd hooks while backward
+    is still running); ``overlap=False`` selects the plain post-backward sweep."""
 
-    def __init__(self, net_hr, net, device, world=1, lr=1e-3, sync_bn=False):
+    def __init__(self, net_hr, net, device, world=1, lr=1e-3, sync_bn=False, overlap=True, timing=False, status_every=100):
         if sync_bn and world > 1:
             # global-batch BatchNorm statistics (what the reference computes on one device): libsrbh BatchNorms all-reduce
             # their partial sums (hrfuse.set_bn_sync), the stock-op encoder / decoders become torch SyncBatchNorm
@@ -100,6 +238,9 @@ class TrainStep:
         self.optimizer = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=1e-4)
         self.optimizer.add_param_group({"params": [c.log_var for c in self.criterion], "lr": lr})
         self.rgbseq = [0, 1, 2]
+        self.reducer = GradReducer(self.params(), world, timing=timing) if (world > 1 and overlap) else None
+        self.steps = 0
+        self.status_every = status_every
 
     def params(self):
         return [p for g in self.optimizer.param_groups for p in g["params"]]
@@ -114,9 +255,54 @@ class TrainStep:
                 + self.criterion[2](build_pred, build, weight))
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        allreduce_grads(self.params(), self.world)
+        if self.reducer is not None:
+            self.reducer.finish()
+        else:
+            allreduce_grads(self.params(), self.world)
         self.optimizer.step()
+        self.steps += 1
+        # a persistent-trunk timeout NaN-poisons hr_fea (loud by itself); the host-side check names the reason.  It costs a
+        # stream synchronisation, so: after the first step (where a co-residency problem shows) and then rarely.
+        if self.steps == 1 or (self.status_every and self.steps % self.status_every == 0):
+            if hasattr(self.net_hr, "check_status"):
+                self.net_hr.check_status()
         return loss.detach(), height_pred.detach()
+
+
+def synthetic_batch_device(batch, gen, device, aggregate=None):
+    """`synthetic_batch` with every tensor drawn ON the device from the torch.Generator `gen` (device RNG): the epoch
+    driver below must not be limited by host-side synthesis or H2D copies (the reference needs 8 loader workers for 20
+    tiles/s).  Same shapes / label statistics as `synthetic_batch`."""
+    lr = torch.rand((batch, 8, 64, 64), generator=gen, device=device)
+    coarse = torch.rand((batch, 1, 32, 32), generator=gen, device=device)
+    hval = torch.rand((batch, 1, 32, 32), generator=gen, device=device) ** 3 * 120.0
+    height = torch.where(coarse > 0.82, hval, torch.zeros_like(hval))
+    height = F.interpolate(height, scale_factor=8, mode="nearest").round()
+    edges = torch.tensor(HIR[1:-1], dtype=torch.float32, device=device)
+    build = torch.bucketize(height[:, 0], edges, right=True)
+    build = torch.where(height[:, 0] <= 0, torch.zeros_like(build), build).long().clamp_(0, 6)
+    weight = torch.tensor(CLASS_WEIGHT, device=device)[build]
+    if aggregate is None:
+        from .aggregate import aggregate_torch as aggregate
+    height_aggre = aggregate(height, 0.25).reshape(batch, 64, 64)
+    weight_aggre = aggregate(weight[:, None].contiguous(), 0.25).reshape(batch, 64, 64)
+    return lr, height[:, 0], height_aggre, build, weight, weight_aggre
+
+
+def train_epoch(ts, n_tiles, batch, rank, world, device, seed=1337, max_steps=None, aggregate=None):
+    """BASELINE configs[3]: one data-parallel pass over `n_tiles` synthetic training tiles (31 500 = 45 000 x 0.7,
+    data/datalist_globe_train_0.7.csv): every rank draws its own `batch` tiles per step on the device (seed + rank +
+    step: no host synthesis, no H2D), drop_last like the reference's loader (train.py:97).  Returns (steps, tiles seen
+    by the whole job, last loss)."""
+    steps = n_tiles // (batch * world)
+    if max_steps is not None:
+        steps = min(steps, max_steps)
+    gen = torch.Generator(device=device)
+    loss = None
+    for i in range(steps):
+        gen.manual_seed(seed + 7919 * rank + 104729 * i)
+        loss, _ = ts(synthetic_batch_device(batch, gen, device, aggregate))
+    return steps, steps * batch * world, loss
 
 
 @torch.no_grad()
@@ -146,4 +332,8 @@ def predict_tiles(net_hr, model, tiles, posall, mosaic, batch=32, rank=0, world=
         hr_fea = net_hr.forward_feature(x[:, :3])
         out = model(x, hr_fea)
         mosaic.add(out[0][:k], out[1][:k], posall[s:e])
+    if hi > lo and hasattr(net_hr, "check_status"):
+        # one synchronisation per city shard: a persistent-trunk timeout (another process holding CUs / LDS) already
+        # NaN-poisoned the features; this raises with the reason instead of shipping a NaN mosaic
+        net_hr.check_status()
     return hi - lo

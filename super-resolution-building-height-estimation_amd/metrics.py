@@ -40,6 +40,7 @@ class SegmentationMetric(nn.Module):
 
     def reset(self):
         self.confusionMatrix = torch.zeros((self.numClass, self.numClass), dtype=torch.float64, device=self.device)
+        self._bad = torch.zeros((), dtype=torch.int64, device=self.device)   # out-of-range label / prediction seen (sticky)
 
     def genConfusionMatrix(self, imgPredict, imgLabel):
         """metrics.py:67-74: cm[label, pred] counts as an int64 (numClass, numClass) tensor."""
@@ -55,13 +56,23 @@ class SegmentationMetric(nn.Module):
 
     def addBatch(self, imgPredict, imgLabel):
         assert imgPredict.shape == imgLabel.shape
-        cm, _ = self.genConfusionMatrix(imgPredict, imgLabel)
+        cm, bad = self.genConfusionMatrix(imgPredict, imgLabel)
         self.confusionMatrix += cm
+        self._bad |= bad              # stays on the device: addBatch never synchronises
+
+    def check_range(self):
+        """Raise if any batch held a label / prediction outside [0, numClass): the reference's bincount
+        (metrics.py:71-73) raises on negatives or fails to reshape, a kernel can only flag.  Called where the
+        scores are read, which is a host synchronisation anyway."""
+        if int(self._bad):
+            raise ValueError("SegmentationMetric: a label or prediction outside [0, %d) was passed to addBatch" % self.numClass)
 
     def getConfusionMatrix(self):
+        self.check_range()
         return self.confusionMatrix
 
     def OverallAccuracy(self):
+        self.check_range()
         return torch.diag(self.confusionMatrix).sum() / self.confusionMatrix.sum()
 
     def Precision(self):

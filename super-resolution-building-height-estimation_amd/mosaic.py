@@ -42,17 +42,20 @@ class Mosaic:
         self.res_height += other.res_height
         self.res_build += other.res_build
         self.res_weight += other.res_weight
+        if other._rows[1] > other._rows[0]:      # the written band is now the union (reduce_to_ ships exactly this band)
+            self._rows = [min(self._rows[0], other._rows[0]), max(self._rows[1], other._rows[1])]
         return self
 
     def all_reduce_(self, dist):
         for t in (self.res_height, self.res_build, self.res_weight):
             dist.all_reduce(t)
+        self._rows = [0, self.H]                 # every rank now holds every rank's rows
         return self
 
     def reduce_to_(self, dist, dst=0):
         """Sum the ranks' mosaics into rank `dst` moving only the ROW BAND each rank has written (contiguous shards of a
         row-major grid touch contiguous bands: an 8-way shard of a 27k x 27k city gathers 27 GB / 8 per rank instead of
-        all-reducing 27 GB on every rank).  One gather of equally padded bands; afterwards only `dst` holds the city."""
+        all-reducing 27 GB on every rank).  Afterwards only `dst` holds the city."""
         world, rank = dist.get_world_size(), dist.get_rank()
         dev = self.res_height.device
         y0, y1 = (self._rows[0], self._rows[1]) if self._rows[1] > self._rows[0] else (0, 0)
@@ -60,26 +63,30 @@ class Mosaic:
         ranges = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(ranges, mine)
         ranges = [(int(r[0]), int(r[1])) for r in ranges]
-        rows = max(1, max(b - a for a, b in ranges))
-        pack = torch.zeros((self.C + 2, rows, self.W), dtype=torch.int32, device=dev)
-        n = y1 - y0
-        if n:
-            pack[0, :n] = self.res_height[y0:y1]
-            pack[1, :n] = self.res_weight[y0:y1]
-            pack[2:, :n] = self.res_build[:, y0:y1]
-        on_host = dist.get_backend() == "gloo"          # (gloo gathers host tensors; RCCL gathers device tensors)
-        send = pack.cpu() if on_host else pack
-        bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-        dist.gather(send, bufs, dst=dst)
-        if rank == dst:
-            for r, (a, b) in enumerate(ranges):
-                if r == dst or b <= a:
-                    continue
-                band = bufs[r].to(dev) if on_host else bufs[r]
-                self.res_height[a:b] += band[0, :b - a]
-                self.res_weight[a:b] += band[1, :b - a]
-                self.res_build[:, a:b] += band[2:, :b - a]
-            self._rows = [min([a for a, b in ranges if b > a] or [self.H]), max([b for a, b in ranges] or [0])]
+        on_host = dist.get_backend() == "gloo"          # (gloo moves host tensors; RCCL moves device tensors)
+        # point-to-point, one band at a time, each exactly as tall as what that rank wrote: `dst` holds ONE receive
+        # buffer (the tallest band) next to its mosaic instead of world x padded bands (which doubled its memory for a
+        # 27k x 27k city), and the senders' copies overlap with dst's accumulation of the previous band
+        if rank != dst:
+            n = y1 - y0
+            if n:
+                pack = torch.empty((self.C + 2, n, self.W), dtype=torch.int32, device=dev)
+                pack[0] = self.res_height[y0:y1]
+                pack[1] = self.res_weight[y0:y1]
+                pack[2:] = self.res_build[:, y0:y1]
+                dist.send(pack.cpu() if on_host else pack, dst=dst)
+            return self
+        for r, (a, b) in enumerate(ranges):
+            if r == dst or b <= a:
+                continue
+            band = torch.empty((self.C + 2, b - a, self.W), dtype=torch.int32, device="cpu" if on_host else dev)
+            dist.recv(band, src=r)
+            band = band.to(dev) if on_host else band
+            self.res_height[a:b] += band[0]
+            self.res_weight[a:b] += band[1]
+            self.res_build[:, a:b] += band[2:]
+            del band
+        self._rows = [min([a for a, b in ranges if b > a] or [self.H]), max([b for a, b in ranges] or [0])]
         return self
 
     def finalize(self):

@@ -223,7 +223,7 @@ class RRDBNet(nn.Module):
         if Cin != self._geom[0]:
             raise ValueError(f"expected {self._geom[0]} input channels, got {Cin}")
         with torch.cuda.device(x.device):
-            key = self._weights_key()
+            key = (self._weights_key(), str(x.device))   # packed weights live on ONE device
             if self._packed is None or self._packed[0] != key:
                 bufs, desc = self._pack(x.device)
                 self._packed = (key, bufs, desc)

@@ -1,0 +1,93 @@
+"""GPU: BASELINE configs at their STATED sizes -- the training step's model at B=64 (configs[2]) and the inference model at
+B=128 (configs[4]: 2 GiB feature tensors, i.e. byte offsets beyond 2^31) -- through size-independent properties:
+tiles are independent in eval mode (a tile of the big batch == the same tile in a batch of 2), and a training-mode
+batch is permutation-equivariant (BatchNorm statistics do not depend on the order of the tiles)."""
+import pytest
+import torch
+
+from oracle import srbh_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(seed, isaggre):
+    from tests.test_gpu_model import make_model
+    return make_model(seed=seed, isaggre=isaggre)
+
+
+def _feature_net(num_block=1, seed=3):
+    from srbh_amd.rrdbnet import RRDBNet
+    net = RRDBNet(3, 3, num_block=num_block)
+    net.load_state_dict(synth.rrdbnet_state_dict(num_block=num_block, seed=seed, mode="stress"))
+    return net.to(DEV).eval()
+
+
+def test_eval_batch128_tiles_are_independent():
+    """configs[4] batch: RRDBNet features (4 trunk sub-launches of 32 images, 2 GiB output) -> eval heads at B=128;
+    tiles 0, 31, 32, 64, 127 must equal what a batch of two produces for them."""
+    B = 128
+    net_hr = _feature_net()
+    model = _model(21, False).to(DEV).eval()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn((B, 8, 64, 64), generator=g, device=DEV) * 0.25 + 0.35
+    with torch.no_grad():
+        fea = net_hr.forward_feature(x[:, :3])
+        assert fea.numel() * 4 > 2 ** 31
+        h, b = model(x, fea)
+        net_hr.check_status()
+        assert bool(torch.isfinite(h).all()) and bool(torch.isfinite(b).all())
+        for t in (0, 31, 32, 64, 127):
+            pair = torch.stack([x[t], x[(t + 1) % B]])
+            f2 = net_hr.forward_feature(pair[:, :3])
+            assert torch.equal(f2[0], fea[t]), t                       # the trunk is batch-size independent bit for bit
+            h2, b2 = model(pair, f2)
+            # the stock-op encoder / decoders may pick other algorithms per batch size: tolerance, not equality
+            assert O.rel_l2(h2[0].cpu(), h[t].cpu()) <= 1e-4, t
+            assert O.rel_l2(b2[0].cpu(), b[t].cpu()) <= 1e-4, t
+
+
+def test_train_batch64_is_permutation_equivariant(monkeypatch):
+    """configs[2] batch: training-mode forward + backward of SRRegress_Cls_feature at B=64 (1 GiB of RRDB features).
+    Reversing the batch must reverse the outputs and leave every parameter gradient unchanged (up to summation order);
+    all gradients finite.  Guards tile indexing / offset arithmetic at B*256^2*C elements."""
+    from srbh_amd import encoders
+    monkeypatch.setattr(encoders, "DROP_CONNECT", 0.0)          # the only RNG in the model
+    B = 64
+    net_hr = _feature_net(seed=4)
+    g = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.rand((B, 8, 64, 64), generator=g, device=DEV)
+    wts = [torch.randn((B, 1, 256, 256), generator=g, device=DEV), torch.randn((B, 7, 256, 256), generator=g, device=DEV),
+           torch.randn((B, 1, 64, 64), generator=g, device=DEV)]
+    with torch.no_grad():
+        fea = net_hr.forward_feature(x[:, :3])
+    perm = torch.arange(B - 1, -1, -1, device=DEV)
+    runs = []
+    for order in (None, perm):
+        m = _model(31, True).to(DEV).train()
+        xi, fi, wi = (x, fea, wts) if order is None else (x[order], fea[order].contiguous(memory_format=torch.channels_last),
+                                                           [w[order] for w in wts])
+        outs = m(xi, fi)
+        sum((o * w).sum() for o, w in zip(outs, wi)).backward()
+        runs.append(([o.detach() for o in outs], {k: p.grad for k, p in m.named_parameters() if p.grad is not None}))
+    (o1, g1), (o2, g2) = runs
+    for a, b in zip(o1, o2):
+        assert bool(torch.isfinite(a).all())
+        assert O.rel_l2(b[perm].cpu(), a.cpu()) <= 2e-5
+    assert len(g1) > 500 and g1.keys() == g2.keys()
+    gmax = max(float(v.norm()) for v in g1.values())
+    for k in g1:
+        assert bool(torch.isfinite(g1[k]).all()), k
+        if float(g1[k].norm()) > 1e-3 * gmax:            # (gradients that are ~0 analytically carry only noise)
+            assert O.rel_l2(g2[k].cpu(), g1[k].cpu()) <= 2e-3, k
+
+
+def test_train_step_batch64_runs_and_learns():
+    """The harness' full training step at the configs[2] batch size (64): finite loss that goes down on a fixed batch."""
+    from srbh_amd.harness import TrainStep, synthetic_batch
+    net_hr = _feature_net(num_block=2, seed=2)
+    ts = TrainStep(net_hr, _model(9, True).to(DEV), DEV)
+    batch = synthetic_batch(64, 11, DEV)
+    losses = [float(ts(batch)[0]) for _ in range(4)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses

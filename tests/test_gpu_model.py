@@ -56,6 +56,43 @@ def test_model_eval_forward_matches_cpu():
         assert p.forward_nobuild(x.to(DEV), fea.to(DEV)).shape == (2, 1, 256, 256)
 
 
+@pytest.mark.parametrize("isaggre", [False, True])
+@pytest.mark.parametrize("training", [False, True])
+def test_forward_unsup_and_nobuild_values_match_cpu(monkeypatch, isaggre, training):
+    """a16 (reference mymodels.py:295-337): `forward_unsup` = squeezed height only; `forward_nobuild` = height (+ the
+    aggregated height when isaggre) without decoder2 / seg -- VALUES against the CPU reference (stock-op encoder /
+    decoder1 on CPU + the oracle head on the same state_dict), eval and train mode."""
+    from srbh_amd import encoders
+    monkeypatch.setattr(encoders, "DROP_CONNECT", 0.0)          # the only RNG in the model
+    x = synth.tiles(2, 8, 64, seed=23)
+    fea = torch.randn(2, 64, 256, 256, generator=torch.Generator().manual_seed(24)) * 0.5
+
+    def fresh():
+        m = make_model(seed=25, isaggre=isaggre)
+        return m.train(training)
+
+    with torch.no_grad():
+        mc = fresh()
+        sd = dict(mc.state_dict(keep_vars=True))
+        feats = mc.encoder(x)
+        sup = O.hrfeature(sd, "hrfeat.", fea, training)
+        hfea = mc.decoder1(*feats)
+        want_h = O.hrfuse_residual(sd, "reg.", hfea, sup, training)
+        want_a = torch.nn.functional.conv2d(hfea, sd["aggre_height.weight"], sd["aggre_height.bias"], 1, 1) if isaggre else None
+        got_u = fresh().to(DEV).forward_unsup(x.to(DEV), fea.to(DEV))
+        got_n = fresh().to(DEV).forward_nobuild(x.to(DEV), fea.to(DEV))
+    tol = 2e-4 if not training else 2e-3        # train-mode BN statistics over 2 tiles amplify MIOpen-vs-oneDNN noise
+    assert got_u.shape == (2, 256, 256)
+    assert O.rel_l2(got_u.cpu(), want_h.squeeze()) <= tol
+    if isaggre:
+        assert isinstance(got_n, tuple) and len(got_n) == 2
+        assert got_n[0].shape == (2, 1, 256, 256) and got_n[1].shape == (2, 1, 64, 64)
+        assert O.rel_l2(got_n[0].cpu(), want_h) <= tol and O.rel_l2(got_n[1].cpu(), want_a) <= tol
+    else:
+        assert torch.is_tensor(got_n) and got_n.shape == (2, 1, 256, 256)
+        assert O.rel_l2(got_n.cpu(), want_h) <= tol
+
+
 def test_model_train_step_gradients_match_cpu_autograd(monkeypatch):
     from srbh_amd import encoders
     monkeypatch.setattr(encoders, "DROP_CONNECT", 0.0)          # the only RNG in the model

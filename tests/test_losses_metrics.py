@@ -113,6 +113,20 @@ def test_hip_losses_full_size_against_oracle():
     (gr,) = torch.autograd.grad(want, [zr])
     assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want))
     assert float((gz.cpu() - gr).norm() / gr.norm()) <= 1e-5
+    # extreme logits: the target class 200 below the maximum.  exp(z_y - max) underflows, the log-softmax form stays
+    # finite exactly like nn.CrossEntropyLoss (reference losses_pytorch/selfloss.py:145-168)
+    ze = torch.zeros(1, 7, 8, 8)
+    ze[:, 3] = 200.0
+    ye = torch.zeros(1, 8, 8, dtype=torch.long)
+    zec = ze.cuda().requires_grad_(True)
+    got_e = SL.CE_DICE_adapt_weight(0.0)(zec, ye.cuda(), torch.ones(1, 8, 8).cuda())
+    want_e = LO.ce_dice_adapt_weight(ze, ye, torch.ones(1, 8, 8), torch.tensor(0.0))
+    assert bool(torch.isfinite(got_e)) and abs(float(got_e) - float(want_e)) <= 1e-5 * abs(float(want_e))
+    (ge,) = torch.autograd.grad(got_e, [zec])
+    assert bool(torch.isfinite(ge).all())
+    yb = ye.clone()
+    yb[0, 0, 0] = 7                                    # out-of-range label: the reference raises, the kernel poisons
+    assert bool(torch.isnan(SL.CE_DICE_adapt_weight(0.0)(ze.cuda(), yb.cuda(), torch.ones(1, 8, 8).cuda())))
     m = SL.MSE_adapt_weight(0.0)
     a = m(hp.cuda(), ht.cuda(), w.cuda())
     b = m(hp.cuda(), ht.cuda(), (1 - w).cuda())
@@ -139,6 +153,13 @@ def test_hip_metrics_match_reference_fixtures(golden_dir):
     assert np.array_equal(m7.confusionMatrix.cpu().numpy(), g["seg_cm"])
     _, bad = m7.genConfusionMatrix(prd + 7, lab)                              # out-of-range predictions are flagged
     assert int(bad) == 1
+    m7.OverallAccuracy()                                                      # (genConfusionMatrix alone is not sticky)
+    m7b = SM.SegmentationMetric(7, "cuda")
+    m7b.addBatch(prd + 7, lab)                                                # ... addBatch is: reading a score raises
+    with pytest.raises(ValueError):
+        m7b.OverallAccuracy()
+    with pytest.raises(ValueError):
+        m7b.getConfusionMatrix()
     hm = SM.HeightMetric(7, "cuda")
     tref = torch.tensor([0, 0, 3, 6, 5, 1]).float().cuda()
     tpred = torch.tensor([0, 1, 0, 1, 0, 2]).float().cuda()

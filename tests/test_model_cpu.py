@@ -129,3 +129,88 @@ def test_dp_gradient_allreduce_gloo_world2():
     for r in res:
         for got, p in zip(r[2], net.parameters()):
             assert torch.allclose(torch.from_numpy(got), p.grad, rtol=1e-5, atol=1e-7)
+
+
+def test_same_pad_conv_known_answers():
+    """a18 anchor (parity otherwise unpinned): efficientnet_pytorch 0.7.1 `Conv2dStaticSamePadding` pads for a NOMINAL image size,
+    pad = max((ceil(i/s)-1)*s + k - i, 0) split (p//2, p - p//2) left/right and top/bottom -- i.e. the odd pixel goes to the
+    RIGHT / BOTTOM.  Hand-computed paddings for the B4 shapes the encoder builds (nominal 380 -> 190 -> 95 -> 48 -> 24 -> 12) and
+    one hand-computed output."""
+    from srbh_amd.encoders import SamePadConv2d
+    cases = {(380, 3, 2): (0, 1, 0, 1), (190, 3, 1): (1, 1, 1, 1), (95, 5, 2): (2, 2, 2, 2), (48, 5, 2): (1, 2, 1, 2),
+             (24, 3, 2): (0, 1, 0, 1), (12, 5, 1): (2, 2, 2, 2), (12, 1, 1): (0, 0, 0, 0), (95, 3, 2): (1, 1, 1, 1)}
+    for (size, k, s), want in cases.items():
+        assert SamePadConv2d(2, 2, k, size, stride=s, bias=False)._pad == want, (size, k, s)
+    c = SamePadConv2d(1, 1, 3, 4, stride=2, bias=False)              # nominal 4x4, stride 2 -> pad (0,1,0,1)
+    with torch.no_grad():
+        c.weight.fill_(1.0)
+        y = c(torch.arange(16.0).reshape(1, 1, 4, 4))
+    assert y.shape == (1, 1, 2, 2) and y.flatten().tolist() == [45.0, 39.0, 66.0, 50.0]
+    # the padding is static: a 64x64 tile through the stem built for 380 still pads right/bottom by one -> 32x32
+    stem = SamePadConv2d(8, 4, 3, 380, stride=2, bias=False)
+    assert stem(torch.zeros(1, 8, 64, 64)).shape == (1, 4, 32, 32)
+
+
+def _reducer_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from srbh_amd.harness import GradReducer, shard_range
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1),
+                              torch.nn.ReLU(), torch.nn.Conv2d(8, 1, 3, padding=1))
+    unused = torch.nn.Parameter(torch.zeros(3))              # like encoder._conv_head: never gets a grad
+    log_var = torch.nn.Parameter(torch.zeros(1))             # like the criteria's log_var param group (train.py:172-179)
+    params = list(net.parameters()) + [unused, log_var]
+    red = GradReducer(params, world, dist, bucket_bytes=512)
+    g = torch.Generator()
+    g.manual_seed(1)
+    x, y = torch.rand(8, 3, 16, 16, generator=g), torch.rand(8, 1, 16, 16, generator=g)
+    lo, hi = shard_range(8, rank, world)
+    out = []
+    for step in range(3):                                    # step 1: recorded sweep; steps 2-3: hook-launched buckets
+        for p in params:
+            p.grad = None
+        loss = ((net(x[lo:hi]) - y[lo:hi]) ** 2).mean() * torch.exp(-log_var[0]) + log_var[0] * (step + 1)
+        loss.backward()
+        nb = red.finish()
+        out.append([None if p.grad is None else p.grad.numpy().copy() for p in params])
+    dist.barrier()
+    q.put((rank, nb, out))
+    red.close()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_overlapped_buckets_gloo_world2():
+    """harness.GradReducer (bucket all-reduces launched from autograd hooks while backward runs): every step's averaged
+    gradients equal the single-process full-batch gradient, incl. an extra log_var-style parameter and a parameter that
+    never receives a gradient."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 17) % 1000
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1),
+                              torch.nn.ReLU(), torch.nn.Conv2d(8, 1, 3, padding=1))
+    log_var = torch.nn.Parameter(torch.zeros(1))
+    g = torch.Generator()
+    g.manual_seed(1)
+    x, y = torch.rand(8, 3, 16, 16, generator=g), torch.rand(8, 1, 16, 16, generator=g)
+    assert res[0][1] >= 3                                    # several buckets
+    for step in range(3):
+        for p in list(net.parameters()) + [log_var]:
+            p.grad = None
+        (((net(x) - y) ** 2).mean() * torch.exp(-log_var[0]) + log_var[0] * (step + 1)).backward()
+        want = [p.grad for p in net.parameters()] + [None, log_var.grad]
+        for r in res:
+            for got, w in zip(r[2][step], want):
+                if w is None:
+                    assert got is None
+                else:
+                    assert torch.allclose(torch.from_numpy(got), w, rtol=1e-5, atol=1e-7), step

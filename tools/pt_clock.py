@@ -1,7 +1,7 @@
 import os, sys, time, torch
 sys.path.insert(0, '.')
 os.environ["SRBH_PT_PROF"] = "1"
-from oracle import synth
+from srbh_amd import synth
 from srbh_amd.rrdbnet import RRDBNet
 sd = synth.rrdbnet_state_dict(seed=1337, mode="init")
 net = RRDBNet(3, 3); net.load_state_dict(sd); net = net.cuda().eval()

@@ -2,7 +2,7 @@
 bit-stable from call to call (the in-launch halo exchange has no tolerance for races)."""
 import sys, time, torch
 sys.path.insert(0, '.')
-from oracle import synth
+from srbh_amd import synth
 from srbh_amd.rrdbnet import RRDBNet
 dev = 'cuda:0'
 net = RRDBNet(3, 3); net.load_state_dict(synth.rrdbnet_state_dict(seed=1337, mode="init")); net = net.to(dev).eval()

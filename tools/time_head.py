@@ -1,6 +1,6 @@
 import sys, torch
 sys.path.insert(0, '.')
-from oracle import synth
+from srbh_amd import synth
 from srbh_amd.hrfuse import HRfeature, HRfuse_residual
 dev = 'cuda:0'; B = 64
 torch.manual_seed(0)

@@ -1,7 +1,7 @@
 """developer timing: parts of the eval model at the city-inference batch size (B=128)"""
 import sys, time, torch
 sys.path.insert(0, '.')
-from oracle import synth
+from srbh_amd import synth
 from srbh_amd.models import SRRegress_Cls_feature
 from srbh_amd.rrdbnet import RRDBNet
 from srbh_amd.mosaic import Mosaic

@@ -1,7 +1,7 @@
 """developer timing of the sharded predict path (BASELINE config 5 shape): RRDBNet features -> eval head -> device mosaic."""
 import sys, time, torch
 sys.path.insert(0, '.')
-from oracle import synth
+from srbh_amd import synth
 from srbh_amd.harness import predict_tiles
 from srbh_amd.models import SRRegress_Cls_feature
 from srbh_amd.mosaic import Mosaic

@@ -2,7 +2,7 @@
 backward, optimizer beyond the per-op gradient parity tests)."""
 import sys, torch
 sys.path.insert(0, '.')
-from oracle import synth
+from srbh_amd import synth
 from srbh_amd.harness import TrainStep, synthetic_batch
 from srbh_amd.models import SRRegress_Cls_feature
 from srbh_amd.rrdbnet import RRDBNet
