@@ -27,7 +27,7 @@
 #define PT_LOAD_SCOPE " sc1"   // cache-coherence bits of the activation LDS-DMA loads
 #endif
 #ifndef PT_DEFAULT_VARIANT
-#define PT_DEFAULT_VARIANT 1
+#define PT_DEFAULT_VARIANT 3
 #endif
 #ifndef PT_DMA_GROUPS
 #define PT_DMA_GROUPS 3
@@ -636,6 +636,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk_kernel(const PParams pp) {
 }
 
 
+#include "srbh_ptrunk3_kernel.h"
+
 // =====================================================================================================================
 // Variant 2: TWO workgroups per CU.
 //
@@ -1187,6 +1189,7 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
     if (tpi > ncu) return SRBH_OK;
     constexpr int LDS_B = P_LDS_B;
     SRBH_ONCE_PER_DEVICE({
+        SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
@@ -1256,8 +1259,12 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
             pp.frag_res = (W == TILE_W) && !(e && atoi(e) == 0);
         }
         if (g_trunk_timing && b0 == 0) SRBH_HIP(hipEventRecord(g_trunk_ev[0], stream));
-        g_trunk_kernel = "ptrunk_kernel";
-        if (pp.prof)
+        // variant 3 (RDB-unrolled instruction stream, see srbh_ptrunk3_kernel.h): full 8 x 64 tiles only
+        const bool v3 = variant == 3 && W == TILE_W && (H % TILE_H) == 0 && !pp.prof && reg_res;
+        g_trunk_kernel = v3 ? "ptrunk3_kernel" : "ptrunk_kernel";
+        if (v3)
+            hipLaunchKernelGGL((ptrunk3_kernel<0>), dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
+        else if (pp.prof)
             hipLaunchKernelGGL((ptrunk_kernel<true, true>), dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
         else if (reg_res)
             hipLaunchKernelGGL((ptrunk_kernel<false, true>), dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);

@@ -66,16 +66,32 @@ def _dp_worker(rank, world, port, backend, B, q):
     dist.destroy_process_group()
 
 
-def _single(B, q):
+def _single(B, q, world=2):
+    """The SAME objective on one process: one forward over the whole batch (= global BatchNorm statistics, what SyncBN
+    reproduces), then the mean over `world` equal shards of the per-shard losses -- exactly what data parallelism optimises
+    (the Dice term is a ratio of per-shard sums, so it is not the whole-batch Dice)."""
     from srbh_amd.harness import TrainStep, synthetic_batch
     dev = torch.device("cuda", 0)
     net_hr, net = _make(3)
     ts = TrainStep(net_hr.to(dev), net.to(dev), dev, world=1, lr=1e-5)
-    full = synthetic_batch(B, 5, dev)
+    lr, height, height_aggre, build, weight, weight_aggre = synthetic_batch(B, 5, dev)
+    per = B // world
     losses, grads = [], []
     for _ in range(3):
-        loss, _ = ts(full)
-        losses.append(float(loss))
+        with torch.no_grad():
+            fea = ts.net_hr.forward_feature(lr[:, :3])
+        hp, bp, ap = ts.net(lr, fea)
+        parts = []
+        for r in range(world):
+            sl = slice(r * per, (r + 1) * per)
+            parts.append(ts.criterion[0](hp[sl].squeeze(1), height[sl], weight[sl])
+                         + ts.criterion[1](ap[sl].squeeze(1), height_aggre[sl], weight_aggre[sl])
+                         + ts.criterion[2](bp[sl].contiguous(), build[sl], weight[sl]))
+        loss = sum(parts) / world
+        ts.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        ts.optimizer.step()
+        losses.append([float(p) for p in parts])
         grads.append(_grads_of(ts))
     q.put((-1, losses, grads[-1], 0))
 
@@ -95,11 +111,11 @@ def _run(backend, B=4):
         p.join(120)
     ref = res[-1]
     assert res[0][3] >= 2                             # several buckets were launched from hooks
-    # mean of the two half-batch losses == the whole-batch loss (equal shards, mean-reduced losses, global BN statistics);
-    # the Dice term is a ratio of sums, hence not exactly additive: a loose bound on it, a tight one on the gradients' agreement
+    # every rank's loss == the single-process loss of that shard (global BatchNorm statistics through SyncBN / the libsrbh
+    # partial-sum all-reduce), step after step
     for step in range(3):
-        dp = 0.5 * (res[0][1][step] + res[1][1][step])
-        assert abs(dp - ref[1][step]) <= 2e-2 * abs(ref[1][step]), (step, dp, ref[1][step])
+        for r in range(2):
+            assert abs(res[r][1][step] - ref[1][step][r]) <= 2e-3 * abs(ref[1][step][r]), (step, r, res[r][1][step], ref[1][step][r])
     n_none = 0
     gmax = max(float(np.linalg.norm(g)) for g in ref[2] if g is not None)
     for i, (a, b, w) in enumerate(zip(res[0][2], res[1][2], ref[2])):
@@ -116,13 +132,13 @@ def _run(backend, B=4):
 def test_real_trainstep_dp2_on_one_gpu_gloo():
     res, ref, gmax = _run("gloo")
     import numpy as np
-    # CE / MSE parts are exactly additive over equal shards; the Dice ratio is per-rank, so gradients agree only approximately
-    # with the whole-batch step.  The head's large gradients must agree to a few percent.
+    # the averaged gradients == the single-process gradients of the same objective (third step: the parameters have moved
+    # by two Adam updates on both sides).  fp32 noise through ~100 train-mode BatchNorms over 4 tiles: a median bound.
     rel = []
     for a, w in zip(res[0][2], ref[2]):
-        if w is not None and float(np.linalg.norm(w)) > 1e-2 * gmax:
+        if w is not None and float(np.linalg.norm(w)) > 1e-3 * gmax:
             rel.append(float(np.linalg.norm(a - w) / np.linalg.norm(w)))
-    assert len(rel) > 20 and float(np.median(rel)) <= 5e-2, (len(rel), float(np.median(rel)), max(rel))
+    assert len(rel) > 20 and float(np.median(rel)) <= 1e-2, (len(rel), float(np.median(rel)), max(rel))
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs >= 2 GPUs (fires on the first multi-GPU box)")

@@ -317,6 +317,102 @@ static void run_step8(const char* name, unsigned long long dmask) {
     hipFree(gsrc);
 }
 
+
+// 8 waves per workgroup (2 per SIMD), SPLIT-K / split-channel-block form: a wave keeps the 4-row x 32-pixel tile of the 4-wave
+// kernel (6 pixel-fragment rows + 3 weight fragments feed 12 MFMAs per group: the same 0.75 LDS reads per MFMA), and the two
+// waves that own the same pixels divide the work along K (cout 32: wave half h runs the 3 groups of k-step h) or along the
+// output channel blocks (cout 64: wave half h runs all 6 groups for channel block h).  NG = groups per wave and step.
+template <int NG, int ND>
+__global__ __launch_bounds__(512, 1) void step8k_kernel(unsigned long long* out, int iters, float* sink, const char* gsrc, unsigned long long dmask, int rnd) {
+    constexpr int NP = 6, NR = 9, NM = 12, ACC = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 160 * 1024 / 4; i += 512) ((float*)smem)[i] = pattern(i, rnd);
+    __syncthreads();
+    const int l31 = lane & 31, hi = lane >> 5, q = wave & 3, h = wave >> 2, wr = q >> 1, wc = q & 1;
+    int off[NR];
+    for (int r = 0; r < NR; ++r) {
+        const int pc = wc * 32 + l31;
+        off[r] = r < NP ? (wr * 4 + r) * 66 * 64 + pc * 64 + (((hi + 2 * h) ^ ((pc >> 2) & 3)) << 4) : 45056 + (h * 9 + r - NP) * 1024 + lane * 16;
+    }
+    floatx16 c[ACC];
+    for (int a = 0; a < ACC; ++a) c[a] = floatx16{0};
+    half8 v[2][NR];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* sb = smem + (it & 1) * 81920;
+        const unsigned dstl = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)(smem + ((it + 1) & 1) * 81920) + wave * 1024;
+        const unsigned long long gb = (unsigned long long)gsrc + (unsigned long long)blockIdx.x * 81920 + (it & 3) * 20480;
+        const unsigned dl = __builtin_amdgcn_readfirstlane(dstl);
+        const unsigned glo = __builtin_amdgcn_readfirstlane((unsigned)gb), ghi = __builtin_amdgcn_readfirstlane((unsigned)(gb >> 32));
+        const unsigned long long gbu = ((unsigned long long)ghi << 32) | glo;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) v[0][r] = *(const half8*)(sb + off[r]);
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+#pragma unroll
+            for (int i = 0; i < ND; ++i)
+                if (i * 2 / ND == u) {
+                    unsigned long long sv;
+                    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                                 "global_load_lds_dwordx4 %3, %4 sc1\n\ts_mov_b64 exec, %0"
+                                 : "=&s"(sv) : "s"(dmask), "s"(dl + i * 8192), "v"(lane * 16 + wave * 1024 + i * 8192), "s"(gbu) : "memory", "m0");
+                }
+            if (u + 1 < NG) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) v[(u + 1) & 1][r] = *(const half8*)(sb + off[r] + (u + 1) * 64);
+            }
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+                c[m % ACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v[u & 1][NP + m % (NR - NP)], v[u & 1][m % NP], c[m % ACC], 0, 0, 0);
+            if (u == 0) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+            if (u + 1 < NG) {
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) out[blockIdx.x] = t1 - t0;
+    float s = 0;
+    for (int a = 0; a < ACC; ++a)
+        for (int q2 = 0; q2 < 16; ++q2) s += c[a][q2];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+template <int NG, int ND>
+static void run_step8k(const char* name, unsigned long long dmask) {
+    unsigned long long* d;
+    float* sink;
+    hipMalloc(&d, 256 * 8);
+    hipMalloc(&sink, 4);
+    hipFuncSetAttribute((const void*)step8k_kernel<NG, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int iters = 400;
+    char* gsrc;
+    hipMalloc(&gsrc, 256 * 81920 + (1 << 20));
+    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, (float*)gsrc, (long)(256 * 81920 + (1 << 20)) / 4, g_rnd);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((step8k_kernel<NG, ND>), dim3(256), dim3(512), 160 * 1024, 0, d, iters, sink, gsrc, dmask, g_rnd);
+    hipDeviceSynchronize();
+    unsigned long long h[256];
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    double avg = 0;
+    for (int i = 0; i < 256; ++i) avg += (double)h[i];
+    avg /= 256;
+    printf("%-60s %8.1f cycles per step (per-SIMD MFMA issue floor %d) -> %.0f %%\n", name, avg / iters, 2 * NG * 12 * 32,
+           100.0 * 2 * NG * 12 * 32 / (avg / iters));
+    hipFree(d);
+    hipFree(sink);
+    hipFree(gsrc);
+}
+
 template <int NR, int NM, int ACC>
 static void run_group(const char* name) {
     unsigned long long* d;
@@ -341,6 +437,11 @@ static void run_group(const char* name) {
 int main(int argc, char** argv) {
     for (g_rnd = 0; g_rnd < 2; ++g_rnd) {
         printf("---- operand data: %s\n", g_rnd ? "pseudo-random fp16 in [-0.5, 0.5)" : "smooth ramp");
+        run_step8k<3, 1>("8 waves split-K, cout 32 STEP: barrier + 3 groups, ~no DMA", 0ull);
+        run_step8k<3, 8>("8 waves split-K, cout 32 STEP + 8 DMA/wave masked off", 0ull);
+        run_step8k<3, 8>("8 waves split-K, cout 32 STEP + 8 DMA/wave (64 KiB/step)", ~0ull);
+        run_step8k<6, 1>("8 waves split-cb, cout 64 STEP: barrier + 6 groups, ~no DMA", 0ull);
+        run_step8k<6, 10>("8 waves split-cb, cout 64 STEP + 10 DMA/wave (80 KiB/step)", ~0ull);
         run_step8<1, 1>("8 waves, cout 32 STEP: barrier + 6 groups, ~no DMA", 0ull);
         run_step8<1, 8>("8 waves, cout 32 STEP + 8 DMA/wave (64 KiB/step)", ~0ull);
         run_step8<2, 1>("8 waves, cout 64 STEP: barrier + 6 groups, ~no DMA", 0ull);
