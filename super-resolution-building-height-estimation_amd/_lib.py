@@ -29,7 +29,7 @@ if os.environ.get("SRBH_HIPFLAGS_OVERRIDE"):      # developer bisecting only
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into the in-tree libsrbh.so (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, "srbh_internal.h"), os.path.join(INCLUDE, "srbh.h")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(INCLUDE, "srbh.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     objs, procs = [], []

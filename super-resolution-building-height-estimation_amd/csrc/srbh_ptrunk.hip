@@ -1190,6 +1190,7 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
     constexpr int LDS_B = P_LDS_B;
     SRBH_ONCE_PER_DEVICE({
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
+        SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
@@ -1260,9 +1261,11 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
         }
         if (g_trunk_timing && b0 == 0) SRBH_HIP(hipEventRecord(g_trunk_ev[0], stream));
         // variant 3 (RDB-unrolled instruction stream, see srbh_ptrunk3_kernel.h): full 8 x 64 tiles only
-        const bool v3 = variant == 3 && W == TILE_W && (H % TILE_H) == 0 && !pp.prof && reg_res;
+        const bool v3 = variant == 3 && W == TILE_W && (H % TILE_H) == 0 && reg_res;
         g_trunk_kernel = v3 ? "ptrunk3_kernel" : "ptrunk_kernel";
-        if (v3)
+        if (v3 && pp.prof)
+            hipLaunchKernelGGL((ptrunk3_kernel<1>), dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
+        else if (v3)
             hipLaunchKernelGGL((ptrunk3_kernel<0>), dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
         else if (pp.prof)
             hipLaunchKernelGGL((ptrunk_kernel<true, true>), dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);

@@ -18,10 +18,20 @@
 #pragma once
 
 #ifndef P3_READS_PER_SHADOW
-#define P3_READS_PER_SHADOW 2
+#define P3_READS_PER_SHADOW 2   // LDS reads of the next group per MFMA shadow
+#endif
+#ifndef P3_S1
+#define P3_S1 1                 // 1: x's second chunk and X1 are staged from registers; 0: every plane by LDS-DMA (A/B aid)
+#endif
+#ifndef P3_ABL
+#define P3_ABL 0                // developer ablations (WRONG RESULTS): 1 no weight DMA, 2 no input/halo DMA, 4 no register staging stores
+#endif
+#ifndef P3_DMA_FIRST
+#define P3_DMA_FIRST 1          // 1: a group's DMA statements sit behind its FIRST MFMAs, the LDS reads behind the later ones
 #endif
 
-template <int DUMMY>
+// PROF = 1 (developer timeline, SRBH_PT_PROF): s_memtime stamps per layer in ptrunk_kernel's 6-slot format
+template <int PROF>
 __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -193,18 +203,40 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         }
     }
 
-    // ---- one K step.  CB = cout/32 of the running layer; KIND = what is staged for the NEXT step:
-    //   0 nothing | 1 input plane + 18 weight fragments | 2 18 weight fragments | 3 input plane + 36 weight fragments
-    auto run_step = [&](auto cb_tag, auto kind_tag, floatx16 (&acc)[decltype(cb_tag)::value][4], const char* sbi, const char* sbw,
-                        const char* nsrc, const char* nw, char* dst) {
-        constexpr int CB = decltype(cb_tag)::value, KIND = decltype(kind_tag)::value;
+    // ---- register-resident planes (S1).  The fp16 planes this workgroup re-reads most -- x's second chunk (5 reads per RDB) and
+    // X1 (4 reads) -- stay in registers in MFMA B-fragment form (the very 16 bytes per lane the epilogues store), and are
+    // staged into a ring slot with ds_write_b128 instead of being fetched back through L2 / MALL / HBM: per XCD the dense
+    // planes of 32 workgroups (8 MB) overflow the 4 MB L2, so ~70 % of those re-reads were fabric traffic, and the steps
+    // behind them ran at the landing time of their DMA, not at the matrix rate.  Only the two halo rows (the neighbours'
+    // rows) still come by DMA.
+    typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+    uintx4 x1p[4][2], X1r[4][2];          // [row][k-step]: x chunk 1 (written by conv5's epilogue), X1 (conv1's epilogue)
+    const int soff = (wr * 4 + 1) * G::ROW_B + (X + 1) * PIX_B;                 // this lane's pixel record in a staged tile, row 0
+    const int sswz[2] = {((0 + hi) ^ (((X + 1) >> 2) & 3)) << 4, ((2 + hi) ^ (((X + 1) >> 2) & 3)) << 4};
+    // the zero border columns of the wave's 4 rows (a DMA-staged plane brings them along; a register-staged one must write them)
+    const int boff = (wr * 4 + 1 + (lane >> 2)) * G::ROW_B + (wc ? (G::COLS - 1) * PIX_B : 0) + (lane & 3) * 16;
+    // halo-only DMA: statements j = 0 (row 0), 1 (its last 128 B), 9 (row 9 from byte 38016 on), 10 (tail), lane-masked to the halo rows
+    auto halo_lane = [&](int j, int row) { const int u = j * 256 + tid; return u < G::UNITS && u / (G::COLS * 4) == row; };
+    const unsigned long long hmask1 = uni64(__builtin_amdgcn_ballot_w64(halo_lane(1, 0)));
+    const unsigned long long hmask9 = uni64(__builtin_amdgcn_ballot_w64(halo_lane(9, G::ROWS - 1)));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)      // x's second chunk as conv_first wrote it (fp16 plane 1 of dense[0])
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+            x1p[i][m] = *(const uintx4*)(pp.dense[0] + tile_off + (long)pp.plane_b + (long)(wr * 4 + i + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16);
+
+    // ---- one K step.  CB = cout/32 of the running layer.  What is staged for the NEXT step is a compile-time property:
+    //   IN: 0 no input plane | 1 input plane by LDS-DMA (11 statements) | 2 input plane from registers (8 ds_write_b128 + 1
+    //   border write + 4 halo DMA statements);   NW: weight DMA statements per wave (0 | 5 = 18 fragments | 9 = 36 fragments)
+    auto run_step = [&](auto cb_tag, auto in_tag, auto nw_tag, floatx16 (&acc)[decltype(cb_tag)::value][4], const char* sbi, const char* sbw,
+                        const char* nsrc, const char* nw, char* dst, const uintx4 (&rsrc)[4][2]) {
+        constexpr int CB = decltype(cb_tag)::value, IN = decltype(in_tag)::value, NW = decltype(nw_tag)::value;
         constexpr int NRD = G::NP + 3 * CB, NMF = 12 * CB;
-        constexpr int NIN = (KIND == 1 || KIND == 3) ? 11 : 0;
-        constexpr int NW = KIND == 0 ? 0 : (KIND == 3 ? 9 : 5);
-        constexpr int ND = NIN + NW;
+        constexpr int NDMA = (IN == 1 ? 11 : IN == 2 ? 4 : 0) + NW;     // DMA statements
+        constexpr int ND = NDMA + (IN == 2 ? 9 : 0);                    // + LDS stores of a register-staged plane
         constexpr int RSH = (NRD + P3_READS_PER_SHADOW - 1) / P3_READS_PER_SHADOW;   // MFMA shadows of a group that carry LDS reads
-        constexpr int DPG = NMF - RSH;                                                 // ... that can carry a DMA statement
-        static_assert(ND <= 3 * DPG, "the step's DMA statements must fit the first three groups");
+        constexpr int DPG = NMF - RSH;                                                 // ... that can carry a staging item
+        static_assert(ND <= 6 * DPG, "the staging items of a step must fit its MFMA shadows");
         const unsigned long long ibase = uni64((unsigned long long)nsrc);
         const unsigned long long wbase = uni64((unsigned long long)(nw + wave * 1024));
         const unsigned din_w = __builtin_amdgcn_readfirstlane(lds_addr(dst) + wave * 1024);
@@ -220,6 +252,30 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 A[set][dy][mb] = *(const half8*)(sbw + woff + ((((dy * 3 + dx) * 2 + ks) * CB + mb) << 10));
             }
         };
+        auto stage_item = [&](const int d) {
+            if ((P3_ABL & 1) && d >= (IN == 1 ? 11 : IN == 2 ? 4 : 0) && d < NDMA) return;
+            if ((P3_ABL & 2) && d < (IN == 1 ? 11 : IN == 2 ? 4 : 0)) return;
+            if ((P3_ABL & 4) && d >= NDMA) return;
+            if constexpr (IN == 2) {
+                if (d < 4) {            // the neighbours' rows
+                    constexpr int HJ[4] = {0, 1, 9, 10};
+                    const int j = HJ[d];
+                    if (j == 0)
+                        dma(SC1{}, ibase, goff[0], din_w);
+                    else
+                        dma_masked(SC1{}, ibase, goff[j], din_w + j * 4096, uni64(j == 1 ? hmask1 : j == 9 ? hmask9 : tail_mask));
+                } else if (d < 4 + NW) {
+                    dma_item(std::integral_constant<int, 0>{}, nw_tag, d - 4, ibase, wbase, din_w, dw_w);
+                } else if (d < 4 + NW + 8) {
+                    const int e = d - 4 - NW, i = e >> 1, m = e & 1;
+                    *(uintx4*)(dst + soff + sswz[m] + i * G::ROW_B) = rsrc[i][m];
+                } else {
+                    if (lane < 16) *(uintx4*)(dst + boff) = uintx4{0u, 0u, 0u, 0u};
+                }
+            } else {
+                dma_item(std::integral_constant<int, IN == 1 ? 11 : 0>{}, nw_tag, d, ibase, wbase, din_w, dw_w);
+            }
+        };
 #pragma unroll
         for (int r = 0; r < NRD; ++r) read_item(0, r, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -230,17 +286,19 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 const int dy = m / (4 * CB), rem = m - dy * 4 * CB, i = rem / CB, mb = rem - i * CB;
                 acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g & 1][dy][mb], P[g & 1][i + dy], acc[mb][i], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (m < RSH) {
+                const int mr = P3_DMA_FIRST ? m - DPG : m;          // shadow index among the read-carrying ones
+                const int md = P3_DMA_FIRST ? m : m - RSH;          // ... among the staging ones
+                if (mr >= 0 && mr < RSH) {
                     if (g + 1 < 6) {
 #pragma unroll
                         for (int q = 0; q < P3_READS_PER_SHADOW; ++q)
-                            if (m * P3_READS_PER_SHADOW + q < NRD) read_item(g + 1, m * P3_READS_PER_SHADOW + q, (g + 1) & 1);
+                            if (mr * P3_READS_PER_SHADOW + q < NRD) read_item(g + 1, mr * P3_READS_PER_SHADOW + q, (g + 1) & 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
-                    const int d = g * DPG + (m - RSH);
+                    const int d = g * DPG + md;
                     if (d < ND) {
-                        dma_item(std::integral_constant<int, NIN>{}, std::integral_constant<int, NW>{}, d, ibase, wbase, din_w, dw_w);
+                        stage_item(d);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -250,10 +308,12 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
 
     using C1 = std::integral_constant<int, 1>;
     using C2 = std::integral_constant<int, 2>;
-    using K0 = std::integral_constant<int, 0>;
-    using K1 = std::integral_constant<int, 1>;
-    using K2 = std::integral_constant<int, 2>;
-    using K3 = std::integral_constant<int, 3>;
+    using I0 = std::integral_constant<int, 0>;   // IN: none / DMA / registers
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, P3_S1 ? 2 : 1>;
+    using W0 = std::integral_constant<int, 0>;   // NW: weight DMA statements per wave
+    using W5 = std::integral_constant<int, 5>;
+    using W9 = std::integral_constant<int, 9>;
 
     // ---- layer prologue: drain the own DMA / stores, barrier, bias into LDS, lazy publish
     auto prologue = [&](const float* bias, const int nb, const int bias_lds) {
@@ -267,13 +327,21 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             pending_pub = false;
         }
     };
+    unsigned long long t_sync = 0, t_vm = 0;   // PROF: cycles in the top-of-step waits (own DMA landing / barrier)
     auto step_sync = [&]() {
+        unsigned long long w0 = 0, w1 = 0;
+        if (PROF) w0 = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of the step has landed ...
+        if (PROF) w1 = __builtin_amdgcn_s_memtime();
         __syncthreads();                                   // ... and everybody else's; all waves are past the previous step
+        if (PROF) {
+            t_vm += w1 - w0;
+            t_sync += __builtin_amdgcn_s_memtime() - w1;
+        }
     };
 
     // ---- epilogue of a cout-32 layer: bias, leaky ReLU, fp16, straight from the MFMA D layout (see ptrunk_kernel)
-    auto epi32 = [&](floatx16 (&acc)[1][4], char* oplane) {
+    auto epi32 = [&](floatx16 (&acc)[1][4], char* oplane, uintx4 (&keep)[4][2]) {
         floatx4 bias4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) bias4[g] = *(const floatx4*)((const float*)(smem + A_BIAS_OFF) + g * 8 + hi * 4);
@@ -301,8 +369,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             for (int m = 0; m < 2; ++m) {
                 auto s0 = __builtin_amdgcn_permlane32_swap(hp[2 * m][0], hp[2 * m + 1][0], false, false);
                 auto s1 = __builtin_amdgcn_permlane32_swap(hp[2 * m][1], hp[2 * m + 1][1], false, false);
-                typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
                 const uintx4 raw = {s0[0], s1[0], s0[1], s1[1]};
+                keep[i][m] = raw;
                 char* o = oplane + (long)(Y + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16;
                 if (wt)
                     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
@@ -363,8 +431,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                     for (int m = 0; m < 2; ++m) {
                         auto s0 = __builtin_amdgcn_permlane32_swap(hp[2 * m][0], hp[2 * m + 1][0], false, false);
                         auto s1 = __builtin_amdgcn_permlane32_swap(hp[2 * m][1], hp[2 * m + 1][1], false, false);
-                        typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
                         const uintx4 raw = {s0[0], s1[0], s0[1], s1[1]};
+                        if (mb == 1) x1p[i][m] = raw;
                         char* o = obase + (long)mb * pp.plane_b + (long)(Y + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16;
                         if (wt)
                             asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
@@ -390,58 +458,95 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     // ---- prologue of the launch: conv1 of RDB 0 reads conv_first's output (no flag needed)
     char* dcur = pp.dense[0] + tile_off;    // tile origin of plane 0 in the running RDB's dense buffer
     char* dnxt = pp.dense[1] + tile_off;
-    stage_cold(dcur, smem, pp.layers[0].w, smem + stage_off(1, 0) + IN_EX, std::integral_constant<int, 5>{});
+    stage_cold(dcur, smem, pp.layers[0].w, smem + stage_off(1, 0) + IN_EX, W5{});
     const int nrdb = pp.nlayers / 5;
     for (int rdb = 0; rdb < nrdb && !aborted; ++rdb) {
         const PLayer* T = pp.layers + rdb * 5;
         const int L0 = rdb * 5;
         int gs = 0;
-        // ---------------- conv1..conv4 (cout 32, plane 0 resident, stages of IN_EX + 18 KiB)
-        for (int k = 0; k < 4 && !aborted; ++k) {
-            const int L = L0 + k, n = k + 2;
-            const char* wl = T[k].w;
-            prologue(T[k].bias, 32, A_BIAS_OFF);
-            // conv1's inputs were verified at the seam; conv2..4: the only NEW input plane is the last chunk -> the neighbour
-            // flags are checked behind step 0
+        // ---------------- conv1..conv4 (cout 32, plane 0 resident, stages of IN_EX + 18 KiB).  One body for conv1..3 and one
+        // for conv4 (their last steps stage different things: compiling them as two variants of ONE layer body made the
+        // accumulators of the two last-step variants meet in a phi, i.e. 64 v_accvgpr_mov per layer)
+        auto layerA = [&](const int kk, auto last_nw_tag) {
+            const int L = L0 + kk, n = kk + 2;
+            const char* wl = T[kk].w;
+            unsigned long long p0 = 0, p1 = 0, p2 = 0;
+            if (PROF) p0 = __builtin_amdgcn_s_memtime();
+            prologue(T[kk].bias, 32, A_BIAS_OFF);
+            if (PROF) p1 = __builtin_amdgcn_s_memtime();
+            t_sync = 0;
+            t_vm = 0;
             floatx16 acc[1][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][i][r] = 0.f;
-            // step 0: resident plane, stages chunk 1
-            run_step(C1{}, K1{}, acc, smem, smem + stage_off(1, gs & 1) + IN_EX, dcur + (long)pp.plane_b, wl + 18 * 1024,
-                     smem + stage_off(1, (gs + 1) & 1));
+            // step 0: resident plane 0; stages chunk 1 (x's second half) from registers
+            run_step(C1{}, I2{}, W5{}, acc, smem, smem + stage_off(1, gs & 1) + IN_EX, dcur + (long)pp.plane_b, wl + 18 * 1024,
+                     smem + stage_off(1, (gs + 1) & 1), x1p);
             ++gs;
-            if (k > 0 && L > 0) {
+            // The only NEW input plane of conv2..4 is the last chunk (index kk + 1): its halo rows are fetched during step kk, so
+            // the neighbours' progress is checked right in front of that step (conv1's inputs were verified at the seam).
+            if (kk == 1) {
                 ensure_flags(L);
-                if (aborted) break;
+                if (aborted) return;
             }
-            for (int c = 1; c + 1 < n; ++c) {
+            if (n >= 3) {      // step 1: chunk 1; stages chunk 2 (X1) from registers
                 step_sync();
                 const char* st = smem + stage_off(1, gs & 1);
-                run_step(C1{}, K1{}, acc, st, st + IN_EX, dcur + (long)(c + 1) * pp.plane_b, wl + (long)(c + 1) * (18 * 1024),
-                         smem + stage_off(1, (gs + 1) & 1));
+                run_step(C1{}, I2{}, W5{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (18 * 1024),
+                         smem + stage_off(1, (gs + 1) & 1), X1r);
+                ++gs;
+            }
+            for (int c = 2; c + 1 < n; ++c) {      // chunks 2 ..: stage chunk c + 1 (X2, X3) by DMA
+                if (c == kk) {
+                    ensure_flags(L);
+                    if (aborted) return;
+                }
+                step_sync();
+                const char* st = smem + stage_off(1, gs & 1);
+                run_step(C1{}, I1{}, W5{}, acc, st, st + IN_EX, dcur + (long)(c + 1) * pp.plane_b, wl + (long)(c + 1) * (18 * 1024),
+                         smem + stage_off(1, (gs + 1) & 1), x1p);
                 ++gs;
             }
             step_sync();
             {
                 const char* st = smem + stage_off(1, gs & 1);
-                if (k < 3)        // last step of conv1..3: the next layer's step 0 reads the resident plane: weights only
-                    run_step(C1{}, K2{}, acc, st, st + IN_EX, nullptr, T[k + 1].w, smem + stage_off(1, (gs + 1) & 1));
-                else              // last step of conv4: conv5's chunk 0 (plane 0) + 36 KiB of weights into the phase-B stage 0
-                    run_step(C1{}, K3{}, acc, st, st + IN_EX, dcur, T[4].w, smem + stage_off(2, 0));
+                if constexpr (decltype(last_nw_tag)::value == 5)   // conv1..3: the next layer's step 0 reads the resident plane: weights only
+                    run_step(C1{}, I0{}, W5{}, acc, st, st + IN_EX, nullptr, T[kk + 1].w, smem + stage_off(1, (gs + 1) & 1), x1p);
+                else              // conv4: conv5's chunk 0 IS the resident plane (phase-B stage 0 starts at the same address): 36 KiB of weights
+                    run_step(C1{}, I0{}, W9{}, acc, st, st + IN_EX, nullptr, T[4].w, smem + stage_off(2, 0), x1p);
                 ++gs;
             }
-            epi32(acc, dcur + (long)(2 + k) * pp.plane_b - (long)Y0 * pp.row_b);
+            if (PROF) p2 = __builtin_amdgcn_s_memtime();
+            uintx4 kept[4][2];
+            epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept);
+            if (kk == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) X1r[i][m] = kept[i][m];
+            }
             pending_pub = true;   // published behind the next top-of-step barrier (whose vmcnt(0) covers these stores)
             pub_val = L + 1;
-        }
+            if (PROF && tid == 0) {
+                unsigned long long* q = pp.prof + ((long)blockIdx.x * pp.nlayers + L) * 6;
+                q[0] = p1; q[1] = p2; q[2] = __builtin_amdgcn_s_memtime(); q[3] = p1 - p0; q[4] = t_sync; q[5] = t_vm;
+            }
+        };
+        for (int k = 0; k < 3 && !aborted; ++k) layerA(k, W5{});
+        if (!aborted) layerA(3, W9{});
         if (aborted) break;
         // ---------------- conv5 (cout 64, stages of IN_EX + 36 KiB, residual epilogue)
         {
             const int L = L0 + 4;
             const char* wl = T[4].w;
+            unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+            if (PROF) p0 = __builtin_amdgcn_s_memtime();
             prologue(T[4].bias, 64, B_BIAS_OFF);
+            if (PROF) p1 = __builtin_amdgcn_s_memtime();
+            t_sync = 0;
+            t_vm = 0;
             floatx16 acc[2][4];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
@@ -449,25 +554,35 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
-            {
+            {   // chunk 0 = the resident plane (in place: phase-B stage 0); stages chunk 1 from registers
                 const char* st = smem + stage_off(2, 0);
-                run_step(C2{}, K3{}, acc, st, st + IN_EX, dcur + (long)pp.plane_b, wl + 36 * 1024, smem + stage_off(2, 1));
+                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + (long)pp.plane_b, wl + 36 * 1024, smem + stage_off(2, 1), x1p);
             }
-            ensure_flags(L);
-            if (aborted) break;
-            for (int c = 1; c < 5; ++c) {
+            step_sync();
+            {   // chunk 1; stages chunk 2 (X1) from registers
+                const char* st = smem + stage_off(2, 1);
+                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (36 * 1024), smem + stage_off(2, 0), X1r);
+            }
+            for (int c = 2; c < 5; ++c) {
+                if (c == 4) {      // X4 (chunk 5) is conv4's output on the neighbours: checked in front of the step that fetches it
+                    ensure_flags(L);
+                    if (aborted) break;
+                }
                 step_sync();
                 const char* st = smem + stage_off(2, c & 1);
-                run_step(C2{}, K3{}, acc, st, st + IN_EX, dcur + (long)(c + 1) * pp.plane_b, wl + (long)(c + 1) * (36 * 1024),
-                         smem + stage_off(2, (c + 1) & 1));
+                run_step(C2{}, I1{}, W9{}, acc, st, st + IN_EX, dcur + (long)(c + 1) * pp.plane_b, wl + (long)(c + 1) * (36 * 1024),
+                         smem + stage_off(2, (c + 1) & 1), x1p);
             }
+            if (aborted) break;
             step_sync();
             {
                 const char* st = smem + stage_off(2, 1);
-                run_step(C2{}, K0{}, acc, st, st + IN_EX, nullptr, nullptr, smem);
+                run_step(C2{}, I0{}, W0{}, acc, st, st + IN_EX, nullptr, nullptr, smem, x1p);
             }
             const bool r2 = (rdb % 3) == 2;
+            if (PROF) p2 = __builtin_amdgcn_s_memtime();
             epi64(acc, dnxt - (long)Y0 * pp.row_b, r2, rdb == 2);
+            if (PROF) p3 = __builtin_amdgcn_s_memtime();
             // RDB seam: the next conv1's first chunk is THIS layer's output on the neighbours: publish now, then wait for them
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -475,7 +590,11 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             if (rdb + 1 < nrdb) {
                 ensure_flags(L + 1);
                 if (aborted) break;
-                stage_cold(dnxt, smem, T[5].w, smem + stage_off(1, 0) + IN_EX, std::integral_constant<int, 5>{});
+                stage_cold(dnxt, smem, T[5].w, smem + stage_off(1, 0) + IN_EX, W5{});
+            }
+            if (PROF && tid == 0) {
+                unsigned long long* q = pp.prof + ((long)blockIdx.x * pp.nlayers + L) * 6;
+                q[0] = p1; q[1] = p2; q[2] = p3; q[3] = (p1 - p0) | ((unsigned long long)(__builtin_amdgcn_s_memtime() - p3) << 32); q[4] = t_sync; q[5] = t_vm;
             }
             char* tmp = dcur;
             dcur = dnxt;
