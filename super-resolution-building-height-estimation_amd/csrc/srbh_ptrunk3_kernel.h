@@ -23,6 +23,12 @@
 #ifndef P3_S1
 #define P3_S1 1                 // 1: x's second chunk and X1 are staged from registers; 0: every plane by LDS-DMA (A/B aid)
 #endif
+#ifndef P3_X2REG
+#define P3_X2REG 1              // 1: X2 is register-resident as well (3 more plane re-reads per RDB leave the fabric)
+#endif
+#ifndef P3_SKIPST
+#define P3_SKIPST 1             // 1: a register-resident plane is stored to memory only where a neighbour reads it (its halo rows)
+#endif
 #ifndef P3_ABL
 #define P3_ABL 0                // developer ablations (WRONG RESULTS): 1 no weight DMA, 2 no input/halo DMA, 4 no register staging stores
 #endif
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     // behind them ran at the landing time of their DMA, not at the matrix rate.  Only the two halo rows (the neighbours'
     // rows) still come by DMA.
     typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
-    uintx4 x1p[4][2], X1r[4][2];          // [row][k-step]: x chunk 1 (written by conv5's epilogue), X1 (conv1's epilogue)
+    uintx4 x1p[4][2], X1r[4][2], X2r[4][2];   // [row][k-step]: x chunk 1 (written by conv5's epilogue), X1 / X2 (conv1's / conv2's epilogue)
     const int soff = (wr * 4 + 1) * G::ROW_B + (X + 1) * PIX_B;                 // this lane's pixel record in a staged tile, row 0
     const int sswz[2] = {((0 + hi) ^ (((X + 1) >> 2) & 3)) << 4, ((2 + hi) ^ (((X + 1) >> 2) & 3)) << 4};
     // the zero border columns of the wave's 4 rows (a DMA-staged plane brings them along; a register-staged one must write them)
@@ -311,6 +317,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     using I0 = std::integral_constant<int, 0>;   // IN: none / DMA / registers
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, P3_S1 ? 2 : 1>;
+    using I2X = std::integral_constant<int, (P3_S1 && P3_X2REG) ? 2 : 1>;   // X2's staging
     using W0 = std::integral_constant<int, 0>;   // NW: weight DMA statements per wave
     using W5 = std::integral_constant<int, 5>;
     using W9 = std::integral_constant<int, 9>;
@@ -341,13 +348,16 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     };
 
     // ---- epilogue of a cout-32 layer: bias, leaky ReLU, fp16, straight from the MFMA D layout (see ptrunk_kernel)
-    auto epi32 = [&](floatx16 (&acc)[1][4], char* oplane, uintx4 (&keep)[4][2]) {
+    auto epi32 = [&](floatx16 (&acc)[1][4], char* oplane, uintx4 (&keep)[4][2], const bool halo_only) {
         floatx4 bias4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) bias4[g] = *(const floatx4*)((const float*)(smem + A_BIAS_OFF) + g * 8 + hi * 4);
+        // rows 0 and 3 first: one of them is the row a neighbour reads (its store is the one the publication waits for)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int io = 0; io < 4; ++io) {
+            const int i = io == 0 ? 0 : io == 1 ? 3 : io - 1;
             const int Y = Y0 + wr * 4 + i;
+            const bool st = !halo_only || (i == 0 && wr == 0) || (i == 3 && wr == 1);   // (wave-uniform)
             unsigned hp[4][2];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -372,6 +382,37 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 const uintx4 raw = {s0[0], s1[0], s0[1], s1[1]};
                 keep[i][m] = raw;
                 char* o = oplane + (long)(Y + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16;
+                if (st) {
+                    if (wt)
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
+                    else
+                        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
+                }
+            }
+        }
+    };
+    // ---- epilogue of conv5: x = 0.2 (acc + bias) + x in registers (+ the RRDB-level stream every third RDB), fp16 copy out
+    // one row of x (channel block mb) -> fp16 fragments, kept (mb == 1) and stored where somebody reads them from memory
+    auto x_row_out = [&](const int mb, const int i, char* obase, const bool st) {
+        const int Y = Y0 + wr * 4 + i;
+        unsigned hp[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            half4 h4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) h4[q] = (_Float16)xres[mb][i][g][q];
+            const uint2 u = __builtin_bit_cast(uint2, h4);
+            hp[g][0] = u.x;
+            hp[g][1] = u.y;
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            auto s0 = __builtin_amdgcn_permlane32_swap(hp[2 * m][0], hp[2 * m + 1][0], false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(hp[2 * m][1], hp[2 * m + 1][1], false, false);
+            const uintx4 raw = {s0[0], s1[0], s0[1], s1[1]};
+            if (mb == 1) x1p[i][m] = raw;
+            char* o = obase + (long)mb * pp.plane_b + (long)(Y + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16;
+            if (st) {
                 if (wt)
                     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
                 else
@@ -379,22 +420,43 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             }
         }
     };
-    // ---- epilogue of conv5: x = 0.2 (acc + bias) + x in registers (+ the RRDB-level stream every third RDB), fp16 copy out
-    auto epi64 = [&](floatx16 (&acc)[2][4], char* obase, const bool r2, const bool r2_pixel) {
+    // ---- epilogue of conv5: x = 0.2 (acc + bias) + x in registers, fp16 copy out.  Every third RDB also closes an RRDB
+    // (x = 0.2 x + x_rrdb, the RRDB-level stream lives in memory): that is a SECOND pass over the registers behind a uniform
+    // branch -- as a flag inside one body hipcc if-converted it into 128 selects, as two bodies the 160 live registers met in
+    // phis and spilled.  In an RRDB-closing RDB the first pass stores nothing (its fp16 values are not final).
+    auto epi64 = [&](floatx16 (&acc)[2][4], char* obase, const bool r2, const bool r2_pixel, const bool x1_halo_only) {
         floatx4 bias4[2][4];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) bias4[mb][g] = *(const floatx4*)((const float*)(smem + B_BIAS_OFF) + mb * 32 + g * 8 + hi * 4);
-        const int frag_lane = wc * 2048 + lane * 4;   // fragment order: instruction (mb, g) owns 1 KiB, lane l its 16 B
-        // rows go two at a time: the 16 loads of the RRDB-level stream (every third RDB) are all issued before any is consumed
+        // rows 0 and 3 first: one of them is the row a neighbour reads (its stores are what the publication waits for)
 #pragma unroll
-        for (int ih = 0; ih < 4; ih += 2) {
-            floatx4 a2[2][2][4];
-            if (r2) {
+        for (int io = 0; io < 4; ++io) {
+            const int i = io == 0 ? 0 : io == 1 ? 3 : io - 1;
+            const bool halo = (i == 0 && wr == 0) || (i == 3 && wr == 1);   // (wave-uniform)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    floatx4 tt;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tt[q] = acc[mb][i][g * 4 + q];
+                    tt += bias4[mb][g];
+                    xres[mb][i][g] = tt * 0.2f + xres[mb][i][g];
+                }
+                x_row_out(mb, i, obase, !r2 && (mb == 0 || !x1_halo_only || halo));
+            }
+        }
+        if (r2) {
+            const int frag_lane = wc * 2048 + lane * 4;   // fragment order: instruction (mb, g) owns 1 KiB, lane l its 16 B
+            // rows go two at a time: the 16 loads of the RRDB-level stream are all issued before any is consumed
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+                floatx4 a2[2][2][4];
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const long rowb = ((long)img * pp.H + Y0 + wr * 4 + ih + k) * pp.W * 64;
+                    const long rowb = ((long)img * pp.H + Y0 + wr * 4 + (ih == 0 ? 3 * k : 1 + k)) * pp.W * 64;
                     const float* q2 = pp.xrr + rowb + (r2_pixel ? X * 64 + hi * 4 : frag_lane);
                     const int sm = r2_pixel ? 32 : 1024, sg = r2_pixel ? 8 : 256;
 #pragma unroll
@@ -402,45 +464,18 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g) a2[k][mb][g] = *(const floatx4*)(q2 + mb * sm + g * sg);
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int i = ih + k;
-                const int Y = Y0 + wr * 4 + i;
-                const long rowb = ((long)img * pp.H + Y) * pp.W * 64;
+                for (int k = 0; k < 2; ++k) {
+                    const int i = ih == 0 ? 3 * k : 1 + k;
+                    const bool halo = (i == 0 && wr == 0) || (i == 3 && wr == 1);
+                    const long rowb = ((long)img * pp.H + Y0 + wr * 4 + i) * pp.W * 64;
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-                    unsigned hp[4][2];
+                    for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        floatx4 tt;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) tt[q] = acc[mb][i][g * 4 + q];
-                        tt += bias4[mb][g];
-                        tt = tt * 0.2f + xres[mb][i][g];
-                        if (r2) tt = tt * 0.2f + a2[k][mb][g];
-                        xres[mb][i][g] = tt;
-                        half4 h4;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) h4[q] = (_Float16)tt[q];
-                        const uint2 u = __builtin_bit_cast(uint2, h4);
-                        hp[g][0] = u.x;
-                        hp[g][1] = u.y;
+                        for (int g = 0; g < 4; ++g) xres[mb][i][g] = xres[mb][i][g] * 0.2f + a2[k][mb][g];
+                        x_row_out(mb, i, obase, mb == 0 || !x1_halo_only || halo);
                     }
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        auto s0 = __builtin_amdgcn_permlane32_swap(hp[2 * m][0], hp[2 * m + 1][0], false, false);
-                        auto s1 = __builtin_amdgcn_permlane32_swap(hp[2 * m][1], hp[2 * m + 1][1], false, false);
-                        const uintx4 raw = {s0[0], s1[0], s0[1], s1[1]};
-                        if (mb == 1) x1p[i][m] = raw;
-                        char* o = obase + (long)mb * pp.plane_b + (long)(Y + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16;
-                        if (wt)
-                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
-                        else
-                            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
-                    }
-                }
-                if (r2) {   // the RRDB-level stream goes back to memory (fragment order): private to this workgroup
+                    // the RRDB-level stream goes back to memory (fragment order): private to this workgroup
                     const float* q = pp.xrr + rowb;
                     const unsigned vo = (unsigned)frag_lane * 4u;
 #pragma unroll
@@ -498,14 +533,23 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                          smem + stage_off(1, (gs + 1) & 1), X1r);
                 ++gs;
             }
-            for (int c = 2; c + 1 < n; ++c) {      // chunks 2 ..: stage chunk c + 1 (X2, X3) by DMA
-                if (c == kk) {
+            if (n >= 4) {      // step 2: chunk 2; stages chunk 3 (X2) from registers
+                if (kk == 2) {
                     ensure_flags(L);
                     if (aborted) return;
                 }
                 step_sync();
                 const char* st = smem + stage_off(1, gs & 1);
-                run_step(C1{}, I1{}, W5{}, acc, st, st + IN_EX, dcur + (long)(c + 1) * pp.plane_b, wl + (long)(c + 1) * (18 * 1024),
+                run_step(C1{}, I2X{}, W5{}, acc, st, st + IN_EX, dcur + 3l * pp.plane_b, wl + 3 * (18 * 1024),
+                         smem + stage_off(1, (gs + 1) & 1), X2r);
+                ++gs;
+            }
+            if (n >= 5) {      // step 3 (conv4): chunk 3; stages chunk 4 (X3) by DMA
+                ensure_flags(L);
+                if (aborted) return;
+                step_sync();
+                const char* st = smem + stage_off(1, gs & 1);
+                run_step(C1{}, I1{}, W5{}, acc, st, st + IN_EX, dcur + 4l * pp.plane_b, wl + 4 * (18 * 1024),
                          smem + stage_off(1, (gs + 1) & 1), x1p);
                 ++gs;
             }
@@ -520,12 +564,19 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             }
             if (PROF) p2 = __builtin_amdgcn_s_memtime();
             uintx4 kept[4][2];
-            epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept);
+            epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept,
+                  P3_SKIPST && P3_S1 && (kk == 0 || (P3_X2REG && kk == 1)));
             if (kk == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int m = 0; m < 2; ++m) X1r[i][m] = kept[i][m];
+            }
+            if (kk == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) X2r[i][m] = kept[i][m];
             }
             pending_pub = true;   // published behind the next top-of-step barrier (whose vmcnt(0) covers these stores)
             pub_val = L + 1;
@@ -563,7 +614,12 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 const char* st = smem + stage_off(2, 1);
                 run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (36 * 1024), smem + stage_off(2, 0), X1r);
             }
-            for (int c = 2; c < 5; ++c) {
+            step_sync();
+            {   // chunk 2; stages chunk 3 (X2) from registers
+                const char* st = smem + stage_off(2, 0);
+                run_step(C2{}, I2X{}, W9{}, acc, st, st + IN_EX, dcur + 3l * pp.plane_b, wl + 3 * (36 * 1024), smem + stage_off(2, 1), X2r);
+            }
+            for (int c = 3; c < 5; ++c) {      // chunks 3, 4; stage X3, X4 by DMA
                 if (c == 4) {      // X4 (chunk 5) is conv4's output on the neighbours: checked in front of the step that fetches it
                     ensure_flags(L);
                     if (aborted) break;
@@ -581,7 +637,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             }
             const bool r2 = (rdb % 3) == 2;
             if (PROF) p2 = __builtin_amdgcn_s_memtime();
-            epi64(acc, dnxt - (long)Y0 * pp.row_b, r2, rdb == 2);
+            epi64(acc, dnxt - (long)Y0 * pp.row_b, r2, rdb == 2, P3_SKIPST && P3_S1 && rdb + 1 < nrdb);   // (the last x goes out whole: conv_body reads it)
             if (PROF) p3 = __builtin_amdgcn_s_memtime();
             // RDB seam: the next conv1's first chunk is THIS layer's output on the neighbours: publish now, then wait for them
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
