@@ -82,21 +82,23 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     const unsigned long long tail_mask = uni64(__builtin_amdgcn_ballot_w64(tail_ok));
     const unsigned long long w4_mask = uni64(wave < 2 ? ~0ull : 0ull);   // weight fragments 16, 17 of an 18-fragment chunk
 
-    // ---- the LDS-DMA statement.  `s_nop 4` = 5 wait states: covers "SALU writes M0 -> LDS-DMA" (1) and "VALU writes an
-    // SGPR (v_readfirstlane, spill reload) -> VMEM reads it as scalar base" (5) whatever the compiler emitted just before.
-    // The statement is placed in the shadow of an MFMA, where these cycles are free.
+    // ---- the LDS-DMA statement carries its own wait states: 5 between anything the compiler emitted in front of it and the
+    // VMEM instruction (s_mov m0 + s_nop 3, or s_mov m0 + EXEC write + s_nop 2).  That covers "SALU writes M0 -> LDS-DMA" (1)
+    // and "a VALU-written SGPR (v_readfirstlane, SGPR-spill reload) read as the scalar base" (5): hazard-proof by construction
+    // wherever the register allocator reloads a base (it does: dropping the nops put a v_readlane 2 wait states in front of
+    // a DMA, caught by tools/hazcheck.py).
     auto dma = [&](auto sc1_tag, const unsigned long long base, const unsigned voff, const unsigned lds_off) {
         if constexpr (decltype(sc1_tag)::value)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2 sc1" ::"s"(lds_off), "v"(voff), "s"(base) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2 sc1" ::"s"(lds_off), "v"(voff), "s"(base) : "memory", "m0");
         else
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_off), "v"(voff), "s"(base) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_off), "v"(voff), "s"(base) : "memory", "m0");
     };
     auto dma_masked = [&](auto sc1_tag, const unsigned long long base, const unsigned voff, const unsigned lds_off, const unsigned long long mask) {
         if constexpr (decltype(sc1_tag)::value)
-            asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 exec, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %2, %3 sc1\n\ts_mov_b64 exec, -1"
+            asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 exec, %0\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %2, %3 sc1\n\ts_mov_b64 exec, -1"
                          ::"s"(mask), "s"(lds_off), "v"(voff), "s"(base) : "memory", "m0");
         else
-            asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 exec, %0\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1"
+            asm volatile("s_mov_b32 m0, %1\n\ts_mov_b64 exec, %0\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1"
                          ::"s"(mask), "s"(lds_off), "v"(voff), "s"(base) : "memory", "m0");
     };
     using SC1 = std::true_type;
@@ -220,11 +222,17 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     const int soff = (wr * 4 + 1) * G::ROW_B + (X + 1) * PIX_B;                 // this lane's pixel record in a staged tile, row 0
     const int sswz[2] = {((0 + hi) ^ (((X + 1) >> 2) & 3)) << 4, ((2 + hi) ^ (((X + 1) >> 2) & 3)) << 4};
     // the zero border columns of the wave's 4 rows (a DMA-staged plane brings them along; a register-staged one must write them)
-    const int boff = (wr * 4 + 1 + (lane >> 2)) * G::ROW_B + (wc ? (G::COLS - 1) * PIX_B : 0) + (lane & 3) * 16;
-    // halo-only DMA: statements j = 0 (row 0), 1 (its last 128 B), 9 (row 9 from byte 38016 on), 10 (tail), lane-masked to the halo rows
-    auto halo_lane = [&](int j, int row) { const int u = j * 256 + tid; return u < G::UNITS && u / (G::COLS * 4) == row; };
-    const unsigned long long hmask1 = uni64(__builtin_amdgcn_ballot_w64(halo_lane(1, 0)));
-    const unsigned long long hmask9 = uni64(__builtin_amdgcn_ballot_w64(halo_lane(9, G::ROWS - 1)));
+    // (lanes 0..19: tile rows 0..4 for the upper pair of waves, 5..9 for the lower one, i.e. the own rows plus one halo row)
+    const int boff = (wr * 5 + (lane >> 2)) * G::ROW_B + (wc ? (G::COLS - 1) * PIX_B : 0) + (lane & 3) * 16;
+    // halo-only DMA: the 64 real pixels of tile row 0 / row 9 are exactly one 256-lane statement each (4 KiB, lane-linear in
+    // LDS behind the border pixel; the XOR swizzle is applied to the source address as everywhere)
+    int hoff[2];
+    {
+        const int px = 1 + (tid >> 2), ps = tid & 3;
+#pragma unroll
+        for (int hrow = 0; hrow < 2; ++hrow)
+            hoff[hrow] = (hrow ? G::ROWS - 1 : 0) * pp.row_b + px * PIX_B + ((ps ^ ((px >> 2) & 3)) << 4);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)      // x's second chunk as conv_first wrote it (fp16 plane 1 of dense[0])
 #pragma unroll
@@ -233,12 +241,13 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
 
     // ---- one K step.  CB = cout/32 of the running layer.  What is staged for the NEXT step is a compile-time property:
     //   IN: 0 no input plane | 1 input plane by LDS-DMA (11 statements) | 2 input plane from registers (8 ds_write_b128 + 1
-    //   border write + 4 halo DMA statements);   NW: weight DMA statements per wave (0 | 5 = 18 fragments | 9 = 36 fragments)
+    //   border write + 2 halo DMA statements);   NW: weight DMA statements per wave (0 | 5 = 18 fragments | 9 = 36 fragments)
     auto run_step = [&](auto cb_tag, auto in_tag, auto nw_tag, floatx16 (&acc)[decltype(cb_tag)::value][4], const char* sbi, const char* sbw,
                         const char* nsrc, const char* nw, char* dst, const uintx4 (&rsrc)[4][2]) {
         constexpr int CB = decltype(cb_tag)::value, IN = decltype(in_tag)::value, NW = decltype(nw_tag)::value;
         constexpr int NRD = G::NP + 3 * CB, NMF = 12 * CB;
-        constexpr int NDMA = (IN == 1 ? 11 : IN == 2 ? 4 : 0) + NW;     // DMA statements
+        constexpr int NH = 2;                                           // halo DMA statements of a register-staged plane
+        constexpr int NDMA = (IN == 1 ? 11 : IN == 2 ? NH : 0) + NW;    // DMA statements
         constexpr int ND = NDMA + (IN == 2 ? 9 : 0);                    // + LDS stores of a register-staged plane
         constexpr int RSH = (NRD + P3_READS_PER_SHADOW - 1) / P3_READS_PER_SHADOW;   // MFMA shadows of a group that carry LDS reads
         constexpr int DPG = NMF - RSH;                                                 // ... that can carry a staging item
@@ -259,24 +268,19 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             }
         };
         auto stage_item = [&](const int d) {
-            if ((P3_ABL & 1) && d >= (IN == 1 ? 11 : IN == 2 ? 4 : 0) && d < NDMA) return;
-            if ((P3_ABL & 2) && d < (IN == 1 ? 11 : IN == 2 ? 4 : 0)) return;
+            if ((P3_ABL & 1) && d >= (IN == 1 ? 11 : IN == 2 ? NH : 0) && d < NDMA) return;
+            if ((P3_ABL & 2) && d < (IN == 1 ? 11 : IN == 2 ? NH : 0)) return;
             if ((P3_ABL & 4) && d >= NDMA) return;
             if constexpr (IN == 2) {
-                if (d < 4) {            // the neighbours' rows
-                    constexpr int HJ[4] = {0, 1, 9, 10};
-                    const int j = HJ[d];
-                    if (j == 0)
-                        dma(SC1{}, ibase, goff[0], din_w);
-                    else
-                        dma_masked(SC1{}, ibase, goff[j], din_w + j * 4096, uni64(j == 1 ? hmask1 : j == 9 ? hmask9 : tail_mask));
-                } else if (d < 4 + NW) {
-                    dma_item(std::integral_constant<int, 0>{}, nw_tag, d - 4, ibase, wbase, din_w, dw_w);
-                } else if (d < 4 + NW + 8) {
-                    const int e = d - 4 - NW, i = e >> 1, m = e & 1;
+                if (d < NH) {           // the neighbours' rows
+                    dma(SC1{}, ibase, hoff[d], din_w + (d ? G::ROWS - 1 : 0) * G::ROW_B + PIX_B);
+                } else if (d < NH + NW) {
+                    dma_item(std::integral_constant<int, 0>{}, nw_tag, d - NH, ibase, wbase, din_w, dw_w);
+                } else if (d < NH + NW + 8) {
+                    const int e = d - NH - NW, i = e >> 1, m = e & 1;
                     *(uintx4*)(dst + soff + sswz[m] + i * G::ROW_B) = rsrc[i][m];
                 } else {
-                    if (lane < 16) *(uintx4*)(dst + boff) = uintx4{0u, 0u, 0u, 0u};
+                    if (lane < 20) *(uintx4*)(dst + boff) = uintx4{0u, 0u, 0u, 0u};
                 }
             } else {
                 dma_item(std::integral_constant<int, IN == 1 ? 11 : 0>{}, nw_tag, d, ibase, wbase, din_w, dw_w);
