@@ -186,6 +186,13 @@ typedef struct srbh_hconv_args {
     int post_relu;
 } srbh_hconv_args;
 int srbh_hconv_f32(const srbh_hconv_args* a, void* stream);
+/* The same convolution with fp16 OPERANDS (staged activations and weights rounded to fp16, fp32 accumulate on
+ * v_mfma_f32_16x16x16_f16; inputs / outputs / BatchNorm statistics stay fp32 in memory): 1/8 of the fp32 matrix-core time,
+ * so the kernel runs at its HBM traffic (the head is HBM-bound; BASELINE configs[4] asks for fp16 MFMA).
+ * `w` is the fp16 pack of srbh_hpack_conv_h16.  srbh_hconv_f32 remains the strict mode (<= 2e-5 against the reference). */
+size_t srbh_hpack_h16_bytes(int cout, int cin, int ksize);
+int srbh_hpack_conv_h16(const float* w_oihw, int cout, int cin, int ksize, int transpose_flip, void* packed, void* stream);
+int srbh_hconv_h16(const srbh_hconv_args* a, void* stream);
 
 /* training-mode nn.BatchNorm2d statistics (SR/HRfuse.py:124,132,135): partial sums -> biased batch variance ->
  * scale = gamma/sqrt(var+eps), shift = beta - mean*scale; running stats updated with `momentum` and the unbiased

@@ -22,6 +22,7 @@ namespace {
 using namespace srbh;
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 constexpr int HT_W = 64;                    // output tile of one workgroup: (4 * RPW) rows x 64 columns, RPW rows per wave
 constexpr int HC = 16;                      // input channels per LDS chunk
@@ -35,6 +36,12 @@ __device__ __forceinline__ int plane_base(int q) {   // bank staggering, see DES
     return q * plane_dw(RPW) + (q & 1) * 16 + (q >> 2) * 8;
 }
 constexpr int in_dw(int rpw) { return 16 * plane_dw(rpw) + 64; }
+// H16 form (fp16 operands, srbh_hconv_h16): the staged tile is pixel-major, one 32-byte record of 16 fp16 channels per
+// pixel, the four 8-byte channel quads XOR-swizzled with bit 3 of the column so that the 16-pixel x 4-quad ds_read_b64
+// of a B fragment (16 records at a 32-byte pitch = twice the 256-byte bank width) is conflict free for any dx shift
+__device__ __forceinline__ int h16_off(int r, int col, int quad, int cols) {
+    return (r * cols + col) * 32 + ((quad ^ (((col >> 3) & 1) << 1)) << 3);
+}
 
 struct HParams {
     const float* src0; const float* src1;
@@ -58,9 +65,13 @@ struct HParams {
 // NOB = cout/16 (1, 2 or 4), KS = 3 or 1, RPW = output rows per wave (2: 8-row tiles, 54 KiB of LDS, 2 workgroups per CU;
 // 1: 4-row tiles, 38 KiB, ~half the registers -> 4 workgroups per CU: more tiles in flight to hide the staging latency
 // of a one-tile-per-workgroup kernel, for 20 % more halo reads)
-template <int NOB, int KS, int RPW>
+// H16 = 1 (srbh_hconv_h16): same kernel, but the staged tile is rounded to fp16 and the contraction runs on
+// v_mfma_f32_16x16x16_f16 (A = 16 out-channels x the chunk's 16 in-channels of one tap, held in registers; B = 16
+// pixels x the same 16 channels; fp32 accumulate; D layout identical to the fp32 form, so the epilogue is shared): at
+// 1/8 of the fp32 matrix-core time the kernel is bound by its HBM traffic, which is what SURVEY 8d prescribes for the head.
+template <int NOB, int KS, int RPW, bool H16>
 __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
-    constexpr int HT_H = 4 * RPW, IN_DW = in_dw(RPW), NI = 4 * RPW;
+    constexpr int HT_H = 4 * RPW, IN_DW = H16 ? ((HT_H + 2) * (HT_W + 2) * 8) : in_dw(RPW), NI = 4 * RPW;
     extern __shared__ __attribute__((aligned(16))) float hsm[];
     constexpr int TAPS = KS * KS;
     constexpr int HALO = KS / 2;
@@ -129,8 +140,16 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
             for (int it = 0; it < NIT; ++it) {
                 if (where[it] >= 0) {
                     const int cg = where[it] >> 16, off = where[it] & 0xffff;
+                    if constexpr (H16) {
+                        const int r = off / RS, col = off - r * RS;
+                        half4 hv;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) s_in[plane_base<RPW>(cg * 4 + j) + off] = ld[it][j];
+                        for (int j = 0; j < 4; ++j) hv[j] = (_Float16)ld[it][j];
+                        *(half4*)((char*)s_in + h16_off(r, col, cg, COLS)) = hv;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s_in[plane_base<RPW>(cg * 4 + j) + off] = ld[it][j];
+                    }
                 }
             }
         } else
@@ -165,13 +184,44 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                     }
                 }
             }
+            if constexpr (H16) {
+                half4 hv;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s_in[plane_base<RPW>(cg * 4 + j) + r * RS + col] = v[j];
+                for (int j = 0; j < 4; ++j) hv[j] = (_Float16)v[j];
+                *(half4*)((char*)s_in + h16_off(r, col, cg, COLS)) = hv;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s_in[plane_base<RPW>(cg * 4 + j) + r * RS + col] = v[j];
+            }
         }
-        // ---- weights of this chunk (already in A-fragment order)
-        for (int u = tid; u < W_DW / 4; u += 256)
-            ((floatx4*)s_w)[u] = ((const floatx4*)(p.w + (long)c * W_DW))[u];
+        // ---- weights of this chunk (already in A-fragment order).  H16: 8 bytes per lane and (tap, ob), straight into registers
+        half4 wa[H16 ? TAPS : 1][H16 ? NOB : 1];
+        if constexpr (H16) {
+            const half4* wp = (const half4*)p.w + (long)c * (TAPS * NOB * 64) + lane;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) wa[tap][ob] = wp[(tap * NOB + ob) * 64];
+        } else {
+            for (int u = tid; u < W_DW / 4; u += 256)
+                ((floatx4*)s_w)[u] = ((const floatx4*)(p.w + (long)c * W_DW))[u];
+        }
         __syncthreads();
+        if constexpr (H16) {
+            // wave owns RPW rows; 4 column tiles of 16 pixels each; one MFMA per (tap, tile, ob) over the chunk's 16 channels
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int dy = tap / KS, dx = tap - dy * KS;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const half4 b = *(const half4*)((const char*)s_in + h16_off(wave * RPW + dy + (i >> 2), dx + (i & 3) * 16 + l15, kk, COLS));
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob)
+                        acc[ob][i] = __builtin_amdgcn_mfma_f32_16x16x16f16(wa[tap][ob], b, acc[ob][i], 0, 0, 0);
+                }
+            }
+            continue;
+        }
         // ---- MFMA: wave owns RPW rows; 4 column tiles of 16 px each
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
@@ -313,6 +363,27 @@ __global__ void hpack_kernel(const float* __restrict__ w, float* __restrict__ ou
     out[idx] = v;
 }
 
+// fp16 form: [chunk][tap][ob][lane 64][4]  (A fragment of v_mfma_f32_16x16x16_f16: row = lane&15, k = 4*(lane>>4) + 0..3)
+__global__ void hpack_h16_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int cout, int cin, int ks, int nchunk,
+                                 int nob, int transpose_flip) {
+    const int taps = ks * ks;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)nchunk * taps * nob * 64 * 4;
+    if (idx >= total) return;
+    int j = idx & 3;
+    int lane = (idx >> 2) & 63;
+    long f = idx >> 8;
+    int ob = f % nob; f /= nob;
+    int tap = f % taps;
+    int chunk = f / taps;
+    int oc = ob * 16 + (lane & 15);
+    int ic = chunk * 16 + (lane >> 4) * 4 + j;
+    float v = 0.f;
+    if (oc < cout && ic < cin)
+        v = transpose_flip ? w[((long)ic * cout + oc) * taps + (taps - 1 - tap)] : w[((long)oc * cin + ic) * taps + tap];
+    out[idx] = (_Float16)v;
+}
+
 // ---- BatchNorm: partial sums -> scale/shift (+ running stats) ------------------------------------------------------
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, double count, const float* gamma,
                                    const float* beta, float eps, float momentum, float* running_mean,
@@ -415,17 +486,18 @@ __global__ void nearest2x_kernel(const floatx4* __restrict__ src, floatx4* __res
     dst[idx] = src[(((long)b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * C4 + c];
 }
 
-template <int NOB, int KS, int RPW>
+template <int NOB, int KS, int RPW, bool H16 = false>
 int launch_hconv(HParams& p, int B, int H, int W, hipStream_t st) {
-    constexpr int LDS_B = (in_dw(RPW) + KS * KS * 4 * NOB * 64) * 4;
+    constexpr int LDS_B = H16 ? ((4 * RPW + 2) * (HT_W + 2) * 32 > 4 * 2 * NOB * 16 * 4 ? (4 * RPW + 2) * (HT_W + 2) * 32 : 4 * 2 * NOB * 16 * 4)
+                              : (in_dw(RPW) + KS * KS * 4 * NOB * 64) * 4;
     p.tiles_x = (W + HT_W - 1) / HT_W;
     p.tiles_per_img = p.tiles_x * ((H + 4 * RPW - 1) / (4 * RPW));
     const int nblocks = p.tiles_per_img * B;
     if (LDS_B > 65536) {
-        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hconv_f32_kernel<NOB, KS, RPW>,
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hconv_f32_kernel<NOB, KS, RPW, H16>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)));
     }
-    hipLaunchKernelGGL((hconv_f32_kernel<NOB, KS, RPW>), dim3(nblocks), dim3(256), LDS_B, st, p);
+    hipLaunchKernelGGL((hconv_f32_kernel<NOB, KS, RPW, H16>), dim3(nblocks), dim3(256), LDS_B, st, p);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }
@@ -460,7 +532,22 @@ extern "C" int srbh_hpack_conv_f32(const float* w, int cout, int cin, int ksize,
 
 extern "C" size_t srbh_bn_stats_bytes(int C) { return C > 0 ? (size_t)NSLOT * 2 * C * sizeof(double) : 0; }
 
-extern "C" int srbh_hconv_f32(const srbh_hconv_args* a, void* stream) {
+extern "C" size_t srbh_hpack_h16_bytes(int cout, int cin, int ksize) {
+    if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    return (size_t)((cin + 15) / 16) * ksize * ksize * ((cout + 15) / 16) * 64 * 4 * sizeof(_Float16);
+}
+
+extern "C" int srbh_hpack_conv_h16(const float* w, int cout, int cin, int ksize, int transpose_flip, void* packed, void* stream) {
+    SRBH_REQUIRE(w && packed && cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), "srbh_hpack_conv_h16: bad arguments");
+    int nchunk = (cin + 15) / 16, nob = (cout + 15) / 16;
+    long total = (long)nchunk * ksize * ksize * nob * 64 * 4;
+    hipLaunchKernelGGL(hpack_h16_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (_Float16*)packed, cout,
+                       cin, ksize, nchunk, nob, transpose_flip);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+static int hconv_impl(const srbh_hconv_args* a, void* stream, const bool h16) {
     SRBH_REQUIRE(a && a->src0 && a->w && a->out, "srbh_hconv_f32: null pointer");
     SRBH_REQUIRE(a->c0 > 0 && a->c1 >= 0 && (a->c1 == 0 || a->src1), "srbh_hconv_f32: bad channel split %d+%d", a->c0, a->c1);
     SRBH_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0, "srbh_hconv_f32: bad geometry");
@@ -491,6 +578,13 @@ extern "C" int srbh_hconv_f32(const srbh_hconv_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->stats) SRBH_HIP(hipMemsetAsync(a->stats, 0, srbh_bn_stats_bytes(p.cout), st));
     const int B = a->B, H = a->H, W = a->W;
+    if (h16) {   // fp16 operands: 8-row tiles (the staged tile is 21 KiB: seven workgroups per CU either way)
+        if (a->ksize == 3)
+            return nob == 1 ? launch_hconv<1, 3, 2, true>(p, B, H, W, st)
+                            : (nob == 2 ? launch_hconv<2, 3, 2, true>(p, B, H, W, st) : launch_hconv<4, 3, 2, true>(p, B, H, W, st));
+        return nob == 1 ? launch_hconv<1, 1, 2, true>(p, B, H, W, st)
+                        : (nob == 2 ? launch_hconv<2, 1, 2, true>(p, B, H, W, st) : launch_hconv<4, 1, 2, true>(p, B, H, W, st));
+    }
     if (hconv_rpw_small() == 1) {
         if (a->ksize == 3)
             return nob == 1 ? launch_hconv<1, 3, 1>(p, B, H, W, st)
@@ -504,6 +598,9 @@ extern "C" int srbh_hconv_f32(const srbh_hconv_args* a, void* stream) {
     return nob == 1 ? launch_hconv<1, 1, 2>(p, B, H, W, st)
                     : (nob == 2 ? launch_hconv<2, 1, 2>(p, B, H, W, st) : launch_hconv<4, 1, 2>(p, B, H, W, st));
 }
+
+extern "C" int srbh_hconv_f32(const srbh_hconv_args* a, void* stream) { return hconv_impl(a, stream, false); }
+extern "C" int srbh_hconv_h16(const srbh_hconv_args* a, void* stream) { return hconv_impl(a, stream, true); }
 
 extern "C" int srbh_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta,
                                 float eps, float momentum, float* running_mean, float* running_var, float* scale,

@@ -57,24 +57,51 @@ def empty_nhwc(B, Cc, H, W, device):
     return torch.empty_strided((B, Cc, H, W), (H * W * Cc, 1, W * Cc, Cc), dtype=torch.float32, device=device)
 
 
+# ---- operand precision of the head convolutions ---------------------------------------------------------------------
+# "f32": exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32), <= 2e-5 against the reference -- the strict mode;
+# "f16": the staged activations and the weights are rounded to fp16, fp32 accumulate (srbh_hconv_h16): ~1/8 of the
+#        matrix-core time, the kernel then runs at its HBM traffic (BASELINE configs[4]: "fp16 MFMA");
+# "auto" (default): f16 under torch.no_grad() / eval (inference, the predict path), f32 when a graph is recorded
+#        (training: forward, data- and weight-gradients stay exact).  Override: SRBH_HEAD_PRECISION or set_head_precision().
+import os as _os
+
+_HEAD_PRECISION = {"mode": _os.environ.get("SRBH_HEAD_PRECISION", "auto"), "depth": 0}   # depth > 0: inside an autograd Function
+
+
+def set_head_precision(mode="auto"):
+    if mode not in ("auto", "f16", "f32"):
+        raise ValueError("head precision must be 'auto', 'f16' or 'f32'")
+    _HEAD_PRECISION["mode"] = mode
+
+
+def head_h16():
+    m = _HEAD_PRECISION["mode"]
+    # (torch disables grad mode inside autograd.Function.forward / backward: those bump "depth" instead, hrfuse_autograd._exact)
+    return m == "f16" or (m == "auto" and not torch.is_grad_enabled() and _HEAD_PRECISION["depth"] == 0)
+
+
 class _PackedConv:
-    """HWPACK32 image of one conv weight (+ zero-padded bias), rebuilt when the parameter changes."""
+    """HWPACK32 (or its fp16 form) of one conv weight (+ zero-padded bias), rebuilt when the parameter changes."""
 
     def __init__(self):
         self.key = None
         self.w = None
         self.b = None
 
-    def get(self, conv: nn.Conv2d):
+    def get(self, conv: nn.Conv2d, h16=False):
         w = conv.weight
-        key = (w._version, w.data_ptr(), None if conv.bias is None else (conv.bias._version, conv.bias.data_ptr()))
+        key = (w._version, w.data_ptr(), None if conv.bias is None else (conv.bias._version, conv.bias.data_ptr()), bool(h16))
         if key != self.key:
             L = _lib.lib()
             cout, cin, ks, _ = w.shape
-            buf = torch.empty(L.srbh_hpack_bytes(cout, cin, ks) // 4, dtype=torch.float32, device=w.device)
             wc = w.detach().float().contiguous()
-            _lib.check(L.srbh_hpack_conv_f32(wc.data_ptr(), cout, cin, ks, 0, buf.data_ptr(), _lib.stream_ptr()),
-                       "hpack_conv_f32")
+            if h16:
+                buf = torch.empty(L.srbh_hpack_h16_bytes(cout, cin, ks) // 2, dtype=torch.float16, device=w.device)
+                _lib.check(L.srbh_hpack_conv_h16(wc.data_ptr(), cout, cin, ks, 0, buf.data_ptr(), _lib.stream_ptr()), "hpack_conv_h16")
+            else:
+                buf = torch.empty(L.srbh_hpack_bytes(cout, cin, ks) // 4, dtype=torch.float32, device=w.device)
+                _lib.check(L.srbh_hpack_conv_f32(wc.data_ptr(), cout, cin, ks, 0, buf.data_ptr(), _lib.stream_ptr()),
+                           "hpack_conv_f32")
             b = None
             if conv.bias is not None:
                 b = torch.zeros((cout + 15) // 16 * 16, dtype=torch.float32, device=w.device)
@@ -96,7 +123,8 @@ def hconv(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_
     cout, cin, ks, _ = conv.weight.shape
     if cin != c0 + c1:
         raise ValueError(f"conv expects {cin} input channels, got {c0}+{c1}")
-    w, b = packed.get(conv)
+    h16 = head_h16()
+    w, b = packed.get(conv, h16)
     a = _lib.HConvArgs()
     a.src0, a.c0 = x0.data_ptr(), c0
     if pre is not None:
@@ -119,7 +147,7 @@ def hconv(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_
     if want_stats:
         stats = torch.empty(L.srbh_bn_stats_bytes((cout + 15) // 16 * 16) // 8, dtype=torch.float64, device=x0.device)
         a.stats = stats.data_ptr()
-    _lib.check(L.srbh_hconv_f32(C.byref(a), _lib.stream_ptr()), "hconv_f32")
+    _lib.check((L.srbh_hconv_h16 if h16 else L.srbh_hconv_f32)(C.byref(a), _lib.stream_ptr()), "hconv")
     return out, stats
 
 

@@ -23,21 +23,25 @@ class _PackedGrad:
         self.key = None
         self.w = None
 
-    def get(self, weight):
-        key = (weight._version, weight.data_ptr())
+    def get(self, weight, h16=False):
+        key = (weight._version, weight.data_ptr(), bool(h16))
         if key != self.key:
             L = _lib.lib()
             cout, cin, ks, _ = weight.shape
-            buf = torch.empty(L.srbh_hpack_bytes(cin, cout, ks) // 4, dtype=torch.float32, device=weight.device)
             wc = weight.detach().float().contiguous()
-            _lib.check(L.srbh_hpack_conv_f32(wc.data_ptr(), cin, cout, ks, 1, buf.data_ptr(), _lib.stream_ptr()),
-                       "hpack_conv_f32(T)")
+            if h16:
+                buf = torch.empty(L.srbh_hpack_h16_bytes(cin, cout, ks) // 2, dtype=torch.float16, device=weight.device)
+                _lib.check(L.srbh_hpack_conv_h16(wc.data_ptr(), cin, cout, ks, 1, buf.data_ptr(), _lib.stream_ptr()), "hpack_conv_h16(T)")
+            else:
+                buf = torch.empty(L.srbh_hpack_bytes(cin, cout, ks) // 4, dtype=torch.float32, device=weight.device)
+                _lib.check(L.srbh_hpack_conv_f32(wc.data_ptr(), cin, cout, ks, 1, buf.data_ptr(), _lib.stream_ptr()),
+                           "hpack_conv_f32(T)")
             # (no host sync: `wc` is recycled by torch's stream-ordered allocator, and the pack kernel runs on that stream)
             self.key, self.w = key, buf
         return self.w
 
 
-def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None):
+def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None, h16=False):
     L = _lib.lib()
     x0 = srcs[0]
     B, c0, Hh, Ww = x0.shape
@@ -56,15 +60,17 @@ def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None):
     a.out = out.data_ptr()
     if res is not None:          # out = conv + res in the conv's epilogue (exact: fma(y, 1, res))
         a.res1, a.res1_ld, a.res1_scale = res.data_ptr(), res.shape[1], 1.0
-    _lib.check(L.srbh_hconv_f32(C.byref(a), _lib.stream_ptr()), "hconv_f32")
+    _lib.check((L.srbh_hconv_h16 if h16 else L.srbh_hconv_f32)(C.byref(a), _lib.stream_ptr()), "hconv")
     return out
 
 
 def conv_dgrad(g, weight, cache: _PackedGrad, res=None):
     """dX = conv^T(g, W) (+ res): the forward kernel with transposed + flipped weights; `res` (NHWC, same shape as dX) is the
-    gradient arriving over a skip connection, added in the epilogue instead of by a separate pass."""
+    gradient arriving over a skip connection, added in the epilogue instead of by a separate pass.  fp16 operands only in
+    the explicit "f16" head precision mode (H.set_head_precision)."""
     cout, cin, ks, _ = weight.shape
-    return _hconv_raw([g], cache.get(weight), None, cin, ks, res=res)
+    h16 = H.head_h16()
+    return _hconv_raw([g], cache.get(weight, h16), None, cin, ks, res=res, h16=h16)
 
 
 def conv_wgrad(srcs, pre, g, cout, ks):
@@ -280,3 +286,21 @@ def blocks_forward(blocks, inputs):
                                  None if ds is None else ds[1].bias)
         x1 = None
     return x0
+
+
+# ---- head precision: everything inside these Functions belongs to a recorded graph (training).  torch switches grad mode
+# off inside Function.forward / backward, so the "auto" precision rule (fp16 operands only for inference) is told explicitly.
+def _exact(fn):
+    def wrapped(*a, **k):
+        H._HEAD_PRECISION["depth"] += 1
+        try:
+            return fn(*a, **k)
+        finally:
+            H._HEAD_PRECISION["depth"] -= 1
+    wrapped.__name__ = getattr(fn, "__name__", "wrapped")
+    return wrapped
+
+
+for _cls in [v for v in list(globals().values()) if isinstance(v, type) and issubclass(v, torch.autograd.Function) and v is not torch.autograd.Function]:
+    _cls.forward = staticmethod(_exact(_cls.forward))
+    _cls.backward = staticmethod(_exact(_cls.backward))

@@ -1,0 +1,117 @@
+"""GPU: the head's DEFAULT inference precision -- fp16 operands / fp32 accumulate (srbh_hconv_h16, BASELINE configs[4] "fp16
+MFMA").  Two statements: (1) the kernel computes exactly the convolution of the fp16-rounded operands (<= 5e-6 against a
+float64 conv of the same rounded values: summation order only), for every shape / fusion the head uses; (2) the whole head
+stays inside the north star's tolerance on the height maps: <= 1e-3 relative L2 against the reference fixtures (g7) and the
+fp32 CPU oracle.  The strict fp32 mode keeps its 2e-5 tests in test_gpu_head.py."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import srbh_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL_HEAD = 1e-3        # north star: height maps within 1e-3 relative of the reference
+TOL_KERNEL = 5e-6      # vs the float64 conv of the SAME fp16-rounded operands
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def h16(t):
+    return t.half().double()
+
+
+@pytest.mark.parametrize("c0,c1,cout,ks,ps2,hw", [(16, 0, 16, 3, False, (24, 70)), (16, 16, 16, 3, False, (17, 64)), (64, 0, 16, 3, False, (8, 130)),
+                                                   (16, 0, 64, 3, True, (12, 20)), (32, 0, 16, 1, False, (9, 66)), (16, 0, 7, 3, False, (16, 16))])
+def test_h16_conv_equals_conv_of_rounded_operands(c0, c1, cout, ks, ps2, hw):
+    from srbh_amd import hrfuse as H
+    Hh, Ww = hw
+    conv = torch.nn.Conv2d(c0 + c1, cout, ks, 1, ks // 2, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(tuple(conv.weight.shape), 3, -0.3, 0.3))
+        conv.bias.copy_(rnd((cout,), 4))
+    x0, x1 = rnd((2, c0, Hh, Ww), 5), (rnd((2, c1, Hh, Ww), 6) if c1 else None)
+    scale, shift = rnd((c0,), 7, 0.5, 1.5), rnd((c0,), 8, -0.2, 0.2)
+    # reference: pre-affine + ReLU in fp32 (as the kernel does while staging), THEN the fp16 rounding of both operands
+    a = torch.relu(x0 * scale[None, :, None, None] + shift[None, :, None, None])
+    xin = torch.cat([a] + ([x1] if c1 else []), 1)
+    want = F.conv2d(h16(xin), h16(conv.weight), conv.bias.double(), 1, ks // 2).float()
+    if ps2:
+        want = F.pixel_shuffle(want, 2)
+    H.set_head_precision("f16")
+    try:
+        conv = conv.to(DEV)
+        srcs = [H.to_nhwc(x0.to(DEV))] + ([H.to_nhwc(x1.to(DEV))] if c1 else [])
+        got, _ = H.hconv(srcs, conv, H._PackedConv(), pre=(scale.to(DEV), shift.to(DEV), True), ps2=ps2)
+    finally:
+        H.set_head_precision("auto")
+    assert got.shape == want.shape
+    assert O.rel_l2(got.cpu(), want) <= TOL_KERNEL
+
+
+def test_default_inference_head_within_north_star_tolerance(golden_dir):
+    """HRfeature and both HRfuse_residual heads in eval mode under no_grad (-> fp16 operands by default) against the
+    fixtures produced by the imported reference."""
+    from srbh_amd import hrfuse as H
+    from srbh_amd.hrfuse import HRfeature, HRfuse_residual
+    assert H._HEAD_PRECISION["mode"] == "auto"
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, "g7_head.npz")).items()}
+    sd = synth.hrfeature_state_dict(64, 16, 16, seed=18, mode="stress")
+    m = HRfeature(64, 16, 16)
+    m.load_state_dict(sd, strict=True)
+    x = rnd((2, 64, 16, 16), 108)
+    with torch.no_grad():
+        assert H.head_h16()
+        e = O.rel_l2(m.to(DEV).eval()(x.to(DEV)).cpu(), g["g7_hrfeat_eval"])
+    assert 1e-6 < e <= TOL_HEAD, e              # (> 1e-6: the fp16 path really ran)
+    for oc in (1, 7):
+        sd = synth.hrfuse_residual_state_dict(16, 16, 16, oc, 4, seed=19 + oc, mode="stress")
+        m = HRfuse_residual(16, 16, 16, oc, 4)
+        m.load_state_dict(sd, strict=True)
+        a, b = rnd((2, 16, 4, 4), 109), rnd((2, 16, 16, 16), 110)      # (the fixture's inputs)
+        with torch.no_grad():
+            ye = m.to(DEV).eval()(a.to(DEV), b.to(DEV)).cpu()
+        assert O.rel_l2(ye, O.hrfuse_residual(synth.clone_sd(sd), "", a, b, False)) <= TOL_HEAD, oc
+        assert O.rel_l2(ye, g[f"g7_fuse{oc}_eval"]) <= TOL_HEAD, oc
+
+
+def test_training_graph_stays_exact_fp32():
+    """auto mode: a recorded graph (training) keeps the exact-fp32 kernels in forward and backward -- same numbers as the
+    explicit strict mode, bit for bit."""
+    from srbh_amd import hrfuse as H
+    from srbh_amd.hrfuse import HRfeature
+    outs = []
+    for mode in ("auto", "f32"):
+        H.set_head_precision(mode)
+        torch.manual_seed(3)
+        m = HRfeature(64, 16, 16).to(DEV).train()
+        x = rnd((2, 64, 24, 40), 9).to(DEV)
+        y = m(x)
+        y.square().mean().backward()
+        outs.append((y.detach().clone(), m[0].conv1.weight.grad.clone()))
+    H.set_head_precision("auto")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_model_eval_default_precision_height_maps():
+    """SRRegress_Cls_feature.forward in the default inference precision against the CPU reference (stock-op encoder /
+    decoders on CPU + the fp32 oracle head): height / building / aggregated maps <= 1e-3."""
+    import copy
+    from tests.test_gpu_model import cpu_reference, make_model
+    m = make_model(seed=41).eval()
+    x = synth.tiles(2, 8, 64, seed=43)
+    fea = torch.randn(2, 64, 256, 256, generator=torch.Generator().manual_seed(44)) * 0.5
+    with torch.no_grad():
+        want = cpu_reference(copy.deepcopy(m), x, fea, False)
+        got = m.to(DEV)(x.to(DEV), fea.to(DEV))
+    for a, b, name in zip(got, want, ("height", "build", "aggre")):
+        assert O.rel_l2(a.cpu(), b) <= TOL_HEAD, name

@@ -8,6 +8,18 @@ from oracle import srbh_oracle as O
 from oracle import synth
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _strict_head_precision():
+    """These tests pin the STRICT mode of the head (exact-fp32 matrix cores, <= 2e-5 / 2e-4 against the reference); the default
+    inference mode (fp16 operands) has its own tests with its own stated tolerance in tests/test_gpu_head_f16.py."""
+    from srbh_amd import hrfuse
+    hrfuse.set_head_precision("f32")
+    yield
+    hrfuse.set_head_precision("auto")
+
+
 DEV = "cuda:0"
 
 
