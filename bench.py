@@ -152,9 +152,10 @@ def head_kernel_rooflines(dev, B):
     g = H.to_nhwc(torch.randn(B, 16, 256, 256, device=dev))
     pk, pg = H._PackedConv(), HA._PackedGrad()
     gflop = 2 * 9 * 16 * 16 * px / 1e9
+    h16 = H.head_h16()
     for name, fn, nbytes in (
-            ("hconv_f32_kernel 16->16 3x3 fwd + BN statistics", lambda: H.hconv([x], conv, pk, want_stats=True), px * (64 + 64)),
-            ("hconv_f32_kernel 16->16 3x3 data gradient", lambda: HA.conv_dgrad(g, conv.weight, pg), px * (64 + 64)),
+            (f"hconv kernel ({'fp16' if h16 else 'fp32'} operands) 16->16 3x3 fwd + BN statistics", lambda: H.hconv([x], conv, pk, want_stats=True), px * (64 + 64)),
+            (f"hconv kernel ({'bf16' if h16 else 'fp32'} operands) 16->16 3x3 data gradient", lambda: HA.conv_dgrad(g, conv.weight, pg), px * (64 + 64)),
             ("hwgrad_f32_kernel 16->16 3x3 weight gradient", lambda: HA.conv_wgrad([x], None, g, 16, 3), px * (64 + 64))):
         ms = _timed(fn, 10, dev)
         out.append({"kernel": f"{name} @256x256, B={B}", "bound": "hbm", "avg_launch_ms": round(ms, 4),
@@ -233,7 +234,7 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
     line = {
         "metric": "tiles/sec (64x64x8ch->256x256 height) fwd+bwd", "value": round(tiles / elapsed, 2), "unit": "tiles/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f16 operands/f32 acc (RRDB), f32 (head fwd+bwd)",
+        "scaling": "weak", "vs_baseline": None, "dtype": f"f16 operands/f32 acc (RRDB), head convs: {ts.head_precision} (f16 = fwd fp16 / dgrad bf16 operands, wgrad + BN + losses + Adam fp32)",
         "data": "synthetic" + (" (batches drawn on the device each step)" if epoch_tiles else " (one fixed batch)"),
         "config": {"workload": (f"one data-parallel pass over {epoch_tiles} synthetic train tiles (BASELINE.json configs[3]), " if epoch_tiles else "")
                                + f"full train step: RRDBNet fwd (no grad) + SRRegress_Cls_feature fwd/bwd + Adam, batch {batch}/GPU "
@@ -338,7 +339,7 @@ def bench_predict(args, rank, world, dev, dist, n_cities, warmup, batch=128, sma
         "metric": "tiles/sec (64x64x8ch->256x256 height) tiled inference incl. quantise + mosaic", "value": round(total / elapsed, 2),
         "unit": "tiles/s", "n_gpus": world, "steps": len(todo), "warmup": warmup, "ms_per_step": round(elapsed / len(todo) * 1e3, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f16 operands/f32 acc (RRDB), f32 (head), integer mosaic", "data": "synthetic cities, random-init weights",
+        "dtype": "f16 operands/f32 acc (RRDB and head convs), f32 BN-affine / stock-op encoder+decoders, integer mosaic", "data": "synthetic cities, random-init weights",
         "config": {"workload": f"sliding-window predict path, {len(todo)} of 301 synthetic cities (cells log-uniform 200..20000, "
                                f"seed 2024{', the ones closest to the median size' if small else ''}), batch {batch}/GPU (BASELINE.json configs[4])",
                    "cities": len(todo), "tiles": total, "parallelism": f"each city's cells sharded x{world}, integer mosaic row bands sent to rank 0"},

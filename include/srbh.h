@@ -191,8 +191,11 @@ int srbh_hconv_f32(const srbh_hconv_args* a, void* stream);
  * so the kernel runs at its HBM traffic (the head is HBM-bound; BASELINE configs[4] asks for fp16 MFMA).
  * `w` is the fp16 pack of srbh_hpack_conv_h16.  srbh_hconv_f32 remains the strict mode (<= 2e-5 against the reference). */
 size_t srbh_hpack_h16_bytes(int cout, int cin, int ksize);
-int srbh_hpack_conv_h16(const float* w_oihw, int cout, int cin, int ksize, int transpose_flip, void* packed, void* stream);
-int srbh_hconv_h16(const srbh_hconv_args* a, void* stream);
+/* bf16 = 0: fp16 operands (forward: activations and weights are O(1));  bf16 = 1: bfloat16 operands on
+ * v_mfma_f32_16x16x16_bf16 (data gradients: per-pixel gradients of a mean-reduced loss sit far below fp16's normal range,
+ * bf16 keeps fp32's exponent).  The pack and the conv must use the same setting. */
+int srbh_hpack_conv_h16(const float* w_oihw, int cout, int cin, int ksize, int transpose_flip, int bf16, void* packed, void* stream);
+int srbh_hconv_h16(const srbh_hconv_args* a, int bf16, void* stream);
 
 /* training-mode nn.BatchNorm2d statistics (SR/HRfuse.py:124,132,135): partial sums -> biased batch variance ->
  * scale = gamma/sqrt(var+eps), shift = beta - mean*scale; running stats updated with `momentum` and the unbiased

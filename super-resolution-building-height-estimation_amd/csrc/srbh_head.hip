@@ -23,6 +23,27 @@ using namespace srbh;
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+// operand rounding of the 16-bit forms: 1 = fp16 (forward: activations and weights are O(1)), 2 = bf16 (data gradients:
+// per-pixel gradients of a mean loss sit far below fp16's normal range, bf16 keeps fp32's exponent); both RNE
+template <int OPT>
+__device__ __forceinline__ short4v round4(const float (&v)[4]) {
+    short4v r;
+    if constexpr (OPT == 1) {
+        half4 h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = (_Float16)v[j];
+        r = __builtin_bit_cast(short4v, h);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned u = __builtin_bit_cast(unsigned, v[j]);
+            const unsigned rounded = u + 0x7fffu + ((u >> 16) & 1u);          // round to nearest even (NaN/Inf do not occur here)
+            r[j] = (short)(rounded >> 16);
+        }
+    }
+    return r;
+}
 
 constexpr int HT_W = 64;                    // output tile of one workgroup: (4 * RPW) rows x 64 columns, RPW rows per wave
 constexpr int HC = 16;                      // input channels per LDS chunk
@@ -69,8 +90,9 @@ struct HParams {
 // v_mfma_f32_16x16x16_f16 (A = 16 out-channels x the chunk's 16 in-channels of one tap, held in registers; B = 16
 // pixels x the same 16 channels; fp32 accumulate; D layout identical to the fp32 form, so the epilogue is shared): at
 // 1/8 of the fp32 matrix-core time the kernel is bound by its HBM traffic, which is what SURVEY 8d prescribes for the head.
-template <int NOB, int KS, int RPW, bool H16>
+template <int NOB, int KS, int RPW, int OPT>
 __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
+    constexpr bool H16 = OPT != 0;
     constexpr int HT_H = 4 * RPW, IN_DW = H16 ? ((HT_H + 2) * (HT_W + 2) * 8) : in_dw(RPW), NI = 4 * RPW;
     extern __shared__ __attribute__((aligned(16))) float hsm[];
     constexpr int TAPS = KS * KS;
@@ -142,10 +164,8 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                     const int cg = where[it] >> 16, off = where[it] & 0xffff;
                     if constexpr (H16) {
                         const int r = off / RS, col = off - r * RS;
-                        half4 hv;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) hv[j] = (_Float16)ld[it][j];
-                        *(half4*)((char*)s_in + h16_off(r, col, cg, COLS)) = hv;
+                        const float t4[4] = {ld[it][0], ld[it][1], ld[it][2], ld[it][3]};
+                        *(short4v*)((char*)s_in + h16_off(r, col, cg, COLS)) = round4<OPT>(t4);
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) s_in[plane_base<RPW>(cg * 4 + j) + off] = ld[it][j];
@@ -185,19 +205,16 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                 }
             }
             if constexpr (H16) {
-                half4 hv;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) hv[j] = (_Float16)v[j];
-                *(half4*)((char*)s_in + h16_off(r, col, cg, COLS)) = hv;
+                *(short4v*)((char*)s_in + h16_off(r, col, cg, COLS)) = round4<OPT>(v);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) s_in[plane_base<RPW>(cg * 4 + j) + r * RS + col] = v[j];
             }
         }
         // ---- weights of this chunk (already in A-fragment order).  H16: 8 bytes per lane and (tap, ob), straight into registers
-        half4 wa[H16 ? TAPS : 1][H16 ? NOB : 1];
+        short4v wa[H16 ? TAPS : 1][H16 ? NOB : 1];
         if constexpr (H16) {
-            const half4* wp = (const half4*)p.w + (long)c * (TAPS * NOB * 64) + lane;
+            const short4v* wp = (const short4v*)p.w + (long)c * (TAPS * NOB * 64) + lane;
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
@@ -214,10 +231,14 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                 const int dy = tap / KS, dx = tap - dy * KS;
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
-                    const half4 b = *(const half4*)((const char*)s_in + h16_off(wave * RPW + dy + (i >> 2), dx + (i & 3) * 16 + l15, kk, COLS));
+                    const short4v b = *(const short4v*)((const char*)s_in + h16_off(wave * RPW + dy + (i >> 2), dx + (i & 3) * 16 + l15, kk, COLS));
 #pragma unroll
-                    for (int ob = 0; ob < NOB; ++ob)
-                        acc[ob][i] = __builtin_amdgcn_mfma_f32_16x16x16f16(wa[tap][ob], b, acc[ob][i], 0, 0, 0);
+                    for (int ob = 0; ob < NOB; ++ob) {
+                        if constexpr (OPT == 1)
+                            acc[ob][i] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, wa[tap][ob]), __builtin_bit_cast(half4, b), acc[ob][i], 0, 0, 0);
+                        else
+                            acc[ob][i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa[tap][ob], b, acc[ob][i], 0, 0, 0);
+                    }
                 }
             }
             continue;
@@ -364,8 +385,8 @@ __global__ void hpack_kernel(const float* __restrict__ w, float* __restrict__ ou
 }
 
 // fp16 form: [chunk][tap][ob][lane 64][4]  (A fragment of v_mfma_f32_16x16x16_f16: row = lane&15, k = 4*(lane>>4) + 0..3)
-__global__ void hpack_h16_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int cout, int cin, int ks, int nchunk,
-                                 int nob, int transpose_flip) {
+__global__ void hpack_h16_kernel(const float* __restrict__ w, short* __restrict__ out, int cout, int cin, int ks, int nchunk,
+                                 int nob, int transpose_flip, int bf16) {
     const int taps = ks * ks;
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long total = (long)nchunk * taps * nob * 64 * 4;
@@ -381,7 +402,12 @@ __global__ void hpack_h16_kernel(const float* __restrict__ w, _Float16* __restri
     float v = 0.f;
     if (oc < cout && ic < cin)
         v = transpose_flip ? w[((long)ic * cout + oc) * taps + (taps - 1 - tap)] : w[((long)oc * cin + ic) * taps + tap];
-    out[idx] = (_Float16)v;
+    if (bf16) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        out[idx] = (short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    } else {
+        out[idx] = __builtin_bit_cast(short, (_Float16)v);
+    }
 }
 
 // ---- BatchNorm: partial sums -> scale/shift (+ running stats) ------------------------------------------------------
@@ -486,18 +512,19 @@ __global__ void nearest2x_kernel(const floatx4* __restrict__ src, floatx4* __res
     dst[idx] = src[(((long)b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * C4 + c];
 }
 
-template <int NOB, int KS, int RPW, bool H16 = false>
+template <int NOB, int KS, int RPW, int OPT = 0>
 int launch_hconv(HParams& p, int B, int H, int W, hipStream_t st) {
+    constexpr bool H16 = OPT != 0;
     constexpr int LDS_B = H16 ? ((4 * RPW + 2) * (HT_W + 2) * 32 > 4 * 2 * NOB * 16 * 4 ? (4 * RPW + 2) * (HT_W + 2) * 32 : 4 * 2 * NOB * 16 * 4)
                               : (in_dw(RPW) + KS * KS * 4 * NOB * 64) * 4;
     p.tiles_x = (W + HT_W - 1) / HT_W;
     p.tiles_per_img = p.tiles_x * ((H + 4 * RPW - 1) / (4 * RPW));
     const int nblocks = p.tiles_per_img * B;
     if (LDS_B > 65536) {
-        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hconv_f32_kernel<NOB, KS, RPW, H16>,
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hconv_f32_kernel<NOB, KS, RPW, OPT>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)));
     }
-    hipLaunchKernelGGL((hconv_f32_kernel<NOB, KS, RPW, H16>), dim3(nblocks), dim3(256), LDS_B, st, p);
+    hipLaunchKernelGGL((hconv_f32_kernel<NOB, KS, RPW, OPT>), dim3(nblocks), dim3(256), LDS_B, st, p);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }
@@ -537,17 +564,18 @@ extern "C" size_t srbh_hpack_h16_bytes(int cout, int cin, int ksize) {
     return (size_t)((cin + 15) / 16) * ksize * ksize * ((cout + 15) / 16) * 64 * 4 * sizeof(_Float16);
 }
 
-extern "C" int srbh_hpack_conv_h16(const float* w, int cout, int cin, int ksize, int transpose_flip, void* packed, void* stream) {
+extern "C" int srbh_hpack_conv_h16(const float* w, int cout, int cin, int ksize, int transpose_flip, int bf16, void* packed, void* stream) {
     SRBH_REQUIRE(w && packed && cout > 0 && cin > 0 && (ksize == 1 || ksize == 3), "srbh_hpack_conv_h16: bad arguments");
     int nchunk = (cin + 15) / 16, nob = (cout + 15) / 16;
     long total = (long)nchunk * ksize * ksize * nob * 64 * 4;
-    hipLaunchKernelGGL(hpack_h16_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (_Float16*)packed, cout,
-                       cin, ksize, nchunk, nob, transpose_flip);
+    hipLaunchKernelGGL(hpack_h16_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (short*)packed, cout,
+                       cin, ksize, nchunk, nob, transpose_flip, bf16);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }
 
-static int hconv_impl(const srbh_hconv_args* a, void* stream, const bool h16) {
+static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
+    const bool h16 = opt != 0;
     SRBH_REQUIRE(a && a->src0 && a->w && a->out, "srbh_hconv_f32: null pointer");
     SRBH_REQUIRE(a->c0 > 0 && a->c1 >= 0 && (a->c1 == 0 || a->src1), "srbh_hconv_f32: bad channel split %d+%d", a->c0, a->c1);
     SRBH_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0, "srbh_hconv_f32: bad geometry");
@@ -578,13 +606,19 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const bool h16) {
     hipStream_t st = (hipStream_t)stream;
     if (a->stats) SRBH_HIP(hipMemsetAsync(a->stats, 0, srbh_bn_stats_bytes(p.cout), st));
     const int B = a->B, H = a->H, W = a->W;
-    if (h16) {   // fp16 operands: 8-row tiles (the staged tile is 21 KiB: seven workgroups per CU either way)
-        if (a->ksize == 3)
-            return nob == 1 ? launch_hconv<1, 3, 2, true>(p, B, H, W, st)
-                            : (nob == 2 ? launch_hconv<2, 3, 2, true>(p, B, H, W, st) : launch_hconv<4, 3, 2, true>(p, B, H, W, st));
-        return nob == 1 ? launch_hconv<1, 1, 2, true>(p, B, H, W, st)
-                        : (nob == 2 ? launch_hconv<2, 1, 2, true>(p, B, H, W, st) : launch_hconv<4, 1, 2, true>(p, B, H, W, st));
-    }
+    // 16-bit operand forms: 4-row tiles (12.7 KiB staged tile; measured level with the 8-row form on single-chunk convs and
+    // 10-25 % ahead on the multi-chunk ones)
+#define SRBH_H16_DISPATCH(OPT_)                                                                                             \
+    do {                                                                                                                    \
+        if (a->ksize == 3)                                                                                                  \
+            return nob == 1 ? launch_hconv<1, 3, 1, OPT_>(p, B, H, W, st)                                                   \
+                            : (nob == 2 ? launch_hconv<2, 3, 1, OPT_>(p, B, H, W, st) : launch_hconv<4, 3, 1, OPT_>(p, B, H, W, st)); \
+        return nob == 1 ? launch_hconv<1, 1, 1, OPT_>(p, B, H, W, st)                                                       \
+                        : (nob == 2 ? launch_hconv<2, 1, 1, OPT_>(p, B, H, W, st) : launch_hconv<4, 1, 1, OPT_>(p, B, H, W, st)); \
+    } while (0)
+    if (opt == 1) SRBH_H16_DISPATCH(1);
+    if (opt == 2) SRBH_H16_DISPATCH(2);
+#undef SRBH_H16_DISPATCH
     if (hconv_rpw_small() == 1) {
         if (a->ksize == 3)
             return nob == 1 ? launch_hconv<1, 3, 1>(p, B, H, W, st)
@@ -599,8 +633,8 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const bool h16) {
                     : (nob == 2 ? launch_hconv<2, 1, 2>(p, B, H, W, st) : launch_hconv<4, 1, 2>(p, B, H, W, st));
 }
 
-extern "C" int srbh_hconv_f32(const srbh_hconv_args* a, void* stream) { return hconv_impl(a, stream, false); }
-extern "C" int srbh_hconv_h16(const srbh_hconv_args* a, void* stream) { return hconv_impl(a, stream, true); }
+extern "C" int srbh_hconv_f32(const srbh_hconv_args* a, void* stream) { return hconv_impl(a, stream, 0); }
+extern "C" int srbh_hconv_h16(const srbh_hconv_args* a, int bf16, void* stream) { return hconv_impl(a, stream, bf16 ? 2 : 1); }
 
 extern "C" int srbh_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta,
                                 float eps, float momentum, float* running_mean, float* running_var, float* scale,

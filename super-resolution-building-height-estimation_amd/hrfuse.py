@@ -97,7 +97,7 @@ class _PackedConv:
             wc = w.detach().float().contiguous()
             if h16:
                 buf = torch.empty(L.srbh_hpack_h16_bytes(cout, cin, ks) // 2, dtype=torch.float16, device=w.device)
-                _lib.check(L.srbh_hpack_conv_h16(wc.data_ptr(), cout, cin, ks, 0, buf.data_ptr(), _lib.stream_ptr()), "hpack_conv_h16")
+                _lib.check(L.srbh_hpack_conv_h16(wc.data_ptr(), cout, cin, ks, 0, 0, buf.data_ptr(), _lib.stream_ptr()), "hpack_conv_h16")
             else:
                 buf = torch.empty(L.srbh_hpack_bytes(cout, cin, ks) // 4, dtype=torch.float32, device=w.device)
                 _lib.check(L.srbh_hpack_conv_f32(wc.data_ptr(), cout, cin, ks, 0, buf.data_ptr(), _lib.stream_ptr()),
@@ -147,7 +147,10 @@ def hconv(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_
     if want_stats:
         stats = torch.empty(L.srbh_bn_stats_bytes((cout + 15) // 16 * 16) // 8, dtype=torch.float64, device=x0.device)
         a.stats = stats.data_ptr()
-    _lib.check((L.srbh_hconv_h16 if h16 else L.srbh_hconv_f32)(C.byref(a), _lib.stream_ptr()), "hconv")
+    if h16:
+        _lib.check(L.srbh_hconv_h16(C.byref(a), 0, _lib.stream_ptr()), "hconv_h16")
+    else:
+        _lib.check(L.srbh_hconv_f32(C.byref(a), _lib.stream_ptr()), "hconv_f32")
     return out, stats
 
 

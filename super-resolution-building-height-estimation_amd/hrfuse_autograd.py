@@ -31,7 +31,7 @@ class _PackedGrad:
             wc = weight.detach().float().contiguous()
             if h16:
                 buf = torch.empty(L.srbh_hpack_h16_bytes(cin, cout, ks) // 2, dtype=torch.float16, device=weight.device)
-                _lib.check(L.srbh_hpack_conv_h16(wc.data_ptr(), cin, cout, ks, 1, buf.data_ptr(), _lib.stream_ptr()), "hpack_conv_h16(T)")
+                _lib.check(L.srbh_hpack_conv_h16(wc.data_ptr(), cin, cout, ks, 1, 1, buf.data_ptr(), _lib.stream_ptr()), "hpack_conv_h16(T, bf16)")
             else:
                 buf = torch.empty(L.srbh_hpack_bytes(cin, cout, ks) // 4, dtype=torch.float32, device=weight.device)
                 _lib.check(L.srbh_hpack_conv_f32(wc.data_ptr(), cin, cout, ks, 1, buf.data_ptr(), _lib.stream_ptr()),
@@ -60,14 +60,17 @@ def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None, h1
     a.out = out.data_ptr()
     if res is not None:          # out = conv + res in the conv's epilogue (exact: fma(y, 1, res))
         a.res1, a.res1_ld, a.res1_scale = res.data_ptr(), res.shape[1], 1.0
-    _lib.check((L.srbh_hconv_h16 if h16 else L.srbh_hconv_f32)(C.byref(a), _lib.stream_ptr()), "hconv")
+    if h16:      # (data gradients: bf16 operands -- fp32's exponent range, no loss scaling needed)
+        _lib.check(L.srbh_hconv_h16(C.byref(a), 1, _lib.stream_ptr()), "hconv_h16(bf16)")
+    else:
+        _lib.check(L.srbh_hconv_f32(C.byref(a), _lib.stream_ptr()), "hconv_f32")
     return out
 
 
 def conv_dgrad(g, weight, cache: _PackedGrad, res=None):
     """dX = conv^T(g, W) (+ res): the forward kernel with transposed + flipped weights; `res` (NHWC, same shape as dX) is the
-    gradient arriving over a skip connection, added in the epilogue instead of by a separate pass.  fp16 operands only in
-    the explicit "f16" head precision mode (H.set_head_precision)."""
+    gradient arriving over a skip connection, added in the epilogue instead of by a separate pass.  16-bit operands (bf16:
+    gradients need fp32's exponent range) only in the explicit "f16" head precision mode (H.set_head_precision)."""
     cout, cin, ks, _ = weight.shape
     h16 = H.head_h16()
     return _hconv_raw([g], cache.get(weight, h16), None, cin, ks, res=res, h16=h16)

@@ -86,7 +86,7 @@ def test_default_inference_head_within_north_star_tolerance(golden_dir):
 
 def test_training_graph_stays_exact_fp32():
     """auto mode: a recorded graph (training) keeps the exact-fp32 kernels in forward and backward -- same numbers as the
-    explicit strict mode, bit for bit."""
+    explicit strict mode (an fp16-operand conv would differ at the 1e-4 level)."""
     from srbh_amd import hrfuse as H
     from srbh_amd.hrfuse import HRfeature
     outs = []
@@ -99,7 +99,8 @@ def test_training_graph_stays_exact_fp32():
         y.square().mean().backward()
         outs.append((y.detach().clone(), m[0].conv1.weight.grad.clone()))
     H.set_head_precision("auto")
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # (not torch.equal: the BatchNorm partial sums are double atomics, their order moves the last bit from run to run)
+    assert O.rel_l2(outs[0][0].cpu(), outs[1][0].cpu()) <= 1e-6 and O.rel_l2(outs[0][1].cpu(), outs[1][1].cpu()) <= 1e-6
 
 
 def test_model_eval_default_precision_height_maps():
@@ -115,3 +116,30 @@ def test_model_eval_default_precision_height_maps():
         got = m.to(DEV)(x.to(DEV), fea.to(DEV))
     for a, b, name in zip(got, want, ("height", "build", "aggre")):
         assert O.rel_l2(a.cpu(), b) <= TOL_HEAD, name
+
+
+def test_mixed_precision_training_gradients_close_to_exact():
+    """TrainStep's default ("f16": forward convs fp16 operands, data gradients bf16 operands, weight gradients fp32): every
+    parameter gradient of the head within 2e-2 relative of the exact-fp32 graph (bf16 keeps 8 mantissa bits: 4e-3 per
+    operand, averaged over the 9 x 16 products of a tap sum), outputs within 1e-3; tiny per-pixel gradients (a mean over
+    10^5 pixels puts them at 1e-6, below fp16's normal range) must survive -- that is why the data gradients are bf16."""
+    from srbh_amd import hrfuse as H
+    from srbh_amd.hrfuse import HRfeature, HRfuse_residual
+    res = {}
+    for mode in ("f32", "f16"):
+        H.set_head_precision(mode)
+        torch.manual_seed(5)
+        hf, fu = HRfeature(64, 16, 16).to(DEV).train(), HRfuse_residual(16, 16, 16, 1, 4).to(DEV).train()
+        x = rnd((2, 64, 64, 96), 11).to(DEV)
+        lo = rnd((2, 16, 16, 24), 12).to(DEV).requires_grad_(True)
+        y = fu(lo, hf(x))
+        (y.square().mean() * 1e-3).backward()          # small per-pixel gradients on purpose
+        res[mode] = (y.detach().cpu(), {k: p.grad.cpu() for k, p in list(hf.named_parameters()) + list(fu.named_parameters())}, lo.grad.cpu())
+    H.set_head_precision("auto")
+    assert O.rel_l2(res["f16"][0], res["f32"][0]) <= TOL_HEAD
+    assert float(res["f32"][2].abs().max()) < 6e-5            # the input gradient really is below fp16's normal range
+    assert O.rel_l2(res["f16"][2], res["f32"][2]) <= 2e-2
+    gmax = max(float(g.norm()) for g in res["f32"][1].values())
+    for k, g in res["f32"][1].items():
+        if float(g.norm()) > 1e-3 * gmax:
+            assert O.rel_l2(res["f16"][1][k], g) <= 2e-2, k
