@@ -229,6 +229,8 @@ typedef struct srbh_hwgrad_args {
     int B, H, W;
     float* dw;            /* OIHW [cout][c0+c1][k][k], fully written (deterministic: fixed summation order) */
     float* ws;            /* scratch of srbh_hwgrad_ws_bytes(cout, c0 + c1, ksize) bytes: per-workgroup partial sums */
+    int src0_ld, src1_ld; /* floats between consecutive pixels of src0 / src1 (0 = c0 / c1): strided views into wider NHWC
+                           * buffers, e.g. the first 64 + 32k channels of a dense block's 192-channel buffer */
 } srbh_hwgrad_args;
 size_t srbh_hwgrad_ws_bytes(int cout, int cin, int ksize);
 int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream);

@@ -88,6 +88,7 @@ class HWGradArgs(C.Structure):
         ("src1", C.c_void_p), ("c1", C.c_int),
         ("dy", C.c_void_p), ("cout", C.c_int), ("ksize", C.c_int),
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dw", C.c_void_p), ("ws", C.c_void_p),
+        ("src0_ld", C.c_int), ("src1_ld", C.c_int),
     ]
 
 

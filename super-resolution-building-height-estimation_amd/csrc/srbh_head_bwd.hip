@@ -29,6 +29,7 @@ struct WGParams {
     float* ws;            // [gridDim.x][nob][nchunk][TAPS*256] per-workgroup partial sums (hwgrad_reduce_kernel adds them)
     int B, H, W;
     int tiles_x, tiles_per_img, ntiles;
+    int ld0, ld1;         // pixel strides (floats) of src0 / src1
 };
 
 // One workgroup walks tiles t = blockIdx.x, +gridDim.x, ... and keeps the 16(oc) x 16(ci) x taps partial sums of
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void hwgrad_f32_kernel(const WGParams p) {
     const int cin = p.c0 + p.c1;
     const int nchunk = (cin + 15) / 16;
     const int ob = blockIdx.y;
-    const bool vec0 = (p.c0 & 3) == 0, vec1 = p.c1 > 0 && (p.c1 & 3) == 0 && (p.c0 & 3) == 0;
+    const bool vec0 = (p.c0 & 3) == 0 && (p.ld0 & 3) == 0, vec1 = p.c1 > 0 && (p.c1 & 3) == 0 && (p.c0 & 3) == 0 && (p.ld1 & 3) == 0;
 
     for (int c = 0; c < nchunk; ++c) {
         floatx4 acc[TAPS];
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void hwgrad_f32_kernel(const WGParams p) {
                         if (y >= 0 && y < p.H && x >= 0 && x < p.W && ch < cin) {
                             const long pixi = ((long)img * p.H + y) * p.W + x;
                             if (ch < p.c0) {
-                                floatx4 a = *(const floatx4*)(p.src0 + pixi * p.c0 + ch);
+                                floatx4 a = *(const floatx4*)(p.src0 + pixi * p.ld0 + ch);
                                 if (p.pre_scale) a = a * *(const floatx4*)(p.pre_scale + ch) + *(const floatx4*)(p.pre_shift + ch);
                                 if (p.pre_relu) {
 #pragma unroll
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void hwgrad_f32_kernel(const WGParams p) {
                                 }
                                 lx[it] = a;
                             } else {
-                                lx[it] = *(const floatx4*)(p.src1 + pixi * p.c1 + (ch - p.c0));
+                                lx[it] = *(const floatx4*)(p.src1 + pixi * p.ld1 + (ch - p.c0));
                             }
                         }
                     }
@@ -120,23 +121,23 @@ __global__ __launch_bounds__(256) void hwgrad_f32_kernel(const WGParams p) {
                 if (y >= 0 && y < p.H && x >= 0 && x < p.W && ch < cin) {
                     const long pixi = ((long)img * p.H + y) * p.W + x;
                     if (vec0 && ch + 3 < p.c0) {
-                        floatx4 a = *(const floatx4*)(p.src0 + pixi * p.c0 + ch);
+                        floatx4 a = *(const floatx4*)(p.src0 + pixi * p.ld0 + ch);
                         if (p.pre_scale) a = a * *(const floatx4*)(p.pre_scale + ch) + *(const floatx4*)(p.pre_shift + ch);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = p.pre_relu ? fmaxf(a[j], 0.f) : a[j];
                     } else if (vec1 && ch >= p.c0 && ch + 3 < cin) {
-                        v = *(const floatx4*)(p.src1 + pixi * p.c1 + (ch - p.c0));
+                        v = *(const floatx4*)(p.src1 + pixi * p.ld1 + (ch - p.c0));
                     } else
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int cc = ch + j;
                         if (cc < p.c0) {
-                            float a = p.src0[pixi * p.c0 + cc];
+                            float a = p.src0[pixi * p.ld0 + cc];
                             if (p.pre_scale) a = a * p.pre_scale[cc] + p.pre_shift[cc];
                             if (p.pre_relu) a = fmaxf(a, 0.f);
                             v[j] = a;
                         } else if (cc < cin) {
-                            v[j] = p.src1[pixi * p.c1 + (cc - p.c0)];
+                            v[j] = p.src1[pixi * p.ld1 + (cc - p.c0)];
                         }
                     }
                 }
@@ -353,6 +354,8 @@ extern "C" int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream) {
     SRBH_REQUIRE(a->cout >= 1 && a->cout <= 64 && a->B > 0 && a->H > 0 && a->W > 0, "srbh_hconv_wgrad_f32: bad shape");
     WGParams p;
     p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1;
+    p.ld0 = a->src0_ld > 0 ? a->src0_ld : a->c0;
+    p.ld1 = a->src1_ld > 0 ? a->src1_ld : a->c1;
     p.pre_scale = a->pre_scale; p.pre_shift = a->pre_shift; p.pre_relu = a->pre_relu;
     p.dy = a->dy; p.cout_total = a->cout; p.dw = a->dw; p.ws = a->ws;
     SRBH_REQUIRE(a->ws, "srbh_hconv_wgrad_f32: workspace missing (srbh_hwgrad_ws_bytes)");

@@ -131,6 +131,14 @@ class RRDBNet(nn.Module):
         self._workspaces.clear()
         return super()._apply(fn, *a, **kw)
 
+    def enable_training_path(self, on=True):
+        """Route forward / forward_feature through the recorded-graph implementation (rrdbnet_autograd.py: forward and backward
+        of every conv on libsrbh's exact-fp32 kernels) whenever autograd is recording.  Off by default: the height stage uses
+        the network frozen (train.py:139-140,243-244) and wants the fp16-MFMA inference path even if a caller forgot
+        ``no_grad``; ``RealESRGAN(is_train=True)`` switches it on for the SR stage (SR/rrdbnet_arch.py:538-592)."""
+        self._train_path = bool(on)
+        return self
+
     def refresh_packed_weights(self):
         """Force a repack (call after mutating ``.data`` in ways that bypass the version counters)."""
         self._packed = None
@@ -205,6 +213,19 @@ class RRDBNet(nn.Module):
                                "fallback (use oracle/ in tests for a CPU comparison)")
         if x.dim() != 4:
             raise ValueError(f"expected a (B,C,H,W) tensor, got shape {tuple(x.shape)}")
+        if getattr(self, "_train_path", False) and torch.is_grad_enabled():
+            if self._geom[2] != 64 or self._geom[4] != 32:
+                raise NotImplementedError("libsrbh RRDBNet kernels are specialised for num_feat=64, num_grow_ch=32")
+            from .rrdbnet_autograd import rrdbnet_apply
+            if self.scale == 2:
+                x = pixel_unshuffle(x, 2)
+            elif self.scale == 1:
+                x = pixel_unshuffle(x, 4)
+            with torch.cuda.device(x.device):
+                r = rrdbnet_apply(self, x, want_forward)
+            if out is not None:
+                raise ValueError("out= is an inference-path extension (no recorded graph)")
+            return r
         if self._use_strict():
             if self._geom[2] != 64 or self._geom[4] != 32:
                 raise NotImplementedError("libsrbh RRDBNet kernels are specialised for num_feat=64, num_grow_ch=32")
@@ -336,27 +357,128 @@ class RRDBNet(nn.Module):
 
 
 class RealESRGAN:
-    """Minimal stand-in for the reference GAN wrapper (SR/rrdbnet_arch.py:437-633): the height stage only
-    touches ``.net_g`` (train.py:133-140, predict_realesanet_feature_globe.py:95-102).  No cv2 / VGG19 /
-    discriminator side effects; SR-stage GAN training is out of scope."""
+    """Stand-in for the reference GAN wrapper (SR/rrdbnet_arch.py:437-633).
+
+    ``is_train=False`` (what the height stage uses: train.py:133-140, predict_realesanet_feature_globe.py:95-102): only
+    ``.net_g`` on ``device``, eval mode, no cv2 / VGG19 / discriminator side effects.
+    ``is_train=True`` (SR-stage fine-tuning, SURVEY.md 8f-4, first slice): the generator trains through libsrbh -- forward and
+    backward of every RRDBNet conv (rrdbnet_autograd.py, exact fp32) -- with the reference's EMA copy, Adam(1e-4, (0.9, 0.99)),
+    MultiStepLR, ``feed_data`` / ``optimize_parameters`` / ``model_ema`` / ``save`` / ``update_learning_rate``; the USM sharpener,
+    the spectral-norm U-Net discriminator and the GAN / L1 losses are stock-op restatements (srgan.py).  The VGG19 perceptual
+    loss needs torchvision's pretrained weights (no network here): pass ``cri_perceptual=<module>`` to use one, otherwise that
+    term is skipped and ``loss_dict`` has no 'l_g_percep'."""
 
     def __init__(self, in_ch=3, out_ch=3, num_block=23, device="cuda", scale=4, ema_decay=0.999,
-                 pretrain_g_path=None, pretrain_d_path=None, is_train=False):
-        if is_train:
-            raise NotImplementedError("SR-stage GAN fine-tuning is outside the MI355X hot path (SURVEY.md 8f-4)")
+                 pretrain_g_path=None, pretrain_d_path=None, is_train=False, cri_perceptual=None):
         self.device = device
         self.scale = scale
         self.ema_decay = ema_decay
-        self.is_train = False
+        self.is_train = bool(is_train)
         self.net_g = RRDBNet(in_ch, out_ch, scale=scale, num_block=num_block).to(device)
+        weights = None
         if pretrain_g_path is not None:
             ckpt = torch.load(pretrain_g_path, map_location="cpu")
             for k in ("params_ema", "net_g_ema", "params"):
                 if isinstance(ckpt, dict) and k in ckpt:
                     ckpt = ckpt[k]
                     break
-            self.net_g.load_state_dict(ckpt, strict=True)
-        self.net_g.eval()
+            weights = ckpt
+            self.net_g.load_state_dict(weights, strict=True)
+        if not self.is_train:
+            self.net_g.eval()
+            return
+        from .srgan import GANLoss, UNetDiscriminatorSN, USMSharp
+        self.usm_sharpener = USMSharp().to(device)
+        if self.ema_decay > 0:
+            self.net_g_ema = RRDBNet(in_ch, out_ch, scale=scale, num_block=num_block).to(device)
+            if weights is not None:
+                self.net_g_ema.load_state_dict(weights, strict=True)
+            else:
+                self.model_ema(0)
+            for p in self.net_g_ema.parameters():
+                p.requires_grad = False
+        self.net_d = UNetDiscriminatorSN(num_in_ch=out_ch, num_feat=64, skip_connection=True).to(device)
+        if pretrain_d_path is not None:
+            self.net_d.load_state_dict(torch.load(pretrain_d_path, map_location="cpu")["params"])
+        self.net_g.train().enable_training_path(True)
+        self.net_d.train()
+        self.cri_pix = nn.L1Loss().to(device)
+        self.cri_perceptual = cri_perceptual
+        self.cri_gan = GANLoss("vanilla", loss_weight=0.1).to(device)
+        self.net_d_iters, self.net_d_init_iters = 1, 0
+        self.optimizer_g = torch.optim.Adam(self.net_g.parameters(), lr=1e-4, betas=(0.9, 0.99), weight_decay=0)
+        self.optimizer_d = torch.optim.Adam(self.net_d.parameters(), lr=1e-4, betas=(0.9, 0.99), weight_decay=0)
+        self.optimizers = [self.optimizer_g, self.optimizer_d]
+        self.schedulers = [torch.optim.lr_scheduler.MultiStepLR(o, milestones=[400000], gamma=0.5) for o in self.optimizers]
+
+    def save(self, epoch, current_iter, respath):
+        import os
+        torch.save({"params": self.net_g.state_dict(),
+                    "params_ema": self.net_g_ema.state_dict() if hasattr(self, "net_g_ema") else None,
+                    "epoch": epoch, "current_iter": current_iter}, os.path.join(respath, "net_g.tar"))
+        torch.save({"params": self.net_d.state_dict(), "epoch": epoch, "current_iter": current_iter},
+                   os.path.join(respath, "net_d.tar"))
+
+    @torch.no_grad()
+    def feed_data(self, data):
+        self.lq = data["lq"].to(self.device, non_blocking=True)
+        self.gt = data["gt"].to(self.device, non_blocking=True)
+        self.gt_usm = self.usm_sharpener(self.gt)
+
+    @torch.no_grad()
+    def model_ema(self, decay=0.999):
+        src = dict(self.net_g.named_parameters())
+        for k, p in self.net_g_ema.named_parameters():
+            p.data.mul_(decay).add_(src[k].data, alpha=1 - decay)
+
+    def optimize_parameters(self):
+        """one generator step + one discriminator step (SR/rrdbnet_arch.py:538-592)"""
+        from collections import OrderedDict as _OD
+        l1_gt = percep_gt = self.gt_usm
+        gan_gt = self.gt
+        for p in self.net_d.parameters():
+            p.requires_grad = False
+        self.optimizer_g.zero_grad()
+        self.output = self.net_g(self.lq)
+        loss_dict = _OD()
+        l_g_pix = self.cri_pix(self.output, l1_gt)
+        l_g_total = l_g_pix
+        loss_dict["l_g_pix"] = l_g_pix.item()
+        if self.cri_perceptual is not None:
+            l_g_percep = self.cri_perceptual(self.output, percep_gt)
+            l_g_total = l_g_total + l_g_percep
+            loss_dict["l_g_percep"] = l_g_percep.item()
+        l_g_gan = self.cri_gan(self.net_d(self.output), True, is_disc=False)
+        l_g_total = l_g_total + l_g_gan
+        loss_dict["l_g_gan"] = l_g_gan.item()
+        l_g_total.backward()
+        self.optimizer_g.step()
+        for p in self.net_d.parameters():
+            p.requires_grad = True
+        self.optimizer_d.zero_grad()
+        real_d_pred = self.net_d(gan_gt)
+        l_d_real = self.cri_gan(real_d_pred, True, is_disc=True)
+        loss_dict["l_d_real"] = l_d_real.item()
+        loss_dict["out_d_real"] = torch.mean(real_d_pred.detach())
+        l_d_real.backward()
+        fake_d_pred = self.net_d(self.output.detach().clone())
+        l_d_fake = self.cri_gan(fake_d_pred, False, is_disc=True)
+        loss_dict["l_d_fake"] = l_d_fake.item()
+        loss_dict["out_d_fake"] = torch.mean(fake_d_pred.detach())
+        l_d_fake.backward()
+        self.optimizer_d.step()
+        if self.ema_decay > 0:
+            self.model_ema(decay=self.ema_decay)
+        return loss_dict
+
+    def update_learning_rate(self, current_iter, warmup_iter=-1):
+        if current_iter >= 0:
+            for sch in self.schedulers:
+                sch.step()
+        if current_iter < warmup_iter:
+            for opt in self.optimizers:
+                for g in opt.param_groups:
+                    g["lr"] = g["initial_lr"] / warmup_iter * current_iter
 
     @torch.no_grad()
     def predict(self, lr):

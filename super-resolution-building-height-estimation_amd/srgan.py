@@ -1,0 +1,123 @@
+"""SR-stage (GAN fine-tuning) companions of RRDBNet, SURVEY.md 8f-4: the pieces around the generator that the reference's
+``RealESRGAN`` trainer uses (SR/rrdbnet_arch.py:244-303 UNetDiscriminatorSN, :387-434 filter2D / USMSharp; SR/srloss.py:144-249
+GANLoss).  They are NOT on the MI355X hot path and stay on stock PyTorch-ROCm ops (VERDICT r01 item 7 allows that); the
+generator's forward AND backward run on libsrbh (rrdbnet_autograd.py).  The VGG19 perceptual loss needs torchvision's
+pretrained network (absent offline): it is an optional plug-in (``RealESRGAN.cri_perceptual``), not restated."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.utils import spectral_norm
+
+__all__ = ["UNetDiscriminatorSN", "filter2D", "USMSharp", "GANLoss"]
+
+
+class UNetDiscriminatorSN(nn.Module):
+    """U-Net discriminator with spectral normalisation; state_dict keys conv0..conv9 (conv1..conv8 carry weight_orig / weight_u /
+    weight_v of torch's spectral_norm) as upstream (SR/rrdbnet_arch.py:244-303)."""
+
+    def __init__(self, num_in_ch, num_feat=64, skip_connection=True):
+        super().__init__()
+        self.skip_connection = skip_connection
+        nf = num_feat
+        self.conv0 = nn.Conv2d(num_in_ch, nf, 3, 1, 1)
+        self.conv1 = spectral_norm(nn.Conv2d(nf, nf * 2, 4, 2, 1, bias=False))
+        self.conv2 = spectral_norm(nn.Conv2d(nf * 2, nf * 4, 4, 2, 1, bias=False))
+        self.conv3 = spectral_norm(nn.Conv2d(nf * 4, nf * 8, 4, 2, 1, bias=False))
+        self.conv4 = spectral_norm(nn.Conv2d(nf * 8, nf * 4, 3, 1, 1, bias=False))
+        self.conv5 = spectral_norm(nn.Conv2d(nf * 4, nf * 2, 3, 1, 1, bias=False))
+        self.conv6 = spectral_norm(nn.Conv2d(nf * 2, nf, 3, 1, 1, bias=False))
+        self.conv7 = spectral_norm(nn.Conv2d(nf, nf, 3, 1, 1, bias=False))
+        self.conv8 = spectral_norm(nn.Conv2d(nf, nf, 3, 1, 1, bias=False))
+        self.conv9 = nn.Conv2d(nf, 1, 3, 1, 1)
+
+    def forward(self, x):
+        act = lambda t: F.leaky_relu(t, 0.2)
+        up = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)
+        x0 = act(self.conv0(x))
+        x1 = act(self.conv1(x0))
+        x2 = act(self.conv2(x1))
+        x3 = act(self.conv3(x2))
+        x4 = act(self.conv4(up(x3)))
+        if self.skip_connection:
+            x4 = x4 + x2
+        x5 = act(self.conv5(up(x4)))
+        if self.skip_connection:
+            x5 = x5 + x1
+        x6 = act(self.conv6(up(x5)))
+        if self.skip_connection:
+            x6 = x6 + x0
+        return self.conv9(act(self.conv8(act(self.conv7(x6)))))
+
+
+def filter2D(img, kernel):
+    """cv2.filter2D on (b,c,h,w) with a (1|b, k, k) kernel, reflect padding (SR/rrdbnet_arch.py:387-409)."""
+    k = kernel.size(-1)
+    if k % 2 != 1:
+        raise ValueError("Wrong kernel size")
+    b, c, h, w = img.shape
+    img = F.pad(img, (k // 2,) * 4, mode="reflect")
+    ph, pw = img.shape[-2:]
+    if kernel.size(0) == 1:
+        return F.conv2d(img.reshape(b * c, 1, ph, pw), kernel.view(1, 1, k, k)).view(b, c, h, w)
+    kern = kernel.view(b, 1, k, k).repeat(1, c, 1, 1).view(b * c, 1, k, k)
+    return F.conv2d(img.reshape(1, b * c, ph, pw), kern, groups=b * c).view(b, c, h, w)
+
+
+def _gaussian_kernel_1d(ksize, sigma):
+    """cv2.getGaussianKernel: sigma <= 0 -> 0.3*((ksize-1)*0.5 - 1) + 0.8; exp(-(i-c)^2 / (2 sigma^2)) normalised to sum 1."""
+    if sigma <= 0:
+        sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+    c = (ksize - 1) * 0.5
+    g = torch.tensor([math.exp(-((i - c) ** 2) / (2.0 * sigma * sigma)) for i in range(ksize)], dtype=torch.float64)
+    return (g / g.sum()).float()
+
+
+class USMSharp(nn.Module):
+    """unsharp masking (SR/rrdbnet_arch.py:412-434): blur with a radius x radius Gaussian, sharpen where |residual|*255 > threshold."""
+
+    def __init__(self, radius=50, sigma=0):
+        super().__init__()
+        if radius % 2 == 0:
+            radius += 1
+        self.radius = radius
+        g = _gaussian_kernel_1d(radius, sigma)
+        self.register_buffer("kernel", torch.outer(g, g).unsqueeze(0))
+
+    def forward(self, img, weight=0.5, threshold=10):
+        blur = filter2D(img, self.kernel)
+        residual = img - blur
+        soft_mask = filter2D((residual.abs() * 255 > threshold).float(), self.kernel)
+        sharp = torch.clip(img + weight * residual, 0, 1)
+        return soft_mask * sharp + (1 - soft_mask) * img
+
+
+class GANLoss(nn.Module):
+    """SR/srloss.py:144-249: 'vanilla' (BCE with logits), 'lsgan', 'wgan', 'wgan_softplus', 'hinge'; loss_weight applies to the
+    generator only."""
+
+    def __init__(self, gan_type, real_label_val=1.0, fake_label_val=0.0, loss_weight=1.0):
+        super().__init__()
+        if gan_type not in ("vanilla", "lsgan", "wgan", "wgan_softplus", "hinge"):
+            raise NotImplementedError(f"GAN type {gan_type} is not implemented.")
+        self.gan_type, self.loss_weight = gan_type, loss_weight
+        self.real_label_val, self.fake_label_val = real_label_val, fake_label_val
+
+    def forward(self, input, target_is_real, is_disc=False):
+        t = self.gan_type
+        if t == "hinge":
+            if is_disc:
+                loss = F.relu(1 + (-input if target_is_real else input)).mean()
+            else:
+                loss = -input.mean()
+        elif t == "wgan":
+            loss = -input.mean() if target_is_real else input.mean()
+        elif t == "wgan_softplus":
+            loss = F.softplus(-input).mean() if target_is_real else F.softplus(input).mean()
+        else:
+            target = input.new_full(input.shape, self.real_label_val if target_is_real else self.fake_label_val)
+            loss = F.binary_cross_entropy_with_logits(input, target) if t == "vanilla" else F.mse_loss(input, target)
+        return loss if is_disc else loss * self.loss_weight

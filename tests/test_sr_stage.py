@@ -1,0 +1,125 @@
+"""SURVEY.md 8f-4, first slice (SR-stage fine-tuning): the generator's forward + backward on libsrbh against the reference's own
+autograd (fixture g14, produced by tools/make_golden.py from /root/reference), the stock-op companions (discriminator,
+filter2D, GANLoss) against the same fixture on the CPU, and one RealESRGAN(is_train=True) step on the device."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import srbh_oracle as O
+from oracle import synth
+
+
+def _g14(golden_dir):
+    return np.load(os.path.join(golden_dir, "g14_sr_stage.npz"))
+
+
+def rand(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def test_sr_companions_match_reference_fixture(golden_dir):
+    from srbh_amd.srgan import GANLoss, UNetDiscriminatorSN, filter2D
+    g = _g14(golden_dir)
+    d = UNetDiscriminatorSN(3, num_feat=8, skip_connection=True).eval()
+    sd = {k[len("disc_sd_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("disc_sd_")}
+    d.load_state_dict(sd, strict=True)                        # same keys as the reference module (spectral-norm buffers included)
+    with torch.no_grad():
+        y = d(rand((2, 3, 32, 32), 143, 0.0, 1.0))
+    assert O.rel_l2(y, torch.from_numpy(g["disc_out"])) <= 1e-6
+    img = rand((2, 3, 20, 24), 144, 0.0, 1.0)
+    k1, kb = rand((1, 5, 5), 145, 0.0, 1.0), rand((2, 7, 7), 146, 0.0, 1.0)
+    assert O.rel_l2(filter2D(img, k1 / k1.sum()), torch.from_numpy(g["f2d_shared"])) <= 1e-6
+    assert O.rel_l2(filter2D(img, kb / kb.sum(dim=(1, 2), keepdim=True)), torch.from_numpy(g["f2d_batch"])) <= 1e-6
+    z = rand((2, 1, 8, 8), 147, -2.0, 2.0)
+    for t in ("vanilla", "lsgan", "wgan", "wgan_softplus", "hinge"):
+        gl = GANLoss(t, loss_weight=0.1)
+        got = torch.stack([gl(z, True, is_disc=False), gl(z, True, is_disc=True), gl(z, False, is_disc=True)])
+        assert torch.allclose(got, torch.from_numpy(g[f"gan_{t}"]), rtol=1e-6, atol=1e-7), t
+    with pytest.raises(NotImplementedError):
+        GANLoss("nope")
+
+
+def test_usm_sharp_gaussian_kernel_known_answers():
+    """cv2.getGaussianKernel(51, 0) restated (cv2 is absent offline): sigma = 0.3*((51-1)*0.5 - 1) + 0.8 = 8.0; the kernel is the
+    normalised outer product, symmetric, and a constant image is a fixed point of the sharpener."""
+    from srbh_amd.srgan import USMSharp, _gaussian_kernel_1d
+    g = _gaussian_kernel_1d(51, 0)
+    assert abs(float(g.sum()) - 1.0) < 1e-6 and torch.allclose(g, g.flip(0))
+    assert abs(float(g[25] / g[24]) - float(np.exp(1.0 / (2 * 8.0 ** 2)))) < 1e-6      # exp(-(0)^2/2s^2) / exp(-(1)^2/2s^2), s = 8
+    u = USMSharp()
+    assert u.radius == 51 and tuple(u.kernel.shape) == (1, 51, 51) and abs(float(u.kernel.sum()) - 1) < 1e-5
+    flat = torch.full((1, 3, 64, 64), 0.37)
+    assert torch.allclose(u(flat), flat, atol=1e-6)
+    x = rand((1, 3, 64, 64), 5, 0.0, 1.0)
+    y = u(x)
+    assert y.shape == x.shape and float(y.min()) >= -1e-6 and float(y.max()) <= 1 + 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["fw", "ft"])
+def test_rrdbnet_backward_matches_reference_autograd(golden_dir, tag):
+    """forward() / forward_feature() of a 2-block RRDBNet with a recorded graph: outputs, input gradient and every parameter
+    gradient against the reference's autograd (exact-fp32 kernels: <= 1e-5 relative; gradient norms of ALL 72 parameters)."""
+    from srbh_amd.rrdbnet import RRDBNet
+    g = _g14(golden_dir)
+    sd = synth.rrdbnet_state_dict(num_block=2, seed=31, mode="stress")
+    net = RRDBNet(3, 3, num_block=2)
+    net.load_state_dict(sd, strict=True)
+    net = net.to("cuda:0").train().enable_training_path(True)
+    x = rand((2, 3, 16, 16), 140, 0.0, 1.0).to("cuda:0").requires_grad_(True)
+    y = net(x) if tag == "fw" else net.forward_feature(x)
+    w = rand(tuple(y.shape), 141 if tag == "fw" else 142).to("cuda:0")
+    (y * w).sum().backward()
+    want_out = torch.from_numpy(g[f"{tag}_out"])
+    got_out = y.detach().cpu() if tag == "fw" else y.detach().cpu()[:, ::8, ::4, ::4]
+    assert O.rel_l2(got_out, want_out) <= 1e-5
+    assert O.rel_l2(x.grad.cpu(), torch.from_numpy(g[f"{tag}_gx"])) <= 1e-5
+    names = [str(n) for n in g["param_names"]]
+    params = dict(net.named_parameters())
+    assert names == list(params.keys())
+    gn = g[f"{tag}_gnorm"]
+    for i, k in enumerate(names):
+        p = params[k]
+        if gn[i] == 0.0:
+            assert p.grad is None or float(p.grad.norm()) == 0.0, k       # conv_last is outside forward_feature's graph
+        else:
+            assert abs(float(p.grad.double().norm()) - gn[i]) <= 2e-5 * gn[i], k
+    for key in g.files:
+        if key.startswith(f"{tag}_g_"):
+            k = key[len(f"{tag}_g_"):]
+            got = params[k].grad.cpu()
+            got = got if got.numel() <= 4096 else got[::4, ::4]
+            assert O.rel_l2(got, torch.from_numpy(g[key])) <= 1e-5, k
+
+
+@pytest.mark.gpu
+def test_realesrgan_training_step_runs_and_learns():
+    """RealESRGAN(is_train=True) (reference SR/rrdbnet_arch.py:437-592): feed_data -> optimize_parameters for a few iterations on
+    one synthetic LR/HR pair: the pixel loss goes down, the EMA copy moves, the discriminator trains, save() writes both nets."""
+    import tempfile
+    from srbh_amd.rrdbnet import RealESRGAN
+    torch.manual_seed(3)
+    m = RealESRGAN(3, 3, num_block=1, device="cuda:0", is_train=True)
+    assert m.net_g.training and hasattr(m, "net_g_ema") and not any(p.requires_grad for p in m.net_g_ema.parameters())
+    gt = torch.nn.functional.interpolate(rand((2, 3, 16, 16), 9, 0.0, 1.0), scale_factor=8, mode="bilinear")   # smooth 128x128 target
+    lq = torch.nn.functional.avg_pool2d(gt, 4)
+    ema0 = m.net_g_ema.conv_first.weight.clone()
+    losses = []
+    for it in range(8):
+        m.feed_data({"lq": lq, "gt": gt})
+        ld = m.optimize_parameters()
+        m.update_learning_rate(it)
+        losses.append(ld["l_g_pix"])
+        assert "l_g_gan" in ld and "l_d_real" in ld and "l_d_fake" in ld and "l_g_percep" not in ld
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    assert not torch.equal(m.net_g_ema.conv_first.weight, ema0)
+    with tempfile.TemporaryDirectory() as td:
+        m.save(0, 8, td)
+        ck = torch.load(os.path.join(td, "net_g.tar"), map_location="cpu")
+        assert set(ck) >= {"params", "params_ema", "epoch", "current_iter"} and len(ck["params"]) == len(m.net_g.state_dict())
+    with torch.no_grad():
+        assert m.predict(lq).shape == (2, 3, 128, 128)

@@ -475,7 +475,55 @@ def g_loader():
     save("g13_loader", **out)
 
 
+# ---- G14: SR-stage slice: autograd through the reference RRDBNet; discriminator / filter2D / GANLoss ----------
+def g_sr_stage():
+    sd = synth.rrdbnet_state_dict(num_block=2, seed=31, mode="stress")
+    net = ref_rrdb.RRDBNet(3, 3, num_block=2)
+    net.load_state_dict(sd, strict=True)
+    out = {}
+    for tag, fn, wseed in (("fw", net.forward, 141), ("ft", net.forward_feature, 142)):
+        x = rand((2, 3, 16, 16), 140, 0.0, 1.0).requires_grad_(True)
+        for p_ in net.parameters():
+            p_.grad = None
+        y = fn(x)
+        w = rand(tuple(y.shape), wseed)
+        (y * w).sum().backward()
+        out[f"{tag}_out"] = y.detach() if y.shape[1] <= 3 else y.detach()[:, ::8, ::4, ::4].contiguous()   # (features: a strided sample)
+        out[f"{tag}_gx"] = x.grad.clone()
+        names = [k for k, _ in net.named_parameters()]
+        out[f"{tag}_gnorm"] = torch.tensor([0.0 if p_.grad is None else float(p_.grad.double().norm()) for _, p_ in net.named_parameters()])
+        for k in ("conv_first.weight", "conv_first.bias", "body.0.rdb1.conv1.weight", "body.0.rdb1.conv5.weight", "body.0.rdb1.conv5.bias",
+                  "body.0.rdb2.conv3.weight", "body.1.rdb3.conv4.weight", "body.1.rdb3.conv4.bias", "conv_body.weight", "conv_up1.weight",
+                  "conv_up2.bias", "conv_hr.weight", "conv_last.weight", "conv_last.bias"):
+            g = dict(net.named_parameters())[k].grad
+            if g is not None:       # large weights: every 4th output and input channel (the norms of ALL gradients are in *_gnorm)
+                out[f"{tag}_g_{k}"] = g.clone() if g.numel() <= 4096 else g[::4, ::4].contiguous()
+    out["param_names"] = np.array(names)
+    # discriminator (spectral norm: eval mode -> no power-iteration update), small width so that its weights fit the fixture
+    torch.manual_seed(77)
+    d = ref_rrdb.UNetDiscriminatorSN(3, num_feat=8, skip_connection=True).eval()
+    xd = rand((2, 3, 32, 32), 143, 0.0, 1.0)
+    with torch.no_grad():
+        out["disc_out"] = d(xd)
+    for k, v in d.state_dict().items():
+        out["disc_sd_" + k] = v
+    # filter2D with a shared and a per-image kernel
+    img = rand((2, 3, 20, 24), 144, 0.0, 1.0)
+    k1 = rand((1, 5, 5), 145, 0.0, 1.0)
+    kb = rand((2, 7, 7), 146, 0.0, 1.0)
+    out["f2d_shared"] = ref_rrdb.filter2D(img, k1 / k1.sum())
+    out["f2d_batch"] = ref_rrdb.filter2D(img, kb / kb.sum(dim=(1, 2), keepdim=True))
+    # GANLoss
+    import SR.srloss as ref_loss
+    z = rand((2, 1, 8, 8), 147, -2.0, 2.0)
+    for t in ("vanilla", "lsgan", "wgan", "wgan_softplus", "hinge"):
+        gl = ref_loss.GANLoss(t, loss_weight=0.1)
+        out[f"gan_{t}"] = torch.stack([gl(z, True, is_disc=False), gl(z, True, is_disc=True), gl(z, False, is_disc=True)])
+    save("g14_sr_stage", **out)
+
+
 if __name__ == "__main__":
+    g_sr_stage()
     g_mosaic()
     g_loader()
     g_losses_metrics()
