@@ -1299,6 +1299,17 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
             fprintf(stderr, "[srbh]   conv%d: loop %.0f (of which: waiting for the own LDS-DMA %.0f, at the step barriers %.0f; prologue %.0f) | "
                     "epilogue %.0f | publish/seam %.0f | start-to-start %.0f\n",
                     k + 1, loop[k] / cnt, dma[k] / cnt, bar[k] / cnt, wait[k] / cnt, epi[k] / cnt, pub[k] / cnt, tot5[k] / cnt);
+        // conv5's epilogue / seam split by RDB kind: every third RDB also closes an RRDB (second residual from memory)
+        double e5[2] = {0, 0}, s5[2] = {0, 0};
+        long n5[2] = {0, 0};
+        for (int b = 0; b < nblk; ++b)
+            for (int L = 4; L + 1 < nl; L += 5) {
+                const unsigned long long* q = &h[((size_t)b * nl + L) * 6];
+                const int kind = ((L / 5) % 3) == 2;
+                e5[kind] += (double)(q[2] - q[1]); s5[kind] += (double)(q[3] >> 32); n5[kind]++;
+            }
+        fprintf(stderr, "[srbh]   conv5 epilogue: %.0f plain / %.0f RRDB-closing; seam %.0f / %.0f\n", e5[0] / (n5[0] ? n5[0] : 1),
+                e5[1] / (n5[1] ? n5[1] : 1), s5[0] / (n5[0] ? n5[0] : 1), s5[1] / (n5[1] ? n5[1] : 1));
     }
     *used = 1;
     return SRBH_OK;
