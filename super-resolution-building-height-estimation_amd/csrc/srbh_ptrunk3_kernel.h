@@ -29,6 +29,9 @@
 #ifndef P3_SKIPST
 #define P3_SKIPST 1             // 1: a register-resident plane is stored to memory only where a neighbour reads it (its halo rows)
 #endif
+#ifndef P3_DEFER
+#define P3_DEFER 0               // 1: rows 1, 2 of a cout-32 epilogue run in the empty MFMA shadows of the next layer's step 0 (measured neutral: see DESIGN.md 5.0)
+#endif
 #ifndef P3_ABL
 #define P3_ABL 0                // developer ablations (WRONG RESULTS): 1 no weight DMA, 2 no input/halo DMA, 4 no register staging stores
 #endif
@@ -239,19 +242,59 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         for (int m = 0; m < 2; ++m)
             x1p[i][m] = *(const uintx4*)(pp.dense[0] + tile_off + (long)pp.plane_b + (long)(wr * 4 + i + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16);
 
+    // ---- deferred half of a cout-32 epilogue (P3_DEFER).  Groups 3-5 of a step carry neither LDS reads nor staging items: ~20
+    // MFMA shadows of 28 cycles with nothing in them, while an epilogue is 350 VALU instructions with the matrix core idle.
+    // So conv1..3 finish only the rows a neighbour may read (0 and 3: halo rows, stored and published as before) right away and
+    // park the accumulators of rows 1, 2 (32 registers + 16 of bias); the next layer's step 0 works them off, one unit of ~6
+    // VALU instructions per empty shadow: 16 units (row, channel group, half) bias + leaky ReLU + fp16, 4 units (row, k-step)
+    // permlane + (store).  Their results are needed one step later at the earliest (staging of X1 / X2 from registers, the own
+    // DMA of X3), and no neighbour ever reads these rows.  Same arithmetic, same bits.
+    float pend[2][16];
+    floatx4 pbias[4];
+    unsigned php[2][4][2];
+    uintx4 pk[2][2];
+    char* poplane = nullptr;
+    bool pst = false;
+    auto defer_unit = [&](const int u) {
+        if (u < 16) {
+            const int r = u >> 3, g = (u >> 1) & 3, hh = u & 1;
+            float w0 = pend[r][g * 4 + 2 * hh] + pbias[g][2 * hh], w1 = pend[r][g * 4 + 2 * hh + 1] + pbias[g][2 * hh + 1];
+            const float s0 = w0 * 0.2f, s1 = w1 * 0.2f;
+            asm("v_max_f32 %0, %1, %2" : "=v"(w0) : "v"(w0), "v"(s0));
+            asm("v_max_f32 %0, %1, %2" : "=v"(w1) : "v"(w1), "v"(s1));
+            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+            const half2v h2 = {(_Float16)w0, (_Float16)w1};
+            php[r][g][hh] = __builtin_bit_cast(unsigned, h2);
+        } else {
+            const int r = (u - 16) >> 1, m = (u - 16) & 1, i = 1 + r;
+            auto s0 = __builtin_amdgcn_permlane32_swap(php[r][2 * m][0], php[r][2 * m + 1][0], false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(php[r][2 * m][1], php[r][2 * m + 1][1], false, false);
+            const uintx4 raw = {s0[0], s1[0], s0[1], s1[1]};
+            pk[r][m] = raw;
+            if (pst) {
+                char* o = poplane + (long)(Y0 + wr * 4 + i + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16;
+                if (wt)
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
+                else
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
+            }
+        }
+    };
+
     // ---- one K step.  CB = cout/32 of the running layer.  What is staged for the NEXT step is a compile-time property:
     //   IN: 0 no input plane | 1 input plane by LDS-DMA (11 statements) | 2 input plane from registers (8 ds_write_b128 + 1
     //   border write + 2 halo DMA statements);   NW: weight DMA statements per wave (0 | 5 = 18 fragments | 9 = 36 fragments)
     auto run_step = [&](auto cb_tag, auto in_tag, auto nw_tag, floatx16 (&acc)[decltype(cb_tag)::value][4], const char* sbi, const char* sbw,
-                        const char* nsrc, const char* nw, char* dst, const uintx4 (&rsrc)[4][2]) {
+                        const char* nsrc, const char* nw, char* dst, const uintx4 (&rsrc)[4][2], auto defer_tag) {
         constexpr int CB = decltype(cb_tag)::value, IN = decltype(in_tag)::value, NW = decltype(nw_tag)::value;
+        constexpr bool DEFER = decltype(defer_tag)::value;   // also work off the parked half of the previous layer's epilogue
         constexpr int NRD = G::NP + 3 * CB, NMF = 12 * CB;
         constexpr int NH = 2;                                           // halo DMA statements of a register-staged plane
         constexpr int NDMA = (IN == 1 ? 11 : IN == 2 ? NH : 0) + NW;    // DMA statements
         constexpr int ND = NDMA + (IN == 2 ? 9 : 0);                    // + LDS stores of a register-staged plane
         constexpr int RSH = (NRD + P3_READS_PER_SHADOW - 1) / P3_READS_PER_SHADOW;   // MFMA shadows of a group that carry LDS reads
         constexpr int DPG = NMF - RSH;                                                 // ... that can carry a staging item
-        static_assert(ND <= 6 * DPG, "the staging items of a step must fit its MFMA shadows");
+        static_assert(ND + (DEFER ? 20 : 0) <= 6 * DPG, "the staging items (and deferred epilogue units) of a step must fit its MFMA shadows");
         const unsigned long long ibase = uni64((unsigned long long)nsrc);
         const unsigned long long wbase = uni64((unsigned long long)(nw + wave * 1024));
         const unsigned din_w = __builtin_amdgcn_readfirstlane(lds_addr(dst) + wave * 1024);
@@ -310,6 +353,9 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                     if (d < ND) {
                         stage_item(d);
                         __builtin_amdgcn_sched_barrier(0);
+                    } else if (DEFER && d - ND < 20) {
+                        defer_unit(d - ND);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
@@ -325,6 +371,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     using W0 = std::integral_constant<int, 0>;   // NW: weight DMA statements per wave
     using W5 = std::integral_constant<int, 5>;
     using W9 = std::integral_constant<int, 9>;
+    using NODEFER = std::false_type;
+    using DODEFER = std::true_type;
 
     // ---- layer prologue: drain the own DMA / stores, barrier, bias into LDS, lazy publish
     auto prologue = [&](const float* bias, const int nb, const int bias_lds) {
@@ -352,13 +400,24 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     };
 
     // ---- epilogue of a cout-32 layer: bias, leaky ReLU, fp16, straight from the MFMA D layout (see ptrunk_kernel)
-    auto epi32 = [&](floatx16 (&acc)[1][4], char* oplane, uintx4 (&keep)[4][2], const bool halo_only) {
+    auto epi32 = [&](floatx16 (&acc)[1][4], char* oplane, uintx4 (&keep)[4][2], const bool halo_only, auto park_tag) {
+        constexpr bool PARK = decltype(park_tag)::value;   // rows 1, 2 are parked for the next layer's step 0 (defer_unit)
         floatx4 bias4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) bias4[g] = *(const floatx4*)((const float*)(smem + A_BIAS_OFF) + g * 8 + hi * 4);
         // rows 0 and 3 first: one of them is the row a neighbour reads (its store is the one the publication waits for)
+        if constexpr (PARK) {
 #pragma unroll
-        for (int io = 0; io < 4; ++io) {
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) pend[r][q] = acc[0][1 + r][q];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pbias[g] = bias4[g];
+            poplane = oplane;
+            pst = !halo_only;
+        }
+#pragma unroll
+        for (int io = 0; io < (PARK ? 2 : 4); ++io) {
             const int i = io == 0 ? 0 : io == 1 ? 3 : io - 1;
             const int Y = Y0 + wr * 4 + i;
             const bool st = !halo_only || (i == 0 && wr == 0) || (i == 3 && wr == 1);   // (wave-uniform)
@@ -513,7 +572,10 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         // ---------------- conv1..conv4 (cout 32, plane 0 resident, stages of IN_EX + 18 KiB).  One body for conv1..3 and one
         // for conv4 (their last steps stage different things: compiling them as two variants of ONE layer body made the
         // accumulators of the two last-step variants meet in a phi, i.e. 64 v_accvgpr_mov per layer)
-        auto layerA = [&](const int kk, auto last_nw_tag) {
+        auto layerA = [&](auto kk_tag, auto last_nw_tag) {
+            // (kk is a compile-time constant: four bodies per RDB instead of two, but the parked epilogue registers of P3_DEFER are
+            //  then provably dead outside conv1..3 -> conv2..4; as a run-time loop variable they were live across conv5: 217 spills)
+            constexpr int kk = decltype(kk_tag)::value;
             const int L = L0 + kk, n = kk + 2;
             const char* wl = T[kk].w;
             unsigned long long p0 = 0, p1 = 0, p2 = 0;
@@ -528,8 +590,25 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][i][r] = 0.f;
             // step 0: resident plane 0; stages chunk 1 (x's second half) from registers
-            run_step(C1{}, I2{}, W5{}, acc, smem, smem + stage_off(1, gs & 1) + IN_EX, dcur + (long)pp.plane_b, wl + 18 * 1024,
-                     smem + stage_off(1, (gs + 1) & 1), x1p);
+            if (P3_DEFER && kk > 0) {   // ... and works off rows 1, 2 of the previous layer's epilogue in its empty MFMA shadows
+                run_step(C1{}, I2{}, W5{}, acc, smem, smem + stage_off(1, gs & 1) + IN_EX, dcur + (long)pp.plane_b, wl + 18 * 1024,
+                         smem + stage_off(1, (gs + 1) & 1), x1p, DODEFER{});
+                if (kk == 1) {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) X1r[1 + r][m] = pk[r][m];
+                }
+                if (kk == 2) {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) X2r[1 + r][m] = pk[r][m];
+                }
+            } else {
+                run_step(C1{}, I2{}, W5{}, acc, smem, smem + stage_off(1, gs & 1) + IN_EX, dcur + (long)pp.plane_b, wl + 18 * 1024,
+                         smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{});
+            }
             ++gs;
             // The only NEW input plane of conv2..4 is the last chunk (index kk + 1): its halo rows are fetched during step kk, so
             // the neighbours' progress is checked right in front of that step (conv1's inputs were verified at the seam).
@@ -541,7 +620,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 step_sync();
                 const char* st = smem + stage_off(1, gs & 1);
                 run_step(C1{}, I2{}, W5{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (18 * 1024),
-                         smem + stage_off(1, (gs + 1) & 1), X1r);
+                         smem + stage_off(1, (gs + 1) & 1), X1r, NODEFER{});
                 ++gs;
             }
             if (n >= 4) {      // step 2: chunk 2; stages chunk 3 (X2) from registers
@@ -552,7 +631,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 step_sync();
                 const char* st = smem + stage_off(1, gs & 1);
                 run_step(C1{}, I2X{}, W5{}, acc, st, st + IN_EX, dcur + 3l * pp.plane_b, wl + 3 * (18 * 1024),
-                         smem + stage_off(1, (gs + 1) & 1), X2r);
+                         smem + stage_off(1, (gs + 1) & 1), X2r, NODEFER{});
                 ++gs;
             }
             if (n >= 5) {      // step 3 (conv4): chunk 3; stages chunk 4 (X3) by DMA
@@ -561,33 +640,37 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 step_sync();
                 const char* st = smem + stage_off(1, gs & 1);
                 run_step(C1{}, I1{}, W5{}, acc, st, st + IN_EX, dcur + 4l * pp.plane_b, wl + 4 * (18 * 1024),
-                         smem + stage_off(1, (gs + 1) & 1), x1p);
+                         smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{});
                 ++gs;
             }
             step_sync();
             {
                 const char* st = smem + stage_off(1, gs & 1);
                 if constexpr (decltype(last_nw_tag)::value == 5)   // conv1..3: the next layer's step 0 reads the resident plane: weights only
-                    run_step(C1{}, I0{}, W5{}, acc, st, st + IN_EX, nullptr, T[kk + 1].w, smem + stage_off(1, (gs + 1) & 1), x1p);
+                    run_step(C1{}, I0{}, W5{}, acc, st, st + IN_EX, nullptr, T[kk + 1].w, smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{});
                 else              // conv4: conv5's chunk 0 IS the resident plane (phase-B stage 0 starts at the same address): 36 KiB of weights
-                    run_step(C1{}, I0{}, W9{}, acc, st, st + IN_EX, nullptr, T[4].w, smem + stage_off(2, 0), x1p);
+                    run_step(C1{}, I0{}, W9{}, acc, st, st + IN_EX, nullptr, T[4].w, smem + stage_off(2, 0), x1p, NODEFER{});
                 ++gs;
             }
             if (PROF) p2 = __builtin_amdgcn_s_memtime();
             uintx4 kept[4][2];
-            epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept,
-                  P3_SKIPST && P3_S1 && (kk == 0 || (P3_X2REG && kk == 1)));
+            const bool halo_only = P3_SKIPST && P3_S1 && (kk == 0 || (P3_X2REG && kk == 1));
+            if constexpr (P3_DEFER && decltype(last_nw_tag)::value == 5)     // conv1..3: rows 1, 2 are finished by the next layer's step 0
+                epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept, halo_only, std::true_type{});
+            else
+                epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept, halo_only, std::false_type{});
+            constexpr int NK = (P3_DEFER && decltype(last_nw_tag)::value == 5) ? 2 : 4;     // rows available now: 0 and 3, or all
             if (kk == 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int io = 0; io < NK; ++io)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) X1r[i][m] = kept[i][m];
+                    for (int m = 0; m < 2; ++m) X1r[NK == 2 ? 3 * io : io][m] = kept[NK == 2 ? 3 * io : io][m];
             }
             if (kk == 1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int io = 0; io < NK; ++io)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) X2r[i][m] = kept[i][m];
+                    for (int m = 0; m < 2; ++m) X2r[NK == 2 ? 3 * io : io][m] = kept[NK == 2 ? 3 * io : io][m];
             }
             pending_pub = true;   // published behind the next top-of-step barrier (whose vmcnt(0) covers these stores)
             pub_val = L + 1;
@@ -596,8 +679,10 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 q[0] = p1; q[1] = p2; q[2] = __builtin_amdgcn_s_memtime(); q[3] = p1 - p0; q[4] = t_sync; q[5] = t_vm;
             }
         };
-        for (int k = 0; k < 3 && !aborted; ++k) layerA(k, W5{});
-        if (!aborted) layerA(3, W9{});
+        layerA(std::integral_constant<int, 0>{}, W5{});
+        if (!aborted) layerA(std::integral_constant<int, 1>{}, W5{});
+        if (!aborted) layerA(std::integral_constant<int, 2>{}, W5{});
+        if (!aborted) layerA(std::integral_constant<int, 3>{}, W9{});
         if (aborted) break;
         // ---------------- conv5 (cout 64, stages of IN_EX + 36 KiB, residual epilogue)
         {
@@ -618,17 +703,17 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                     for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
             {   // chunk 0 = the resident plane (in place: phase-B stage 0); stages chunk 1 from registers
                 const char* st = smem + stage_off(2, 0);
-                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + (long)pp.plane_b, wl + 36 * 1024, smem + stage_off(2, 1), x1p);
+                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + (long)pp.plane_b, wl + 36 * 1024, smem + stage_off(2, 1), x1p, NODEFER{});
             }
             step_sync();
             {   // chunk 1; stages chunk 2 (X1) from registers
                 const char* st = smem + stage_off(2, 1);
-                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (36 * 1024), smem + stage_off(2, 0), X1r);
+                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (36 * 1024), smem + stage_off(2, 0), X1r, NODEFER{});
             }
             step_sync();
             {   // chunk 2; stages chunk 3 (X2) from registers
                 const char* st = smem + stage_off(2, 0);
-                run_step(C2{}, I2X{}, W9{}, acc, st, st + IN_EX, dcur + 3l * pp.plane_b, wl + 3 * (36 * 1024), smem + stage_off(2, 1), X2r);
+                run_step(C2{}, I2X{}, W9{}, acc, st, st + IN_EX, dcur + 3l * pp.plane_b, wl + 3 * (36 * 1024), smem + stage_off(2, 1), X2r, NODEFER{});
             }
             for (int c = 3; c < 5; ++c) {      // chunks 3, 4; stage X3, X4 by DMA
                 if (c == 4) {      // X4 (chunk 5) is conv4's output on the neighbours: checked in front of the step that fetches it
@@ -638,13 +723,13 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 step_sync();
                 const char* st = smem + stage_off(2, c & 1);
                 run_step(C2{}, I1{}, W9{}, acc, st, st + IN_EX, dcur + (long)(c + 1) * pp.plane_b, wl + (long)(c + 1) * (36 * 1024),
-                         smem + stage_off(2, (c + 1) & 1), x1p);
+                         smem + stage_off(2, (c + 1) & 1), x1p, NODEFER{});
             }
             if (aborted) break;
             step_sync();
             {
                 const char* st = smem + stage_off(2, 1);
-                run_step(C2{}, I0{}, W0{}, acc, st, st + IN_EX, nullptr, nullptr, smem, x1p);
+                run_step(C2{}, I0{}, W0{}, acc, st, st + IN_EX, nullptr, nullptr, smem, x1p, NODEFER{});
             }
             const bool r2 = (rdb % 3) == 2;
             if (PROF) p2 = __builtin_amdgcn_s_memtime();
