@@ -222,7 +222,7 @@ class TrainStep:
     is still running); ``overlap=False`` selects the plain post-backward sweep."""
 
     def __init__(self, net_hr, net, device, world=1, lr=1e-3, sync_bn=False, overlap=True, timing=False, status_every=100,
-                 head_precision="f16"):
+                 head_precision="f16", graph=False):
         # mixed precision of the head's convolutions while training (hrfuse.set_head_precision): "f16" = forward convs with
         # fp16 operands, data gradients with bf16 operands (fp32's exponent range: no loss scaling), weight gradients,
         # BatchNorm, losses and Adam in fp32 -- what the north star's "fp16 MFMA, <= 1e-3 on the height maps" buys;
@@ -243,17 +243,51 @@ class TrainStep:
             p.requires_grad_(False)
         self.criterion = [MSE_adapt_weight(device=device), MSE_adapt_weight(device=device),
                           CE_DICE_adapt_weight(device=device)]
-        self.optimizer = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=1e-4)
+        # graph=True (one GPU): after three eager steps the WHOLE step -- RRDBNet features, model forward, losses, backward, Adam --
+        # is captured into one HIP graph and replayed (Adam with capturable=True keeps its step counters on the device).  The
+        # step is ~1 400 launches; once the kernels were tuned the host could no longer issue them fast enough (rocprofv3:
+        # 35 ms of kernel time in a 56 ms step), a graph replay issues them back to back.
+        self.use_graph = bool(graph) and world == 1
+        self.optimizer = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=1e-4, capturable=self.use_graph)
         self.optimizer.add_param_group({"params": [c.log_var for c in self.criterion], "lr": lr})
         self.rgbseq = [0, 1, 2]
         self.reducer = GradReducer(self.params(), world, timing=timing) if (world > 1 and overlap) else None
         self.steps = 0
         self.status_every = status_every
+        self._graph = None
+        self._static = None
 
     def params(self):
         return [p for g in self.optimizer.param_groups for p in g["params"]]
 
     def __call__(self, batch):
+        if self.use_graph:
+            return self._graph_step(batch)
+        return self._step(batch)
+
+    def _graph_step(self, batch):
+        if self._graph is None:
+            self._static = tuple(t.clone() for t in batch)
+            if self.steps < 3:                       # eager warm-up (lazy packs, MIOpen kernels, Adam state) before the capture
+                for dst, src in zip(self._static, batch):
+                    dst.copy_(src)
+                return self._step(self._static)
+            self.net_hr.check_status()
+            self.optimizer.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._static_out = self._step(self._static, in_graph=True)
+        for dst, src in zip(self._static, batch):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        self._graph.replay()
+        self.steps += 1
+        if self.status_every and self.steps % self.status_every == 0 and hasattr(self.net_hr, "check_status"):
+            self.net_hr.check_status()
+        return self._static_out
+
+    def _step(self, batch, in_graph=False):
         lr, height, height_aggre, build, weight, weight_aggre = batch
         with torch.no_grad():
             hr_fea = self.net_hr.forward_feature(lr[:, self.rgbseq])
@@ -268,6 +302,8 @@ class TrainStep:
         else:
             allreduce_grads(self.params(), self.world)
         self.optimizer.step()
+        if in_graph:
+            return loss.detach(), height_pred.detach()
         self.steps += 1
         # a persistent-trunk timeout NaN-poisons hr_fea (loud by itself); the host-side check names the reason.  It costs a
         # stream synchronisation, so: after the first step (where a co-residency problem shows) and then rarely.
