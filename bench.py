@@ -156,7 +156,7 @@ def head_kernel_rooflines(dev, B):
     for name, fn, nbytes in (
             (f"hconv kernel ({'fp16' if h16 else 'fp32'} operands) 16->16 3x3 fwd + BN statistics", lambda: H.hconv([x], conv, pk, want_stats=True), px * (64 + 64)),
             (f"hconv kernel ({'bf16' if h16 else 'fp32'} operands) 16->16 3x3 data gradient", lambda: HA.conv_dgrad(g, conv.weight, pg), px * (64 + 64)),
-            ("hwgrad_f32_kernel 16->16 3x3 weight gradient", lambda: HA.conv_wgrad([x], None, g, 16, 3), px * (64 + 64))):
+            (f"hwgrad kernel ({'bf16' if h16 else 'fp32'} operands) 16->16 3x3 weight gradient (+ its 2 reduce launches)", lambda: HA.conv_wgrad([x], None, g, 16, 3), px * (64 + 64))):
         ms = _timed(fn, 10, dev)
         out.append({"kernel": f"{name} @256x256, B={B}", "bound": "hbm", "avg_launch_ms": round(ms, 4),
                     "algorithmic_bytes_per_launch": nbytes, "achieved": round(nbytes / ms / 1e6, 1), "peak": PEAK_HBM_GBS,
@@ -194,7 +194,7 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
     from srbh_amd.harness import TrainStep, synthetic_batch, train_epoch
     sd, net_hr, net = _make_nets(args, dev, True)
     sync_bn = os.environ.get("SRBH_SYNC_BN", "0") == "1"        # default: per-rank BatchNorm statistics
-    use_graph = world == 1 and os.environ.get("SRBH_TRAIN_GRAPH", "1") == "1" and not epoch_tiles   # one HIP graph per step (host-bound otherwise)
+    use_graph = world == 1 and os.environ.get("SRBH_TRAIN_GRAPH", "0") == "1" and not epoch_tiles   # one HIP graph per step (measured: no faster than eager launches on ROCm 7.2)
     ts = TrainStep(net_hr, net, dev, world=world, sync_bn=sync_bn, timing=True, status_every=0, graph=use_graph)
     fixed = synthetic_batch(batch, 1337 + rank, dev)
     for _ in range(max(warmup, 5 if use_graph else (2 if world > 1 else 1))):          # (world > 1: step 1 records the bucket plan; graph: 3 eager steps, then the capture)

@@ -234,6 +234,11 @@ typedef struct srbh_hwgrad_args {
 } srbh_hwgrad_args;
 size_t srbh_hwgrad_ws_bytes(int cout, int cin, int ksize);
 int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream);
+/* Mixed-precision form of the same gradient (torch.cuda.amp-style training; the reference itself trains in fp32,
+ * train.py:254-256): X and dY are rounded to bf16 (RNE) while staged, products on v_mfma_f32_16x16x16_bf16, fp32 accumulation,
+ * same workspace and fixed summation order.  Needs c0, c1, the pixel strides % 4 == 0, cout % 16 == 0 and 16-byte aligned
+ * pointers; a layer outside that (the 1- / 7-channel output convs) is computed by the fp32 kernel. */
+int srbh_hconv_wgrad_b16(const srbh_hwgrad_args* a, void* stream);
 /* out = g where ref > 0 else 0   (ReLU backward with the saved output, SR/HRfuse.py:157) */
 int srbh_relu_mask_mul(const float* g, const float* ref, float* out, long n, void* stream);
 int srbh_add_inplace(float* a, const float* b, long n, void* stream);

@@ -204,6 +204,164 @@ __global__ __launch_bounds__(256) void hwgrad_f32_kernel(const WGParams p) {
     }
 }
 
+// ---- 16-bit-operand weight gradient (mixed-precision training: hrfuse.set_head_precision("f16")) ----------------------------------
+// Same GEMM over pixels, same tile walk, workspace and deterministic two-stage reduction as hwgrad_f32_kernel, but the products run
+// on v_mfma_f32_16x16x16_bf16 (K = 16 pixels per instruction; the fp32 form's K = 4 at 32 cycles made the fp32 kernel MFMA-bound at
+// ~2x its HBM time).  Both operands are rounded to bf16 (RNE) while staged -- dY needs bf16's exponent range, see srbh_head.hip --
+// and accumulated in fp32.  K is the pixel axis, so the 16-bit operands must be contiguous along PIXELS: the staging transposes
+// 4 pixels x 4 channels in registers and writes channel-major rows ([channel][row][pixel], 2 pixels per dword; channel stride
+// = 4 mod 64 dwords: the 8-byte fragment reads and the staging writes are bank-conflict free).  A tap's dx = -1/+1 fragments are
+// funnel-shifted (v_alignbit) out of the aligned quad and one dword of its neighbour.
+typedef short short4w __attribute__((ext_vector_type(4)));
+typedef unsigned uint2w __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned bf16_pair(float lo, float hi) {
+    unsigned a = __builtin_bit_cast(unsigned, lo), b = __builtin_bit_cast(unsigned, hi);
+    a += 0x7fffu + ((a >> 16) & 1u);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xffff0000u);
+}
+
+template <int KS>
+struct WG16 {
+    static constexpr int TAPS = KS * KS, HALO = KS / 2;
+    static constexpr int ROWS = HT_H + 2 * HALO;
+    static constexpr int QX = KS == 3 ? 18 : 16;       // staged 4-pixel groups per row: image columns X0-4 .. X0+67 (3x3) / X0 .. X0+63
+    static constexpr int XOFF = KS == 3 ? 4 : 0;       // staged column of image column X0
+    static constexpr int SX = KS == 3 ? 388 : 260;     // dwords per staged X channel (>= ROWS*QX*2, = 4 mod 64)
+    static constexpr int SD = 260;                     // dwords per staged dY channel (8 rows x 64 pixels / 2 + 4)
+    static constexpr int LDS_B = (16 * SX + 16 * SD) * 4;   // >= the flush buffer (4 waves x TAPS x 256 floats)
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    using G = WG16<KS>;
+    constexpr int TAPS = G::TAPS, HALO = G::HALO, ROWS = G::ROWS, QX = G::QX, SX = G::SX, SD = G::SD;
+    static_assert(G::LDS_B >= 4 * TAPS * 256 * 4, "flush buffer must fit");
+    unsigned* s_x = (unsigned*)wsm;                 // [16 ci][SX]
+    unsigned* s_dy = s_x + 16 * SX;                 // [16 oc][SD]
+    float* s_red = wsm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kk = lane >> 4;
+    const int cin = p.c0 + p.c1;
+    const int nchunk = (cin + 15) / 16;
+    const int ob = blockIdx.y;
+
+    for (int c = 0; c < nchunk; ++c) {
+        floatx4 acc[TAPS];
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) acc[tp] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+            const int img = t / p.tiles_per_img;
+            const int trem = t - img * p.tiles_per_img;
+            const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+            const int Y0 = ty * HT_H, X0 = tx * HT_W;
+            // ---- stage: every global load of the tile is issued before the first LDS store
+            constexpr int NIX = (ROWS * QX * 4 + 255) / 256, NID = HT_H * 16 * 4 / 256;
+            floatx4 lx[NIX][4], ld[NID][4];
+#pragma unroll
+            for (int it = 0; it < NIX; ++it) {
+                const int u = tid + it * 256;
+                const int cg = u & 3, q = u >> 2;
+                const int r = q / QX, qc = q - r * QX;
+                const int y = Y0 + r - HALO, x0 = X0 - G::XOFF + qc * 4;
+                const int ch = c * 16 + cg * 4;
+                const bool rowok = u < ROWS * QX * 4 && y >= 0 && y < p.H && ch < cin;
+                const long rowbase = ((long)img * p.H + y) * p.W;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    floatx4 a = {0.f, 0.f, 0.f, 0.f};
+                    const int x = x0 + i;
+                    if (rowok && x >= 0 && x < p.W) {
+                        if (ch < p.c0) {
+                            a = *(const floatx4*)(p.src0 + (rowbase + x) * p.ld0 + ch);
+                            if (p.pre_scale) a = a * *(const floatx4*)(p.pre_scale + ch) + *(const floatx4*)(p.pre_shift + ch);
+                            if (p.pre_relu) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) a[j] = fmaxf(a[j], 0.f);
+                            }
+                        } else {
+                            a = *(const floatx4*)(p.src1 + (rowbase + x) * p.ld1 + (ch - p.c0));
+                        }
+                    }
+                    lx[it][i] = a;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NID; ++it) {
+                const int u = tid + it * 256;
+                const int cg = u & 3, q = u >> 2;
+                const int y = Y0 + (q >> 4), x0 = X0 + (q & 15) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    floatx4 a = {0.f, 0.f, 0.f, 0.f};
+                    if (y < p.H && x0 + i < p.W)
+                        a = *(const floatx4*)(p.dy + (((long)img * p.H + y) * p.W + x0 + i) * p.cout_total + ob * 16 + cg * 4);
+                    ld[it][i] = a;
+                }
+            }
+            __syncthreads();                       // the previous tile's fragment reads are done
+#pragma unroll
+            for (int it = 0; it < NIX; ++it) {
+                const int u = tid + it * 256;
+                if (u < ROWS * QX * 4) {
+                    const int cg = u & 3, q = u >> 2;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *(uint2w*)(s_x + (cg * 4 + j) * SX + q * 2) =
+                            uint2w{bf16_pair(lx[it][0][j], lx[it][1][j]), bf16_pair(lx[it][2][j], lx[it][3][j])};
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NID; ++it) {
+                const int u = tid + it * 256;
+                const int cg = u & 3, q = u >> 2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *(uint2w*)(s_dy + (cg * 4 + j) * SD + q * 2) =
+                        uint2w{bf16_pair(ld[it][0][j], ld[it][1][j]), bf16_pair(ld[it][2][j], ld[it][3][j])};
+            }
+            __syncthreads();
+            // ---- 2 rows x 4 groups of 16 pixels per wave
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int row = wave * 2 + (ks >> 2), g = ks & 3;
+                const uint2w a2 = *(const uint2w*)(s_dy + l15 * SD + (row * 16 + g * 4 + kk) * 2);
+                const short4w a = __builtin_bit_cast(short4w, a2);
+                const unsigned* bp = s_x + l15 * SX + (row * QX + (G::XOFF >> 2) + g * 4 + kk) * 2;
+#pragma unroll
+                for (int dy = 0; dy < KS; ++dy) {
+                    const unsigned* rp = bp + dy * QX * 2;
+                    const uint2w cur = *(const uint2w*)rp;
+                    if constexpr (KS == 3) {
+                        const unsigned pv = rp[-1], nx = rp[2];
+                        const unsigned mid = __builtin_amdgcn_alignbit(cur[1], cur[0], 16);
+                        const uint2w b0 = {__builtin_amdgcn_alignbit(cur[0], pv, 16), mid};
+                        const uint2w b2 = {mid, __builtin_amdgcn_alignbit(nx, cur[1], 16)};
+                        acc[dy * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, b0), acc[dy * 3 + 0], 0, 0, 0);
+                        acc[dy * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, cur), acc[dy * 3 + 1], 0, 0, 0);
+                        acc[dy * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, b2), acc[dy * 3 + 2], 0, 0, 0);
+                    } else {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, cur), acc[0], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_red[((wave * TAPS + tp) * 16 + kk * 4 + r) * 16 + l15] = acc[tp][r];
+        __syncthreads();
+        for (int u = tid; u < TAPS * 256; u += 256) {
+            const float v = s_red[u] + s_red[TAPS * 256 + u] + s_red[2 * TAPS * 256 + u] + s_red[3 * TAPS * 256 + u];
+            p.ws[(((long)blockIdx.x * gridDim.y + ob) * nchunk + c) * (TAPS * 256) + u] = v;
+        }
+        __syncthreads();                           // s_red aliases the staging buffers of the next chunk
+    }
+}
+
 // Sum of the workgroups' partials in a fixed order (deterministic), two stages so that enough loads are in flight:
 //   stage 1: tmp[s][u] = sum of the partials x in slice s (x = s*per .. s*per+per-1), grid (U/256, slices);
 //   stage 2: dw[oc][ci][tap] = sum over s of tmp[s][u(oc, ci, tap)]
@@ -347,18 +505,19 @@ int grid_for(long n) {
 
 }  // namespace
 
-extern "C" int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream) {
-    SRBH_REQUIRE(a && a->src0 && a->dy && a->dw, "srbh_hconv_wgrad_f32: null pointer");
-    SRBH_REQUIRE(a->c0 > 0 && a->c1 >= 0 && (a->c1 == 0 || a->src1), "srbh_hconv_wgrad_f32: bad channel split");
-    SRBH_REQUIRE(a->ksize == 3 || a->ksize == 1, "srbh_hconv_wgrad_f32: ksize must be 1 or 3");
-    SRBH_REQUIRE(a->cout >= 1 && a->cout <= 64 && a->B > 0 && a->H > 0 && a->W > 0, "srbh_hconv_wgrad_f32: bad shape");
+namespace {
+int wgrad_impl(const srbh_hwgrad_args* a, void* stream, bool b16, const char* who) {
+    SRBH_REQUIRE(a && a->src0 && a->dy && a->dw, "%s: null pointer", who);
+    SRBH_REQUIRE(a->c0 > 0 && a->c1 >= 0 && (a->c1 == 0 || a->src1), "srbh_hconv_wgrad: bad channel split");
+    SRBH_REQUIRE(a->ksize == 3 || a->ksize == 1, "srbh_hconv_wgrad: ksize must be 1 or 3");
+    SRBH_REQUIRE(a->cout >= 1 && a->cout <= 64 && a->B > 0 && a->H > 0 && a->W > 0, "srbh_hconv_wgrad: bad shape");
     WGParams p;
     p.src0 = a->src0; p.src1 = a->src1; p.c0 = a->c0; p.c1 = a->c1;
     p.ld0 = a->src0_ld > 0 ? a->src0_ld : a->c0;
     p.ld1 = a->src1_ld > 0 ? a->src1_ld : a->c1;
     p.pre_scale = a->pre_scale; p.pre_shift = a->pre_shift; p.pre_relu = a->pre_relu;
     p.dy = a->dy; p.cout_total = a->cout; p.dw = a->dw; p.ws = a->ws;
-    SRBH_REQUIRE(a->ws, "srbh_hconv_wgrad_f32: workspace missing (srbh_hwgrad_ws_bytes)");
+    SRBH_REQUIRE(a->ws, "srbh_hconv_wgrad: workspace missing (srbh_hwgrad_ws_bytes)");
     p.B = a->B; p.H = a->H; p.W = a->W;
     p.tiles_x = (a->W + HT_W - 1) / HT_W;
     p.tiles_per_img = p.tiles_x * ((a->H + HT_H - 1) / HT_H);
@@ -367,7 +526,19 @@ extern "C" int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream) {
     const int cin = a->c0 + a->c1;
     const int nob = (a->cout + 15) / 16;
     const int gx = p.ntiles < 512 ? p.ntiles : 512;
-    if (a->ksize == 3) {
+    // the bf16 form moves whole 4-channel groups with 16-byte loads and whole 16-channel output blocks; the few layers outside
+    // that (the 1- and 7-channel output convs) keep the fp32 kernel
+    const bool can16 = (a->c0 & 3) == 0 && (a->c1 & 3) == 0 && (p.ld0 & 3) == 0 && (a->c1 == 0 || (p.ld1 & 3) == 0) && (a->cout & 15) == 0 &&
+                       ((uintptr_t)a->src0 & 15) == 0 && ((uintptr_t)a->src1 & 15) == 0 && ((uintptr_t)a->dy & 15) == 0;
+    if (b16 && can16) {
+        if (a->ksize == 3) {
+            SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_b16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WG16<3>::LDS_B)));
+            hipLaunchKernelGGL(hwgrad_b16_kernel<3>, dim3(gx, nob), dim3(256), WG16<3>::LDS_B, st, p);
+        } else {
+            SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_b16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WG16<1>::LDS_B)));
+            hipLaunchKernelGGL(hwgrad_b16_kernel<1>, dim3(gx, nob), dim3(256), WG16<1>::LDS_B, st, p);
+        }
+    } else if (a->ksize == 3) {
         constexpr int LDS_B = (10 * 66 * 16 + 4 * 9 * 256) * 4;   // X tile + max(dY tile, flush buffer)
         SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_f32_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)));
         hipLaunchKernelGGL(hwgrad_f32_kernel<3>, dim3(gx, nob), dim3(256), LDS_B, st, p);
@@ -389,6 +560,11 @@ extern "C" int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream) {
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }
+}  // namespace
+
+extern "C" int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream) { return wgrad_impl(a, stream, false, "srbh_hconv_wgrad_f32"); }
+
+extern "C" int srbh_hconv_wgrad_b16(const srbh_hwgrad_args* a, void* stream) { return wgrad_impl(a, stream, true, "srbh_hconv_wgrad_b16"); }
 
 extern "C" size_t srbh_hwgrad_ws_bytes(int cout, int cin, int ksize) {
     if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;

@@ -21,6 +21,7 @@ import math
 
 import torch
 import torch.nn.functional as F
+from . import wcache
 from torch import nn
 
 # (width, depth, resolution, dropout) -- EfficientNet paper table / efficientnet_pytorch.utils.efficientnet_params
@@ -114,7 +115,16 @@ def bn_act(bn, x, act=None):
         _lib.check(_lib.lib().srbh_affine_act_nchw(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, C, H * W,
                                                    _ACT[act], _lib.stream_ptr()), "affine_act_nchw")
         return y
-    x = bn(x)
+    if bn.training and type(bn) is nn.BatchNorm2d and bn.track_running_stats and bn.momentum is not None:
+        # the module's own forward, minus its per-module `num_batches_tracked.add_(1)` launch (hrfuse.note_batch: one fused
+        # increment per model forward); SyncBatchNorm and exotic configurations keep the module call
+        from . import hrfuse as _H
+        _H.note_batch(bn)
+        x = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)
+        if _H._NBT["depth"] == 0:
+            _H.flush_batches()
+    else:
+        x = bn(x)
     if act == "silu":
         return _swish(x)
     if act == "relu":
@@ -126,7 +136,7 @@ def _bn_affine(bn, device):
     """(scale, shift) of an inference BatchNorm, cached on the module and invalidated by parameter / buffer versions"""
     from . import _lib
     C = bn.num_features
-    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.data_ptr())
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.data_ptr(), wcache.gen(bn.weight, bn.bias))
     cache = bn.__dict__.get("_srbh_affine")
     if cache is None or cache[0] != key:
         scale = torch.empty(C, dtype=torch.float32, device=device)

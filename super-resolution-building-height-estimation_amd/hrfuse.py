@@ -21,7 +21,7 @@ from typing import Callable, Optional
 import torch
 from torch import nn
 
-from . import _lib
+from . import _lib, wcache
 
 __all__ = ["default_conv", "Upsampler", "conv3x3", "conv1x1", "BasicBlock", "HRfeature", "HRfuse_residual",
            "HRfuse", "HRfuse_x2", "HRupsample", "GeoNet", "Refine_residual"]
@@ -90,7 +90,8 @@ class _PackedConv:
 
     def get(self, conv: nn.Conv2d, h16=False):
         w = conv.weight
-        key = (w._version, w.data_ptr(), None if conv.bias is None else (conv.bias._version, conv.bias.data_ptr()), bool(h16))
+        key = (w._version, w.data_ptr(), None if conv.bias is None else (conv.bias._version, conv.bias.data_ptr()), bool(h16),
+               wcache.gen(w, conv.bias))            # (fused optimizers do not bump _version, see wcache.py)
         if key != self.key:
             L = _lib.lib()
             cout, cin, ks, _ = w.shape
@@ -202,12 +203,43 @@ def bn_scale_shift(bn: nn.BatchNorm2d, stats, count, training):
                                       rm, rv, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                       _lib.stream_ptr()), "bn_finalize")
         if bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+            note_batch(bn)
         return scale, shift, mean, invstd
     _lib.check(L.srbh_bn_eval_scale_shift(Cc, g.data_ptr(), bta.data_ptr(), bn.running_mean.data_ptr(),
                                           bn.running_var.data_ptr(), bn.eps, scale.data_ptr(), shift.data_ptr(),
                                           _lib.stream_ptr()), "bn_eval_scale_shift")
     return scale, shift, None, None
+
+
+# ---- num_batches_tracked: ONE fused increment per forward instead of one launch per BatchNorm ---------------------------------
+# nn.BatchNorm2d.forward does `num_batches_tracked.add_(1)` per module: 68 one-element kernels per training step of the height
+# model, each costing a launch and ~40 us of host dispatch in a step that is bound by exactly that.  Training-mode BatchNorms
+# (libsrbh's here, the stock-op ones in encoders.bn_act) note their counter; the outermost forward adds 1 to all of them with a
+# single multi-tensor op.  The counters are exact whenever a forward has returned (state_dict / checkpoints see no difference).
+_NBT = {"pending": [], "depth": 0}
+
+
+def note_batch(bn):
+    _NBT["pending"].append(bn.num_batches_tracked)
+
+
+def flush_batches(force=False):
+    if _NBT["pending"] and (force or _NBT["depth"] == 0):
+        with torch.no_grad():
+            torch._foreach_add_(_NBT["pending"], 1)
+        _NBT["pending"] = []
+
+
+class defer_batch_counters:
+    """context of an outer forward: inner modules do not flush, the outermost exit does (once)"""
+
+    def __enter__(self):
+        _NBT["depth"] += 1
+
+    def __exit__(self, *exc):
+        _NBT["depth"] -= 1
+        flush_batches()
+        return False
 
 
 def bn_add_relu(a, sa, ha, idt, si=None, hi=None):
@@ -362,10 +394,13 @@ def run_blocks(blocks, inputs):
     """Run a chain of BasicBlocks on the channel concat of `inputs` ((B,C,H,W) tensors)."""
     if _needs_grad(blocks, inputs):
         from . import hrfuse_autograd as AG
-        return AG.blocks_forward(blocks, inputs)
+        out = AG.blocks_forward(blocks, inputs)
+        flush_batches()
+        return out
     x = [to_nhwc(t) for t in inputs]
     for b in blocks:
         x = [b.forward_nhwc(x)]
+    flush_batches()
     return x[0]
 
 

@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 from torch import nn
 
-from . import _lib
+from . import _lib, wcache
 from . import hrfuse as H
 
 
@@ -24,7 +24,7 @@ class _PackedGrad:
         self.w = None
 
     def get(self, weight, h16=False):
-        key = (weight._version, weight.data_ptr(), bool(h16))
+        key = (weight._version, weight.data_ptr(), bool(h16), wcache.gen(weight))
         if key != self.key:
             L = _lib.lib()
             cout, cin, ks, _ = weight.shape
@@ -93,7 +93,10 @@ def conv_wgrad(srcs, pre, g, cout, ks):
     a.dw = dw.data_ptr()
     ws = torch.empty(L.srbh_hwgrad_ws_bytes(cout, c0 + c1, ks) // 4, dtype=torch.float32, device=x0.device)
     a.ws = ws.data_ptr()
-    _lib.check(L.srbh_hconv_wgrad_f32(C.byref(a), _lib.stream_ptr()), "hconv_wgrad_f32")
+    if H.head_h16():       # mixed precision: bf16 operands (like the data gradients), fp32 accumulation
+        _lib.check(L.srbh_hconv_wgrad_b16(C.byref(a), _lib.stream_ptr()), "hconv_wgrad_b16")
+    else:
+        _lib.check(L.srbh_hconv_wgrad_f32(C.byref(a), _lib.stream_ptr()), "hconv_wgrad_f32")
     return dw
 
 

@@ -18,6 +18,13 @@ from .hrfuse import HRfeature, HRfuse_residual
 
 __all__ = ["SRRegress_Cls_feature"]
 
+import os as _os
+
+# encoder / decoders on a side stream next to the HR head (see _forward_two_streams): "auto" (default) = when no graph is recorded
+# (inference: measured +12 % on the tiled-predict path; the training step is bound by the host's op dispatch and gains nothing),
+# "1" = always, "0" = never
+SIDE_STREAM = _os.environ.get("SRBH_SIDE_STREAM", "auto")
+
 
 class SRRegress_Cls_feature(torch.nn.Module):
     def __init__(self, encoder_name="resnet50", encoder_weights="imagenet", encoder_depth=5, in_channels=7, classes=1,
@@ -47,6 +54,12 @@ class SRRegress_Cls_feature(torch.nn.Module):
     def forward(self, x, super_fea):
         """x: (B,in_channels,64,64) Sentinel-2+1 tile; super_fea: (B,super_in,256,256) RRDBNet.forward_feature output.
         Order of ops as upstream (mymodels.py:270-293)."""
+        with H.defer_batch_counters():     # one fused num_batches_tracked increment for all training-mode BatchNorms
+            return self._forward_impl(x, super_fea)
+
+    def _forward_impl(self, x, super_fea):
+        if x.is_cuda and (SIDE_STREAM == "1" or (SIDE_STREAM == "auto" and not torch.is_grad_enabled())):
+            return self._forward_two_streams(x, super_fea)
         encode_fea = self.encoder(x)
         super_fea = self.hrfeat(super_fea)
         height_fea = self.decoder1(*encode_fea)
@@ -55,6 +68,33 @@ class SRRegress_Cls_feature(torch.nn.Module):
         height = self.reg(height_fea, super_fea)
         build = self.decoder2(*encode_fea)
         build = self.seg(build, super_fea)
+        if self.isaggre:
+            return height, build, height_aggre
+        return height, build
+
+    def _forward_two_streams(self, x, super_fea):
+        """Same ops, two HIP streams: the EfficientNet encoder and the two U-Net decoders are ~500 small stock-op launches at
+        64x64 and below (dispatch-latency bound, a few CUs each), the 256x256 HR head is a handful of chip-filling kernels;
+        they do not depend on each other until `reg` / `seg` need the decoder outputs.  Autograd replays each op's backward on the
+        stream its forward ran on, so the backward overlaps the same way."""
+        cur = torch.cuda.current_stream(x.device)
+        side = self.__dict__.get("_side_stream")
+        if side is None or side.device != x.device:
+            side = torch.cuda.Stream(device=x.device)
+            self.__dict__["_side_stream"] = side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            encode_fea = self.encoder(x)
+            height_fea = self.decoder1(*encode_fea)
+            build_fea = self.decoder2(*encode_fea)
+            height_aggre = self._aggre(height_fea) if self.isaggre else None
+        super_fea = self.hrfeat(super_fea)
+        cur.wait_stream(side)
+        for t in (height_fea, build_fea, height_aggre):      # produced on `side`, consumed on `cur`: keep the allocator from recycling early
+            if t is not None:
+                t.record_stream(cur)
+        height = self.reg(height_fea, super_fea)
+        build = self.seg(build_fea, super_fea)
         if self.isaggre:
             return height, build, height_aggre
         return height, build

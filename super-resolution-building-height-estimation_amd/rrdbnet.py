@@ -16,7 +16,7 @@ from collections import OrderedDict
 import torch
 from torch import nn
 
-from . import _lib
+from . import _lib, wcache
 
 __all__ = ["default_init_weights", "make_layer", "pixel_unshuffle", "ResidualDenseBlock", "RRDB", "RRDBNet",
            "RealESRGAN"]
@@ -122,9 +122,9 @@ class RRDBNet(nn.Module):
     def _weights_key(self):
         ver, ptr = 0, 0
         for p in self.parameters():
-            ver += p._version
+            ver += p._version + getattr(p, "_srbh_gen", 0)      # (_srbh_gen: fused optimizers do not bump _version, see wcache.py)
             ptr ^= p.data_ptr()
-        return (ver, ptr)
+        return (ver, ptr, wcache.gen())
 
     def _apply(self, fn, *a, **kw):
         self._packed = None

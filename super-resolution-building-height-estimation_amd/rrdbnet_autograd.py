@@ -25,7 +25,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, wcache
 from . import hrfuse as H
 
 __all__ = ["rrdbnet_apply"]
@@ -40,7 +40,7 @@ class _Packs:
 
     def get(self, conv):
         w = conv.weight
-        key = (w._version, w.data_ptr(), conv.bias._version, conv.bias.data_ptr())
+        key = (w._version, w.data_ptr(), conv.bias._version, conv.bias.data_ptr(), wcache.gen(w, conv.bias))
         if key != self.key:
             L = _lib.lib()
             cout, cin, ks, _ = w.shape

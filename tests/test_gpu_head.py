@@ -36,6 +36,23 @@ def gold(golden_dir, name):
     return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, name + ".npz")).items()}
 
 
+def test_packed_weights_follow_a_fused_optimizer():
+    """a fused Adam step does not bump `weight._version`; the pack cache must still repack (wcache.py)"""
+    from srbh_amd import hrfuse as H
+    conv = torch.nn.Conv2d(16, 16, 3, 1, 1, bias=True).to(DEV)
+    x = torch.randn(1, 16, 12, 20, device=DEV)
+    pk = H._PackedConv()
+    opt = torch.optim.Adam(conv.parameters(), lr=0.05, fused=True)
+    for _ in range(2):
+        with torch.no_grad():
+            got, _ = H.hconv([H.to_nhwc(x)], conv, pk)
+            want = torch.nn.functional.conv2d(x, conv.weight, conv.bias, 1, 1)
+        assert O.rel_l2(got.cpu(), want.cpu()) <= 2e-5
+        for p in conv.parameters():
+            p.grad = torch.ones_like(p)
+        opt.step()
+
+
 def test_pixelshuffle_fold_bit_exact():
     """Upsampler with a channel-identity centre tap: the output must be the exact PixelShuffle gather."""
     from srbh_amd.hrfuse import Upsampler

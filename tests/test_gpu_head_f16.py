@@ -58,6 +58,42 @@ def test_h16_conv_equals_conv_of_rounded_operands(c0, c1, cout, ks, ps2, hw):
     assert O.rel_l2(got.cpu(), want) <= TOL_KERNEL
 
 
+def b16(t):
+    return t.bfloat16().double()
+
+
+@pytest.mark.parametrize("c0,c1,cout,ks,pre,hw", [(16, 0, 16, 3, True, (24, 70)), (64, 16, 16, 3, False, (17, 64)), (16, 0, 32, 3, True, (8, 130)),
+                                                   (80, 0, 16, 1, False, (9, 66)), (24, 0, 16, 3, False, (16, 16)), (16, 0, 7, 3, False, (16, 16))])
+def test_b16_wgrad_equals_wgrad_of_rounded_operands(c0, c1, cout, ks, pre, hw):
+    """srbh_hconv_wgrad_b16: exactly the weight gradient of the bf16-rounded (transformed input, dY) pair, fp32-accumulated
+    (<= 5e-6 against float64 on the same rounded values); ragged tile edges, the concat, the folded BN+ReLU, a half-filled
+    16-channel chunk (cin 24), and the fp32 fallback for a 7-channel output (then: no rounding at all)."""
+    from srbh_amd import hrfuse as H
+    from srbh_amd import hrfuse_autograd as AG
+    Hh, Ww = hw
+    x0, x1 = rnd((2, c0, Hh, Ww), 15), (rnd((2, c1, Hh, Ww), 16) if c1 else None)
+    dy = rnd((2, cout, Hh, Ww), 17) * 1e-6            # per-pixel gradients of a mean loss: below fp16's normal range
+    # power-of-two scales: x*scale is exact, so the kernel's fused multiply-add and torch's mul-then-add round identically
+    # (a 1-ulp fp32 difference would flip the bf16 rounding of a few inputs: a 2^-9 error each, 1e-5 on the sum)
+    scale, shift = 2.0 ** torch.randint(-1, 2, (c0,), generator=torch.Generator().manual_seed(7)).float(), rnd((c0,), 8, -0.2, 0.2)
+    a = torch.relu(x0 * scale[None, :, None, None] + shift[None, :, None, None]) if pre else x0
+    xin = torch.cat([a] + ([x1] if c1 else []), 1)
+    rx, rg = (b16, b16) if cout % 16 == 0 else (lambda t: t.double(), lambda t: t.double())
+    w = torch.zeros(cout, c0 + c1, ks, ks, dtype=torch.float64, requires_grad=True)
+    F.conv2d(rx(xin), w, None, 1, ks // 2).backward(rg(dy))
+    H.set_head_precision("f16")
+    try:
+        srcs = [H.to_nhwc(x0.to(DEV))] + ([H.to_nhwc(x1.to(DEV))] if c1 else [])
+        got = AG.conv_wgrad(srcs, (scale.to(DEV), shift.to(DEV), True) if pre else None, H.to_nhwc(dy.to(DEV)), cout, ks)
+    finally:
+        H.set_head_precision("auto")
+    assert O.rel_l2(got.cpu().double(), w.grad) <= TOL_KERNEL
+    # and the rounding itself stays at bf16's level against the unrounded gradient
+    w2 = torch.zeros_like(w, requires_grad=True)
+    F.conv2d(xin.double(), w2, None, 1, ks // 2).backward(dy.double())
+    assert O.rel_l2(got.cpu().double(), w2.grad) <= 6e-3
+
+
 def test_default_inference_head_within_north_star_tolerance(golden_dir):
     """HRfeature and both HRfuse_residual heads in eval mode under no_grad (-> fp16 operands by default) against the
     fixtures produced by the imported reference."""

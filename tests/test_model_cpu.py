@@ -214,3 +214,24 @@ def test_grad_reducer_overlapped_buckets_gloo_world2():
                     assert got is None
                 else:
                     assert torch.allclose(torch.from_numpy(got), w, rtol=1e-5, atol=1e-7), step
+
+
+def test_weight_pack_caches_see_fused_optimizer_steps():
+    """torch.optim.Adam(fused=True) updates parameters WITHOUT bumping their version counters (torch 2.10), so a packed-weight
+    cache keyed on `_version` alone would keep convolving with stale weights (caught on the GPU as a training run whose loss fell
+    3x slower).  wcache stamps the parameters of any optimizer that steps; only those (a frozen network keeps its packs)."""
+    from srbh_amd import wcache
+    w = torch.nn.Parameter(torch.randn(4, 4))
+    frozen = torch.nn.Parameter(torch.randn(4, 4))
+    for fused in (False, True):
+        opt = torch.optim.Adam([w], lr=1e-2, fused=fused)
+        w.grad = torch.ones_like(w)
+        before, ver, val = wcache.gen(w), w._version, w.detach().clone()
+        opt.step()
+        assert not torch.equal(val, w.detach())
+        assert wcache.gen(w) != before, fused                     # the cache key moved ...
+        assert (ver, before) != (w._version, wcache.gen(w))
+    assert wcache.gen(frozen) == wcache.gen(torch.nn.Parameter(torch.zeros(1)))   # ... and nobody else's did
+    k = wcache.gen(frozen)
+    wcache.invalidate_weight_caches()
+    assert wcache.gen(frozen) != k
