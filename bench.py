@@ -194,11 +194,16 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
     from srbh_amd.harness import TrainStep, synthetic_batch, train_epoch
     sd, net_hr, net = _make_nets(args, dev, True)
     sync_bn = os.environ.get("SRBH_SYNC_BN", "0") == "1"        # default: per-rank BatchNorm statistics
-    use_graph = world == 1 and os.environ.get("SRBH_TRAIN_GRAPH", "0") == "1" and not epoch_tiles   # one HIP graph per step (measured: no faster than eager launches on ROCm 7.2)
+    # one GPU, fixed batch: the whole step replayed as ONE HIP graph (47.5 ms; eager launches 53.3 ms -- the ~1 700 launches of a
+    # step are host-bound in the stock-op encoder / decoders).  The fixed batch lives in the graph's static input buffers, as an
+    # in-place loader would leave it (the eager path does not copy its fixed batch either).  SRBH_TRAIN_GRAPH=0: eager.
+    use_graph = world == 1 and os.environ.get("SRBH_TRAIN_GRAPH", "1") == "1" and not epoch_tiles
     ts = TrainStep(net_hr, net, dev, world=world, sync_bn=sync_bn, timing=True, status_every=0, graph=use_graph)
     fixed = synthetic_batch(batch, 1337 + rank, dev)
     for _ in range(max(warmup, 5 if use_graph else (2 if world > 1 else 1))):          # (world > 1: step 1 records the bucket plan; graph: 3 eager steps, then the capture)
         ts(fixed)
+    if use_graph:
+        fixed = ts.static_batch()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -483,7 +488,8 @@ def main():
     tb = args.batch if args.batch != 32 else 64
     pb = args.batch if args.batch != 32 else 128
     if args.workload == "train":
-        line = bench_train(args, rank, world, dev, dist, args.steps, args.warmup, batch=tb)
+        line = bench_train(args, rank, world, dev, dist, args.steps, args.warmup, batch=tb, with_kernels=not args.no_extras,
+                           with_cpu=not (args.no_extras or args.no_cpu_baseline))
     elif args.workload == "epoch":
         line = bench_train(args, rank, world, dev, dist, 0, args.warmup, batch=tb, epoch_tiles=31500, with_kernels=False)
     elif args.workload == "predict":

@@ -8,9 +8,13 @@ row 8f-3, not yet kernels).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
+
+from . import wcache
 
 HIR = (0, 3, 12, 21, 30, 60, 90, 256)                       # train.py:55
 # hierweight(bh_stats_globe, HIR) as probed on the reference data; synthetic labels reuse it
@@ -272,10 +276,23 @@ class TrainStep:
 
     def _graph_step(self, batch):
         if self._graph is None:
-            self._static = tuple(t.clone() for t in batch)
+            # static inputs: the floating-point tensors are views of ONE flat buffer, so that a new batch reaches them with a
+            # single `cat` launch (+ one for the int64 labels).  Three or more eager launches between two graph launches cost
+            # 5.5 ms per step on ROCm 7.2 (measured: replay only 47.3 ms, +1 or 2 kernels 47.5, +3..6 kernels 52.9 -- whatever
+            # their size; 64 us on their own), so the staging must stay at two.
+            if getattr(self, "_static", None) is None:
+                fl = [t for t in batch if t.dtype == torch.float32]
+                flat = torch.empty(sum(t.numel() for t in fl), dtype=torch.float32, device=fl[0].device)
+                views, o = [], 0
+                for t in batch:
+                    if t.dtype == torch.float32:
+                        views.append(flat[o:o + t.numel()].view(t.shape))
+                        o += t.numel()
+                    else:
+                        views.append(torch.empty_like(t))
+                self._static, self._static_flat = tuple(views), flat
+            self._stage(batch)
             if self.steps < 3:                       # eager warm-up (lazy packs, MIOpen kernels, Adam state) before the capture
-                for dst, src in zip(self._static, batch):
-                    dst.copy_(src)
                 return self._step(self._static)
             self.net_hr.check_status()
             self.optimizer.zero_grad(set_to_none=True)
@@ -283,14 +300,24 @@ class TrainStep:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._static_out = self._step(self._static, in_graph=True)
-        for dst, src in zip(self._static, batch):
-            if dst.data_ptr() != src.data_ptr():
-                dst.copy_(src)
+        self._stage(batch)
         self._graph.replay()
         self.steps += 1
         if self.status_every and self.steps % self.status_every == 0 and hasattr(self.net_hr, "check_status"):
             self.net_hr.check_status()
         return self._static_out
+
+    def _stage(self, batch):
+        if all(d.data_ptr() == s.data_ptr() for d, s in zip(self._static, batch)):
+            return                                   # the caller filled `static_batch()` in place
+        torch.cat([t.reshape(-1) for t in batch if t.dtype == torch.float32], out=self._static_flat)
+        for d, s in zip(self._static, batch):
+            if d.dtype != torch.float32:
+                torch.add(s, 0, out=d)
+
+    def static_batch(self):
+        """graph mode: the tensors the captured step reads (None before the first call); a loader may fill them in place"""
+        return getattr(self, "_static", None)
 
     def _step(self, batch, in_graph=False):
         lr, height, height_aggre, build, weight, weight_aggre = batch
@@ -354,6 +381,46 @@ def train_epoch(ts, n_tiles, batch, rank, world, device, seed=1337, max_steps=No
     return steps, steps * batch * world, loss
 
 
+PREDICT_GRAPH = os.environ.get("SRBH_PREDICT_GRAPH", "1") == "1"
+
+
+class _PredictGraph:
+    """One full batch of the tiled prediction -- RRDBNet features, encoder / decoders, HR head -- captured into a HIP graph: the
+    ~700 launches of a batch (most of them the stock-op encoder's, a few microseconds of GPU work each) are issued by one
+    hipGraphLaunch instead of by the Python host.  Bound to the networks' weights at capture time (the packed-weight buffers
+    are baked into the graph): `key` changes when any parameter does, and predict_tiles re-captures."""
+
+    def __init__(self, net_hr, model, batch, dev, chans):
+        self.key = _PredictGraph.weights_key(net_hr, model, batch, dev)
+        self.x = torch.zeros((batch, chans, 64, 64), device=dev)
+        side = torch.cuda.Stream(device=dev)          # warm-up off the capture (lazy packs, workspaces, MIOpen's solver search)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                model(self.x, net_hr.forward_feature(self.x[:, :3]))
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = model(self.x, net_hr.forward_feature(self.x[:, :3]))
+
+    @staticmethod
+    def weights_key(net_hr, model, batch, dev):
+        k = 0
+        for m in (net_hr, model):
+            for t in list(m.parameters()) + list(m.buffers()):
+                k += t._version + getattr(t, "_srbh_gen", 0) + (t.data_ptr() & 0xffffffff)
+        from . import hrfuse as _H
+        return (k, batch, str(dev), wcache.gen(), _H._HEAD_PRECISION["mode"])
+
+    def __call__(self, x_src, k):
+        self.x[:k].copy_(x_src, non_blocking=True)
+        if k < self.x.shape[0]:
+            self.x[k:].zero_()
+        self.graph.replay()
+        return self.out
+
+
 @torch.no_grad()
 def predict_tiles(net_hr, model, tiles, posall, mosaic, batch=32, rank=0, world=1, pad_to=None):
     """predict_whole_image_grid's inner loop (predict_realesanet_feature_globe.py:167-185) for this rank's shard of a
@@ -366,10 +433,20 @@ def predict_tiles(net_hr, model, tiles, posall, mosaic, batch=32, rank=0, world=
     net_hr.eval()
     lo, hi = shard_range(tiles.shape[0], rank, world)
     dev = mosaic.res_height.device
+    pg = None
+    if PREDICT_GRAPH and dev.type == "cuda" and hi - lo >= batch and hasattr(net_hr, "forward_feature"):
+        pg = model.__dict__.get("_srbh_predict_graph")
+        if pg is None or pg.key != _PredictGraph.weights_key(net_hr, model, batch, dev):
+            pg = model.__dict__["_srbh_predict_graph"] = None      # (drop the old graph's memory pool first)
+            pg = model.__dict__["_srbh_predict_graph"] = _PredictGraph(net_hr, model, batch, dev, tiles.shape[1])
     for s in range(lo, hi, batch):
         e = min(s + batch, hi)
-        x = tiles[s:e].to(dev, non_blocking=True)
         k = e - s
+        if pg is not None and k == batch:
+            out = pg(tiles[s:e], k)
+            mosaic.add(out[0], out[1], posall[s:e])
+            continue
+        x = tiles[s:e].to(dev, non_blocking=True)
         if k < batch:
             # ragged tail: run a padded batch (eval mode: tiles are independent) instead of a new tensor shape, for which the
             # stock-op encoder would first search / compile kernels (0.5 s per new shape, more than a small city's work).

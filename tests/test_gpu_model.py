@@ -188,3 +188,46 @@ def test_predict_path_sharded_mosaic():
     assert int(dh.max()) <= 1 and float((dh > 0).float().mean()) < 1e-3
     assert float((c1 != c2).float().mean()) < 1e-3
     assert int(one.res_weight.max()) == 2          # the overlapping window really overlapped
+
+
+def test_predict_graph_replay_equals_eager_launches(monkeypatch):
+    """predict_tiles replays one captured HIP graph per full batch (harness._PredictGraph); same kernels, same order: the integer
+    mosaic must be identical to the eagerly launched path, the ragged tail goes through the eager path, and a parameter
+    update (fused optimizer: no version bump) must trigger a re-capture instead of replaying stale weights."""
+    from srbh_amd import harness
+    from srbh_amd.mosaic import Mosaic
+    from srbh_amd.rrdbnet import RRDBNet
+    net_hr = RRDBNet(3, 3, num_block=1)
+    net_hr.load_state_dict(synth.rrdbnet_state_dict(num_block=1, seed=4, mode="stress"))
+    net_hr = net_hr.to(DEV).eval()
+    model = make_model(seed=12, isaggre=False).to(DEV).eval()
+    tiles = synth.tiles(10, 8, 64, seed=23, kind="grid").to(DEV)
+    pos = [[(i % 4) * 48, (i // 4) * 48, 64, 64] for i in range(10)]
+    Hh, Ww = 4 * (48 * 2 + 64), 4 * (48 * 3 + 64)
+
+    def run(graph):
+        monkeypatch.setattr(harness, "PREDICT_GRAPH", graph)
+        m = Mosaic(Hh, Ww, 7, DEV)
+        assert harness.predict_tiles(net_hr, model, tiles, pos, m, batch=4) == 10      # 2 full batches + a tail of 2
+        return m
+
+    def same(a, b):
+        """the forward is not bit-reproducible from run to run (atomics in the pooled reductions: 5e-5 between two eager runs),
+        so, as in test_predict_path_sharded_mosaic: final rasters equal up to 1 LSB on a vanishing fraction of the pixels"""
+        (h1, c1), (h2, c2) = a.finalize(), b.finalize()
+        dh = (h1.int() - h2.int()).abs()
+        return (torch.equal(a.res_weight, b.res_weight) and int(dh.max()) <= 1 and float((dh > 0).float().mean()) < 1e-3
+                and float((c1 != c2).float().mean()) < 1e-3)
+
+    eager, replay = run(False), run(True)
+    pg = model.__dict__["_srbh_predict_graph"]
+    assert pg is not None and same(eager, replay)
+    again = run(True)
+    assert model.__dict__["_srbh_predict_graph"] is pg and same(again, replay)     # cached graph reused
+    opt = torch.optim.SGD(model.reg.parameters(), lr=0.5)
+    for p in model.reg.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    moved = run(True)
+    assert model.__dict__["_srbh_predict_graph"] is not pg
+    assert same(moved, run(False)) and not same(moved, replay)

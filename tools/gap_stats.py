@@ -9,7 +9,7 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-bounds = [i for i, r in enumerate(rows) if "ptrunk" in r[2] and "_kernel" in r[2] and (i == 0 or "ptrunk" not in rows[i - 1][2])]
+bounds = [i for i, r in enumerate(rows) if "conv_first_kernel" in r[2]]           # exactly one per RRDBNet forward = per step
 start = bounds[-n - 1] if len(bounds) > n else bounds[0]
 end = bounds[-1]
 sel = rows[start:end]

@@ -1,6 +1,6 @@
 """developer aid: per-kernel time of the LAST n steps of a bench run from a rocprofv3 --kernel-trace csv (the first steps
 carry MIOpen's solver search, which runs every applicable kernel incl. the naive ones).  A step boundary = a launch of
-ptrunk_kernel that follows a non-ptrunk kernel.   usage: steady_stats.py <dir with *kernel_trace.csv> <n_steps> [top] [calls]   (calls: sort by launch count)"""
+conv_first_kernel (the RRDBNet forward's first launch, one per step).   usage: steady_stats.py <dir with *kernel_trace.csv> <n_steps> [top] [calls]   (calls: sort by launch count)"""
 import csv, glob, sys, collections
 d, n = sys.argv[1], int(sys.argv[2])
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
@@ -9,7 +9,7 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-bounds = [i for i, r in enumerate(rows) if "ptrunk" in r[2] and "_kernel" in r[2] and (i == 0 or "ptrunk" not in rows[i - 1][2])]
+bounds = [i for i, r in enumerate(rows) if "conv_first_kernel" in r[2]]           # exactly one per RRDBNet forward = per step
 start = bounds[-n - 1] if len(bounds) > n else bounds[0]
 end = bounds[-1]
 sel = rows[start:end]
@@ -24,3 +24,20 @@ print("steps %d | kernel time %.2f ms/step | wall %.2f ms/step | %d launches/ste
 bycalls = len(sys.argv) > 4
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0 if bycalls else 1])[:top]:
     print("%7.3f ms/step %5.1f %% %6d calls/step  %s" % (v[1] / steps / 1e6, 100.0 * v[1] / tot, v[0] // steps, k))
+GROUPS = (("RRDBNet (trunk, first/tail convs)", ("ptrunk", "ptail", "conv_first", "rrdb", "poison", "upconv", "tail_")),
+          ("head (libsrbh hconv / hwgrad / BN / elementwise)", ("hconv", "hwgrad", "hpack", "bn_", "relu_mask", "nchw_to_nhwc", "nhwc_to_nchw", "ps2_", "add_inplace", "aggregate", "chan_sum", "bias_grad")),
+          ("encoder / decoders: libsrbh depthwise + SE", ("dw_fwd", "dw_bwd", "dw_reduce", "se_hidden", "se_gate", "affine_act")),
+          ("optimizer (multi_tensor_apply)", ("multi_tensor_apply",)),
+          ("losses (libsrbh)", ("wmse_", "cedice_")))
+gs = collections.OrderedDict((g[0], [0, 0]) for g in GROUPS)
+gs["encoder / decoders / losses: stock ops (MIOpen, rocBLAS, ATen)"] = [0, 0]
+for k, v in agg.items():
+    for name, pats in GROUPS:
+        if any(p in k for p in pats):
+            gs[name][0] += v[0]; gs[name][1] += v[1]
+            break
+    else:
+        gs["encoder / decoders / losses: stock ops (MIOpen, rocBLAS, ATen)"][0] += v[0]; gs["encoder / decoders / losses: stock ops (MIOpen, rocBLAS, ATen)"][1] += v[1]
+print("by group:")
+for name, v in gs.items():
+    print("%7.3f ms/step %5.1f %% %6d launches/step  %s" % (v[1] / steps / 1e6, 100.0 * v[1] / tot, v[0] // steps, name))
