@@ -194,10 +194,9 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
     from srbh_amd.harness import TrainStep, synthetic_batch, train_epoch
     sd, net_hr, net = _make_nets(args, dev, True)
     sync_bn = os.environ.get("SRBH_SYNC_BN", "0") == "1"        # default: per-rank BatchNorm statistics
-    # one GPU, fixed batch: the whole step replayed as ONE HIP graph (47.5 ms; eager launches 53.3 ms -- the ~1 700 launches of a
-    # step are host-bound in the stock-op encoder / decoders).  The fixed batch lives in the graph's static input buffers, as an
-    # in-place loader would leave it (the eager path does not copy its fixed batch either).  SRBH_TRAIN_GRAPH=0: eager.
-    use_graph = world == 1 and os.environ.get("SRBH_TRAIN_GRAPH", "1") == "1" and not epoch_tiles
+    # SRBH_TRAIN_GRAPH=1 (one GPU, fixed batch): the whole step replayed as ONE HIP graph.  Measured equal to eager launches
+    # (53.0 ms both): with the fused optimizer the host keeps up, the step is bound by its ~1 700 kernels and the gaps between them.
+    use_graph = world == 1 and os.environ.get("SRBH_TRAIN_GRAPH", "0") == "1" and not epoch_tiles
     ts = TrainStep(net_hr, net, dev, world=world, sync_bn=sync_bn, timing=True, status_every=0, graph=use_graph)
     fixed = synthetic_batch(batch, 1337 + rank, dev)
     for _ in range(max(warmup, 5 if use_graph else (2 if world > 1 else 1))):          # (world > 1: step 1 records the bucket plan; graph: 3 eager steps, then the capture)

@@ -17,6 +17,22 @@ int hip_fail(hipError_t e, const char* what) {
     return (int)e;
 }
 
+__global__ void zero_words_kernel(unsigned* __restrict__ p, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = 0u;
+}
+
+int zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (!bytes) return SRBH_OK;
+    if (!p || (bytes & 3) || ((uintptr_t)p & 3)) { set_error("zero_async: bad buffer"); return SRBH_ERR_ARG; }
+    const size_t n = bytes / 4;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(zero_words_kernel, dim3(blocks), dim3(256), 0, st, (unsigned*)p, n);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
 }  // namespace srbh
 
 using namespace srbh;

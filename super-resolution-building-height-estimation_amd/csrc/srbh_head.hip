@@ -75,7 +75,7 @@ struct HParams {
     int ps2;
     float* out;
     double* stats;                                     // [NSLOT][2][cout] or nullptr
-    int tiles_x, tiles_per_img;
+    int tiles_x, tiles_per_img, ntiles, tiles_per_xcd;
     int ld0, ld1, out_ld, out_coff;                    // pixel strides (floats) of src0 / src1 / out, channel offset of out
     int post_lrelu;
     const float* res1; int res1_ld; float res1_scale;  // y = y*res1_scale + res1 ; then y = y*res2_scale + res2
@@ -104,7 +104,11 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kk = lane >> 4;
-    const int t = blockIdx.x;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  Consecutive tiles
+    // (x-neighbours, then the next tile row) share halo rows -- 55 % more input rows than a tile owns at 4-row tiles -- so every
+    // XCD walks its own contiguous run of tiles and the halo re-reads hit that XCD's L2 instead of going out to the fabric.
+    const int t = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
+    if (t >= p.ntiles) return;
     const int img = t / p.tiles_per_img;
     const int trem = t - img * p.tiles_per_img;
     const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
@@ -519,7 +523,9 @@ int launch_hconv(HParams& p, int B, int H, int W, hipStream_t st) {
                               : (in_dw(RPW) + KS * KS * 4 * NOB * 64) * 4;
     p.tiles_x = (W + HT_W - 1) / HT_W;
     p.tiles_per_img = p.tiles_x * ((H + 4 * RPW - 1) / (4 * RPW));
-    const int nblocks = p.tiles_per_img * B;
+    p.ntiles = p.tiles_per_img * B;
+    p.tiles_per_xcd = (p.ntiles + 7) / 8;
+    const int nblocks = p.tiles_per_xcd * 8;
     if (LDS_B > 65536) {
         SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hconv_f32_kernel<NOB, KS, RPW, OPT>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)));
@@ -604,7 +610,7 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
     p.B = a->B; p.H = a->H; p.W = a->W; p.ps2 = a->pixelshuffle2;
     p.out = a->out; p.stats = a->stats;
     hipStream_t st = (hipStream_t)stream;
-    if (a->stats) SRBH_HIP(hipMemsetAsync(a->stats, 0, srbh_bn_stats_bytes(p.cout), st));
+    if (a->stats) { if (int rc = zero_async(a->stats, srbh_bn_stats_bytes(p.cout), st)) return rc; }
     const int B = a->B, H = a->H, W = a->W;
     // 16-bit operand forms: 4-row tiles (12.7 KiB staged tile; measured level with the 8-row form on single-chunk convs and
     // 10-25 % ahead on the multi-chunk ones)

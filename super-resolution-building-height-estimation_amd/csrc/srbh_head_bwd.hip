@@ -28,7 +28,7 @@ struct WGParams {
     float* dw;            // OIHW fp32 [cout_total][cin][KS][KS]
     float* ws;            // [gridDim.x][nob][nchunk][TAPS*256] per-workgroup partial sums (hwgrad_reduce_kernel adds them)
     int B, H, W;
-    int tiles_x, tiles_per_img, ntiles;
+    int tiles_x, tiles_per_img, ntiles, tiles_per_xcd;
     int ld0, ld1;         // pixel strides (floats) of src0 / src1
 };
 
@@ -53,7 +53,10 @@ __global__ __launch_bounds__(256) void hwgrad_f32_kernel(const WGParams p) {
         floatx4 acc[TAPS];
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp) acc[tp] = floatx4{0.f, 0.f, 0.f, 0.f};
-        for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+        // XCD-aware walk (see hconv_f32_kernel): XCD x = blockIdx % 8 owns the contiguous tiles [x*per_xcd, (x+1)*per_xcd), its
+        // gridDim/8 workgroups sweep them side by side, so the tiles' shared halo rows are re-read from that XCD's L2
+        const int t_end = min((int)(blockIdx.x & 7) * p.tiles_per_xcd + p.tiles_per_xcd, p.ntiles);
+        for (int t = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3); t < t_end; t += gridDim.x >> 3) {
             const int img = t / p.tiles_per_img;
             const int trem = t - img * p.tiles_per_img;
             const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
@@ -252,12 +255,16 @@ __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
         floatx4 acc[TAPS];
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp) acc[tp] = floatx4{0.f, 0.f, 0.f, 0.f};
-        for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+        // XCD-aware walk (see hconv_f32_kernel): XCD x = blockIdx % 8 owns the contiguous tiles [x*per_xcd, (x+1)*per_xcd), its
+        // gridDim/8 workgroups sweep them side by side, so the tiles' shared halo rows are re-read from that XCD's L2
+        const int t_end = min((int)(blockIdx.x & 7) * p.tiles_per_xcd + p.tiles_per_xcd, p.ntiles);
+        for (int t = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3); t < t_end; t += gridDim.x >> 3) {
             const int img = t / p.tiles_per_img;
             const int trem = t - img * p.tiles_per_img;
             const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
             const int Y0 = ty * HT_H, X0 = tx * HT_W;
-            // ---- stage: every global load of the tile is issued before the first LDS store
+            // ---- stage: every global load of the tile is issued before the first LDS store.  (Issuing the NEXT tile's loads before this
+            // tile's MFMAs -- a software pipeline over the walk -- needs 281 registers, one workgroup per CU: 152 -> 232 us.)
             constexpr int NIX = (ROWS * QX * 4 + 255) / 256, NID = HT_H * 16 * 4 / 256;
             floatx4 lx[NIX][4], ld[NID][4];
 #pragma unroll
@@ -525,7 +532,8 @@ int wgrad_impl(const srbh_hwgrad_args* a, void* stream, bool b16, const char* wh
     hipStream_t st = (hipStream_t)stream;
     const int cin = a->c0 + a->c1;
     const int nob = (a->cout + 15) / 16;
-    const int gx = p.ntiles < 512 ? p.ntiles : 512;
+    const int gx = p.ntiles < 512 ? (p.ntiles + 7) / 8 * 8 : 512;          // (a multiple of 8: the same number of workgroups per XCD)
+    p.tiles_per_xcd = (p.ntiles + 7) / 8;
     // the bf16 form moves whole 4-channel groups with 16-byte loads and whole 16-channel output blocks; the few layers outside
     // that (the 1- and 7-channel output convs) keep the fp32 kernel
     const bool can16 = (a->c0 & 3) == 0 && (a->c1 & 3) == 0 && (p.ld0 & 3) == 0 && (a->c1 == 0 || (p.ld1 & 3) == 0) && (a->cout & 15) == 0 &&
@@ -594,7 +602,7 @@ extern "C" int srbh_bn_bwd_reduce(const float* g, const float* c, const float* m
     SRBH_REQUIRE(!c || (mean && invstd), "srbh_bn_bwd_reduce: c needs mean/invstd");
     SRBH_REQUIRE(!mask_scale || (c && mask_shift), "srbh_bn_bwd_reduce: mask needs c and mask_shift");
     hipStream_t st = (hipStream_t)stream;
-    SRBH_HIP(hipMemsetAsync(stats, 0, (size_t)NSLOT * 2 * C * sizeof(double), st));
+    if (int rc = zero_async(stats, (size_t)NSLOT * 2 * C * sizeof(double), st)) return rc;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(npix * C)), dim3(256), 2 * C * sizeof(float), st, g, c, mean,
                        invstd, mask_scale, mask_shift, npix, C, stats);
     SRBH_HIP(hipGetLastError());

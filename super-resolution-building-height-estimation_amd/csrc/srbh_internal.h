@@ -14,6 +14,10 @@ constexpr int TILE_W = 64;      // output columns per workgroup
 constexpr int TILE_H = 8;       // output rows per workgroup
 
 void set_error(const char* fmt, ...);
+// Stream-ordered zero fill of `bytes` (a multiple of 4) by a KERNEL.  Not hipMemsetAsync: captured into a HIP graph, a memset node is
+// not kept in order with the kernels of the previous replay of the same graph (srbh_ptrunk.hip, ptrunk_reset_kernel), and every
+// libsrbh call must stay correct inside back-to-back graph replays (harness.TrainStep(graph=True), predict_tiles).
+int zero_async(void* p, size_t bytes, hipStream_t st);
 int hip_fail(hipError_t e, const char* what);
 
 #define SRBH_HIP(call)                                         \

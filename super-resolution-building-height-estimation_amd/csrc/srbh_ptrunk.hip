@@ -1029,6 +1029,16 @@ static size_t table_bytes() { return ((size_t)MAX_BLOCKS * 15 * sizeof(PLayer) +
 static size_t prog_bytes(int B, int tpi) { return ((size_t)B * 2 * tpi * sizeof(int) + 255) & ~(size_t)255; }   // (x2: 4-row tiles of variant 2)
 
 size_t ptrunk_aux_bytes(int B, int tiles_per_img) { return table_bytes() + 2 * prog_bytes(B, tiles_per_img) + 256; }
+// The launch's progress counters, XCC words and error word are cleared by a KERNEL, not by hipMemsetAsync: inside a replayed HIP
+// graph the runtime does not keep memset nodes in stream order with the kernels of the PREVIOUS replay (measured: back-to-back
+// replays of a captured training step timed out in the halo exchange -- the next replay's memsets had zeroed the running launch's
+// progress counters; one replay at a time, or eager launches, never did).  A kernel node is ordered like any other launch.
+__global__ void ptrunk_reset_kernel(int* __restrict__ prog, int* __restrict__ xcc, int* __restrict__ err, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { prog[i] = 0; xcc[i] = 0; }
+    if (i == 0) *err = 0;
+}
+
 size_t ptrunk_err_offset(int B, int tiles_per_img) { return table_bytes() + prog_bytes(B, tiles_per_img); }
 
 // The layer table depends only on the packed-weight pointers and num_block: it is uploaded ONCE per (device, contents)
@@ -1107,9 +1117,8 @@ static int ptrunk2_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, f
     int* d_prog = (int*)(a + table_bytes());
     int* d_err = (int*)(a + ptrunk_err_offset(B, tpi8));
     int* d_xcc = (int*)(a + ptrunk_err_offset(B, tpi8) + 256);
-    SRBH_HIP(hipMemsetAsync(d_prog, 0, (size_t)B * tpi * sizeof(int), stream));
-    SRBH_HIP(hipMemsetAsync(d_err, 0, sizeof(int), stream));
-    SRBH_HIP(hipMemsetAsync(d_xcc, 0, (size_t)B * tpi * sizeof(int), stream));
+    hipLaunchKernelGGL(ptrunk_reset_kernel, dim3((B * tpi + 255) / 256), dim3(256), 0, stream, d_prog, d_xcc, d_err, B * tpi);
+    SRBH_HIP(hipGetLastError());
     const Act16Geo g = act16_geo(B, 6, H, W);
     const int imgs_per_launch = slots / tpi;
     for (int b0 = 0; b0 < B; b0 += imgs_per_launch) {
@@ -1223,10 +1232,9 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
     if (int rc = device_table(tab, &d_tab)) return rc;
     int* d_prog = (int*)(a + table_bytes());
     int* d_err = (int*)(a + ptrunk_err_offset(B, tpi));
-    SRBH_HIP(hipMemsetAsync(d_prog, 0, (size_t)B * tpi * sizeof(int) , stream));
-    SRBH_HIP(hipMemsetAsync(d_err, 0, sizeof(int), stream));
     int* d_xcc = (int*)(a + ptrunk_err_offset(B, tpi) + 256);
-    SRBH_HIP(hipMemsetAsync(d_xcc, 0, (size_t)B * tpi * sizeof(int), stream));
+    hipLaunchKernelGGL(ptrunk_reset_kernel, dim3((B * tpi + 255) / 256), dim3(256), 0, stream, d_prog, d_xcc, d_err, B * tpi);
+    SRBH_HIP(hipGetLastError());
     const Act16Geo g = act16_geo(B, 6, H, W);
     const int imgs_per_launch = ncu / tpi;
     for (int b0 = 0; b0 < B; b0 += imgs_per_launch) {

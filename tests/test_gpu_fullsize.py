@@ -96,3 +96,21 @@ def test_train_step_batch64_runs_and_learns():
     batch = synthetic_batch(64, 11, DEV)
     losses = [float(ts(batch)[0]) for _ in range(4)]
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+
+
+def test_graph_replays_back_to_back_at_full_size():
+    """TrainStep(graph=True) at the bench's size (23-block RRDBNet, B=64: two persistent trunk launches of 8 ms per step), replays
+    enqueued WITHOUT a synchronisation in between -- the host runs one replay ahead of the GPU.  This is the case that broke when
+    libsrbh cleared the trunk's progress counters / BatchNorm partial sums with hipMemsetAsync: inside a replayed graph those memset
+    nodes were not ordered behind the previous replay's kernels, the running trunk launch lost its counters and timed out (and the
+    graph looked 6 ms faster than it is).  All clears are kernels now; the trunk must report a clean status and the loss must fall."""
+    from srbh_amd.harness import TrainStep, synthetic_batch
+    net_hr = _feature_net(num_block=23, seed=2)
+    ts = TrainStep(net_hr, _model(9, True).to(DEV), DEV, graph=True, status_every=0)
+    batch = synthetic_batch(64, 11, DEV)
+    losses = [ts(batch)[0].clone() for _ in range(12)]          # 3 eager steps, the capture, 8 back-to-back replays
+    torch.cuda.synchronize()
+    assert ts._graph is not None
+    net_hr.check_status()
+    losses = [float(l) for l in losses]
+    assert all(l == l for l in losses) and losses[-1] < losses[3] < losses[0], losses
