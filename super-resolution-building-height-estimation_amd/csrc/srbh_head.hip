@@ -126,6 +126,17 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
 
     for (int c = 0; c < nchunk; ++c) {
         __syncthreads();
+        // ---- weights of this chunk (already in A-fragment order).  H16: 8 bytes per lane and (tap, ob), straight into registers --
+        // issued BEFORE the input loads: they are L2 hits that arrive during the staging (loaded after it, the first MFMA of every
+        // tile waited a full L2 round trip behind the barrier)
+        short4v wa[H16 ? TAPS : 1][H16 ? NOB : 1];
+        if constexpr (H16) {
+            const short4v* wp = (const short4v*)p.w + (long)c * (TAPS * NOB * 64) + lane;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) wa[tap][ob] = wp[(tap * NOB + ob) * 64];
+        }
         // ---- stage the input chunk: channel-major planes, transform + zero padding applied here.
         // Fast path (every 4-channel group is one aligned 16-byte load from src0 or src1): ALL global loads of the chunk
         // are issued before the first LDS store -- the one-load-per-iteration loop below exposes a full memory latency
@@ -133,46 +144,61 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
         constexpr int NIT = (ROWS * COLS * 4 + 255) / 256;
         const bool fast = vec0 && (p.c1 == 0 || vec1) && (cin & 3) == 0;
         if (fast) {
+            // Address arithmetic of the walk: unit u = tid + 256*it is pixel (tid >> 2) + 64*it of the staged window and channel
+            // group tid & 3 (the same for every iteration), so the thread forms ONE pointer to its channel group at the window's
+            // origin and then only adds 32-bit element offsets that advance by constants (no 64-bit multiply, no division by the
+            // window width per load: those quarter-rate integer ops were half of the kernel's VALU time).
             floatx4 ld[NIT];
-            int where[NIT];   // LDS dword offset of the unit's first channel plane entry, -1 = no unit
+            int loff[NIT];
+            const int cg = tid & 3;
+            const int ch = c * HC + cg * 4;
+            const bool chok = ch < cin, in0 = ch < p.c0;
+            const int ldp = in0 ? p.ld0 : p.ld1;
+            const float* tp = (in0 ? p.src0 + ch : p.src1 + (ch - p.c0)) + (((long)img * p.H + (Y0 - HALO)) * p.W + (X0 - HALO)) * ldp;
+            floatx4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+            bool relu_t = false;                                   // (a select, not max(a, -inf): a NaN-poisoned input must stay NaN)
+            if (in0 && chok) {
+                if (p.pre_scale) { psc = *(const floatx4*)(p.pre_scale + ch); psh = *(const floatx4*)(p.pre_shift + ch); }
+                relu_t = p.pre_relu != 0;
+            }
+            int col = tid >> 2, y = Y0 - HALO, x = X0 - HALO + col;
+            int voff = col * ldp, lo_px = col;                     // (r*W + col) * ld ; r*RS + col
+            const int vstep = 64 * ldp, vwrap = (p.W + 64 - COLS) * ldp;
+            unsigned okmask = 0;                                   // loaded units (the others are the zero padding: no transform)
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int u = tid + it * 256;
+                bool ok = chok && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                bool unit = true;
+                if ((it + 1) * 256 > ROWS * COLS * 4) unit = tid + it * 256 < ROWS * COLS * 4;
+                // (only the load here: the transform sits in the store loop below, so that all loads are in flight before the first use)
                 ld[it] = floatx4{0.f, 0.f, 0.f, 0.f};
-                where[it] = -1;
-                if (u < ROWS * COLS * 4) {
-                    const int cg = u & 3, pix = u >> 2;
-                    const int r = pix / COLS, col = pix - r * COLS;
-                    const int y = Y0 + r - HALO, x = X0 + col - HALO;
-                    const int ch = c * HC + cg * 4;
-                    where[it] = (cg << 16) | (r * RS + col);
-                    if (y >= 0 && y < p.H && x >= 0 && x < p.W && ch < cin) {
-                        const long pixi = ((long)img * p.H + y) * p.W + x;
-                        if (ch < p.c0) {
-                            floatx4 a = *(const floatx4*)(p.src0 + pixi * p.ld0 + ch);
-                            if (p.pre_scale) a = a * *(const floatx4*)(p.pre_scale + ch) + *(const floatx4*)(p.pre_shift + ch);
-                            if (p.pre_relu) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) a[j] = fmaxf(a[j], 0.f);
-                            }
-                            ld[it] = a;
-                        } else {
-                            ld[it] = *(const floatx4*)(p.src1 + pixi * p.ld1 + (ch - p.c0));
-                        }
-                    }
+                if (ok && unit) {
+                    ld[it] = *(const floatx4*)(tp + voff);
+                    okmask |= 1u << it;
                 }
+                if constexpr (H16) loff[it] = unit ? ((tid >> 2) + 64 * it) * 32 + ((cg ^ ((col >> 2) & 2)) << 3) : -1;   // = h16_off(r, col, cg, COLS)
+                else loff[it] = unit ? lo_px : -1;
+                const bool wrapped = col + 64 >= COLS;
+                col += wrapped ? 64 - COLS : 64;
+                x += wrapped ? 64 - COLS : 64;
+                y += wrapped ? 1 : 0;
+                voff += wrapped ? vwrap : vstep;
+                lo_px += wrapped ? RS + 64 - COLS : 64;
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                if (where[it] >= 0) {
-                    const int cg = where[it] >> 16, off = where[it] & 0xffff;
+                if (loff[it] >= 0) {
+                    if (okmask & (1u << it)) {
+                        ld[it] = ld[it] * psc + psh;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ld[it][j] = relu_t ? fmaxf(ld[it][j], 0.f) : ld[it][j];
+                    }
                     if constexpr (H16) {
-                        const int r = off / RS, col = off - r * RS;
                         const float t4[4] = {ld[it][0], ld[it][1], ld[it][2], ld[it][3]};
-                        *(short4v*)((char*)s_in + h16_off(r, col, cg, COLS)) = round4<OPT>(t4);
+                        *(short4v*)((char*)s_in + loff[it]) = round4<OPT>(t4);
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) s_in[plane_base<RPW>(cg * 4 + j) + off] = ld[it][j];
+                        for (int j = 0; j < 4; ++j) s_in[plane_base<RPW>(cg * 4 + j) + loff[it]] = ld[it][j];
                     }
                 }
             }
@@ -215,15 +241,7 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                 for (int j = 0; j < 4; ++j) s_in[plane_base<RPW>(cg * 4 + j) + r * RS + col] = v[j];
             }
         }
-        // ---- weights of this chunk (already in A-fragment order).  H16: 8 bytes per lane and (tap, ob), straight into registers
-        short4v wa[H16 ? TAPS : 1][H16 ? NOB : 1];
-        if constexpr (H16) {
-            const short4v* wp = (const short4v*)p.w + (long)c * (TAPS * NOB * 64) + lane;
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap)
-#pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) wa[tap][ob] = wp[(tap * NOB + ob) * 64];
-        } else {
+        if constexpr (!H16) {
             for (int u = tid; u < W_DW / 4; u += 256)
                 ((floatx4*)s_w)[u] = ((const floatx4*)(p.w + (long)c * W_DW))[u];
         }
@@ -274,20 +292,35 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
     for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
         for (int q = 0; q < 4; ++q) ssum[ob][q] = ssq[ob][q] = 0.f;
+    // per-thread constants of the epilogue hoisted out of the pixel loop: channel parameters, and ONE pointer per tensor to this lane's
+    // first pixel (row Y0 + wave*RPW, column X0 + l15, channels kk*4..); the pixels of the loop are uniform element offsets from it
+    floatx4 e_bias[NOB], e_sc[NOB], e_sh[NOB];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        const int oc = ob * 16 + kk * 4;
+        e_bias[ob] = p.bias ? *(const floatx4*)(p.bias + oc) : floatx4{0.f, 0.f, 0.f, 0.f};
+        e_sc[ob] = p.post_scale ? *(const floatx4*)(p.post_scale + oc) : floatx4{1.f, 1.f, 1.f, 1.f};
+        e_sh[ob] = p.post_scale ? *(const floatx4*)(p.post_shift + oc) : floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    const long pix0 = ((long)img * p.H + Y0 + wave * RPW) * p.W + X0 + l15;
+    float* const o0 = p.out + pix0 * p.out_ld + p.out_coff + kk * 4;
+    const float* const r1p = p.res1 ? p.res1 + pix0 * p.res1_ld + kk * 4 : nullptr;
+    const float* const r2p = p.res2 ? p.res2 + pix0 * p.res2_ld + kk * 4 : nullptr;
+    const bool vec_out = (p.cout_store & 3) == 0 && (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int Y = Y0 + wave * RPW + (i >> 2), X = X0 + (i & 3) * 16 + l15;
         const bool ok = Y < p.H && X < p.W;
+        const int dpx = (i >> 2) * p.W + (i & 3) * 16;          // uniform pixel offset from pix0
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
             const int oc = ob * 16 + kk * 4;
             floatx4 v = acc[ob][i];
-            if (p.bias) v += *(const floatx4*)(p.bias + oc);
-            if (p.post_scale) v = v * *(const floatx4*)(p.post_scale + oc) + *(const floatx4*)(p.post_shift + oc);   // eval-mode BatchNorm
+            if (p.bias) v += e_bias[ob];
+            if (p.post_scale) v = v * e_sc[ob] + e_sh[ob];   // eval-mode BatchNorm
             if (ok && p.res1) {      // residual epilogues of the strict fp32 trunk (x5*0.2 + x, out*0.2 + x)
-                const long pixr = ((long)img * p.H + Y) * p.W + X;
-                v = v * p.res1_scale + *(const floatx4*)(p.res1 + pixr * p.res1_ld + oc);
-                if (p.res2) v = v * p.res2_scale + *(const floatx4*)(p.res2 + pixr * p.res2_ld + oc);
+                v = v * p.res1_scale + *(const floatx4*)(r1p + dpx * p.res1_ld + ob * 16);
+                if (p.res2) v = v * p.res2_scale + *(const floatx4*)(r2p + dpx * p.res2_ld + ob * 16);
             }
             if (p.post_lrelu) {
 #pragma unroll
@@ -315,8 +348,8 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                         }
                     }
                 } else {
-                    float* o = p.out + (((long)img * p.H + Y) * p.W + X) * p.out_ld + p.out_coff + oc;
-                    if ((p.cout_store & 3) == 0 && (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0) {
+                    float* o = o0 + dpx * p.out_ld + ob * 16;
+                    if (vec_out) {
                         if (oc < p.cout_store) *(floatx4*)o = v;
                     } else {
 #pragma unroll
@@ -526,11 +559,13 @@ int launch_hconv(HParams& p, int B, int H, int W, hipStream_t st) {
     p.ntiles = p.tiles_per_img * B;
     p.tiles_per_xcd = (p.ntiles + 7) / 8;
     const int nblocks = p.tiles_per_xcd * 8;
-    if (LDS_B > 65536) {
+    static const int lds_floor = getenv("SRBH_HCONV_LDS") ? atoi(getenv("SRBH_HCONV_LDS")) : 0;     // developer aid: occupancy A/B
+    const int lds_b = H16 && lds_floor > LDS_B ? lds_floor : LDS_B;
+    if (lds_b > 65536 || LDS_B > 65536) {
         SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hconv_f32_kernel<NOB, KS, RPW, OPT>,
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)));
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_b > LDS_B ? lds_b : LDS_B)));
     }
-    hipLaunchKernelGGL((hconv_f32_kernel<NOB, KS, RPW, OPT>), dim3(nblocks), dim3(256), LDS_B, st, p);
+    hipLaunchKernelGGL((hconv_f32_kernel<NOB, KS, RPW, OPT>), dim3(nblocks), dim3(256), lds_b, st, p);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }

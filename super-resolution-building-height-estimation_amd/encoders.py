@@ -97,6 +97,10 @@ class _DepthwiseConvFn(torch.autograd.Function):
         return dx, dw, None, None
 
 
+# (1x1 convs stay on MIOpen in the training graph too.  Restating them as batched rocBLAS GEMMs -- forward W @ X_b, data gradient
+# W^T @ dY_b, weight gradient sum_b dY_b @ X_b^T -- removed ~220 of the step's launches (MIOpen's backward wraps its NHWC
+# implicit-GEMM kernels in batched transposes and zero fills) but the step got 1.5 ms SLOWER: at these shapes the Tensile kernels
+# behind bmm lose more than the launches cost.  Measured round 2)
 _ACT = {None: 0, "silu": 1, "relu": 2}
 FUSED_SE_EVAL = True       # squeeze-and-excitation of the MBConv blocks as three libsrbh launches at inference
 FUSED_BN_EVAL = True      # tests switch it off to compare with the stock inference-BatchNorm path
@@ -207,9 +211,14 @@ def _swish(x):
     return F.silu(x)
 
 
-def _drop_connect(x, p, training):
+def _drop_connect(x, p, training, mask=None):
+    """stochastic depth (efficientnet_pytorch utils.drop_connect): x / keep * floor(keep + U[0,1)) per sample.  `mask` = this
+    block's precomputed (B,1,1,1) factor floor(keep + u) / keep (EfficientNetEncoder draws the uniforms of ALL blocks with one
+    launch per forward instead of rand + add + floor + div + mul per block: 25 blocks x 5 launches)."""
     if not training or p <= 0:
         return x
+    if mask is not None:
+        return x * mask
     keep = 1.0 - p
     mask = torch.floor(keep + torch.rand([x.shape[0], 1, 1, 1], dtype=x.dtype, device=x.device))
     return x / keep * mask
@@ -231,7 +240,7 @@ class MBConvBlock(nn.Module):
         self._project_conv = SamePadConv2d(mid, out, 1, math.ceil(image_size / stride), bias=False)
         self._bn2 = nn.BatchNorm2d(out, momentum=BN_MOM, eps=BN_EPS)
 
-    def forward(self, x, drop_connect_rate=None):
+    def forward(self, x, drop_connect_rate=None, drop_mask=None):
         inputs = x
         if self.expand != 1:
             x = bn_act(self._bn0, self._expand_conv(x), "silu")
@@ -246,7 +255,7 @@ class MBConvBlock(nn.Module):
         x = bn_act(self._bn2, self._project_conv(x))
         if self.stride == 1 and self.inp == self.out:
             if drop_connect_rate:
-                x = _drop_connect(x, drop_connect_rate, self.training)
+                x = _drop_connect(x, drop_connect_rate, self.training, drop_mask)
             x = x + inputs
         return x
 
@@ -287,7 +296,17 @@ class EfficientNetEncoder(nn.Module):
         feats.append(x)
         n = len(self._blocks)
         bounds = list(self._stage_idxs[:3]) + [n]
+        masks = None
+        if self.training and DROP_CONNECT > 0 and x.is_cuda:
+            # all blocks' stochastic-depth factors from ONE uniform draw: floor(keep_i + u) / keep_i, keep_i = 1 - rate * i / n
+            keep = 1.0 - DROP_CONNECT * torch.arange(n, dtype=x.dtype, device=x.device) / n
+            masks = torch.floor(keep + torch.rand((x.shape[0], n), dtype=x.dtype, device=x.device)) / keep
         for idx, blk in enumerate(self._blocks):
+            if masks is not None:
+                x = blk(x, DROP_CONNECT * idx / n, masks[:, idx].view(-1, 1, 1, 1))
+                if idx + 1 in bounds:
+                    feats.append(x)
+                continue
             x = blk(x, DROP_CONNECT * idx / n)
             if idx + 1 in bounds:
                 feats.append(x)

@@ -93,3 +93,4 @@ def test_fused_inference_batchnorm_agrees_with_the_stock_path():
         finally:
             encoders.FUSED_BN_EVAL = True
     assert rel(a2, b2) <= 1e-5
+
