@@ -184,7 +184,16 @@ typedef struct srbh_hconv_args {
      * y = y*post_scale[c] + post_shift[c] (applied after the bias, before res1) and a plain ReLU at the very end */
     const float* post_scale; const float* post_shift;   /* [cout padded to 16] or NULL */
     int post_relu;
+    /* srbh_hconv_h16(bf16 = 0) only -- fp16 ACTIVATIONS in memory (inference: the producing epilogue rounds once, the consumer
+     * stages the 8-byte channel quads as they are): bit 0 = src0 holds fp16, bit 1 = src1, bit 2 = res1, bit 3 = out is written as
+     * fp16.  Such a tensor is NHWC with 2-byte elements; its *_ld stays in ELEMENTS.  An fp16 src0 takes no pre_scale / pre_relu (the
+     * producer applied them), an fp16 out no PixelShuffle store and no statistics; channel counts and strides multiples of 4. */
+    int io_h16;
 } srbh_hconv_args;
+#define SRBH_IO_SRC0_H16 1
+#define SRBH_IO_SRC1_H16 2
+#define SRBH_IO_RES1_H16 4
+#define SRBH_IO_OUT_H16 8
 int srbh_hconv_f32(const srbh_hconv_args* a, void* stream);
 /* The same convolution with fp16 OPERANDS (staged activations and weights rounded to fp16, fp32 accumulate on
  * v_mfma_f32_16x16x16_f16; inputs / outputs / BatchNorm statistics stay fp32 in memory): 1/8 of the fp32 matrix-core time,

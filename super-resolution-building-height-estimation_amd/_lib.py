@@ -78,6 +78,7 @@ class HConvArgs(C.Structure):
         ("res1", C.c_void_p), ("res1_ld", C.c_int), ("res1_scale", C.c_float),
         ("res2", C.c_void_p), ("res2_ld", C.c_int), ("res2_scale", C.c_float),
         ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("post_relu", C.c_int),
+        ("io_h16", C.c_int),
     ]
 
 

@@ -24,6 +24,7 @@ using namespace srbh;
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef short short4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
 // operand rounding of the 16-bit forms: 1 = fp16 (forward: activations and weights are O(1)), 2 = bf16 (data gradients:
 // per-pixel gradients of a mean loss sit far below fp16's normal range, bf16 keeps fp32's exponent); both RNE
 template <int OPT>
@@ -81,6 +82,7 @@ struct HParams {
     const float* res1; int res1_ld; float res1_scale;  // y = y*res1_scale + res1 ; then y = y*res2_scale + res2
     const float* res2; int res2_ld; float res2_scale;
     const float* post_scale; const float* post_shift; int post_relu;
+    int io_h16;                                        // SRBH_IO_*: which of src0 / src1 / res1 / out hold fp16 elements (OPT 1 only)
 };
 
 // NOB = cout/16 (1, 2 or 4), KS = 3 or 1, RPW = output rows per wave (2: 8-row tiles, 54 KiB of LDS, 2 workgroups per CU;
@@ -107,6 +109,11 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
     // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  Consecutive tiles
     // (x-neighbours, then the next tile row) share halo rows -- 55 % more input rows than a tile owns at 4-row tiles -- so every
     // XCD walks its own contiguous run of tiles and the halo re-reads hit that XCD's L2 instead of going out to the fabric.
+    // (A PERSISTENT walk -- a few workgroups per CU looping over their XCD's tiles, BatchNorm statistics flushed once per workgroup,
+    // optionally with the next tile's loads issued ahead of this tile's MFMAs -- was measured in round 2: the loop lets the compiler
+    // keep ~80 more loop-invariant values in registers (182 VGPRs, occupancy 2: 180 us vs 160; pipelined 255 + 52 AGPRs, occupancy
+    // 1: 280 us).  At EQUAL occupancy the persistent form is 23 % faster than one workgroup per tile, so it is the right shape --
+    // for a kernel written around it, not for this template.  DESIGN.md 5.0b / 8.)
     const int t = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
     if (t >= p.ntiles) return;
     const int img = t / p.tiles_per_img;
@@ -154,7 +161,11 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
             const int ch = c * HC + cg * 4;
             const bool chok = ch < cin, in0 = ch < p.c0;
             const int ldp = in0 ? p.ld0 : p.ld1;
-            const float* tp = (in0 ? p.src0 + ch : p.src1 + (ch - p.c0)) + (((long)img * p.H + (Y0 - HALO)) * p.W + (X0 - HALO)) * ldp;
+            // fp16 activations in memory (inference, SRBH_IO_*): element size 2, the quad is staged as it is (8-byte load, no rounding)
+            const bool srch = OPT == 1 && (p.io_h16 & (in0 ? SRBH_IO_SRC0_H16 : SRBH_IO_SRC1_H16)) != 0;
+            const int esz = srch ? 2 : 4;
+            const char* tp = (const char*)(in0 ? p.src0 : p.src1) +
+                             ((((long)img * p.H + (Y0 - HALO)) * p.W + (X0 - HALO)) * ldp + (in0 ? ch : ch - p.c0)) * esz;
             floatx4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
             bool relu_t = false;                                   // (a select, not max(a, -inf): a NaN-poisoned input must stay NaN)
             if (in0 && chok) {
@@ -173,7 +184,12 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                 // (only the load here: the transform sits in the store loop below, so that all loads are in flight before the first use)
                 ld[it] = floatx4{0.f, 0.f, 0.f, 0.f};
                 if (ok && unit) {
-                    ld[it] = *(const floatx4*)(tp + voff);
+                    if (srch) {
+                        const float2v h = *(const float2v*)(tp + (long)voff * 2);      // 4 fp16 channels, kept as raw bits in ld[it][0..1]
+                        ld[it][0] = h[0]; ld[it][1] = h[1];
+                    } else {
+                        ld[it] = *(const floatx4*)(tp + (long)voff * 4);
+                    }
                     okmask |= 1u << it;
                 }
                 if constexpr (H16) loff[it] = unit ? ((tid >> 2) + 64 * it) * 32 + ((cg ^ ((col >> 2) & 2)) << 3) : -1;   // = h16_off(r, col, cg, COLS)
@@ -188,14 +204,15 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 if (loff[it] >= 0) {
-                    if (okmask & (1u << it)) {
+                    if ((okmask & (1u << it)) && !srch) {
                         ld[it] = ld[it] * psc + psh;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) ld[it][j] = relu_t ? fmaxf(ld[it][j], 0.f) : ld[it][j];
                     }
                     if constexpr (H16) {
                         const float t4[4] = {ld[it][0], ld[it][1], ld[it][2], ld[it][3]};
-                        *(short4v*)((char*)s_in + loff[it]) = round4<OPT>(t4);
+                        if (srch) *(float2v*)((char*)s_in + loff[it]) = float2v{ld[it][0], ld[it][1]};
+                        else *(short4v*)((char*)s_in + loff[it]) = round4<OPT>(t4);
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) s_in[plane_base<RPW>(cg * 4 + j) + loff[it]] = ld[it][j];
@@ -303,8 +320,9 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
         e_sh[ob] = p.post_scale ? *(const floatx4*)(p.post_shift + oc) : floatx4{0.f, 0.f, 0.f, 0.f};
     }
     const long pix0 = ((long)img * p.H + Y0 + wave * RPW) * p.W + X0 + l15;
-    float* const o0 = p.out + pix0 * p.out_ld + p.out_coff + kk * 4;
-    const float* const r1p = p.res1 ? p.res1 + pix0 * p.res1_ld + kk * 4 : nullptr;
+    const bool out16 = OPT == 1 && (p.io_h16 & SRBH_IO_OUT_H16) != 0, res16 = OPT == 1 && (p.io_h16 & SRBH_IO_RES1_H16) != 0;
+    float* const o0 = (float*)((char*)p.out + (pix0 * p.out_ld + p.out_coff + kk * 4) * (out16 ? 2 : 4));
+    const float* const r1p = p.res1 ? (const float*)((const char*)p.res1 + (pix0 * p.res1_ld + kk * 4) * (res16 ? 2 : 4)) : nullptr;
     const float* const r2p = p.res2 ? p.res2 + pix0 * p.res2_ld + kk * 4 : nullptr;
     const bool vec_out = (p.cout_store & 3) == 0 && (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0;
 #pragma unroll
@@ -319,7 +337,12 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
             if (p.bias) v += e_bias[ob];
             if (p.post_scale) v = v * e_sc[ob] + e_sh[ob];   // eval-mode BatchNorm
             if (ok && p.res1) {      // residual epilogues of the strict fp32 trunk (x5*0.2 + x, out*0.2 + x)
-                v = v * p.res1_scale + *(const floatx4*)(r1p + dpx * p.res1_ld + ob * 16);
+                if (res16) {
+                    const half4 r = *(const half4*)((const char*)r1p + (long)(dpx * p.res1_ld + ob * 16) * 2);
+                    v = v * p.res1_scale + floatx4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+                } else {
+                    v = v * p.res1_scale + *(const floatx4*)(r1p + dpx * p.res1_ld + ob * 16);
+                }
                 if (p.res2) v = v * p.res2_scale + *(const floatx4*)(r2p + dpx * p.res2_ld + ob * 16);
             }
             if (p.post_lrelu) {
@@ -349,7 +372,10 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                     }
                 } else {
                     float* o = o0 + dpx * p.out_ld + ob * 16;
-                    if (vec_out) {
+                    if (out16) {          // (host: 4-aligned channels) one rounding here, none in the consumer
+                        if (oc < p.cout_store)
+                            *(half4*)((char*)o0 + (long)(dpx * p.out_ld + ob * 16) * 2) = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    } else if (vec_out) {
                         if (oc < p.cout_store) *(floatx4*)o = v;
                     } else {
 #pragma unroll
@@ -638,6 +664,18 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
     p.res1 = a->res1; p.res1_ld = a->res1_ld; p.res1_scale = a->res1_scale;
     p.res2 = a->res2; p.res2_ld = a->res2_ld; p.res2_scale = a->res2_scale;
     p.post_scale = a->post_scale; p.post_shift = a->post_shift; p.post_relu = a->post_relu;
+    p.io_h16 = a->io_h16;
+    if (a->io_h16) {
+        SRBH_REQUIRE(opt == 1, "srbh_hconv: fp16 activations in memory (io_h16) need srbh_hconv_h16 with fp16 operands");
+        SRBH_REQUIRE((a->io_h16 & ~15) == 0, "srbh_hconv_h16: unknown io_h16 bits");
+        SRBH_REQUIRE(!(a->io_h16 & SRBH_IO_SRC0_H16) || (!a->pre_scale && !a->pre_relu), "srbh_hconv_h16: an fp16 src0 takes no pre-affine / ReLU");
+        SRBH_REQUIRE(!(a->io_h16 & SRBH_IO_OUT_H16) || (!a->pixelshuffle2 && !a->stats && a->cout % 4 == 0 && p.out_ld % 4 == 0 && a->out_coff % 4 == 0),
+                     "srbh_hconv_h16: an fp16 output needs 4-aligned channels, no PixelShuffle store, no statistics");
+        SRBH_REQUIRE(!(a->io_h16 & SRBH_IO_RES1_H16) || (a->res1 && !a->res2), "srbh_hconv_h16: fp16 residual: res1 only");
+        // the 16-bit staging of fp16 sources exists in the vectorised path only
+        SRBH_REQUIRE((a->c0 & 3) == 0 && (a->c1 & 3) == 0 && (p.ld0 & 3) == 0 && (a->c1 == 0 || (p.ld1 & 3) == 0),
+                     "srbh_hconv_h16: fp16 activations need channel counts and strides that are multiples of 4");
+    }
     SRBH_REQUIRE(!a->post_scale || a->post_shift, "srbh_hconv_f32: post_scale needs post_shift");
     SRBH_REQUIRE(!a->pixelshuffle2 || (a->out_ld <= 0 && a->out_coff == 0), "srbh_hconv_f32: PixelShuffle store needs a dense output");
     SRBH_REQUIRE(!a->res1 || (a->cout % 4 == 0 && a->res1_ld % 4 == 0), "srbh_hconv_f32: residual epilogue needs 4-aligned channels");

@@ -30,10 +30,10 @@ BN_EPS_DEFAULT = 1e-5
 
 
 # ----------------------------------------------------------------------------- low-level ops (NHWC fp32)
-def _require_dev(x, who):
+def _require_dev(x, who, h16_ok=False):
     if not (torch.is_tensor(x) and x.is_cuda):
         raise RuntimeError(f"{who} (libsrbh): input must be a ROCm/HIP device tensor; the head has no CPU fallback")
-    if x.dtype != torch.float32:
+    if x.dtype != torch.float32 and not (h16_ok and x.dtype == torch.float16):
         raise TypeError(f"{who}: expected float32, got {x.dtype}")
 
 
@@ -53,8 +53,8 @@ def to_nhwc(x):
     return out
 
 
-def empty_nhwc(B, Cc, H, W, device):
-    return torch.empty_strided((B, Cc, H, W), (H * W * Cc, 1, W * Cc, Cc), dtype=torch.float32, device=device)
+def empty_nhwc(B, Cc, H, W, device, dtype=torch.float32):
+    return torch.empty_strided((B, Cc, H, W), (H * W * Cc, 1, W * Cc, Cc), dtype=dtype, device=device)
 
 
 # ---- operand precision of the head convolutions ---------------------------------------------------------------------
@@ -78,6 +78,19 @@ def head_h16():
     m = _HEAD_PRECISION["mode"]
     # (torch disables grad mode inside autograd.Function.forward / backward: those bump "depth" instead, hrfuse_autograd._exact)
     return m == "f16" or (m == "auto" and not torch.is_grad_enabled() and _HEAD_PRECISION["depth"] == 0)
+
+
+# fp16 ACTIVATIONS in memory between the convs of an inference chain (BasicBlock.forward_nhwc; SRBH_FP16_ACT=1 or this flag).  OFF by
+# default: it halves the bytes every head conv moves (32 + 32 instead of 64 + 64 per pixel; height maps 4e-4 from the fp32-tensor
+# chain, inside the 1e-3 tolerance) and is 3 % SLOWER -- measured A/B in one process at B=128: model forward 15.0 vs 14.55 ms.  The
+# head kernels are not bound by bytes but by their one-tile-per-workgroup structure; the flag is what a persistent
+# kernel will want, and stays covered by tests/test_gpu_head_f16.py.
+FP16_ACTIVATIONS = _os.environ.get("SRBH_FP16_ACT", "0") == "1"
+
+
+def fp16_chain(mod):
+    """True when `mod`'s blocks run the fp16-activation inference chain right now (eval mode, no graph, fp16-operand precision)"""
+    return FP16_ACTIVATIONS and not mod.training and not torch.is_grad_enabled() and head_h16()
 
 
 class _PackedConv:
@@ -113,10 +126,12 @@ class _PackedConv:
 
 
 def hconv(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_stats=False, post=None, res=None,
-          post_relu=False):
+          post_relu=False, out_h16=False):
     """conv(cat(srcs)) through srbh_hconv_f32.  srcs: list of 1..2 NHWC tensors; pre=(scale, shift, relu) is
     applied to srcs[0]; returns (out, stats) with out NHWC and stats the partial-sum buffer or None.
-    Epilogue extras (inference fusion): post=(scale, shift) per output channel, res = NHWC tensor added, post_relu."""
+    Epilogue extras (inference fusion): post=(scale, shift) per output channel, res = NHWC tensor added, post_relu.
+    fp16 activations in memory (inference chain, fp16-operand mode only): any of srcs / res may be a torch.float16 NHWC tensor,
+    out_h16=True writes one (the epilogue rounds once; the consumer stages the halves as they are)."""
     L = _lib.lib()
     x0 = srcs[0]
     B, c0, H, W = x0.shape
@@ -137,7 +152,13 @@ def hconv(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_
     a.cout, a.ksize = cout, ks
     a.B, a.H, a.W = B, H, W
     a.pixelshuffle2 = int(ps2)
-    out = empty_nhwc(B, cout // 4, 2 * H, 2 * W, x0.device) if ps2 else empty_nhwc(B, cout, H, W, x0.device)
+    io = ((1 if x0.dtype == torch.float16 else 0) | (2 if c1 and srcs[1].dtype == torch.float16 else 0)
+          | (4 if res is not None and res.dtype == torch.float16 else 0) | (8 if out_h16 else 0))
+    if io and not h16:
+        raise RuntimeError("libsrbh hconv: fp16 activations need the fp16-operand mode (set_head_precision)")
+    a.io_h16 = io
+    out = (empty_nhwc(B, cout // 4, 2 * H, 2 * W, x0.device) if ps2
+           else empty_nhwc(B, cout, H, W, x0.device, torch.float16 if out_h16 else torch.float32))
     a.out = out.data_ptr()
     if post is not None:
         a.post_scale, a.post_shift = post[0].data_ptr(), post[1].data_ptr()
@@ -348,12 +369,32 @@ class BasicBlock(nn.Module):
             if not isinstance(bn, nn.BatchNorm2d):
                 raise NotImplementedError("libsrbh BasicBlock supports nn.BatchNorm2d norm layers")
 
-    def forward_nhwc(self, srcs):
-        """srcs: list of 1..2 NHWC tensors whose channel concat is the block input (no autograd)."""
+    def forward_nhwc(self, srcs, out_h16=False):
+        """srcs: list of 1..2 NHWC tensors whose channel concat is the block input (no autograd).
+        Inference with fp16 operands (`head_h16()`): the block's intermediates live in memory as fp16 -- bn1 + ReLU run in conv1's
+        epilogue (the value conv2 would round while staging is rounded there, once: same numbers), the downsample branch and,
+        with out_h16, the block output are written as fp16 too (the residual stream of a chain of blocks is then fp16: one extra
+        rounding of 2^-11 per block on the identity path).  Every conv then moves 32 + 32 instead of 64 + 64 bytes per pixel."""
         self._check()
         tr = self.training
         B, _, H, W = srcs[0].shape
         n = B * H * W
+        if (not tr and FP16_ACTIVATIONS and head_h16() and self.bn2.num_features % 16 == 0 and self.bn1.num_features % 4 == 0
+                and all(t.shape[1] % 4 == 0 for t in srcs)):
+            s1, h1, _, _ = bn_scale_shift(self.bn1, None, n, False)
+            s2, h2, _, _ = bn_scale_shift(self.bn2, None, n, False)
+            a1, _ = hconv(srcs, self.conv1, self._p1, post=(s1, h1), post_relu=True, out_h16=True)
+            if self.downsample is not None:
+                sd, hd, _, _ = bn_scale_shift(self.downsample[1], None, n, False)
+                idt, _ = hconv(srcs, self.downsample[0], self._pd, post=(sd, hd), out_h16=True)
+            else:
+                if len(srcs) != 1:
+                    raise ValueError("identity path needs a single source")
+                idt = srcs[0]
+            out, _ = hconv([a1], self.conv2, self._p2, post=(s2, h2), res=idt, post_relu=True, out_h16=out_h16)
+            return out
+        if any(t.dtype != torch.float32 for t in srcs):
+            raise RuntimeError("libsrbh BasicBlock: fp16 activations outside the fp16 inference chain")
         c1, st1 = hconv(srcs, self.conv1, self._p1, want_stats=tr)
         s1, h1, _, _ = bn_scale_shift(self.bn1, st1, n, tr)
         if not tr and self.bn2.num_features % 16 == 0:
@@ -390,16 +431,17 @@ def _needs_grad(mods, tensors):
     return any(t.requires_grad for t in tensors) or any(p.requires_grad for m in mods for p in m.parameters())
 
 
-def run_blocks(blocks, inputs):
-    """Run a chain of BasicBlocks on the channel concat of `inputs` ((B,C,H,W) tensors)."""
+def run_blocks(blocks, inputs, out_h16=False):
+    """Run a chain of BasicBlocks on the channel concat of `inputs` ((B,C,H,W) tensors).  out_h16: the caller consumes the result
+    through another libsrbh conv and takes it as an fp16 NHWC tensor (inference chain, see BasicBlock.forward_nhwc)."""
     if _needs_grad(blocks, inputs):
         from . import hrfuse_autograd as AG
         out = AG.blocks_forward(blocks, inputs)
         flush_batches()
         return out
     x = [to_nhwc(t) for t in inputs]
-    for b in blocks:
-        x = [b.forward_nhwc(x)]
+    for i, b in enumerate(blocks):
+        x = [b.forward_nhwc(x, out_h16 or i + 1 < len(blocks))]      # (a non-chain block ignores the flag and returns fp32)
     flush_batches()
     return x[0]
 
@@ -411,9 +453,9 @@ class HRfeature(nn.Sequential):
         super().__init__(BasicBlock(in_chans, mid_chans, stride=1), BasicBlock(mid_chans, mid_chans, stride=1),
                          BasicBlock(mid_chans, out_chans, stride=1))
 
-    def forward(self, x):
+    def forward(self, x, out_h16=False):
         _require_dev(x, "HRfeature")
-        return run_blocks(list(self), [x])
+        return run_blocks(list(self), [x], out_h16 and fp16_chain(self))
 
 
 class _LastConv:
@@ -442,9 +484,9 @@ class HRfuse_residual(nn.Module):
 
     def forward(self, x_lr, x_hr):
         _require_dev(x_lr, "HRfuse_residual")
-        _require_dev(x_hr, "HRfuse_residual")
+        _require_dev(x_hr, "HRfuse_residual", h16_ok=fp16_chain(self))      # (HRfeature(..., out_h16=True) inside the inference chain)
         x_lr = self.upsampler(x_lr)
-        x = run_blocks(list(self.fuse), [x_lr, x_hr])
+        x = run_blocks(list(self.fuse), [x_lr, x_hr], fp16_chain(self))      # (conv_last reads the chain's fp16 output)
         return _LastConv.run(self, self.conv_last, x)
 
 

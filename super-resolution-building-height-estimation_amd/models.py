@@ -61,7 +61,7 @@ class SRRegress_Cls_feature(torch.nn.Module):
         if x.is_cuda and (SIDE_STREAM == "1" or (SIDE_STREAM == "auto" and not torch.is_grad_enabled())):
             return self._forward_two_streams(x, super_fea)
         encode_fea = self.encoder(x)
-        super_fea = self.hrfeat(super_fea)
+        super_fea = self.hrfeat(super_fea, out_h16=True)     # (fp16 NHWC inside the inference chain; reg / seg read it as such)
         height_fea = self.decoder1(*encode_fea)
         if self.isaggre:
             height_aggre = self._aggre(height_fea)
@@ -88,7 +88,7 @@ class SRRegress_Cls_feature(torch.nn.Module):
             height_fea = self.decoder1(*encode_fea)
             build_fea = self.decoder2(*encode_fea)
             height_aggre = self._aggre(height_fea) if self.isaggre else None
-        super_fea = self.hrfeat(super_fea)
+        super_fea = self.hrfeat(super_fea, out_h16=True)     # (fp16 NHWC inside the inference chain; reg / seg read it as such)
         cur.wait_stream(side)
         for t in (height_fea, build_fea, height_aggre):      # produced on `side`, consumed on `cur`: keep the allocator from recycling early
             if t is not None:
@@ -109,7 +109,7 @@ class SRRegress_Cls_feature(torch.nn.Module):
     def forward_nobuild(self, x, super_fea):
         """mymodels.py:315-337: skips decoder2 / seg."""
         encode_fea = self.encoder(x)
-        super_fea = self.hrfeat(super_fea)
+        super_fea = self.hrfeat(super_fea, out_h16=True)     # (fp16 NHWC inside the inference chain; reg / seg read it as such)
         height_fea = self.decoder1(*encode_fea)
         if self.isaggre:
             height_aggre = self._aggre(height_fea)

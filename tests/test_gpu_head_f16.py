@@ -187,3 +187,30 @@ def test_mixed_precision_training_gradients_close_to_exact():
             assert cos(res["f16"][1][k], g) >= 0.99, k
             rels.append(O.rel_l2(res["f16"][1][k], g))
     assert len(rels) > 10 and sorted(rels)[len(rels) // 2] <= 3e-2, sorted(rels)
+
+
+def test_fp16_activation_chain_within_tolerance(monkeypatch):
+    """hrfuse.FP16_ACTIVATIONS (off by default: measured slower): every conv of the inference head reads / writes fp16 NHWC tensors
+    (srbh_hconv_args.io_h16), bn1 + ReLU in conv1's epilogue, fp16 residual stream.  Whole model, eval, no_grad: height / building
+    maps within the 1e-3 tolerance of the CPU reference and 1e-3 of the fp32-tensor chain; the public modules still return fp32."""
+    import copy
+    from srbh_amd import hrfuse as H
+    from srbh_amd.hrfuse import HRfeature
+    from tests.test_gpu_model import cpu_reference, make_model
+    m = make_model(seed=41).eval()
+    x = synth.tiles(2, 8, 64, seed=43)
+    fea = torch.randn(2, 64, 256, 256, generator=torch.Generator().manual_seed(44)) * 0.5
+    with torch.no_grad():
+        want = cpu_reference(copy.deepcopy(m), x, fea, False)
+        m = m.to(DEV)
+        base = m(x.to(DEV), fea.to(DEV))
+        monkeypatch.setattr(H, "FP16_ACTIVATIONS", True)
+        got = m(x.to(DEV), fea.to(DEV))
+        feat = m.hrfeat(fea.to(DEV))
+        feat16 = m.hrfeat(fea.to(DEV), out_h16=True)
+    assert feat.dtype == torch.float32 and feat16.dtype == torch.float16
+    assert O.rel_l2(feat16.float().cpu(), feat.cpu()) <= 1e-3
+    for a, b, c, name in zip(got, want, base, ("height", "build", "aggre")):
+        assert a.dtype == torch.float32
+        assert O.rel_l2(a.cpu(), b) <= TOL_HEAD, name
+        assert 0 < O.rel_l2(a.cpu(), c.cpu()) <= TOL_HEAD, name        # (> 0: the fp16 chain really ran)
