@@ -1,0 +1,190 @@
+// srbh_hconv16_kernel.h -- the head's dominant convolution as its own kernel: 3x3, 16 -> 16 channels, one fp32 NHWC source, fp16 / bf16
+// operands (included by srbh_head.hip inside its anonymous namespace, after HParams / h16_off / round4).
+//
+// Why a second kernel next to the hconv_f32_kernel template (round 2): the template runs ONE 4 x 64 tile per
+// workgroup -- 16 384 workgroups of ~2.7 us for a B=64 layer -- and PMC / SQ counters showed it bound by that serial chain (launch,
+// kernel-argument load, input load, LDS, MFMA, residual load, store), not by bytes: it moves exactly the algorithmic 537 MB at
+// 3.4 TB/s, does not speed up when the bytes are halved, and a persistent walk bolted into the template blew its registers.  This
+// kernel is written around the walk:
+//   * a few workgroups per CU, each walks its XCD's contiguous run of tiles (halo rows from that XCD's L2);
+//   * the weights (9 taps x 8 bytes per lane) are loaded once per workgroup;
+//   * two LDS stages: while tile k is multiplied out of stage k&1 and stored, the global loads of tile k+1 are in flight (issued
+//     right after tile k went to LDS) and the residual of tile k was requested before its MFMAs -- one barrier per tile;
+//   * BatchNorm partial sums are kept in registers over the walk and flushed once per workgroup.
+// Same arithmetic as hconv_f32_kernel<1, 3, 1, OPT> (same rounding, same MFMA order per pixel): results are bit-identical except the
+// order in which the BatchNorm partial sums are added.  Restrictions (the host falls back to the template otherwise): c0 = 16,
+// c1 = 0, cout = 16, W % 64 == 0, H % 4 == 0, 4-aligned strides, no PixelShuffle store, no second residual, no LeakyReLU.
+template <int OPT>
+__global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
+    static_assert(OPT == 1 || OPT == 2, "16-bit operand forms only");
+    constexpr int ROWS = 6, COLS = 66, NIT = (ROWS * COLS * 4 + 255) / 256;        // 7 staging units per thread (the last one partial)
+    constexpr int STAGE_B = ROWS * COLS * 32;                                       // 12 672 bytes per stage
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    char* const s_base = (char*)hsm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kk = lane >> 4;
+    const int cg = tid & 3;
+    const int t_end = min((int)(blockIdx.x & 7) * p.tiles_per_xcd + p.tiles_per_xcd, p.ntiles);
+    const int t_first = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3), t_step = gridDim.x >> 3;
+
+    // ---- per-thread constants of the walk
+    short4v wa[9];
+    {
+        const short4v* wp = (const short4v*)p.w + lane;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) wa[tap] = wp[tap * 64];
+    }
+    floatx4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+    if (p.pre_scale) { psc = *(const floatx4*)(p.pre_scale + cg * 4); psh = *(const floatx4*)(p.pre_shift + cg * 4); }
+    const bool pre_relu = p.pre_relu != 0;
+    const floatx4 e_bias = p.bias ? *(const floatx4*)(p.bias + kk * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+    const floatx4 e_sc = p.post_scale ? *(const floatx4*)(p.post_scale + kk * 4) : floatx4{1.f, 1.f, 1.f, 1.f};
+    const floatx4 e_sh = p.post_scale ? *(const floatx4*)(p.post_shift + kk * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+    // staging unit `it` of this thread: window pixel (tid >> 2) + 64*it = (row ur[it], column uc[it]); tile-independent
+    int uoff[NIT];          // element offset (r*W + col) * ld0 from the window origin
+    int ulds[NIT];          // byte offset inside a stage (h16_off)
+    unsigned urow = 0;      // 3 bits per unit: window row
+    unsigned ucol1 = 0;     // bit it: the unit sits in window column 0 (left halo) ; bit 8+it: column 65 (right halo)
+    {
+        int r = 0, col = tid >> 2;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            uoff[it] = (r * p.W + col) * p.ld0 + cg * 4;
+            ulds[it] = (r * COLS + col) * 32 + ((cg ^ ((col >> 2) & 2)) << 3);
+            urow |= (unsigned)r << (3 * it);
+            if (col == 0) ucol1 |= 1u << it;
+            if (col == COLS - 1) ucol1 |= 1u << (8 + it);
+            const bool wrapped = col + 64 >= COLS;
+            col += wrapped ? 64 - COLS : 64;
+            r += wrapped ? 1 : 0;
+        }
+    }
+    const bool last_unit = tid + (NIT - 1) * 256 < ROWS * COLS * 4;
+    // B-fragment reads: lane base per dx (the swizzle bit depends on (dx + l15) >> 3 only); (dy, 16-pixel group) are immediate offsets
+    int bbase[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) bbase[dx] = (wave * COLS + dx + l15) * 32 + ((kk ^ ((((dx + l15) >> 3) & 1) << 1)) << 3);
+
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    floatx4 ld[NIT];
+    unsigned okmask = 0;
+    auto issue = [&](const int t) {
+        const int img = t / p.tiles_per_img;
+        const int trem = t - img * p.tiles_per_img;
+        const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+        const int Y0 = ty * 4, X0 = tx * 64;
+        const float* tp = p.src0 + (((long)img * p.H + (Y0 - 1)) * p.W + (X0 - 1)) * p.ld0;
+        okmask = 0;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = (urow >> (3 * it)) & 7;
+            bool ok = (unsigned)(Y0 - 1 + r) < (unsigned)p.H;
+            if ((ucol1 >> it) & 1) ok = ok && X0 > 0;
+            if ((ucol1 >> (8 + it)) & 1) ok = ok && X0 + 64 < p.W;
+            if (it == NIT - 1) ok = ok && last_unit;
+            ld[it] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                ld[it] = *(const floatx4*)(tp + uoff[it]);
+                okmask |= 1u << it;
+            }
+        }
+    };
+    auto commit = [&](char* stage) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (it < NIT - 1 || last_unit) {
+                floatx4 a = ld[it];
+                if (okmask & (1u << it)) {
+                    a = a * psc + psh;
+                    if (pre_relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[j] = fmaxf(a[j], 0.f);
+                    }
+                }
+                const float t4[4] = {a[0], a[1], a[2], a[3]};
+                *(short4v*)(stage + ulds[it]) = round4<OPT>(t4);
+            }
+        }
+    };
+
+    if (t_first < t_end) issue(t_first);
+    int buf = 0;
+    for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
+        char* const stage = s_base + buf * STAGE_B;
+        commit(stage);
+        const int img = t / p.tiles_per_img;
+        const int trem = t - img * p.tiles_per_img;
+        const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+        const long pix0 = ((long)img * p.H + ty * 4 + wave) * p.W + tx * 64 + l15;
+        // this tile's residual first, then the next tile's input: the epilogue can wait for the residual alone
+        floatx4 rres[4];
+        if (p.res1) {
+            const float* rp = p.res1 + pix0 * p.res1_ld + kk * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rres[i] = *(const floatx4*)(rp + i * 16 * p.res1_ld);
+        }
+        if (t + t_step < t_end) issue(t + t_step);
+        __syncthreads();           // stage `buf` is complete; every wave is past the MFMAs of the tile before (they read the other stage)
+        floatx4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const short4v b = *(const short4v*)(stage + bbase[dx] + (dy * COLS + i * 16) * 32);      // = h16_off(wave + dy, dx + i*16 + l15, kk)
+                if constexpr (OPT == 1)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, wa[tap]), __builtin_bit_cast(half4, b), acc[i], 0, 0, 0);
+                else
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa[tap], b, acc[i], 0, 0, 0);
+            }
+        }
+        float* const o0 = p.out + pix0 * p.out_ld + p.out_coff + kk * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            floatx4 v = acc[i];
+            if (p.bias) v += e_bias;
+            if (p.post_scale) v = v * e_sc + e_sh;
+            if (p.res1) v = v * p.res1_scale + rres[i];
+            if (p.post_relu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            if (p.stats) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ssum[q] += v[q];
+                    ssq[q] += v[q] * v[q];
+                }
+            }
+            *(floatx4*)(o0 + i * 16 * p.out_ld) = v;
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        float* red = hsm;                      // [4 waves][2 moments][16 channels]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float a = ssum[q], b = ssq[q];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                a += __shfl_xor(a, m);
+                b += __shfl_xor(b, m);
+            }
+            if (l15 == 0) {
+                red[(wave * 2 + 0) * 16 + kk * 4 + q] = a;
+                red[(wave * 2 + 1) * 16 + kk * 4 + q] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int mom = tid >> 4, oc = tid & 15;
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += (double)red[(w * 2 + mom) * 16 + oc];
+            double* slot = p.stats + (long)(blockIdx.x % NSLOT) * 2 * p.cout;
+            atomicAdd(slot + mom * p.cout + oc, v);
+        }
+    }
+}

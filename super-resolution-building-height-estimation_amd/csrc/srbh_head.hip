@@ -575,6 +575,8 @@ __global__ void nearest2x_kernel(const floatx4* __restrict__ src, floatx4* __res
     dst[idx] = src[(((long)b * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * C4 + c];
 }
 
+#include "srbh_hconv16_kernel.h"
+
 template <int NOB, int KS, int RPW, int OPT = 0>
 int launch_hconv(HParams& p, int B, int H, int W, hipStream_t st) {
     constexpr bool H16 = OPT != 0;
@@ -695,6 +697,22 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
         return nob == 1 ? launch_hconv<1, 1, 1, OPT_>(p, B, H, W, st)                                                       \
                         : (nob == 2 ? launch_hconv<2, 1, 1, OPT_>(p, B, H, W, st) : launch_hconv<4, 1, 1, OPT_>(p, B, H, W, st)); \
     } while (0)
+    // the dominant layer shape has its own persistent, double-buffered kernel (srbh_hconv16_kernel.h)
+    static const int k16_wgs = getenv("SRBH_HCONV16_WGS") ? atoi(getenv("SRBH_HCONV16_WGS")) : 768;     // 0 = always the template
+    if (opt != 0 && k16_wgs >= 8 && a->ksize == 3 && a->cout == 16 && a->c0 == 16 && a->c1 == 0 && (W & 63) == 0 && (H & 3) == 0 &&
+        !a->pixelshuffle2 && !a->res2 && !a->post_lrelu && !a->io_h16 && (p.ld0 & 3) == 0 && (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 &&
+        (!a->res1 || (a->res1_ld & 3) == 0) && (((uintptr_t)a->src0 | (uintptr_t)a->out | (uintptr_t)a->res1) & 15) == 0) {
+        p.tiles_x = W / 64;
+        p.tiles_per_img = p.tiles_x * (H / 4);
+        p.ntiles = p.tiles_per_img * B;
+        p.tiles_per_xcd = (p.ntiles + 7) / 8;
+        const int per_xcd = p.tiles_per_xcd < k16_wgs / 8 ? p.tiles_per_xcd : k16_wgs / 8;
+        constexpr int LDS16 = 2 * 6 * 66 * 32;
+        if (opt == 1) hipLaunchKernelGGL(hconv16_kernel<1>, dim3(per_xcd * 8), dim3(256), LDS16, st, p);
+        else hipLaunchKernelGGL(hconv16_kernel<2>, dim3(per_xcd * 8), dim3(256), LDS16, st, p);
+        SRBH_HIP(hipGetLastError());
+        return SRBH_OK;
+    }
     if (opt == 1) SRBH_H16_DISPATCH(1);
     if (opt == 2) SRBH_H16_DISPATCH(2);
 #undef SRBH_H16_DISPATCH
