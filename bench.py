@@ -154,9 +154,9 @@ def head_kernel_rooflines(dev, B):
     gflop = 2 * 9 * 16 * 16 * px / 1e9
     h16 = H.head_h16()
     for name, fn, nbytes in (
-            (f"hconv kernel ({'fp16' if h16 else 'fp32'} operands) 16->16 3x3 fwd + BN statistics", lambda: H.hconv([x], conv, pk, want_stats=True), px * (64 + 64)),
-            (f"hconv kernel ({'bf16' if h16 else 'fp32'} operands) 16->16 3x3 data gradient", lambda: HA.conv_dgrad(g, conv.weight, pg), px * (64 + 64)),
-            (f"hwgrad kernel ({'bf16' if h16 else 'fp32'} operands) 16->16 3x3 weight gradient (+ its 2 reduce launches)", lambda: HA.conv_wgrad([x], None, g, 16, 3), px * (64 + 64))):
+            (f"{'hconv16_kernel (fp16' if h16 else 'hconv_f32_kernel (fp32'} operands) 16->16 3x3 fwd + BN statistics", lambda: H.hconv([x], conv, pk, want_stats=True), px * (64 + 64)),
+            (f"{'hconv16_kernel (bf16' if h16 else 'hconv_f32_kernel (fp32'} operands) 16->16 3x3 data gradient", lambda: HA.conv_dgrad(g, conv.weight, pg), px * (64 + 64)),
+            (f"{'hwgrad_b16_kernel (bf16' if h16 else 'hwgrad_f32_kernel (fp32'} operands) 16->16 3x3 weight gradient (+ its 2 reduce launches)", lambda: HA.conv_wgrad([x], None, g, 16, 3), px * (64 + 64))):
         ms = _timed(fn, 10, dev)
         out.append({"kernel": f"{name} @256x256, B={B}", "bound": "hbm", "avg_launch_ms": round(ms, 4),
                     "algorithmic_bytes_per_launch": nbytes, "achieved": round(nbytes / ms / 1e6, 1), "peak": PEAK_HBM_GBS,
