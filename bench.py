@@ -156,7 +156,7 @@ def head_kernel_rooflines(dev, B):
     for name, fn, nbytes in (
             (f"{'hconv16_kernel (fp16' if h16 else 'hconv_f32_kernel (fp32'} operands) 16->16 3x3 fwd + BN statistics", lambda: H.hconv([x], conv, pk, want_stats=True), px * (64 + 64)),
             (f"{'hconv16_kernel (bf16' if h16 else 'hconv_f32_kernel (fp32'} operands) 16->16 3x3 data gradient", lambda: HA.conv_dgrad(g, conv.weight, pg), px * (64 + 64)),
-            (f"{'hwgrad_b16_kernel (bf16' if h16 else 'hwgrad_f32_kernel (fp32'} operands) 16->16 3x3 weight gradient (+ its 2 reduce launches)", lambda: HA.conv_wgrad([x], None, g, 16, 3), px * (64 + 64))):
+            (f"{'hwgrad16_kernel (bf16' if h16 else 'hwgrad_f32_kernel (fp32'} operands) 16->16 3x3 weight gradient (+ its 2 reduce launches)", lambda: HA.conv_wgrad([x], None, g, 16, 3), px * (64 + 64))):
         ms = _timed(fn, 10, dev)
         out.append({"kernel": f"{name} @256x256, B={B}", "bound": "hbm", "avg_launch_ms": round(ms, 4),
                     "algorithmic_bytes_per_launch": nbytes, "achieved": round(nbytes / ms / 1e6, 1), "peak": PEAK_HBM_GBS,

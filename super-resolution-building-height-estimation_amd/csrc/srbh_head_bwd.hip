@@ -17,6 +17,7 @@ using namespace srbh;
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int HT_H = 8, HT_W = 64;
 constexpr int NSLOT = 64;
+constexpr int WS_SLOTS = 768;                  // per-workgroup partial-sum slots of the weight-gradient workspace (max grid.x)
 
 struct WGParams {
     const float* src0; const float* src1;
@@ -369,6 +370,8 @@ __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
     }
 }
 
+#include "srbh_hwgrad16_kernel.h"
+
 // Sum of the workgroups' partials in a fixed order (deterministic), two stages so that enough loads are in flight:
 //   stage 1: tmp[s][u] = sum of the partials x in slice s (x = s*per .. s*per+per-1), grid (U/256, slices);
 //   stage 2: dw[oc][ci][tap] = sum over s of tmp[s][u(oc, ci, tap)]
@@ -532,12 +535,26 @@ int wgrad_impl(const srbh_hwgrad_args* a, void* stream, bool b16, const char* wh
     hipStream_t st = (hipStream_t)stream;
     const int cin = a->c0 + a->c1;
     const int nob = (a->cout + 15) / 16;
-    const int gx = p.ntiles < 512 ? (p.ntiles + 7) / 8 * 8 : 512;          // (a multiple of 8: the same number of workgroups per XCD)
+    int gx = p.ntiles < 512 ? (p.ntiles + 7) / 8 * 8 : 512;                // (a multiple of 8: the same number of workgroups per XCD)
     p.tiles_per_xcd = (p.ntiles + 7) / 8;
     // the bf16 form moves whole 4-channel groups with 16-byte loads and whole 16-channel output blocks; the few layers outside
     // that (the 1- and 7-channel output convs) keep the fp32 kernel
     const bool can16 = (a->c0 & 3) == 0 && (a->c1 & 3) == 0 && (p.ld0 & 3) == 0 && (a->c1 == 0 || (p.ld1 & 3) == 0) && (a->cout & 15) == 0 &&
                        ((uintptr_t)a->src0 & 15) == 0 && ((uintptr_t)a->src1 & 15) == 0 && ((uintptr_t)a->dy & 15) == 0;
+    // the dominant layer shape has its own double-buffered kernel (srbh_hwgrad16_kernel.h)
+    static const int k16_wgs = getenv("SRBH_HWGRAD16_WGS") ? atoi(getenv("SRBH_HWGRAD16_WGS")) : 768;   // 0 = never
+    const bool k16 = b16 && k16_wgs >= 8 && k16_wgs <= WS_SLOTS && a->ksize == 3 && a->c0 == 16 && a->c1 == 0 && a->cout == 16 &&
+                     (a->W & 63) == 0 && (a->H & 3) == 0 && (p.ld0 & 3) == 0 && (((uintptr_t)a->src0 | (uintptr_t)a->dy) & 15) == 0;
+    if (k16) {
+        p.tiles_x = a->W / 64;
+        p.tiles_per_img = p.tiles_x * (a->H / 4);
+        p.ntiles = p.tiles_per_img * a->B;
+        p.tiles_per_xcd = (p.ntiles + 7) / 8;
+        const int per_xcd = p.tiles_per_xcd < k16_wgs / 8 ? p.tiles_per_xcd : k16_wgs / 8;
+        gx = per_xcd * 8;
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG16T::LDS_B)));
+        hipLaunchKernelGGL(hwgrad16_kernel, dim3(gx), dim3(256), WG16T::LDS_B, st, p);
+    } else
     if (b16 && can16) {
         if (a->ksize == 3) {
             SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_b16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WG16<3>::LDS_B)));
@@ -559,7 +576,7 @@ int wgrad_impl(const srbh_hwgrad_args* a, void* stream, bool b16, const char* wh
     constexpr int SLICES = 16;
     const int taps = a->ksize * a->ksize, nchunk = (cin + 15) / 16;
     const long U = (long)nob * nchunk * taps * 256;
-    float* tmp = a->ws + (long)512 * U;
+    float* tmp = a->ws + (long)WS_SLOTS * U;
     const int per = (gx + SLICES - 1) / SLICES;
     hipLaunchKernelGGL(hwgrad_reduce1_kernel, dim3((unsigned)((U + 255) / 256), SLICES), dim3(256), 0, st, a->ws, tmp, U, gx, per);
     SRBH_HIP(hipGetLastError());
@@ -576,7 +593,7 @@ extern "C" int srbh_hconv_wgrad_b16(const srbh_hwgrad_args* a, void* stream) { r
 
 extern "C" size_t srbh_hwgrad_ws_bytes(int cout, int cin, int ksize) {
     if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
-    return (size_t)(512 + 16) * ((cout + 15) / 16) * ((cin + 15) / 16) * ksize * ksize * 256 * sizeof(float);
+    return (size_t)(WS_SLOTS + 16) * ((cout + 15) / 16) * ((cin + 15) / 16) * ksize * ksize * 256 * sizeof(float);
 }
 
 extern "C" int srbh_relu_mask_mul(const float* g, const float* ref, float* out, long n, void* stream) {

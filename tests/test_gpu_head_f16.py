@@ -62,12 +62,13 @@ def b16(t):
     return t.bfloat16().double()
 
 
-@pytest.mark.parametrize("c0,c1,cout,ks,pre,hw", [(16, 0, 16, 3, True, (24, 70)), (64, 16, 16, 3, False, (17, 64)), (16, 0, 32, 3, True, (8, 130)),
+@pytest.mark.parametrize("c0,c1,cout,ks,pre,hw", [(16, 0, 16, 3, True, (8, 128)), (16, 0, 16, 3, False, (12, 64)), (16, 0, 16, 3, True, (24, 70)), (64, 16, 16, 3, False, (17, 64)), (16, 0, 32, 3, True, (8, 130)),
                                                    (80, 0, 16, 1, False, (9, 66)), (24, 0, 16, 3, False, (16, 16)), (16, 0, 7, 3, False, (16, 16))])
 def test_b16_wgrad_equals_wgrad_of_rounded_operands(c0, c1, cout, ks, pre, hw):
     """srbh_hconv_wgrad_b16: exactly the weight gradient of the bf16-rounded (transformed input, dY) pair, fp32-accumulated
     (<= 5e-6 against float64 on the same rounded values); ragged tile edges, the concat, the folded BN+ReLU, a half-filled
-    16-channel chunk (cin 24), and the fp32 fallback for a 7-channel output (then: no rounding at all)."""
+    16-channel chunk (cin 24), and the fp32 fallback for a 7-channel output (then: no rounding at all).  The first two shapes
+    (W % 64 == 0, H % 4 == 0, 16 -> 16) run the double-buffered hwgrad16_kernel, the others hwgrad_b16_kernel."""
     from srbh_amd import hrfuse as H
     from srbh_amd import hrfuse_autograd as AG
     Hh, Ww = hw

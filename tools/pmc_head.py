@@ -12,6 +12,7 @@ fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
 px = B * 256 * 256
 alg = {"hconv16_kernel<1>": ("forward 16->16 3x3, fp16 operands, + BN statistics (persistent kernel)", px * 128), "hconv16_kernel<2>": ("data gradient 16->16 3x3, bf16 operands (persistent kernel)", px * 128),
        "hconv_f32_kernel<1, 3, 1, 1>": ("forward 16->16 3x3, fp16 operands, + BN statistics", px * 128), "hconv_f32_kernel<1, 3, 1, 2>": ("data gradient 16->16 3x3, bf16 operands", px * 128),
+       "hwgrad16_kernel": ("weight gradient 16->16 3x3, bf16 operands (double-buffered kernel)", px * 128),
        "hwgrad_b16_kernel<3>": ("weight gradient 16->16 3x3, bf16 operands", px * 128), "hwgrad_f32_kernel<3>": ("weight gradient 16->16 3x3, fp32", px * 128),
        "bn_bwd_reduce_kernel": ("BatchNorm backward: per-channel sums of dy, dy*xhat", px * 128), "bn_bwd_apply_kernel": ("BatchNorm backward: dx", px * 192),
        "bn_add_relu_kernel": ("relu(bn(c) + identity)", px * 192)}

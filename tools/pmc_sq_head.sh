@@ -16,7 +16,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("/tmp/sqh/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-        if any(p in n for p in ("hconv", "hwgrad_b16", "bn_bwd", "bn_add_relu")):
+        if any(p in n for p in ("hconv", "hwgrad", "bn_bwd", "bn_add_relu")):
             agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("gpurun_out/sq_head_summary.txt", "w") as o:
     for n in sorted(agg):
