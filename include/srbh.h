@@ -255,6 +255,10 @@ int srbh_add_inplace(float* a, const float* b, long n, void* stream);
  * dy = g * [c*mask_scale + mask_shift > 0] (mask optional), xhat = (c - mean)*invstd (c optional: bias gradients) */
 int srbh_bn_bwd_reduce(const float* g, const float* c, const float* mean, const float* invstd, const float* mask_scale,
                        const float* mask_shift, long npix, int C, double* stats, void* stream);
+/* The same reduction with the block-closing ReLU backward folded in (SR/HRfuse.py:157): dy = g where relu_ref > 0, else 0; dy is also
+ * written to dz_out (may be NULL) for the skip / downsample branches.  C % 4 == 0, 16-byte aligned tensors. */
+int srbh_bn_bwd_reduce_relu(const float* g, const float* relu_ref, float* dz_out, const float* c, const float* mean,
+                            const float* invstd, long npix, int C, double* stats, void* stream);
 /* dgamma = sum dy*xhat, dbeta = sum dy, and the constants of dc = coef*(dy - k1 - xhat*k2) (coef may be NULL) */
 int srbh_bn_bwd_finalize(const double* stats, int C, double count, const float* gamma, const float* invstd,
                          float* dgamma, float* dbeta, float* coef, float* k1, float* k2, void* stream);

@@ -494,6 +494,81 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
     }
 }
 
+// ---- 16-byte forms of the two BatchNorm-backward passes (C % 4 == 0: every head layer).  A thread owns the 4-channel group
+// (flat index % (C/4)) of the pixels it walks, its per-channel constants live in registers, partial sums are flushed once per thread.
+// `relu_ref` / `dz_out` fold the block-closing ReLU backward into the reduce pass (dz = g where ref > 0; it is written for the
+// skip / downsample branches and read back by the apply pass): one 3-tensor elementwise launch per BasicBlock less.
+__global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const floatx4* __restrict__ g, const floatx4* __restrict__ c, const float* mean,
+                                                              const float* invstd, const float* ms, const float* mh,
+                                                              const floatx4* __restrict__ relu_ref, floatx4* __restrict__ dz_out,
+                                                              long n4, int C, double* stats /* [NSLOT][2][C] */) {
+    extern __shared__ float red[];   // [2][C]
+    for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) red[k] = 0.f;
+    __syncthreads();
+    const int C4 = C >> 2;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;          // host: a multiple of C/4 -> the channel group is fixed per thread
+    const int ch = (int)(i % C4) * 4;
+    floatx4 mn = {0.f, 0.f, 0.f, 0.f}, is = mn, msv = mn, mhv = mn;
+    if (c) { mn = *(const floatx4*)(mean + ch); is = *(const floatx4*)(invstd + ch); }
+    if (ms) { msv = *(const floatx4*)(ms + ch); mhv = *(const floatx4*)(mh + ch); }
+    floatx4 s = {0.f, 0.f, 0.f, 0.f}, q = s;
+    for (; i < n4; i += stride) {
+        floatx4 dy = g[i];
+        if (relu_ref) {
+            const floatx4 r = relu_ref[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dy[j] = r[j] > 0.f ? dy[j] : 0.f;
+            if (dz_out) dz_out[i] = dy;
+        }
+        if (c) {
+            const floatx4 cv = c[i];
+            if (ms) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dy[j] = cv[j] * msv[j] + mhv[j] > 0.f ? dy[j] : 0.f;
+            }
+            q += dy * ((cv - mn) * is);
+        }
+        s += dy;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        atomicAdd(&red[ch + j], s[j]);
+        atomicAdd(&red[C + ch + j], q[j]);
+    }
+    __syncthreads();
+    double* slot = stats + (long)(blockIdx.x % NSLOT) * 2 * C;
+    for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) atomicAdd(slot + k, (double)red[k]);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const floatx4* __restrict__ g, const floatx4* __restrict__ c, const float* mean,
+                                                             const float* invstd, const float* ms, const float* mh, const float* coef,
+                                                             const float* k1, const float* k2, floatx4* __restrict__ out, long n4, int C) {
+    const int C4 = C >> 2;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const int ch = (int)(i % C4) * 4;
+    const floatx4 mn = *(const floatx4*)(mean + ch), is = *(const floatx4*)(invstd + ch), cf = *(const floatx4*)(coef + ch),
+                  a1 = *(const floatx4*)(k1 + ch), a2 = *(const floatx4*)(k2 + ch);
+    floatx4 msv = {0.f, 0.f, 0.f, 0.f}, mhv = msv;
+    if (ms) { msv = *(const floatx4*)(ms + ch); mhv = *(const floatx4*)(mh + ch); }
+    for (; i < n4; i += stride) {
+        floatx4 dy = g[i];
+        const floatx4 cv = c[i];
+        if (ms) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dy[j] = cv[j] * msv[j] + mhv[j] > 0.f ? dy[j] : 0.f;
+        }
+        out[i] = cf * (dy - a1 - ((cv - mn) * is) * a2);
+    }
+}
+
+// grid for the 16-byte forms: a multiple of C/4 threads in total (blockDim 256, C/4 in {1, 2, 4, 8, 16} divides it)
+int grid4_for(long n4) {
+    long b = (n4 + 255) / 256;
+    return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
+}
+
 // PixelShuffle(2) inverse: g_ps [B][2H][2W][C] -> g [B][H][W][4C], channel 4c + 2i + j <- (2y+i, 2x+j, c)
 __global__ void ps2_inverse_kernel(const float* __restrict__ gps, float* __restrict__ g, int B, int H, int W, int C) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -612,18 +687,40 @@ extern "C" int srbh_add_inplace(float* a, const float* b, long n, void* stream) 
     return SRBH_OK;
 }
 
+static int bn_bwd_reduce_impl(const float* g, const float* relu_ref, float* dz_out, const float* c, const float* mean, const float* invstd,
+                              const float* mask_scale, const float* mask_shift, long npix, int C, double* stats, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = zero_async(stats, (size_t)NSLOT * 2 * C * sizeof(double), st)) return rc;
+    const bool v4 = (C & 3) == 0 && (256 % (C >> 2)) == 0 && (((uintptr_t)g | (uintptr_t)c | (uintptr_t)mean | (uintptr_t)invstd |
+                     (uintptr_t)mask_scale | (uintptr_t)mask_shift) & 15) == 0;
+    if (v4) {
+        const long n4 = npix * (C >> 2);
+        hipLaunchKernelGGL(bn_bwd_reduce4_kernel, dim3(grid4_for(n4)), dim3(256), 2 * C * sizeof(float), st, (const floatx4*)g,
+                           (const floatx4*)c, mean, invstd, mask_scale, mask_shift, (const floatx4*)relu_ref, (floatx4*)dz_out, n4, C, stats);
+    } else {
+        SRBH_REQUIRE(!relu_ref, "srbh_bn_bwd_reduce_relu: needs the 16-byte form (C %% 4 == 0, aligned)");
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(npix * C)), dim3(256), 2 * C * sizeof(float), st, g, c, mean,
+                           invstd, mask_scale, mask_shift, npix, C, stats);
+    }
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
 extern "C" int srbh_bn_bwd_reduce(const float* g, const float* c, const float* mean, const float* invstd,
                                   const float* mask_scale, const float* mask_shift, long npix, int C, double* stats,
                                   void* stream) {
     SRBH_REQUIRE(g && stats && npix > 0 && C > 0 && C <= 64, "srbh_bn_bwd_reduce: bad arguments");
     SRBH_REQUIRE(!c || (mean && invstd), "srbh_bn_bwd_reduce: c needs mean/invstd");
     SRBH_REQUIRE(!mask_scale || (c && mask_shift), "srbh_bn_bwd_reduce: mask needs c and mask_shift");
-    hipStream_t st = (hipStream_t)stream;
-    if (int rc = zero_async(stats, (size_t)NSLOT * 2 * C * sizeof(double), st)) return rc;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(npix * C)), dim3(256), 2 * C * sizeof(float), st, g, c, mean,
-                       invstd, mask_scale, mask_shift, npix, C, stats);
-    SRBH_HIP(hipGetLastError());
-    return SRBH_OK;
+    return bn_bwd_reduce_impl(g, nullptr, nullptr, c, mean, invstd, mask_scale, mask_shift, npix, C, stats, stream);
+}
+
+extern "C" int srbh_bn_bwd_reduce_relu(const float* g, const float* relu_ref, float* dz_out, const float* c, const float* mean,
+                                       const float* invstd, long npix, int C, double* stats, void* stream) {
+    SRBH_REQUIRE(g && relu_ref && stats && npix > 0 && C > 0 && C <= 64 && (C & 3) == 0, "srbh_bn_bwd_reduce_relu: bad arguments (C % 4 == 0)");
+    SRBH_REQUIRE(!c || (mean && invstd), "srbh_bn_bwd_reduce_relu: c needs mean/invstd");
+    SRBH_REQUIRE((((uintptr_t)g | (uintptr_t)relu_ref | (uintptr_t)dz_out | (uintptr_t)c) & 15) == 0, "srbh_bn_bwd_reduce_relu: 16-byte aligned tensors");
+    return bn_bwd_reduce_impl(g, relu_ref, dz_out, c, mean, invstd, nullptr, nullptr, npix, C, stats, stream);
 }
 
 extern "C" int srbh_bn_bwd_finalize(const double* stats, int C, double count, const float* gamma, const float* invstd,
@@ -640,6 +737,12 @@ extern "C" int srbh_bn_bwd_apply(const float* g, const float* c, const float* me
                                  const float* mask_scale, const float* mask_shift, const float* coef, const float* k1,
                                  const float* k2, float* out, long npix, int C, void* stream) {
     SRBH_REQUIRE(g && c && mean && invstd && coef && k1 && k2 && out && npix > 0 && C > 0, "srbh_bn_bwd_apply: bad arguments");
+    if ((C & 3) == 0 && (256 % (C >> 2)) == 0 && (((uintptr_t)g | (uintptr_t)c | (uintptr_t)out | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)coef |
+                                                    (uintptr_t)k1 | (uintptr_t)k2 | (uintptr_t)mask_scale | (uintptr_t)mask_shift) & 15) == 0) {
+        const long n4 = npix * (C >> 2);
+        hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(grid4_for(n4)), dim3(256), 0, (hipStream_t)stream, (const floatx4*)g, (const floatx4*)c,
+                           mean, invstd, mask_scale, mask_shift, coef, k1, k2, (floatx4*)out, n4, C);
+    } else
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * C)), dim3(256), 0, (hipStream_t)stream, g, c, mean,
                        invstd, mask_scale, mask_shift, coef, k1, k2, out, npix * C, C);
     SRBH_HIP(hipGetLastError());

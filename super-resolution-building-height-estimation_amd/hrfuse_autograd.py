@@ -117,16 +117,27 @@ def channel_sum(g):
     return out
 
 
-def bn_backward(g, c, mean, invstd, gamma, mask, training):
-    """BatchNorm (+ optional ReLU mask [c*ms+mh > 0]) backward.  Returns (dc, dgamma, dbeta)."""
+def bn_backward(g, c, mean, invstd, gamma, mask, training, relu_ref=None):
+    """BatchNorm (+ optional ReLU mask [c*ms+mh > 0]) backward.  Returns (dc, dgamma, dbeta).
+    relu_ref: the gradient first passes the block-closing ReLU (dz = g where relu_ref > 0) inside the reduce pass; returns
+    (dc, dgamma, dbeta, dz)."""
     L = _lib.lib()
     B, Cc, Hh, Ww = c.shape
     n = B * Hh * Ww
     dev = c.device
     st = _stats_buf(Cc, dev)
     ms, mh = (mask[0].data_ptr(), mask[1].data_ptr()) if mask is not None else (None, None)
-    _lib.check(L.srbh_bn_bwd_reduce(g.data_ptr(), c.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ms, mh, n, Cc,
-                                    st.data_ptr(), _lib.stream_ptr()), "bn_bwd_reduce")
+    dz = None
+    if relu_ref is not None and Cc % 4 == 0 and mask is None:
+        dz = torch.empty_like(relu_ref)
+        _lib.check(L.srbh_bn_bwd_reduce_relu(g.data_ptr(), relu_ref.data_ptr(), dz.data_ptr(), c.data_ptr(), mean.data_ptr(),
+                                             invstd.data_ptr(), n, Cc, st.data_ptr(), _lib.stream_ptr()), "bn_bwd_reduce_relu")
+        g = dz
+    else:
+        if relu_ref is not None:
+            g = dz = relu_mask(g, relu_ref)
+        _lib.check(L.srbh_bn_bwd_reduce(g.data_ptr(), c.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ms, mh, n, Cc,
+                                        st.data_ptr(), _lib.stream_ptr()), "bn_bwd_reduce")
     dgamma = torch.empty(Cc, dtype=torch.float32, device=dev)
     dbeta = torch.empty(Cc, dtype=torch.float32, device=dev)
     coef = torch.empty(Cc, dtype=torch.float32, device=dev)
@@ -149,6 +160,8 @@ def bn_backward(g, c, mean, invstd, gamma, mask, training):
     dc = H.empty_nhwc(B, Cc, Hh, Ww, dev)
     _lib.check(L.srbh_bn_bwd_apply(g.data_ptr(), c.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ms, mh, coef.data_ptr(),
                                    k1.data_ptr(), k2.data_ptr(), dc.data_ptr(), n, Cc, _lib.stream_ptr()), "bn_bwd_apply")
+    if relu_ref is not None:
+        return dc, dgamma, dbeta, dz
     return dc, dgamma, dbeta
 
 
@@ -255,9 +268,8 @@ class _BasicBlockFn(torch.autograd.Function):
         if has_ds:
             d, md, idd, wd, gd = sv[nsrc + 13:]
         caches = blk.__dict__.setdefault("_srbh_gcaches", [_PackedGrad(), _PackedGrad(), _PackedGrad()])
-        dz = relu_mask(H.to_nhwc(g), out)                                   # through the final ReLU
-        # bn2 -> conv2
-        dc2, dg2, db2 = bn_backward(dz, c2, m2, i2, g2, None, tr)
+        # through the final ReLU (folded into bn2's reduce pass) -> bn2 -> conv2
+        dc2, dg2, db2, dz = bn_backward(H.to_nhwc(g), c2, m2, i2, g2, None, tr, relu_ref=out)
         dw2 = conv_wgrad([c1], (s1, h1, True), dc2, w2.shape[0], 3)
         da1 = conv_dgrad(dc2, w2, caches[1])
         # relu -> bn1 -> conv1   (mask: bn1(c1) > 0)
