@@ -205,6 +205,11 @@ size_t srbh_hpack_h16_bytes(int cout, int cin, int ksize);
  * bf16 keeps fp32's exponent).  The pack and the conv must use the same setting. */
 int srbh_hpack_conv_h16(const float* w_oihw, int cout, int cin, int ksize, int transpose_flip, int bf16, void* packed, void* stream);
 int srbh_hconv_h16(const srbh_hconv_args* a, int bf16, void* stream);
+/* The entry of a BasicBlock with a downsample branch (SR/HRfuse.py:142-159): conv1 (3x3, `c1`) and downsample[0] (1x1, `ds`) read the
+ * SAME input -- the widest tensor of each head.  One fused pass (the 1x1 is the centre tap with other weights) when both produce 16
+ * channels from the same sources with 16-aligned channel counts, no pre-affine, W % 64 == 0, H % 4 == 0; otherwise exactly the two
+ * srbh_hconv_h16 launches.  Same results either way (same operand rounding, fp32 accumulation). */
+int srbh_hconv_entry_h16(const srbh_hconv_args* c1, const srbh_hconv_args* ds, int bf16, void* stream);
 
 /* training-mode nn.BatchNorm2d statistics (SR/HRfuse.py:124,132,135): partial sums -> biased batch variance ->
  * scale = gamma/sqrt(var+eps), shift = beta - mean*scale; running stats updated with `momentum` and the unbiased

@@ -1,0 +1,186 @@
+// srbh_hconv_entry_kernel.h -- the ENTRY of a BasicBlock with a downsample branch (SR/HRfuse.py:142-159: conv1 = 3x3 and
+// downsample[0] = 1x1 over the SAME input, the widest tensor of each head: 64 channels in HRfeature, 16 + 16 concatenated in the fuse
+// heads) as ONE pass in the shape of hconv16_kernel (included by srbh_head.hip after it).
+//
+// The 1x1 conv is the centre tap with other weights: one more MFMA per (tile, 16-channel chunk, 16-pixel group) on the B fragment the
+// 3x3 already holds.  The input is read once instead of twice (the template ran two launches, each one workgroup per tile).  Walk,
+// stages and statistics as hconv16_kernel; the pipeline unit is (tile, chunk): while chunk c is multiplied, chunk c+1 (or chunk 0 of the
+// next tile) is in flight.  All chunks' weights sit in LDS (A fragments, 8 bytes per lane and tap: (9 + 1) x 512 bytes per chunk),
+// loaded once per workgroup.  fp16 / bf16 operands, fp32 accumulate, same rounding as the template -> same numbers per output.
+// Restrictions (host falls back to two template launches): 16 output channels each, c0 % 16 == 0, c1 % 16 == 0, <= 5 chunks, no
+// pre-affine, W % 64 == 0, H % 4 == 0, 4-aligned strides.
+struct EParams {
+    HParams a;                 // conv1: sources, bias / post / relu, out, stats ; a.w = 3x3 pack
+    const float* w2;           // 1x1 pack (srbh_hpack_conv_h16 of downsample[0])
+    const float* bias2; const float* post2_scale; const float* post2_shift;
+    float* out2; int out2_ld, out2_coff;
+    double* stats2;
+    int nchunk;
+};
+
+template <int OPT>
+__global__ __launch_bounds__(256, 3) void hconv_entry_kernel(const EParams e) {
+    static_assert(OPT == 1 || OPT == 2, "16-bit operand forms only");
+    const HParams& p = e.a;
+    constexpr int ROWS = 6, COLS = 66, NIT = (ROWS * COLS * 4 + 255) / 256;
+    constexpr int STAGE_B = ROWS * COLS * 32;
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    char* const s_base = (char*)hsm;                              // 2 stages, then the weights
+    char* const s_w = s_base + 2 * STAGE_B;                       // [chunk][10 taps: 9 of conv1, then the 1x1][64 lanes] 8 bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kk = lane >> 4;
+    const int cg = tid & 3;
+    const int nchunk = e.nchunk;
+    const int t_end = min((int)(blockIdx.x & 7) * p.tiles_per_xcd + p.tiles_per_xcd, p.ntiles);
+    const int t_first = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3), t_step = gridDim.x >> 3;
+
+    for (int u = tid; u < nchunk * 10 * 64; u += 256) {
+        const int c = u / 640, r = u - c * 640, tap = r >> 6, ln = r & 63;
+        const short4v v = tap < 9 ? ((const short4v*)p.w)[(c * 9 + tap) * 64 + ln] : ((const short4v*)e.w2)[c * 64 + ln];
+        *(short4v*)(s_w + (long)u * 8) = v;
+    }
+    const floatx4 e_bias = p.bias ? *(const floatx4*)(p.bias + kk * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+    const floatx4 e_sc = p.post_scale ? *(const floatx4*)(p.post_scale + kk * 4) : floatx4{1.f, 1.f, 1.f, 1.f};
+    const floatx4 e_sh = p.post_scale ? *(const floatx4*)(p.post_shift + kk * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+    const floatx4 d_bias = e.bias2 ? *(const floatx4*)(e.bias2 + kk * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+    const floatx4 d_sc = e.post2_scale ? *(const floatx4*)(e.post2_scale + kk * 4) : floatx4{1.f, 1.f, 1.f, 1.f};
+    const floatx4 d_sh = e.post2_scale ? *(const floatx4*)(e.post2_shift + kk * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+    int upix[NIT], ulds[NIT];       // window pixel offset r*W + col ; byte offset inside a stage (h16_off)
+    unsigned urow = 0, ucol1 = 0;
+    {
+        int r = 0, col = tid >> 2;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            upix[it] = r * p.W + col;
+            ulds[it] = (r * COLS + col) * 32 + ((cg ^ ((col >> 2) & 2)) << 3);
+            urow |= (unsigned)r << (3 * it);
+            if (col == 0) ucol1 |= 1u << it;
+            if (col == COLS - 1) ucol1 |= 1u << (8 + it);
+            const bool wrapped = col + 64 >= COLS;
+            col += wrapped ? 64 - COLS : 64;
+            r += wrapped ? 1 : 0;
+        }
+    }
+    const bool last_unit = tid + (NIT - 1) * 256 < ROWS * COLS * 4;
+    int bbase[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) bbase[dx] = (wave * COLS + dx + l15) * 32 + ((kk ^ ((((dx + l15) >> 3) & 1) << 1)) << 3);
+
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f}, dsum[4] = {0.f, 0.f, 0.f, 0.f}, dsq[4] = {0.f, 0.f, 0.f, 0.f};
+    floatx4 ld[NIT];
+    auto issue = [&](const int t, const int c) {
+        const int img = t / p.tiles_per_img;
+        const int trem = t - img * p.tiles_per_img;
+        const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+        const int Y0 = ty * 4, X0 = tx * 64;
+        const bool in0 = c * 16 < p.c0;
+        const int ldp = in0 ? p.ld0 : p.ld1;
+        const float* tp = (in0 ? p.src0 + c * 16 : p.src1 + (c * 16 - p.c0)) + (((long)img * p.H + (Y0 - 1)) * p.W + (X0 - 1)) * ldp + cg * 4;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = (urow >> (3 * it)) & 7;
+            bool ok = (unsigned)(Y0 - 1 + r) < (unsigned)p.H;
+            if ((ucol1 >> it) & 1) ok = ok && X0 > 0;
+            if ((ucol1 >> (8 + it)) & 1) ok = ok && X0 + 64 < p.W;
+            if (it == NIT - 1) ok = ok && last_unit;
+            ld[it] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (ok) ld[it] = *(const floatx4*)(tp + upix[it] * ldp);
+        }
+    };
+    auto commit = [&](char* stage) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (it < NIT - 1 || last_unit) {
+                const float t4[4] = {ld[it][0], ld[it][1], ld[it][2], ld[it][3]};
+                *(short4v*)(stage + ulds[it]) = round4<OPT>(t4);
+            }
+        }
+    };
+
+    if (t_first < t_end) issue(t_first, 0);
+    __syncthreads();                   // the weights are in LDS
+    int buf = 0;
+    for (int t = t_first; t < t_end; t += t_step) {
+        floatx4 acc[4], acd[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = acd[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < nchunk; ++c, buf ^= 1) {
+            char* const stage = s_base + buf * STAGE_B;
+            commit(stage);
+            if (c + 1 < nchunk) issue(t, c + 1);
+            else if (t + t_step < t_end) issue(t + t_step, 0);
+            __syncthreads();           // stage `buf` complete; every wave is past the MFMAs of the unit before (other stage)
+            const char* wc = s_w + ((long)c * 640 + lane) * 8;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap - dy * 3;
+                const short4v wa = *(const short4v*)(wc + tap * 512);
+                short4v wd;
+                if (tap == 4) wd = *(const short4v*)(wc + 9 * 512);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const short4v b = *(const short4v*)(stage + bbase[dx] + (dy * COLS + i * 16) * 32);
+                    if constexpr (OPT == 1) {
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, wa), __builtin_bit_cast(half4, b), acc[i], 0, 0, 0);
+                        if (tap == 4) acd[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, wd), __builtin_bit_cast(half4, b), acd[i], 0, 0, 0);
+                    } else {
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa, b, acc[i], 0, 0, 0);
+                        if (tap == 4) acd[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wd, b, acd[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const int img = t / p.tiles_per_img;
+        const int trem = t - img * p.tiles_per_img;
+        const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+        const long pix0 = ((long)img * p.H + ty * 4 + wave) * p.W + tx * 64 + l15;
+        float* const o1 = p.out + pix0 * p.out_ld + p.out_coff + kk * 4;
+        float* const o2 = e.out2 + pix0 * e.out2_ld + e.out2_coff + kk * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            floatx4 v = acc[i];
+            if (p.bias) v += e_bias;
+            if (p.post_scale) v = v * e_sc + e_sh;
+            if (p.post_relu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            floatx4 d = acd[i];
+            if (e.bias2) d += d_bias;
+            if (e.post2_scale) d = d * d_sc + d_sh;
+            if (p.stats) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ssum[q] += v[q]; ssq[q] += v[q] * v[q];
+                    dsum[q] += d[q]; dsq[q] += d[q] * d[q];
+                }
+            }
+            *(floatx4*)(o1 + i * 16 * p.out_ld) = v;
+            *(floatx4*)(o2 + i * 16 * e.out2_ld) = d;
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        float* red = hsm;                      // [4 waves][4 rows: sum1, sq1, sum2, sq2][16 channels]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v4[4] = {ssum[q], ssq[q], dsum[q], dsq[q]};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a = v4[k];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) a += __shfl_xor(a, m);
+                if (l15 == 0) red[(wave * 4 + k) * 16 + kk * 4 + q] = a;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int k = tid >> 4, oc = tid & 15;
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += (double)red[(w * 4 + k) * 16 + oc];
+            double* slot = (k < 2 ? p.stats : e.stats2) + (long)(blockIdx.x % NSLOT) * 2 * 16;
+            atomicAdd(slot + (k & 1) * 16 + oc, v);
+        }
+    }
+}

@@ -576,6 +576,7 @@ __global__ void nearest2x_kernel(const floatx4* __restrict__ src, floatx4* __res
 }
 
 #include "srbh_hconv16_kernel.h"
+#include "srbh_hconv_entry_kernel.h"
 
 template <int NOB, int KS, int RPW, int OPT = 0>
 int launch_hconv(HParams& p, int B, int H, int W, hipStream_t st) {
@@ -732,6 +733,61 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
 
 extern "C" int srbh_hconv_f32(const srbh_hconv_args* a, void* stream) { return hconv_impl(a, stream, 0); }
 extern "C" int srbh_hconv_h16(const srbh_hconv_args* a, int bf16, void* stream) { return hconv_impl(a, stream, bf16 ? 2 : 1); }
+
+// conv1 (3x3) + downsample[0] (1x1) of a BasicBlock entry over the same input: one fused pass when the shapes allow
+// (srbh_hconv_entry_kernel.h), otherwise the two template launches -- the results are the same either way.
+extern "C" int srbh_hconv_entry_h16(const srbh_hconv_args* c1, const srbh_hconv_args* ds, int bf16, void* stream) {
+    SRBH_REQUIRE(c1 && ds, "srbh_hconv_entry_h16: null arguments");
+    static const int wgs = getenv("SRBH_HCONV_ENTRY_WGS") ? atoi(getenv("SRBH_HCONV_ENTRY_WGS")) : 768;      // 0 = never fuse
+    const int cin = c1->c0 + c1->c1;
+    const int ld0 = c1->src0_ld > 0 ? c1->src0_ld : c1->c0, ld1 = c1->src1_ld > 0 ? c1->src1_ld : c1->c1;
+    const int dld0 = ds->src0_ld > 0 ? ds->src0_ld : ds->c0, dld1 = ds->src1_ld > 0 ? ds->src1_ld : ds->c1;
+    const bool same = c1->src0 == ds->src0 && c1->src1 == ds->src1 && c1->c0 == ds->c0 && c1->c1 == ds->c1 && ld0 == dld0 && ld1 == dld1 &&
+                      c1->B == ds->B && c1->H == ds->H && c1->W == ds->W;
+    const int out1_ld = c1->out_ld > 0 ? c1->out_ld : c1->cout, out2_ld = ds->out_ld > 0 ? ds->out_ld : ds->cout;
+    const bool plain = !c1->pre_scale && !c1->pre_relu && !ds->pre_scale && !ds->pre_relu && !c1->pixelshuffle2 && !ds->pixelshuffle2 &&
+                       !c1->res1 && !ds->res1 && !c1->res2 && !ds->res2 && !c1->post_lrelu && !ds->post_lrelu && !ds->post_relu &&
+                       !c1->io_h16 && !ds->io_h16 && (!c1->stats == !ds->stats);
+    const bool shape = c1->ksize == 3 && ds->ksize == 1 && c1->cout == 16 && ds->cout == 16 && c1->c0 > 0 && (c1->c0 & 15) == 0 &&
+                       (c1->c1 & 15) == 0 && cin <= 80 && (c1->c1 == 0 || c1->src1) && c1->B > 0 && (c1->W & 63) == 0 && (c1->H & 3) == 0 &&
+                       (ld0 & 3) == 0 && (c1->c1 == 0 || (ld1 & 3) == 0) && (out1_ld & 3) == 0 && (out2_ld & 3) == 0 &&
+                       (c1->out_coff & 3) == 0 && (ds->out_coff & 3) == 0 &&
+                       (((uintptr_t)c1->src0 | (uintptr_t)c1->src1 | (uintptr_t)c1->out | (uintptr_t)ds->out) & 15) == 0;
+    if (!(wgs >= 8 && same && plain && shape && c1->src0 && c1->w && ds->w && c1->out && ds->out)) {
+        if (int rc = hconv_impl(c1, stream, bf16 ? 2 : 1)) return rc;
+        return hconv_impl(ds, stream, bf16 ? 2 : 1);
+    }
+    SRBH_REQUIRE(!c1->post_scale || c1->post_shift, "srbh_hconv_entry_h16: post_scale needs post_shift");
+    SRBH_REQUIRE(!ds->post_scale || ds->post_shift, "srbh_hconv_entry_h16: post_scale needs post_shift");
+    hipStream_t st = (hipStream_t)stream;
+    EParams e;
+    HParams& p = e.a;
+    p.src0 = c1->src0; p.src1 = c1->src1; p.c0 = c1->c0; p.c1 = c1->c1;
+    p.pre_scale = nullptr; p.pre_shift = nullptr; p.pre_relu = 0;
+    p.w = c1->w; p.bias = c1->bias; p.cout = 16; p.cout_store = 16;
+    p.B = c1->B; p.H = c1->H; p.W = c1->W; p.ps2 = 0;
+    p.out = c1->out; p.stats = c1->stats;
+    p.ld0 = ld0; p.ld1 = ld1; p.out_ld = out1_ld; p.out_coff = c1->out_coff;
+    p.post_lrelu = 0; p.res1 = nullptr; p.res1_ld = 0; p.res1_scale = 1.f; p.res2 = nullptr; p.res2_ld = 0; p.res2_scale = 1.f;
+    p.post_scale = c1->post_scale; p.post_shift = c1->post_shift; p.post_relu = c1->post_relu; p.io_h16 = 0;
+    p.tiles_x = c1->W / 64;
+    p.tiles_per_img = p.tiles_x * (c1->H / 4);
+    p.ntiles = p.tiles_per_img * c1->B;
+    p.tiles_per_xcd = (p.ntiles + 7) / 8;
+    e.w2 = ds->w; e.bias2 = ds->bias; e.post2_scale = ds->post_scale; e.post2_shift = ds->post_shift;
+    e.out2 = ds->out; e.out2_ld = out2_ld; e.out2_coff = ds->out_coff; e.stats2 = ds->stats;
+    e.nchunk = cin / 16;
+    if (c1->stats) {
+        if (int rc = zero_async(c1->stats, srbh_bn_stats_bytes(16), st)) return rc;
+        if (int rc = zero_async(ds->stats, srbh_bn_stats_bytes(16), st)) return rc;
+    }
+    const int per_xcd = p.tiles_per_xcd < wgs / 8 ? p.tiles_per_xcd : wgs / 8;
+    const int lds_b = 2 * 6 * 66 * 32 + e.nchunk * 640 * 8;
+    if (bf16) hipLaunchKernelGGL(hconv_entry_kernel<2>, dim3(per_xcd * 8), dim3(256), lds_b, st, e);
+    else hipLaunchKernelGGL(hconv_entry_kernel<1>, dim3(per_xcd * 8), dim3(256), lds_b, st, e);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
 
 extern "C" int srbh_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta,
                                 float eps, float momentum, float* running_mean, float* running_var, float* scale,

@@ -125,8 +125,8 @@ class _PackedConv:
         return self.w, self.b
 
 
-def hconv(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_stats=False, post=None, res=None,
-          post_relu=False, out_h16=False):
+def _hconv_args(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_stats=False, post=None, res=None,
+                post_relu=False, out_h16=False):
     """conv(cat(srcs)) through srbh_hconv_f32.  srcs: list of 1..2 NHWC tensors; pre=(scale, shift, relu) is
     applied to srcs[0]; returns (out, stats) with out NHWC and stats the partial-sum buffer or None.
     Epilogue extras (inference fusion): post=(scale, shift) per output channel, res = NHWC tensor added, post_relu.
@@ -169,11 +169,32 @@ def hconv(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_
     if want_stats:
         stats = torch.empty(L.srbh_bn_stats_bytes((cout + 15) // 16 * 16) // 8, dtype=torch.float64, device=x0.device)
         a.stats = stats.data_ptr()
+    return a, out, stats, h16, (w, b)          # (w, b: keep the packed buffers alive until the launch is issued)
+
+
+def hconv(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_stats=False, post=None, res=None,
+          post_relu=False, out_h16=False):
+    """conv(cat(srcs)) through srbh_hconv_f32 / srbh_hconv_h16: see _hconv_args for the arguments; returns (out, stats)."""
+    L = _lib.lib()
+    a, out, stats, h16, _keep = _hconv_args(srcs, conv, packed, pre, ps2, want_stats, post, res, post_relu, out_h16)
     if h16:
         _lib.check(L.srbh_hconv_h16(C.byref(a), 0, _lib.stream_ptr()), "hconv_h16")
     else:
         _lib.check(L.srbh_hconv_f32(C.byref(a), _lib.stream_ptr()), "hconv_f32")
     return out, stats
+
+
+def hconv_entry(srcs, conv1, packed1, convd, packedd, want_stats=False, postd=None):
+    """The entry of a BasicBlock with a downsample branch: conv1 (3x3) and downsample[0] (1x1) over the same cat(srcs) in ONE
+    libsrbh call (srbh_hconv_entry_h16: one fused pass over the input when the shapes allow, else the two launches; 16-bit operand
+    modes only).  Returns (c1, stats1, d, statsd); postd = (scale, shift) of the downsample BatchNorm in inference."""
+    L = _lib.lib()
+    a1, c1, st1, h16, _k1 = _hconv_args(srcs, conv1, packed1, want_stats=want_stats)
+    a2, d, st2, _, _k2 = _hconv_args(srcs, convd, packedd, want_stats=want_stats, post=postd)
+    if not h16:
+        raise RuntimeError("hconv_entry: fp16-operand mode only")
+    _lib.check(L.srbh_hconv_entry_h16(C.byref(a1), C.byref(a2), 0, _lib.stream_ptr()), "hconv_entry_h16")
+    return c1, st1, d, st2
 
 
 # ---- synchronised BatchNorm statistics for data-parallel training -------------------------------------------------------
@@ -395,13 +416,25 @@ class BasicBlock(nn.Module):
             return out
         if any(t.dtype != torch.float32 for t in srcs):
             raise RuntimeError("libsrbh BasicBlock: fp16 activations outside the fp16 inference chain")
-        c1, st1 = hconv(srcs, self.conv1, self._p1, want_stats=tr)
+        fuse_entry = self.downsample is not None and head_h16()      # conv1 + the 1x1 downsample conv: one pass over the input
+        infer = not tr and self.bn2.num_features % 16 == 0
+        d = std = None
+        if fuse_entry:
+            sd = hd = None
+            if infer:
+                sd, hd, _, _ = bn_scale_shift(self.downsample[1], None, n, False)
+            c1, st1, d, std = hconv_entry(srcs, self.conv1, self._p1, self.downsample[0], self._pd, want_stats=tr,
+                                          postd=(sd, hd) if infer else None)
+        else:
+            c1, st1 = hconv(srcs, self.conv1, self._p1, want_stats=tr)
         s1, h1, _, _ = bn_scale_shift(self.bn1, st1, n, tr)
-        if not tr and self.bn2.num_features % 16 == 0:
+        if infer:
             # inference: BatchNorm is a per-channel affine -> bn2, the skip connection and the final ReLU run in conv2's
             # epilogue (and the downsample BatchNorm in the 1x1 conv's): no c2 round trip, no separate elementwise pass
             s2, h2, _, _ = bn_scale_shift(self.bn2, None, n, False)
-            if self.downsample is not None:
+            if fuse_entry:
+                idt = d
+            elif self.downsample is not None:
                 sd, hd, _, _ = bn_scale_shift(self.downsample[1], None, n, False)
                 idt, _ = hconv(srcs, self.downsample[0], self._pd, post=(sd, hd))
             else:
@@ -413,7 +446,8 @@ class BasicBlock(nn.Module):
         c2, st2 = hconv([c1], self.conv2, self._p2, pre=(s1, h1, True), want_stats=tr)
         s2, h2, _, _ = bn_scale_shift(self.bn2, st2, n, tr)
         if self.downsample is not None:
-            d, std = hconv(srcs, self.downsample[0], self._pd, want_stats=tr)
+            if not fuse_entry:
+                d, std = hconv(srcs, self.downsample[0], self._pd, want_stats=tr)
             sd, hd, _, _ = bn_scale_shift(self.downsample[1], std, n, tr)
             return bn_add_relu(c2, s2, h2, d, sd, hd)
         if len(srcs) != 1:

@@ -238,7 +238,11 @@ class _BasicBlockFn(torch.autograd.Function):
         srcs = [H.to_nhwc(x0.detach())] + ([H.to_nhwc(x1.detach())] if x1 is not None else [])
         B, _, Hh, Ww = srcs[0].shape
         n = B * Hh * Ww
-        c1, st1 = H.hconv(srcs, blk.conv1, blk._p1, want_stats=tr)
+        fuse_entry = blk.downsample is not None and H.head_h16()     # conv1 + the 1x1 downsample conv: one pass over the input
+        if fuse_entry:
+            c1, st1, d_f, std_f = H.hconv_entry(srcs, blk.conv1, blk._p1, blk.downsample[0], blk._pd, want_stats=tr)
+        else:
+            c1, st1 = H.hconv(srcs, blk.conv1, blk._p1, want_stats=tr)
         s1, h1, m1, i1 = H.bn_scale_shift(blk.bn1, st1, n, tr)
         c2, st2 = H.hconv([c1], blk.conv2, blk._p2, pre=(s1, h1, True), want_stats=tr)
         s2, h2, m2, i2 = H.bn_scale_shift(blk.bn2, st2, n, tr)
@@ -246,7 +250,7 @@ class _BasicBlockFn(torch.autograd.Function):
             (m1, i1), (m2, i2) = _bn_eval_stats(blk.bn1), _bn_eval_stats(blk.bn2)
         d = md = idd = None
         if blk.downsample is not None:
-            d, std = H.hconv(srcs, blk.downsample[0], blk._pd, want_stats=tr)
+            d, std = (d_f, std_f) if fuse_entry else H.hconv(srcs, blk.downsample[0], blk._pd, want_stats=tr)
             sd, hd, md, idd = H.bn_scale_shift(blk.downsample[1], std, n, tr)
             if not tr:
                 md, idd = _bn_eval_stats(blk.downsample[1])

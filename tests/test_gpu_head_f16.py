@@ -215,3 +215,30 @@ def test_fp16_activation_chain_within_tolerance(monkeypatch):
         assert a.dtype == torch.float32
         assert O.rel_l2(a.cpu(), b) <= TOL_HEAD, name
         assert 0 < O.rel_l2(a.cpu(), c.cpu()) <= TOL_HEAD, name        # (> 0: the fp16 chain really ran)
+
+
+@pytest.mark.parametrize("c0,c1,hw,stats", [(64, 0, (8, 64), True), (16, 16, (12, 128), False), (64, 16, (4, 64), True), (16, 0, (8, 70), False)])
+def test_block_entry_fused_conv_pair_equals_the_two_convs(c0, c1, hw, stats):
+    """srbh_hconv_entry_h16: conv1 (3x3) + downsample[0] (1x1) of a BasicBlock entry over the same (concatenated) input in one pass
+    (srbh_hconv_entry_kernel.h) must give the numbers of the two separate fp16-operand convs: outputs <= 1e-6 (same rounding, same
+    accumulation order per pixel), BatchNorm partial sums <= 1e-6 relative.  The last shape (W = 70) takes the fallback inside the call."""
+    from srbh_amd import hrfuse as H
+    Hh, Ww = hw
+    conv1 = torch.nn.Conv2d(c0 + c1, 16, 3, 1, 1, bias=False).to(DEV)
+    convd = torch.nn.Conv2d(c0 + c1, 16, 1, 1, 0, bias=False).to(DEV)
+    with torch.no_grad():
+        conv1.weight.copy_(rnd(tuple(conv1.weight.shape), 3, -0.3, 0.3))
+        convd.weight.copy_(rnd(tuple(convd.weight.shape), 4, -0.5, 0.5))
+    srcs = [H.to_nhwc(rnd((3, c0, Hh, Ww), 5).to(DEV))] + ([H.to_nhwc(rnd((3, c1, Hh, Ww), 6).to(DEV))] if c1 else [])
+    sd, hd = rnd((16,), 7, 0.5, 1.5).to(DEV), rnd((16,), 8, -0.2, 0.2).to(DEV)
+    H.set_head_precision("f16")
+    try:
+        a, sa = H.hconv(srcs, conv1, H._PackedConv(), want_stats=stats)
+        b, sb = H.hconv(srcs, convd, H._PackedConv(), want_stats=stats, post=None if stats else (sd, hd))
+        c1o, s1, d, s2 = H.hconv_entry(srcs, conv1, H._PackedConv(), convd, H._PackedConv(), want_stats=stats, postd=None if stats else (sd, hd))
+    finally:
+        H.set_head_precision("auto")
+    assert O.rel_l2(c1o.cpu(), a.cpu()) <= 1e-6 and O.rel_l2(d.cpu(), b.cpu()) <= 1e-6
+    if stats:
+        fold = lambda t: t.view(-1, 2, 16).sum(0)
+        assert O.rel_l2(fold(s1).cpu(), fold(sa).cpu()) <= 1e-6 and O.rel_l2(fold(s2).cpu(), fold(sb).cpu()) <= 1e-6
