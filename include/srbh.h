@@ -290,6 +290,10 @@ int srbh_dwconv_bwd_weight(const float* x, const float* dy, float* dw, float* ws
  * y = act(x * scale[c] + shift[c]), act 0 none | 1 SiLU | 2 ReLU; y may alias x. */
 int srbh_affine_act_nchw(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW, int act,
                          void* stream);
+/* y = act(x * scale[c] + shift[c]) + res: the closing BatchNorm of an MBConv block together with its skip connection
+ * (efficientnet_pytorch MBConvBlock.forward: x = bn2(project_conv(x)); x = x + inputs), one pass instead of two. */
+int srbh_affine_act_add_nchw(const float* x, const float* scale, const float* shift, const float* res, float* y, int B, int C, int HW,
+                             int act, void* stream);
 
 /* squeeze-and-excitation of an MBConv block at inference (efficientnet_pytorch MBConvBlock.forward, called through
  * mymodels.py:242-248): (1) affine + activation as above, also writing the per-plane mean pooled [B][C];

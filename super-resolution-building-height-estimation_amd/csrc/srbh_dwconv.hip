@@ -138,8 +138,8 @@ __global__ void dw_reduce_kernel(const float* __restrict__ ws, float* __restrict
 // 115 calls per batch in the encoder / decoders).
 template <int VEC>
 __global__ __launch_bounds__(256) void affine_act_nchw_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                             const float* __restrict__ shift, float* __restrict__ y, long planes,
-                                                             int C, int hw, int act) {
+                                                             const float* __restrict__ shift, const float* __restrict__ res,
+                                                             float* __restrict__ y, long planes, int C, int hw, int act) {
     const int per = hw / VEC;
     const long total = planes * per;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -161,10 +161,11 @@ __global__ __launch_bounds__(256) void affine_act_nchw_kernel(const float* __res
             v[q] = u;
         }
         if (VEC == 4) {
-            const floatx4 t = {v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]};
+            floatx4 t = {v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]};
+            if (res) t += ((const floatx4*)res)[idx];          // the block's skip connection (MBConv: x = bn2(project(x)) + inputs)
             ((floatx4*)y)[idx] = t;
         } else {
-            y[idx] = v[0];
+            y[idx] = res ? v[0] + res[idx] : v[0];
         }
     }
 }
@@ -311,19 +312,30 @@ extern "C" int srbh_dwconv_bwd_weight(const float* x, const float* dy, float* dw
     return SRBH_OK;
 }
 
-extern "C" int srbh_affine_act_nchw(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW, int act,
-                                    void* stream) {
+static int affine_act_impl(const float* x, const float* scale, const float* shift, const float* res, float* y, int B, int C, int HW,
+                           int act, void* stream) {
     SRBH_REQUIRE(x && scale && shift && y, "srbh_affine_act_nchw: null pointer");
     SRBH_REQUIRE(B > 0 && C > 0 && HW > 0 && act >= 0 && act <= 2, "srbh_affine_act_nchw: bad arguments");
     const long planes = (long)B * C;
-    const bool v4 = (HW % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
+    const bool v4 = (HW % 4 == 0) && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) % 16 == 0);
     const int g = grid_for(planes * (v4 ? HW / 4 : HW));
     if (v4)
-        hipLaunchKernelGGL(affine_act_nchw_kernel<4>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, planes, C, HW, act);
+        hipLaunchKernelGGL(affine_act_nchw_kernel<4>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, scale, shift, res, y, planes, C, HW, act);
     else
-        hipLaunchKernelGGL(affine_act_nchw_kernel<1>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, planes, C, HW, act);
+        hipLaunchKernelGGL(affine_act_nchw_kernel<1>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, scale, shift, res, y, planes, C, HW, act);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
+}
+
+extern "C" int srbh_affine_act_nchw(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW, int act,
+                                    void* stream) {
+    return affine_act_impl(x, scale, shift, nullptr, y, B, C, HW, act, stream);
+}
+
+extern "C" int srbh_affine_act_add_nchw(const float* x, const float* scale, const float* shift, const float* res, float* y, int B, int C,
+                                        int HW, int act, void* stream) {
+    SRBH_REQUIRE(res, "srbh_affine_act_add_nchw: null residual");
+    return affine_act_impl(x, scale, shift, res, y, B, C, HW, act, stream);
 }
 
 extern "C" int srbh_affine_act_pool_nchw(const float* x, const float* scale, const float* shift, float* y, float* pooled, int B, int C,

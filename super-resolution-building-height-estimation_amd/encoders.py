@@ -106,7 +106,7 @@ FUSED_SE_EVAL = True       # squeeze-and-excitation of the MBConv blocks as thre
 FUSED_BN_EVAL = True      # tests switch it off to compare with the stock inference-BatchNorm path
 
 
-def bn_act(bn, x, act=None):
+def bn_act(bn, x, act=None, res=None):
     """BatchNorm2d followed by an activation.  Inference on the device: ONE libsrbh pass y = act(x * scale + shift) with the
     running statistics folded into (scale, shift) (csrc/srbh_dwconv.hip) -- MIOpen's inference-BatchNorm kernel costs
     ~39 us per call whatever the size, 8.6 % of the tiled-inference path.  Training / CPU: the stock ops."""
@@ -116,6 +116,11 @@ def bn_act(bn, x, act=None):
         x = x.contiguous()
         B, C, H, W = x.shape
         y = torch.empty_like(x)
+        if res is not None:        # the block's skip connection in the same pass (res: what the caller would add to the result)
+            res = res.contiguous()
+            _lib.check(_lib.lib().srbh_affine_act_add_nchw(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), res.data_ptr(), y.data_ptr(),
+                                                           B, C, H * W, _ACT[act], _lib.stream_ptr()), "affine_act_add_nchw")
+            return y
         _lib.check(_lib.lib().srbh_affine_act_nchw(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, C, H * W,
                                                    _ACT[act], _lib.stream_ptr()), "affine_act_nchw")
         return y
@@ -130,10 +135,10 @@ def bn_act(bn, x, act=None):
     else:
         x = bn(x)
     if act == "silu":
-        return _swish(x)
-    if act == "relu":
-        return F.relu(x)
-    return x
+        x = _swish(x)
+    elif act == "relu":
+        x = F.relu(x)
+    return x if res is None else x + res
 
 
 def _bn_affine(bn, device):
@@ -252,8 +257,11 @@ class MBConvBlock(nn.Module):
             s = F.adaptive_avg_pool2d(x, 1)
             s = self._se_expand(_swish(self._se_reduce(s)))
             x = torch.sigmoid(s) * x
+        skip = self.stride == 1 and self.inp == self.out
+        if skip and not (self.training and drop_connect_rate):
+            return bn_act(self._bn2, self._project_conv(x), res=inputs)      # inference: BatchNorm + skip connection in one pass
         x = bn_act(self._bn2, self._project_conv(x))
-        if self.stride == 1 and self.inp == self.out:
+        if skip:
             if drop_connect_rate:
                 x = _drop_connect(x, drop_connect_rate, self.training, drop_mask)
             x = x + inputs
