@@ -14,6 +14,7 @@ alg = {"hconv16_kernel<1>": ("forward 16->16 3x3, fp16 operands, + BN statistics
        "hconv_f32_kernel<1, 3, 1, 1>": ("forward 16->16 3x3, fp16 operands, + BN statistics", px * 128), "hconv_f32_kernel<1, 3, 1, 2>": ("data gradient 16->16 3x3, bf16 operands", px * 128),
        "hwgrad16_kernel": ("weight gradient 16->16 3x3, bf16 operands (double-buffered kernel)", px * 128),
        "hwgrad_b16_kernel<3>": ("weight gradient 16->16 3x3, bf16 operands", px * 128), "hwgrad_f32_kernel<3>": ("weight gradient 16->16 3x3, fp32", px * 128),
+       "bn_bwd_reduce4_kernel": ("BatchNorm backward: per-channel sums of dy, dy*xhat (16-byte form)", px * 128), "bn_bwd_apply4_kernel": ("BatchNorm backward: dx (16-byte form)", px * 192),
        "bn_bwd_reduce_kernel": ("BatchNorm backward: per-channel sums of dy, dy*xhat", px * 128), "bn_bwd_apply_kernel": ("BatchNorm backward: dx", px * 192),
        "bn_add_relu_kernel": ("relu(bn(c) + identity)", px * 192)}
 res = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python tools/head_kernels.py %d (separate passes)" % B,
