@@ -239,7 +239,7 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
     line = {
         "metric": "tiles/sec (64x64x8ch->256x256 height) fwd+bwd", "value": round(tiles / elapsed, 2), "unit": "tiles/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": f"f16 operands/f32 acc (RRDB), head convs: {ts.head_precision} (f16 = fwd fp16 / dgrad bf16 operands, wgrad + BN + losses + Adam fp32)",
+        "scaling": "weak", "vs_baseline": None, "dtype": f"f16 operands/f32 acc (RRDB), head convs: {ts.head_precision} (f16 = forward fp16 operands, data and weight gradients bf16 operands, fp32 accumulation; BN + losses + Adam fp32)",
         "data": "synthetic" + (" (batches drawn on the device each step)" if epoch_tiles else " (one fixed batch)"),
         "config": {"workload": (f"one data-parallel pass over {epoch_tiles} synthetic train tiles (BASELINE.json configs[3]), " if epoch_tiles else "")
                                + f"full train step: RRDBNet fwd (no grad) + SRRegress_Cls_feature fwd/bwd + Adam, batch {batch}/GPU "
