@@ -228,8 +228,8 @@ class TrainStep:
     def __init__(self, net_hr, net, device, world=1, lr=1e-3, sync_bn=False, overlap=True, timing=False, status_every=100,
                  head_precision="f16", graph=False):
         # mixed precision of the head's convolutions while training (hrfuse.set_head_precision): "f16" = forward convs with
-        # fp16 operands, data gradients with bf16 operands (fp32's exponent range: no loss scaling), weight gradients,
-        # BatchNorm, losses and Adam in fp32 -- what the north star's "fp16 MFMA, <= 1e-3 on the height maps" buys;
+        # fp16 operands, data and weight gradients with bf16 operands (fp32's exponent range: no loss scaling), fp32 accumulation
+        # everywhere, BatchNorm, losses and Adam in fp32 -- what the north star's "fp16 MFMA, <= 1e-3 on the height maps" buys;
         # "f32" = the exact-fp32 head the parity tests pin; "auto" = leave the module default (exact while a graph is recorded)
         from . import hrfuse as _H
         _H.set_head_precision(head_precision)

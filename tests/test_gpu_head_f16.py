@@ -156,7 +156,7 @@ def test_model_eval_default_precision_height_maps():
 
 
 def test_mixed_precision_training_gradients_close_to_exact():
-    """TrainStep's default ("f16": forward convs fp16 operands, data gradients bf16 operands, weight gradients fp32): every
+    """TrainStep's default ("f16": forward convs fp16 operands, data and weight gradients bf16 operands, fp32 accumulation): every
     parameter gradient of the head within 2e-2 relative of the exact-fp32 graph (bf16 keeps 8 mantissa bits: 4e-3 per
     operand, averaged over the 9 x 16 products of a tap sum), outputs within 1e-3; tiny per-pixel gradients (a mean over
     10^5 pixels puts them at 1e-6, below fp16's normal range) must survive -- that is why the data gradients are bf16."""
