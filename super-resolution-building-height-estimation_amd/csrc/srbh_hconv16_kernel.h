@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
             }
         }
         float* const o0 = p.out + pix0 * p.out_ld + p.out_coff + kk * 4;
+        const bool vec_out = p.cout_store == 16 && (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             floatx4 v = acc[i];
@@ -158,7 +159,13 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
                     ssq[q] += v[q] * v[q];
                 }
             }
-            *(floatx4*)(o0 + i * 16 * p.out_ld) = v;
+            if (vec_out) {
+                *(floatx4*)(o0 + i * 16 * p.out_ld) = v;
+            } else {                   // the 1- / 7-channel output convs (conv_last): scalar stores of the real channels
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (kk * 4 + q < p.cout_store) o0[i * 16 * p.out_ld + q] = v[q];
+            }
         }
     }
     if (p.stats) {

@@ -700,9 +700,11 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
     } while (0)
     // the dominant layer shape has its own persistent, double-buffered kernel (srbh_hconv16_kernel.h)
     static const int k16_wgs = getenv("SRBH_HCONV16_WGS") ? atoi(getenv("SRBH_HCONV16_WGS")) : 768;     // 0 = always the template
-    if (opt != 0 && k16_wgs >= 8 && a->ksize == 3 && a->cout == 16 && a->c0 == 16 && a->c1 == 0 && (W & 63) == 0 && (H & 3) == 0 &&
-        !a->pixelshuffle2 && !a->res2 && !a->post_lrelu && !a->io_h16 && (p.ld0 & 3) == 0 && (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 &&
-        (!a->res1 || (a->res1_ld & 3) == 0) && (((uintptr_t)a->src0 | (uintptr_t)a->out | (uintptr_t)a->res1) & 15) == 0) {
+    const bool full16 = a->cout == 16 && (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 && ((uintptr_t)a->out & 15) == 0;
+    const bool narrow = a->cout < 16 && !a->stats && !a->res1;                 // conv_last (1 / 7 channels): scalar stores
+    if (opt != 0 && k16_wgs >= 8 && a->ksize == 3 && (full16 || narrow) && a->c0 == 16 && a->c1 == 0 && (W & 63) == 0 && (H & 3) == 0 &&
+        !a->pixelshuffle2 && !a->res2 && !a->post_lrelu && !a->io_h16 && (p.ld0 & 3) == 0 &&
+        (!a->res1 || (a->res1_ld & 3) == 0) && (((uintptr_t)a->src0 | (uintptr_t)a->res1) & 15) == 0) {
         p.tiles_x = W / 64;
         p.tiles_per_img = p.tiles_x * (H / 4);
         p.ntiles = p.tiles_per_img * B;

@@ -31,7 +31,8 @@ def h16(t):
 
 
 @pytest.mark.parametrize("c0,c1,cout,ks,ps2,hw", [(16, 0, 16, 3, False, (24, 70)), (16, 16, 16, 3, False, (17, 64)), (64, 0, 16, 3, False, (8, 130)),
-                                                   (16, 0, 64, 3, True, (12, 20)), (32, 0, 16, 1, False, (9, 66)), (16, 0, 7, 3, False, (16, 16))])
+                                                   (16, 0, 64, 3, True, (12, 20)), (32, 0, 16, 1, False, (9, 66)), (16, 0, 7, 3, False, (16, 16)),
+                                                   (16, 0, 16, 3, False, (8, 128)), (16, 0, 7, 3, False, (8, 64)), (16, 0, 1, 3, False, (4, 128))])
 def test_h16_conv_equals_conv_of_rounded_operands(c0, c1, cout, ks, ps2, hw):
     from srbh_amd import hrfuse as H
     Hh, Ww = hw
