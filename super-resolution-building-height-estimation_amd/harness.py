@@ -277,9 +277,7 @@ class TrainStep:
     def _graph_step(self, batch):
         if self._graph is None:
             # static inputs: the floating-point tensors are views of ONE flat buffer, so that a new batch reaches them with a
-            # single `cat` launch (+ one for the int64 labels).  Three or more eager launches between two graph launches cost
-            # 5.5 ms per step on ROCm 7.2 (measured: replay only 47.3 ms, +1 or 2 kernels 47.5, +3..6 kernels 52.9 -- whatever
-            # their size; 64 us on their own), so the staging must stay at two.
+            # single `cat` launch (+ one for the int64 labels) in front of the replay
             if getattr(self, "_static", None) is None:
                 fl = [t for t in batch if t.dtype == torch.float32]
                 flat = torch.empty(sum(t.numel() for t in fl), dtype=torch.float32, device=fl[0].device)
