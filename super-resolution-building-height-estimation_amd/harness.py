@@ -247,10 +247,12 @@ class TrainStep:
             p.requires_grad_(False)
         self.criterion = [MSE_adapt_weight(device=device), MSE_adapt_weight(device=device),
                           CE_DICE_adapt_weight(device=device)]
-        # graph=True (one GPU): after three eager steps the WHOLE step -- RRDBNet features, model forward, losses, backward, Adam --
-        # is captured into one HIP graph and replayed (Adam with capturable=True keeps its step counters on the device).  The
-        # step is ~1 400 launches; once the kernels were tuned the host could no longer issue them fast enough (rocprofv3:
-        # 35 ms of kernel time in a 56 ms step), a graph replay issues them back to back.
+        # graph=True (one GPU; optional, NOT faster than eager launches since the optimizer is fused: 49.0 vs 49.1 ms): after three
+        # eager steps the WHOLE step -- RRDBNet features, model forward, losses, backward, Adam --
+        # is captured into one HIP graph and replayed (Adam with capturable=True keeps its step counters on the device).  libsrbh's
+        # own calls are replay-safe (device state is cleared by kernels: hipMemsetAsync nodes of a replayed graph are not ordered
+        # behind the previous replay's kernels on ROCm 7.2); the stock ops of the step still contain a few device-to-device memcpy
+        # nodes (ATen clone / copy_), for which the same caution applies -- synchronise between replays if in doubt.
         self.use_graph = bool(graph) and world == 1
         # fused=True on the GPU: the whole Adam update is a handful of multi-tensor launches (the default foreach path is ~50
         # launches and 5.5 ms of host time per step; with capturable=True its bias-correction pow even falls back to one launch
