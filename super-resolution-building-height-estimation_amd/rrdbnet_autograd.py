@@ -28,7 +28,25 @@ import torch
 from . import _lib, wcache
 from . import hrfuse as H
 
-__all__ = ["rrdbnet_apply"]
+__all__ = ["rrdbnet_apply", "set_train_precision"]
+
+# Operand precision of the RRDBNet TRAINING graph: "f32" (default) = exact fp32 matrix cores in forward, data and weight gradients
+# (what the <= 2e-3 / float64 parity tests pin); "mixed" = forward convs with fp16 operands, data and weight gradients with bf16
+# operands, fp32 accumulation and fp32 residual / LeakyReLU epilogues everywhere (the head's TrainStep policy, hrfuse.py): the
+# 16-bit matrix cores run these 64..192-channel convs several times faster.  SRBH_SR_TRAIN_PRECISION / set_train_precision().
+import os as _os
+
+_PRECISION = {"mode": _os.environ.get("SRBH_SR_TRAIN_PRECISION", "f32")}
+
+
+def set_train_precision(mode):
+    if mode not in ("f32", "mixed"):
+        raise ValueError("RRDBNet training precision must be 'f32' or 'mixed'")
+    _PRECISION["mode"] = mode
+
+
+def _mixed():
+    return _PRECISION["mode"] == "mixed"
 
 
 class _Packs:
@@ -40,22 +58,32 @@ class _Packs:
 
     def get(self, conv):
         w = conv.weight
-        key = (w._version, w.data_ptr(), conv.bias._version, conv.bias.data_ptr(), wcache.gen(w, conv.bias))
+        mixed = _mixed()
+        key = (w._version, w.data_ptr(), conv.bias._version, conv.bias.data_ptr(), wcache.gen(w, conv.bias), mixed)
         if key != self.key:
             L = _lib.lib()
             cout, cin, ks, _ = w.shape
             wc = w.detach().float().contiguous()
             st = _lib.stream_ptr()
-            self.fwd = torch.empty(L.srbh_hpack_bytes(cout, cin, ks) // 4, dtype=torch.float32, device=w.device)
-            _lib.check(L.srbh_hpack_conv_f32(wc.data_ptr(), cout, cin, ks, 0, self.fwd.data_ptr(), st), "hpack(fwd)")
+            self.mixed = mixed
+            if mixed:          # fp16 forward pack, bf16 transposed / flipped packs for the data gradient (srbh_hpack_conv_h16)
+                self.fwd = torch.empty(L.srbh_hpack_h16_bytes(cout, cin, ks) // 2, dtype=torch.float16, device=w.device)
+                _lib.check(L.srbh_hpack_conv_h16(wc.data_ptr(), cout, cin, ks, 0, 0, self.fwd.data_ptr(), st), "hpack_h16(fwd)")
+            else:
+                self.fwd = torch.empty(L.srbh_hpack_bytes(cout, cin, ks) // 4, dtype=torch.float32, device=w.device)
+                _lib.check(L.srbh_hpack_conv_f32(wc.data_ptr(), cout, cin, ks, 0, self.fwd.data_ptr(), st), "hpack(fwd)")
             self.bias = torch.zeros((cout + 15) // 16 * 16, dtype=torch.float32, device=w.device)
             self.bias[:cout] = conv.bias.detach().float()
             self.bwd = []          # [(c_lo, n, pack)]: data-gradient conv producing input channels c_lo .. c_lo + n
             for c_lo in range(0, cin, 64):
                 n = min(64, cin - c_lo)
                 sub = wc[:, c_lo:c_lo + n].contiguous()
-                pk = torch.empty(L.srbh_hpack_bytes(n, cout, ks) // 4, dtype=torch.float32, device=w.device)
-                _lib.check(L.srbh_hpack_conv_f32(sub.data_ptr(), n, cout, ks, 1, pk.data_ptr(), st), "hpack(bwd)")
+                if mixed:
+                    pk = torch.empty(L.srbh_hpack_h16_bytes(n, cout, ks) // 2, dtype=torch.float16, device=w.device)
+                    _lib.check(L.srbh_hpack_conv_h16(sub.data_ptr(), n, cout, ks, 1, 1, pk.data_ptr(), st), "hpack_h16(bwd)")
+                else:
+                    pk = torch.empty(L.srbh_hpack_bytes(n, cout, ks) // 4, dtype=torch.float32, device=w.device)
+                    _lib.check(L.srbh_hpack_conv_f32(sub.data_ptr(), n, cout, ks, 1, pk.data_ptr(), st), "hpack(bwd)")
                 self.bwd.append((c_lo, n, pk))
             self.key = key
         return self
@@ -65,8 +93,9 @@ def _packs(conv) -> _Packs:
     return conv.__dict__.setdefault("_srbh_train_packs", _Packs()).get(conv)
 
 
-def _conv(src, c0, ld0, pack, bias, cout, out, out_ld=0, out_coff=0, lrelu=False, res1=None, res2=None):
-    """out[..., out_coff : out_coff + cout] = epilogue(conv3x3(src[..., :c0])) on the exact-fp32 kernel."""
+def _conv(src, c0, ld0, pack, bias, cout, out, out_ld=0, out_coff=0, lrelu=False, res1=None, res2=None, bf16=False):
+    """out[..., out_coff : out_coff + cout] = epilogue(conv3x3(src[..., :c0])): the exact-fp32 kernel, or -- `pack` is a 16-bit pack
+    (mixed precision) -- the fp16 (forward) / bf16 (`bf16`: data gradients) operand form with the same fp32 epilogue."""
     a = _lib.HConvArgs()
     a.src0, a.c0, a.src0_ld = src.data_ptr(), c0, ld0
     a.w, a.bias = pack.data_ptr(), (bias.data_ptr() if bias is not None else None)
@@ -77,7 +106,10 @@ def _conv(src, c0, ld0, pack, bias, cout, out, out_ld=0, out_coff=0, lrelu=False
         a.res1, a.res1_ld, a.res1_scale = res1[0].data_ptr(), res1[1], res1[2]
     if res2 is not None:
         a.res2, a.res2_ld, a.res2_scale = res2[0].data_ptr(), res2[1], res2[2]
-    _lib.check(_lib.lib().srbh_hconv_f32(C.byref(a), _lib.stream_ptr()), "hconv_f32(rrdbnet train)")
+    if pack.dtype == torch.float16:
+        _lib.check(_lib.lib().srbh_hconv_h16(C.byref(a), int(bf16), _lib.stream_ptr()), "hconv_h16(rrdbnet train)")
+    else:
+        _lib.check(_lib.lib().srbh_hconv_f32(C.byref(a), _lib.stream_ptr()), "hconv_f32(rrdbnet train)")
 
 
 def _wgrad(src, c0, ld0, g, cout):
@@ -91,14 +123,17 @@ def _wgrad(src, c0, ld0, g, cout):
     a.dw = dw.data_ptr()
     ws = torch.empty(L.srbh_hwgrad_ws_bytes(cout, c0, 3) // 4, dtype=torch.float32, device=g.device)
     a.ws = ws.data_ptr()
-    _lib.check(L.srbh_hconv_wgrad_f32(C.byref(a), _lib.stream_ptr()), "hconv_wgrad_f32(rrdbnet train)")
+    if _mixed():           # (layers outside the bf16 kernel's granularity -- conv_first's 3 input channels -- are computed in fp32 inside)
+        _lib.check(L.srbh_hconv_wgrad_b16(C.byref(a), _lib.stream_ptr()), "hconv_wgrad_b16(rrdbnet train)")
+    else:
+        _lib.check(L.srbh_hconv_wgrad_f32(C.byref(a), _lib.stream_ptr()), "hconv_wgrad_f32(rrdbnet train)")
     return dw
 
 
 def _dgrad_into(g, cout, packs, dst, dst_ld, accumulate):
     """dst[..., :cin] (+)= conv^T(g, W), 64 input channels per launch; `accumulate`: add to what dst holds (residual epilogue)."""
     for c_lo, n, pk in packs.bwd:
-        _conv(g, cout, cout, pk, None, n, dst, dst_ld, c_lo, res1=(dst[..., c_lo:], dst_ld, 1.0) if accumulate else None)
+        _conv(g, cout, cout, pk, None, n, dst, dst_ld, c_lo, res1=(dst[..., c_lo:], dst_ld, 1.0) if accumulate else None, bf16=True)
 
 
 def _up2(t):
