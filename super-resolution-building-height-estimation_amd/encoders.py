@@ -145,7 +145,8 @@ def _bn_affine(bn, device):
     """(scale, shift) of an inference BatchNorm, cached on the module and invalidated by parameter / buffer versions"""
     from . import _lib
     C = bn.num_features
-    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.data_ptr(), wcache.gen(bn.weight, bn.bias))
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.data_ptr(),
+           wcache.gen(bn.weight, bn.bias, bn.running_mean, bn.running_var))     # (buffers are stamped by graph replays: harness.TrainStep)
     cache = bn.__dict__.get("_srbh_affine")
     if cache is None or cache[0] != key:
         scale = torch.empty(C, dtype=torch.float32, device=device)
@@ -155,6 +156,7 @@ def _bn_affine(bn, device):
                                                        _lib.stream_ptr()), "bn_eval_scale_shift")
         cache = (key, scale, shift)
         bn.__dict__["_srbh_affine"] = cache
+    wcache.keep(cache)
     return cache[1], cache[2]
 
 

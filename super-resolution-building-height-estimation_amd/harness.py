@@ -138,6 +138,25 @@ class GradReducer:
         torch._foreach_copy_([flat[o:o + n].view_as(q.grad) for q, o, n in b["items"]], [q.grad for q, _, _ in b["items"]])
         self._work.append((b, self.dist.all_reduce(flat, async_op=True)))
 
+    def _agree_on_order(self):
+        """The bucket layout comes from THIS rank's autograd ready order; flat buffers of different ranks must line up the same
+        parameters.  Like DDP, rank 0's order wins: its sequence of parameter indices is broadcast and every rank re-orders to
+        it; a rank whose SET of gradient-receiving parameters differs raises instead of averaging unrelated gradients."""
+        index = {id(p): i for i, p in enumerate(self.params)}
+        mine = [index[id(p)] for p in self._order]
+        dev = self._order[0].device if self._order else torch.device("cpu")
+        n = torch.tensor([len(mine)], dtype=torch.int64, device=dev)
+        self.dist.broadcast(n, src=0)
+        ref = torch.tensor(mine if len(mine) == int(n) else [0] * int(n), dtype=torch.int64, device=dev)
+        self.dist.broadcast(ref, src=0)
+        ref = [int(v) for v in ref.tolist()]
+        ok = torch.tensor([1 if sorted(ref) == sorted(mine) else 0], dtype=torch.int64, device=dev)
+        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
+        if int(ok) == 0:
+            raise RuntimeError("GradReducer: the ranks disagree on WHICH parameters receive gradients (rank 0 has %d, this rank %d); "
+                               "the bucketed all-reduce would average unrelated tensors" % (len(ref), len(mine)))
+        self._order = [self.params[i] for i in ref]
+
     def _build_plan(self):
         buckets, cur, size = [], [], 0
         for p in self._order:
@@ -167,6 +186,7 @@ class GradReducer:
         if self.plan is None:        # first step: plain sweep in ready order, then freeze the bucket plan
             seen = set()
             self._order = [p for p in self._order if p.grad is not None and not (id(p) in seen or seen.add(id(p)))]
+            self._agree_on_order()       # (before the first sweep: its buckets are cut from this order too)
             allreduce_grads(self._order, self.world, self.dist, self.bucket_bytes)
             self._build_plan()
             return self.n_buckets
@@ -231,8 +251,11 @@ class TrainStep:
         # fp16 operands, data and weight gradients with bf16 operands (fp32's exponent range: no loss scaling), fp32 accumulation
         # everywhere, BatchNorm, losses and Adam in fp32 -- what the north star's "fp16 MFMA, <= 1e-3 on the height maps" buys;
         # "f32" = the exact-fp32 head the parity tests pin; "auto" = leave the module default (exact while a graph is recorded)
+        # Scoped to the step (hrfuse.head_precision context): constructing a TrainStep leaves the process-wide mode alone.
         from . import hrfuse as _H
-        _H.set_head_precision(head_precision)
+        if head_precision not in ("auto", "f16", "f32"):
+            raise ValueError("head precision must be 'auto', 'f16' or 'f32'")
+        self._H = _H
         self.head_precision = head_precision
         if sync_bn and world > 1:
             # global-batch BatchNorm statistics (what the reference computes on one device): libsrbh BatchNorms all-reduce
@@ -272,9 +295,10 @@ class TrainStep:
         return [p for g in self.optimizer.param_groups for p in g["params"]]
 
     def __call__(self, batch):
-        if self.use_graph:
-            return self._graph_step(batch)
-        return self._step(batch)
+        with self._H.head_precision(self.head_precision):
+            if self.use_graph:
+                return self._graph_step(batch)
+            return self._step(batch)
 
     def _graph_step(self, batch):
         if self._graph is None:
@@ -298,10 +322,21 @@ class TrainStep:
             self.optimizer.zero_grad(set_to_none=True)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
-                self._static_out = self._step(self._static, in_graph=True)
+            # the graph OWNS the eager-made buffers it bakes in (the frozen RRDBNet's layer table / packed weights / workspace:
+            # pinned, so calling net_hr at other geometries between replays cannot free them) -- wcache.Holder
+            self._holder = wcache.Holder()
+            with wcache.capturing(self._holder):
+                self.net_hr.forward_feature(self._static[0].index_select(1, self._rgb_idx))   # eager: reports packs + workspace
+                torch.cuda.synchronize()
+                with torch.cuda.graph(self._graph):
+                    self._static_out = self._step(self._static, in_graph=True)
+            self._stamped = [p for p in self.params()] + [b for b in self.net.buffers()]
         self._stage(batch)
         self._graph.replay()
+        # a replay updates the weights and the BatchNorm running statistics on the device without any Python-side trace (no
+        # _version bump, no optimizer hook): stamp them, or eval / predict_tiles after training reuses the packed weights, folded
+        # BatchNorm affines and captured predict graph of an earlier state (round-2 ADVICE)
+        wcache.stamp(self._stamped)
         self.steps += 1
         if self.status_every and self.steps % self.status_every == 0 and hasattr(self.net_hr, "check_status"):
             self.net_hr.check_status()
@@ -310,6 +345,12 @@ class TrainStep:
     def _stage(self, batch):
         if all(d.data_ptr() == s.data_ptr() for d, s in zip(self._static, batch)):
             return                                   # the caller filled `static_batch()` in place
+        for i, (d, s) in enumerate(zip(self._static, batch)):
+            if tuple(d.shape) != tuple(s.shape) or d.dtype != s.dtype or d.device != s.device:
+                # (torch.cat(out=) would silently RESIZE the flat buffer: the captured graph keeps reading the old views)
+                raise ValueError(f"TrainStep(graph=True): batch tensor {i} is {tuple(s.shape)} {s.dtype} on {s.device}, the captured "
+                                 f"step reads {tuple(d.shape)} {d.dtype} on {d.device}; a graph replays ONE batch geometry "
+                                 "(drop the ragged last batch as the reference's loader does, train.py:97, or use graph=False)")
         torch.cat([t.reshape(-1) for t in batch if t.dtype == torch.float32], out=self._static_flat)
         for d, s in zip(self._static, batch):
             if d.dtype != torch.float32:
@@ -393,24 +434,30 @@ class _PredictGraph:
     def __init__(self, net_hr, model, batch, dev, chans):
         self.key = _PredictGraph.weights_key(net_hr, model, batch, dev)
         self.x = torch.zeros((batch, chans, 64, 64), device=dev)
-        side = torch.cuda.Stream(device=dev)          # warm-up off the capture (lazy packs, workspaces, MIOpen's solver search)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                model(self.x, net_hr.forward_feature(self.x[:, :3]))
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = model(self.x, net_hr.forward_feature(self.x[:, :3]))
+        # The graph OWNS every eager-made device buffer it bakes in (wcache.Holder): RRDBNet's layer table / packed weights and
+        # its (B, 64, 64) workspace -- pinned against the workspace budget until this object dies --, the head's weight packs, the
+        # encoder's folded BatchNorm affines.  (Round 2 kept none of them: the second distinct ragged-tail size of a city run
+        # evicted the B=128 workspace from a 2-entry LRU and every later replay wrote the trunk's activations into freed memory.)
+        self.holder = wcache.Holder()
+        with wcache.capturing(self.holder):
+            side = torch.cuda.Stream(device=dev)      # warm-up off the capture (lazy packs, workspaces, MIOpen's solver search)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    model(self.x, net_hr.forward_feature(self.x[:, :3]))
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = model(self.x, net_hr.forward_feature(self.x[:, :3]))
 
     @staticmethod
     def weights_key(net_hr, model, batch, dev):
-        k = 0
-        for m in (net_hr, model):
-            for t in list(m.parameters()) + list(m.buffers()):
-                k += t._version + getattr(t, "_srbh_gen", 0) + (t.data_ptr() & 0xffffffff)
+        """exact (no hashing: a collision would replay a stale graph): version, generation stamp and address of every parameter
+        and buffer of both networks"""
         from . import hrfuse as _H
+        k = tuple((t._version, getattr(t, "_srbh_gen", 0), t.data_ptr())
+                  for m in (net_hr, model) for t in list(m.parameters()) + list(m.buffers()))
         return (k, batch, str(dev), wcache.gen(), _H._HEAD_PRECISION["mode"])
 
     def __call__(self, x_src, k):

@@ -74,6 +74,25 @@ def set_head_precision(mode="auto"):
     _HEAD_PRECISION["mode"] = mode
 
 
+class head_precision:
+    """scoped `set_head_precision`: `with head_precision("f16"): ...` restores the previous mode on exit (harness.TrainStep uses
+    it around its step so that constructing a TrainStep does not change what the rest of the process computes)."""
+
+    def __init__(self, mode):
+        if mode not in ("auto", "f16", "f32"):
+            raise ValueError("head precision must be 'auto', 'f16' or 'f32'")
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = _HEAD_PRECISION["mode"]
+        _HEAD_PRECISION["mode"] = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        _HEAD_PRECISION["mode"] = self.prev
+        return False
+
+
 def head_h16():
     m = _HEAD_PRECISION["mode"]
     # (torch disables grad mode inside autograd.Function.forward / backward: those bump "depth" instead, hrfuse_autograd._exact)
@@ -122,6 +141,7 @@ class _PackedConv:
                 b[:cout] = conv.bias.detach().float()
             # (no host sync: `wc` is recycled by torch's stream-ordered allocator, and the pack kernel runs on that stream)
             self.key, self.w, self.b = key, buf, b
+        wcache.keep(self.w, self.b)
         return self.w, self.b
 
 

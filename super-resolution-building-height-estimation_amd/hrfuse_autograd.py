@@ -38,6 +38,7 @@ class _PackedGrad:
                            "hpack_conv_f32(T)")
             # (no host sync: `wc` is recycled by torch's stream-ordered allocator, and the pack kernel runs on that stream)
             self.key, self.w = key, buf
+        wcache.keep(self.w)
         return self.w
 
 
@@ -128,7 +129,9 @@ def bn_backward(g, c, mean, invstd, gamma, mask, training, relu_ref=None):
     st = _stats_buf(Cc, dev)
     ms, mh = (mask[0].data_ptr(), mask[1].data_ptr()) if mask is not None else (None, None)
     dz = None
-    if relu_ref is not None and Cc % 4 == 0 and mask is None:
+    # (the fused reduce+ReLU pass exists in the 16-byte form only: a thread owns one 4-channel group and 256 threads must hold
+    # whole pixels -- csrc/srbh_head_bwd.hip bn_bwd_reduce_impl; other widths, e.g. super_mid=24, take the two-pass fallback)
+    if relu_ref is not None and Cc % 4 == 0 and 256 % (Cc // 4) == 0 and mask is None:
         dz = torch.empty_like(relu_ref)
         _lib.check(L.srbh_bn_bwd_reduce_relu(g.data_ptr(), relu_ref.data_ptr(), dz.data_ptr(), c.data_ptr(), mean.data_ptr(),
                                              invstd.data_ptr(), n, Cc, st.data_ptr(), _lib.stream_ptr()), "bn_bwd_reduce_relu")

@@ -86,6 +86,7 @@ class _Packs:
                     _lib.check(L.srbh_hpack_conv_f32(sub.data_ptr(), n, cout, ks, 1, pk.data_ptr(), st), "hpack(bwd)")
                 self.bwd.append((c_lo, n, pk))
             self.key = key
+        wcache.keep(self.fwd, self.bias, self.bwd)
         return self
 
 

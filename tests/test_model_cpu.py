@@ -235,3 +235,99 @@ def test_weight_pack_caches_see_fused_optimizer_steps():
     k = wcache.gen(frozen)
     wcache.invalidate_weight_caches()
     assert wcache.gen(frozen) != k
+
+
+def _reducer_order_worker(rank, world, port, q, mismatch):
+    import torch.distributed as dist
+    from srbh_amd.harness import GradReducer, shard_range
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1),
+                              torch.nn.ReLU(), torch.nn.Conv2d(8, 1, 3, padding=1))
+    extra = torch.nn.Parameter(torch.ones(3))
+    params = list(net.parameters()) + [extra]
+    red = GradReducer(params, world, dist, bucket_bytes=512)
+    g = torch.Generator()
+    g.manual_seed(1)
+    x, y = torch.rand(8, 3, 16, 16, generator=g), torch.rand(8, 1, 16, 16, generator=g)
+    lo, hi = shard_range(8, rank, world)
+    out, err = [], None
+    try:
+        for step in range(3):
+            for p in params:
+                p.grad = None
+            loss = ((net(x[lo:hi]) - y[lo:hi]) ** 2).mean()
+            if mismatch and rank == 1:
+                loss = loss + extra.sum()                    # this rank alone produces a gradient for `extra`
+            loss.backward()
+            if step == 0 and rank == 1:
+                red._order.reverse()                         # this rank's autograd ready order differs from rank 0's
+            red.finish()
+            out.append([None if p.grad is None else p.grad.numpy().copy() for p in params])
+    except RuntimeError as e:
+        err = str(e)
+    idx = {id(p): i for i, p in enumerate(params)}
+    q.put((rank, out, err, None if red.plan is None else [[idx[id(p)] for p, _, _ in b["items"]] for b in red.plan]))
+    red.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mismatch", [False, True])
+def test_grad_reducer_ranks_agree_on_bucket_layout_gloo_world2(mismatch):
+    """the bucket layout came from each rank's LOCAL autograd ready order with nothing checking that the ranks agree.
+    Now rank 0's order is broadcast (a rank with another order re-orders to it: averaged gradients still equal the full-batch
+    gradient), and ranks whose SETS of gradient-receiving parameters differ raise instead of averaging unrelated tensors."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 41 + int(mismatch)) % 1000
+    procs = [ctx.Process(target=_reducer_order_worker, args=(r, 2, port, q, mismatch)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    if mismatch:
+        assert all(r[2] is not None and "disagree" in r[2] for r in res), [r[2] for r in res]
+        return
+    assert all(r[2] is None for r in res), [r[2] for r in res]
+    assert res[0][3] == res[1][3] and len(res[0][3]) >= 3          # identical bucket layouts on both ranks
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1),
+                              torch.nn.ReLU(), torch.nn.Conv2d(8, 1, 3, padding=1))
+    g = torch.Generator()
+    g.manual_seed(1)
+    x, y = torch.rand(8, 3, 16, 16, generator=g), torch.rand(8, 1, 16, 16, generator=g)
+    ((net(x) - y) ** 2).mean().backward()
+    for r in res:
+        for step in range(3):
+            for got, p in zip(r[1][step], net.parameters()):
+                assert torch.allclose(torch.from_numpy(got), p.grad, rtol=1e-5, atol=1e-7), step
+
+
+def test_capture_holder_keeps_reported_buffers_and_unpins():
+    """wcache.Holder / capturing / keep: what a captured HIP graph uses to own the buffers it points at (CPU logic)."""
+    import gc
+    import weakref
+    from srbh_amd import wcache
+    t = torch.zeros(4)
+    r = weakref.ref(t)
+    wcache.keep(t)                                             # no capture active: a no-op
+    h = wcache.Holder()
+    calls = []
+    with wcache.capturing(h) as hh:
+        assert hh is h and wcache.active_holder() is h
+        wcache.keep(t, None)
+        h.on_release(lambda: calls.append(1))
+    assert wcache.active_holder() is None and len(h.refs) == 1
+    del t
+    gc.collect()
+    assert r() is not None                                     # the holder keeps it alive ...
+    del h, hh
+    gc.collect()
+    assert r() is None and calls == [1]                        # ... exactly as long as it lives; release callbacks ran once
+    b = torch.zeros(2)
+    k = wcache.gen(b)
+    wcache.stamp([b, None])
+    assert wcache.gen(b) != k                                  # buffers can be stamped like parameters
