@@ -438,13 +438,16 @@ def bench_feature(args, rank, world, dev, dist):
     trunk_ms = None
     if L.srbh_trunk_timing(1) == 0:
         acc, nrep = 0.0, max(5, min(20, args.steps))
-        for _ in range(nrep):
-            step()
-            ms = ctypes.c_float(0.0)
-            _lib.check(L.srbh_trunk_last_ms(ctypes.byref(ms)), "srbh_trunk_last_ms")
-            acc += ms.value
+        try:
+            for _ in range(nrep):
+                step()
+                ms = ctypes.c_float(0.0)
+                _lib.check(L.srbh_trunk_last_ms(ctypes.byref(ms)), "srbh_trunk_last_ms")
+                acc += ms.value
+            trunk_ms = acc / nrep
+        except RuntimeError:          # SRBH_PERSISTENT=0 (per-layer launches: no single dominant kernel) -> roofline fields null
+            trunk_ms = None
         L.srbh_trunk_timing(0)
-        trunk_ms = acc / nrep
     trunk_tflops = trunk_gflop_tile * B / (trunk_ms / 1e3) / 1e3 if trunk_ms else None
     traffic, traffic_src = (None, None)
     if B == 32 and args.num_block == 23:

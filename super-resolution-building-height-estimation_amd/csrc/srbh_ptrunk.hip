@@ -1022,6 +1022,7 @@ namespace srbh {
 unsigned long long* g_ptrunk_prof = nullptr;   // set by tools/convbench only
 static int g_trunk_timing = 0;                 // srbh_trunk_timing(): HIP events around the trunk launch(es), on their stream
 static hipEvent_t g_trunk_ev[2];
+static int g_trunk_ev_recorded = 0;       // a timed persistent launch has recorded both events since srbh_trunk_timing(1)
 static const char* g_trunk_kernel = "none";    // srbh_trunk_kernel_name()
 
 constexpr int MAX_BLOCKS = 64;   // layer-table capacity (RRDB blocks)
@@ -1152,7 +1153,7 @@ static int ptrunk2_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, f
         hipLaunchKernelGGL(ptrunk2_kernel, dim3(pp.nblocks), dim3(256), T2_LDS_B, stream, pp);
         SRBH_HIP(hipGetLastError());
     }
-    if (g_trunk_timing) SRBH_HIP(hipEventRecord(g_trunk_ev[1], stream));
+    if (g_trunk_timing) { SRBH_HIP(hipEventRecord(g_trunk_ev[1], stream)); g_trunk_ev_recorded = 1; }
     if (getenv("SRBH_PT_PROF") && g_ptrunk_prof) {
         SRBH_HIP(hipStreamSynchronize(stream));
         const int nblk = (B < imgs_per_launch ? B : imgs_per_launch) * tpi;
@@ -1283,7 +1284,7 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
             hipLaunchKernelGGL((ptrunk_kernel<false, false>), dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
         SRBH_HIP(hipGetLastError());
     }
-    if (g_trunk_timing) SRBH_HIP(hipEventRecord(g_trunk_ev[1], stream));
+    if (g_trunk_timing) { SRBH_HIP(hipEventRecord(g_trunk_ev[1], stream)); g_trunk_ev_recorded = 1; }
     if (getenv("SRBH_PT_PROF") && g_ptrunk_prof) {   // developer aid: cycles vs wall clock of the real forward
         SRBH_HIP(hipStreamSynchronize(stream));
         const int nblk = (B < imgs_per_launch ? B : imgs_per_launch) * tpi;
@@ -1337,6 +1338,7 @@ extern "C" int srbh_trunk_timing(int on) {
         SRBH_HIP(hipEventDestroy(g_trunk_ev[1]));
     }
     g_trunk_timing = on ? 1 : 0;
+    g_trunk_ev_recorded = 0;
     return SRBH_OK;
 }
 
@@ -1345,6 +1347,9 @@ extern "C" const char* srbh_trunk_kernel_name(void) { return srbh::g_trunk_kerne
 extern "C" int srbh_trunk_last_ms(float* ms) {
     using namespace srbh;
     SRBH_REQUIRE(ms && g_trunk_timing, "srbh_trunk_last_ms: timing is off (srbh_trunk_timing(1) first)");
+    // (never hand unrecorded events to hipEventElapsedTime: it leaves a sticky 'invalid resource handle' behind that the next,
+    // unrelated HIP call of the process reports)
+    SRBH_REQUIRE(g_trunk_ev_recorded, "srbh_trunk_last_ms: no persistent trunk launch was timed (per-layer path, SRBH_PERSISTENT=0?)");
     SRBH_HIP(hipEventSynchronize(g_trunk_ev[1]));
     SRBH_HIP(hipEventElapsedTime(ms, g_trunk_ev[0], g_trunk_ev[1]));
     return SRBH_OK;

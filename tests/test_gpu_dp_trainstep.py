@@ -78,6 +78,8 @@ def _single(B, q, world=2):
     lr, height, height_aggre, build, weight, weight_aggre = synthetic_batch(B, 5, dev)
     per = B // world
     losses, grads = [], []
+    from srbh_amd import hrfuse
+    hrfuse.set_head_precision(ts.head_precision)       # (TrainStep scopes its precision to its own __call__; this loop drives the nets by hand)
     for _ in range(3):
         with torch.no_grad():
             fea = ts.net_hr.forward_feature(lr[:, :3])
