@@ -224,6 +224,12 @@ int srbh_bn_eval_scale_shift(int C, const float* gamma, const float* beta, const
  * i_scale NULL = identity path without downsample */
 int srbh_bn_add_relu(const float* a, const float* a_scale, const float* a_shift, const float* idt,
                      const float* i_scale, const float* i_shift, float* out, long npix, int C, void* stream);
+/* The same pass with fp16 tensors in memory (round 3: the training step keeps the block-internal activations c1 / c2 / downsample
+ * output as fp16): io bit SRBH_BAR_A_H16 = `a` holds fp16 elements, SRBH_BAR_IDT_H16 = `idt` does; `out` stays fp32. */
+#define SRBH_BAR_A_H16 1
+#define SRBH_BAR_IDT_H16 2
+int srbh_bn_add_relu_io(const void* a, const float* a_scale, const float* a_shift, const void* idt,
+                        const float* i_scale, const float* i_shift, float* out, long npix, int C, int io, void* stream);
 /* aggregate_torch (aggregate_utils.py:29-41): data [N][H][W] fp32 -> out [N][H/step][W/step] */
 int srbh_aggregate(const float* data, float* out, int N, int H, int W, int step, void* stream);
 /* F.interpolate(scale_factor=2, mode='nearest') on NHWC fp32 (SR/rrdbnet_arch.py:236-237); H, W = output size */
@@ -245,7 +251,11 @@ typedef struct srbh_hwgrad_args {
     float* ws;            /* scratch of srbh_hwgrad_ws_bytes(cout, c0 + c1, ksize) bytes: per-workgroup partial sums */
     int src0_ld, src1_ld; /* floats between consecutive pixels of src0 / src1 (0 = c0 / c1): strided views into wider NHWC
                            * buffers, e.g. the first 64 + 32k channels of a dense block's 192-channel buffer */
+    int io;               /* srbh_hconv_wgrad_b16 only: SRBH_WG_SRC0_H16 = src0 holds fp16 elements (16 -> 16 3x3 form),
+                           * SRBH_WG_DY_B16 = dy holds bf16 elements (its bits are the MFMA operand: no rounding) */
 } srbh_hwgrad_args;
+#define SRBH_WG_SRC0_H16 1
+#define SRBH_WG_DY_B16 2
 size_t srbh_hwgrad_ws_bytes(int cout, int cin, int ksize);
 int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream);
 /* Mixed-precision form of the same gradient (torch.cuda.amp-style training; the reference itself trains in fp32,
@@ -270,6 +280,19 @@ int srbh_bn_bwd_finalize(const double* stats, int C, double count, const float* 
 int srbh_bn_bwd_apply(const float* g, const float* c, const float* mean, const float* invstd, const float* mask_scale,
                       const float* mask_shift, const float* coef, const float* k1, const float* k2, float* out, long npix,
                       int C, void* stream);
+/* The two BatchNorm-backward passes with 16-bit tensors in memory (round 3; vector form only: C % 4 == 0, 256 % (C/4) == 0): the
+ * gradient tensors that live INSIDE one BasicBlock's backward are bf16 (SRBH_BN_G_B16: g; SRBH_BN_OUT_B16: dz_out / out -- their
+ * consumers round their operands to bf16 anyway), the saved activation c is fp16 (SRBH_BN_C_H16); relu_ref stays fp32; the
+ * arithmetic is fp32, and with a bf16 dz_out the sums are taken over the rounded values (what the consumers read).
+ * srbh_bn_bwd_reduce_io: relu_ref / dz_out as srbh_bn_bwd_reduce_relu (may be NULL), mask_* as srbh_bn_bwd_reduce. */
+#define SRBH_BN_OUT_B16 1
+#define SRBH_BN_C_H16 2
+#define SRBH_BN_G_B16 4
+int srbh_bn_bwd_reduce_io(const void* g, const float* relu_ref, void* dz_out, const void* c, const float* mean, const float* invstd,
+                          const float* mask_scale, const float* mask_shift, long npix, int C, double* stats, int io, void* stream);
+int srbh_bn_bwd_apply_io(const void* g, const void* c, const float* mean, const float* invstd, const float* mask_scale,
+                         const float* mask_shift, const float* coef, const float* k1, const float* k2, void* out, long npix, int C,
+                         int io, void* stream);
 /* inverse of the PixelShuffle(2) store map: g_ps [B][2H][2W][C] -> g [B][H][W][4C] */
 int srbh_ps2_inverse(const float* g_ps, float* g, int B, int H, int W, int C, void* stream);
 

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libsrbh.so")
+_DEV_LIB = os.environ.get("SRBH_LIB_PATH")      # developer A/B only (tools/ab_variants.sh): load another build of the same ABI
 SOURCES = ["srbh_conv3x3.hip", "srbh_aux.hip", "srbh_rrdbnet.hip", "srbh_ptrunk.hip", "srbh_ptail.hip", "srbh_head.hip", "srbh_head_bwd.hip", "srbh_mosaic.hip", "srbh_loader.hip", "srbh_loss.hip", "srbh_dwconv.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # NOTE: `-mllvm -amdgpu-mfma-vgpr-form=1` removes the AGPR<->VGPR accumulator copies hipcc emits at every K-loop
@@ -89,7 +90,7 @@ class HWGradArgs(C.Structure):
         ("src1", C.c_void_p), ("c1", C.c_int),
         ("dy", C.c_void_p), ("cout", C.c_int), ("ksize", C.c_int),
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dw", C.c_void_p), ("ws", C.c_void_p),
-        ("src0_ld", C.c_int), ("src1_ld", C.c_int),
+        ("src0_ld", C.c_int), ("src1_ld", C.c_int), ("io", C.c_int),
     ]
 
 
@@ -130,6 +131,7 @@ SIGNATURES = {
     "srbh_bn_finalize": (_i, [_vp, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srbh_bn_eval_scale_shift": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "srbh_bn_add_relu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp]),
+    "srbh_bn_add_relu_io": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _i, _vp]),
     "srbh_aggregate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_nearest2x_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -141,6 +143,8 @@ SIGNATURES = {
     "srbh_bn_bwd_reduce_relu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp, _vp]),
     "srbh_bn_bwd_finalize": (_i, [_vp, _i, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srbh_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp]),
+    "srbh_bn_bwd_reduce_io": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp, _i, _vp]),
+    "srbh_bn_bwd_apply_io": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _i, _vp]),
     "srbh_hwgrad_ws_bytes": (_sz, [_i, _i, _i]),
     "srbh_ps2_inverse": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_affine_act_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -184,7 +188,7 @@ def lib() -> C.CDLL:
                     raise RuntimeError(
                         f"libsrbh.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; "
                         "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP hot path.")
-                l = C.CDLL(LIB_PATH)
+                l = C.CDLL(_DEV_LIB or LIB_PATH)
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(l, name)  # AttributeError here == header/library mismatch
                     fn.restype = res

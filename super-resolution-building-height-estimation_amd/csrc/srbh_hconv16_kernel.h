@@ -14,7 +14,15 @@
 // Same arithmetic as hconv_f32_kernel<1, 3, 1, OPT> (same rounding, same MFMA order per pixel): results are bit-identical except the
 // order in which the BatchNorm partial sums are added.  Restrictions (the host falls back to the template otherwise): c0 = 16,
 // c1 = 0, cout = 16, W % 64 == 0, H % 4 == 0, 4-aligned strides, no PixelShuffle store, no second residual, no LeakyReLU.
-template <int OPT>
+//
+// 16-bit tensors IN MEMORY (round 3; HParams::io_h16, element type = the operand type: fp16 for OPT 1, bf16 for OPT 2): S16 = the
+// source holds 16-bit elements -- a staging unit is then ONE 8-byte load, and without a pre-affine it goes to LDS as it is (no VALU at
+// all: the fp32 form spends ~10 VALU instructions per MFMA rounding); with a pre-affine (the producer's BatchNorm + ReLU) it is widened,
+// transformed and rounded once.  SRBH_IO_RES1_H16 / SRBH_IO_OUT_H16 (run-time flags): the residual is read / the output written as
+// 16-bit quads (one rounding in the epilogue; BatchNorm statistics are still taken from the fp32 values).  Used for the fp16
+// activations of the inference chain and for the saved activations (fp16) / internal gradient tensors (bf16) of the training step.
+// IO (compile-time, so that the all-fp32 form keeps its registers): bit 0 = the residual, bit 1 = the output is a 16-bit tensor
+template <int OPT, int S16, int IO>
 __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
     static_assert(OPT == 1 || OPT == 2, "16-bit operand forms only");
     constexpr int ROWS = 6, COLS = 66, NIT = (ROWS * COLS * 4 + 255) / 256;        // 7 staging units per thread (the last one partial)
@@ -66,14 +74,17 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
     for (int dx = 0; dx < 3; ++dx) bbase[dx] = (wave * COLS + dx + l15) * 32 + ((kk ^ ((((dx + l15) >> 3) & 1) << 1)) << 3);
 
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-    floatx4 ld[NIT];
+    typedef typename std::conditional<S16 != 0, float2v, floatx4>::type ldv_t;      // a staging unit in flight: 8 or 16 bytes
+    ldv_t ld[NIT];
     unsigned okmask = 0;
+    const bool has_pre = p.pre_scale != nullptr || pre_relu;
+    constexpr bool res16 = (IO & 1) != 0, out16 = (IO & 2) != 0;
     auto issue = [&](const int t) {
         const int img = t / p.tiles_per_img;
         const int trem = t - img * p.tiles_per_img;
         const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
         const int Y0 = ty * 4, X0 = tx * 64;
-        const float* tp = p.src0 + (((long)img * p.H + (Y0 - 1)) * p.W + (X0 - 1)) * p.ld0;
+        const char* tp = (const char*)p.src0 + (((long)img * p.H + (Y0 - 1)) * p.W + (X0 - 1)) * p.ld0 * (S16 ? 2 : 4);
         okmask = 0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -82,9 +93,10 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
             if ((ucol1 >> it) & 1) ok = ok && X0 > 0;
             if ((ucol1 >> (8 + it)) & 1) ok = ok && X0 + 64 < p.W;
             if (it == NIT - 1) ok = ok && last_unit;
-            ld[it] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (S16) ld[it] = float2v{0.f, 0.f};
+            else ld[it] = floatx4{0.f, 0.f, 0.f, 0.f};
             if (ok) {
-                ld[it] = *(const floatx4*)(tp + uoff[it]);
+                ld[it] = *(const ldv_t*)(tp + (long)uoff[it] * (S16 ? 2 : 4));
                 okmask |= 1u << it;
             }
         }
@@ -93,7 +105,15 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (it < NIT - 1 || last_unit) {
-                floatx4 a = ld[it];
+                if constexpr (S16) {
+                    if (!has_pre) {          // 16-bit source, no transform: the quad goes to LDS as it is (zero padding = zero bits)
+                        *(float2v*)(stage + ulds[it]) = ld[it];
+                        continue;
+                    }
+                }
+                floatx4 a;
+                if constexpr (S16) a = widen4<OPT>(ld[it]);
+                else a = ld[it];
                 if (okmask & (1u << it)) {
                     a = a * psc + psh;
                     if (pre_relu) {
@@ -119,9 +139,18 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
         // this tile's residual first, then the next tile's input: the epilogue can wait for the residual alone
         floatx4 rres[4];
         if (p.res1) {
-            const float* rp = p.res1 + pix0 * p.res1_ld + kk * 4;
+            if constexpr (res16) {
+                const char* rp = (const char*)p.res1 + (pix0 * p.res1_ld + kk * 4) * 2;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rres[i] = *(const floatx4*)(rp + i * 16 * p.res1_ld);
+                for (int i = 0; i < 4; ++i) {
+                    const float2v raw = *(const float2v*)(rp + (long)i * 16 * p.res1_ld * 2);
+                    rres[i][0] = raw[0]; rres[i][1] = raw[1];          // (raw bits: widened in the epilogue, after the MFMAs)
+                }
+            } else {
+                const float* rp = p.res1 + pix0 * p.res1_ld + kk * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rres[i] = *(const floatx4*)(rp + i * 16 * p.res1_ld);
+            }
         }
         if (t + t_step < t_end) issue(t + t_step);
         __syncthreads();           // stage `buf` is complete; every wave is past the MFMAs of the tile before (they read the other stage)
@@ -147,7 +176,10 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
             floatx4 v = acc[i];
             if (p.bias) v += e_bias;
             if (p.post_scale) v = v * e_sc + e_sh;
-            if (p.res1) v = v * p.res1_scale + rres[i];
+            if (p.res1) {
+                if constexpr (res16) v = v * p.res1_scale + widen4<OPT>(float2v{rres[i][0], rres[i][1]});
+                else v = v * p.res1_scale + rres[i];
+            }
             if (p.post_relu) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
@@ -159,7 +191,10 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
                     ssq[q] += v[q] * v[q];
                 }
             }
-            if (vec_out) {
+            if constexpr (out16) {     // (host: cout_store == 16, 4-aligned strides) one rounding here, none in the consumer
+                const float t4[4] = {v[0], v[1], v[2], v[3]};
+                *(short4v*)((char*)p.out + ((pix0 + i * 16) * p.out_ld + p.out_coff + kk * 4) * 2) = round4<OPT>(t4);
+            } else if (vec_out) {
                 *(floatx4*)(o0 + i * 16 * p.out_ld) = v;
             } else {                   // the 1- / 7-channel output convs (conv_last): scalar stores of the real channels
 #pragma unroll

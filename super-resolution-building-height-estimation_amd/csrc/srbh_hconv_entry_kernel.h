@@ -18,7 +18,8 @@ struct EParams {
     int nchunk;
 };
 
-template <int OPT>
+// O16 (compile-time): both outputs are 16-bit tensors (fp16 for OPT 1)
+template <int OPT, int O16>
 __global__ __launch_bounds__(256, 3) void hconv_entry_kernel(const EParams e) {
     static_assert(OPT == 1 || OPT == 2, "16-bit operand forms only");
     const HParams& p = e.a;
@@ -155,8 +156,18 @@ __global__ __launch_bounds__(256, 3) void hconv_entry_kernel(const EParams e) {
                     dsum[q] += d[q]; dsq[q] += d[q] * d[q];
                 }
             }
-            *(floatx4*)(o1 + i * 16 * p.out_ld) = v;
-            *(floatx4*)(o2 + i * 16 * e.out2_ld) = d;
+            if constexpr (O16 != 0) {
+                const float t4[4] = {v[0], v[1], v[2], v[3]};
+                *(short4v*)((char*)p.out + ((pix0 + i * 16) * p.out_ld + p.out_coff + kk * 4) * 2) = round4<OPT>(t4);
+            } else {
+                *(floatx4*)(o1 + i * 16 * p.out_ld) = v;
+            }
+            if constexpr (O16 != 0) {
+                const float t4[4] = {d[0], d[1], d[2], d[3]};
+                *(short4v*)((char*)e.out2 + ((pix0 + i * 16) * e.out2_ld + e.out2_coff + kk * 4) * 2) = round4<OPT>(t4);
+            } else {
+                *(floatx4*)(o2 + i * 16 * e.out2_ld) = d;
+            }
         }
     }
     if (p.stats) {

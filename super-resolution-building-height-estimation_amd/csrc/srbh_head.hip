@@ -18,6 +18,8 @@
 #include <stdlib.h>
 #include "srbh_internal.h"
 
+#include <type_traits>
+
 namespace {
 using namespace srbh;
 
@@ -44,6 +46,22 @@ __device__ __forceinline__ short4v round4(const float (&v)[4]) {
         }
     }
     return r;
+}
+
+// 4 elements of a 16-bit tensor in memory (fp16 for OPT 1, bf16 for OPT 2; raw bits in a float2v) -> fp32
+template <int OPT>
+__device__ __forceinline__ floatx4 widen4(const float2v raw) {
+    // (whole-vector bit casts: bit_cast(unsigned, raw[1]) of a single ext-vector element returned element 0 with this hipcc)
+    typedef unsigned uint2q __attribute__((ext_vector_type(2)));
+    const uint2q rw = __builtin_bit_cast(uint2q, raw);
+    const unsigned lo = rw[0], hi = rw[1];
+    if constexpr (OPT == 1) {
+        const half4 h = __builtin_bit_cast(half4, raw);
+        return floatx4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    } else {
+        return floatx4{__builtin_bit_cast(float, lo << 16), __builtin_bit_cast(float, lo & 0xffff0000u),
+                       __builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+    }
 }
 
 constexpr int HT_W = 64;                    // output tile of one workgroup: (4 * RPW) rows x 64 columns, RPW rows per wave
@@ -162,7 +180,7 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
             const bool chok = ch < cin, in0 = ch < p.c0;
             const int ldp = in0 ? p.ld0 : p.ld1;
             // fp16 activations in memory (inference, SRBH_IO_*): element size 2, the quad is staged as it is (8-byte load, no rounding)
-            const bool srch = OPT == 1 && (p.io_h16 & (in0 ? SRBH_IO_SRC0_H16 : SRBH_IO_SRC1_H16)) != 0;
+            const bool srch = OPT != 0 && (p.io_h16 & (in0 ? SRBH_IO_SRC0_H16 : SRBH_IO_SRC1_H16)) != 0;
             const int esz = srch ? 2 : 4;
             const char* tp = (const char*)(in0 ? p.src0 : p.src1) +
                              ((((long)img * p.H + (Y0 - HALO)) * p.W + (X0 - HALO)) * ldp + (in0 ? ch : ch - p.c0)) * esz;
@@ -320,7 +338,7 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
         e_sh[ob] = p.post_scale ? *(const floatx4*)(p.post_shift + oc) : floatx4{0.f, 0.f, 0.f, 0.f};
     }
     const long pix0 = ((long)img * p.H + Y0 + wave * RPW) * p.W + X0 + l15;
-    const bool out16 = OPT == 1 && (p.io_h16 & SRBH_IO_OUT_H16) != 0, res16 = OPT == 1 && (p.io_h16 & SRBH_IO_RES1_H16) != 0;
+    const bool out16 = OPT != 0 && (p.io_h16 & SRBH_IO_OUT_H16) != 0, res16 = OPT != 0 && (p.io_h16 & SRBH_IO_RES1_H16) != 0;
     float* const o0 = (float*)((char*)p.out + (pix0 * p.out_ld + p.out_coff + kk * 4) * (out16 ? 2 : 4));
     const float* const r1p = p.res1 ? (const float*)((const char*)p.res1 + (pix0 * p.res1_ld + kk * 4) * (res16 ? 2 : 4)) : nullptr;
     const float* const r2p = p.res2 ? p.res2 + pix0 * p.res2_ld + kk * 4 : nullptr;
@@ -338,8 +356,8 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
             if (p.post_scale) v = v * e_sc[ob] + e_sh[ob];   // eval-mode BatchNorm
             if (ok && p.res1) {      // residual epilogues of the strict fp32 trunk (x5*0.2 + x, out*0.2 + x)
                 if (res16) {
-                    const half4 r = *(const half4*)((const char*)r1p + (long)(dpx * p.res1_ld + ob * 16) * 2);
-                    v = v * p.res1_scale + floatx4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+                    const float2v r = *(const float2v*)((const char*)r1p + (long)(dpx * p.res1_ld + ob * 16) * 2);
+                    v = v * p.res1_scale + widen4<OPT == 0 ? 1 : OPT>(r);
                 } else {
                     v = v * p.res1_scale + *(const floatx4*)(r1p + dpx * p.res1_ld + ob * 16);
                 }
@@ -373,8 +391,10 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                 } else {
                     float* o = o0 + dpx * p.out_ld + ob * 16;
                     if (out16) {          // (host: 4-aligned channels) one rounding here, none in the consumer
-                        if (oc < p.cout_store)
-                            *(half4*)((char*)o0 + (long)(dpx * p.out_ld + ob * 16) * 2) = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                        if (oc < p.cout_store) {
+                            const float t4[4] = {v[0], v[1], v[2], v[3]};
+                            *(short4v*)((char*)o0 + (long)(dpx * p.out_ld + ob * 16) * 2) = round4<OPT == 0 ? 1 : OPT>(t4);
+                        }
                     } else if (vec_out) {
                         if (oc < p.cout_store) *(floatx4*)o = v;
                     } else {
@@ -512,15 +532,21 @@ __global__ void bn_eval_kernel(int C, const float* gamma, const float* beta, con
 }
 
 // out = relu(a*sa + ha + (idt*si + hi))   (C multiple of 4; NHWC fp32)
-__global__ void bn_add_relu_kernel(const floatx4* __restrict__ a, const float* sa, const float* ha,
-                                   const floatx4* __restrict__ idt, const float* si, const float* hi, floatx4* out,
+// AH / IH: `a` / `idt` hold fp16 elements in memory (the saved activations of the training step, round 3)
+template <int AH, int IH>
+__global__ void bn_add_relu_kernel(const void* __restrict__ a, const float* sa, const float* ha,
+                                   const void* __restrict__ idt, const float* si, const float* hi, floatx4* out,
                                    long n4, int C) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long stride = (long)gridDim.x * blockDim.x;
     for (; i < n4; i += stride) {
         int c = (int)((i * 4) % C);
-        floatx4 v = a[i] * *(const floatx4*)(sa + c) + *(const floatx4*)(ha + c);
-        floatx4 d = idt[i];
+        floatx4 av, d;
+        if constexpr (AH != 0) av = widen4<1>(((const float2v*)a)[i]);
+        else av = ((const floatx4*)a)[i];
+        if constexpr (IH != 0) d = widen4<1>(((const float2v*)idt)[i]);
+        else d = ((const floatx4*)idt)[i];
+        floatx4 v = av * *(const floatx4*)(sa + c) + *(const floatx4*)(ha + c);
         if (si) d = d * *(const floatx4*)(si + c) + *(const floatx4*)(hi + c);
         v += d;
 #pragma unroll
@@ -669,11 +695,10 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
     p.post_scale = a->post_scale; p.post_shift = a->post_shift; p.post_relu = a->post_relu;
     p.io_h16 = a->io_h16;
     if (a->io_h16) {
-        SRBH_REQUIRE(opt == 1, "srbh_hconv: fp16 activations in memory (io_h16) need srbh_hconv_h16 with fp16 operands");
+        SRBH_REQUIRE(opt != 0, "srbh_hconv: 16-bit tensors in memory (io_h16) need srbh_hconv_h16 (element type = operand type: fp16 / bf16)");
         SRBH_REQUIRE((a->io_h16 & ~15) == 0, "srbh_hconv_h16: unknown io_h16 bits");
-        SRBH_REQUIRE(!(a->io_h16 & SRBH_IO_SRC0_H16) || (!a->pre_scale && !a->pre_relu), "srbh_hconv_h16: an fp16 src0 takes no pre-affine / ReLU");
-        SRBH_REQUIRE(!(a->io_h16 & SRBH_IO_OUT_H16) || (!a->pixelshuffle2 && !a->stats && a->cout % 4 == 0 && p.out_ld % 4 == 0 && a->out_coff % 4 == 0),
-                     "srbh_hconv_h16: an fp16 output needs 4-aligned channels, no PixelShuffle store, no statistics");
+        SRBH_REQUIRE(!(a->io_h16 & SRBH_IO_OUT_H16) || (!a->pixelshuffle2 && a->cout % 4 == 0 && p.out_ld % 4 == 0 && a->out_coff % 4 == 0),
+                     "srbh_hconv_h16: a 16-bit output needs 4-aligned channels and no PixelShuffle store");
         SRBH_REQUIRE(!(a->io_h16 & SRBH_IO_RES1_H16) || (a->res1 && !a->res2), "srbh_hconv_h16: fp16 residual: res1 only");
         // the 16-bit staging of fp16 sources exists in the vectorised path only
         SRBH_REQUIRE((a->c0 & 3) == 0 && (a->c1 & 3) == 0 && (p.ld0 & 3) == 0 && (a->c1 == 0 || (p.ld1 & 3) == 0),
@@ -700,22 +725,33 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
     } while (0)
     // the dominant layer shape has its own persistent, double-buffered kernel (srbh_hconv16_kernel.h)
     static const int k16_wgs = getenv("SRBH_HCONV16_WGS") ? atoi(getenv("SRBH_HCONV16_WGS")) : 768;     // 0 = always the template
-    const bool full16 = a->cout == 16 && (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 && ((uintptr_t)a->out & 15) == 0;
-    const bool narrow = a->cout < 16 && !a->stats && !a->res1;                 // conv_last (1 / 7 channels): scalar stores
+    const bool src16 = (a->io_h16 & SRBH_IO_SRC0_H16) != 0, o16 = (a->io_h16 & SRBH_IO_OUT_H16) != 0, r16 = (a->io_h16 & SRBH_IO_RES1_H16) != 0;
+    const bool full16 = a->cout == 16 && (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 && ((uintptr_t)a->out & (o16 ? 7 : 15)) == 0;
+    const bool narrow = a->cout < 16 && !a->stats && !a->res1 && !o16;         // conv_last (1 / 7 channels): scalar stores
     if (opt != 0 && k16_wgs >= 8 && a->ksize == 3 && (full16 || narrow) && a->c0 == 16 && a->c1 == 0 && (W & 63) == 0 && (H & 3) == 0 &&
-        !a->pixelshuffle2 && !a->res2 && !a->post_lrelu && !a->io_h16 && (p.ld0 & 3) == 0 &&
-        (!a->res1 || (a->res1_ld & 3) == 0) && (((uintptr_t)a->src0 | (uintptr_t)a->res1) & 15) == 0) {
+        !a->pixelshuffle2 && !a->res2 && !a->post_lrelu && (p.ld0 & 3) == 0 &&
+        (!a->res1 || (a->res1_ld & 3) == 0) && ((uintptr_t)a->src0 & (src16 ? 7 : 15)) == 0 && ((uintptr_t)a->res1 & (r16 ? 7 : 15)) == 0) {
         p.tiles_x = W / 64;
         p.tiles_per_img = p.tiles_x * (H / 4);
         p.ntiles = p.tiles_per_img * B;
         p.tiles_per_xcd = (p.ntiles + 7) / 8;
         const int per_xcd = p.tiles_per_xcd < k16_wgs / 8 ? p.tiles_per_xcd : k16_wgs / 8;
         constexpr int LDS16 = 2 * 6 * 66 * 32;
-        if (opt == 1) hipLaunchKernelGGL(hconv16_kernel<1>, dim3(per_xcd * 8), dim3(256), LDS16, st, p);
-        else hipLaunchKernelGGL(hconv16_kernel<2>, dim3(per_xcd * 8), dim3(256), LDS16, st, p);
+        const int io = (r16 && a->res1 ? 1 : 0) | (o16 ? 2 : 0);
+#define SRBH_K16(O_, S_, I_) hipLaunchKernelGGL((hconv16_kernel<O_, S_, I_>), dim3(per_xcd * 8), dim3(256), LDS16, st, p)
+#define SRBH_K16_IO(O_, S_) do { switch (io) { case 0: SRBH_K16(O_, S_, 0); break; case 1: SRBH_K16(O_, S_, 1); break; \
+                                               case 2: SRBH_K16(O_, S_, 2); break; default: SRBH_K16(O_, S_, 3); } } while (0)
+        if (opt == 1 && !src16) SRBH_K16_IO(1, 0);
+        else if (opt == 1) SRBH_K16_IO(1, 1);
+        else if (!src16) SRBH_K16_IO(2, 0);
+        else SRBH_K16_IO(2, 1);
+#undef SRBH_K16_IO
+#undef SRBH_K16
         SRBH_HIP(hipGetLastError());
         return SRBH_OK;
     }
+    // (the template stages a 16-bit source as it is: no transform on the way)
+    SRBH_REQUIRE(!src16 || (!a->pre_scale && !a->pre_relu), "srbh_hconv_h16: a 16-bit src0 takes a pre-affine / ReLU only in the 16 -> 16 3x3 form");
     if (opt == 1) SRBH_H16_DISPATCH(1);
     if (opt == 2) SRBH_H16_DISPATCH(2);
 #undef SRBH_H16_DISPATCH
@@ -749,12 +785,12 @@ extern "C" int srbh_hconv_entry_h16(const srbh_hconv_args* c1, const srbh_hconv_
     const int out1_ld = c1->out_ld > 0 ? c1->out_ld : c1->cout, out2_ld = ds->out_ld > 0 ? ds->out_ld : ds->cout;
     const bool plain = !c1->pre_scale && !c1->pre_relu && !ds->pre_scale && !ds->pre_relu && !c1->pixelshuffle2 && !ds->pixelshuffle2 &&
                        !c1->res1 && !ds->res1 && !c1->res2 && !ds->res2 && !c1->post_lrelu && !ds->post_lrelu && !ds->post_relu &&
-                       !c1->io_h16 && !ds->io_h16 && (!c1->stats == !ds->stats);
+                       !(c1->io_h16 & ~SRBH_IO_OUT_H16) && c1->io_h16 == ds->io_h16 && (!c1->stats == !ds->stats);
     const bool shape = c1->ksize == 3 && ds->ksize == 1 && c1->cout == 16 && ds->cout == 16 && c1->c0 > 0 && (c1->c0 & 15) == 0 &&
                        (c1->c1 & 15) == 0 && cin <= 80 && (c1->c1 == 0 || c1->src1) && c1->B > 0 && (c1->W & 63) == 0 && (c1->H & 3) == 0 &&
                        (ld0 & 3) == 0 && (c1->c1 == 0 || (ld1 & 3) == 0) && (out1_ld & 3) == 0 && (out2_ld & 3) == 0 &&
                        (c1->out_coff & 3) == 0 && (ds->out_coff & 3) == 0 &&
-                       (((uintptr_t)c1->src0 | (uintptr_t)c1->src1 | (uintptr_t)c1->out | (uintptr_t)ds->out) & 15) == 0;
+                       (((uintptr_t)c1->src0 | (uintptr_t)c1->src1) & 15) == 0 && (((uintptr_t)c1->out | (uintptr_t)ds->out) & 7) == 0;
     if (!(wgs >= 8 && same && plain && shape && c1->src0 && c1->w && ds->w && c1->out && ds->out)) {
         if (int rc = hconv_impl(c1, stream, bf16 ? 2 : 1)) return rc;
         return hconv_impl(ds, stream, bf16 ? 2 : 1);
@@ -771,7 +807,7 @@ extern "C" int srbh_hconv_entry_h16(const srbh_hconv_args* c1, const srbh_hconv_
     p.out = c1->out; p.stats = c1->stats;
     p.ld0 = ld0; p.ld1 = ld1; p.out_ld = out1_ld; p.out_coff = c1->out_coff;
     p.post_lrelu = 0; p.res1 = nullptr; p.res1_ld = 0; p.res1_scale = 1.f; p.res2 = nullptr; p.res2_ld = 0; p.res2_scale = 1.f;
-    p.post_scale = c1->post_scale; p.post_shift = c1->post_shift; p.post_relu = c1->post_relu; p.io_h16 = 0;
+    p.post_scale = c1->post_scale; p.post_shift = c1->post_shift; p.post_relu = c1->post_relu; p.io_h16 = c1->io_h16 & SRBH_IO_OUT_H16;
     p.tiles_x = c1->W / 64;
     p.tiles_per_img = p.tiles_x * (c1->H / 4);
     p.ntiles = p.tiles_per_img * c1->B;
@@ -785,8 +821,11 @@ extern "C" int srbh_hconv_entry_h16(const srbh_hconv_args* c1, const srbh_hconv_
     }
     const int per_xcd = p.tiles_per_xcd < wgs / 8 ? p.tiles_per_xcd : wgs / 8;
     const int lds_b = 2 * 6 * 66 * 32 + e.nchunk * 640 * 8;
-    if (bf16) hipLaunchKernelGGL(hconv_entry_kernel<2>, dim3(per_xcd * 8), dim3(256), lds_b, st, e);
-    else hipLaunchKernelGGL(hconv_entry_kernel<1>, dim3(per_xcd * 8), dim3(256), lds_b, st, e);
+    const bool eo16 = (c1->io_h16 & SRBH_IO_OUT_H16) != 0;
+    if (bf16 && eo16) hipLaunchKernelGGL((hconv_entry_kernel<2, 1>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);
+    else if (bf16) hipLaunchKernelGGL((hconv_entry_kernel<2, 0>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);
+    else if (eo16) hipLaunchKernelGGL((hconv_entry_kernel<1, 1>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);
+    else hipLaunchKernelGGL((hconv_entry_kernel<1, 0>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }
@@ -809,15 +848,29 @@ extern "C" int srbh_bn_eval_scale_shift(int C, const float* gamma, const float* 
     return SRBH_OK;
 }
 
-extern "C" int srbh_bn_add_relu(const float* a, const float* a_scale, const float* a_shift, const float* idt,
-                                const float* i_scale, const float* i_shift, float* out, long npix, int C, void* stream) {
+static int bn_add_relu_impl(const void* a, const float* a_scale, const float* a_shift, const void* idt, const float* i_scale,
+                            const float* i_shift, float* out, long npix, int C, int io, void* stream) {
     SRBH_REQUIRE(a && a_scale && a_shift && idt && out && npix > 0 && C > 0 && C % 4 == 0, "srbh_bn_add_relu: bad arguments");
+    SRBH_REQUIRE((io & ~3) == 0, "srbh_bn_add_relu_io: unknown io bits");
     long n4 = npix * C / 4;
     int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(bn_add_relu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const floatx4*)a, a_scale,
-                       a_shift, (const floatx4*)idt, i_scale, i_shift, (floatx4*)out, n4, C);
+#define SRBH_BAR(A_, I_) hipLaunchKernelGGL((bn_add_relu_kernel<A_, I_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, a_scale, a_shift, \
+                                            idt, i_scale, i_shift, (floatx4*)out, n4, C)
+    switch (io) { case 0: SRBH_BAR(0, 0); break; case 1: SRBH_BAR(1, 0); break; case 2: SRBH_BAR(0, 1); break; default: SRBH_BAR(1, 1); break; }
+#undef SRBH_BAR
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
+}
+
+extern "C" int srbh_bn_add_relu(const float* a, const float* a_scale, const float* a_shift, const float* idt,
+                                const float* i_scale, const float* i_shift, float* out, long npix, int C, void* stream) {
+    return bn_add_relu_impl(a, a_scale, a_shift, idt, i_scale, i_shift, out, npix, C, 0, stream);
+}
+
+/* io: SRBH_BAR_A_H16 (1) = `a` holds fp16 elements, SRBH_BAR_IDT_H16 (2) = `idt` does */
+extern "C" int srbh_bn_add_relu_io(const void* a, const float* a_scale, const float* a_shift, const void* idt,
+                                   const float* i_scale, const float* i_shift, float* out, long npix, int C, int io, void* stream) {
+    return bn_add_relu_impl(a, a_scale, a_shift, idt, i_scale, i_shift, out, npix, C, io, stream);
 }
 
 extern "C" int srbh_aggregate(const float* data, float* out, int N, int H, int W, int step, void* stream) {

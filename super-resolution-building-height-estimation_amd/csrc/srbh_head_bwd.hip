@@ -11,10 +11,14 @@
 //  * small elementwise helpers: relu mask, in-place add, per-channel sum (bias grad), PixelShuffle(2) inverse.
 #include "srbh_internal.h"
 
+#include <type_traits>
+
 namespace {
 using namespace srbh;
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float float2w __attribute__((ext_vector_type(2)));
+typedef _Float16 half4w __attribute__((ext_vector_type(4)));
 constexpr int HT_H = 8, HT_W = 64;
 constexpr int NSLOT = 64;
 constexpr int WS_SLOTS = 768;                  // per-workgroup partial-sum slots of the weight-gradient workspace (max grid.x)
@@ -31,7 +35,41 @@ struct WGParams {
     int B, H, W;
     int tiles_x, tiles_per_img, ntiles, tiles_per_xcd;
     int ld0, ld1;         // pixel strides (floats) of src0 / src1
+    int io;               // SRBH_WG_SRC0_H16: src0 holds fp16 elements; SRBH_WG_DY_B16: dy holds bf16 elements (16-bit forms only)
 };
+
+// 4 elements of a 16-bit tensor (raw bits in a float2w) -> fp32: fp16 activations / bf16 gradients
+__device__ __forceinline__ floatx4 widen_h4(const float2w raw) {
+    const half4w h = __builtin_bit_cast(half4w, raw);
+    return floatx4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+// (bit casts go through WHOLE vectors: __builtin_bit_cast of one ext-vector element -- bit_cast(unsigned, v[j]) -- returned element 0
+//  for every j with this hipcc: every quad came back as (e0, e1, e0, e1).  Found by tools/io16_unit.py; now a test.)
+typedef unsigned uint2q __attribute__((ext_vector_type(2)));
+typedef unsigned uint4q __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ floatx4 widen_b4(const float2w raw) {
+    const uint2q rw = __builtin_bit_cast(uint2q, raw);
+    const unsigned lo = rw[0], hi = rw[1];
+    return floatx4{__builtin_bit_cast(float, lo << 16), __builtin_bit_cast(float, lo & 0xffff0000u),
+                   __builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+}
+__device__ __forceinline__ float2w narrow_b4(const floatx4 v) {      // fp32 -> bf16 (RNE), 4 elements as raw bits
+    const uint4q uv = __builtin_bit_cast(uint4q, v);
+    unsigned r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned u = uv[j];
+        r[j] = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    }
+    const uint2q o = {r[0] | (r[1] << 16), r[2] | (r[3] << 16)};
+    return __builtin_bit_cast(float2w, o);
+}
+// the 16-bit element j (0..3) of two raw quads a, b -> one dword (a's element in the low half)
+__device__ __forceinline__ unsigned b16_field_pair(const float2w a, const float2w b, const int j) {
+    const uint2q ua = __builtin_bit_cast(uint2q, a), ub = __builtin_bit_cast(uint2q, b);
+    const unsigned wa = ua[j >> 1], wb = ub[j >> 1];
+    return (j & 1) ? ((wa >> 16) | (wb & 0xffff0000u)) : ((wa & 0xffffu) | (wb << 16));
+}
 
 // One workgroup walks tiles t = blockIdx.x, +gridDim.x, ... and keeps the 16(oc) x 16(ci) x taps partial sums of
 // one (oc block = blockIdx.y, ci chunk) in registers; flushed once per chunk through LDS with one atomic per value.
@@ -237,7 +275,8 @@ struct WG16 {
     static constexpr int LDS_B = (16 * SX + 16 * SD) * 4;   // >= the flush buffer (4 waves x TAPS x 256 floats)
 };
 
-template <int KS>
+// DS = 1: dY holds bf16 elements in memory (an internal gradient tensor of the training step): its bits are the operand
+template <int KS, int DS>
 __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     using G = WG16<KS>;
@@ -267,7 +306,9 @@ __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
             // ---- stage: every global load of the tile is issued before the first LDS store.  (Issuing the NEXT tile's loads before this
             // tile's MFMAs -- a software pipeline over the walk -- needs 281 registers, one workgroup per CU: 152 -> 232 us.)
             constexpr int NIX = (ROWS * QX * 4 + 255) / 256, NID = HT_H * 16 * 4 / 256;
-            floatx4 lx[NIX][4], ld[NID][4];
+            typedef typename std::conditional<DS != 0, float2w, floatx4>::type ldv_t;
+            floatx4 lx[NIX][4];
+            ldv_t ld[NID][4];
 #pragma unroll
             for (int it = 0; it < NIX; ++it) {
                 const int u = tid + it * 256;
@@ -303,9 +344,9 @@ __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
                 const int y = Y0 + (q >> 4), x0 = X0 + (q & 15) * 4;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    floatx4 a = {0.f, 0.f, 0.f, 0.f};
+                    ldv_t a = ldv_t{};
                     if (y < p.H && x0 + i < p.W)
-                        a = *(const floatx4*)(p.dy + (((long)img * p.H + y) * p.W + x0 + i) * p.cout_total + ob * 16 + cg * 4);
+                        a = *(const ldv_t*)((const char*)p.dy + ((((long)img * p.H + y) * p.W + x0 + i) * p.cout_total + ob * 16 + cg * 4) * (DS ? 2 : 4));
                     ld[it][i] = a;
                 }
             }
@@ -326,9 +367,13 @@ __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
                 const int u = tid + it * 256;
                 const int cg = u & 3, q = u >> 2;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *(uint2w*)(s_dy + (cg * 4 + j) * SD + q * 2) =
-                        uint2w{bf16_pair(ld[it][0][j], ld[it][1][j]), bf16_pair(ld[it][2][j], ld[it][3][j])};
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (DS != 0)
+                        *(uint2w*)(s_dy + (cg * 4 + j) * SD + q * 2) = uint2w{b16_field_pair(ld[it][0], ld[it][1], j), b16_field_pair(ld[it][2], ld[it][3], j)};
+                    else
+                        *(uint2w*)(s_dy + (cg * 4 + j) * SD + q * 2) =
+                            uint2w{bf16_pair(ld[it][0][j], ld[it][1][j]), bf16_pair(ld[it][2][j], ld[it][3][j])};
+                }
             }
             __syncthreads();
             // ---- 2 rows x 4 groups of 16 pixels per wave
@@ -498,9 +543,18 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
 // (flat index % (C/4)) of the pixels it walks, its per-channel constants live in registers, partial sums are flushed once per thread.
 // `relu_ref` / `dz_out` fold the block-closing ReLU backward into the reduce pass (dz = g where ref > 0; it is written for the
 // skip / downsample branches and read back by the apply pass): one 3-tensor elementwise launch per BasicBlock less.
-__global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const floatx4* __restrict__ g, const floatx4* __restrict__ c, const float* mean,
+// 16-bit tensors in memory (round 3; template flags): GB = g holds bf16 elements, CH = c holds fp16 elements, OB = dz_out / out is written
+// as bf16.  One 4-channel group is then an 8-byte access; the arithmetic stays fp32.
+template <int B16, typename T>
+__device__ __forceinline__ floatx4 ld4(const T* base, const long i) {
+    if constexpr (B16 == 0) return ((const floatx4*)base)[i];
+    else if constexpr (B16 == 1) return widen_h4(((const float2w*)base)[i]);
+    else return widen_b4(((const float2w*)base)[i]);
+}
+template <int GB, int CH, int OB>
+__global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const void* __restrict__ g, const void* __restrict__ c, const float* mean,
                                                               const float* invstd, const float* ms, const float* mh,
-                                                              const floatx4* __restrict__ relu_ref, floatx4* __restrict__ dz_out,
+                                                              const floatx4* __restrict__ relu_ref, void* __restrict__ dz_out,
                                                               long n4, int C, double* stats /* [NSLOT][2][C] */) {
     extern __shared__ float red[];   // [2][C]
     for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) red[k] = 0.f;
@@ -514,15 +568,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const floatx4* __re
     if (ms) { msv = *(const floatx4*)(ms + ch); mhv = *(const floatx4*)(mh + ch); }
     floatx4 s = {0.f, 0.f, 0.f, 0.f}, q = s;
     for (; i < n4; i += stride) {
-        floatx4 dy = g[i];
+        floatx4 dy = ld4<GB ? 2 : 0>(g, i);
         if (relu_ref) {
             const floatx4 r = relu_ref[i];
 #pragma unroll
             for (int j = 0; j < 4; ++j) dy[j] = r[j] > 0.f ? dy[j] : 0.f;
-            if (dz_out) dz_out[i] = dy;
+            if (dz_out) {
+                if constexpr (OB != 0) {
+                    const float2w nb = narrow_b4(dy);
+                    ((float2w*)dz_out)[i] = nb;
+                    dy = widen_b4(nb);          // the sums are taken over the values the consumers will read
+                } else {
+                    ((floatx4*)dz_out)[i] = dy;
+                }
+            }
         }
         if (c) {
-            const floatx4 cv = c[i];
+            const floatx4 cv = ld4<CH ? 1 : 0>(c, i);
             if (ms) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dy[j] = cv[j] * msv[j] + mhv[j] > 0.f ? dy[j] : 0.f;
@@ -541,9 +603,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const floatx4* __re
     for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) atomicAdd(slot + k, (double)red[k]);
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const floatx4* __restrict__ g, const floatx4* __restrict__ c, const float* mean,
+template <int GB, int CH, int OB>
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const void* __restrict__ g, const void* __restrict__ c, const float* mean,
                                                              const float* invstd, const float* ms, const float* mh, const float* coef,
-                                                             const float* k1, const float* k2, floatx4* __restrict__ out, long n4, int C) {
+                                                             const float* k1, const float* k2, void* __restrict__ out, long n4, int C) {
     const int C4 = C >> 2;
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -553,13 +616,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const floatx4* __res
     floatx4 msv = {0.f, 0.f, 0.f, 0.f}, mhv = msv;
     if (ms) { msv = *(const floatx4*)(ms + ch); mhv = *(const floatx4*)(mh + ch); }
     for (; i < n4; i += stride) {
-        floatx4 dy = g[i];
-        const floatx4 cv = c[i];
+        floatx4 dy = ld4<GB ? 2 : 0>(g, i);
+        const floatx4 cv = ld4<CH ? 1 : 0>(c, i);
         if (ms) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) dy[j] = cv[j] * msv[j] + mhv[j] > 0.f ? dy[j] : 0.f;
         }
-        out[i] = cf * (dy - a1 - ((cv - mn) * is) * a2);
+        const floatx4 r = cf * (dy - a1 - ((cv - mn) * is) * a2);
+        if constexpr (OB != 0) ((float2w*)out)[i] = narrow_b4(r);
+        else ((floatx4*)out)[i] = r;
     }
 }
 
@@ -602,7 +667,11 @@ int wgrad_impl(const srbh_hwgrad_args* a, void* stream, bool b16, const char* wh
     p.ld1 = a->src1_ld > 0 ? a->src1_ld : a->c1;
     p.pre_scale = a->pre_scale; p.pre_shift = a->pre_shift; p.pre_relu = a->pre_relu;
     p.dy = a->dy; p.cout_total = a->cout; p.dw = a->dw; p.ws = a->ws;
+    p.io = a->io;
     SRBH_REQUIRE(a->ws, "srbh_hconv_wgrad: workspace missing (srbh_hwgrad_ws_bytes)");
+    SRBH_REQUIRE((a->io & ~(SRBH_WG_SRC0_H16 | SRBH_WG_DY_B16)) == 0, "srbh_hconv_wgrad: unknown io bits");
+    SRBH_REQUIRE(!a->io || b16, "srbh_hconv_wgrad_f32: 16-bit tensors in memory need the bf16-operand form (srbh_hconv_wgrad_b16)");
+    const bool xs16 = (a->io & SRBH_WG_SRC0_H16) != 0, ds16 = (a->io & SRBH_WG_DY_B16) != 0;
     p.B = a->B; p.H = a->H; p.W = a->W;
     p.tiles_x = (a->W + HT_W - 1) / HT_W;
     p.tiles_per_img = p.tiles_x * ((a->H + HT_H - 1) / HT_H);
@@ -615,11 +684,14 @@ int wgrad_impl(const srbh_hwgrad_args* a, void* stream, bool b16, const char* wh
     // the bf16 form moves whole 4-channel groups with 16-byte loads and whole 16-channel output blocks; the few layers outside
     // that (the 1- and 7-channel output convs) keep the fp32 kernel
     const bool can16 = (a->c0 & 3) == 0 && (a->c1 & 3) == 0 && (p.ld0 & 3) == 0 && (a->c1 == 0 || (p.ld1 & 3) == 0) && (a->cout & 15) == 0 &&
-                       ((uintptr_t)a->src0 & 15) == 0 && ((uintptr_t)a->src1 & 15) == 0 && ((uintptr_t)a->dy & 15) == 0;
+                       ((uintptr_t)a->src0 & 15) == 0 && ((uintptr_t)a->src1 & 15) == 0 && ((uintptr_t)a->dy & (ds16 ? 7 : 15)) == 0;
     // the dominant layer shape has its own double-buffered kernel (srbh_hwgrad16_kernel.h)
     static const int k16_wgs = getenv("SRBH_HWGRAD16_WGS") ? atoi(getenv("SRBH_HWGRAD16_WGS")) : 768;   // 0 = never
     const bool k16 = b16 && k16_wgs >= 8 && k16_wgs <= WS_SLOTS && a->ksize == 3 && a->c0 == 16 && a->c1 == 0 && a->cout == 16 &&
-                     (a->W & 63) == 0 && (a->H & 3) == 0 && (p.ld0 & 3) == 0 && (((uintptr_t)a->src0 | (uintptr_t)a->dy) & 15) == 0;
+                     (a->W & 63) == 0 && (a->H & 3) == 0 && (p.ld0 & 3) == 0 && ((uintptr_t)a->src0 & (xs16 ? 7 : 15)) == 0 &&
+                     ((uintptr_t)a->dy & (ds16 ? 7 : 15)) == 0;
+    SRBH_REQUIRE(!xs16 || k16, "srbh_hconv_wgrad_b16: an fp16 source tensor is supported by the 16 -> 16 3x3 form only");
+    SRBH_REQUIRE(!ds16 || k16 || can16, "srbh_hconv_wgrad_b16: a bf16 dY needs 4-aligned channels / 16-channel output blocks");
     if (k16) {
         p.tiles_x = a->W / 64;
         p.tiles_per_img = p.tiles_x * (a->H / 4);
@@ -627,17 +699,29 @@ int wgrad_impl(const srbh_hwgrad_args* a, void* stream, bool b16, const char* wh
         p.tiles_per_xcd = (p.ntiles + 7) / 8;
         const int per_xcd = p.tiles_per_xcd < k16_wgs / 8 ? p.tiles_per_xcd : k16_wgs / 8;
         gx = per_xcd * 8;
-        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG16T::LDS_B)));
-        hipLaunchKernelGGL(hwgrad16_kernel, dim3(gx), dim3(256), WG16T::LDS_B, st, p);
+#define SRBH_WG16(X_, D_)                                                                                                              \
+    do {                                                                                                                          \
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad16_kernel<X_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, WG16T::LDS_B))); \
+        hipLaunchKernelGGL((hwgrad16_kernel<X_, D_>), dim3(gx), dim3(256), WG16T::LDS_B, st, p);                                   \
+    } while (0)
+        if (xs16 && ds16) SRBH_WG16(1, 1);
+        else if (xs16) SRBH_WG16(1, 0);
+        else if (ds16) SRBH_WG16(0, 1);
+        else SRBH_WG16(0, 0);
+#undef SRBH_WG16
     } else
     if (b16 && can16) {
+#define SRBH_WGB(K_, D_)                                                                                                               \
+    do {                                                                                                                          \
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_b16_kernel<K_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, WG16<K_>::LDS_B))); \
+        hipLaunchKernelGGL((hwgrad_b16_kernel<K_, D_>), dim3(gx, nob), dim3(256), WG16<K_>::LDS_B, st, p);                          \
+    } while (0)
         if (a->ksize == 3) {
-            SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_b16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WG16<3>::LDS_B)));
-            hipLaunchKernelGGL(hwgrad_b16_kernel<3>, dim3(gx, nob), dim3(256), WG16<3>::LDS_B, st, p);
+            if (ds16) SRBH_WGB(3, 1); else SRBH_WGB(3, 0);
         } else {
-            SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_b16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WG16<1>::LDS_B)));
-            hipLaunchKernelGGL(hwgrad_b16_kernel<1>, dim3(gx, nob), dim3(256), WG16<1>::LDS_B, st, p);
+            if (ds16) SRBH_WGB(1, 1); else SRBH_WGB(1, 0);
         }
+#undef SRBH_WGB
     } else if (a->ksize == 3) {
         constexpr int LDS_B = (10 * 66 * 16 + 4 * 9 * 256) * 4;   // X tile + max(dY tile, flush buffer)
         SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_f32_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)));
@@ -687,19 +771,27 @@ extern "C" int srbh_add_inplace(float* a, const float* b, long n, void* stream) 
     return SRBH_OK;
 }
 
-static int bn_bwd_reduce_impl(const float* g, const float* relu_ref, float* dz_out, const float* c, const float* mean, const float* invstd,
-                              const float* mask_scale, const float* mask_shift, long npix, int C, double* stats, void* stream) {
+static int bn_bwd_reduce_impl(const void* g, const float* relu_ref, void* dz_out, const void* c, const float* mean, const float* invstd,
+                              const float* mask_scale, const float* mask_shift, long npix, int C, double* stats, void* stream, int io = 0) {
     hipStream_t st = (hipStream_t)stream;
     if (int rc = zero_async(stats, (size_t)NSLOT * 2 * C * sizeof(double), st)) return rc;
-    const bool v4 = (C & 3) == 0 && (256 % (C >> 2)) == 0 && (((uintptr_t)g | (uintptr_t)c | (uintptr_t)mean | (uintptr_t)invstd |
+    const bool gb = (io & SRBH_BN_G_B16) != 0, ch = (io & SRBH_BN_C_H16) != 0, ob = (io & SRBH_BN_OUT_B16) != 0;
+    const bool v4 = (C & 3) == 0 && (256 % (C >> 2)) == 0 && ((uintptr_t)g & (gb ? 7 : 15)) == 0 && ((uintptr_t)c & (ch ? 7 : 15)) == 0 &&
+                    ((uintptr_t)dz_out & (ob ? 7 : 15)) == 0 && (((uintptr_t)relu_ref | (uintptr_t)mean | (uintptr_t)invstd |
                      (uintptr_t)mask_scale | (uintptr_t)mask_shift) & 15) == 0;
+    SRBH_REQUIRE(!io || v4, "srbh_bn_bwd_reduce: 16-bit tensors need the vector form (C %% 4 == 0, 256 %% (C/4) == 0, aligned)");
     if (v4) {
         const long n4 = npix * (C >> 2);
-        hipLaunchKernelGGL(bn_bwd_reduce4_kernel, dim3(grid4_for(n4)), dim3(256), 2 * C * sizeof(float), st, (const floatx4*)g,
-                           (const floatx4*)c, mean, invstd, mask_scale, mask_shift, (const floatx4*)relu_ref, (floatx4*)dz_out, n4, C, stats);
+#define SRBH_BNR(G_, C_, O_) hipLaunchKernelGGL((bn_bwd_reduce4_kernel<G_, C_, O_>), dim3(grid4_for(n4)), dim3(256), 2 * C * sizeof(float), st, \
+                                                g, c, mean, invstd, mask_scale, mask_shift, (const floatx4*)relu_ref, dz_out, n4, C, stats)
+        switch ((gb ? 4 : 0) | (ch ? 2 : 0) | (ob ? 1 : 0)) {
+            case 0: SRBH_BNR(0, 0, 0); break; case 1: SRBH_BNR(0, 0, 1); break; case 2: SRBH_BNR(0, 1, 0); break; case 3: SRBH_BNR(0, 1, 1); break;
+            case 4: SRBH_BNR(1, 0, 0); break; case 5: SRBH_BNR(1, 0, 1); break; case 6: SRBH_BNR(1, 1, 0); break; default: SRBH_BNR(1, 1, 1); break;
+        }
+#undef SRBH_BNR
     } else {
         SRBH_REQUIRE(!relu_ref, "srbh_bn_bwd_reduce_relu: needs the 16-byte form (C %% 4 == 0, aligned)");
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(npix * C)), dim3(256), 2 * C * sizeof(float), st, g, c, mean,
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(npix * C)), dim3(256), 2 * C * sizeof(float), st, (const float*)g, (const float*)c, mean,
                            invstd, mask_scale, mask_shift, npix, C, stats);
     }
     SRBH_HIP(hipGetLastError());
@@ -723,6 +815,36 @@ extern "C" int srbh_bn_bwd_reduce_relu(const float* g, const float* relu_ref, fl
     return bn_bwd_reduce_impl(g, relu_ref, dz_out, c, mean, invstd, nullptr, nullptr, npix, C, stats, stream);
 }
 
+/* the same two reductions with 16-bit tensors in memory (io: SRBH_BN_G_B16 | SRBH_BN_C_H16 | SRBH_BN_OUT_B16); relu_ref / dz_out optional */
+extern "C" int srbh_bn_bwd_reduce_io(const void* g, const float* relu_ref, void* dz_out, const void* c, const float* mean, const float* invstd,
+                                     const float* mask_scale, const float* mask_shift, long npix, int C, double* stats, int io, void* stream) {
+    SRBH_REQUIRE(g && stats && npix > 0 && C > 0 && C <= 64, "srbh_bn_bwd_reduce_io: bad arguments");
+    SRBH_REQUIRE(!c || (mean && invstd), "srbh_bn_bwd_reduce_io: c needs mean/invstd");
+    SRBH_REQUIRE(!mask_scale || (c && mask_shift), "srbh_bn_bwd_reduce_io: mask needs c and mask_shift");
+    SRBH_REQUIRE(!(relu_ref && mask_scale), "srbh_bn_bwd_reduce_io: either the block-closing ReLU (relu_ref) or the bn1 mask");
+    SRBH_REQUIRE((io & ~7) == 0, "srbh_bn_bwd_reduce_io: unknown io bits");
+    return bn_bwd_reduce_impl(g, relu_ref, dz_out, c, mean, invstd, mask_scale, mask_shift, npix, C, stats, stream, io);
+}
+
+extern "C" int srbh_bn_bwd_apply_io(const void* g, const void* c, const float* mean, const float* invstd, const float* mask_scale,
+                                    const float* mask_shift, const float* coef, const float* k1, const float* k2, void* out, long npix, int C,
+                                    int io, void* stream) {
+    SRBH_REQUIRE(g && c && mean && invstd && coef && k1 && k2 && out && npix > 0 && C > 0, "srbh_bn_bwd_apply_io: bad arguments");
+    const bool gb = (io & SRBH_BN_G_B16) != 0, ch = (io & SRBH_BN_C_H16) != 0, ob = (io & SRBH_BN_OUT_B16) != 0;
+    SRBH_REQUIRE((io & ~7) == 0 && (C & 3) == 0 && (256 % (C >> 2)) == 0 && ((uintptr_t)g & (gb ? 7 : 15)) == 0 && ((uintptr_t)c & (ch ? 7 : 15)) == 0 &&
+                 ((uintptr_t)out & (ob ? 7 : 15)) == 0, "srbh_bn_bwd_apply_io: needs the vector form (C %% 4 == 0, 256 %% (C/4) == 0, aligned)");
+    const long n4 = npix * (C >> 2);
+#define SRBH_BNA(G_, C_, O_) hipLaunchKernelGGL((bn_bwd_apply4_kernel<G_, C_, O_>), dim3(grid4_for(n4)), dim3(256), 0, (hipStream_t)stream, \
+                                                g, c, mean, invstd, mask_scale, mask_shift, coef, k1, k2, out, n4, C)
+    switch ((gb ? 4 : 0) | (ch ? 2 : 0) | (ob ? 1 : 0)) {
+        case 0: SRBH_BNA(0, 0, 0); break; case 1: SRBH_BNA(0, 0, 1); break; case 2: SRBH_BNA(0, 1, 0); break; case 3: SRBH_BNA(0, 1, 1); break;
+        case 4: SRBH_BNA(1, 0, 0); break; case 5: SRBH_BNA(1, 0, 1); break; case 6: SRBH_BNA(1, 1, 0); break; default: SRBH_BNA(1, 1, 1); break;
+    }
+#undef SRBH_BNA
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
 extern "C" int srbh_bn_bwd_finalize(const double* stats, int C, double count, const float* gamma, const float* invstd,
                                     float* dgamma, float* dbeta, float* coef, float* k1, float* k2, void* stream) {
     SRBH_REQUIRE(stats && C > 0 && C <= 64 && count > 0, "srbh_bn_bwd_finalize: bad arguments");
@@ -740,8 +862,8 @@ extern "C" int srbh_bn_bwd_apply(const float* g, const float* c, const float* me
     if ((C & 3) == 0 && (256 % (C >> 2)) == 0 && (((uintptr_t)g | (uintptr_t)c | (uintptr_t)out | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)coef |
                                                     (uintptr_t)k1 | (uintptr_t)k2 | (uintptr_t)mask_scale | (uintptr_t)mask_shift) & 15) == 0) {
         const long n4 = npix * (C >> 2);
-        hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(grid4_for(n4)), dim3(256), 0, (hipStream_t)stream, (const floatx4*)g, (const floatx4*)c,
-                           mean, invstd, mask_scale, mask_shift, coef, k1, k2, (floatx4*)out, n4, C);
+        hipLaunchKernelGGL((bn_bwd_apply4_kernel<0, 0, 0>), dim3(grid4_for(n4)), dim3(256), 0, (hipStream_t)stream, (const void*)g, (const void*)c,
+                           mean, invstd, mask_scale, mask_shift, coef, k1, k2, (void*)out, n4, C);
     } else
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * C)), dim3(256), 0, (hipStream_t)stream, g, c, mean,
                        invstd, mask_scale, mask_shift, coef, k1, k2, out, npix * C, C);

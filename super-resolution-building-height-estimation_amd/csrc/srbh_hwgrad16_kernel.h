@@ -17,6 +17,10 @@ struct WG16T {
     static constexpr int LDS_B = 2 * STAGE_DW * 4;    // 50 176 bytes (>= the 36 864-byte flush buffer)
 };
 
+// 16-bit tensors in memory (round 3, WGParams::io): XS = the source holds fp16 elements (a saved activation: widened, transformed by the
+// pre-affine as before, rounded to bf16 while staged), DS = dY holds bf16 elements (an internal gradient tensor: its bits ARE the
+// operand, no rounding).  A staging item is then an 8-byte load per pixel; the raw quads stay in registers until the LDS store.
+template <int XS, int DS>
 __global__ __launch_bounds__(256, 3) void hwgrad16_kernel(const WGParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     using G = WG16T;
@@ -51,15 +55,18 @@ __global__ __launch_bounds__(256, 3) void hwgrad16_kernel(const WGParams p) {
     floatx4 acc[9];
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) acc[tp] = floatx4{0.f, 0.f, 0.f, 0.f};
-    floatx4 lx[NIX][4], ld[4];
+    typedef typename std::conditional<XS != 0, float2w, floatx4>::type lxv_t;
+    typedef typename std::conditional<DS != 0, float2w, floatx4>::type ldv_t;
+    lxv_t lx[NIX][4];
+    ldv_t ld[4];
     unsigned okx = 0;
     auto issue = [&](const int t) {
         const int img = t / p.tiles_per_img;
         const int trem = t - img * p.tiles_per_img;
         const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
         const int Y0 = ty * 4, X0 = tx * 64;
-        const float* xp = p.src0 + (((long)img * p.H + (Y0 - 1)) * p.W + (X0 - 4)) * p.ld0;
-        const float* dp = p.dy + (((long)img * p.H + Y0) * p.W + X0) * p.cout_total;
+        const char* xp = (const char*)p.src0 + (((long)img * p.H + (Y0 - 1)) * p.W + (X0 - 4)) * p.ld0 * (XS ? 2 : 4);
+        const char* dp = (const char*)p.dy + (((long)img * p.H + Y0) * p.W + X0) * p.cout_total * (DS ? 2 : 4);
         okx = 0;
 #pragma unroll
         for (int it = 0; it < NIX; ++it) {
@@ -68,39 +75,51 @@ __global__ __launch_bounds__(256, 3) void hwgrad16_kernel(const WGParams p) {
             if (xq[it] == QX - 1) ok = ok && X0 + 64 < p.W;
             if (it == 1) ok = ok && x1_valid;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lx[it][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4; ++i) lx[it][i] = lxv_t{};
             if (ok) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) lx[it][i] = *(const floatx4*)(xp + xoff[it] + i * p.ld0);
+                for (int i = 0; i < 4; ++i) lx[it][i] = *(const lxv_t*)(xp + (long)(xoff[it] + i * p.ld0) * (XS ? 2 : 4));
                 okx |= 1u << it;
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ld[i] = *(const floatx4*)(dp + doff + i * p.cout_total);
+        for (int i = 0; i < 4; ++i) ld[i] = *(const ldv_t*)(dp + (long)(doff + i * p.cout_total) * (DS ? 2 : 4));
     };
     auto commit = [&](unsigned* stage) {
 #pragma unroll
         for (int it = 0; it < NIX; ++it) {
             if (it == 0 || x1_valid) {
+                floatx4 xv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (XS != 0) xv[i] = widen_h4(lx[it][i]);
+                    else xv[i] = lx[it][i];
+                }
                 if (okx & (1u << it)) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        floatx4 a = lx[it][i] * psc + psh;
+                        floatx4 a = xv[i] * psc + psh;
                         if (pre_relu) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) a[j] = fmaxf(a[j], 0.f);
                         }
-                        lx[it][i] = a;
+                        xv[i] = a;
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    *(uint2w*)(stage + xlds[it] + j * SX) = uint2w{bf16_pair(lx[it][0][j], lx[it][1][j]), bf16_pair(lx[it][2][j], lx[it][3][j])};
+                    *(uint2w*)(stage + xlds[it] + j * SX) = uint2w{bf16_pair(xv[0][j], xv[1][j]), bf16_pair(xv[2][j], xv[3][j])};
             }
         }
+        if constexpr (DS != 0) {      // bf16 in memory: channel j of the 4 pixels = 16-bit fields of the raw quads
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            *(uint2w*)(stage + dlds + j * SD) = uint2w{bf16_pair(ld[0][j], ld[1][j]), bf16_pair(ld[2][j], ld[3][j])};
+            for (int j = 0; j < 4; ++j)
+                *(uint2w*)(stage + dlds + j * SD) = uint2w{b16_field_pair(ld[0], ld[1], j), b16_field_pair(ld[2], ld[3], j)};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(uint2w*)(stage + dlds + j * SD) = uint2w{bf16_pair(ld[0][j], ld[1][j]), bf16_pair(ld[2][j], ld[3][j])};
+        }
     };
 
     if (t_first < t_end) issue(t_first);

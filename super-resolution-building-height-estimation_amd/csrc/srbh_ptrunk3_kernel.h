@@ -38,6 +38,24 @@
 #ifndef P3_DMA_FIRST
 #define P3_DMA_FIRST 1          // 1: a group's DMA statements sit behind its FIRST MFMAs, the LDS reads behind the later ones
 #endif
+#ifndef P3_LAZYDRAIN
+// 1 (round 3): a layer prologue waits only for what the layer's step 0 READS (the LDS-DMA issued during the previous layer's last
+// step: `s_waitcnt vmcnt(<stores of the epilogue in between>)`), not for the epilogue's global stores to be acknowledged by L2 as
+// well (r02: vmcnt(0), 1.1 k cycles per cout-32 prologue, 1.9 k behind the whole-plane stores of X3 / X4, with the matrix core idle);
+// the stores drain under step 0's MFMAs and the progress counter is published behind the layer's FIRST top-of-step barrier instead
+// (whose vmcnt(0) then covers them for free), in front of any neighbour check of that layer: every workgroup publishes layer L before
+// it waits for layer L, so the exchange cannot deadlock.
+#define P3_LAZYDRAIN 1
+#endif
+#ifndef P3_SPREAD
+// 1 (round 3): the next group's LDS reads are spread EVENLY over the group's MFMA shadows (one read behind every MFMA of a
+// cout-32 group, every second MFMA of conv5's) in the order of their FIRST USE, and the staging items share those shadows
+// (LDS and VMEM are separate issue paths).  The r02 schedule packed a group's 9 (12) reads, two per shadow, behind its LAST 5 (6)
+// MFMAs: all four waves march in lock-step, so every group boundary put 36 (48) ds_read_b128 = 288 (384) cycles of LDS
+// pipe into a 160 (192)-cycle window, with the fragment the next group's FIRST MFMA needs (A[dy=0]) issued 7th -- the matrix
+// core waited ~100 cycles at each of the 6 group boundaries of a step, and 7 reads deep after every step barrier.
+#define P3_SPREAD 1
+#endif
 
 // PROF = 1 (developer timeline, SRBH_PT_PROF): s_memtime stamps per layer in ptrunk_kernel's 6-slot format
 template <int PROF>
@@ -294,7 +312,13 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         constexpr int ND = NDMA + (IN == 2 ? 9 : 0);                    // + LDS stores of a register-staged plane
         constexpr int RSH = (NRD + P3_READS_PER_SHADOW - 1) / P3_READS_PER_SHADOW;   // MFMA shadows of a group that carry LDS reads
         constexpr int DPG = NMF - RSH;                                                 // ... that can carry a staging item
-        static_assert(ND + (DEFER ? 20 : 0) <= 6 * DPG, "the staging items (and deferred epilogue units) of a step must fit its MFMA shadows");
+        static_assert(ND + (DEFER ? 20 : 0) <= 6 * (P3_SPREAD ? 12 : DPG), "the staging items (and deferred epilogue units) of a step must fit its MFMA shadows");
+        // LDS reads of a group in the order of their first use by the MFMA sequence below (m = dy-major, then row, then channel block):
+        // r < NP: pixel-row fragment P[r]; r = NP + dy * CB + mb: weight fragment A[dy][mb]
+        constexpr int ORD1[9] = {6, 0, 1, 2, 3, 7, 4, 8, 5};                   // CB = 1: A0 P0 P1 P2 P3 A1 P4 A2 P5
+        constexpr int ORD2[12] = {6, 0, 7, 1, 2, 3, 8, 9, 4, 10, 11, 5};       // CB = 2: A00 P0 A01 P1 P2 P3 A10 A11 P4 A20 A21 P5
+        static_assert(G::NP == 6, "read order tables are written for 6 pixel-row fragments");
+        constexpr int RSTRIDE = NMF / NRD;                                      // shadows per read when spread: 1 (CB = 1), 2 (CB = 2)
         const unsigned long long ibase = uni64((unsigned long long)nsrc);
         const unsigned long long wbase = uni64((unsigned long long)(nw + wave * 1024));
         const unsigned din_w = __builtin_amdgcn_readfirstlane(lds_addr(dst) + wave * 1024);
@@ -330,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             }
         };
 #pragma unroll
-        for (int r = 0; r < NRD; ++r) read_item(0, r, 0);
+        for (int r = 0; r < NRD; ++r) read_item(0, P3_SPREAD ? (CB == 1 ? ORD1[r % 9] : ORD2[r % 12]) : r, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
@@ -339,6 +363,19 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 const int dy = m / (4 * CB), rem = m - dy * 4 * CB, i = rem / CB, mb = rem - i * CB;
                 acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g & 1][dy][mb], P[g & 1][i + dy], acc[mb][i], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (P3_SPREAD) {
+                    const int k = m / RSTRIDE;
+                    if (g + 1 < 6 && m % RSTRIDE == 0 && k < NRD) read_item(g + 1, CB == 1 ? ORD1[k % 9] : ORD2[k % 12], (g + 1) & 1);
+                    // staging: one item per shadow for a cout-32 group (12), every other shadow of conv5's (the ones without a read)
+                    const int sm = CB == 1 ? m : (m % 2 ? m / 2 : -1);
+                    if (sm >= 0) {
+                        const int d = g * 12 + sm;
+                        if (d < ND) stage_item(d);
+                        else if (DEFER && d - ND < 20) defer_unit(d - ND);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
                 const int mr = P3_DMA_FIRST ? m - DPG : m;          // shadow index among the read-carrying ones
                 const int md = P3_DMA_FIRST ? m : m - RSH;          // ... among the staging ones
                 if (mr >= 0 && mr < RSH) {
@@ -381,6 +418,29 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid < nb) ((float*)(smem + bias_lds))[tid] = bias_v;
+        if (pending_pub) {
+            publish(pub_val);
+            pending_pub = false;
+        }
+    };
+    // P3_LAZYDRAIN: the next layer's bias is requested BEFORE the epilogue's stores (an asm load: the compiler's own wait for a load
+    // it tracks would be vmcnt(0) -- it does not count the asm stores issued behind it), so that `vmcnt(NST)` in the prologue
+    // covers it together with the step-0 DMA and leaves exactly the epilogue's NST stores in flight
+    auto bias_request = [&](const float* bias, const int nb) {
+        float v;
+        const float* q = bias + (tid < nb ? tid : 0);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(q) : "memory");
+        return v;
+    };
+    auto prologue_lazy = [&](auto nst_tag, const float bias_v, const int nb, const int bias_lds) {
+        constexpr int NST = decltype(nst_tag)::value;
+        if constexpr (NST == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid < nb) ((float*)(smem + bias_lds))[tid] = bias_v;
+    };
+    auto publish_pending = [&]() {
         if (pending_pub) {
             publish(pub_val);
             pending_pub = false;
@@ -572,6 +632,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         // ---------------- conv1..conv4 (cout 32, plane 0 resident, stages of IN_EX + 18 KiB).  One body for conv1..3 and one
         // for conv4 (their last steps stage different things: compiling them as two variants of ONE layer body made the
         // accumulators of the two last-step variants meet in a phi, i.e. 64 v_accvgpr_mov per layer)
+        float next_bias = 0.f;   // P3_LAZYDRAIN: the next layer's bias element of this thread, requested ahead of the epilogue
         auto layerA = [&](auto kk_tag, auto last_nw_tag) {
             // (kk is a compile-time constant: four bodies per RDB instead of two, but the parked epilogue registers of P3_DEFER are
             //  then provably dead outside conv1..3 -> conv2..4; as a run-time loop variable they were live across conv5: 217 spills)
@@ -580,7 +641,13 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             const char* wl = T[kk].w;
             unsigned long long p0 = 0, p1 = 0, p2 = 0;
             if (PROF) p0 = __builtin_amdgcn_s_memtime();
-            prologue(T[kk].bias, 32, A_BIAS_OFF);
+            if (P3_LAZYDRAIN && kk > 0) {
+                // stores of the previous layer's epilogue still in flight per wave: X1 / X2 go out as one halo row (2 x 16 B), X3 whole (8)
+                constexpr bool prev_halo_only = P3_SKIPST && P3_S1 && (kk - 1 == 0 || (P3_X2REG && kk - 1 == 1));
+                prologue_lazy(std::integral_constant<int, prev_halo_only ? 2 : 8>{}, next_bias, 32, A_BIAS_OFF);
+            } else {
+                prologue(T[kk].bias, 32, A_BIAS_OFF);
+            }
             if (PROF) p1 = __builtin_amdgcn_s_memtime();
             t_sync = 0;
             t_vm = 0;
@@ -610,6 +677,14 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                          smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{});
             }
             ++gs;
+            // the layer's FIRST top-of-step barrier (P3_LAZYDRAIN: it carries the lazy publication of the previous layer's output:
+            // its vmcnt(0) covers the epilogue stores that drained under step 0), in front of any neighbour check
+            bool synced = false;
+            if (P3_LAZYDRAIN) {
+                step_sync();
+                publish_pending();
+                synced = true;
+            }
             // The only NEW input plane of conv2..4 is the last chunk (index kk + 1): its halo rows are fetched during step kk, so
             // the neighbours' progress is checked right in front of that step (conv1's inputs were verified at the seam).
             if (kk == 1) {
@@ -617,7 +692,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 if (aborted) return;
             }
             if (n >= 3) {      // step 1: chunk 1; stages chunk 2 (X1) from registers
-                step_sync();
+                if (!synced) step_sync();
+                synced = false;
                 const char* st = smem + stage_off(1, gs & 1);
                 run_step(C1{}, I2{}, W5{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (18 * 1024),
                          smem + stage_off(1, (gs + 1) & 1), X1r, NODEFER{});
@@ -643,7 +719,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                          smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{});
                 ++gs;
             }
-            step_sync();
+            if (!synced) step_sync();
             {
                 const char* st = smem + stage_off(1, gs & 1);
                 if constexpr (decltype(last_nw_tag)::value == 5)   // conv1..3: the next layer's step 0 reads the resident plane: weights only
@@ -652,6 +728,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                     run_step(C1{}, I0{}, W9{}, acc, st, st + IN_EX, nullptr, T[4].w, smem + stage_off(2, 0), x1p, NODEFER{});
                 ++gs;
             }
+            if (P3_LAZYDRAIN) next_bias = bias_request(T[kk + 1].bias, kk == 3 ? 64 : 32);   // (older than the epilogue's stores)
             if (PROF) p2 = __builtin_amdgcn_s_memtime();
             uintx4 kept[4][2];
             const bool halo_only = P3_SKIPST && P3_S1 && (kk == 0 || (P3_X2REG && kk == 1));
@@ -690,7 +767,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             const char* wl = T[4].w;
             unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;
             if (PROF) p0 = __builtin_amdgcn_s_memtime();
-            prologue(T[4].bias, 64, B_BIAS_OFF);
+            if (P3_LAZYDRAIN) prologue_lazy(std::integral_constant<int, 8>{}, next_bias, 64, B_BIAS_OFF);   // (X4 went out whole: 8 stores per wave)
+            else prologue(T[4].bias, 64, B_BIAS_OFF);
             if (PROF) p1 = __builtin_amdgcn_s_memtime();
             t_sync = 0;
             t_vm = 0;
@@ -706,6 +784,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + (long)pp.plane_b, wl + 36 * 1024, smem + stage_off(2, 1), x1p, NODEFER{});
             }
             step_sync();
+            if (P3_LAZYDRAIN) publish_pending();       // conv4's output: its stores drained under step 0
             {   // chunk 1; stages chunk 2 (X1) from registers
                 const char* st = smem + stage_off(2, 1);
                 run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (36 * 1024), smem + stage_off(2, 0), X1r, NODEFER{});

@@ -30,6 +30,9 @@ BN_EPS_DEFAULT = 1e-5
 
 
 # ----------------------------------------------------------------------------- low-level ops (NHWC fp32)
+_T16 = (torch.float16, torch.bfloat16)      # 16-bit tensors in memory: fp16 activations (fp16-operand kernels), bf16 gradients (bf16-operand kernels)
+
+
 def _require_dev(x, who, h16_ok=False):
     if not (torch.is_tensor(x) and x.is_cuda):
         raise RuntimeError(f"{who} (libsrbh): input must be a ROCm/HIP device tensor; the head has no CPU fallback")
@@ -104,7 +107,21 @@ def head_h16():
 # chain, inside the 1e-3 tolerance) and is 3 % SLOWER -- measured A/B in one process at B=128: model forward 15.0 vs 14.55 ms.  The
 # head kernels are not bound by bytes but by their one-tile-per-workgroup structure; the flag is what a persistent
 # kernel will want, and stays covered by tests/test_gpu_head_f16.py.
-FP16_ACTIVATIONS = _os.environ.get("SRBH_FP16_ACT", "0") == "1"
+FP16_ACTIVATIONS = _os.environ.get("SRBH_FP16_ACT", "1") == "1"
+
+# 16-bit tensors INSIDE a BasicBlock of the training step (hrfuse_autograd._BasicBlockFn, mixed-precision mode "f16" only; round 3).
+# (1) TRAIN_IO16: the gradient tensors that never leave one block's backward -- dz, dc2, da1, dc1, dd -- are stored as bf16.  Their
+#     consumers, the data- and weight-gradient kernels, round their operands to bf16 anyway, and the BatchNorm-backward passes read
+#     them widened to fp32: measured against the exact-fp32 graph the parameter gradients are as accurate as with fp32 tensors
+#     (median relative error 7.4e-3 both ways, tools/io16_err.py) -- 14 of a plain block's 21 backward tensor passes move half the
+#     bytes, the step 49.3 -> 47.0 ms.  SRBH_TRAIN_IO16=0 keeps every tensor fp32 (A/B aid).
+# (2) TRAIN_IO16_ACT: additionally store saved ACTIVATIONS as fp16: "c1c2" = conv1's, conv2's and the downsample conv's outputs,
+#     "c1" / "c2" = one of them, "none" (default) = none.  "c1c2" is another 2 ms (45.0 ms) but costs accuracy the default mode does
+#     not spend: the consumer rounds an already-rounded value (training-mode forward of HRfeature + HRfuse_residual against the exact
+#     graph: 8.9e-4 -> 1.11e-3, i.e. past the 1e-3 the mixed mode otherwise keeps; gradients unchanged at cos 0.996).  Opt in.
+# Block inputs / outputs and the gradients crossing autograd stay fp32 either way.
+TRAIN_IO16 = _os.environ.get("SRBH_TRAIN_IO16", "1") == "1"
+TRAIN_IO16_ACT = _os.environ.get("SRBH_TRAIN_IO16_ACT", "none")
 
 
 def fp16_chain(mod):
@@ -172,10 +189,12 @@ def _hconv_args(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False,
     a.cout, a.ksize = cout, ks
     a.B, a.H, a.W = B, H, W
     a.pixelshuffle2 = int(ps2)
-    io = ((1 if x0.dtype == torch.float16 else 0) | (2 if c1 and srcs[1].dtype == torch.float16 else 0)
-          | (4 if res is not None and res.dtype == torch.float16 else 0) | (8 if out_h16 else 0))
+    io = ((1 if x0.dtype in _T16 else 0) | (2 if c1 and srcs[1].dtype in _T16 else 0)
+          | (4 if res is not None and res.dtype in _T16 else 0) | (8 if out_h16 else 0))
     if io and not h16:
         raise RuntimeError("libsrbh hconv: fp16 activations need the fp16-operand mode (set_head_precision)")
+    if any(t is not None and t.dtype == torch.bfloat16 for t in (x0, srcs[1] if c1 else None, res)):
+        raise TypeError("libsrbh hconv (forward, fp16 operands): 16-bit tensors must be float16 (bfloat16 is the gradient kernels' type)")
     a.io_h16 = io
     out = (empty_nhwc(B, cout // 4, 2 * H, 2 * W, x0.device) if ps2
            else empty_nhwc(B, cout, H, W, x0.device, torch.float16 if out_h16 else torch.float32))
@@ -204,13 +223,15 @@ def hconv(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_
     return out, stats
 
 
-def hconv_entry(srcs, conv1, packed1, convd, packedd, want_stats=False, postd=None):
+def hconv_entry(srcs, conv1, packed1, convd, packedd, want_stats=False, postd=None, post1=None, post1_relu=False, out_h16=False):
     """The entry of a BasicBlock with a downsample branch: conv1 (3x3) and downsample[0] (1x1) over the same cat(srcs) in ONE
     libsrbh call (srbh_hconv_entry_h16: one fused pass over the input when the shapes allow, else the two launches; 16-bit operand
-    modes only).  Returns (c1, stats1, d, statsd); postd = (scale, shift) of the downsample BatchNorm in inference."""
+    modes only).  Returns (c1, stats1, d, statsd); postd = (scale, shift) of the downsample BatchNorm in inference; post1 /
+    post1_relu = bn1 (+ ReLU) in conv1's epilogue and out_h16 = both outputs as fp16 tensors (the fp16 inference chain, and the
+    fp16 saved activations of the training step)."""
     L = _lib.lib()
-    a1, c1, st1, h16, _k1 = _hconv_args(srcs, conv1, packed1, want_stats=want_stats)
-    a2, d, st2, _, _k2 = _hconv_args(srcs, convd, packedd, want_stats=want_stats, post=postd)
+    a1, c1, st1, h16, _k1 = _hconv_args(srcs, conv1, packed1, want_stats=want_stats, post=post1, post_relu=post1_relu, out_h16=out_h16)
+    a2, d, st2, _, _k2 = _hconv_args(srcs, convd, packedd, want_stats=want_stats, post=postd, out_h16=out_h16)
     if not h16:
         raise RuntimeError("hconv_entry: fp16-operand mode only")
     _lib.check(L.srbh_hconv_entry_h16(C.byref(a1), C.byref(a2), 0, _lib.stream_ptr()), "hconv_entry_h16")
@@ -305,11 +326,13 @@ class defer_batch_counters:
 
 
 def bn_add_relu(a, sa, ha, idt, si=None, hi=None):
+    """out = relu(a * sa + ha + [idt * si + hi | idt]) (fp32 NHWC); `a` / `idt` may be fp16 tensors (the training step's saved activations)"""
     B, Cc, H, W = a.shape
     out = empty_nhwc(B, Cc, H, W, a.device)
-    _lib.check(_lib.lib().srbh_bn_add_relu(a.data_ptr(), sa.data_ptr(), ha.data_ptr(), idt.data_ptr(),
-                                           None if si is None else si.data_ptr(), None if hi is None else hi.data_ptr(),
-                                           out.data_ptr(), B * H * W, Cc, _lib.stream_ptr()), "bn_add_relu")
+    io = (1 if a.dtype == torch.float16 else 0) | (2 if idt.dtype == torch.float16 else 0)
+    _lib.check(_lib.lib().srbh_bn_add_relu_io(a.data_ptr(), sa.data_ptr(), ha.data_ptr(), idt.data_ptr(),
+                                              None if si is None else si.data_ptr(), None if hi is None else hi.data_ptr(),
+                                              out.data_ptr(), B * H * W, Cc, io, _lib.stream_ptr()), "bn_add_relu")
     return out
 
 
@@ -424,11 +447,16 @@ class BasicBlock(nn.Module):
                 and all(t.shape[1] % 4 == 0 for t in srcs)):
             s1, h1, _, _ = bn_scale_shift(self.bn1, None, n, False)
             s2, h2, _, _ = bn_scale_shift(self.bn2, None, n, False)
-            a1, _ = hconv(srcs, self.conv1, self._p1, post=(s1, h1), post_relu=True, out_h16=True)
-            if self.downsample is not None:
+            if self.downsample is not None and all(t.dtype == torch.float32 for t in srcs):
+                sd, hd, _, _ = bn_scale_shift(self.downsample[1], None, n, False)      # conv1 + the 1x1 downsample conv: one pass over the input
+                a1, _, idt, _ = hconv_entry(srcs, self.conv1, self._p1, self.downsample[0], self._pd, postd=(sd, hd), post1=(s1, h1),
+                                            post1_relu=True, out_h16=True)
+            elif self.downsample is not None:
+                a1, _ = hconv(srcs, self.conv1, self._p1, post=(s1, h1), post_relu=True, out_h16=True)
                 sd, hd, _, _ = bn_scale_shift(self.downsample[1], None, n, False)
                 idt, _ = hconv(srcs, self.downsample[0], self._pd, post=(sd, hd), out_h16=True)
             else:
+                a1, _ = hconv(srcs, self.conv1, self._p1, post=(s1, h1), post_relu=True, out_h16=True)
                 if len(srcs) != 1:
                     raise ValueError("identity path needs a single source")
                 idt = srcs[0]

@@ -42,7 +42,9 @@ class _PackedGrad:
         return self.w
 
 
-def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None, h16=False):
+def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None, h16=False, out_b16=False):
+    """data-gradient conv (bf16 operands when h16): `srcs[0]` / `res` may be bf16 tensors (internal gradient tensors of a block),
+    out_b16 writes one"""
     L = _lib.lib()
     x0 = srcs[0]
     B, c0, Hh, Ww = x0.shape
@@ -57,10 +59,15 @@ def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None, h1
     a.cout, a.ksize = cout, ks
     a.B, a.H, a.W = B, Hh, Ww
     a.pixelshuffle2 = int(ps2)
-    out = H.empty_nhwc(B, cout // 4, 2 * Hh, 2 * Ww, x0.device) if ps2 else H.empty_nhwc(B, cout, Hh, Ww, x0.device)
+    out = (H.empty_nhwc(B, cout // 4, 2 * Hh, 2 * Ww, x0.device) if ps2
+           else H.empty_nhwc(B, cout, Hh, Ww, x0.device, torch.bfloat16 if out_b16 else torch.float32))
     a.out = out.data_ptr()
     if res is not None:          # out = conv + res in the conv's epilogue (exact: fma(y, 1, res))
         a.res1, a.res1_ld, a.res1_scale = res.data_ptr(), res.shape[1], 1.0
+    a.io_h16 = ((1 if x0.dtype == torch.bfloat16 else 0) | (4 if res is not None and res.dtype == torch.bfloat16 else 0)
+                | (8 if out_b16 else 0))
+    if a.io_h16 and not h16:
+        raise RuntimeError("libsrbh data gradient: bf16 tensors need the bf16-operand mode")
     if h16:      # (data gradients: bf16 operands -- fp32's exponent range, no loss scaling needed)
         _lib.check(L.srbh_hconv_h16(C.byref(a), 1, _lib.stream_ptr()), "hconv_h16(bf16)")
     else:
@@ -68,13 +75,13 @@ def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None, h1
     return out
 
 
-def conv_dgrad(g, weight, cache: _PackedGrad, res=None):
+def conv_dgrad(g, weight, cache: _PackedGrad, res=None, out_b16=False):
     """dX = conv^T(g, W) (+ res): the forward kernel with transposed + flipped weights; `res` (NHWC, same shape as dX) is the
     gradient arriving over a skip connection, added in the epilogue instead of by a separate pass.  16-bit operands (bf16:
     gradients need fp32's exponent range) only in the explicit "f16" head precision mode (H.set_head_precision)."""
     cout, cin, ks, _ = weight.shape
     h16 = H.head_h16()
-    return _hconv_raw([g], cache.get(weight, h16), None, cin, ks, res=res, h16=h16)
+    return _hconv_raw([g], cache.get(weight, h16), None, cin, ks, res=res, h16=h16, out_b16=out_b16 and h16)
 
 
 def conv_wgrad(srcs, pre, g, cout, ks):
@@ -94,6 +101,7 @@ def conv_wgrad(srcs, pre, g, cout, ks):
     a.dw = dw.data_ptr()
     ws = torch.empty(L.srbh_hwgrad_ws_bytes(cout, c0 + c1, ks) // 4, dtype=torch.float32, device=x0.device)
     a.ws = ws.data_ptr()
+    a.io = (1 if x0.dtype == torch.float16 else 0) | (2 if g.dtype == torch.bfloat16 else 0)
     if H.head_h16():       # mixed precision: bf16 operands (like the data gradients), fp32 accumulation
         _lib.check(L.srbh_hconv_wgrad_b16(C.byref(a), _lib.stream_ptr()), "hconv_wgrad_b16")
     else:
@@ -118,10 +126,10 @@ def channel_sum(g):
     return out
 
 
-def bn_backward(g, c, mean, invstd, gamma, mask, training, relu_ref=None):
+def bn_backward(g, c, mean, invstd, gamma, mask, training, relu_ref=None, out_b16=False):
     """BatchNorm (+ optional ReLU mask [c*ms+mh > 0]) backward.  Returns (dc, dgamma, dbeta).
     relu_ref: the gradient first passes the block-closing ReLU (dz = g where relu_ref > 0) inside the reduce pass; returns
-    (dc, dgamma, dbeta, dz)."""
+    (dc, dgamma, dbeta, dz).  16-bit tensors (TRAIN_IO16): g may be bf16, c fp16; out_b16 writes dz / dc as bf16."""
     L = _lib.lib()
     B, Cc, Hh, Ww = c.shape
     n = B * Hh * Ww
@@ -129,9 +137,24 @@ def bn_backward(g, c, mean, invstd, gamma, mask, training, relu_ref=None):
     st = _stats_buf(Cc, dev)
     ms, mh = (mask[0].data_ptr(), mask[1].data_ptr()) if mask is not None else (None, None)
     dz = None
+    vec = Cc % 4 == 0 and 256 % (Cc // 4) == 0
+    io_c = 2 if c.dtype == torch.float16 else 0
+    use_io = vec and (io_c or out_b16 or g.dtype == torch.bfloat16)
+    if (io_c or out_b16 or g.dtype == torch.bfloat16) and not vec:
+        raise NotImplementedError("libsrbh BatchNorm backward: 16-bit tensors need C % 4 == 0 and 256 % (C/4) == 0")
+    odt = torch.bfloat16 if out_b16 else torch.float32
+    if use_io:
+        if relu_ref is not None:
+            dz = H.empty_nhwc(B, Cc, Hh, Ww, dev, odt)
+        io = io_c | (4 if g.dtype == torch.bfloat16 else 0) | (1 if out_b16 else 0)
+        _lib.check(L.srbh_bn_bwd_reduce_io(g.data_ptr(), None if relu_ref is None else relu_ref.data_ptr(),
+                                           None if dz is None else dz.data_ptr(), c.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                           ms, mh, n, Cc, st.data_ptr(), io, _lib.stream_ptr()), "bn_bwd_reduce_io")
+        if dz is not None:
+            g = dz
     # (the fused reduce+ReLU pass exists in the 16-byte form only: a thread owns one 4-channel group and 256 threads must hold
     # whole pixels -- csrc/srbh_head_bwd.hip bn_bwd_reduce_impl; other widths, e.g. super_mid=24, take the two-pass fallback)
-    if relu_ref is not None and Cc % 4 == 0 and 256 % (Cc // 4) == 0 and mask is None:
+    elif relu_ref is not None and vec and mask is None:
         dz = torch.empty_like(relu_ref)
         _lib.check(L.srbh_bn_bwd_reduce_relu(g.data_ptr(), relu_ref.data_ptr(), dz.data_ptr(), c.data_ptr(), mean.data_ptr(),
                                              invstd.data_ptr(), n, Cc, st.data_ptr(), _lib.stream_ptr()), "bn_bwd_reduce_relu")
@@ -160,9 +183,14 @@ def bn_backward(g, c, mean, invstd, gamma, mask, training, relu_ref=None):
     if not training:       # frozen statistics: the mean terms vanish
         k1.zero_()
         k2.zero_()
-    dc = H.empty_nhwc(B, Cc, Hh, Ww, dev)
-    _lib.check(L.srbh_bn_bwd_apply(g.data_ptr(), c.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ms, mh, coef.data_ptr(),
-                                   k1.data_ptr(), k2.data_ptr(), dc.data_ptr(), n, Cc, _lib.stream_ptr()), "bn_bwd_apply")
+    dc = H.empty_nhwc(B, Cc, Hh, Ww, dev, odt)
+    if use_io:
+        io = io_c | (4 if g.dtype == torch.bfloat16 else 0) | (1 if out_b16 else 0)
+        _lib.check(L.srbh_bn_bwd_apply_io(g.data_ptr(), c.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ms, mh, coef.data_ptr(),
+                                          k1.data_ptr(), k2.data_ptr(), dc.data_ptr(), n, Cc, io, _lib.stream_ptr()), "bn_bwd_apply_io")
+    else:
+        _lib.check(L.srbh_bn_bwd_apply(g.data_ptr(), c.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ms, mh, coef.data_ptr(),
+                                       k1.data_ptr(), k2.data_ptr(), dc.data_ptr(), n, Cc, _lib.stream_ptr()), "bn_bwd_apply")
     if relu_ref is not None:
         return dc, dgamma, dbeta, dz
     return dc, dgamma, dbeta
@@ -242,18 +270,23 @@ class _BasicBlockFn(torch.autograd.Function):
         B, _, Hh, Ww = srcs[0].shape
         n = B * Hh * Ww
         fuse_entry = blk.downsample is not None and H.head_h16()     # conv1 + the 1x1 downsample conv: one pass over the input
+        # 16-bit block-internal tensors (H.TRAIN_IO16): the 16-channel 3x3 blocks of the head, mixed-precision mode only
+        io16 = (H.TRAIN_IO16 and H.head_h16() and blk.conv1.out_channels == 16 and blk.conv2.out_channels == 16 and Ww % 64 == 0
+                and Hh % 4 == 0 and all(t.shape[1] % 16 == 0 for t in srcs) and (blk.downsample is not None or srcs[0].shape[1] == 16))
+        ctx.io16 = io16
+        a1_16, a2_16 = io16 and "c1" in H.TRAIN_IO16_ACT, io16 and "c2" in H.TRAIN_IO16_ACT
         if fuse_entry:
-            c1, st1, d_f, std_f = H.hconv_entry(srcs, blk.conv1, blk._p1, blk.downsample[0], blk._pd, want_stats=tr)
+            c1, st1, d_f, std_f = H.hconv_entry(srcs, blk.conv1, blk._p1, blk.downsample[0], blk._pd, want_stats=tr, out_h16=a1_16)
         else:
-            c1, st1 = H.hconv(srcs, blk.conv1, blk._p1, want_stats=tr)
+            c1, st1 = H.hconv(srcs, blk.conv1, blk._p1, want_stats=tr, out_h16=a1_16)
         s1, h1, m1, i1 = H.bn_scale_shift(blk.bn1, st1, n, tr)
-        c2, st2 = H.hconv([c1], blk.conv2, blk._p2, pre=(s1, h1, True), want_stats=tr)
+        c2, st2 = H.hconv([c1], blk.conv2, blk._p2, pre=(s1, h1, True), want_stats=tr, out_h16=a2_16)
         s2, h2, m2, i2 = H.bn_scale_shift(blk.bn2, st2, n, tr)
         if not tr:
             (m1, i1), (m2, i2) = _bn_eval_stats(blk.bn1), _bn_eval_stats(blk.bn2)
         d = md = idd = None
         if blk.downsample is not None:
-            d, std = (d_f, std_f) if fuse_entry else H.hconv(srcs, blk.downsample[0], blk._pd, want_stats=tr)
+            d, std = (d_f, std_f) if fuse_entry else H.hconv(srcs, blk.downsample[0], blk._pd, want_stats=tr, out_h16=a1_16)
             sd, hd, md, idd = H.bn_scale_shift(blk.downsample[1], std, n, tr)
             if not tr:
                 md, idd = _bn_eval_stats(blk.downsample[1])
@@ -275,20 +308,21 @@ class _BasicBlockFn(torch.autograd.Function):
         if has_ds:
             d, md, idd, wd, gd = sv[nsrc + 13:]
         caches = blk.__dict__.setdefault("_srbh_gcaches", [_PackedGrad(), _PackedGrad(), _PackedGrad()])
+        b16 = bool(getattr(ctx, "io16", False)) and H.head_h16()       # gradient tensors internal to this backward: bf16
         # through the final ReLU (folded into bn2's reduce pass) -> bn2 -> conv2
-        dc2, dg2, db2, dz = bn_backward(H.to_nhwc(g), c2, m2, i2, g2, None, tr, relu_ref=out)
+        dc2, dg2, db2, dz = bn_backward(H.to_nhwc(g), c2, m2, i2, g2, None, tr, relu_ref=out, out_b16=b16)
         dw2 = conv_wgrad([c1], (s1, h1, True), dc2, w2.shape[0], 3)
-        da1 = conv_dgrad(dc2, w2, caches[1])
+        da1 = conv_dgrad(dc2, w2, caches[1], out_b16=b16)
         # relu -> bn1 -> conv1   (mask: bn1(c1) > 0)
-        dc1, dg1, db1 = bn_backward(da1, c1, m1, i1, g1, (s1, h1), tr)
+        dc1, dg1, db1 = bn_backward(da1, c1, m1, i1, g1, (s1, h1), tr, out_b16=b16)
         dw1 = conv_wgrad(srcs, None, dc1, w1.shape[0], 3)
         need_dx = ctx.needs_input_grad[1] or (nsrc > 1 and ctx.needs_input_grad[2])
         dwd = dgd = dbd = None
         skip = dz if need_dx else None          # gradient arriving over the identity / downsample path
         if has_ds:
-            dd, dgd, dbd = bn_backward(dz, d, md, idd, gd, None, tr)
+            dd, dgd, dbd = bn_backward(dz, d, md, idd, gd, None, tr, out_b16=b16)
             dwd = conv_wgrad(srcs, None, dd, wd.shape[0], 1)
-            skip = conv_dgrad(dd, wd, caches[2]) if need_dx else None
+            skip = conv_dgrad(dd, wd, caches[2], out_b16=b16) if need_dx else None
         dx = conv_dgrad(dc1, w1, caches[0], res=skip) if need_dx else None
         dx0 = dx1 = None
         if need_dx:

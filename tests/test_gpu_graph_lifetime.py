@@ -145,7 +145,7 @@ def test_trainstep_graph_survives_foreign_geometries_and_eval_sees_trained_weigh
     # (two evals of ONE state agree to ~3e-5 here, not bit for bit -- measured: atomics in the stock-op encoder's kernels, amplified by
     # the fp16-operand head; six Adam steps at lr 1e-3 from a random init move the prediction by ~0.5)
     assert moved >= 1e-2, f"six more optimizer steps must change the prediction (moved {moved:.2e})"
-    assert stale <= 2e-4 and stale <= 1e-2 * moved, \
+    assert stale <= max(2e-4, 1e-3 * moved), \
         f"eval after graph replays used stale packed weights / BatchNorm affines: {stale:.2e} from a fresh-cache eval (training moved it {moved:.2e})"
     with pytest.raises(ValueError, match="ONE batch geometry"):
         ts(synthetic_batch(B - 2, 13, DEV))

@@ -156,28 +156,42 @@ def test_model_eval_default_precision_height_maps():
         assert O.rel_l2(a.cpu(), b) <= TOL_HEAD, name
 
 
-def test_mixed_precision_training_gradients_close_to_exact():
-    """TrainStep's default ("f16": forward convs fp16 operands, data and weight gradients bf16 operands, fp32 accumulation): every
+@pytest.mark.parametrize("width,io16,act", [(96, False, "none"), (128, False, "none"), (128, True, "none"), (128, True, "c1c2")])
+def test_mixed_precision_training_gradients_close_to_exact(monkeypatch, width, io16, act):
+    """(width 128 + io16: the gradient tensors internal to a block's backward -- dz / dc2 / da1 / dc1 / dd -- are bf16 in memory
+    (hrfuse.TRAIN_IO16, the default), same bounds; act "c1c2" (opt-in): the saved activations c1 / c2 / downsample output are fp16 as
+    well -- gradients within the same bounds, the training-mode forward 1.5e-3 instead of 1e-3 (stated here, measured 1.1e-3);
+    width 96 is not a multiple of the persistent kernels' 64-pixel tiles, so the template kernels and fp32 tensors run.)
+    TrainStep's default ("f16": forward convs fp16 operands, data and weight gradients bf16 operands, fp32 accumulation): every
     parameter gradient of the head within 2e-2 relative of the exact-fp32 graph (bf16 keeps 8 mantissa bits: 4e-3 per
     operand, averaged over the 9 x 16 products of a tap sum), outputs within 1e-3; tiny per-pixel gradients (a mean over
     10^5 pixels puts them at 1e-6, below fp16's normal range) must survive -- that is why the data gradients are bf16."""
     from srbh_amd import hrfuse as H
+    from srbh_amd import hrfuse_autograd as HA
     from srbh_amd.hrfuse import HRfeature, HRfuse_residual
+    monkeypatch.setattr(H, "TRAIN_IO16", io16)
+    monkeypatch.setattr(H, "TRAIN_IO16_ACT", act)
+    seen = []
+    real_bwd = HA.bn_backward
+    monkeypatch.setattr(HA, "bn_backward", lambda g, c, *a, **k: (seen.append((g.dtype, c.dtype, k.get("out_b16", False))), real_bwd(g, c, *a, **k))[1])
     res = {}
     for mode in ("f32", "f16"):
         H.set_head_precision(mode)
         torch.manual_seed(5)
         hf, fu = HRfeature(64, 16, 16).to(DEV).train(), HRfuse_residual(16, 16, 16, 1, 4).to(DEV).train()
-        x = rnd((2, 64, 64, 96), 11).to(DEV)
-        lo = rnd((2, 16, 16, 24), 12).to(DEV).requires_grad_(True)
+        x = rnd((2, 64, 64, width), 11).to(DEV)
+        lo = rnd((2, 16, 16, width // 4), 12).to(DEV).requires_grad_(True)
         y = fu(lo, hf(x))
         (y.square().mean() * 1e-3).backward()          # small per-pixel gradients on purpose
         res[mode] = (y.detach().cpu(), {k: p.grad.cpu() for k, p in list(hf.named_parameters()) + list(fu.named_parameters())}, lo.grad.cpu())
     H.set_head_precision("auto")
+    # the 16-bit tensors really were used (fp16 saved activations, bf16 internal gradients) exactly when asked for
+    assert any(c == torch.float16 for _, c, _ in seen) == (act != "none") and any(g == torch.bfloat16 and b for g, _, b in seen) == io16
+
     def cos(a, b):
         return float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm()).clamp_min(1e-300))
 
-    assert O.rel_l2(res["f16"][0], res["f32"][0]) <= TOL_HEAD
+    assert O.rel_l2(res["f16"][0], res["f32"][0]) <= (1.5e-3 if act != "none" else TOL_HEAD)
     assert float(res["f32"][2].abs().max()) < 6e-5            # the input gradient really is below fp16's normal range
     # train-mode BatchNorm backward subtracts the batch means of dy and dy*xhat: what is left after that cancellation carries
     # the 1e-3 forward difference amplified, so the bound on a gradient is its direction (cosine) plus a loose norm bound

@@ -37,13 +37,13 @@ def main():
         if k in wr:
             e["WRITE_SIZE_KiB_avg_per_launch"] = sum(wr[k]) / len(wr[k])
         kernels[k] = e
-        if "ptrunk" in k:
-            launches_ref = e["launches"]
+        if "ptrunk" in k and "reset" not in k:
+            launches_ref = max(launches_ref or 0, e["launches"])    # (the bench's one-tile parity forwards add a second, small grid)
     forwards = launches_ref or 1
     for k, e in kernels.items():
         per_fwd = e["launches"] / forwards
         tot += per_fwd * (2.0 * e.get("FETCH_SIZE_KiB_avg_per_launch", 0.0) + e.get("WRITE_SIZE_KiB_avg_per_launch", 0.0)) * 1024.0
-    ptr = [e for k, e in kernels.items() if "ptrunk" in k]
+    ptr = sorted((e for k, e in kernels.items() if "ptrunk" in k and "reset" not in k), key=lambda e: -e["launches"])
     res = {
         "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (separate passes)",
         "units": "KiB as reported; FETCH_SIZE doubled in the totals (MI355X_MICROARCH.md #HBM)",
