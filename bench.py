@@ -298,6 +298,25 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
         with _H.head_precision(ts.head_precision):
             ks += head_kernel_rooflines(dev, batch)
         line["kernels"] = ks
+        # the WHOLE head (+ losses) of this very step against the HBM roofline: every libsrbh call of two extra steps bracketed by
+        # HIP events and priced with the algorithmic bytes its arguments imply (srbh_amd/kprof.py); outside the timed region
+        from srbh_amd.kprof import KernelProfile
+        with KernelProfile() as kp:
+            for _ in range(2):
+                ts(fixed)
+        rows, totals = kp.table(steps=2)
+        cum, top = 0.0, []
+        for r in rows:
+            top.append(r)
+            cum += r["ms_per_step"]
+            if cum >= 0.92 * totals["ms_per_step"] and len(top) >= 8:
+                break
+        totals["note"] = ("every libsrbh head / loss call of the step (HIP events around each call; a weight gradient = its 3 launches); "
+                          "`kernels` lists the top calls covering >= 92 % of that time; bytes = each tensor read or written once at its "
+                          "stored element size; peak 8000 GB/s")
+        totals["covered_ms_per_step"] = round(cum, 3)
+        totals["kernels"] = top
+        line["head_roofline"] = totals
     if with_cpu and world == 1:
         line["cpu_baseline"] = cpu_baseline_train(sd)
     return line

@@ -75,17 +75,22 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
 
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
     typedef typename std::conditional<S16 != 0, float2v, floatx4>::type ldv_t;      // a staging unit in flight: 8 or 16 bytes
-    ldv_t ld[NIT];
-    unsigned okmask = 0;
+    // loads in flight: the fp32 form holds ONE tile ahead (7 x 16 bytes per thread); a 16-bit source is half the bytes per tile, so at
+    // the same depth only half the bytes were in flight per CU and the walk ran at the same ~85 us for half the traffic (load latency x
+    // bytes in flight = bandwidth): the 16-bit forms therefore hold TWO tiles ahead in the same registers
+    constexpr int DEPTH = S16 ? 2 : 1;
+    ldv_t ld[DEPTH][NIT];
+    unsigned okmask[DEPTH] = {};
     const bool has_pre = p.pre_scale != nullptr || pre_relu;
     constexpr bool res16 = (IO & 1) != 0, out16 = (IO & 2) != 0;
-    auto issue = [&](const int t) {
+    auto issue = [&](auto slot_tag, const int t) {
+        constexpr int SL = decltype(slot_tag)::value;
         const int img = t / p.tiles_per_img;
         const int trem = t - img * p.tiles_per_img;
         const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
         const int Y0 = ty * 4, X0 = tx * 64;
         const char* tp = (const char*)p.src0 + (((long)img * p.H + (Y0 - 1)) * p.W + (X0 - 1)) * p.ld0 * (S16 ? 2 : 4);
-        okmask = 0;
+        okmask[SL] = 0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int r = (urow >> (3 * it)) & 7;
@@ -93,28 +98,29 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
             if ((ucol1 >> it) & 1) ok = ok && X0 > 0;
             if ((ucol1 >> (8 + it)) & 1) ok = ok && X0 + 64 < p.W;
             if (it == NIT - 1) ok = ok && last_unit;
-            if constexpr (S16) ld[it] = float2v{0.f, 0.f};
-            else ld[it] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (S16) ld[SL][it] = float2v{0.f, 0.f};
+            else ld[SL][it] = floatx4{0.f, 0.f, 0.f, 0.f};
             if (ok) {
-                ld[it] = *(const ldv_t*)(tp + (long)uoff[it] * (S16 ? 2 : 4));
-                okmask |= 1u << it;
+                ld[SL][it] = *(const ldv_t*)(tp + (long)uoff[it] * (S16 ? 2 : 4));
+                okmask[SL] |= 1u << it;
             }
         }
     };
-    auto commit = [&](char* stage) {
+    auto commit = [&](auto slot_tag, char* stage) {
+        constexpr int SL = decltype(slot_tag)::value;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (it < NIT - 1 || last_unit) {
                 if constexpr (S16) {
                     if (!has_pre) {          // 16-bit source, no transform: the quad goes to LDS as it is (zero padding = zero bits)
-                        *(float2v*)(stage + ulds[it]) = ld[it];
+                        *(float2v*)(stage + ulds[it]) = ld[SL][it];
                         continue;
                     }
                 }
                 floatx4 a;
-                if constexpr (S16) a = widen4<OPT>(ld[it]);
-                else a = ld[it];
-                if (okmask & (1u << it)) {
+                if constexpr (S16) a = widen4<OPT>(ld[SL][it]);
+                else a = ld[SL][it];
+                if (okmask[SL] & (1u << it)) {
                     a = a * psc + psh;
                     if (pre_relu) {
 #pragma unroll
@@ -127,11 +133,13 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
         }
     };
 
-    if (t_first < t_end) issue(t_first);
-    int buf = 0;
-    for (int t = t_first; t < t_end; t += t_step, buf ^= 1) {
+    using SL0 = std::integral_constant<int, 0>;
+    using SL1 = std::integral_constant<int, DEPTH - 1>;
+    if (t_first < t_end) issue(SL0{}, t_first);
+    if (DEPTH == 2 && t_first + t_step < t_end) issue(SL1{}, t_first + t_step);
+    auto tile = [&](auto slot_tag, const int t, const int buf) {
         char* const stage = s_base + buf * STAGE_B;
-        commit(stage);
+        commit(slot_tag, stage);
         const int img = t / p.tiles_per_img;
         const int trem = t - img * p.tiles_per_img;
         const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
                 for (int i = 0; i < 4; ++i) rres[i] = *(const floatx4*)(rp + i * 16 * p.res1_ld);
             }
         }
-        if (t + t_step < t_end) issue(t + t_step);
+        if (t + DEPTH * t_step < t_end) issue(slot_tag, t + DEPTH * t_step);      // (into the registers `commit` has just emptied)
         __syncthreads();           // stage `buf` is complete; every wave is past the MFMAs of the tile before (they read the other stage)
         floatx4 acc[4];
 #pragma unroll
@@ -201,6 +209,18 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
                 for (int q = 0; q < 4; ++q)
                     if (kk * 4 + q < p.cout_store) o0[i * 16 * p.out_ld + q] = v[q];
             }
+        }
+    };
+    if constexpr (DEPTH == 1) {
+        int buf = 0;
+        for (int t = t_first; t < t_end; t += t_step, buf ^= 1) tile(SL0{}, t, buf);
+    } else {
+        for (int t = t_first; t < t_end;) {      // two tiles per trip: LDS stage and register slot are compile-time constants
+            tile(SL0{}, t, 0);
+            t += t_step;
+            if (t >= t_end) break;
+            tile(SL1{}, t, 1);
+            t += t_step;
         }
     }
     if (p.stats) {

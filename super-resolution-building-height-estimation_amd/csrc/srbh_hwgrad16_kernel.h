@@ -20,6 +20,9 @@ struct WG16T {
 // 16-bit tensors in memory (round 3, WGParams::io): XS = the source holds fp16 elements (a saved activation: widened, transformed by the
 // pre-affine as before, rounded to bf16 while staged), DS = dY holds bf16 elements (an internal gradient tensor: its bits ARE the
 // operand, no rounding).  A staging item is then an 8-byte load per pixel; the raw quads stay in registers until the LDS store.
+// DS = 2: a NARROW fp32 dY (cout_total < 16: the 1- / 7-channel output convs conv_last, whose weight gradients used to fall back to the
+// fp32-MFMA kernel at 0.10-0.13 of the HBM peak): channels >= cout_total are staged as zeros, the pixel records are not 16-byte
+// aligned, so the quads are assembled from guarded scalar loads; dW rows >= cout_total come out zero and are never read.
 template <int XS, int DS>
 __global__ __launch_bounds__(256, 3) void hwgrad16_kernel(const WGParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256, 3) void hwgrad16_kernel(const WGParams p) {
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) acc[tp] = floatx4{0.f, 0.f, 0.f, 0.f};
     typedef typename std::conditional<XS != 0, float2w, floatx4>::type lxv_t;
-    typedef typename std::conditional<DS != 0, float2w, floatx4>::type ldv_t;
+    typedef typename std::conditional<DS == 1, float2w, floatx4>::type ldv_t;
     lxv_t lx[NIX][4];
     ldv_t ld[4];
     unsigned okx = 0;
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256, 3) void hwgrad16_kernel(const WGParams p) {
         const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
         const int Y0 = ty * 4, X0 = tx * 64;
         const char* xp = (const char*)p.src0 + (((long)img * p.H + (Y0 - 1)) * p.W + (X0 - 4)) * p.ld0 * (XS ? 2 : 4);
-        const char* dp = (const char*)p.dy + (((long)img * p.H + Y0) * p.W + X0) * p.cout_total * (DS ? 2 : 4);
+        const char* dp = (const char*)p.dy + (((long)img * p.H + Y0) * p.W + X0) * p.cout_total * (DS == 1 ? 2 : 4);
         okx = 0;
 #pragma unroll
         for (int it = 0; it < NIX; ++it) {
@@ -82,8 +85,20 @@ __global__ __launch_bounds__(256, 3) void hwgrad16_kernel(const WGParams p) {
                 okx |= 1u << it;
             }
         }
+        if constexpr (DS == 2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ld[i] = *(const ldv_t*)(dp + (long)(doff + i * p.cout_total) * (DS ? 2 : 4));
+            for (int i = 0; i < 4; ++i) {
+                const float* q = (const float*)dp + doff + i * p.cout_total;
+                floatx4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (cg * 4 + j < p.cout_total) v[j] = q[j];
+                ld[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ld[i] = *(const ldv_t*)(dp + (long)(doff + i * p.cout_total) * (DS == 1 ? 2 : 4));
+        }
     };
     auto commit = [&](unsigned* stage) {
 #pragma unroll
@@ -111,7 +126,7 @@ __global__ __launch_bounds__(256, 3) void hwgrad16_kernel(const WGParams p) {
                     *(uint2w*)(stage + xlds[it] + j * SX) = uint2w{bf16_pair(xv[0][j], xv[1][j]), bf16_pair(xv[2][j], xv[3][j])};
             }
         }
-        if constexpr (DS != 0) {      // bf16 in memory: channel j of the 4 pixels = 16-bit fields of the raw quads
+        if constexpr (DS == 1) {      // bf16 in memory: channel j of the 4 pixels = 16-bit fields of the raw quads
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 *(uint2w*)(stage + dlds + j * SD) = uint2w{b16_field_pair(ld[0], ld[1], j), b16_field_pair(ld[2], ld[3], j)};

@@ -23,8 +23,9 @@ class _PackedGrad:
         self.key = None
         self.w = None
 
-    def get(self, weight, h16=False):
-        key = (weight._version, weight.data_ptr(), bool(h16), wcache.gen(weight))
+    def get(self, weight, h16=False, gen_src=None):
+        # (gen_src: `weight` is a fresh view of a parameter -- the optimizer's stamp lives on the parameter object, wcache.py)
+        key = (weight._version, weight.data_ptr(), bool(h16), wcache.gen(weight if gen_src is None else gen_src))
         if key != self.key:
             L = _lib.lib()
             cout, cin, ks, _ = weight.shape
@@ -42,7 +43,7 @@ class _PackedGrad:
         return self.w
 
 
-def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None, h16=False, out_b16=False):
+def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None, h16=False, out_b16=False, res_ld=0):
     """data-gradient conv (bf16 operands when h16): `srcs[0]` / `res` may be bf16 tensors (internal gradient tensors of a block),
     out_b16 writes one"""
     L = _lib.lib()
@@ -63,7 +64,7 @@ def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None, h1
            else H.empty_nhwc(B, cout, Hh, Ww, x0.device, torch.bfloat16 if out_b16 else torch.float32))
     a.out = out.data_ptr()
     if res is not None:          # out = conv + res in the conv's epilogue (exact: fma(y, 1, res))
-        a.res1, a.res1_ld, a.res1_scale = res.data_ptr(), res.shape[1], 1.0
+        a.res1, a.res1_ld, a.res1_scale = res.data_ptr(), res_ld or res.shape[1], 1.0     # (res_ld: a channel slice of a wider tensor)
     a.io_h16 = ((1 if x0.dtype == torch.bfloat16 else 0) | (4 if res is not None and res.dtype == torch.bfloat16 else 0)
                 | (8 if out_b16 else 0))
     if a.io_h16 and not h16:
@@ -75,13 +76,13 @@ def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None, h1
     return out
 
 
-def conv_dgrad(g, weight, cache: _PackedGrad, res=None, out_b16=False):
+def conv_dgrad(g, weight, cache: _PackedGrad, res=None, out_b16=False, res_ld=0, gen_src=None):
     """dX = conv^T(g, W) (+ res): the forward kernel with transposed + flipped weights; `res` (NHWC, same shape as dX) is the
     gradient arriving over a skip connection, added in the epilogue instead of by a separate pass.  16-bit operands (bf16:
     gradients need fp32's exponent range) only in the explicit "f16" head precision mode (H.set_head_precision)."""
     cout, cin, ks, _ = weight.shape
     h16 = H.head_h16()
-    return _hconv_raw([g], cache.get(weight, h16), None, cin, ks, res=res, h16=h16, out_b16=out_b16 and h16)
+    return _hconv_raw([g], cache.get(weight, h16, gen_src), None, cin, ks, res=res, h16=h16, out_b16=out_b16 and h16, res_ld=res_ld)
 
 
 def conv_wgrad(srcs, pre, g, cout, ks):
@@ -323,13 +324,23 @@ class _BasicBlockFn(torch.autograd.Function):
             dd, dgd, dbd = bn_backward(dz, d, md, idd, gd, None, tr, out_b16=b16)
             dwd = conv_wgrad(srcs, None, dd, wd.shape[0], 1)
             skip = conv_dgrad(dd, wd, caches[2], out_b16=b16) if need_dx else None
-        dx = conv_dgrad(dc1, w1, caches[0], res=skip) if need_dx else None
         dx0 = dx1 = None
-        if need_dx:
+        c0 = srcs[0].shape[1]
+        if need_dx and nsrc == 2 and c0 == 16 and srcs[1].shape[1] == 16 and w1.shape[0] == 16 and H.head_h16():
+            # two-source entry (cat(x_lr, x_hr), 16 + 16 channels): the data gradient as TWO 16 -> 16 convs over dc1 (the persistent
+            # kernel: ~0.67 of the HBM peak, the 16 -> 32 template form ran at 0.28) that write dx_lr and dx_hr as two dense NHWC
+            # tensors -- channel slices of one 32-channel tensor came back through autograd as strided views and cost an
+            # nchw_to_nhwc pass each.  The skip gradient (32 channels) is read in place through its channel stride.
+            halves = blk.__dict__.setdefault("_srbh_gcaches_split", [_PackedGrad(), _PackedGrad()])
+            wa, wb = w1[:, :16], w1[:, 16:]
+            ld = skip.shape[1] if skip is not None else 0
+            dx0 = conv_dgrad(dc1, wa, halves[0], res=None if skip is None else skip[:, :16], res_ld=ld, gen_src=w1)
+            dx1 = conv_dgrad(dc1, wb, halves[1], res=None if skip is None else skip[:, 16:], res_ld=ld, gen_src=w1)
+        elif need_dx:
+            dx = conv_dgrad(dc1, w1, caches[0], res=skip)
             if nsrc == 1:
                 dx0 = dx
             else:
-                c0 = srcs[0].shape[1]
                 dx0, dx1 = dx[:, :c0], dx[:, c0:]
         return (None, dx0, dx1, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd)
 

