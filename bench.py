@@ -402,6 +402,70 @@ def bench_predict(args, rank, world, dev, dist, n_cities, warmup, batch=128, sma
         "tail_shapes_run": sorted({(c % batch + 31) // 32 * 32 for c in todo if c % batch}) if pad_to else None}
 
 
+def bench_sr_train(args, rank, world, dev, dist, steps, warmup, batch=8):
+    """SURVEY 8f-4 (SR-stage fine-tuning, reference SR/rrdbnet_arch.py:538-592): forward + backward of the GENERATOR -- RRDBNet.forward
+    on `batch` 64x64 tiles with a recorded graph, every parameter gradient -- in the training path's precision modes.  A "step" is one
+    forward + backward (no optimizer, no discriminator: those are stock ops).  Work: 3 x 146.857 GFLOP per tile (forward, data
+    gradients, weight gradients: SURVEY 8d's hook-counted forward figure)."""
+    from srbh_amd import rrdbnet_autograd as RA
+    from srbh_amd import synth
+    from srbh_amd.rrdbnet import RRDBNet
+    sd = synth.rrdbnet_state_dict(num_block=args.num_block, seed=1337, mode="init")
+    gf_tile = 3 * (146.857 if args.num_block == 23 else (args.num_block * 5.8886 + 11.42))
+    out = {}
+    modes = [m for m in os.environ.get("SRBH_SR_BENCH_MODES", "fast,mixed,f32").split(",") if m]
+    for mode in modes:
+        RA.set_train_precision(mode)
+        net = RRDBNet(3, 3, num_block=args.num_block)
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dev).train().enable_training_path(True)
+        x = synth.tiles(batch, 8, 64, seed=1337 + rank)[:, :3].contiguous().to(dev)
+        w = None
+        n_w, n_s = (warmup, steps) if mode != "f32" else (1, max(1, min(steps, 3)))
+
+        def step():
+            nonlocal w
+            for p in net.parameters():
+                p.grad = None
+            y = net(x)
+            if w is None:
+                w = torch.randn(y.shape, generator=torch.Generator(device=dev).manual_seed(4242), device=dev)      # (the same cotangent in every mode)
+            (y * w).sum().backward()
+
+        for _ in range(n_w):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_s):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        (el,) = _max_over_ranks([time.perf_counter() - t0], dev, dist)
+        ms = el / n_s * 1e3
+        gn = float(sum(p.grad.double().pow(2).sum() for p in net.parameters() if p.grad is not None).sqrt())
+        out[mode] = {"ms_per_step": round(ms, 3), "tiles_per_s": round(batch * world / ms * 1e3, 2), "achieved_tflops": round(gf_tile * batch / ms, 2),
+                     "steps": n_s, "grad_norm": gn}
+        del net
+        torch.cuda.empty_cache()
+    RA.set_train_precision("f32")
+    if rank != 0:
+        return None
+    head = out[modes[0]]
+    return {"metric": "tiles/sec (64x64 -> 256x256) generator fwd+bwd, SR-stage fine-tuning", "value": head["tiles_per_s"], "unit": "tiles/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": {"fast": "f16 forward / bf16 gradient operands on the trunk's 32x32x16 MFMA kernels (dense blocks), f32 accumulate + residual streams",
+                                           "mixed": "f16 / bf16 operands on the head's 16x16x16 kernels", "f32": "exact fp32 matrix cores"}[modes[0]],
+            "data": "synthetic tiles, random-init weights",
+            "config": {"workload": f"RRDBNet x4 ({args.num_block} RRDB) forward + backward (all parameter gradients), batch {batch}/GPU (SURVEY 8f-4)", "batch": batch, "mode": modes[0]},
+            "roofline": {"bound": "mfma", "achieved": head["achieved_tflops"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(head["achieved_tflops"] / PEAK_F16_TFLOPS, 4), "gflop_per_step": round(gf_tile * batch, 1),
+                         "note": "whole fwd+bwd (345 dense-block convs x 3 + the non-trunk convs in 'mixed'), not one kernel"},
+            "modes": out}
+
+
 def bench_feature(args, rank, world, dev, dist):
     from srbh_amd import synth
     from srbh_amd.rrdbnet import RRDBNet
@@ -536,7 +600,7 @@ def main():
     ap.add_argument("--num-block", type=int, default=23)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="default run: skip the train_step / predict sub-objects")
-    ap.add_argument("--workload", choices=["feature", "train", "predict", "epoch"], default="feature",
+    ap.add_argument("--workload", choices=["feature", "train", "predict", "epoch", "sr_train"], default="feature",
                     help="feature = BASELINE configs[1] (default; carries bounded train_step / predict sub-objects); train = "
                          "configs[2]: full training step, batch 64; epoch = configs[3]: one DP pass over 31 500 synthetic tiles; "
                          "predict = configs[4]: tiled city inference incl. mosaic, one city per step (try --steps 12)")
@@ -575,6 +639,8 @@ def main():
         line = bench_train(args, rank, world, dev, dist, 0, args.warmup, batch=tb, epoch_tiles=31500, with_kernels=False)
     elif args.workload == "predict":
         line = bench_predict(args, rank, world, dev, dist, args.steps, args.warmup, batch=pb)
+    elif args.workload == "sr_train":
+        line = bench_sr_train(args, rank, world, dev, dist, args.steps, args.warmup, batch=args.batch if args.batch != 32 else 8)
     else:
         line = bench_feature(args, rank, world, dev, dist)
         if not args.no_extras and args.num_block == 23 and args.batch == 32:

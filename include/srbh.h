@@ -94,6 +94,26 @@ typedef struct srbh_conv3x3_args {
 } srbh_conv3x3_args;
 
 int srbh_conv3x3_f16(const srbh_conv3x3_args* a, void* stream);
+/* The same convolution for the GRADIENT side of the RRDBNet training path (reference SR/rrdbnet_arch.py:538-592 differentiates the
+ * generator; round 3, SURVEY 8f-4 second slice).  bf16 != 0: the ACT16 input / output planes and the WPACK16 weights hold bf16
+ * (srbh_pack_conv3x3_b16; gradients need fp32's exponent range), products on v_mfma_f32_32x32x16_bf16.  mask16 != NULL: the output is
+ * multiplied by the LeakyReLU derivative taken from the SAVED fp16 activation plane(s) -- chunks mask_chunk0.. of an ACT16 buffer with
+ * mask_chunks_total planes: post-activation > 0 ? 1 : 0.2 (torch's leaky_relu backward) -- before the 16-bit / fp32 stores.  No
+ * nearest-x2 read in these forms. */
+int srbh_conv3x3_x16(const srbh_conv3x3_args* a, int bf16, const void* mask16, int mask_chunks_total, int mask_chunk0, void* stream);
+int srbh_pack_conv3x3_b16(const float* w_oihw, int cout, int cin, void* packed, void* stream);
+/* NHWC fp32 [B][H][W][C] (C % 32 == 0) * scale -> chunk planes chunk0.. of an ACT16 buffer with chunks_total planes, as fp16 or bf16 */
+int srbh_nhwc32_to_act16(const float* src, void* dst, int B, int C, int H, int W, int chunks_total, int chunk0, float scale, int bf16,
+                         void* stream);
+/* out[nchunk*32] = per-channel sums over (B,H,W) of nchunk ACT16 planes starting at chunk0 (bias gradients); fp16 or bf16 elements */
+int srbh_act16_channel_sum(const void* src, int B, int H, int W, int chunks_total, int chunk0, int nchunk, int bf16, float* out,
+                           void* stream);
+/* weight gradient of a 3x3 conv on ACT16 tensors: x fp16 planes (channels 0..cin-1), dy bf16 planes (channels dy_ch0..+cout);
+ * cin, cout, dy_ch0 multiples of 16, cout <= 64; dw OIHW fp32; ws = srbh_hwgrad_ws_bytes(cout, cin, 3) bytes (declared below) */
+int srbh_act16_wgrad_b16(const void* x, int x_chunks_total, int cin, const void* dy, int dy_chunks_total, int dy_ch0, int cout,
+                         int B, int H, int W, float* dw, float* ws, void* stream);
+/* dst = a * x + b * y on fp32 vectors (y may be NULL; dst may alias x or y); n % 4 == 0 */
+int srbh_axpby_f32(float* dst, float a, const float* x, float b, const float* y, long n, void* stream);
 
 /* conv_first (SR/rrdbnet_arch.py:197,232): 3x3 conv on the NCHW fp32 network input with few input
  * channels (3, 12 or 48), computed in fp32 on the vector ALUs.  Writes the 64-channel result to up to
@@ -127,6 +147,21 @@ size_t srbh_rrdbnet_workspace_bytes(int B, int H, int W, int want_forward);
 int srbh_rrdbnet_forward(const srbh_rrdbnet_desc* d, const float* x, float* out, int B, int H, int W,
                          int want_forward, void* ws, size_t ws_bytes, void* stream);
 
+
+/* Training path of the 3 * num_block dense blocks (SR/rrdbnet_arch.py:538-592 differentiates the generator), the launch
+ * loops of rrdbnet_autograd.py's "fast" mode on the device side of the C ABI.
+ * forward: xr and xrr hold (copies of) conv_first's output (B,H,W,64) fp32 on entry and the trunk output on return; dense_all = 3 *
+ * num_block + 1 zero-bordered ACT16 buffers of 6 planes, dense_stride bytes apart: buffer i keeps [x | x1 | x2 | x3 | x4] of RDB i.
+ * backward: g_a = gradient of the trunk output on entry, g_b / g_c scratch of the same size, *g_out = which of the three holds the
+ * gradient of the trunk input; packs = per RDB the five bf16 gradient-conv packs (srbh_pack_conv3x3_b16 of the stacked transposed +
+ * flipped weight slices, at pack_off[0..4] inside a pack_stride-byte record); G = one zero-bordered 6-plane ACT16 buffer (bf16
+ * gradients [g5 | g4 | g3 | g2 | g1]); dw_all = per RDB 239 616 floats (conv1..conv5, OIHW each), db_all = per RDB 192 floats in G's
+ * channel order; wgrad_ws = srbh_hwgrad_ws_bytes(64, 192, 3) bytes. */
+int srbh_rrdbnet_trunk_train_forward(const srbh_rrdbnet_desc* d, float* xr, float* xrr, void* dense_all, size_t dense_stride, int B, int H,
+                                     int W, void* stream);
+int srbh_rrdbnet_trunk_train_backward(int num_block, const void* dense_all, size_t dense_stride, const void* packs, size_t pack_stride,
+                                      const size_t* pack_off, float* g_a, float* g_b, float* g_c, float** g_out, void* G, float* dw_all,
+                                      float* db_all, float* wgrad_ws, int B, int H, int W, void* stream);
 
 /* Synchronises `stream` and returns 0 if the last srbh_rrdbnet_forward on this workspace completed normally, or a
  * negative code if the persistent trunk kernel gave up waiting for a neighbour workgroup (its spins are bounded so a

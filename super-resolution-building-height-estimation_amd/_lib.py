@@ -19,9 +19,12 @@ LIB_PATH = os.path.join(_HERE, "libsrbh.so")
 _DEV_LIB = os.environ.get("SRBH_LIB_PATH")      # developer A/B only (tools/ab_variants.sh): load another build of the same ABI
 SOURCES = ["srbh_conv3x3.hip", "srbh_aux.hip", "srbh_rrdbnet.hip", "srbh_ptrunk.hip", "srbh_ptail.hip", "srbh_head.hip", "srbh_head_bwd.hip", "srbh_mosaic.hip", "srbh_loader.hip", "srbh_loss.hip", "srbh_dwconv.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-# NOTE: `-mllvm -amdgpu-mfma-vgpr-form=1` removes the AGPR<->VGPR accumulator copies hipcc emits at every K-loop
-# back-edge (~20 % of the loop), but the persistent trunk kernel then produced non-deterministic garbage on MI355X
-# (ROCm 7.2); until that is understood the flag stays off.
+# NOTE: `-mllvm -amdgpu-mfma-vgpr-form=1` (accumulators in VGPRs: no v_accvgpr copies at K-loop back-edges).  Round 1 saw the
+# first persistent trunk kernel produce non-deterministic garbage with it; round 3 re-ran it on the current kernel (ptrunk3:
+# fully unrolled steps, every LDS-DMA guarded by an explicit vmcnt wait -- the round-1 kernel lacked those waits, DESIGN.md 5.1
+# "lessons"): tests/test_gpu_rrdbnet.py 13/13 green, parity 7.095e-4 identical, hazcheck clean -- and NO speed-up (3.891 vs 3.897 ms,
+# 3.911 vs 3.940 ms per trunk launch on one box; the compiler then parks the long-lived residual stream in AGPRs instead: 5 914 vs
+# 5 486 v_accvgpr moves in the ISA).  The garbage was the missing waits, not the flag; the flag buys nothing here and stays off.
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-inline-asm"]   # (M0 is clobbered on purpose by the LDS-DMA asm)
 if os.environ.get("SRBH_HIPFLAGS_OVERRIDE"):      # developer bisecting only
     HIPFLAGS = os.environ["SRBH_HIPFLAGS_OVERRIDE"].split()
@@ -119,6 +122,14 @@ SIGNATURES = {
     "srbh_wpack16_bytes": (_sz, [_i, _i]),
     "srbh_pack_conv3x3_f16": (_i, [_vp, _i, _i, _vp, _vp]),
     "srbh_conv3x3_f16": (_i, [C.POINTER(ConvArgs), _vp]),
+    "srbh_conv3x3_x16": (_i, [C.POINTER(ConvArgs), _i, _vp, _i, _i, _vp]),
+    "srbh_pack_conv3x3_b16": (_i, [_vp, _i, _i, _vp, _vp]),
+    "srbh_nhwc32_to_act16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "srbh_act16_channel_sum": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "srbh_axpby_f32": (_i, [_vp, _f, _vp, _f, _vp, C.c_long, _vp]),
+    "srbh_rrdbnet_trunk_train_forward": (_i, [C.POINTER(RRDBNetDesc), _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "srbh_rrdbnet_trunk_train_backward": (_i, [_i, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp, _vp, _vp, C.POINTER(_vp), _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "srbh_act16_wgrad_b16": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "srbh_conv_first_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "srbh_hpack_bytes": (_sz, [_i, _i, _i]),
     "srbh_hpack_conv_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),

@@ -90,6 +90,7 @@ __global__ void act16_to_nchw32_kernel(const char* src, float* __restrict__ dst,
 }
 
 // ---- OIHW fp32 -> WPACK16:  [chunk][tap][ks][mb][lane][8] ------------------------------------------
+template <int BF>
 __global__ void pack_w_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int cout, int cin, int nchunk,
                               int nmb) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one per packed half
@@ -107,7 +108,86 @@ __global__ void pack_w_kernel(const float* __restrict__ w, _Float16* __restrict_
     int oc = mb * 32 + (lane & 31);
     int ic = chunk * 32 + ks * 16 + (lane >> 5) * 8 + j;
     float v = (oc < cout && ic < cin) ? w[((long)oc * cin + ic) * 9 + tap] : 0.f;
-    out[idx] = (_Float16)v;
+    if constexpr (BF) {          // bf16 (RNE) bits in the 16-bit slot
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        ((unsigned short*)out)[idx] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    } else {
+        out[idx] = (_Float16)v;
+    }
+}
+
+// ---- NHWC fp32 [B][H][W][C] (C a multiple of 32) -> ACT16 chunk planes chunk0.. of a `chunks_total`-plane buffer, scaled, as fp16 or bf16
+template <int BF>
+__global__ void nhwc32_to_act16_kernel(const float* __restrict__ src, char* dst, int B, int C, int H, int W, int chunk0, float scale,
+                                       int row_b, int plane_b, long img_b) {
+    // one thread per (pixel, 8-channel octet): 32-byte read, 16-byte write
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int oct = C / 8;
+    const long total = (long)B * H * W * oct;
+    if (idx >= total) return;
+    const int o8 = (int)(idx % oct);
+    long r = idx / oct;
+    const int x = (int)(r % W);
+    r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    const float* s = src + (((long)b * H + y) * W + x) * C + o8 * 8;
+    unsigned short hv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = s[j] * scale;
+        if constexpr (BF) {
+            const unsigned u = __builtin_bit_cast(unsigned, v);
+            hv[j] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        } else {
+            const _Float16 h = (_Float16)v;
+            hv[j] = __builtin_bit_cast(unsigned short, h);
+        }
+    }
+    char* o = dst + (long)b * img_b + (long)(chunk0 + (o8 >> 2)) * plane_b + (long)(y + 1) * row_b + (x + 1) * PIX_B + (o8 & 3) * 16;
+    uint4 pk = {(unsigned)hv[0] | ((unsigned)hv[1] << 16), (unsigned)hv[2] | ((unsigned)hv[3] << 16),
+                (unsigned)hv[4] | ((unsigned)hv[5] << 16), (unsigned)hv[6] | ((unsigned)hv[7] << 16)};
+    *(uint4*)o = pk;
+}
+
+// per-channel sums over (B, H, W) of `nchunk` ACT16 planes (bias gradients of the RRDBNet training path); fp16 or bf16 elements.
+// A thread owns one 16-byte octet (8 channels) of the pixel records it walks: whole 64-byte records per 4 lanes.
+template <int BF>
+__global__ __launch_bounds__(256) void act16_channel_sum_kernel(const char* __restrict__ src, int B, int H, int W, int nchunk, int row_b,
+                                                                 int plane_b, long img_b, float* __restrict__ out /* [nchunk*32], zeroed */) {
+    __shared__ float red[32];
+    if (threadIdx.x < 32) red[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int oct = threadIdx.x & 3, pl = threadIdx.x >> 2;          // 64 pixel lanes x 4 octets
+    const int chunk = blockIdx.y;
+    const long npix = (long)B * H * W;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long px = (long)blockIdx.x * 64 + pl; px < npix; px += (long)gridDim.x * 64) {
+        const int x = (int)(px % W);
+        const long r = px / W;
+        const int y = (int)(r % H), b = (int)(r / H);
+        const uint4 v = *(const uint4*)(src + (long)b * img_b + (long)chunk * plane_b + (long)(y + 1) * row_b + (x + 1) * PIX_B + oct * 16);
+        const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if constexpr (BF) {
+                acc[2 * k] += __builtin_bit_cast(float, w4[k] << 16);
+                acc[2 * k + 1] += __builtin_bit_cast(float, w4[k] & 0xffff0000u);
+            } else {
+                acc[2 * k] += (float)__builtin_bit_cast(_Float16, (unsigned short)(w4[k] & 0xffffu));
+                acc[2 * k + 1] += (float)__builtin_bit_cast(_Float16, (unsigned short)(w4[k] >> 16));
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float a = acc[k];
+#pragma unroll
+        for (int m = 4; m < 64; m <<= 1) a += __shfl_xor(a, m);       // over the 16 pixel lanes of this wave with the same octet
+        if ((threadIdx.x & 63) < 4) atomicAdd(&red[oct * 8 + k], a);
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) atomicAdd(out + chunk * 32 + threadIdx.x, red[threadIdx.x]);
 }
 
 // ---- conv_first: fp32 direct conv, few input channels ------------------------------------------------
@@ -211,8 +291,66 @@ extern "C" int srbh_pack_conv3x3_f16(const float* w, int cout, int cin, void* pa
     SRBH_REQUIRE(w && packed && cout > 0 && cin > 0, "srbh_pack_conv3x3_f16: bad arguments");
     int nchunk = (cin + 31) / 32, nmb = (cout + 31) / 32;
     long total = (long)nchunk * 18 * nmb * 512;
-    hipLaunchKernelGGL(pack_w_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
+    hipLaunchKernelGGL(pack_w_kernel<0>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
                        (_Float16*)packed, cout, cin, nchunk, nmb);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_pack_conv3x3_b16(const float* w, int cout, int cin, void* packed, void* stream) {
+    SRBH_REQUIRE(w && packed && cout > 0 && cin > 0, "srbh_pack_conv3x3_b16: bad arguments");
+    int nchunk = (cin + 31) / 32, nmb = (cout + 31) / 32;
+    long total = (long)nchunk * 18 * nmb * 512;
+    hipLaunchKernelGGL(pack_w_kernel<1>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w,
+                       (_Float16*)packed, cout, cin, nchunk, nmb);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_nhwc32_to_act16(const float* src, void* dst, int B, int C, int H, int W, int chunks_total, int chunk0, float scale,
+                                    int bf16, void* stream) {
+    SRBH_REQUIRE(src && dst && B > 0 && C > 0 && (C & 31) == 0 && H > 0 && W > 0, "srbh_nhwc32_to_act16: bad arguments (C %% 32 == 0)");
+    SRBH_REQUIRE(chunk0 >= 0 && chunk0 + C / 32 <= chunks_total, "srbh_nhwc32_to_act16: chunk range outside the buffer");
+    const Act16Geo g = act16_geo(B, chunks_total, H, W);
+    const long total = (long)B * H * W * (C / 8);
+    if (bf16) hipLaunchKernelGGL(nhwc32_to_act16_kernel<1>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, (char*)dst, B, C, H, W, chunk0, scale, g.row_b, g.plane_b, g.img_b);
+    else hipLaunchKernelGGL(nhwc32_to_act16_kernel<0>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, (char*)dst, B, C, H, W, chunk0, scale, g.row_b, g.plane_b, g.img_b);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+__global__ void axpby_kernel(float4* __restrict__ dst, float a, const float4* __restrict__ x, float b, const float4* __restrict__ y, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = x[i];
+        v.x *= a; v.y *= a; v.z *= a; v.w *= a;
+        if (y) {
+            const float4 w = y[i];
+            v.x += b * w.x; v.y += b * w.y; v.z += b * w.z; v.w += b * w.w;
+        }
+        dst[i] = v;
+    }
+}
+
+/* dst = a * x + b * y (y may be NULL; dst may alias x or y); n % 4 == 0, 16-byte aligned */
+extern "C" int srbh_axpby_f32(float* dst, float a, const float* x, float b, const float* y, long n, void* stream) {
+    SRBH_REQUIRE(dst && x && n > 0 && (n & 3) == 0, "srbh_axpby_f32: bad arguments");
+    const long n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(axpby_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)dst, a, (const float4*)x, b, (const float4*)y, n4);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_act16_channel_sum(const void* src, int B, int H, int W, int chunks_total, int chunk0, int nchunk, int bf16, float* out,
+                                      void* stream) {
+    SRBH_REQUIRE(src && out && B > 0 && H > 0 && W > 0 && nchunk > 0 && chunk0 >= 0 && chunk0 + nchunk <= chunks_total, "srbh_act16_channel_sum: bad arguments");
+    const Act16Geo g = act16_geo(B, chunks_total, H, W);
+    if (int rc = zero_async(out, (size_t)nchunk * 32 * sizeof(float), (hipStream_t)stream)) return rc;
+    const long npix = (long)B * H * W;
+    const int gx = (int)((npix + 255) / 256 < 1024 ? (npix + 255) / 256 : 1024);
+    const char* base = (const char*)src + (long)chunk0 * g.plane_b;
+    if (bf16) hipLaunchKernelGGL(act16_channel_sum_kernel<1>, dim3(gx, nchunk), dim3(256), 0, (hipStream_t)stream, base, B, H, W, nchunk, g.row_b, g.plane_b, g.img_b, out);
+    else hipLaunchKernelGGL(act16_channel_sum_kernel<0>, dim3(gx, nchunk), dim3(256), 0, (hipStream_t)stream, base, B, H, W, nchunk, g.row_b, g.plane_b, g.img_b, out);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }

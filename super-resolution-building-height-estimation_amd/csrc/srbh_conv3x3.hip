@@ -27,20 +27,22 @@ namespace {
 using namespace srbh;
 using namespace srbh_k;
 
-template <int CB, int UPS>
+template <int CB, int UPS, int BF = 0>
 int launch(const KParams& p, hipStream_t stream) {
     constexpr int LDS_B = lds_bytes<CB, UPS>();
-    SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)conv3x3_f16_kernel<CB, UPS>,
+    SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)conv3x3_f16_kernel<CB, UPS, 0, BF>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B)));
-    hipLaunchKernelGGL((conv3x3_f16_kernel<CB, UPS>), dim3(p.nblocks), dim3(256), LDS_B, stream, p);
+    hipLaunchKernelGGL((conv3x3_f16_kernel<CB, UPS, 0, BF>), dim3(p.nblocks), dim3(256), LDS_B, stream, p);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }
 
 }  // namespace
 
-extern "C" int srbh_conv3x3_f16(const srbh_conv3x3_args* a, void* stream_) {
+static int conv3x3_impl(const srbh_conv3x3_args* a, const int bf16, const void* mask16, const int mask_chunks_total, const int mask_chunk0,
+                        void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const bool ext = bf16 || mask16;
     SRBH_REQUIRE(a != nullptr, "srbh_conv3x3_f16: null args");
     SRBH_REQUIRE(a->in && a->w, "srbh_conv3x3_f16: null input/weight pointer");
     SRBH_REQUIRE(a->cout == 32 || a->cout == 64, "srbh_conv3x3_f16: cout must be 32 or 64 (got %d)", a->cout);
@@ -58,11 +60,13 @@ extern "C" int srbh_conv3x3_f16(const srbh_conv3x3_args* a, void* stream_) {
     SRBH_REQUIRE(!(a->res1 || a->res2 || a->skip) || a->cout == 64,
                  "srbh_conv3x3_f16: residual/skip epilogues need cout == 64");
 
-    {   // many-tile 64 -> 64 convs (the up-sampler tail) have a persistent form, see srbh_ptail.hip
+    if (!ext) {   // many-tile 64 -> 64 convs (the up-sampler tail) have a persistent form, see srbh_ptail.hip
         int used = 0;
         const int rc = ptail_run(a, stream, &used);
         if (rc != SRBH_OK || used) return rc;
     }
+    SRBH_REQUIRE(!ext || !a->upsample2x, "srbh_conv3x3_x16: the gradient forms have no nearest-x2 read");
+    SRBH_REQUIRE(!mask16 || (mask_chunk0 >= 0 && mask_chunk0 + a->cout / 32 <= mask_chunks_total), "srbh_conv3x3_x16: mask chunk range outside its buffer");
 
     const int inH = a->upsample2x ? a->H / 2 : a->H, inW = a->upsample2x ? a->W / 2 : a->W;
     const Act16Geo gi = act16_geo(a->B, a->in_chunks_total, inH, inW);
@@ -101,7 +105,25 @@ extern "C" int srbh_conv3x3_f16(const srbh_conv3x3_args* a, void* stream_) {
     p.out32 = a->out32;
     p.out32_c = a->out32_c;
     p.prof = nullptr;
+    p.mask16 = nullptr; p.mask_img_b = 0; p.mask_plane_b = 0; p.mask_row_b = 0;
+    if (mask16) {
+        const Act16Geo gm = act16_geo(a->B, mask_chunks_total, a->H, a->W);
+        p.mask16 = (const char*)mask16 + (long)mask_chunk0 * gm.plane_b;
+        p.mask_img_b = gm.img_b; p.mask_plane_b = gm.plane_b; p.mask_row_b = gm.row_b;
+    }
+    if (bf16) return a->cout == 64 ? launch<2, 0, 1>(p, stream) : launch<1, 0, 1>(p, stream);
 
     if (a->upsample2x) return a->cout == 64 ? launch<2, 1>(p, stream) : launch<1, 1>(p, stream);
     return a->cout == 64 ? launch<2, 0>(p, stream) : launch<1, 0>(p, stream);
+}
+
+extern "C" int srbh_conv3x3_f16(const srbh_conv3x3_args* a, void* stream) { return conv3x3_impl(a, 0, nullptr, 0, 0, stream); }
+
+/* The same convolution for the GRADIENT side of the RRDBNet training path (SR/rrdbnet_arch.py:538-592 differentiates the generator):
+ * bf16 != 0: the ACT16 input / output planes and the WPACK16 weights hold bf16 (srbh_pack_conv3x3_b16), products on
+ * v_mfma_f32_32x32x16_bf16; mask16 != NULL: the output is multiplied by the LeakyReLU derivative taken from the SAVED fp16
+ * activation plane(s) mask16[chunk mask_chunk0 ..] (post-activation > 0 ? 1 : 0.2), before the 16-bit / fp32 stores. */
+extern "C" int srbh_conv3x3_x16(const srbh_conv3x3_args* a, int bf16, const void* mask16, int mask_chunks_total, int mask_chunk0,
+                                void* stream) {
+    return conv3x3_impl(a, bf16, mask16, mask_chunks_total, mask_chunk0, stream);
 }

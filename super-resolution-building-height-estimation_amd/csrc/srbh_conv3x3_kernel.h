@@ -55,7 +55,15 @@ struct KParams {
     float* out32;
     int out32_c;
     unsigned long long* prof;   // bench-only (ABL==9): per-workgroup s_memtime stamps
+    // gradient convs of the RRDBNet training path (round 3, srbh_conv3x3_x16): LeakyReLU backward folded into the epilogue --
+    // out *= (saved activation > 0 ? 1 : 0.2), the saved activation being the fp16 ACT16 plane(s) the forward wrote
+    const char* mask16;
+    long mask_img_b;
+    int mask_plane_b;
+    int mask_row_b;
 };
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // dynamic LDS of one workgroup: two pipeline stages, or the epilogue transpose slices, whichever is larger
 template <int CB, int UPS>
@@ -77,7 +85,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 // 3 = no epilogue stores, 4 = MFMA only (no ds_read), 9 = s_memtime stamps.
 // PERSIST = 1 (persistent trunk kernel): activations are read with sc1 LDS-DMA (L1 bypass) and written with
 // write-through (sc1) stores so that a neighbouring workgroup can consume them inside the same launch.
-template <int CB, int UPS, int ABL, int PERSIST>
+// BF = 1: bf16 operands (gradients: fp32's exponent range, no loss scaling) -- the staged 16-bit records and the packed weights are
+// bf16, the products run on v_mfma_f32_32x32x16_bf16 and a 16-bit output is rounded to bf16 (RNE); everything else is identical.
+template <int CB, int UPS, int ABL, int PERSIST, int BF = 0>
 __device__ __forceinline__ void conv_tile(const KParams& p, char* smem, const int img, const int Y0, const int X0,
                                           unsigned long long* tstamp) {
     using G = TileGeo<UPS>;
@@ -201,7 +211,11 @@ __device__ __forceinline__ void conv_tile(const KParams& p, char* smem, const in
                     const int pr = UPS ? (((i + dy - 1) >> 1) + 1) : (i + dy);
 #pragma unroll
                     for (int mb = 0; mb < CB; ++mb)
-                        acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g & 1][dy][mb], P[g & 1][pr], acc[mb][i], 0, 0, 0);
+                        if constexpr (BF)
+                            acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[g & 1][dy][mb]),
+                                                                                 __builtin_bit_cast(bf16x8, P[g & 1][pr]), acc[mb][i], 0, 0, 0);
+                        else
+                            acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g & 1][dy][mb], P[g & 1][pr], acc[mb][i], 0, 0, 0);
                 }
             }
 #if SRBH_SCHED_HINTS
@@ -338,12 +352,34 @@ __device__ __forceinline__ void conv_tile(const KParams& p, char* smem, const in
                             v1[q] = v1[q] >= 0.f ? v1[q] : v1[q] * 0.2f;
                         }
                     }
-                    if (p.out16) {
-                        half8 hv;
+                    if (p.mask16) {   // LeakyReLU backward with the SAVED post-activation (y > 0 <=> z > 0; slope 0.2 at z <= 0 as torch)
+                        const half8 mv = *(const half8*)(p.mask16 + (long)img * p.mask_img_b + (long)(c8 >> 2) * p.mask_plane_b +
+                                                         (long)(Y + 1) * p.mask_row_b + (X + 1) * PIX_B + (c8 & 3) * 16);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            hv[q] = (_Float16)v0[q];
-                            hv[4 + q] = (_Float16)v1[q];
+                            v0[q] = (float)mv[q] > 0.f ? v0[q] : v0[q] * 0.2f;
+                            v1[q] = (float)mv[4 + q] > 0.f ? v1[q] : v1[q] * 0.2f;
+                        }
+                    }
+                    if (p.out16) {
+                        half8 hv;
+                        if constexpr (BF) {
+                            typedef unsigned uint4e __attribute__((ext_vector_type(4)));
+                            const uint4e u0 = __builtin_bit_cast(uint4e, v0), u1 = __builtin_bit_cast(uint4e, v1);
+                            unsigned r[8];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                r[q] = (u0[q] + 0x7fffu + ((u0[q] >> 16) & 1u)) >> 16;
+                                r[4 + q] = (u1[q] + 0x7fffu + ((u1[q] >> 16) & 1u)) >> 16;
+                            }
+                            const uint4e pk = {r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16)};
+                            hv = __builtin_bit_cast(half8, pk);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                hv[q] = (_Float16)v0[q];
+                                hv[4 + q] = (_Float16)v1[q];
+                            }
                         }
                         char* o = p.out16 + (long)img * p.out16_img_b + (long)(c8 >> 2) * p.out16_plane_b +
                                   (long)(Y + 1) * p.out16_row_b + (X + 1) * PIX_B + (c8 & 3) * 16;
@@ -373,7 +409,7 @@ __device__ __forceinline__ void conv_tile(const KParams& p, char* smem, const in
     }
 }
 
-template <int CB, int UPS, int ABL = 0>
+template <int CB, int UPS, int ABL = 0, int BF = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long tstamp[8];
@@ -382,7 +418,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f16_kernel(const KParams p) {
     const int img = t / p.tiles_per_img;
     const int trem = t - img * p.tiles_per_img;
     const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
-    conv_tile<CB, UPS, ABL, 0>(p, smem, img, ty * TILE_H, tx * TILE_W, tstamp);
+    conv_tile<CB, UPS, ABL, 0, BF>(p, smem, img, ty * TILE_H, tx * TILE_W, tstamp);
     if (ABL == 9 && p.prof) {
         tstamp[5] = __builtin_amdgcn_s_memtime();
         if (threadIdx.x == 0)

@@ -36,6 +36,11 @@ struct WGParams {
     int tiles_x, tiles_per_img, ntiles, tiles_per_xcd;
     int ld0, ld1;         // pixel strides (floats) of src0 / src1
     int io;               // SRBH_WG_SRC0_H16: src0 holds fp16 elements; SRBH_WG_DY_B16: dy holds bf16 elements (16-bit forms only)
+    // ACT16 addressing (hwgrad_b16_kernel<.., XM = 1>, srbh_act16_wgrad_b16: the RRDBNet training path): src0 = fp16 chunk planes
+    // [B][chunks][H+2][W+2][32] (channel ch lives in plane ch / 32), dy = bf16 chunk planes starting at channel dy_ch0
+    long x_img_b, dy_img_b;
+    int x_plane_b, x_row_b, dy_plane_b, dy_row_b, dy_ch0;
+    int zchunk;           // 1: the 16-channel input chunk is blockIdx.z (few tiles per launch: one (tile set, oc block, chunk) per workgroup)
 };
 
 // 4 elements of a 16-bit tensor (raw bits in a float2w) -> fp32: fp16 activations / bf16 gradients
@@ -276,7 +281,8 @@ struct WG16 {
 };
 
 // DS = 1: dY holds bf16 elements in memory (an internal gradient tensor of the training step): its bits are the operand
-template <int KS, int DS>
+// XM = 1: both tensors are ACT16 chunk planes (WGParams::x_* / dy_*): X fp16, dY bf16 (DS must be 1)
+template <int KS, int DS, int XM = 0>
 __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     using G = WG16<KS>;
@@ -290,8 +296,11 @@ __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
     const int cin = p.c0 + p.c1;
     const int nchunk = (cin + 15) / 16;
     const int ob = blockIdx.y;
+    // (zchunk: with few tiles -- the RRDBNet training path at batch 8 has 64 -- the chunk loop is spread over blockIdx.z: a workgroup's
+    //  chunk iterations are a serial load -> LDS -> MFMA chain of ~4 us each, 12 of them for a 192-channel conv on a quarter-filled GPU)
+    const int c_lo = p.zchunk ? (int)blockIdx.z : 0, c_hi = p.zchunk ? (int)blockIdx.z + 1 : nchunk;
 
-    for (int c = 0; c < nchunk; ++c) {
+    for (int c = c_lo; c < c_hi; ++c) {
         floatx4 acc[TAPS];
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp) acc[tp] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -323,7 +332,10 @@ __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
                     floatx4 a = {0.f, 0.f, 0.f, 0.f};
                     const int x = x0 + i;
                     if (rowok && x >= 0 && x < p.W) {
-                        if (ch < p.c0) {
+                        if constexpr (XM != 0) {
+                            a = widen_h4(*(const float2w*)((const char*)p.src0 + (long)img * p.x_img_b + (long)(ch >> 5) * p.x_plane_b +
+                                                          (long)(y + 1) * p.x_row_b + (x + 1) * 64 + (ch & 31) * 2));
+                        } else if (ch < p.c0) {
                             a = *(const floatx4*)(p.src0 + (rowbase + x) * p.ld0 + ch);
                             if (p.pre_scale) a = a * *(const floatx4*)(p.pre_scale + ch) + *(const floatx4*)(p.pre_shift + ch);
                             if (p.pre_relu) {
@@ -345,8 +357,15 @@ __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     ldv_t a = ldv_t{};
-                    if (y < p.H && x0 + i < p.W)
-                        a = *(const ldv_t*)((const char*)p.dy + ((((long)img * p.H + y) * p.W + x0 + i) * p.cout_total + ob * 16 + cg * 4) * (DS ? 2 : 4));
+                    if (y < p.H && x0 + i < p.W) {
+                        if constexpr (XM != 0) {
+                            const int dch = p.dy_ch0 + ob * 16 + cg * 4;
+                            a = *(const ldv_t*)((const char*)p.dy + (long)img * p.dy_img_b + (long)(dch >> 5) * p.dy_plane_b + (long)(y + 1) * p.dy_row_b +
+                                                (x0 + i + 1) * 64 + (dch & 31) * 2);
+                        } else {
+                            a = *(const ldv_t*)((const char*)p.dy + ((((long)img * p.H + y) * p.W + x0 + i) * p.cout_total + ob * 16 + cg * 4) * (DS ? 2 : 4));
+                        }
+                    }
                     ld[it][i] = a;
                 }
             }
@@ -668,6 +687,7 @@ int wgrad_impl(const srbh_hwgrad_args* a, void* stream, bool b16, const char* wh
     p.pre_scale = a->pre_scale; p.pre_shift = a->pre_shift; p.pre_relu = a->pre_relu;
     p.dy = a->dy; p.cout_total = a->cout; p.dw = a->dw; p.ws = a->ws;
     p.io = a->io;
+    p.zchunk = 0;
     SRBH_REQUIRE(a->ws, "srbh_hconv_wgrad: workspace missing (srbh_hwgrad_ws_bytes)");
     SRBH_REQUIRE((a->io & ~(SRBH_WG_SRC0_H16 | SRBH_WG_DY_B16)) == 0, "srbh_hconv_wgrad: unknown io bits");
     SRBH_REQUIRE(!a->io || b16, "srbh_hconv_wgrad_f32: 16-bit tensors in memory need the bf16-operand form (srbh_hconv_wgrad_b16)");
@@ -752,6 +772,46 @@ int wgrad_impl(const srbh_hwgrad_args* a, void* stream, bool b16, const char* wh
 extern "C" int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream) { return wgrad_impl(a, stream, false, "srbh_hconv_wgrad_f32"); }
 
 extern "C" int srbh_hconv_wgrad_b16(const srbh_hwgrad_args* a, void* stream) { return wgrad_impl(a, stream, true, "srbh_hconv_wgrad_b16"); }
+
+/* Weight gradient of a 3x3 conv of the RRDBNet training path on ACT16 tensors: x = fp16 chunk planes (the saved dense buffer: channels
+ * 0 .. cin-1, cin % 16 == 0), dy = bf16 chunk planes (channels dy_ch0 .. dy_ch0 + cout - 1 of a dy_chunks_total-plane buffer, cout % 16 == 0);
+ * dw OIHW fp32 [cout][cin][3][3]; ws as srbh_hwgrad_ws_bytes(cout, cin, 3).  bf16 operands (x rounded while staged), fp32 accumulate,
+ * fixed summation order. */
+extern "C" int srbh_act16_wgrad_b16(const void* x, int x_chunks_total, int cin, const void* dy, int dy_chunks_total, int dy_ch0, int cout,
+                                    int B, int H, int W, float* dw, float* ws, void* stream) {
+    SRBH_REQUIRE(x && dy && dw && ws && B > 0 && H > 0 && W > 0, "srbh_act16_wgrad_b16: bad arguments");
+    SRBH_REQUIRE(cin > 0 && (cin & 15) == 0 && cin <= x_chunks_total * 32 && cout > 0 && (cout & 15) == 0 && cout <= 64 && (dy_ch0 & 15) == 0 &&
+                 dy_ch0 + cout <= dy_chunks_total * 32, "srbh_act16_wgrad_b16: channel ranges (multiples of 16, inside the buffers)");
+    WGParams p = {};
+    p.src0 = (const float*)x; p.src1 = nullptr; p.c0 = cin; p.c1 = 0; p.ld0 = 0; p.ld1 = 0;
+    p.dy = (const float*)dy; p.cout_total = cout; p.dw = dw; p.ws = ws; p.io = 0;
+    const Act16Geo gx_ = act16_geo(B, x_chunks_total, H, W), gd = act16_geo(B, dy_chunks_total, H, W);
+    p.x_img_b = gx_.img_b; p.x_plane_b = gx_.plane_b; p.x_row_b = gx_.row_b;
+    p.dy_img_b = gd.img_b; p.dy_plane_b = gd.plane_b; p.dy_row_b = gd.row_b; p.dy_ch0 = dy_ch0;
+    p.B = B; p.H = H; p.W = W;
+    p.tiles_x = (W + HT_W - 1) / HT_W;
+    p.tiles_per_img = p.tiles_x * ((H + HT_H - 1) / HT_H);
+    p.ntiles = p.tiles_per_img * B;
+    p.tiles_per_xcd = (p.ntiles + 7) / 8;
+    hipStream_t st = (hipStream_t)stream;
+    const int nob = cout / 16;
+    const int gx = p.ntiles < 512 ? (p.ntiles + 7) / 8 * 8 : 512;
+    SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_b16_kernel<3, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WG16<3>::LDS_B)));
+    p.zchunk = p.ntiles <= 256 ? 1 : 0;
+    hipLaunchKernelGGL((hwgrad_b16_kernel<3, 1, 1>), dim3(gx, nob, p.zchunk ? cin / 16 : 1), dim3(256), WG16<3>::LDS_B, st, p);
+    SRBH_HIP(hipGetLastError());
+    constexpr int SLICES = 16;
+    const int taps = 9, nchunk = cin / 16;
+    const long U = (long)nob * nchunk * taps * 256;
+    float* tmp = ws + (long)WS_SLOTS * U;
+    const int per = (gx + SLICES - 1) / SLICES;
+    hipLaunchKernelGGL(hwgrad_reduce1_kernel, dim3((unsigned)((U + 255) / 256), SLICES), dim3(256), 0, st, ws, tmp, U, gx, per);
+    SRBH_HIP(hipGetLastError());
+    const int total = cout * cin * taps;
+    hipLaunchKernelGGL(hwgrad_reduce2_kernel, dim3((total + 255) / 256), dim3(256), 0, st, tmp, dw, U, SLICES, nchunk, taps, cout, cin);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
 
 extern "C" size_t srbh_hwgrad_ws_bytes(int cout, int cin, int ksize) {
     if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return 0;

@@ -176,3 +176,90 @@ extern "C" int srbh_rrdbnet_last_status(const void* ws, int B, int H, int W, int
     if (err) set_error("persistent trunk kernel timed out waiting for a neighbour workgroup (err=%d)", err);
     return err ? -3 : SRBH_OK;
 }
+
+
+// ---- training path of the trunk (second slice; host mirror: rrdbnet_autograd.py "fast") -------------------------------
+// The two loops below are the per-layer launch sequence above with every RDB's dense buffer KEPT (forward) and its mirror image on
+// gradients (backward); they live here rather than in Python because at batch 8 a step is ~2 400 launches of a few microseconds each
+// and the ctypes call overhead (~10 us) was the whole runtime.
+extern "C" int srbh_rrdbnet_trunk_train_forward(const srbh_rrdbnet_desc* d, float* xr, float* xrr, void* dense_all, size_t dense_stride,
+                                                int B, int H, int W, void* stream) {
+    SRBH_REQUIRE(d && d->rdb && xr && xrr && dense_all && B > 0 && H > 0 && W > 0, "srbh_rrdbnet_trunk_train_forward: bad arguments");
+    // xr == xrr == feat on entry (the caller's copies); dense buffer 0 receives feat as fp16 planes 0..1
+    int rc = srbh_nhwc32_to_act16(xr, dense_all, B, 64, H, W, 6, 0, 1.0f, 0, stream);
+    if (rc) return rc;
+    srbh_conv3x3_args a;
+    const int n_rdb = d->num_block * 3;
+    for (int i = 0; i < n_rdb; ++i) {
+        char* D = (char*)dense_all + (size_t)i * dense_stride;
+        const srbh_conv_w* cw = d->rdb + i * 5;
+        for (int k = 0; k < 4; ++k) {
+            a = srbh_conv3x3_args{};
+            a.in = D; a.in_chunks_total = 6; a.in_chunk0 = 0; a.in_chunks = 2 + k;
+            a.w = cw[k].w; a.bias = cw[k].bias; a.cout = 32;
+            a.B = B; a.H = H; a.W = W; a.lrelu = 1;
+            a.out16 = D; a.out16_chunks_total = 6; a.out16_chunk0 = 2 + k;
+            if ((rc = srbh_conv3x3_f16(&a, stream))) return rc;
+        }
+        a = srbh_conv3x3_args{};
+        a.in = D; a.in_chunks_total = 6; a.in_chunk0 = 0; a.in_chunks = 6;
+        a.w = cw[4].w; a.bias = cw[4].bias; a.cout = 64;
+        a.B = B; a.H = H; a.W = W;
+        a.res_scale = 0.2f; a.res1 = xr; a.res1_update = 1;
+        if (i % 3 == 2) { a.res2 = xrr; a.res2_scale = 0.2f; a.res2_update = 1; }
+        a.out16 = D + dense_stride; a.out16_chunks_total = 6; a.out16_chunk0 = 0;
+        if ((rc = srbh_conv3x3_f16(&a, stream))) return rc;
+    }
+    return SRBH_OK;
+}
+
+// g_a: gradient of the trunk output on entry (fp32 NHWC64); g_b, g_c: scratch of the same size.  Returns the gradient of the trunk
+// input in *g_out (one of the three).  packs: per RDB `pack_stride` bytes, gradient conv j (dX4, dX3, dX2, dX1, dx) at pack_off[j].
+// dw_all: per RDB 239 616 floats in conv1..conv5 order (OIHW each); db_all: per RDB 192 floats in G order [g5 (64) | g4 | g3 | g2 | g1].
+extern "C" int srbh_rrdbnet_trunk_train_backward(int num_block, const void* dense_all, size_t dense_stride, const void* packs, size_t pack_stride,
+                                                 const size_t* pack_off, float* g_a, float* g_b, float* g_c, float** g_out, void* G,
+                                                 float* dw_all, float* db_all, float* wgrad_ws, int B, int H, int W, void* stream) {
+    SRBH_REQUIRE(num_block > 0 && dense_all && packs && pack_off && g_a && g_b && g_c && g_out && G && dw_all && db_all && wgrad_ws,
+                 "srbh_rrdbnet_trunk_train_backward: null pointer");
+    const long n = (long)B * H * W * 64;
+    static const int CH0[5] = {160, 128, 96, 64, 0}, COUT[5] = {32, 32, 32, 32, 64}, CIN[5] = {64, 96, 128, 160, 192};
+    static const long DWOFF[5] = {0, 9L * 2048, 9L * (2048 + 3072), 9L * (2048 + 3072 + 4096), 9L * (2048 + 3072 + 4096 + 5120)};
+    constexpr long DW_RDB = 9L * 26624;
+    float* gout = g_a;            // gradient of the current RRDB's output
+    float* cur = g_b;             // gradient flowing down the RDBs
+    float* nxt = g_c;
+    int rc;
+    int i = num_block * 3;
+    srbh_conv3x3_args a;
+    for (int blk = num_block - 1; blk >= 0; --blk) {
+        if ((rc = srbh_axpby_f32(cur, 0.2f, gout, 0.f, nullptr, n, stream))) return rc;        // out = rdb3(.) * 0.2 + x_rrdb
+        for (int r = 2; r >= 0; --r) {
+            --i;
+            const char* D = (const char*)dense_all + (size_t)i * dense_stride;
+            const char* pk = (const char*)packs + (size_t)i * pack_stride;
+            if ((rc = srbh_nhwc32_to_act16(cur, G, B, 64, H, W, 6, 0, 0.2f, 1, stream))) return rc;        // g5 = 0.2 g (bf16)
+            for (int j = 0; j < 4; ++j) {          // g4 .. g1: masked by the saved planes X4 .. X1
+                a = srbh_conv3x3_args{};
+                a.in = G; a.in_chunks_total = 6; a.in_chunk0 = 0; a.in_chunks = 2 + j;
+                a.w = pk + pack_off[j]; a.cout = 32; a.B = B; a.H = H; a.W = W;
+                a.out16 = G; a.out16_chunks_total = 6; a.out16_chunk0 = 2 + j;
+                if ((rc = srbh_conv3x3_x16(&a, 1, D, 6, 5 - j, stream))) return rc;
+            }
+            a = srbh_conv3x3_args{};
+            a.in = G; a.in_chunks_total = 6; a.in_chunk0 = 0; a.in_chunks = 6;
+            a.w = pk + pack_off[4]; a.cout = 64; a.B = B; a.H = H; a.W = W;
+            a.skip = cur; a.out32 = nxt; a.out32_c = 64;
+            if ((rc = srbh_conv3x3_x16(&a, 1, nullptr, 0, 0, stream))) return rc;
+            if ((rc = srbh_act16_channel_sum(G, B, H, W, 6, 0, 6, 1, db_all + (long)i * 192, stream))) return rc;
+            for (int k = 0; k < 5; ++k)
+                if ((rc = srbh_act16_wgrad_b16(D, 6, CIN[k], G, 6, CH0[k], COUT[k], B, H, W, dw_all + (long)i * DW_RDB + DWOFF[k], wgrad_ws, stream)))
+                    return rc;
+            float* t = cur; cur = nxt; nxt = t;
+        }
+        // the RRDB's skip connection: gradient of the RRDB input = cur + gout; it is the next (lower) RRDB's output gradient
+        if ((rc = srbh_axpby_f32(nxt, 1.f, cur, 1.f, gout, n, stream))) return rc;
+        float* t = gout; gout = nxt; nxt = t;
+    }
+    *g_out = gout;
+    return SRBH_OK;
+}

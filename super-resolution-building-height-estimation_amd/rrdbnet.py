@@ -198,6 +198,17 @@ class RRDBNet(nn.Module):
     # predict graph as soon as two other tail shapes had run).
     WS_BUDGET_BYTES = int(float(__import__("os").environ.get("SRBH_WS_BUDGET_GB", "24")) * 2 ** 30)
 
+    def _ensure_packed(self, device):
+        """(buffers, descriptor) of the packed inference weights on `device`, rebuilt when any parameter changed (the training
+        path's "fast" mode drives the trunk's per-layer kernels with the same packs: rrdbnet_autograd._trunk_fast_forward)"""
+        with torch.cuda.device(device):
+            key = (self._weights_key(), str(device))
+            if self._packed is None or self._packed[0] != key:
+                bufs, desc = self._pack(device)
+                self._packed = (key, bufs, desc)
+            wcache.keep(self._packed)
+            return self._packed[1], self._packed[2]
+
     def _workspace(self, B, H, W, want_forward, device):
         key = (B, H, W, int(want_forward), device)
         pins = self.__dict__.setdefault("_ws_pins", {})

@@ -40,13 +40,157 @@ _PRECISION = {"mode": _os.environ.get("SRBH_SR_TRAIN_PRECISION", "f32")}
 
 
 def set_train_precision(mode):
-    if mode not in ("f32", "mixed"):
-        raise ValueError("RRDBNet training precision must be 'f32' or 'mixed'")
+    if mode not in ("f32", "mixed", "fast"):
+        raise ValueError("RRDBNet training precision must be 'f32', 'mixed' or 'fast'")
     _PRECISION["mode"] = mode
 
 
 def _mixed():
-    return _PRECISION["mode"] == "mixed"
+    return _PRECISION["mode"] in ("mixed", "fast")
+
+
+def _fast():
+    return _PRECISION["mode"] == "fast"
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# "fast" (round 3, SURVEY 8f-4 second slice): the 69 dense blocks -- 92 % of the network's FLOPs -- forward AND backward on the trunk's
+# own kernel family (csrc/srbh_conv3x3_kernel.h: v_mfma_f32_32x32x16, ACT16 chunk planes, LDS-DMA staging), the rest of the network
+# (conv_first, conv_body, the up-sampler, conv_hr / conv_last) as in "mixed".
+#   forward  : the per-layer launch sequence of the inference path (csrc/srbh_rrdbnet.hip) driven from here, with ONE dense ACT16 buffer
+#              PER RDB kept for the backward (fp16 [x | x1 | x2 | x3 | x4]: 1.6 MiB per tile and RDB; the LeakyReLU masks are the signs of
+#              the saved planes);
+#   backward : the gradient of a dense block is itself a dense block run in reverse: with G = [g5 | g4 | g3 | g2 | g1] (the gradients of
+#              the five convs' outputs, g5 = 0.2 g) the gradient of plane X_m is ONE 3x3 conv over the first channels of G with the
+#              transposed + flipped weight slices of every conv that consumed X_m stacked along K -- the forward's shapes exactly (64,
+#              96, 128, 160 -> 32 and 192 -> 64 channels), so srbh_conv3x3_x16 runs them: bf16 operands (gradients need fp32's exponent
+#              range), the LeakyReLU derivative from the saved plane folded into the epilogue, the identity path added as `skip`;
+#              weight gradients as GEMMs over pixels straight from the ACT16 planes (srbh_act16_wgrad_b16), bias gradients as plane sums.
+_FAST_WS = {}
+
+
+def _fast_buffers(B, Hh, Ww, n_rdb, dev):
+    """zero-bordered ACT16 buffers (the kernels never write the borders): n_rdb + 1 dense activation buffers, one gradient buffer"""
+    key = (B, Hh, Ww, n_rdb, str(dev))
+    ws = _FAST_WS.get(key)
+    if ws is None:
+        L = _lib.lib()
+        nb = L.srbh_act16_bytes(B, 192, Hh, Ww)
+        nb = (nb + 255) // 256 * 256
+        _FAST_WS.clear()
+        ws = {"nb": nb, "D": torch.zeros((n_rdb + 1) * nb, dtype=torch.uint8, device=dev), "G": torch.zeros(nb, dtype=torch.uint8, device=dev),
+              "wg": torch.empty(L.srbh_hwgrad_ws_bytes(64, 192, 3) // 4, dtype=torch.float32, device=dev)}
+        _FAST_WS[key] = ws
+    return ws
+
+
+class _TrunkBwdPacks:
+    """bf16 WPACK16 images of the five gradient convs of every RDB (stacked transposed + flipped weight slices, see above)"""
+
+    def __init__(self):
+        self.key = None
+
+    def get(self, net):
+        ps = [p for blk in net.body for r in (1, 2, 3) for k in range(1, 6) for p in (getattr(getattr(blk, f"rdb{r}"), f"conv{k}").weight,)]
+        key = tuple((p._version, getattr(p, "_srbh_gen", 0), p.data_ptr()) for p in ps) + wcache.gen()
+        if key != self.key:
+            L = _lib.lib()
+            st = _lib.stream_ptr()
+            n = len(ps) // 5
+            dev = ps[0].device
+            with torch.no_grad():
+                W = [torch.stack([ps[i * 5 + k].detach().float() for i in range(n)]) for k in range(5)]      # W[k]: (n, cout_k, cin_k, 3, 3)
+                tf = lambda w, lo, hi: w[:, :, lo:hi].permute(0, 2, 1, 3, 4).flip(3, 4)                        # noqa: E731  (n, hi-lo, cout_k, 3, 3)
+                # plane X_m (dense channels lo:hi) is consumed by conv_{m+1}..conv5; G order: g5, g4, g3, g2, g1
+                planes = [(160, 192, [4]), (128, 160, [4, 3]), (96, 128, [4, 3, 2]), (64, 96, [4, 3, 2, 1]), (0, 64, [4, 3, 2, 1, 0])]
+                stacked = [torch.cat([tf(W[k], lo, hi) for k in ks], dim=2).contiguous() for lo, hi, ks in planes]
+            sizes = [L.srbh_wpack16_bytes(t.shape[1], t.shape[2]) for t in stacked]
+            offs, tot = [], 0
+            for sz in sizes:
+                offs.append(tot)
+                tot += (sz + 255) // 256 * 256
+            buf = torch.zeros(n * tot, dtype=torch.uint8, device=dev)
+            for i in range(n):
+                for j, t in enumerate(stacked):
+                    _lib.check(L.srbh_pack_conv3x3_b16(t[i].data_ptr(), t.shape[1], t.shape[2], buf.data_ptr() + i * tot + offs[j], st), "pack_conv3x3_b16")
+            torch.cuda.current_stream().synchronize()          # (`stacked` temporaries may be freed after this)
+            self.key, self.buf, self.offs, self.stride = key, buf, offs, tot
+        wcache.keep(self.buf)
+        return self
+
+    def ptr(self, i, j):
+        return self.buf.data_ptr() + i * self.stride + self.offs[j]
+
+
+def _conv16(a_in, in_chunks, w, bias, cout, B, Hh, Ww, *, lrelu=0, out16=None, out16_chunk0=0, res1=None, res2=None, skip=None, out32=None,
+            bf16=0, mask=None, mask_chunk0=0):
+    a = _lib.ConvArgs()
+    a.in_, a.in_chunks_total, a.in_chunk0, a.in_chunks = a_in, 6, 0, in_chunks
+    a.w, a.bias, a.cout = w, bias, cout
+    a.B, a.H, a.W, a.lrelu = B, Hh, Ww, lrelu
+    if res1 is not None:
+        a.res_scale, a.res1, a.res1_update = 0.2, res1, 1
+    if res2 is not None:
+        a.res2_scale, a.res2, a.res2_update = 0.2, res2, 1
+    if skip is not None:
+        a.skip = skip
+    if out16 is not None:
+        a.out16, a.out16_chunks_total, a.out16_chunk0 = out16, 6, out16_chunk0
+    if out32 is not None:
+        a.out32, a.out32_c = out32, 64
+    L = _lib.lib()
+    if bf16 or mask is not None:
+        _lib.check(L.srbh_conv3x3_x16(C.byref(a), bf16, mask, 6, mask_chunk0, _lib.stream_ptr()), "conv3x3_x16")
+    else:
+        _lib.check(L.srbh_conv3x3_f16(C.byref(a), _lib.stream_ptr()), "conv3x3_f16")
+
+
+def _trunk_fast_forward(net, feat):
+    """feat (B,H,W,64) fp32 NHWC -> trunk output (same shape, fp32) + the saved dense buffers.  (The launch loop -- 5 convs per RDB,
+    mirroring csrc/srbh_rrdbnet.hip's per-layer inference sequence -- runs behind ONE C-ABI call: at batch 8 the ~350 + ~2 000 launches of
+    a step cost more in ctypes overhead than on the device.  `_conv16` above is the same call for tests / single layers.)"""
+    L = _lib.lib()
+    B, Hh, Ww, _ = feat.shape
+    n_rdb = len(net.body) * 3
+    ws = _fast_buffers(B, Hh, Ww, n_rdb, feat.device)
+    _, desc = net._ensure_packed(feat.device)
+    xr, xrr = feat.clone(), feat.clone()
+    _lib.check(L.srbh_rrdbnet_trunk_train_forward(C.byref(desc), xr.data_ptr(), xrr.data_ptr(), ws["D"].data_ptr(), ws["nb"], B, Hh, Ww,
+                                                  _lib.stream_ptr()), "rrdbnet_trunk_train_forward")
+    return xr, ws
+
+
+_DW_RDB = 9 * 26624          # weights of one RDB: 9 * (32*64 + 32*96 + 32*128 + 32*160 + 64*192)
+_DW_OFF = (0, 9 * 2048, 9 * (2048 + 3072), 9 * (2048 + 3072 + 4096), 9 * (2048 + 3072 + 4096 + 5120))
+_CONV_GEO = ((160, 32, 64), (128, 32, 96), (96, 32, 128), (64, 32, 160), (0, 64, 192))      # conv1..5: (G channel offset, cout, cin)
+
+
+def _trunk_fast_backward(net, ws, g, grads):
+    """g: gradient of the trunk output (B,H,W,64) fp32 contiguous -> gradient of its input; fills grads[id(param)]"""
+    L = _lib.lib()
+    B, Hh, Ww, _ = g.shape
+    packs = net.__dict__.setdefault("_srbh_trunk_bwd_packs", _TrunkBwdPacks()).get(net)
+    n_rdb = len(net.body) * 3
+    dev = g.device
+    gb, gc = torch.empty_like(g), torch.empty_like(g)
+    dw_all = torch.empty(n_rdb * _DW_RDB, dtype=torch.float32, device=dev)
+    db_all = torch.empty(n_rdb * 192, dtype=torch.float32, device=dev)
+    offs = (C.c_size_t * 5)(*packs.offs)
+    gout = C.c_void_p()
+    _lib.check(L.srbh_rrdbnet_trunk_train_backward(len(net.body), ws["D"].data_ptr(), ws["nb"], packs.buf.data_ptr(), packs.stride, offs,
+                                                   g.data_ptr(), gb.data_ptr(), gc.data_ptr(), C.byref(gout), ws["G"].data_ptr(), dw_all.data_ptr(),
+                                                   db_all.data_ptr(), ws["wg"].data_ptr(), B, Hh, Ww, _lib.stream_ptr()), "rrdbnet_trunk_train_backward")
+    i = 0
+    for blk in net.body:
+        for r in (1, 2, 3):
+            rdb = getattr(blk, f"rdb{r}")
+            for k, (ch0, cout, cin) in enumerate(_CONV_GEO):
+                conv = getattr(rdb, f"conv{k + 1}")
+                o = i * _DW_RDB + _DW_OFF[k]
+                grads[id(conv.weight)] = dw_all[o:o + cout * cin * 9].view(cout, cin, 3, 3)
+                grads[id(conv.bias)] = db_all[i * 192 + ch0:i * 192 + ch0 + cout]
+            i += 1
+    return {g.data_ptr(): g, gb.data_ptr(): gb, gc.data_ptr(): gc}[gout.value]
 
 
 class _Packs:
@@ -164,7 +308,10 @@ class _RRDBNetFn(torch.autograd.Function):
         _conv(xs, cin, cin, convs["conv_first"].fwd, convs["conv_first"].bias, 64, feat)
         dense = []                                                          # one saved (B,H,W,192) buffer per RDB
         cur = feat
-        for blk in net.body:
+        fast_ws = None
+        if _fast() and Hh % 8 == 0 and Ww % 64 == 0 and len(net.body) > 0:
+            cur, fast_ws = _trunk_fast_forward(net, feat)
+        for blk in (net.body if fast_ws is None else ()):
             x_rrdb = cur
             for r in (1, 2, 3):
                 rdb = getattr(blk, f"rdb{r}")
@@ -191,6 +338,7 @@ class _RRDBNetFn(torch.autograd.Function):
         _conv(u2, 64, 64, convs["conv_hr"].fwd, convs["conv_hr"].bias, 64, hr, lrelu=bool(want_forward))
         ctx.net, ctx.want_forward, ctx.in_shape = net, bool(want_forward), tuple(x.shape)
         ctx.saved = (xs, feat, dense, cur, t1, u1, t2, u2, hr)
+        ctx.fast_ws = fast_ws
         if not want_forward:
             return hr.permute(0, 3, 1, 2)
         cout = net.conv_last.out_channels
@@ -230,7 +378,10 @@ class _RRDBNetFn(torch.autograd.Function):
         g_feat2 = _up2_bwd(conv_bwd("conv_up1", t1, 64, 64, g))           # gradient of feat + body_feat
         g = conv_bwd("conv_body", last, 64, 64, g_feat2)                  # ... flows into the body's output
         i = len(dense)
-        for blk in reversed(list(net.body)):
+        fast_ws = getattr(ctx, "fast_ws", None)
+        if fast_ws is not None:
+            g = _trunk_fast_backward(net, fast_ws, g.contiguous(), grads)
+        for blk in (reversed(list(net.body)) if fast_ws is None else ()):
             g_rrdb_out = g                                                # out = rdb3(.)*0.2 + x_rrdb
             g = g_rrdb_out * 0.2
             for r in (3, 2, 1):

@@ -160,8 +160,12 @@ def test_realesrgan_training_step_runs_and_learns():
 
 
 @pytest.mark.gpu
-def test_rrdbnet_mixed_precision_training_graph_close_to_exact():
-    """rrdbnet_autograd.set_train_precision("mixed"): forward convs with fp16 operands, data / weight gradients with bf16 operands
+@pytest.mark.parametrize("fast_mode", ["mixed", "fast"])
+def test_rrdbnet_mixed_precision_training_graph_close_to_exact(fast_mode):
+    """("fast", round 3: the dense blocks forward AND backward on the trunk's own 32x32x16-MFMA kernel family -- ACT16 planes, fp16
+    forward, bf16 gradient convs with the LeakyReLU mask folded in, weight gradients straight from the saved planes -- same bounds;
+    64 x 64 tiles, the geometry that kernel family is written for.)
+    rrdbnet_autograd.set_train_precision("mixed"): forward convs with fp16 operands, data / weight gradients with bf16 operands
     (fp32 accumulation, fp32 residual and LeakyReLU epilogues).  Against the exact-fp32 graph of the same 2-block net: output within
     2e-3 (the inference trunk's own fp16-operand error level), every parameter gradient with cosine >= 0.995 and norm within 5 %,
     and the mixed graph is the faster one (it is why it exists)."""
@@ -171,12 +175,13 @@ def test_rrdbnet_mixed_precision_training_graph_close_to_exact():
     sd = synth.rrdbnet_state_dict(num_block=2, seed=31, mode="stress")
     res, times = {}, {}
     try:
-        for mode in ("f32", "mixed"):
+        hw = 64 if fast_mode == "fast" else 32
+        for mode in ("f32", fast_mode):
             RA.set_train_precision(mode)
             net = RRDBNet(3, 3, num_block=2)
             net.load_state_dict(sd, strict=True)
             net = net.to("cuda:0").train().enable_training_path(True)
-            x = rand((2, 3, 32, 32), 140, 0.0, 1.0).to("cuda:0").requires_grad_(True)
+            x = rand((2, 3, hw, hw), 140, 0.0, 1.0).to("cuda:0").requires_grad_(True)
             w = None
             for rep in range(3):
                 for p in net.parameters():
@@ -193,11 +198,13 @@ def test_rrdbnet_mixed_precision_training_graph_close_to_exact():
             res[mode] = (y.detach().cpu(), x.grad.cpu(), {k: p.grad.cpu() for k, p in net.named_parameters()})
     finally:
         RA.set_train_precision("f32")
-    (y0, gx0, g0), (y1, gx1, g1) = res["f32"], res["mixed"]
+    (y0, gx0, g0), (y1, gx1, g1) = res["f32"], res[fast_mode]
+    if fast_mode == "fast":
+        assert RA._FAST_WS, "the fast trunk path did not run"
     assert 1e-6 < O.rel_l2(y1, y0) <= 2e-3
     cos = lambda a, b: float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm()).clamp_min(1e-300))
     assert cos(gx1, gx0) >= 0.995
     for k in g0:
         assert cos(g1[k], g0[k]) >= 0.995, k
         assert abs(float(g1[k].norm()) / float(g0[k].norm()) - 1.0) <= 0.05, k
-    assert times["mixed"] < times["f32"], times
+    assert times[fast_mode] < times["f32"], times
