@@ -154,14 +154,15 @@ int srbh_rrdbnet_forward(const srbh_rrdbnet_desc* d, const float* x, float* out,
  * num_block + 1 zero-bordered ACT16 buffers of 6 planes, dense_stride bytes apart: buffer i keeps [x | x1 | x2 | x3 | x4] of RDB i.
  * backward: g_a = gradient of the trunk output on entry, g_b / g_c scratch of the same size, *g_out = which of the three holds the
  * gradient of the trunk input; packs = per RDB the five bf16 gradient-conv packs (srbh_pack_conv3x3_b16 of the stacked transposed +
- * flipped weight slices, at pack_off[0..4] inside a pack_stride-byte record); G = one zero-bordered 6-plane ACT16 buffer (bf16
- * gradients [g5 | g4 | g3 | g2 | g1]); dw_all = per RDB 239 616 floats (conv1..conv5, OIHW each), db_all = per RDB 192 floats in G's
+ * flipped weight slices, at pack_off[0..4] inside a pack_stride-byte record); G = zero-bordered 6-plane ACT16 buffer(s) for the bf16
+ * gradients [g5 | g4 | g3 | g2 | g1]: g_stride > 0 = two of them, g_stride bytes apart -- the weight / bias gradients of an RDB then
+ * run on an internal side stream next to the gradient convs of the RDB below (joined before the call returns control of `stream`); dw_all = per RDB 239 616 floats (conv1..conv5, OIHW each), db_all = per RDB 192 floats in G's
  * channel order; wgrad_ws = srbh_hwgrad_ws_bytes(64, 192, 3) bytes. */
 int srbh_rrdbnet_trunk_train_forward(const srbh_rrdbnet_desc* d, float* xr, float* xrr, void* dense_all, size_t dense_stride, int B, int H,
                                      int W, void* stream);
 int srbh_rrdbnet_trunk_train_backward(int num_block, const void* dense_all, size_t dense_stride, const void* packs, size_t pack_stride,
-                                      const size_t* pack_off, float* g_a, float* g_b, float* g_c, float** g_out, void* G, float* dw_all,
-                                      float* db_all, float* wgrad_ws, int B, int H, int W, void* stream);
+                                      const size_t* pack_off, float* g_a, float* g_b, float* g_c, float** g_out, void* G, size_t g_stride,
+                                      float* dw_all, float* db_all, float* wgrad_ws, int B, int H, int W, void* stream);
 
 /* Synchronises `stream` and returns 0 if the last srbh_rrdbnet_forward on this workspace completed normally, or a
  * negative code if the persistent trunk kernel gave up waiting for a neighbour workgroup (its spins are bounded so a

@@ -470,6 +470,30 @@ __global__ void hwgrad_reduce2_kernel(const float* __restrict__ tmp, float* __re
     dw[idx] = v;
 }
 
+// one-stage form for few partial slots (gx <= 128: small batches, where the two-stage form is two launch latencies for 28 MB of L2 reads):
+// dw[oc][ci][tap] = sum over x = 0 .. gx-1 of ws[x][u], in that fixed order
+__global__ void hwgrad_reduce_direct_kernel(const float* __restrict__ ws, float* __restrict__ dw, long U, int gx, int nchunk, int taps, int cout,
+                                            int cin) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = cout * cin * taps;
+    if (idx >= total) return;
+    const int tp = idx % taps;
+    const int ci = (idx / taps) % cin;
+    const int oc = idx / (taps * cin);
+    const long u = ((long)(oc >> 4) * nchunk + (ci >> 4)) * (taps * 256) + tp * 256 + (oc & 15) * 16 + (ci & 15);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // 8 loads in flight; the order of the additions is fixed all the same
+    int x = 0;
+    for (; x + 8 <= gx; x += 8) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = ws[(long)(x + k) * U + u];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += t[k];
+    }
+    for (; x < gx; ++x) v[0] += ws[(long)x * U + u];
+    dw[idx] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+
 // ---- elementwise / reduction helpers (NHWC fp32, C % 4 == 0 unless noted) ------------------------------------------
 __global__ void relu_mask_mul_kernel(const floatx4* __restrict__ g, const floatx4* __restrict__ ref, floatx4* out, long n4) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
@@ -803,11 +827,16 @@ extern "C" int srbh_act16_wgrad_b16(const void* x, int x_chunks_total, int cin, 
     constexpr int SLICES = 16;
     const int taps = 9, nchunk = cin / 16;
     const long U = (long)nob * nchunk * taps * 256;
+    const int total = cout * cin * taps;
+    if (gx <= 128) {
+        hipLaunchKernelGGL(hwgrad_reduce_direct_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws, dw, U, gx, nchunk, taps, cout, cin);
+        SRBH_HIP(hipGetLastError());
+        return SRBH_OK;
+    }
     float* tmp = ws + (long)WS_SLOTS * U;
     const int per = (gx + SLICES - 1) / SLICES;
     hipLaunchKernelGGL(hwgrad_reduce1_kernel, dim3((unsigned)((U + 255) / 256), SLICES), dim3(256), 0, st, ws, tmp, U, gx, per);
     SRBH_HIP(hipGetLastError());
-    const int total = cout * cin * taps;
     hipLaunchKernelGGL(hwgrad_reduce2_kernel, dim3((total + 255) / 256), dim3(256), 0, st, tmp, dw, U, SLICES, nchunk, taps, cout, cin);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;

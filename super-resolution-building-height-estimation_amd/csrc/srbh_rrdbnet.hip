@@ -216,8 +216,32 @@ extern "C" int srbh_rrdbnet_trunk_train_forward(const srbh_rrdbnet_desc* d, floa
 // g_a: gradient of the trunk output on entry (fp32 NHWC64); g_b, g_c: scratch of the same size.  Returns the gradient of the trunk
 // input in *g_out (one of the three).  packs: per RDB `pack_stride` bytes, gradient conv j (dX4, dX3, dX2, dX1, dx) at pack_off[j].
 // dw_all: per RDB 239 616 floats in conv1..conv5 order (OIHW each); db_all: per RDB 192 floats in G order [g5 (64) | g4 | g3 | g2 | g1].
+// The weight / bias gradients of RDB i only READ what the gradient convs of RDB i produced (G) and the saved planes: they run on a
+// side stream next to the gradient convs of RDB i-1 -- at small batch a conv launch fills a quarter of the chip (64 workgroups at
+// batch 8), so the two chains overlap almost completely.  G is double buffered for that (G and G + g_stride).
+namespace {
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+    int dev = -1;
+};
+SideStream g_side;
+int side_init() {
+    int dev = 0;
+    SRBH_HIP(hipGetDevice(&dev));
+    if (g_side.s && g_side.dev == dev) return SRBH_OK;
+    SRBH_HIP(hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        SRBH_HIP(hipEventCreateWithFlags(&g_side.ready[k], hipEventDisableTiming));
+        SRBH_HIP(hipEventCreateWithFlags(&g_side.done[k], hipEventDisableTiming));
+    }
+    g_side.dev = dev;
+    return SRBH_OK;
+}
+}  // namespace
+
 extern "C" int srbh_rrdbnet_trunk_train_backward(int num_block, const void* dense_all, size_t dense_stride, const void* packs, size_t pack_stride,
-                                                 const size_t* pack_off, float* g_a, float* g_b, float* g_c, float** g_out, void* G,
+                                                 const size_t* pack_off, float* g_a, float* g_b, float* g_c, float** g_out, void* G, size_t g_stride,
                                                  float* dw_all, float* db_all, float* wgrad_ws, int B, int H, int W, void* stream) {
     SRBH_REQUIRE(num_block > 0 && dense_all && packs && pack_off && g_a && g_b && g_c && g_out && G && dw_all && db_all && wgrad_ws,
                  "srbh_rrdbnet_trunk_train_backward: null pointer");
@@ -225,41 +249,68 @@ extern "C" int srbh_rrdbnet_trunk_train_backward(int num_block, const void* dens
     static const int CH0[5] = {160, 128, 96, 64, 0}, COUT[5] = {32, 32, 32, 32, 64}, CIN[5] = {64, 96, 128, 160, 192};
     static const long DWOFF[5] = {0, 9L * 2048, 9L * (2048 + 3072), 9L * (2048 + 3072 + 4096), 9L * (2048 + 3072 + 4096 + 5120)};
     constexpr long DW_RDB = 9L * 26624;
+    static const bool overlap = !(getenv("SRBH_SR_OVERLAP") && getenv("SRBH_SR_OVERLAP")[0] == '0');
+    const bool two = overlap && g_stride > 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (two) { if (int rc0 = side_init()) return rc0; }
+    hipStream_t ws_st = two ? g_side.s : st;
     float* gout = g_a;            // gradient of the current RRDB's output
     float* cur = g_b;             // gradient flowing down the RDBs
     float* nxt = g_c;
     int rc;
     int i = num_block * 3;
+    int used[2] = {0, 0};
     srbh_conv3x3_args a;
     for (int blk = num_block - 1; blk >= 0; --blk) {
         if ((rc = srbh_axpby_f32(cur, 0.2f, gout, 0.f, nullptr, n, stream))) return rc;        // out = rdb3(.) * 0.2 + x_rrdb
         for (int r = 2; r >= 0; --r) {
             --i;
+            const int gb = two ? (i & 1) : 0;
+            char* Gi = (char*)G + (size_t)gb * g_stride;
             const char* D = (const char*)dense_all + (size_t)i * dense_stride;
             const char* pk = (const char*)packs + (size_t)i * pack_stride;
-            if ((rc = srbh_nhwc32_to_act16(cur, G, B, 64, H, W, 6, 0, 0.2f, 1, stream))) return rc;        // g5 = 0.2 g (bf16)
+            if (two && used[gb]) SRBH_HIP(hipStreamWaitEvent(st, g_side.done[gb], 0));          // the side stream is done reading this G
+            if ((rc = srbh_nhwc32_to_act16(cur, Gi, B, 64, H, W, 6, 0, 0.2f, 1, stream))) return rc;        // g5 = 0.2 g (bf16)
             for (int j = 0; j < 4; ++j) {          // g4 .. g1: masked by the saved planes X4 .. X1
                 a = srbh_conv3x3_args{};
-                a.in = G; a.in_chunks_total = 6; a.in_chunk0 = 0; a.in_chunks = 2 + j;
+                a.in = Gi; a.in_chunks_total = 6; a.in_chunk0 = 0; a.in_chunks = 2 + j;
                 a.w = pk + pack_off[j]; a.cout = 32; a.B = B; a.H = H; a.W = W;
-                a.out16 = G; a.out16_chunks_total = 6; a.out16_chunk0 = 2 + j;
+                a.out16 = Gi; a.out16_chunks_total = 6; a.out16_chunk0 = 2 + j;
                 if ((rc = srbh_conv3x3_x16(&a, 1, D, 6, 5 - j, stream))) return rc;
             }
-            a = srbh_conv3x3_args{};
-            a.in = G; a.in_chunks_total = 6; a.in_chunk0 = 0; a.in_chunks = 6;
-            a.w = pk + pack_off[4]; a.cout = 64; a.B = B; a.H = H; a.W = W;
-            a.skip = cur; a.out32 = nxt; a.out32_c = 64;
-            if ((rc = srbh_conv3x3_x16(&a, 1, nullptr, 0, 0, stream))) return rc;
-            if ((rc = srbh_act16_channel_sum(G, B, H, W, 6, 0, 6, 1, db_all + (long)i * 192, stream))) return rc;
+            if (two) {      // G of this RDB is complete: the weight / bias gradients start on the side stream
+                SRBH_HIP(hipEventRecord(g_side.ready[gb], st));
+                SRBH_HIP(hipStreamWaitEvent(ws_st, g_side.ready[gb], 0));
+            }
+            if (!two) {
+                a = srbh_conv3x3_args{};
+                a.in = Gi; a.in_chunks_total = 6; a.in_chunk0 = 0; a.in_chunks = 6;
+                a.w = pk + pack_off[4]; a.cout = 64; a.B = B; a.H = H; a.W = W;
+                a.skip = cur; a.out32 = nxt; a.out32_c = 64;
+                if ((rc = srbh_conv3x3_x16(&a, 1, nullptr, 0, 0, stream))) return rc;
+            }
+            if ((rc = srbh_act16_channel_sum(Gi, B, H, W, 6, 0, 6, 1, db_all + (long)i * 192, ws_st))) return rc;
             for (int k = 0; k < 5; ++k)
-                if ((rc = srbh_act16_wgrad_b16(D, 6, CIN[k], G, 6, CH0[k], COUT[k], B, H, W, dw_all + (long)i * DW_RDB + DWOFF[k], wgrad_ws, stream)))
+                if ((rc = srbh_act16_wgrad_b16(D, 6, CIN[k], Gi, 6, CH0[k], COUT[k], B, H, W, dw_all + (long)i * DW_RDB + DWOFF[k], wgrad_ws, ws_st)))
                     return rc;
+            if (two) {
+                SRBH_HIP(hipEventRecord(g_side.done[gb], ws_st));
+                used[gb] = 1;
+                a = srbh_conv3x3_args{};
+                a.in = Gi; a.in_chunks_total = 6; a.in_chunk0 = 0; a.in_chunks = 6;
+                a.w = pk + pack_off[4]; a.cout = 64; a.B = B; a.H = H; a.W = W;
+                a.skip = cur; a.out32 = nxt; a.out32_c = 64;
+                if ((rc = srbh_conv3x3_x16(&a, 1, nullptr, 0, 0, stream))) return rc;
+            }
             float* t = cur; cur = nxt; nxt = t;
         }
         // the RRDB's skip connection: gradient of the RRDB input = cur + gout; it is the next (lower) RRDB's output gradient
         if ((rc = srbh_axpby_f32(nxt, 1.f, cur, 1.f, gout, n, stream))) return rc;
         float* t = gout; gout = nxt; nxt = t;
     }
+    if (two)      // join: everything the side stream wrote (dw_all, db_all) is ordered before what follows on `stream`
+        for (int k = 0; k < 2; ++k)
+            if (used[k]) SRBH_HIP(hipStreamWaitEvent(st, g_side.done[k], 0));
     *g_out = gout;
     return SRBH_OK;
 }

@@ -78,7 +78,7 @@ def _fast_buffers(B, Hh, Ww, n_rdb, dev):
         nb = L.srbh_act16_bytes(B, 192, Hh, Ww)
         nb = (nb + 255) // 256 * 256
         _FAST_WS.clear()
-        ws = {"nb": nb, "D": torch.zeros((n_rdb + 1) * nb, dtype=torch.uint8, device=dev), "G": torch.zeros(nb, dtype=torch.uint8, device=dev),
+        ws = {"nb": nb, "D": torch.zeros((n_rdb + 1) * nb, dtype=torch.uint8, device=dev), "G": torch.zeros(2 * nb, dtype=torch.uint8, device=dev),
               "wg": torch.empty(L.srbh_hwgrad_ws_bytes(64, 192, 3) // 4, dtype=torch.float32, device=dev)}
         _FAST_WS[key] = ws
     return ws
@@ -178,7 +178,7 @@ def _trunk_fast_backward(net, ws, g, grads):
     offs = (C.c_size_t * 5)(*packs.offs)
     gout = C.c_void_p()
     _lib.check(L.srbh_rrdbnet_trunk_train_backward(len(net.body), ws["D"].data_ptr(), ws["nb"], packs.buf.data_ptr(), packs.stride, offs,
-                                                   g.data_ptr(), gb.data_ptr(), gc.data_ptr(), C.byref(gout), ws["G"].data_ptr(), dw_all.data_ptr(),
+                                                   g.data_ptr(), gb.data_ptr(), gc.data_ptr(), C.byref(gout), ws["G"].data_ptr(), ws["nb"], dw_all.data_ptr(),
                                                    db_all.data_ptr(), ws["wg"].data_ptr(), B, Hh, Ww, _lib.stream_ptr()), "rrdbnet_trunk_train_backward")
     i = 0
     for blk in net.body:
