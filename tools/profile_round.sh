@@ -31,6 +31,8 @@ leg() {         # leg '<shell command>': any other step, exit status checked
 bench_leg $O/${TAG}_bench_feature_b32.json.log
 bench_leg $O/${TAG}_bench_train_b64.json.log --workload train --no-cpu-baseline
 bench_leg $O/${TAG}_bench_predict_12cities.json.log --workload predict --steps 12 --warmup 2
+bench_leg $O/${TAG}_bench_sr_train_b8.json.log --workload sr_train --steps 6 --warmup 2
+SRBH_SR_BENCH_MODES=fast,mixed bench_leg $O/${TAG}_bench_sr_train_b24.json.log --workload sr_train --steps 6 --warmup 2 --batch 24
 leg 'timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- python bench.py --no-cpu-baseline --no-extras > $O/${TAG}_stats.log 2>&1'
 leg 'cp $(find $O/${TAG}_stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_feature_b32_kernel_stats.csv'
 leg 'timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/${TAG}_pmc_fetch.log 2>&1'
