@@ -24,6 +24,10 @@ import os as _os
 # (inference: measured +12 % on the tiled-predict path; the training step is bound by the host's op dispatch and gains nothing),
 # "1" = always, "0" = never
 SIDE_STREAM = _os.environ.get("SRBH_SIDE_STREAM", "auto")
+# hrfeat's output as an fp16 tensor inside the inference chain (1) or fp32 (0, default since round 3: reg / seg read it next to the fp32
+# up-sampler output, and the fused block-entry kernel -- conv1 + the 1x1 downsample conv in one pass -- takes sources of ONE element type;
+# the two separate template launches it fell back to cost more than the fp16 tensor saved)
+HRFEAT_OUT_H16 = _os.environ.get("SRBH_HRFEAT_OUT_H16", "0") == "1"
 
 
 class SRRegress_Cls_feature(torch.nn.Module):
@@ -61,7 +65,7 @@ class SRRegress_Cls_feature(torch.nn.Module):
         if x.is_cuda and (SIDE_STREAM == "1" or (SIDE_STREAM == "auto" and not torch.is_grad_enabled())):
             return self._forward_two_streams(x, super_fea)
         encode_fea = self.encoder(x)
-        super_fea = self.hrfeat(super_fea, out_h16=True)     # (fp16 NHWC inside the inference chain; reg / seg read it as such)
+        super_fea = self.hrfeat(super_fea, out_h16=HRFEAT_OUT_H16)     # (fp16 NHWC inside the inference chain; reg / seg read it as such)
         height_fea = self.decoder1(*encode_fea)
         if self.isaggre:
             height_aggre = self._aggre(height_fea)
@@ -88,7 +92,7 @@ class SRRegress_Cls_feature(torch.nn.Module):
             height_fea = self.decoder1(*encode_fea)
             build_fea = self.decoder2(*encode_fea)
             height_aggre = self._aggre(height_fea) if self.isaggre else None
-        super_fea = self.hrfeat(super_fea, out_h16=True)     # (fp16 NHWC inside the inference chain; reg / seg read it as such)
+        super_fea = self.hrfeat(super_fea, out_h16=HRFEAT_OUT_H16)     # (fp16 NHWC inside the inference chain; reg / seg read it as such)
         cur.wait_stream(side)
         for t in (height_fea, build_fea, height_aggre):      # produced on `side`, consumed on `cur`: keep the allocator from recycling early
             if t is not None:
@@ -109,7 +113,7 @@ class SRRegress_Cls_feature(torch.nn.Module):
     def forward_nobuild(self, x, super_fea):
         """mymodels.py:315-337: skips decoder2 / seg."""
         encode_fea = self.encoder(x)
-        super_fea = self.hrfeat(super_fea, out_h16=True)     # (fp16 NHWC inside the inference chain; reg / seg read it as such)
+        super_fea = self.hrfeat(super_fea, out_h16=HRFEAT_OUT_H16)     # (fp16 NHWC inside the inference chain; reg / seg read it as such)
         height_fea = self.decoder1(*encode_fea)
         if self.isaggre:
             height_aggre = self._aggre(height_fea)

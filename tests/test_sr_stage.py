@@ -160,6 +160,41 @@ def test_realesrgan_training_step_runs_and_learns():
 
 
 @pytest.mark.gpu
+def test_realesrgan_training_steps_in_fast_precision_learn_and_repack():
+    """The SR-stage step with the generator's dense blocks on the trunk's kernel family (set_train_precision("fast")): 64 x 64 LR tiles
+    (the geometry that path is written for), Adam updates between the steps -- so the per-RDB forward packs AND the stacked bf16
+    gradient packs must be rebuilt every step (cache keys: version, optimizer stamp) -- the pixel loss falls, and the first step's
+    generator gradients agree with the exact-fp32 graph's (cosine >= 0.99 on the dense-block weights)."""
+    from srbh_amd import rrdbnet_autograd as RA
+    from srbh_amd.rrdbnet import RealESRGAN
+    gt = torch.nn.functional.interpolate(rand((2, 3, 32, 32), 9, 0.0, 1.0), scale_factor=8, mode="bilinear")   # smooth 256x256 target
+    lq = torch.nn.functional.avg_pool2d(gt, 4)                                                                    # 64x64
+    grads = {}
+    try:
+        for mode in ("f32", "fast"):
+            RA.set_train_precision(mode)
+            RA._FAST_WS.clear()
+            torch.manual_seed(3)
+            m = RealESRGAN(3, 3, num_block=1, device="cuda:0", is_train=True)
+            losses = []
+            for it in range(6 if mode == "fast" else 1):
+                m.feed_data({"lq": lq, "gt": gt})
+                if it == 0:
+                    m.optimizer_g.zero_grad()
+                    m.cri_pix(m.net_g(m.lq), m.gt_usm).backward()
+                    grads[mode] = {k: p.grad.detach().clone() for k, p in m.net_g.named_parameters() if p.grad is not None}
+                losses.append(m.optimize_parameters()["l_g_pix"])
+            if mode == "fast":
+                assert RA._FAST_WS, "the fast trunk path did not run"
+                assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+    finally:
+        RA.set_train_precision("f32")
+    cos = lambda a, b: float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm()).clamp_min(1e-300))   # noqa: E731
+    body = [k for k in grads["f32"] if k.startswith("body.") and k.endswith("weight")]
+    assert len(body) == 15 and all(cos(grads["fast"][k], grads["f32"][k]) >= 0.99 for k in body), {k: cos(grads["fast"][k], grads["f32"][k]) for k in body}
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fast_mode", ["mixed", "fast"])
 def test_rrdbnet_mixed_precision_training_graph_close_to_exact(fast_mode):
     """("fast", round 3: the dense blocks forward AND backward on the trunk's own 32x32x16-MFMA kernel family -- ACT16 planes, fp16
