@@ -110,6 +110,12 @@ struct HParams {
 // v_mfma_f32_16x16x16_f16 (A = 16 out-channels x the chunk's 16 in-channels of one tap, held in registers; B = 16
 // pixels x the same 16 channels; fp32 accumulate; D layout identical to the fp32 form, so the epilogue is shared): at
 // 1/8 of the fp32 matrix-core time the kernel is bound by its HBM traffic, which is what SURVEY 8d prescribes for the head.
+// PixelShuffle(2) store staging of the 16 -> 64 up-sampler convs (NOB = 4): per wave [2 sub-rows][32 output pixels][16 channels + 1 pad] floats
+#ifndef HCONV_PS2_STAGE
+#define HCONV_PS2_STAGE 1        // (0: the direct scattered store, for same-box A/B builds)
+#endif
+constexpr int PS2_PITCH = 17, PS2_WAVE_DW = 2 * 32 * PS2_PITCH, PS2_STAGE_B = 4 * PS2_WAVE_DW * 4;
+
 template <int NOB, int KS, int RPW, int OPT>
 __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
     constexpr bool H16 = OPT != 0;
@@ -343,6 +349,13 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
     const float* const r1p = p.res1 ? (const float*)((const char*)p.res1 + (pix0 * p.res1_ld + kk * 4) * (res16 ? 2 : 4)) : nullptr;
     const float* const r2p = p.res2 ? p.res2 + pix0 * p.res2_ld + kk * 4 : nullptr;
     const bool vec_out = (p.cout_store & 3) == 0 && (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0;
+    // PixelShuffle(2) store (SR/HRfuse.py:23) of a full 16 -> 64 conv: a lane's 4 accumulators are the 2x2 sub-pixels of ONE output
+    // channel, so storing them directly is 64 scattered 4-byte stores per lane and tile (this kernel ran at 0.19 of the HBM peak).
+    // Instead each wave passes its 16-pixel group through an LDS slice in output order and writes it back as 16-byte quads of
+    // consecutive channels: 64 lanes x 16 bytes = 1 KiB contiguous per instruction.
+    const bool ps2_staged = HCONV_PS2_STAGE && NOB == 4 && p.ps2 && p.cout_store == 64 && !p.res1;
+    float* const ps2_lds = hsm + wave * PS2_WAVE_DW;
+    if (NOB == 4 && ps2_staged) __syncthreads();                 // every wave is past its last read of the input tile
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int Y = Y0 + wave * RPW + (i >> 2), X = X0 + (i & 3) * 16 + l15;
@@ -377,7 +390,10 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                     ssum[ob][q] += v[q];
                     ssq[ob][q] += v[q] * v[q];
                 }
-                if (p.ps2) {
+                if (NOB == 4 && ps2_staged) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ps2_lds[((q >> 1) * 32 + 2 * l15 + (q & 1)) * PS2_PITCH + ob * 4 + kk] = v[q];
+                } else if (p.ps2) {
                     // PixelShuffle(2): out[b, oc>>2, 2Y + ((oc>>1)&1), 2X + (oc&1)] (SR/HRfuse.py:23); lane's 4 channels
                     // are the 2x2 sub-pixels of output channel oc>>2
                     const int co = p.cout_store >> 2, cq = oc >> 2;
@@ -404,6 +420,24 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                     }
                 }
             }
+        }
+        if (NOB == 4 && ps2_staged) {
+            // the wave's own slice: LDS operations of one wave complete in order, the waitcnt + memory clobber keep the compiler
+            // from moving the reads above the writes
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int Xg = X0 + (i & 3) * 16;
+            if (Y < p.H) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = lane + 64 * r, dy = c >> 7, px2 = (c >> 2) & 31, c4 = (c & 3) * 4;
+                    const float* s = ps2_lds + (dy * 32 + px2) * PS2_PITCH + c4;
+                    floatx4 t;
+                    t[0] = s[0]; t[1] = s[1]; t[2] = s[2]; t[3] = s[3];
+                    if (Xg + (px2 >> 1) < p.W)
+                        *(floatx4*)(p.out + (((long)img * 2 * p.H + 2 * Y + dy) * (2 * p.W) + 2 * Xg + px2) * 16 + c4) = t;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the next group's writes
         }
     }
     if (p.stats) {
@@ -607,8 +641,9 @@ __global__ void nearest2x_kernel(const floatx4* __restrict__ src, floatx4* __res
 template <int NOB, int KS, int RPW, int OPT = 0>
 int launch_hconv(HParams& p, int B, int H, int W, hipStream_t st) {
     constexpr bool H16 = OPT != 0;
-    constexpr int LDS_B = H16 ? ((4 * RPW + 2) * (HT_W + 2) * 32 > 4 * 2 * NOB * 16 * 4 ? (4 * RPW + 2) * (HT_W + 2) * 32 : 4 * 2 * NOB * 16 * 4)
+    constexpr int LDS_T = H16 ? ((4 * RPW + 2) * (HT_W + 2) * 32 > 4 * 2 * NOB * 16 * 4 ? (4 * RPW + 2) * (HT_W + 2) * 32 : 4 * 2 * NOB * 16 * 4)
                               : (in_dw(RPW) + KS * KS * 4 * NOB * 64) * 4;
+    constexpr int LDS_B = (NOB == 4 && LDS_T < PS2_STAGE_B) ? PS2_STAGE_B : LDS_T;     // (PixelShuffle store staging, see the epilogue)
     p.tiles_x = (W + HT_W - 1) / HT_W;
     p.tiles_per_img = p.tiles_x * ((H + 4 * RPW - 1) / (4 * RPW));
     p.ntiles = p.tiles_per_img * B;
