@@ -363,6 +363,64 @@ int srbh_se_hidden(const float* pooled, const float* w1, const float* b1, float*
 int srbh_se_gate_scale(float* y, const float* hidden, const float* w2, const float* b2, int B, int C, int SQ, int HW,
                        void* stream);
 
+/* ---- TRAINING-mode BatchNorm + activation and squeeze-and-excitation of the MBConv / U-Net decoder blocks (csrc/srbh_mbconv.hip) ----
+ * Replaces, for the encoder / decoders the reference builds at mymodels.py:242-258 and runs at mymodels.py:276-287, the stock
+ * F.batch_norm(training=True) + SiLU/ReLU (+ adaptive_avg_pool2d, + drop-connect multiply and skip add) launches and their autograd
+ * backward.  fp32 NCHW; planes of HW = 1, 4, 16, 64 or 256 elements with B * max(64, HW) floats within LDS
+ * (srbh_bn_act_train_supported; larger planes stay on the stock ops).
+ *   forward :  mean / biased variance over (B, HW) in two passes, running statistics updated as nn.BatchNorm2d does (momentum, unbiased
+ *              variance), y = act(gamma (x - mean) invstd + beta) [* drop[b]] [+ res],  pooled[b][c] = mean over the plane of y
+ *   backward:  dy_eff = dy [* gate[b][c] + dpooled[b][c] / HW] [* drop[b]];  dz = dy_eff act'(z);  dbeta = sum dz;  dgamma = sum dz xhat;
+ *              dx = gamma invstd (dz - mean(dz) - xhat mean(dz xhat))   (dx may be NULL: parameter gradients only)            */
+typedef struct srbh_bnact_args {
+    const float* x;            /* [B][C][HW] the convolution output */
+    float* y;                  /* [B][C][HW] */
+    const float* gamma;        /* [C] */
+    const float* beta;         /* [C] */
+    float* running_mean;       /* [C], updated in place; NULL (both) = no running statistics */
+    float* running_var;
+    float* save_mean;          /* [C] out: batch mean */
+    float* save_invstd;        /* [C] out: 1 / sqrt(biased variance + eps) */
+    float* pooled;             /* optional [B][C] out: plane means of y (the squeeze of squeeze-and-excitation) */
+    const float* res;          /* optional [B][C][HW]: added after the activation (MBConv skip connection) */
+    const float* drop;         /* optional [B]: per-sample drop-connect factor floor(keep + u) / keep, applied before `res` */
+    float momentum, eps;
+    int B, C, HW;
+    int act;                   /* 0 none | 1 SiLU | 2 ReLU */
+} srbh_bnact_args;
+typedef struct srbh_bnact_bwd_args {
+    const float* dy;           /* [B][C][HW] gradient of the output */
+    const float* x;            /* the forward's x */
+    const float* gamma;
+    const float* beta;
+    const float* save_mean;
+    const float* save_invstd;
+    const float* gate;         /* optional [B][C] (with dpooled): the squeeze-excite gate the forward output was scaled by */
+    const float* dpooled;      /* optional [B][C]: gradient of the plane means */
+    const float* drop;         /* optional [B] */
+    float* dx;                 /* [B][C][HW] or NULL */
+    float* dgamma;             /* [C] */
+    float* dbeta;              /* [C] */
+    int B, C, HW;
+    int act;
+} srbh_bnact_bwd_args;
+int srbh_bn_act_train_supported(int B, int C, int HW);
+int srbh_bn_act_train_fwd(const srbh_bnact_args* a, void* stream);
+int srbh_bn_act_train_bwd(const srbh_bnact_bwd_args* a, void* stream);
+/* squeeze-and-excitation in training (efficientnet_pytorch MBConvBlock.forward: x_squeezed = avg_pool(x); se_expand(swish(se_reduce(.)));
+ * x = sigmoid(.) * x): forward = hidden_pre [B][SQ] = b1 + w1 [SQ][C] . pooled, hidden = swish(hidden_pre), gate [B][C] =
+ * sigmoid(b2 + w2 [C][SQ] . hidden), y[plane (b, c)] *= gate in place (two launches); the three extra outputs are what the backward reads.
+ * backward (three launches; ws: srbh_se_train_bwd_ws_floats): from dout = gradient of the scaled output and the BatchNorm's saved x /
+ * statistics (y = act(bn(x)) is recomputed, it was scaled in place) -> dpooled [B][C] (feed it with `gate` to srbh_bn_act_train_bwd) and the
+ * gradients of the four squeeze-excite parameters, batch sums in a fixed order. */
+int srbh_se_train_fwd(float* y, const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* hidden,
+                      float* hidden_pre, float* gate, int B, int C, int SQ, int HW, void* stream);
+int srbh_se_train_bwd(const float* dout, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                      const float* save_invstd, const float* pooled, const float* hidden, const float* hidden_pre, const float* gate,
+                      const float* w1, const float* w2, float* ws, float* dpooled, float* dw1, float* db1, float* dw2, float* db2, int B,
+                      int C, int SQ, int HW, int act, void* stream);
+size_t srbh_se_train_bwd_ws_floats(int B, int C, int SQ);
+
 /* ---- inference epilogue: quantise + integer mosaic (predict_realesanet_feature_globe.py:172-204) ------------------
  * accumulate: height [B][th][tw] fp32 (model output, C=1), build logits NHWC [B][th][tw][C] fp32, pos [B][4] int32
  *   = (xoff, yoff, xcount, ycount) already multiplied by 4 (predict...py:182); adds round(max(h,0)*10) and

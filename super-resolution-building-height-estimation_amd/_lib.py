@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libsrbh.so")
 _DEV_LIB = os.environ.get("SRBH_LIB_PATH")      # developer A/B only (tools/ab_variants.sh): load another build of the same ABI
-SOURCES = ["srbh_conv3x3.hip", "srbh_aux.hip", "srbh_rrdbnet.hip", "srbh_ptrunk.hip", "srbh_ptail.hip", "srbh_head.hip", "srbh_head_bwd.hip", "srbh_mosaic.hip", "srbh_loader.hip", "srbh_loss.hip", "srbh_dwconv.hip"]
+SOURCES = ["srbh_conv3x3.hip", "srbh_aux.hip", "srbh_rrdbnet.hip", "srbh_ptrunk.hip", "srbh_ptail.hip", "srbh_head.hip", "srbh_head_bwd.hip", "srbh_mosaic.hip", "srbh_loader.hip", "srbh_loss.hip", "srbh_dwconv.hip", "srbh_mbconv.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # NOTE: `-mllvm -amdgpu-mfma-vgpr-form=1` (accumulators in VGPRs: no v_accvgpr copies at K-loop back-edges).  Round 1 saw the
 # first persistent trunk kernel produce non-deterministic garbage with it; round 3 re-ran it on the current kernel (ptrunk3:
@@ -97,6 +97,24 @@ class HWGradArgs(C.Structure):
     ]
 
 
+class BnActArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
+        ("pooled", C.c_void_p), ("res", C.c_void_p), ("drop", C.c_void_p),
+        ("momentum", C.c_float), ("eps", C.c_float), ("B", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("act", C.c_int),
+    ]
+
+
+class BnActBwdArgs(C.Structure):
+    _fields_ = [
+        ("dy", C.c_void_p), ("x", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p), ("gate", C.c_void_p), ("dpooled", C.c_void_p), ("drop", C.c_void_p),
+        ("dx", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+        ("B", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("act", C.c_int),
+    ]
+
+
 class ConvW(C.Structure):
     _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p)]
 
@@ -163,6 +181,12 @@ SIGNATURES = {
     "srbh_affine_act_pool_nchw": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_se_hidden": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srbh_se_gate_scale": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "srbh_bn_act_train_supported": (_i, [_i, _i, _i]),
+    "srbh_bn_act_train_fwd": (_i, [C.POINTER(BnActArgs), _vp]),
+    "srbh_bn_act_train_bwd": (_i, [C.POINTER(BnActBwdArgs), _vp]),
+    "srbh_se_train_fwd": (_i, [_vp] * 9 + [_i] * 4 + [_vp]),
+    "srbh_se_train_bwd": (_i, [_vp] * 18 + [_i] * 5 + [_vp]),
+    "srbh_se_train_bwd_ws_floats": (_sz, [_i, _i, _i]),
     "srbh_dwconv_fwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "srbh_dwconv_bwd_data": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "srbh_dwconv_bwd_weight_splits": (_i, [_i, _i]),

@@ -1,0 +1,628 @@
+// srbh_mbconv.hip -- TRAINING-mode BatchNorm + activation and squeeze-and-excitation of the EfficientNet MBConv blocks and the
+// U-Net decoder blocks (fp32 NCHW), forward and backward.
+//
+// Why it exists: the encoder / decoders the reference instantiates (mymodels.py:242-258, forward at 276-287) are stock ops in this
+// build, and at 64x64 tiles their training step is ~2 070 tiny launches (16.3 ms of a 44 ms step, round-2 VERDICT item 4): per
+// MBConv block BatchNorm + SiLU, the pooled squeeze-excite branch (avg-pool, two 1x1 convs with their bias adds, SiLU, sigmoid,
+// scale) and BatchNorm + drop-connect + skip are ~14 launches forward and ~30 backward, each moving well under a megabyte.  These
+// are HBM/L2-resident element-wise + reduction passes; nothing here is a GEMM.
+//
+// Layout trick: below 32x32 a channel plane is at most 256 floats, so ONE workgroup owns a group of adjacent channels whose planes
+// form a contiguous run of RW = 64 or 256 floats per image (CPW = RW / HW channels), holds all B images of that run in LDS
+// (B * RW floats: 16 KB at B = 64, RW = 64) and does the whole training-mode BatchNorm in one launch: exact two-pass statistics from
+// LDS, running-statistics update, normalise + activation (+ plane means for squeeze-excite, + drop-connect and skip connection),
+// ONE global read of x and one write of y.  The backward has the same shape: dz = dy * act'(z) cached in LDS, the two channel sums,
+// then dx.  Planes of 32x32 and larger (6 encoder and 8 decoder layers) stay on the stock ops: the host checks
+// srbh_bn_act_train_supported.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "srbh.h"
+#include "srbh_internal.h"
+
+namespace {
+using namespace srbh;
+
+constexpr int MAX_LDS_B = 160 * 1024 - 4096;
+constexpr int NW = 16;               // waves per workgroup of the BatchNorm kernels (1024 threads)
+constexpr int U = 4;                 // images per wave and round of global loads (16 waves x 4 = the whole batch of 64 in ONE round)
+
+// (v_rcp_f32: 1 ulp; these kernels are bound by the instruction stream of one wave per SIMD, an IEEE division is ~10 instructions)
+__device__ __forceinline__ float sigmoidf(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
+template <int ACT>
+__device__ __forceinline__ float act_f(float z) {
+    if (ACT == 1) return z * sigmoidf(z);
+    if (ACT == 2) return fmaxf(z, 0.f);
+    return z;
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad(float z) {
+    if (ACT == 1) {
+        const float s = sigmoidf(z);
+        return s * (1.f + z * (1.f - s));
+    }
+    if (ACT == 2) return z > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+// sum over the lanes that share a channel (a run of `seg` = min(HW, 64) consecutive lanes, seg a power of two), then over the NW waves
+// through `red`; every thread returns the total of ITS channel.  RW == 64: a wave spans the CPW channels of the workgroup (channel
+// of a lane = lane / HW); RW == 256: the whole workgroup is one channel.  Deterministic order.
+__device__ __forceinline__ float channel_sum(float v, int seg, int slot, float (*red)[64], int wave, int lane) {
+    for (int o = 1; o < seg; o <<= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();                          // `red` may still be read from the previous reduction
+    if ((lane & (seg - 1)) == 0) red[wave][slot] = v;
+    __syncthreads();
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w += 2) {
+        a += red[w][slot];
+        b += red[w + 1][slot];
+    }
+    return a + b;
+}
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+template <int VEC> struct Vt { float v[VEC]; };
+template <int VEC> __device__ __forceinline__ Vt<VEC> ldv(const float* p) {
+    Vt<VEC> r;
+    if (VEC == 4) {
+        const floatx4 t = *(const floatx4*)p;
+        r.v[0] = t[0]; r.v[1 % VEC] = t[1]; r.v[2 % VEC] = t[2]; r.v[3 % VEC] = t[3];
+    } else {
+        r.v[0] = *p;
+    }
+    return r;
+}
+template <int VEC> __device__ __forceinline__ void stv(float* p, const Vt<VEC>& r) {
+    if (VEC == 4) *(floatx4*)p = floatx4{r.v[0], r.v[1 % VEC], r.v[2 % VEC], r.v[3 % VEC]};
+    else *p = r.v[0];
+}
+template <int VEC> __device__ __forceinline__ Vt<VEC> zerov() {
+    Vt<VEC> r;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) r.v[k] = 0.f;
+    return r;
+}
+
+// Geometry shared by the forward and the backward kernel.  A workgroup owns a run of 64 * VEC contiguous floats per image: VEC = 1 --
+// CPW = 64 / HW adjacent channels of HW <= 64 elements; VEC = 4 -- one channel of 256 elements, a float4 per lane.  Wave w takes the
+// images w, w + NW, ...; a lane keeps the same position of the run for every image.
+struct FwdP {
+    const float* x; float* y;
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var;
+    float* save_mean; float* save_invstd;
+    float* pooled; const float* res; const float* drop;
+    float momentum, eps;
+    int B, C, HW;
+};
+
+template <int ACT, int VEC>
+__global__ __launch_bounds__(64 * NW) void bn_act_train_fwd_kernel(const FwdP p) {
+    extern __shared__ __attribute__((aligned(16))) float cache[];      // [B][64 * VEC]
+    __shared__ float red[NW][64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int HW = p.HW, RW = 64 * VEC;
+    const int seg = (VEC == 4 || HW >= 64) ? 64 : HW;
+    const int slot = VEC == 4 ? 0 : lane / HW;
+    const int c0 = blockIdx.x * (RW / HW), c = c0 + slot;
+    const bool cok = c < p.C;
+    const float invN = 1.f / ((float)p.B * (float)HW);
+    const long off = (long)c0 * HW + lane * VEC, bstride = (long)p.C * HW;
+    // These kernels are LATENCY chains, not bandwidth: a workgroup moves 16-64 KB.  Every global pass is therefore issued U images at
+    // a time (a plain loop leaves one load in flight per lane: measured 12-16 us per launch), and everything the later phases
+    // need -- affine parameters, running statistics, the first round of the skip connection -- is requested before the reductions.
+    const float gam = cok ? p.gamma[c] : 0.f, bet = cok ? p.beta[c] : 0.f;
+    const float rm0 = (cok && p.running_mean) ? p.running_mean[c] : 0.f, rv0 = (cok && p.running_mean) ? p.running_var[c] : 0.f;
+    float s = 0.f;
+    for (int b0 = wave; b0 < p.B; b0 += NW * U) {
+        Vt<VEC> v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + NW * u;
+            v[u] = (cok && b < p.B) ? ldv<VEC>(p.x + b * bstride + off) : zerov<VEC>();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + NW * u;
+            if (b < p.B) stv<VEC>(cache + (b * 64 + lane) * VEC, v[u]);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) s += v[u].v[k];
+        }
+    }
+    Vt<VEC> r0[U];
+    float dr0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int b = wave + NW * u;
+        r0[u] = (p.res && cok && b < p.B) ? ldv<VEC>(p.res + b * bstride + off) : zerov<VEC>();
+        dr0[u] = (p.drop && b < p.B) ? p.drop[b] : 1.f;
+    }
+    const float mean = channel_sum(s, seg, slot, red, wave, lane) * invN;
+    float q = 0.f;
+    for (int b = wave; b < p.B; b += NW) {
+        const Vt<VEC> v = ldv<VEC>(cache + (b * 64 + lane) * VEC);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) q = fmaf(v.v[k] - mean, v.v[k] - mean, q);
+    }
+    const float var = channel_sum(q, seg, slot, red, wave, lane) * invN;       // biased, as F.batch_norm normalises
+    const float invstd = 1.f / sqrtf(var + p.eps);
+    if (cok && wave == 0 && (lane & (seg - 1)) == 0) {
+        p.save_mean[c] = mean;
+        p.save_invstd[c] = invstd;
+        if (p.running_mean) {
+            const float n = (float)p.B * (float)HW;
+            p.running_mean[c] = (1.f - p.momentum) * rm0 + p.momentum * mean;
+            p.running_var[c] = (1.f - p.momentum) * rv0 + p.momentum * (n > 1.f ? var * n / (n - 1.f) : var);
+        }
+    }
+    const float scale = gam * invstd, shift = bet - mean * scale;
+    for (int b0 = wave; b0 < p.B; b0 += NW * U) {
+        Vt<VEC> r[U];
+        float dr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + NW * u;
+            if (b0 == wave) {
+                r[u] = r0[u];
+                dr[u] = dr0[u];
+            } else {
+                r[u] = (p.res && cok && b < p.B) ? ldv<VEC>(p.res + b * bstride + off) : zerov<VEC>();
+                dr[u] = (p.drop && b < p.B) ? p.drop[b] : 1.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + NW * u;
+            if (b >= p.B) continue;                                // (uniform per wave: b depends on the wave only)
+            Vt<VEC> a = ldv<VEC>(cache + (b * 64 + lane) * VEC);
+            float w = 0.f;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                a.v[k] = fmaf(act_f<ACT>(fmaf(a.v[k], scale, shift)), dr[u], r[u].v[k]);
+                w += a.v[k];
+            }
+            if (cok) stv<VEC>(p.y + b * bstride + off, a);
+            if (p.pooled) {
+                for (int o = 1; o < seg; o <<= 1) w += __shfl_xor(w, o, 64);
+                if (cok && (lane & (seg - 1)) == 0) p.pooled[(long)b * p.C + c] = w / (float)HW;
+            }
+        }
+    }
+}
+
+struct BwdP {
+    const float* dy; const float* x;
+    const float* gamma; const float* beta; const float* save_mean; const float* save_invstd;
+    const float* gate; const float* dpooled; const float* drop;
+    float* dx; float* dgamma; float* dbeta;
+    int B, C, HW;
+};
+
+template <int ACT, int VEC>
+__global__ __launch_bounds__(64 * NW) void bn_act_train_bwd_kernel(const BwdP p) {
+    extern __shared__ __attribute__((aligned(16))) float cache[];      // [B][64 * VEC] dz | [B][64 * VEC] xhat
+    __shared__ float red[NW][64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int HW = p.HW, RW = 64 * VEC;
+    const int seg = (VEC == 4 || HW >= 64) ? 64 : HW;
+    const int slot = VEC == 4 ? 0 : lane / HW;
+    const int c0 = blockIdx.x * (RW / HW), c = c0 + slot;
+    const bool cok = c < p.C;
+    const float invN = 1.f / ((float)p.B * (float)HW), invHW = 1.f / (float)HW;
+    const float mean = cok ? p.save_mean[c] : 0.f, invstd = cok ? p.save_invstd[c] : 0.f;
+    const float g = cok ? p.gamma[c] : 0.f, be = cok ? p.beta[c] : 0.f;
+    const long off = (long)c0 * HW + lane * VEC, bstride = (long)p.C * HW;
+    float* const xhc = cache + p.B * 64 * VEC;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b0 = wave; b0 < p.B; b0 += NW * U) {
+        Vt<VEC> xv[U], dv[U];
+        float gt[U], dpo[U], dr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + NW * u;
+            const bool ok = cok && b < p.B;
+            xv[u] = ok ? ldv<VEC>(p.x + b * bstride + off) : zerov<VEC>();
+            dv[u] = ok ? ldv<VEC>(p.dy + b * bstride + off) : zerov<VEC>();
+            gt[u] = (ok && p.gate) ? p.gate[(long)b * p.C + c] : 1.f;
+            dpo[u] = (ok && p.gate) ? p.dpooled[(long)b * p.C + c] * invHW : 0.f;
+            dr[u] = (ok && p.drop) ? p.drop[b] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + NW * u;
+            if (b >= p.B) continue;
+            Vt<VEC> dz, xh;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                xh.v[k] = (xv[u].v[k] - mean) * invstd;
+                const float d = fmaf(dv[u].v[k], gt[u], dpo[u]) * dr[u];
+                dz.v[k] = cok ? d * act_grad<ACT>(fmaf(xh.v[k], g, be)) : 0.f;
+                s2 = fmaf(dz.v[k], xh.v[k], s2);
+                s1 += dz.v[k];
+            }
+            stv<VEC>(cache + (b * 64 + lane) * VEC, dz);
+            stv<VEC>(xhc + (b * 64 + lane) * VEC, xh);
+        }
+    }
+    const float sum_dz = channel_sum(s1, seg, slot, red, wave, lane);
+    const float sum_dzx = channel_sum(s2, seg, slot, red, wave, lane);
+    if (cok && wave == 0 && (lane & (seg - 1)) == 0) {
+        p.dbeta[c] = sum_dz;
+        p.dgamma[c] = sum_dzx;
+    }
+    if (!p.dx) return;
+    const float k1 = sum_dz * invN, k2 = sum_dzx * invN, gi = g * invstd;
+    for (int b = wave; b < p.B; b += NW) {
+        if (!cok) continue;
+        Vt<VEC> dz = ldv<VEC>(cache + (b * 64 + lane) * VEC);
+        const Vt<VEC> xh = ldv<VEC>(xhc + (b * 64 + lane) * VEC);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) dz.v[k] = gi * (dz.v[k] - k1 - xh.v[k] * k2);
+        stv<VEC>(p.dx + b * bstride + off, dz);
+    }
+}
+
+// squeeze-excite backward, step 1: draw[b][c] = sum over the plane of dout * y, y = act(bn(x)) recomputed from the saved conv output
+// (the forward scaled y in place, it is not kept).  Planes are contiguous, so a wave takes 64 consecutive elements = 64 / hw whole
+// planes when hw < 64 (a wave per 4-element plane would be 172 k nearly empty waves at 2x2), else one plane per wave.
+template <int ACT>
+__global__ __launch_bounds__(256) void se_bwd_dgate_kernel(const float* __restrict__ dout, const float* __restrict__ x,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          float* __restrict__ draw, long planes, int C, int hw) {
+    const int lane = threadIdx.x & 63;
+    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (hw < 64) {
+        const long idx = wv * 64 + lane;
+        const long pl = idx / hw;
+        float acc = 0.f;
+        if (pl < planes) {
+            const int c = (int)(pl % C);
+            const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+            acc = dout[idx] * act_f<ACT>(fmaf(x[idx], sc, sh));
+        }
+        for (int o = 1; o < hw; o <<= 1) acc += __shfl_xor(acc, o, 64);
+        if (pl < planes && (lane & (hw - 1)) == 0) draw[pl] = acc;
+        return;
+    }
+    const long pl = wv;
+    if (pl >= planes) return;
+    const int c = (int)(pl % C);
+    const float sc = gamma[c] * invstd[c], sh = beta[c] - mean[c] * sc;
+    const float* xp = x + pl * hw;
+    const float* dp = dout + pl * hw;
+    float acc = 0.f;
+    for (int i = lane; i < hw; i += 64) acc = fmaf(dp[i], act_f<ACT>(fmaf(xp[i], sc, sh)), acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) draw[pl] = acc;
+}
+
+// step 2a, grid (B, NCH): workgroup (b, k) owns the channels [k CC, (k+1) CC): through the sigmoid, and its share of the expand conv
+//   dsig[c] = draw[c] gate[c] (1 - gate[c]);   part[b][k][s] = sum over its c of dsig[c] w2[c][s]
+// (one workgroup per image ran a 672-iteration dependent loop per wave at C = 2688; chunks keep every loop under ~30 iterations)
+constexpr int SE_MAX_SQ = 256;
+__global__ __launch_bounds__(256) void se_bwd_expand_kernel(const float* __restrict__ draw, const float* __restrict__ gate,
+                                                           const float* __restrict__ w2, float* __restrict__ dsig_out,
+                                                           float* __restrict__ part, int C, int SQ, int CC) {
+    __shared__ float dsig[256 * 4];
+    __shared__ float red[4][SE_MAX_SQ];
+    const int b = blockIdx.x, k = blockIdx.y, nch = gridDim.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cb = k * CC, ce = (cb + CC < C) ? cb + CC : C, n = ce - cb;
+    for (int i = t; i < n; i += 256) {
+        const float gt = gate[(long)b * C + cb + i];
+        const float d = draw[(long)b * C + cb + i] * gt * (1.f - gt);
+        dsig[i] = d;
+        dsig_out[(long)b * C + cb + i] = d;
+    }
+    __syncthreads();
+    for (int s0 = 0; s0 < SQ; s0 += 64) {
+        const int s = s0 + lane;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if (s < SQ) {
+            int i = wave;
+            for (; i + 12 < n; i += 16) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = fmaf(dsig[i + 4 * u], w2[(long)(cb + i + 4 * u) * SQ + s], a[u]);
+            }
+            for (; i < n; i += 4) a[0] = fmaf(dsig[i], w2[(long)(cb + i) * SQ + s], a[0]);
+            red[wave][s] = (a[0] + a[1]) + (a[2] + a[3]);
+        }
+    }
+    __syncthreads();
+    for (int s = t; s < SQ; s += 256) part[((long)b * nch + k) * SQ + s] = (red[0][s] + red[1][s]) + (red[2][s] + red[3][s]);
+}
+
+// step 2b, grid (B, NCH): dh[s] = sum_k part[b][k][s];  dhp[s] = dh[s] silu'(hp[s]);  dpooled[c] = sum_s dhp[s] w1[s][c] for its channels
+__global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const float* __restrict__ part, const float* __restrict__ hidden_pre,
+                                                           const float* __restrict__ w1, float* __restrict__ dhp_out,
+                                                           float* __restrict__ dpooled, int C, int SQ, int CC) {
+    __shared__ float dhp[SE_MAX_SQ];
+    const int b = blockIdx.x, k = blockIdx.y, nch = gridDim.y, t = threadIdx.x;
+    for (int s = t; s < SQ; s += 256) {
+        float dh = 0.f;
+        for (int j = 0; j < nch; ++j) dh += part[((long)b * nch + j) * SQ + s];
+        const float d = dh * act_grad<1>(hidden_pre[(long)b * SQ + s]);
+        dhp[s] = d;
+        if (k == 0) dhp_out[(long)b * SQ + s] = d;
+    }
+    __syncthreads();
+    const int cb = k * CC, ce = (cb + CC < C) ? cb + CC : C;
+    for (int c = cb + t; c < ce; c += 256) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 3 < SQ; s += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = fmaf(dhp[s + u], w1[(long)(s + u) * C + c], a[u]);
+        }
+        for (; s < SQ; ++s) a[0] = fmaf(dhp[s], w1[(long)s * C + c], a[0]);
+        dpooled[(long)b * C + c] = (a[0] + a[1]) + (a[2] + a[3]);
+    }
+}
+
+// step 3: the four parameter gradients, sums over the batch:
+//   dw2[c][s] = sum_b dsig[b][c] h[b][s];  db2[c] = sum_b dsig[b][c];  dw1[s][c] = sum_b dhp[b][s] pooled[b][c];  db1[s] = sum_b dhp[b][s]
+// Two small "A^T B" products with K = B.  One thread per output element looping over the batch re-read both operands from L2 for
+// every element (~300 MB of L1 traffic at C = 2688, 20 us per block); here a wave owns a 32 x 32 tile and feeds the fp32 matrix unit
+// straight from global memory -- v_mfma_f32_32x32x2_f32 takes A[i][k] / B[k][j] with i, j = lane % 32 and k = lane / 32, which is
+// exactly a coalesced row read of both operands -- in true fp32, fixed order.  The bias gradients are the column sums of A.
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+struct GemmTN {
+    const float* A;        // [K][M]
+    const float* Bm;       // [K][N]
+    float* out;            // [M][N] = A^T Bm
+    float* colsum;         // [M] = sum_k A[k][:]
+    int M, N;
+};
+__global__ __launch_bounds__(256) void se_bwd_params_kernel(const GemmTN g0, const GemmTN g1, int K, int tiles0, int tn0, int tn1) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int tile = blockIdx.x * 4 + wave;
+    const bool second = tile >= tiles0;
+    if (second) tile -= tiles0;
+    const float* __restrict__ A = second ? g1.A : g0.A;
+    const float* __restrict__ Bm = second ? g1.Bm : g0.Bm;
+    float* __restrict__ out = second ? g1.out : g0.out;
+    float* __restrict__ colsum = second ? g1.colsum : g0.colsum;
+    const int M = second ? g1.M : g0.M, N = second ? g1.N : g0.N, tn = second ? tn1 : tn0;
+    const int ti = tile / tn, tj = tile - ti * tn;
+    if (ti * 32 >= M) return;
+    const int i = ti * 32 + (lane & 31), j = tj * 32 + (lane & 31), kh = lane >> 5;
+    const bool iok = i < M, jok = j < N;
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float cs = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        float a[32], b[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int k = k0 + 2 * u + kh;
+            a[u] = (iok && k < K) ? A[(long)k * M + i] : 0.f;
+            b[u] = (jok && k < K) ? Bm[(long)k * N + j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+            cs += a[u];
+        }
+    }
+    if (tj == 0) {
+        cs += __shfl_xor(cs, 32, 64);
+        if (kh == 0 && iok) colsum[i] = cs;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ii = ti * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+        if (ii < M && jok) out[(long)ii * N + j] = acc[r];
+    }
+}
+
+// training forms of the two inference squeeze-excite kernels (srbh_dwconv.hip): they also keep what the backward needs
+__global__ __launch_bounds__(256) void se_hidden_train_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                             const float* __restrict__ b1, float* __restrict__ hidden,
+                                                             float* __restrict__ hidden_pre, int C, int SQ) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (j >= SQ) return;
+    const float* wr = w1 + (long)j * C;
+    const float* pr = pooled + (long)b * C;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int c = lane;
+    for (; c + 192 < C; c += 256) {
+        a0 = fmaf(wr[c], pr[c], a0);
+        a1 = fmaf(wr[c + 64], pr[c + 64], a1);
+        a2 = fmaf(wr[c + 128], pr[c + 128], a2);
+        a3 = fmaf(wr[c + 192], pr[c + 192], a3);
+    }
+    for (; c < C; c += 64) a0 = fmaf(wr[c], pr[c], a0);
+    float acc = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) {
+        const float u = acc + b1[j];
+        hidden_pre[(long)b * SQ + j] = u;
+        hidden[(long)b * SQ + j] = u * sigmoidf(u);
+    }
+}
+
+// gate + scale, planes of 4 / 16 / 64 / 256 elements: a workgroup takes 1024 consecutive elements (a float4 per thread); the G = hw / 4
+// threads that hold one plane compute its gate together (a wave per 4-element plane would be 172 k nearly empty waves at 2x2)
+__global__ __launch_bounds__(256) void se_gate_scale_train_kernel(float* __restrict__ y, const float* __restrict__ hidden,
+                                                                 const float* __restrict__ w2, const float* __restrict__ b2,
+                                                                 float* __restrict__ gate, long planes, int C, int SQ, int hw) {
+    const int t = threadIdx.x, G = hw >> 2, sub = t & (G - 1);
+    const long e = (long)blockIdx.x * 1024 + 4 * t;
+    const long pl = e / hw;
+    const bool ok = pl < planes;
+    const int c = ok ? (int)(pl % C) : 0;
+    const long b = ok ? pl / C : 0;
+    const float* wr = w2 + (long)c * SQ;
+    const float* hr = hidden + b * SQ;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    int j = sub;
+    for (; j + 3 * G < SQ; j += 4 * G) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = fmaf(wr[j + u * G], hr[j + u * G], a[u]);
+    }
+    for (; j < SQ; j += G) a[0] = fmaf(wr[j], hr[j], a[0]);
+    float acc = (a[0] + a[1]) + (a[2] + a[3]);
+    for (int o = 1; o < G; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (!ok) return;
+    const float g = sigmoidf(acc + b2[c]);
+    if (sub == 0) gate[pl] = g;
+    floatx4 v = *(floatx4*)(y + e);
+    v *= g;
+    *(floatx4*)(y + e) = v;
+}
+
+// (any other plane size: one wave per plane)
+__global__ __launch_bounds__(256) void se_gate_scale_train_wave_kernel(float* __restrict__ y, const float* __restrict__ hidden,
+                                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                                      float* __restrict__ gate, long planes, int C, int SQ, int hw) {
+    const int lane = threadIdx.x & 63;
+    const long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pl >= planes) return;
+    const int c = (int)(pl % C);
+    const long b = pl / C;
+    const float* wr = w2 + (long)c * SQ;
+    const float* hr = hidden + b * SQ;
+    float acc = 0.f;
+    for (int j = lane; j < SQ; j += 64) acc = fmaf(wr[j], hr[j], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    const float g = sigmoidf(acc + b2[c]);
+    if (lane == 0) gate[pl] = g;
+    float* yp = y + pl * hw;
+    for (int i = lane; i < hw; i += 64) yp[i] *= g;
+}
+
+int se_chunks(int C) {                      // channel chunks of the squeeze-excite backward: <= 1024 channels each (LDS), ~16 at most
+    int n = (C + 127) / 128;
+    return n < 1 ? 1 : (n > 16 ? ((C + 1023) / 1024 > 16 ? (C + 1023) / 1024 : 16) : n);
+}
+int row_width(int HW) { return HW == 256 ? 256 : ((HW == 64 || HW == 16 || HW == 4 || HW == 1) ? 64 : 0); }
+size_t fwd_lds(int B, int RW) { return (size_t)B * RW * 4; }
+}  // namespace
+
+extern "C" int srbh_bn_act_train_supported(int B, int C, int HW) {
+    const int RW = row_width(HW);
+    return RW != 0 && B > 0 && C > 0 && 2 * fwd_lds(B, RW) <= (size_t)MAX_LDS_B;       // (the backward keeps dz and xhat)
+}
+
+extern "C" int srbh_bn_act_train_fwd(const srbh_bnact_args* a, void* stream) {
+    SRBH_REQUIRE(a && a->x && a->y && a->gamma && a->beta && a->save_mean && a->save_invstd, "srbh_bn_act_train_fwd: null pointer");
+    SRBH_REQUIRE(a->act >= 0 && a->act <= 2, "srbh_bn_act_train_fwd: act must be 0 (none), 1 (SiLU) or 2 (ReLU)");
+    SRBH_REQUIRE(srbh_bn_act_train_supported(a->B, a->C, a->HW), "srbh_bn_act_train_fwd: unsupported shape B=%d C=%d HW=%d (planes of 1, 4, 16, 64 or 256 floats, B * row within LDS)", a->B, a->C, a->HW);
+    SRBH_REQUIRE((a->running_mean == nullptr) == (a->running_var == nullptr), "srbh_bn_act_train_fwd: running_mean / running_var go together");
+    FwdP p;
+    p.x = a->x; p.y = a->y; p.gamma = a->gamma; p.beta = a->beta; p.running_mean = a->running_mean; p.running_var = a->running_var;
+    p.save_mean = a->save_mean; p.save_invstd = a->save_invstd; p.pooled = a->pooled; p.res = a->res; p.drop = a->drop;
+    p.momentum = a->momentum; p.eps = a->eps; p.B = a->B; p.C = a->C; p.HW = a->HW;
+    const int RW = row_width(a->HW), cpw = RW / p.HW;
+    const size_t lds = fwd_lds(p.B, RW);
+    const dim3 grid((p.C + cpw - 1) / cpw);
+#define SRBH_FWD(A_, V_)                                                                                                                  \
+    do {                                                                                                                                  \
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)bn_act_train_fwd_kernel<A_, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_B))); \
+        hipLaunchKernelGGL((bn_act_train_fwd_kernel<A_, V_>), grid, dim3(64 * NW), lds, (hipStream_t)stream, p);                              \
+    } while (0)
+#define SRBH_FWD_V(A_)          \
+    do {                        \
+        if (RW == 256) SRBH_FWD(A_, 4); \
+        else SRBH_FWD(A_, 1);   \
+    } while (0)
+    if (a->act == 0) SRBH_FWD_V(0);
+    else if (a->act == 1) SRBH_FWD_V(1);
+    else SRBH_FWD_V(2);
+#undef SRBH_FWD_V
+#undef SRBH_FWD
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_bn_act_train_bwd(const srbh_bnact_bwd_args* a, void* stream) {
+    SRBH_REQUIRE(a && a->dy && a->x && a->gamma && a->beta && a->save_mean && a->save_invstd && a->dgamma && a->dbeta,
+                 "srbh_bn_act_train_bwd: null pointer");
+    SRBH_REQUIRE(a->act >= 0 && a->act <= 2, "srbh_bn_act_train_bwd: act must be 0 (none), 1 (SiLU) or 2 (ReLU)");
+    SRBH_REQUIRE(srbh_bn_act_train_supported(a->B, a->C, a->HW), "srbh_bn_act_train_bwd: unsupported shape B=%d C=%d HW=%d", a->B, a->C, a->HW);
+    SRBH_REQUIRE((a->gate == nullptr) == (a->dpooled == nullptr), "srbh_bn_act_train_bwd: gate / dpooled go together");
+    BwdP p;
+    p.dy = a->dy; p.x = a->x; p.gamma = a->gamma; p.beta = a->beta; p.save_mean = a->save_mean; p.save_invstd = a->save_invstd;
+    p.gate = a->gate; p.dpooled = a->dpooled; p.drop = a->drop; p.dx = a->dx; p.dgamma = a->dgamma; p.dbeta = a->dbeta;
+    p.B = a->B; p.C = a->C; p.HW = a->HW;
+    const int RW = row_width(a->HW), cpw = RW / p.HW;
+    const size_t lds = 2 * fwd_lds(p.B, RW);
+    const dim3 grid((p.C + cpw - 1) / cpw);
+#define SRBH_BWD(A_, V_)                                                                                                                  \
+    do {                                                                                                                                  \
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)bn_act_train_bwd_kernel<A_, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_B))); \
+        hipLaunchKernelGGL((bn_act_train_bwd_kernel<A_, V_>), grid, dim3(64 * NW), lds, (hipStream_t)stream, p);                              \
+    } while (0)
+#define SRBH_BWD_V(A_)          \
+    do {                        \
+        if (RW == 256) SRBH_BWD(A_, 4); \
+        else SRBH_BWD(A_, 1);   \
+    } while (0)
+    if (a->act == 0) SRBH_BWD_V(0);
+    else if (a->act == 1) SRBH_BWD_V(1);
+    else SRBH_BWD_V(2);
+#undef SRBH_BWD_V
+#undef SRBH_BWD
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_se_train_fwd(float* y, const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
+                                 float* hidden, float* hidden_pre, float* gate, int B, int C, int SQ, int HW, void* stream) {
+    SRBH_REQUIRE(y && pooled && w1 && b1 && w2 && b2 && hidden && hidden_pre && gate, "srbh_se_train_fwd: null pointer");
+    SRBH_REQUIRE(B > 0 && C > 0 && SQ > 0 && SQ <= 65535 * 4 && HW > 0, "srbh_se_train_fwd: bad shape");
+    const long planes = (long)B * C;
+    hipLaunchKernelGGL(se_hidden_train_kernel, dim3(B, (SQ + 3) / 4), dim3(256), 0, (hipStream_t)stream, pooled, w1, b1, hidden,
+                       hidden_pre, C, SQ);
+    if (HW == 4 || HW == 16 || HW == 64 || HW == 256)
+        hipLaunchKernelGGL(se_gate_scale_train_kernel, dim3((unsigned)((planes * HW + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, y,
+                           hidden, w2, b2, gate, planes, C, SQ, HW);
+    else
+        hipLaunchKernelGGL(se_gate_scale_train_wave_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y,
+                           hidden, w2, b2, gate, planes, C, SQ, HW);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_se_train_bwd(const float* dout, const float* x, const float* gamma, const float* beta, const float* save_mean,
+                                 const float* save_invstd, const float* pooled, const float* hidden, const float* hidden_pre,
+                                 const float* gate, const float* w1, const float* w2, float* ws, float* dpooled, float* dw1, float* db1,
+                                 float* dw2, float* db2, int B, int C, int SQ, int HW, int act, void* stream) {
+    SRBH_REQUIRE(dout && x && gamma && beta && save_mean && save_invstd && pooled && hidden && hidden_pre && gate && w1 && w2 && ws &&
+                 dpooled && dw1 && db1 && dw2 && db2, "srbh_se_train_bwd: null pointer");
+    SRBH_REQUIRE(B > 0 && C > 0 && SQ > 0 && HW > 0 && act >= 0 && act <= 2, "srbh_se_train_bwd: bad arguments");
+    SRBH_REQUIRE(SQ <= SE_MAX_SQ, "srbh_se_train_bwd: SQ = %d exceeds %d", SQ, SE_MAX_SQ);
+    const int nch = se_chunks(C), CC = (C + nch - 1) / nch;
+    float* draw = ws;                       // [B][C]
+    float* dsig = ws + (size_t)B * C;       // [B][C]
+    float* dhp = dsig + (size_t)B * C;      // [B][SQ]
+    float* part = dhp + (size_t)B * SQ;     // [B][nch][SQ]
+    const long planes = (long)B * C;
+    const long waves = HW < 64 ? (planes * HW + 63) / 64 : planes;
+    const dim3 g1((unsigned)((waves + 3) / 4));
+    SRBH_REQUIRE(HW >= 64 || (HW & (HW - 1)) == 0, "srbh_se_train_bwd: planes below 64 elements must be a power of two (HW = %d)", HW);
+    if (act == 0) hipLaunchKernelGGL(se_bwd_dgate_kernel<0>, g1, dim3(256), 0, (hipStream_t)stream, dout, x, gamma, beta, save_mean, save_invstd, draw, planes, C, HW);
+    else if (act == 1) hipLaunchKernelGGL(se_bwd_dgate_kernel<1>, g1, dim3(256), 0, (hipStream_t)stream, dout, x, gamma, beta, save_mean, save_invstd, draw, planes, C, HW);
+    else hipLaunchKernelGGL(se_bwd_dgate_kernel<2>, g1, dim3(256), 0, (hipStream_t)stream, dout, x, gamma, beta, save_mean, save_invstd, draw, planes, C, HW);
+    hipLaunchKernelGGL(se_bwd_expand_kernel, dim3(B, nch), dim3(256), 0, (hipStream_t)stream, draw, gate, w2, dsig, part, C, SQ, CC);
+    hipLaunchKernelGGL(se_bwd_reduce_kernel, dim3(B, nch), dim3(256), 0, (hipStream_t)stream, part, hidden_pre, w1, dhp, dpooled, C, SQ, CC);
+    GemmTN ga, gb;                 // dw2 [C][SQ] = dsig^T hidden (+ db2);  dw1 [SQ][C] = dhp^T pooled (+ db1)
+    ga.A = dsig; ga.Bm = hidden; ga.out = dw2; ga.colsum = db2; ga.M = C; ga.N = SQ;
+    gb.A = dhp; gb.Bm = pooled; gb.out = dw1; gb.colsum = db1; gb.M = SQ; gb.N = C;
+    const int tn0 = (SQ + 31) / 32, tn1 = (C + 31) / 32;
+    const int tiles0 = ((C + 31) / 32) * tn0, tiles1 = ((SQ + 31) / 32) * tn1;
+    hipLaunchKernelGGL(se_bwd_params_kernel, dim3((unsigned)((tiles0 + tiles1 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ga, gb, B,
+                       tiles0, tn0, tn1);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" size_t srbh_se_train_bwd_ws_floats(int B, int C, int SQ) {
+    return 2 * (size_t)B * C + (size_t)B * SQ + (size_t)B * se_chunks(C) * SQ;
+}

@@ -106,10 +106,16 @@ FUSED_SE_EVAL = True       # squeeze-and-excitation of the MBConv blocks as thre
 FUSED_BN_EVAL = True      # tests switch it off to compare with the stock inference-BatchNorm path
 
 
-def bn_act(bn, x, act=None, res=None):
-    """BatchNorm2d followed by an activation.  Inference on the device: ONE libsrbh pass y = act(x * scale + shift) with the
-    running statistics folded into (scale, shift) (csrc/srbh_dwconv.hip) -- MIOpen's inference-BatchNorm kernel costs
-    ~39 us per call whatever the size, 8.6 % of the tiled-inference path.  Training / CPU: the stock ops."""
+def bn_act(bn, x, act=None, res=None, drop=None):
+    """BatchNorm2d followed by an activation [, the drop-connect factor `drop` (B,) and the skip connection `res`].  Inference on
+    the device: ONE libsrbh pass y = act(x * scale + shift) with the running statistics folded into (scale, shift)
+    (csrc/srbh_dwconv.hip) -- MIOpen's inference-BatchNorm kernel costs ~39 us per call whatever the size, 8.6 % of the
+    tiled-inference path.  Training on the device, planes below 32x32: one libsrbh launch forward and one backward
+    (mbconv_autograd.bn_act_train).  Otherwise (CPU, large planes, SyncBatchNorm): the stock ops."""
+    if x.is_cuda and bn.training:
+        from . import mbconv_autograd as MB
+        if MB.supported(bn, x):
+            return MB.bn_act_train(bn, x, act, res, drop)
     if _fused_eval_ok(bn, x):
         from . import _lib
         scale, shift = _bn_affine(bn, x.device)
@@ -138,6 +144,8 @@ def bn_act(bn, x, act=None, res=None):
         x = _swish(x)
     elif act == "relu":
         x = F.relu(x)
+    if drop is not None:
+        x = x * drop.view(-1, 1, 1, 1)
     return x if res is None else x + res
 
 
@@ -220,12 +228,12 @@ def _swish(x):
 
 def _drop_connect(x, p, training, mask=None):
     """stochastic depth (efficientnet_pytorch utils.drop_connect): x / keep * floor(keep + U[0,1)) per sample.  `mask` = this
-    block's precomputed (B,1,1,1) factor floor(keep + u) / keep (EfficientNetEncoder draws the uniforms of ALL blocks with one
+    block's precomputed (B,) factor floor(keep + u) / keep (EfficientNetEncoder draws the uniforms of ALL blocks with one
     launch per forward instead of rand + add + floor + div + mul per block: 25 blocks x 5 launches)."""
     if not training or p <= 0:
         return x
     if mask is not None:
-        return x * mask
+        return x * mask.view(-1, 1, 1, 1)
     keep = 1.0 - p
     mask = torch.floor(keep + torch.rand([x.shape[0], 1, 1, 1], dtype=x.dtype, device=x.device))
     return x / keep * mask
@@ -252,7 +260,10 @@ class MBConvBlock(nn.Module):
         if self.expand != 1:
             x = bn_act(self._bn0, self._expand_conv(x), "silu")
         x = self._depthwise_conv(x)
-        if FUSED_SE_EVAL and _fused_eval_ok(self._bn1, x) and self._se_reduce.weight.is_contiguous() and self._se_expand.weight.is_contiguous():
+        MB = _mbconv_train(self._bn1, x)
+        if MB is not None and MB.se_supported(self._se_reduce, self._se_expand):
+            x = MB.bn_swish_se_train(self._bn1, x, self._se_reduce, self._se_expand)
+        elif FUSED_SE_EVAL and _fused_eval_ok(self._bn1, x) and self._se_reduce.weight.is_contiguous() and self._se_expand.weight.is_contiguous():
             x = bn_swish_se(self._bn1, x, self._se_reduce, self._se_expand)
         else:
             x = bn_act(self._bn1, x, "silu")
@@ -262,12 +273,24 @@ class MBConvBlock(nn.Module):
         skip = self.stride == 1 and self.inp == self.out
         if skip and not (self.training and drop_connect_rate):
             return bn_act(self._bn2, self._project_conv(x), res=inputs)      # inference: BatchNorm + skip connection in one pass
-        x = bn_act(self._bn2, self._project_conv(x))
+        x = self._project_conv(x)
+        if skip and drop_mask is not None:
+            return bn_act(self._bn2, x, res=inputs, drop=drop_mask)           # training: BatchNorm, drop-connect and skip in one pass
+        x = bn_act(self._bn2, x)
         if skip:
             if drop_connect_rate:
                 x = _drop_connect(x, drop_connect_rate, self.training, drop_mask)
             x = x + inputs
         return x
+
+
+def _mbconv_train(bn, x):
+    """the libsrbh training kernels module if they take this BatchNorm input, else None"""
+    if x.is_cuda and bn.training:
+        from . import mbconv_autograd as MB
+        if MB.supported(bn, x):
+            return MB
+    return None
 
 
 class EfficientNetEncoder(nn.Module):
@@ -309,11 +332,11 @@ class EfficientNetEncoder(nn.Module):
         masks = None
         if self.training and DROP_CONNECT > 0 and x.is_cuda:
             # all blocks' stochastic-depth factors from ONE uniform draw: floor(keep_i + u) / keep_i, keep_i = 1 - rate * i / n
-            keep = 1.0 - DROP_CONNECT * torch.arange(n, dtype=x.dtype, device=x.device) / n
-            masks = torch.floor(keep + torch.rand((x.shape[0], n), dtype=x.dtype, device=x.device)) / keep
+            keep = (1.0 - DROP_CONNECT * torch.arange(n, dtype=x.dtype, device=x.device) / n).view(n, 1)
+            masks = torch.floor(keep + torch.rand((n, x.shape[0]), dtype=x.dtype, device=x.device)) / keep     # [block][sample], rows contiguous
         for idx, blk in enumerate(self._blocks):
             if masks is not None:
-                x = blk(x, DROP_CONNECT * idx / n, masks[:, idx].view(-1, 1, 1, 1))
+                x = blk(x, DROP_CONNECT * idx / n, masks[idx])
                 if idx + 1 in bounds:
                     feats.append(x)
                 continue

@@ -1,0 +1,157 @@
+"""Training-mode BatchNorm + activation and squeeze-and-excitation of the MBConv / U-Net decoder blocks on libsrbh
+(csrc/srbh_mbconv.hip), with hand-written backward.
+
+The reference runs these blocks through segmentation_models_pytorch (mymodels.py:242-258, forward at mymodels.py:276-287); in
+training each MBConv block is ~14 stock launches forward and ~30 backward around its three convolutions.  Here
+
+* ``bn_act_train(bn, x, act, res, drop)``   = F.batch_norm(training=True) -> SiLU / ReLU / none -> [* drop-connect factor] -> [+ skip]
+  in ONE launch forward and ONE backward;
+* ``bn_swish_se_train(bn, x, se_reduce, se_expand)`` = BatchNorm -> SiLU -> avg-pool -> 1x1 reduce -> SiLU -> 1x1 expand -> sigmoid ->
+  scale in THREE launches forward and FOUR backward (the plane means come out of the BatchNorm kernel; the backward of the
+  gate re-enters the BatchNorm backward kernel as a per-plane scale and offset of dy).
+
+Both update ``running_mean`` / ``running_var`` exactly as nn.BatchNorm2d does and count the batch through hrfuse.note_batch.  Shapes
+the kernels do not take (planes of 32x32 and larger, SyncBatchNorm, CPU tensors) return None from ``supported`` and the caller
+keeps the stock ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+from torch import nn
+
+from . import _lib, wcache
+
+ENABLED = os.environ.get("SRBH_ENC_TRAIN_FUSED", "1") == "1"
+_ACT = {None: 0, "silu": 1, "relu": 2}
+
+
+def supported(bn, x) -> bool:
+    if not (ENABLED and bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and type(bn) is nn.BatchNorm2d
+            and bn.affine and bn.track_running_stats and bn.momentum is not None and torch.is_grad_enabled()):
+        return False
+    B, Cc, H, W = x.shape
+    return bool(_lib.lib().srbh_bn_act_train_supported(B, Cc, H * W))
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _note(bn):
+    from . import hrfuse as _H
+    _H.note_batch(bn)
+    wcache.stamp((bn.running_mean, bn.running_var))          # written by the kernel, behind the version counters
+    if _H._NBT["depth"] == 0:
+        _H.flush_batches()
+
+
+def _fwd(x, bn, act, y, mean, invstd, pooled=None, res=None, drop=None):
+    B, Cc, H, W = x.shape
+    a = _lib.BnActArgs(x=x.data_ptr(), y=y.data_ptr(), gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(),
+                       running_mean=bn.running_mean.data_ptr(), running_var=bn.running_var.data_ptr(), save_mean=mean.data_ptr(),
+                       save_invstd=invstd.data_ptr(), pooled=_ptr(pooled), res=_ptr(res), drop=_ptr(drop), momentum=float(bn.momentum),
+                       eps=float(bn.eps), B=B, C=Cc, HW=H * W, act=act)
+    _lib.check(_lib.lib().srbh_bn_act_train_fwd(C.byref(a), _lib.stream_ptr()), "bn_act_train_fwd")
+
+
+def _bwd(dy, x, gamma, beta, mean, invstd, act, need_dx, gate=None, dpooled=None, drop=None):
+    B, Cc, H, W = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    dgamma = torch.empty_like(gamma)
+    dbeta = torch.empty_like(beta)
+    a = _lib.BnActBwdArgs(dy=dy.data_ptr(), x=x.data_ptr(), gamma=gamma.data_ptr(), beta=beta.data_ptr(), save_mean=mean.data_ptr(),
+                          save_invstd=invstd.data_ptr(), gate=_ptr(gate), dpooled=_ptr(dpooled), drop=_ptr(drop), dx=_ptr(dx),
+                          dgamma=dgamma.data_ptr(), dbeta=dbeta.data_ptr(), B=B, C=Cc, HW=H * W, act=act)
+    _lib.check(_lib.lib().srbh_bn_act_train_bwd(C.byref(a), _lib.stream_ptr()), "bn_act_train_bwd")
+    return dx, dgamma, dbeta
+
+
+class _BnActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, drop, bn, act):
+        x = x.contiguous()
+        if res is not None:
+            res = res.contiguous()
+        y = torch.empty_like(x)
+        Cc = x.shape[1]
+        mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        _fwd(x, bn, act, y, mean, invstd, None, res, drop)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, drop)
+        ctx.act = act
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd, drop = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx, dgamma, dbeta = _bwd(dy, x, gamma, beta, mean, invstd, ctx.act, ctx.needs_input_grad[0], drop=drop)
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        return dx, dgamma, dbeta, dres, None, None, None
+
+
+class _BnSwishSEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w1, b1, w2, b2, bn):
+        x = x.contiguous()
+        B, Cc, H, W = x.shape
+        SQ = w1.shape[0]
+        dev = x.device
+        y = torch.empty_like(x)
+        mean = torch.empty(Cc, dtype=torch.float32, device=dev)
+        invstd = torch.empty_like(mean)
+        small = torch.empty(2 * B * Cc + 2 * B * SQ, dtype=torch.float32, device=dev)     # pooled | gate | hidden | hidden_pre
+        pooled, gate = small[:B * Cc], small[B * Cc:2 * B * Cc]
+        hidden, hidden_pre = small[2 * B * Cc:2 * B * Cc + B * SQ], small[2 * B * Cc + B * SQ:]
+        _fwd(x, bn, 1, y, mean, invstd, pooled)
+        _lib.check(_lib.lib().srbh_se_train_fwd(y.data_ptr(), pooled.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                                hidden.data_ptr(), hidden_pre.data_ptr(), gate.data_ptr(), B, Cc, SQ, H * W,
+                                                _lib.stream_ptr()), "se_train_fwd")
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, small, w1, w2)
+        ctx.geo = (B, Cc, SQ, H * W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gamma, beta, mean, invstd, small, w1, w2 = ctx.saved_tensors
+        B, Cc, SQ, HW = ctx.geo
+        dev = x.device
+        dout = dout.contiguous()
+        pooled, gate = small[:B * Cc], small[B * Cc:2 * B * Cc]
+        hidden, hidden_pre = small[2 * B * Cc:2 * B * Cc + B * SQ], small[2 * B * Cc + B * SQ:]
+        L = _lib.lib()
+        ws = torch.empty(L.srbh_se_train_bwd_ws_floats(B, Cc, SQ) + B * Cc, dtype=torch.float32, device=dev)
+        dpooled = ws[-B * Cc:]
+        dw1 = torch.empty_like(w1)
+        dw2 = torch.empty_like(w2)
+        db1 = torch.empty(SQ, dtype=torch.float32, device=dev)
+        db2 = torch.empty(Cc, dtype=torch.float32, device=dev)
+        _lib.check(L.srbh_se_train_bwd(dout.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                       pooled.data_ptr(), hidden.data_ptr(), hidden_pre.data_ptr(), gate.data_ptr(), w1.data_ptr(),
+                                       w2.data_ptr(), ws.data_ptr(), dpooled.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
+                                       db2.data_ptr(), B, Cc, SQ, HW, 1, _lib.stream_ptr()), "se_train_bwd")
+        dx, dgamma, dbeta = _bwd(dout, x, gamma, beta, mean, invstd, 1, ctx.needs_input_grad[0], gate=gate, dpooled=dpooled)
+        return dx, dgamma, dbeta, dw1, db1, dw2, db2, None
+
+
+def bn_act_train(bn, x, act=None, res=None, drop=None):
+    """y = act(batch_norm(x)) [* drop[b]] [+ res]; `drop`: contiguous (B,) factors or None"""
+    y = _BnActFn.apply(x, bn.weight, bn.bias, res, drop, bn, _ACT[act])
+    _note(bn)
+    return y
+
+
+def se_supported(se_reduce, se_expand) -> bool:
+    return (se_reduce.weight.is_contiguous() and se_expand.weight.is_contiguous() and se_reduce.bias is not None
+            and se_expand.bias is not None and se_reduce.weight.shape[0] <= 256)
+
+
+def bn_swish_se_train(bn, x, se_reduce, se_expand):
+    """sigmoid(se_expand(swish(se_reduce(avg_pool(s))))) * s with s = swish(batch_norm(x)) (efficientnet_pytorch MBConvBlock.forward)"""
+    y = _BnSwishSEFn.apply(x, bn.weight, bn.bias, se_reduce.weight, se_reduce.bias, se_expand.weight, se_expand.bias, bn)
+    _note(bn)
+    return y

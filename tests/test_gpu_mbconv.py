@@ -1,0 +1,152 @@
+"""Training-mode BatchNorm + activation and squeeze-and-excitation kernels (csrc/srbh_mbconv.hip) through the C ABI (autograd Functions
+in mbconv_autograd.py) against the stock fp32 ops of the same computation -- what efficientnet_pytorch's MBConvBlock.forward and smp's
+Conv2dReLU do, as the reference runs them at mymodels.py:276-287.  Tolerance 2e-5 relative against the stock ops evaluated in fp64
+(fp32 kernels, different summation order), and the stock fp32 ops themselves must be no closer than ~the same order."""
+import copy
+
+import pytest, torch
+import torch.nn.functional as F
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 2e-5
+
+
+def rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _bn(C, g, dtype=torch.float32):
+    bn = nn.BatchNorm2d(C, momentum=0.01, eps=1e-3)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    return bn.to(DEV).to(dtype).train()
+
+
+def _stock(bn, x, act, res, drop):
+    y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)
+    if act == "silu":
+        y = F.silu(y)
+    elif act == "relu":
+        y = F.relu(y)
+    if drop is not None:
+        y = y * drop.view(-1, 1, 1, 1)
+    return y if res is None else y + res
+
+
+@pytest.mark.parametrize("B,C,H", [(6, 37, 2), (64, 20, 4), (5, 9, 8), (3, 5, 16), (2, 130, 2), (7, 3, 1), (64, 16, 8)])
+@pytest.mark.parametrize("act,with_res,with_drop", [("silu", False, False), ("relu", False, False), (None, True, True), (None, True, False),
+                                                    (None, False, False)])
+def test_bn_act_train_matches_stock_ops(B, C, H, act, with_res, with_drop):
+    from srbh_amd import mbconv_autograd as MB
+    g = torch.Generator().manual_seed(B * 1000 + C * 10 + H)
+    bn = _bn(C, g)
+    ref = copy.deepcopy(bn).double()
+    x0 = (torch.randn((B, C, H, H), generator=g) * 1.5 + 0.4).to(DEV)
+    res0 = torch.randn((B, C, H, H), generator=g).to(DEV) if with_res else None
+    drop = (torch.floor(0.8 + torch.rand(B, generator=g)) / 0.8).to(DEV) if with_drop else None
+    x = x0.clone().requires_grad_(True)
+    res = res0.clone().requires_grad_(True) if with_res else None
+    assert MB.supported(bn, x)
+    y = MB.bn_act_train(bn, x, act, res, drop)
+    xr = x0.double().requires_grad_(True)
+    rr = res0.double().requires_grad_(True) if with_res else None
+    yr = _stock(ref, xr, act, rr, drop.double() if with_drop else None)
+    assert rel(y, yr) <= TOL
+    assert rel(bn.running_mean, ref.running_mean) <= TOL and rel(bn.running_var, ref.running_var) <= TOL
+    gy = torch.randn(y.shape, generator=g).to(DEV)
+    y.backward(gy)
+    yr.backward(gy.double())
+    assert rel(x.grad, xr.grad) <= 5 * TOL               # (the input gradient subtracts two channel means: cancellation)
+    assert rel(bn.weight.grad, ref.weight.grad) <= TOL
+    assert rel(bn.bias.grad, ref.bias.grad) <= TOL
+    if with_res:
+        assert torch.equal(res.grad, gy)
+
+
+@pytest.mark.parametrize("B,C,SQ,H", [(6, 144, 6, 16), (64, 40, 10, 8), (5, 672, 28, 4), (3, 2688, 112, 2), (2, 19, 3, 2)])
+def test_bn_swish_se_train_matches_stock_ops(B, C, SQ, H):
+    from srbh_amd import mbconv_autograd as MB
+    g = torch.Generator().manual_seed(B * 1000 + C + H)
+    bn = _bn(C, g)
+    red = nn.Conv2d(C, SQ, 1).to(DEV)
+    exp = nn.Conv2d(SQ, C, 1).to(DEV)
+    with torch.no_grad():
+        red.weight.mul_(3.0)
+        exp.weight.mul_(3.0)
+    ref_bn, ref_red, ref_exp = copy.deepcopy(bn).double(), copy.deepcopy(red).double(), copy.deepcopy(exp).double()
+    x0 = (torch.randn((B, C, H, H), generator=g) * 1.5 + 0.4).to(DEV)
+    x = x0.clone().requires_grad_(True)
+    assert MB.supported(bn, x) and MB.se_supported(red, exp)
+    y = MB.bn_swish_se_train(bn, x, red, exp)
+    xr = x0.double().requires_grad_(True)
+    s = F.silu(F.batch_norm(xr, ref_bn.running_mean, ref_bn.running_var, ref_bn.weight, ref_bn.bias, True, ref_bn.momentum, ref_bn.eps))
+    yr = torch.sigmoid(ref_exp(F.silu(ref_red(F.adaptive_avg_pool2d(s, 1))))) * s
+    assert rel(y, yr) <= TOL
+    assert rel(bn.running_var, ref_bn.running_var) <= TOL
+    gy = torch.randn(y.shape, generator=g).to(DEV)
+    y.backward(gy)
+    yr.backward(gy.double())
+    assert rel(x.grad, xr.grad) <= 5 * TOL
+    for a, b in ((bn.weight, ref_bn.weight), (bn.bias, ref_bn.bias), (red.weight, ref_red.weight), (red.bias, ref_red.bias),
+                 (exp.weight, ref_exp.weight), (exp.bias, ref_exp.bias)):
+        assert rel(a.grad, b.grad) <= 2 * TOL
+
+
+def test_unsupported_shapes_keep_the_stock_ops_and_eval_is_untouched():
+    from srbh_amd import mbconv_autograd as MB
+    g = torch.Generator().manual_seed(1)
+    bn = _bn(8, g)
+    assert not MB.supported(bn, torch.zeros(2, 8, 32, 32, device=DEV))        # 32x32 planes: stock ops
+    assert not MB.supported(bn, torch.zeros(2, 8, 6, 6, device=DEV))          # 36-element planes
+    assert not MB.supported(bn.eval(), torch.zeros(2, 8, 4, 4, device=DEV))
+    assert not MB.supported(bn.train(), torch.zeros(2, 8, 4, 4))              # CPU tensor
+    with torch.no_grad():
+        assert not MB.supported(bn, torch.zeros(2, 8, 4, 4, device=DEV))
+
+
+def test_encoder_and_decoder_training_step_agrees_with_the_stock_path(monkeypatch):
+    """whole EfficientNet-B4 encoder + U-Net decoder, training mode, kernels on vs off: outputs, every gradient, every running statistic"""
+    from srbh_amd import encoders, mbconv_autograd as MB
+    torch.manual_seed(11)
+    enc = encoders.get_encoder("efficientnet-b4", in_channels=8, depth=5, weights=None).to(DEV).train()
+    dec = encoders.UnetDecoder(enc.out_channels, (256, 128, 64, 32, 16), n_blocks=5).to(DEV).train()
+    enc2, dec2 = copy.deepcopy(enc), copy.deepcopy(dec)
+    x = torch.randn(4, 8, 64, 64, device=DEV)
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: torch.full(a[0], 0.5, device=k.get("device"), dtype=k.get("dtype")))
+    calls = {"n": 0}
+    real = MB._fwd
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(MB, "_fwd", counting)
+    out = dec(*enc(x))
+    out.square().mean().backward()
+    assert calls["n"] >= 90                      # 28 of 32 blocks x 3 BatchNorms + the decoder's small planes
+    monkeypatch.setattr(MB, "ENABLED", False)
+    out2 = dec2(*enc2(x))
+    out2.square().mean().backward()
+    assert calls["n"] >= 90 and rel(out, out2) <= 2e-4
+    big = max(float(p.grad.norm()) for p in enc2.parameters() if p.grad is not None)
+    for (k, a), (_, b) in zip(list(enc.named_parameters()) + list(dec.named_parameters()),
+                              list(enc2.named_parameters()) + list(dec2.named_parameters())):
+        if b.grad is None:
+            assert a.grad is None, k
+            continue
+        # 32 blocks of training-mode BatchNorm over 4 x (2x2 .. 16x16) samples amplify the 1e-6 differences between two fp32 evaluation
+        # orders (the same bound test_gpu_model.py applies between the stock GPU and CPU ops); the tight per-kernel bounds are above
+        if float(b.grad.norm()) > 1e-3 * big:    # (gradients that are ~0 by construction carry only noise)
+            assert rel(a.grad, b.grad) <= 5e-2, (k, rel(a.grad, b.grad))
+    for (k, a), (_, b) in zip(list(enc.named_buffers()) + list(dec.named_buffers()), list(enc2.named_buffers()) + list(dec2.named_buffers())):
+        if a.dtype.is_floating_point:
+            # (running statistics of the deep 2x2 stages: same amplification; a mean that is 0 by construction -- the BatchNorm of a
+            #  convolution of a BatchNorm output -- is 1e-10 of pure rounding noise, hence the absolute term)
+            assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-6, (k, rel(a, b))
+        else:
+            assert torch.equal(a, b), k

@@ -25,8 +25,8 @@ bycalls = len(sys.argv) > 4
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0 if bycalls else 1])[:top]:
     print("%7.3f ms/step %5.1f %% %6d calls/step  %s" % (v[1] / steps / 1e6, 100.0 * v[1] / tot, v[0] // steps, k))
 GROUPS = (("RRDBNet (trunk, first/tail convs)", ("ptrunk", "ptail", "conv_first", "rrdb", "poison", "upconv", "tail_")),
+          ("encoder / decoders: libsrbh depthwise + SE + training BatchNorm", ("dw_fwd", "dw_bwd", "dw_reduce", "se_hidden", "se_gate", "se_bwd", "affine_act", "bn_act_train")),
           ("head (libsrbh hconv / hwgrad / BN / elementwise)", ("hconv", "hwgrad", "hpack", "bn_", "relu_mask", "nchw_to_nhwc", "nhwc_to_nchw", "ps2_", "add_inplace", "aggregate", "chan_sum", "bias_grad")),
-          ("encoder / decoders: libsrbh depthwise + SE", ("dw_fwd", "dw_bwd", "dw_reduce", "se_hidden", "se_gate", "affine_act")),
           ("optimizer (multi_tensor_apply)", ("multi_tensor_apply",)),
           ("losses (libsrbh)", ("wmse_", "cedice_")))
 gs = collections.OrderedDict((g[0], [0, 0]) for g in GROUPS)
