@@ -366,8 +366,8 @@ int srbh_se_gate_scale(float* y, const float* hidden, const float* w2, const flo
 /* ---- TRAINING-mode BatchNorm + activation and squeeze-and-excitation of the MBConv / U-Net decoder blocks (csrc/srbh_mbconv.hip) ----
  * Replaces, for the encoder / decoders the reference builds at mymodels.py:242-258 and runs at mymodels.py:276-287, the stock
  * F.batch_norm(training=True) + SiLU/ReLU (+ adaptive_avg_pool2d, + drop-connect multiply and skip add) launches and their autograd
- * backward.  fp32 NCHW; planes of HW = 1, 4, 16, 64 or 256 elements with B * max(64, HW) floats within LDS
- * (srbh_bn_act_train_supported; larger planes stay on the stock ops).
+ * backward.  fp32 NCHW; planes of HW = 1, 4, 16, 64 or 256 elements with B * max(64, HW) floats within LDS, or large planes
+ * (srbh_bn_act_train_supported; anything else stays on the stock ops).
  *   forward :  mean / biased variance over (B, HW) in two passes, running statistics updated as nn.BatchNorm2d does (momentum, unbiased
  *              variance), y = act(gamma (x - mean) invstd + beta) [* drop[b]] [+ res],  pooled[b][c] = mean over the plane of y
  *   backward:  dy_eff = dy [* gate[b][c] + dpooled[b][c] / HW] [* drop[b]];  dz = dy_eff act'(z);  dbeta = sum dz;  dgamma = sum dz xhat;
@@ -387,6 +387,7 @@ typedef struct srbh_bnact_args {
     float momentum, eps;
     int B, C, HW;
     int act;                   /* 0 none | 1 SiLU | 2 ReLU */
+    void* ws;                  /* srbh_bn_act_train_ws_bytes(B, C, HW) bytes of scratch (large planes only; may be NULL when that is 0) */
 } srbh_bnact_args;
 typedef struct srbh_bnact_bwd_args {
     const float* dy;           /* [B][C][HW] gradient of the output */
@@ -403,8 +404,12 @@ typedef struct srbh_bnact_bwd_args {
     float* dbeta;              /* [C] */
     int B, C, HW;
     int act;
+    void* ws;                  /* as in the forward */
 } srbh_bnact_bwd_args;
+/* 0 = not taken; 1 = small planes (one launch each way); 2 = large planes, HW a multiple of 4 from 256 up (two launches each way:
+ * per-(channel, image subset) partial sums in double in fixed slots of `ws`, then one workgroup per plane) */
 int srbh_bn_act_train_supported(int B, int C, int HW);
+size_t srbh_bn_act_train_ws_bytes(int B, int C, int HW);
 int srbh_bn_act_train_fwd(const srbh_bnact_args* a, void* stream);
 int srbh_bn_act_train_bwd(const srbh_bnact_bwd_args* a, void* stream);
 /* squeeze-and-excitation in training (efficientnet_pytorch MBConvBlock.forward: x_squeezed = avg_pool(x); se_expand(swish(se_reduce(.)));
@@ -420,6 +425,12 @@ int srbh_se_train_bwd(const float* dout, const float* x, const float* gamma, con
                       const float* w1, const float* w2, float* ws, float* dpooled, float* dw1, float* db1, float* dw2, float* db2, int B,
                       int C, int SQ, int HW, int act, void* stream);
 size_t srbh_se_train_bwd_ws_floats(int B, int C, int SQ);
+
+/* U-Net decoder block entry (smp DecoderBlock.forward, reached through mymodels.py:279,287): out [B][Cx+Cs][2H][2W] =
+ * cat(nearest-x2(x [B][Cx][H][W]), skip [B][Cs][2H][2W]) in one launch (skip may be NULL with Cs = 0); backward: dx = 2x2 sums of the first
+ * Cx channels of dout, dskip = the remaining channels as a contiguous tensor (either output may be NULL).  fp32 NCHW, W even. */
+int srbh_up2_cat_fwd(const float* x, const float* skip, float* out, int B, int Cx, int Cs, int H, int W, void* stream);
+int srbh_up2_cat_bwd(const float* dout, float* dx, float* dskip, int B, int Cx, int Cs, int H, int W, void* stream);
 
 /* ---- inference epilogue: quantise + integer mosaic (predict_realesanet_feature_globe.py:172-204) ------------------
  * accumulate: height [B][th][tw] fp32 (model output, C=1), build logits NHWC [B][th][tw][C] fp32, pos [B][4] int32

@@ -103,6 +103,7 @@ class BnActArgs(C.Structure):
         ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p),
         ("pooled", C.c_void_p), ("res", C.c_void_p), ("drop", C.c_void_p),
         ("momentum", C.c_float), ("eps", C.c_float), ("B", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("act", C.c_int),
+        ("ws", C.c_void_p),
     ]
 
 
@@ -111,7 +112,7 @@ class BnActBwdArgs(C.Structure):
         ("dy", C.c_void_p), ("x", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
         ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p), ("gate", C.c_void_p), ("dpooled", C.c_void_p), ("drop", C.c_void_p),
         ("dx", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
-        ("B", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("act", C.c_int),
+        ("B", C.c_int), ("C", C.c_int), ("HW", C.c_int), ("act", C.c_int), ("ws", C.c_void_p),
     ]
 
 
@@ -182,11 +183,14 @@ SIGNATURES = {
     "srbh_se_hidden": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srbh_se_gate_scale": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_bn_act_train_supported": (_i, [_i, _i, _i]),
+    "srbh_bn_act_train_ws_bytes": (_sz, [_i, _i, _i]),
     "srbh_bn_act_train_fwd": (_i, [C.POINTER(BnActArgs), _vp]),
     "srbh_bn_act_train_bwd": (_i, [C.POINTER(BnActBwdArgs), _vp]),
     "srbh_se_train_fwd": (_i, [_vp] * 9 + [_i] * 4 + [_vp]),
     "srbh_se_train_bwd": (_i, [_vp] * 18 + [_i] * 5 + [_vp]),
     "srbh_se_train_bwd_ws_floats": (_sz, [_i, _i, _i]),
+    "srbh_up2_cat_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "srbh_up2_cat_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "srbh_dwconv_fwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "srbh_dwconv_bwd_data": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "srbh_dwconv_bwd_weight_splits": (_i, [_i, _i]),

@@ -497,6 +497,218 @@ __global__ __launch_bounds__(256) void se_gate_scale_train_wave_kernel(float* __
     for (int i = lane; i < hw; i += 64) yp[i] *= g;
 }
 
+// ---- U-Net decoder block entry (smp DecoderBlock.forward: x = F.interpolate(x, scale_factor=2, mode="nearest"); x = torch.cat([x, skip], 1)),
+// one launch forward and one backward instead of upsample + cat and their autograd (ATen's nearest backward alone ran 56 us per call).
+// A thread owns 4 consecutive output columns: two source pixels of x, or a float4 of skip.
+__global__ __launch_bounds__(256) void up2_cat_fwd_kernel(const float* __restrict__ x, const float* __restrict__ skip,
+                                                         float* __restrict__ out, long total4, int Cx, int Cs, int H, int W) {
+    const int W4 = (2 * W) >> 2, OH = 2 * H, Ct = Cx + Cs;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+        const int xq = (int)(idx % W4);
+        long r = idx / W4;
+        const int y = (int)(r % OH);
+        r /= OH;
+        const int c = (int)(r % Ct);
+        const long b = r / Ct;
+        floatx4 v;
+        if (c < Cx) {
+            const float* s = x + ((b * Cx + c) * H + (y >> 1)) * W + 2 * xq;
+            const float s0 = s[0], s1 = s[1];
+            v = floatx4{s0, s0, s1, s1};
+        } else {
+            v = *(const floatx4*)(skip + ((b * Cs + (c - Cx)) * OH + y) * (long)(2 * W) + 4 * xq);
+        }
+        *(floatx4*)(out + 4 * idx) = v;
+    }
+}
+
+// backward: dx[b][c][y][x] = the sum of its 2x2 output pixels (a thread makes two dx columns from two float4 of dout),
+// dskip = the skip slice of dout as a contiguous tensor
+__global__ __launch_bounds__(256) void up2_cat_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, float* __restrict__ dskip,
+                                                         long n_x2, long n_s4, int Cx, int Cs, int H, int W) {
+    const int W2 = W >> 1, OH = 2 * H, OW = 2 * W, Ct = Cx + Cs, W4 = OW >> 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n_x2 + n_s4; idx += (long)gridDim.x * 256) {
+        if (idx < n_x2) {
+            const int xp = (int)(idx % W2);
+            long r = idx / W2;
+            const int y = (int)(r % H);
+            r /= H;
+            const int c = (int)(r % Cx);
+            const long b = r / Cx;
+            const float* d = dout + ((b * Ct + c) * OH + 2 * y) * (long)OW + 4 * xp;
+            const floatx4 a = *(const floatx4*)d, e = *(const floatx4*)(d + OW);
+            float* o = dx + ((b * Cx + c) * H + y) * (long)W + 2 * xp;
+            o[0] = (a[0] + a[1]) + (e[0] + e[1]);
+            o[1] = (a[2] + a[3]) + (e[2] + e[3]);
+        } else {
+            const long i = idx - n_x2;
+            const int xq = (int)(i % W4);
+            long r = i / W4;
+            const int y = (int)(r % OH);
+            r /= OH;
+            const int c = (int)(r % Cs);
+            const long b = r / Cs;
+            *(floatx4*)(dskip + 4 * i) = *(const floatx4*)(dout + ((b * Ct + Cx + c) * OH + y) * (long)OW + 4 * xq);
+        }
+    }
+}
+
+// ---- the same two operations for LARGE planes (32x32 and up: the stem, the first three encoder blocks, the last two decoder levels):
+// a channel no longer fits one workgroup's LDS, so each direction is two launches -- per-(channel, image subset) partial sums in
+// double (fixed slots, no atomics: deterministic and nothing to zero), then one workgroup per (b, c) plane that folds the S partials
+// and applies.  Traffic: forward x twice + y once; backward x and dy twice + dx once (dz is recomputed instead of stored).
+__device__ __forceinline__ double wg_sum_double(double v, double* red, int t) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((t & 63) == 0) red[t >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void bn_large_stats_kernel(const float* __restrict__ x, double* __restrict__ part, int B, int C, int HW, int S) {
+    __shared__ double red[4];
+    const int c = blockIdx.x, sp = blockIdx.y, t = threadIdx.x, n4 = HW >> 2;
+    float s = 0.f, q = 0.f;
+#pragma unroll 4
+    for (int b = sp; b < B; b += S) {
+        const floatx4* pl = (const floatx4*)(x + ((long)b * C + c) * HW);
+        for (int i = t; i < n4; i += 256) {
+            const floatx4 v = pl[i];
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+            q = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], q))));
+        }
+    }
+    const double ds = wg_sum_double((double)s, red, t), dq = wg_sum_double((double)q, red, t);
+    if (t == 0) {
+        part[((long)c * S + sp) * 2] = ds;
+        part[((long)c * S + sp) * 2 + 1] = dq;
+    }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_large_apply_kernel(const FwdP p, const double* __restrict__ part, int S) {
+    __shared__ double red[4];
+    const long pl = blockIdx.x;
+    const int c = (int)(pl % p.C), t = threadIdx.x, n4 = p.HW >> 2;
+    const long b = pl / p.C;
+    double ds = 0.0, dq = 0.0;
+    for (int k = 0; k < S; ++k) {
+        ds += part[((long)c * S + k) * 2];
+        dq += part[((long)c * S + k) * 2 + 1];
+    }
+    const double n = (double)p.B * (double)p.HW, dmean = ds / n;
+    double dvar = dq / n - dmean * dmean;
+    dvar = dvar > 0.0 ? dvar : 0.0;
+    const float mean = (float)dmean, var = (float)dvar, invstd = 1.f / sqrtf(var + p.eps);
+    if (b == 0 && t == 0) {
+        p.save_mean[c] = mean;
+        p.save_invstd[c] = invstd;
+        if (p.running_mean) {
+            p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
+            p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)(n > 1.0 ? dvar * n / (n - 1.0) : dvar);
+        }
+    }
+    const float scale = p.gamma[c] * invstd, shift = p.beta[c] - mean * scale, dr = p.drop ? p.drop[b] : 1.f;
+    const floatx4* xp = (const floatx4*)(p.x + pl * p.HW);
+    const floatx4* rp = p.res ? (const floatx4*)(p.res + pl * p.HW) : nullptr;
+    floatx4* yp = (floatx4*)(p.y + pl * p.HW);
+    float w = 0.f;
+    for (int i = t; i < n4; i += 256) {
+        floatx4 v = xp[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = act_f<ACT>(fmaf(v[k], scale, shift)) * dr;
+        if (rp) v += rp[i];
+        yp[i] = v;
+        w += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    if (p.pooled) {
+        const double tot = wg_sum_double((double)w, red, t);
+        if (t == 0) p.pooled[pl] = (float)(tot / (double)p.HW);
+    }
+}
+
+template <int ACT>
+__device__ __forceinline__ floatx4 large_dz(const floatx4 xv, const floatx4 dv, float mean, float invstd, float g, float be, float gt, float dpo,
+                                            floatx4& xh) {
+    floatx4 dz;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        xh[k] = (xv[k] - mean) * invstd;
+        dz[k] = fmaf(dv[k], gt, dpo) * act_grad<ACT>(fmaf(xh[k], g, be));
+    }
+    return dz;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_large_bwd_stats_kernel(const BwdP p, double* __restrict__ part, int S) {
+    __shared__ double red[4];
+    const int c = blockIdx.x, sp = blockIdx.y, t = threadIdx.x, n4 = p.HW >> 2;
+    const float mean = p.save_mean[c], invstd = p.save_invstd[c], g = p.gamma[c], be = p.beta[c], invHW = 1.f / (float)p.HW;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 2
+    for (int b = sp; b < p.B; b += S) {
+        const long pl = (long)b * p.C + c;
+        const float dr = p.drop ? p.drop[b] : 1.f;
+        const float gt = (p.gate ? p.gate[pl] : 1.f) * dr, dpo = (p.gate ? p.dpooled[pl] * invHW : 0.f) * dr;
+        const floatx4* xp = (const floatx4*)(p.x + pl * p.HW);
+        const floatx4* dp = (const floatx4*)(p.dy + pl * p.HW);
+        for (int i = t; i < n4; i += 256) {
+            floatx4 xh;
+            const floatx4 dz = large_dz<ACT>(xp[i], dp[i], mean, invstd, g, be, gt, dpo, xh);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s1 += dz[k];
+                s2 = fmaf(dz[k], xh[k], s2);
+            }
+        }
+    }
+    const double d1 = wg_sum_double((double)s1, red, t), d2 = wg_sum_double((double)s2, red, t);
+    if (t == 0) {
+        part[((long)c * S + sp) * 2] = d1;
+        part[((long)c * S + sp) * 2 + 1] = d2;
+    }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_large_bwd_apply_kernel(const BwdP p, const double* __restrict__ part, int S) {
+    const long pl = blockIdx.x;
+    const int c = (int)(pl % p.C), t = threadIdx.x, n4 = p.HW >> 2;
+    const long b = pl / p.C;
+    double d1 = 0.0, d2 = 0.0;
+    for (int k = 0; k < S; ++k) {
+        d1 += part[((long)c * S + k) * 2];
+        d2 += part[((long)c * S + k) * 2 + 1];
+    }
+    if (b == 0 && t == 0) {
+        p.dbeta[c] = (float)d1;
+        p.dgamma[c] = (float)d2;
+    }
+    if (!p.dx) return;
+    const double n = (double)p.B * (double)p.HW;
+    const float k1 = (float)(d1 / n), k2 = (float)(d2 / n);
+    const float mean = p.save_mean[c], invstd = p.save_invstd[c], g = p.gamma[c], be = p.beta[c], gi = g * invstd, invHW = 1.f / (float)p.HW;
+    const float dr = p.drop ? p.drop[b] : 1.f;
+    const float gt = (p.gate ? p.gate[pl] : 1.f) * dr, dpo = (p.gate ? p.dpooled[pl] * invHW : 0.f) * dr;
+    const floatx4* xp = (const floatx4*)(p.x + pl * p.HW);
+    const floatx4* dp = (const floatx4*)(p.dy + pl * p.HW);
+    floatx4* op = (floatx4*)(p.dx + pl * p.HW);
+    for (int i = t; i < n4; i += 256) {
+        floatx4 xh;
+        floatx4 dz = large_dz<ACT>(xp[i], dp[i], mean, invstd, g, be, gt, dpo, xh);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dz[k] = gi * (dz[k] - k1 - xh[k] * k2);
+        op[i] = dz;
+    }
+}
+
+int large_splits(int B, int C) {
+    int S = 1024 / (C > 0 ? C : 1);
+    S = S < 1 ? 1 : S;
+    S = S > 32 ? 32 : S;
+    return S > B ? B : S;
+}
+bool large_ok(int B, int C, int HW) { return B > 0 && C > 0 && HW >= 256 && (HW & 3) == 0; }
+
 int se_chunks(int C) {                      // channel chunks of the squeeze-excite backward: <= 1024 channels each (LDS), ~16 at most
     int n = (C + 127) / 128;
     return n < 1 ? 1 : (n > 16 ? ((C + 1023) / 1024 > 16 ? (C + 1023) / 1024 : 16) : n);
@@ -507,18 +719,35 @@ size_t fwd_lds(int B, int RW) { return (size_t)B * RW * 4; }
 
 extern "C" int srbh_bn_act_train_supported(int B, int C, int HW) {
     const int RW = row_width(HW);
-    return RW != 0 && B > 0 && C > 0 && 2 * fwd_lds(B, RW) <= (size_t)MAX_LDS_B;       // (the backward keeps dz and xhat)
+    if (RW != 0 && B > 0 && C > 0 && 2 * fwd_lds(B, RW) <= (size_t)MAX_LDS_B) return 1;       // (the backward keeps dz and xhat)
+    return large_ok(B, C, HW) ? 2 : 0;
+}
+
+extern "C" size_t srbh_bn_act_train_ws_bytes(int B, int C, int HW) {
+    return srbh_bn_act_train_supported(B, C, HW) == 2 ? (size_t)C * large_splits(B, C) * 2 * sizeof(double) : 0;
 }
 
 extern "C" int srbh_bn_act_train_fwd(const srbh_bnact_args* a, void* stream) {
     SRBH_REQUIRE(a && a->x && a->y && a->gamma && a->beta && a->save_mean && a->save_invstd, "srbh_bn_act_train_fwd: null pointer");
     SRBH_REQUIRE(a->act >= 0 && a->act <= 2, "srbh_bn_act_train_fwd: act must be 0 (none), 1 (SiLU) or 2 (ReLU)");
-    SRBH_REQUIRE(srbh_bn_act_train_supported(a->B, a->C, a->HW), "srbh_bn_act_train_fwd: unsupported shape B=%d C=%d HW=%d (planes of 1, 4, 16, 64 or 256 floats, B * row within LDS)", a->B, a->C, a->HW);
+    SRBH_REQUIRE(srbh_bn_act_train_supported(a->B, a->C, a->HW), "srbh_bn_act_train_fwd: unsupported shape B=%d C=%d HW=%d (planes of 1, 4, 16, 64 or 256 floats with B * row within LDS, or a multiple of 4 from 256 up)", a->B, a->C, a->HW);
     SRBH_REQUIRE((a->running_mean == nullptr) == (a->running_var == nullptr), "srbh_bn_act_train_fwd: running_mean / running_var go together");
     FwdP p;
     p.x = a->x; p.y = a->y; p.gamma = a->gamma; p.beta = a->beta; p.running_mean = a->running_mean; p.running_var = a->running_var;
     p.save_mean = a->save_mean; p.save_invstd = a->save_invstd; p.pooled = a->pooled; p.res = a->res; p.drop = a->drop;
     p.momentum = a->momentum; p.eps = a->eps; p.B = a->B; p.C = a->C; p.HW = a->HW;
+    if (srbh_bn_act_train_supported(a->B, a->C, a->HW) == 2) {
+        SRBH_REQUIRE(a->ws, "srbh_bn_act_train_fwd: planes of %d elements need the workspace (srbh_bn_act_train_ws_bytes)", a->HW);
+        const int S = large_splits(p.B, p.C);
+        double* part = (double*)a->ws;
+        hipLaunchKernelGGL(bn_large_stats_kernel, dim3(p.C, S), dim3(256), 0, (hipStream_t)stream, p.x, part, p.B, p.C, p.HW, S);
+        const dim3 gp((unsigned)((long)p.B * p.C));
+        if (a->act == 0) hipLaunchKernelGGL(bn_large_apply_kernel<0>, gp, dim3(256), 0, (hipStream_t)stream, p, part, S);
+        else if (a->act == 1) hipLaunchKernelGGL(bn_large_apply_kernel<1>, gp, dim3(256), 0, (hipStream_t)stream, p, part, S);
+        else hipLaunchKernelGGL(bn_large_apply_kernel<2>, gp, dim3(256), 0, (hipStream_t)stream, p, part, S);
+        SRBH_HIP(hipGetLastError());
+        return SRBH_OK;
+    }
     const int RW = row_width(a->HW), cpw = RW / p.HW;
     const size_t lds = fwd_lds(p.B, RW);
     const dim3 grid((p.C + cpw - 1) / cpw);
@@ -551,6 +780,24 @@ extern "C" int srbh_bn_act_train_bwd(const srbh_bnact_bwd_args* a, void* stream)
     p.dy = a->dy; p.x = a->x; p.gamma = a->gamma; p.beta = a->beta; p.save_mean = a->save_mean; p.save_invstd = a->save_invstd;
     p.gate = a->gate; p.dpooled = a->dpooled; p.drop = a->drop; p.dx = a->dx; p.dgamma = a->dgamma; p.dbeta = a->dbeta;
     p.B = a->B; p.C = a->C; p.HW = a->HW;
+    if (srbh_bn_act_train_supported(a->B, a->C, a->HW) == 2) {
+        SRBH_REQUIRE(a->ws, "srbh_bn_act_train_bwd: planes of %d elements need the workspace (srbh_bn_act_train_ws_bytes)", a->HW);
+        const int S = large_splits(p.B, p.C);
+        double* part = (double*)a->ws;
+        const dim3 gs(p.C, S), gp((unsigned)((long)p.B * p.C));
+        if (a->act == 0) {
+            hipLaunchKernelGGL(bn_large_bwd_stats_kernel<0>, gs, dim3(256), 0, (hipStream_t)stream, p, part, S);
+            hipLaunchKernelGGL(bn_large_bwd_apply_kernel<0>, gp, dim3(256), 0, (hipStream_t)stream, p, part, S);
+        } else if (a->act == 1) {
+            hipLaunchKernelGGL(bn_large_bwd_stats_kernel<1>, gs, dim3(256), 0, (hipStream_t)stream, p, part, S);
+            hipLaunchKernelGGL(bn_large_bwd_apply_kernel<1>, gp, dim3(256), 0, (hipStream_t)stream, p, part, S);
+        } else {
+            hipLaunchKernelGGL(bn_large_bwd_stats_kernel<2>, gs, dim3(256), 0, (hipStream_t)stream, p, part, S);
+            hipLaunchKernelGGL(bn_large_bwd_apply_kernel<2>, gp, dim3(256), 0, (hipStream_t)stream, p, part, S);
+        }
+        SRBH_HIP(hipGetLastError());
+        return SRBH_OK;
+    }
     const int RW = row_width(a->HW), cpw = RW / p.HW;
     const size_t lds = 2 * fwd_lds(p.B, RW);
     const dim3 grid((p.C + cpw - 1) / cpw);
@@ -625,4 +872,27 @@ extern "C" int srbh_se_train_bwd(const float* dout, const float* x, const float*
 
 extern "C" size_t srbh_se_train_bwd_ws_floats(int B, int C, int SQ) {
     return 2 * (size_t)B * C + (size_t)B * SQ + (size_t)B * se_chunks(C) * SQ;
+}
+
+extern "C" int srbh_up2_cat_fwd(const float* x, const float* skip, float* out, int B, int Cx, int Cs, int H, int W, void* stream) {
+    SRBH_REQUIRE(x && out && (skip || Cs == 0), "srbh_up2_cat_fwd: null pointer");
+    SRBH_REQUIRE(B > 0 && Cx > 0 && Cs >= 0 && H > 0 && W > 0 && (W & 1) == 0, "srbh_up2_cat_fwd: bad shape (W must be even)");
+    const long total4 = (long)B * (Cx + Cs) * 2 * H * (2 * W / 4);
+    const long blocks = (total4 + 255) / 256;
+    hipLaunchKernelGGL(up2_cat_fwd_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, x, skip, out,
+                       total4, Cx, Cs, H, W);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_up2_cat_bwd(const float* dout, float* dx, float* dskip, int B, int Cx, int Cs, int H, int W, void* stream) {
+    SRBH_REQUIRE(dout && (dx || dskip), "srbh_up2_cat_bwd: null pointer");
+    SRBH_REQUIRE(B > 0 && Cx > 0 && Cs >= 0 && H > 0 && W > 0 && (W & 1) == 0, "srbh_up2_cat_bwd: bad shape (W must be even)");
+    const long n_x2 = dx ? (long)B * Cx * H * (W / 2) : 0, n_s4 = (dskip && Cs) ? (long)B * Cs * 2 * H * (2 * W / 4) : 0;
+    if (n_x2 + n_s4 == 0) return SRBH_OK;
+    const long blocks = (n_x2 + n_s4 + 255) / 256;
+    hipLaunchKernelGGL(up2_cat_bwd_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, dout, dx, dskip,
+                       n_x2, n_s4, Cx, Cs, H, W);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
 }

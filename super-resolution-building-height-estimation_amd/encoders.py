@@ -402,6 +402,13 @@ class DecoderBlock(nn.Module):
         self.attention2 = _Attention(attention_type)
 
     def forward(self, x, skip=None):
+        if x.is_cuda:
+            from . import mbconv_autograd as MB
+            if MB.up2_cat_supported(x, skip):                    # nearest x2 + concat as ONE libsrbh launch (and one backward)
+                x = MB.up2_cat(x, skip)
+                if skip is not None:
+                    x = self.attention1(x)
+                return self.attention2(self.conv2(self.conv1(x)))
         x = F.interpolate(x, scale_factor=2, mode="nearest")
         if skip is not None:
             x = self.attention1(torch.cat([x, skip], dim=1))

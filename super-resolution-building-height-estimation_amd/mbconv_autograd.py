@@ -11,7 +11,7 @@ training each MBConv block is ~14 stock launches forward and ~30 backward around
   gate re-enters the BatchNorm backward kernel as a per-plane scale and offset of dy).
 
 Both update ``running_mean`` / ``running_var`` exactly as nn.BatchNorm2d does and count the batch through hrfuse.note_batch.  Shapes
-the kernels do not take (planes of 32x32 and larger, SyncBatchNorm, CPU tensors) return None from ``supported`` and the caller
+the kernels do not take (plane sizes that are not a multiple of 4, SyncBatchNorm, CPU tensors) return None from ``supported`` and the caller
 keeps the stock ops.
 """
 from __future__ import annotations
@@ -48,9 +48,16 @@ def _note(bn):
         _H.flush_batches()
 
 
+def _ws(x):
+    B, Cc, H, W = x.shape
+    n = _lib.lib().srbh_bn_act_train_ws_bytes(B, Cc, H * W)
+    return torch.empty(n // 8, dtype=torch.float64, device=x.device) if n else None
+
+
 def _fwd(x, bn, act, y, mean, invstd, pooled=None, res=None, drop=None):
     B, Cc, H, W = x.shape
-    a = _lib.BnActArgs(x=x.data_ptr(), y=y.data_ptr(), gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(),
+    ws = _ws(x)
+    a = _lib.BnActArgs(ws=_ptr(ws), x=x.data_ptr(), y=y.data_ptr(), gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(),
                        running_mean=bn.running_mean.data_ptr(), running_var=bn.running_var.data_ptr(), save_mean=mean.data_ptr(),
                        save_invstd=invstd.data_ptr(), pooled=_ptr(pooled), res=_ptr(res), drop=_ptr(drop), momentum=float(bn.momentum),
                        eps=float(bn.eps), B=B, C=Cc, HW=H * W, act=act)
@@ -62,7 +69,8 @@ def _bwd(dy, x, gamma, beta, mean, invstd, act, need_dx, gate=None, dpooled=None
     dx = torch.empty_like(x) if need_dx else None
     dgamma = torch.empty_like(gamma)
     dbeta = torch.empty_like(beta)
-    a = _lib.BnActBwdArgs(dy=dy.data_ptr(), x=x.data_ptr(), gamma=gamma.data_ptr(), beta=beta.data_ptr(), save_mean=mean.data_ptr(),
+    ws = _ws(x)
+    a = _lib.BnActBwdArgs(ws=_ptr(ws), dy=dy.data_ptr(), x=x.data_ptr(), gamma=gamma.data_ptr(), beta=beta.data_ptr(), save_mean=mean.data_ptr(),
                           save_invstd=invstd.data_ptr(), gate=_ptr(gate), dpooled=_ptr(dpooled), drop=_ptr(drop), dx=_ptr(dx),
                           dgamma=dgamma.data_ptr(), dbeta=dbeta.data_ptr(), B=B, C=Cc, HW=H * W, act=act)
     _lib.check(_lib.lib().srbh_bn_act_train_bwd(C.byref(a), _lib.stream_ptr()), "bn_act_train_bwd")
@@ -155,3 +163,39 @@ def bn_swish_se_train(bn, x, se_reduce, se_expand):
     y = _BnSwishSEFn.apply(x, bn.weight, bn.bias, se_reduce.weight, se_reduce.bias, se_expand.weight, se_expand.bias, bn)
     _note(bn)
     return y
+
+
+class _Up2CatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, skip):
+        x = x.contiguous()
+        B, Cx, H, W = x.shape
+        Cs = 0
+        if skip is not None:
+            skip = skip.contiguous()
+            Cs = skip.shape[1]
+        out = torch.empty((B, Cx + Cs, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().srbh_up2_cat_fwd(x.data_ptr(), _ptr(skip), out.data_ptr(), B, Cx, Cs, H, W, _lib.stream_ptr()), "up2_cat_fwd")
+        ctx.geo = (B, Cx, Cs, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, Cx, Cs, H, W = ctx.geo
+        dout = dout.contiguous()
+        dx = torch.empty((B, Cx, H, W), dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[0] else None
+        dskip = (torch.empty((B, Cs, 2 * H, 2 * W), dtype=torch.float32, device=dout.device)
+                 if (Cs and ctx.needs_input_grad[1]) else None)
+        _lib.check(_lib.lib().srbh_up2_cat_bwd(dout.data_ptr(), _ptr(dx), _ptr(dskip), B, Cx, Cs, H, W, _lib.stream_ptr()), "up2_cat_bwd")
+        return dx, dskip
+
+
+def up2_cat_supported(x, skip) -> bool:
+    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] % 2 == 0
+            and (skip is None or (skip.is_cuda and skip.dtype == torch.float32 and skip.shape[0] == x.shape[0]
+                                  and skip.shape[2] == 2 * x.shape[2] and skip.shape[3] == 2 * x.shape[3])))
+
+
+def up2_cat(x, skip=None):
+    """torch.cat([F.interpolate(x, scale_factor=2, mode="nearest"), skip], dim=1) (smp DecoderBlock.forward), one launch each way"""
+    return _Up2CatFn.apply(x, skip)

@@ -39,7 +39,8 @@ def _stock(bn, x, act, res, drop):
     return y if res is None else y + res
 
 
-@pytest.mark.parametrize("B,C,H", [(6, 37, 2), (64, 20, 4), (5, 9, 8), (3, 5, 16), (2, 130, 2), (7, 3, 1), (64, 16, 8)])
+@pytest.mark.parametrize("B,C,H", [(6, 37, 2), (64, 20, 4), (5, 9, 8), (3, 5, 16), (2, 130, 2), (7, 3, 1), (64, 16, 8),
+                                   (4, 6, 32), (3, 5, 64), (90, 2, 16), (33, 40, 32)])      # (last four: the large-plane path)
 @pytest.mark.parametrize("act,with_res,with_drop", [("silu", False, False), ("relu", False, False), (None, True, True), (None, True, False),
                                                     (None, False, False)])
 def test_bn_act_train_matches_stock_ops(B, C, H, act, with_res, with_drop):
@@ -69,7 +70,7 @@ def test_bn_act_train_matches_stock_ops(B, C, H, act, with_res, with_drop):
         assert torch.equal(res.grad, gy)
 
 
-@pytest.mark.parametrize("B,C,SQ,H", [(6, 144, 6, 16), (64, 40, 10, 8), (5, 672, 28, 4), (3, 2688, 112, 2), (2, 19, 3, 2)])
+@pytest.mark.parametrize("B,C,SQ,H", [(6, 144, 6, 16), (64, 40, 10, 8), (5, 672, 28, 4), (3, 2688, 112, 2), (2, 19, 3, 2), (4, 24, 6, 32)])
 def test_bn_swish_se_train_matches_stock_ops(B, C, SQ, H):
     from srbh_amd import mbconv_autograd as MB
     g = torch.Generator().manual_seed(B * 1000 + C + H)
@@ -102,7 +103,8 @@ def test_unsupported_shapes_keep_the_stock_ops_and_eval_is_untouched():
     from srbh_amd import mbconv_autograd as MB
     g = torch.Generator().manual_seed(1)
     bn = _bn(8, g)
-    assert not MB.supported(bn, torch.zeros(2, 8, 32, 32, device=DEV))        # 32x32 planes: stock ops
+    assert MB.supported(bn, torch.zeros(2, 8, 32, 32, device=DEV))            # 32x32 planes: the two-launch path
+    assert not MB.supported(bn, torch.zeros(2, 8, 9, 9, device=DEV))          # 81-element planes
     assert not MB.supported(bn, torch.zeros(2, 8, 6, 6, device=DEV))          # 36-element planes
     assert not MB.supported(bn.eval(), torch.zeros(2, 8, 4, 4, device=DEV))
     assert not MB.supported(bn.train(), torch.zeros(2, 8, 4, 4))              # CPU tensor
@@ -128,11 +130,11 @@ def test_encoder_and_decoder_training_step_agrees_with_the_stock_path(monkeypatc
     monkeypatch.setattr(MB, "_fwd", counting)
     out = dec(*enc(x))
     out.square().mean().backward()
-    assert calls["n"] >= 90                      # 28 of 32 blocks x 3 BatchNorms + the decoder's small planes
+    assert calls["n"] >= 105                     # every BatchNorm of the encoder and the decoder
     monkeypatch.setattr(MB, "ENABLED", False)
     out2 = dec2(*enc2(x))
     out2.square().mean().backward()
-    assert calls["n"] >= 90 and rel(out, out2) <= 2e-4
+    assert rel(out, out2) <= 2e-4
     big = max(float(p.grad.norm()) for p in enc2.parameters() if p.grad is not None)
     for (k, a), (_, b) in zip(list(enc.named_parameters()) + list(dec.named_parameters()),
                               list(enc2.named_parameters()) + list(dec2.named_parameters())):
@@ -150,3 +152,25 @@ def test_encoder_and_decoder_training_step_agrees_with_the_stock_path(monkeypatc
             assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-6, (k, rel(a, b))
         else:
             assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize("B,Cx,Cs,H,W", [(3, 5, 7, 2, 2), (2, 16, 0, 32, 32), (4, 9, 3, 4, 6), (2, 448, 160, 2, 2)])
+def test_up2_cat_matches_interpolate_and_cat_bit_exact_forward(B, Cx, Cs, H, W):
+    from srbh_amd import mbconv_autograd as MB
+    g = torch.Generator().manual_seed(B + Cx + H)
+    x = torch.randn((B, Cx, H, W), generator=g).to(DEV).requires_grad_(True)
+    skip = torch.randn((B, Cs, 2 * H, 2 * W), generator=g).to(DEV).requires_grad_(True) if Cs else None
+    assert MB.up2_cat_supported(x, skip)
+    y = MB.up2_cat(x, skip)
+    xr = x.detach().clone().requires_grad_(True)
+    sr = skip.detach().clone().requires_grad_(True) if Cs else None
+    yr = F.interpolate(xr, scale_factor=2, mode="nearest")
+    if Cs:
+        yr = torch.cat([yr, sr], dim=1)
+    assert torch.equal(y, yr)
+    gy = torch.randn(yr.shape, generator=g).to(DEV)
+    y.backward(gy)
+    yr.backward(gy)
+    assert rel(x.grad, xr.grad) <= 1e-6                  # (2x2 sums in a different order)
+    if Cs:
+        assert torch.equal(skip.grad, sr.grad)
