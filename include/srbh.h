@@ -432,6 +432,26 @@ size_t srbh_se_train_bwd_ws_floats(int B, int C, int SQ);
 int srbh_up2_cat_fwd(const float* x, const float* skip, float* out, int B, int Cx, int Cs, int H, int W, void* stream);
 int srbh_up2_cat_bwd(const float* dout, float* dx, float* dskip, int B, int Cx, int Cs, int H, int W, void* stream);
 
+/* ---- 1x1 convolutions of the MBConv blocks (expand / project: no bias, stride 1, no padding), fp32 NCHW (csrc/srbh_pwconv.hip) ----
+ * What F.conv2d and its autograd do for efficientnet_pytorch's _expand_conv / _project_conv (reached through mymodels.py:276), as ONE launch
+ * per product on the fp32 matrix unit (true fp32, fixed summation order):  x [B][Cin][HW], w [Cout][Cin], y [B][Cout][HW].
+ * The weight gradient splits over images when its tile grid is small: partials in `ws` (srbh_pwconv_bwd_weight_ws_floats floats, 0 = not
+ * needed) + one ordered reduce.  srbh_pwconv_supported: HW == 4 or a multiple of 16. */
+int srbh_pwconv_supported(int B, int Cin, int Cout, int HW);
+int srbh_pwconv_fwd(const float* x, const float* w, float* y, int B, int Cin, int Cout, int HW, void* stream);
+/* the same forward reading W^T [Cin][Cout] (coalesced along Cout, as the input gradient reads W): 2x faster on the deep products.
+ * srbh_transpose_many makes the transposed copies of a whole table of matrices (device-resident descriptors) in one launch. */
+typedef struct srbh_transpose_desc {
+    const float* src;          /* [rows][cols] */
+    float* dst;                /* [cols][rows] */
+    int rows, cols;
+} srbh_transpose_desc;
+int srbh_transpose_many(const srbh_transpose_desc* table_dev, int n, void* stream);
+int srbh_pwconv_fwd_wt(const float* x, const float* wt, float* y, int B, int Cin, int Cout, int HW, void* stream);
+int srbh_pwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int HW, void* stream);
+size_t srbh_pwconv_bwd_weight_ws_floats(int B, int Cin, int Cout, int HW);
+int srbh_pwconv_bwd_weight(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int Cout, int HW, void* stream);
+
 /* ---- inference epilogue: quantise + integer mosaic (predict_realesanet_feature_globe.py:172-204) ------------------
  * accumulate: height [B][th][tw] fp32 (model output, C=1), build logits NHWC [B][th][tw][C] fp32, pos [B][4] int32
  *   = (xoff, yoff, xcount, ycount) already multiplied by 4 (predict...py:182); adds round(max(h,0)*10) and

@@ -97,7 +97,89 @@ class _DepthwiseConvFn(torch.autograd.Function):
         return dx, dw, None, None
 
 
-# (1x1 convs stay on MIOpen in the training graph too.  Restating them as batched rocBLAS GEMMs -- forward W @ X_b, data gradient
+class _PointwiseConvFn(torch.autograd.Function):
+    """1x1 convolution without bias (MBConv expand / project) on libsrbh (csrc/srbh_pwconv.hip): one fp32-MFMA launch forward, one for
+    the input gradient, one (+ an ordered reduce when it splits over images) for the weight gradient.  MIOpen wraps its NHWC kernels
+    for these shapes in batched transposes, zero fills and split-K atomics: ~390 launches / 4.1 ms of the training step."""
+
+    @staticmethod
+    def forward(ctx, x, weight, wt=None):
+        """wt: the transposed weight [Cin][Cout] made by `PointwiseTransposes` for THIS state of `weight` (or None)"""
+        from . import _lib
+        x = x.contiguous()
+        weight = weight.contiguous()
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+        if wt is not None:
+            _lib.check(_lib.lib().srbh_pwconv_fwd_wt(x.data_ptr(), wt.data_ptr(), y.data_ptr(), B, Cin, Cout, H * W, _lib.stream_ptr()), "pwconv_fwd_wt")
+        else:
+            _lib.check(_lib.lib().srbh_pwconv_fwd(x.data_ptr(), weight.data_ptr(), y.data_ptr(), B, Cin, Cout, H * W, _lib.stream_ptr()), "pwconv_fwd")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        x, weight = ctx.saved_tensors
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dy = dy.contiguous()
+        L = _lib.lib()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(L.srbh_pwconv_bwd_data(dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), B, Cin, Cout, H * W, _lib.stream_ptr()), "pwconv_bwd_data")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            n = L.srbh_pwconv_bwd_weight_ws_floats(B, Cin, Cout, H * W)
+            ws = torch.empty(n, dtype=torch.float32, device=x.device) if n else None
+            _lib.check(L.srbh_pwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr() if n else None, B, Cin, Cout, H * W,
+                                                _lib.stream_ptr()), "pwconv_bwd_weight")
+        return dx, dw, None
+
+
+class PointwiseTransposes:
+    """W^T [Cin][Cout] of every 1x1 convolution of an encoder in ONE flat buffer, refreshed by ONE launch (srbh_transpose_many) at the
+    start of a forward whenever a weight changed -- in training that is once per step.  The forward kernel then reads the weights as
+    the input-gradient kernel reads W: coalesced along the output channel."""
+
+    def __init__(self, convs):
+        self.convs = list(convs)
+        self.key = None
+        self.flat = None
+        self.table = None
+        self.table_ptrs = None
+
+    def _key(self):
+        return tuple((c.weight._version, c.weight.data_ptr()) for c in self.convs) + wcache.gen(*[c.weight for c in self.convs])
+
+    def refresh(self, device):
+        from . import _lib
+        import numpy as np
+        key = (self._key(), str(device))
+        if key != self.key:
+            if self.flat is None or self.flat.device != device or self.table_ptrs != tuple(c.weight.data_ptr() for c in self.convs):
+                self.flat = torch.empty(sum(c.weight.numel() for c in self.convs), dtype=torch.float32, device=device)
+                desc = np.zeros(len(self.convs), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4")]))
+                o = 0
+                for i, c in enumerate(self.convs):
+                    cout, cin = c.weight.shape[:2]
+                    c.__dict__["_srbh_wt"] = self.flat[o:o + cout * cin].view(cin, cout)
+                    desc[i] = (c.weight.data_ptr(), self.flat.data_ptr() + 4 * o, cout, cin)
+                    o += cout * cin
+                self.table = torch.from_numpy(desc.view(np.uint8).copy()).to(device)
+                self.table_ptrs = tuple(c.weight.data_ptr() for c in self.convs)
+            _lib.check(_lib.lib().srbh_transpose_many(self.table.data_ptr(), len(self.convs), _lib.stream_ptr()), "transpose_many")
+            self.key = key
+            for c in self.convs:
+                c.__dict__["_srbh_wt_state"] = (c.weight._version, c.weight.data_ptr(), wcache.gen(c.weight))
+        wcache.keep(self.flat, self.table)
+
+
+PWCONV = __import__("os").environ.get("SRBH_PWCONV", "train")      # "train" (default): when gradients are recorded; "1": always; "0": never
+
+# (history, round 2: restating the 1x1 convs as batched rocBLAS GEMMs -- forward W @ X_b, data gradient
 # W^T @ dY_b, weight gradient sum_b dY_b @ X_b^T -- removed ~220 of the step's launches (MIOpen's backward wraps its NHWC
 # implicit-GEMM kernels in batched transposes and zero fills) but the step got 1.5 ms SLOWER: at these shapes the Tensile kernels
 # behind bmm lose more than the launches cost.  Measured round 2, DESIGN.md 5.0.)
@@ -211,12 +293,22 @@ class SamePadConv2d(nn.Conv2d):
             self.static_padding = nn.ZeroPad2d(self._pad)
         else:
             self.static_padding = nn.Identity()
+        self._pointwise = (kh == kw == 1 and sh == sw == 1 and groups == 1 and not bias and pad_h == 0 and pad_w == 0)
         self._depthwise = (groups == in_ch == out_ch and groups > 1 and kh == kw and kh in (3, 5) and sh == sw and sh in (1, 2)
                            and not bias)
 
     def forward(self, x):
         if self._depthwise and x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32:
             return _DepthwiseConvFn.apply(x, self.weight, self.stride[0], self._pad)
+        if (self._pointwise and x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32 and x.dim() == 4
+                and (PWCONV == "1" or (PWCONV == "train" and torch.is_grad_enabled()))):
+            from . import _lib
+            if _lib.lib().srbh_pwconv_supported(x.shape[0], x.shape[1], self.weight.shape[0], x.shape[2] * x.shape[3]):
+                wt = self.__dict__.get("_srbh_wt")           # (valid only for the weight state it was made from)
+                if wt is not None and (wt.device != x.device or self.__dict__.get("_srbh_wt_state") != (
+                        self.weight._version, self.weight.data_ptr(), wcache.gen(self.weight))):
+                    wt = None
+                return _PointwiseConvFn.apply(x, self.weight, wt)
         return F.conv2d(self.static_padding(x), self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
 
 
@@ -325,6 +417,12 @@ class EfficientNetEncoder(nn.Module):
 
     def forward(self, x):
         feats = [x]
+        if x.is_cuda and x.dtype == torch.float32 and (PWCONV == "1" or (PWCONV == "train" and torch.is_grad_enabled())):
+            pt = self.__dict__.get("_srbh_pwt")
+            if pt is None:
+                pt = self.__dict__["_srbh_pwt"] = PointwiseTransposes(
+                    m for m in self.modules() if isinstance(m, SamePadConv2d) and m._pointwise and m is not self._conv_head)
+            pt.refresh(x.device)
         x = bn_act(self._bn0, self._conv_stem(x), "silu")
         feats.append(x)
         n = len(self._blocks)

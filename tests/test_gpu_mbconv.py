@@ -174,3 +174,46 @@ def test_up2_cat_matches_interpolate_and_cat_bit_exact_forward(B, Cx, Cs, H, W):
     assert rel(x.grad, xr.grad) <= 1e-6                  # (2x2 sums in a different order)
     if Cs:
         assert torch.equal(skip.grad, sr.grad)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(64, 272, 1632, 2), (5, 24, 144, 16), (3, 1632, 272, 2), (64, 32, 192, 16), (7, 56, 336, 8), (2, 960, 160, 4),
+                                          (9, 19, 37, 4), (64, 2688, 448, 2), (3, 48, 24, 32)])
+def test_pointwise_conv_matches_stock_conv(B, Cin, Cout, H):
+    """1x1 convolution kernels (csrc/srbh_pwconv.hip, fp32 MFMA) against F.conv2d evaluated in fp64: forward, input gradient, weight gradient"""
+    from srbh_amd.encoders import _PointwiseConvFn
+    g = torch.Generator().manual_seed(B + Cin + Cout)
+    x0 = torch.randn((B, Cin, H, H), generator=g).to(DEV)
+    w0 = (torch.randn((Cout, Cin, 1, 1), generator=g) / Cin ** 0.5).to(DEV)
+    x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    y = _PointwiseConvFn.apply(x, w)
+    xr, wr = x0.double().requires_grad_(True), w0.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr)
+    assert y.shape == yr.shape and rel(y, yr) <= 2e-6
+    with torch.no_grad():                                   # the forward that reads W^T (what the encoder uses)
+        assert rel(_PointwiseConvFn.apply(x0, w0, w0.view(Cout, Cin).t().contiguous()), yr) <= 2e-6
+    gy = torch.randn(yr.shape, generator=g).to(DEV)
+    y.backward(gy)
+    yr.backward(gy.double())
+    assert rel(x.grad, xr.grad) <= 2e-6
+    assert rel(w.grad, wr.grad) <= 2e-6
+
+
+def test_transpose_many_and_encoder_refresh():
+    """one launch transposes every 1x1 weight of the encoder; a changed weight is seen by the next forward (never a stale W^T)"""
+    from srbh_amd import encoders
+    torch.manual_seed(5)
+    enc = encoders.get_encoder("efficientnet-b4", in_channels=8, depth=5, weights=None).to(DEV).train()
+    x = torch.randn(2, 8, 64, 64, device=DEV)
+    enc(x)
+    pt = enc.__dict__["_srbh_pwt"]
+    assert len(pt.convs) == 62
+    for c in pt.convs:
+        assert torch.equal(c.__dict__["_srbh_wt"], c.weight.detach().view(c.weight.shape[0], -1).t())
+    c = pt.convs[7]
+    with torch.no_grad():
+        c.weight.mul_(2.0)                                  # version bump: the cached W^T is stale now
+    xi = torch.randn(2, c.weight.shape[1], 4, 4, device=DEV)
+    y = c(xi)                                               # direct call between refreshes: must not use the stale copy
+    assert rel(y, F.conv2d(xi.double(), c.weight.detach().double())) <= 2e-6
+    enc(x)
+    assert torch.equal(c.__dict__["_srbh_wt"], c.weight.detach().view(c.weight.shape[0], -1).t())
