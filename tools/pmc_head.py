@@ -19,9 +19,22 @@ alg = {"hconv16_kernel<1>": ("forward 16->16 3x3, fp16 operands, + BN statistics
        "bn_add_relu_kernel": ("relu(bn(c) + identity)", px * 192)}
 res = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python tools/head_kernels.py %d (separate passes)" % B,
        "units": "bytes per launch; FETCH_SIZE doubled (MI355X_MICROARCH.md #HBM)", "kernels": {}}
+def lookup(name):
+    """alg key whose base name matches and whose template arguments are a prefix of the kernel's (the kernels gained template
+    parameters after this table was written: hconv16_kernel<1, 0, 0> is the forward form hconv16_kernel<1>)"""
+    base, _, targs = name.partition("<")
+    targs = [t.strip() for t in targs.rstrip(">").split(",")] if targs else []
+    for key in alg:
+        kb, _, ka = key.partition("<")
+        ka = [t.strip() for t in ka.rstrip(">").split(",")] if ka else []
+        if kb == base and targs[:len(ka)] == ka:
+            return key
+    return None
+
+
 for k in sorted(set(fe) | set(wr)):
-    name = k.split(" grid=")[0]
-    if name not in alg:
+    name = lookup(k.split(" grid=")[0].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip())
+    if name is None:
         continue
     f = 2.0 * 1024 * sum(fe.get(k, [0])) / max(1, len(fe.get(k, [])))
     w = 1024.0 * sum(wr.get(k, [0])) / max(1, len(wr.get(k, [])))
