@@ -34,10 +34,9 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.srbh_rrdbnet_workspace_bytes(0, 64, 64, 0) == 0
 
 
-def test_ctypes_struct_matches_header_field_order():
-    from srbh_amd import _lib
+def _header_fields(struct):
     hdr = open(os.path.join(ROOT, "include", "srbh.h")).read()
-    body = re.search(r"typedef struct srbh_conv3x3_args \{(.*?)\} srbh_conv3x3_args;", hdr, re.S).group(1)
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = []
     for decl in body.split(";"):
@@ -46,8 +45,18 @@ def test_ctypes_struct_matches_header_field_order():
             continue
         for part in decl.split(","):
             names.append(re.findall(r"([A-Za-z_0-9]+)\s*$", part.strip())[0])
-    py = [n.rstrip("_") for n, _ in _lib.ConvArgs._fields_]
-    assert names == py
+    return names
+
+
+def test_ctypes_struct_matches_header_field_order():
+    """every argument struct of include/srbh.h against its ctypes mirror in _lib.py, field for field"""
+    from srbh_amd import _lib
+    pairs = {"srbh_conv3x3_args": _lib.ConvArgs, "srbh_hconv_args": _lib.HConvArgs, "srbh_hwgrad_args": _lib.HWGradArgs,
+             "srbh_bnact_args": _lib.BnActArgs, "srbh_bnact_bwd_args": _lib.BnActBwdArgs, "srbh_conv_w": _lib.ConvW,
+             "srbh_rrdbnet_desc": _lib.RRDBNetDesc}
+    for struct, cls in pairs.items():
+        assert _header_fields(struct) == [n.rstrip("_") for n, _ in cls._fields_], struct
+    assert _header_fields("srbh_transpose_desc") == ["src", "dst", "rows", "cols"]       # (built as a numpy record in encoders.py)
 
 
 def test_rrdbnet_state_dict_layout_and_signature():
