@@ -125,6 +125,101 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const DWParams p, fl
         ws[((long)sp * p.C + c) * K * K + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// ---- LDS-staged forms (round 3).  The one-thread-per-output kernels above spend ~150 instructions per output on 25 predicated taps with 64-bit
+// address arithmetic (13-25 us per call on tensors that take 3-5 us to stream); here a workgroup stages P whole planes ZERO-PADDED in LDS
+// (coalesced reads of P contiguous planes), so every tap is one unconditional ds_read + fma.
+//   forward        : out[oy][ox] = sum_ij xpad[oy s + i][ox s + j] w[i][j]                      (x placed at (pad_t, pad_l))
+//   input gradient : dx[y][x]   = sum_ij dyup[y + pad_t + K-1 - i][x + pad_l + K-1 - j] w[i][j]  (dy placed at (K-1 + oy s, K-1 + ox s): zero-upsampled)
+struct DWLds {
+    const float* src; const float* w; float* out;
+    long planes;
+    int C, SH, SW, OUTH, OUTW, PH, PW, ss, soy, sox, os, by, bx, P;
+};
+template <int K, int FLIP>
+__global__ __launch_bounds__(256) void dw_lds_kernel(const DWLds p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int t = threadIdx.x, plane_sz = p.PH * p.PW;
+    float* wl = sm + p.P * plane_sz;
+    const long p0 = (long)blockIdx.x * p.P;
+    const int np = (int)((p.planes - p0) < p.P ? (p.planes - p0) : p.P);
+    for (int e = t; e < p.P * plane_sz; e += 256) sm[e] = 0.f;
+    for (int e = t; e < np * K * K; e += 256) wl[e] = p.w[(long)((p0 + e / (K * K)) % p.C) * K * K + e % (K * K)];
+    __syncthreads();
+    const int ssz = p.SH * p.SW;
+    const float* sp = p.src + p0 * ssz;
+    for (int e = t; e < np * ssz; e += 256) {
+        const int pl = e / ssz, q = e - pl * ssz, u = q / p.SW, v = q - u * p.SW;
+        const int r = u * p.ss + p.soy, c = v * p.ss + p.sox;
+        if (r < p.PH && c < p.PW) sm[pl * plane_sz + r * p.PW + c] = sp[e];
+    }
+    __syncthreads();
+    const int osz = p.OUTH * p.OUTW;
+    float* op = p.out + p0 * osz;
+    for (int e = t; e < np * osz; e += 256) {
+        const int pl = e / osz, q = e - pl * osz, oy = q / p.OUTW, ox = q - oy * p.OUTW;
+        const float* base = sm + pl * plane_sz + (oy * p.os + p.by) * p.PW + ox * p.os + p.bx;
+        const float* wp = wl + pl * K * K;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const float v = FLIP ? base[-(i * p.PW + j)] : base[i * p.PW + j];
+                if ((i * K + j) & 1) a1 = fmaf(v, wp[i * K + j], a1);
+                else a0 = fmaf(v, wp[i * K + j], a0);
+            }
+        op[e] = a0 + a1;
+    }
+}
+
+// weight gradient, LDS-staged: workgroup (c, slice) stages P images' zero-padded x planes and dy planes per round; thread = one output pixel
+template <int K>
+__global__ __launch_bounds__(256) void dw_lds_wgrad_kernel(const DWParams p, float* __restrict__ ws, int splits, int PH, int PW, int P) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int c = blockIdx.x, sp = blockIdx.y, t = threadIdx.x;
+    const int per_img = p.OH * p.OW, plane_sz = PH * PW, xsz = p.H * p.W;
+    float* dyl = sm + P * plane_sz;
+    const int b0 = (int)((long)p.B * sp / splits), b1 = (int)((long)p.B * (sp + 1) / splits);
+    float acc[K * K];
+#pragma unroll
+    for (int q = 0; q < K * K; ++q) acc[q] = 0.f;
+    for (int e = t; e < P * plane_sz; e += 256) sm[e] = 0.f;          // the halo stays zero for every round
+    for (int br = b0; br < b1; br += P) {
+        const int np = b1 - br < P ? b1 - br : P;
+        __syncthreads();                                               // previous round's reads are done
+        for (int e = t; e < np * xsz; e += 256) {
+            const int pl = e / xsz, q = e - pl * xsz, u = q / p.W, v = q - u * p.W;
+            const int r = u + p.pad_t, cc = v + p.pad_l;
+            if (r < PH && cc < PW) sm[pl * plane_sz + r * PW + cc] = p.x[((long)(br + pl) * p.C + c) * xsz + q];
+        }
+        for (int e = t; e < np * per_img; e += 256) {
+            const int pl = e / per_img, q = e - pl * per_img;
+            dyl[e] = p.dy[((long)(br + pl) * p.C + c) * per_img + q];
+        }
+        __syncthreads();
+        for (int e = t; e < np * per_img; e += 256) {
+            const int pl = e / per_img, q = e - pl * per_img, oy = q / p.OW, ox = q - oy * p.OW;
+            const float g = dyl[e];
+            const float* base = sm + pl * plane_sz + oy * p.stride * PW + ox * p.stride;
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+#pragma unroll
+                for (int j = 0; j < K; ++j) acc[i * K + j] = fmaf(g, base[i * PW + j], acc[i * K + j]);
+        }
+    }
+    __shared__ float red[4][K * K];
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int q = 0; q < K * K; ++q) {
+        float v = acc[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) red[wave][q] = v;
+    }
+    __syncthreads();
+    if (t < K * K) ws[((long)sp * p.C + c) * K * K + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+}
+
 __global__ void dw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int n, int splits) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -255,6 +350,14 @@ int check(const DWParams& p, int K, const char* what) {
     return SRBH_OK;
 }
 
+constexpr size_t DW_LDS_MAX = 60 * 1024;
+#ifndef DW_LDS_FORMS
+#define DW_LDS_FORMS 1          // (0: the one-thread-per-output kernels, for same-box A/B builds)
+#endif
+int lds_planes(int out_px) {     // planes a workgroup stages per round: ~256 outputs
+    int P = 256 / (out_px > 0 ? out_px : 1);
+    return P < 1 ? 1 : (P > 64 ? 64 : P);
+}
 int grid_for(long n) {
     const long b = (n + 255) / 256;
     return (int)(b < 8192 ? (b > 0 ? b : 1) : 8192);
@@ -266,6 +369,20 @@ extern "C" int srbh_dwconv_fwd(const float* x, const float* w, float* y, int B, 
     SRBH_REQUIRE(x && w && y, "srbh_dwconv_fwd: null pointer");
     DWParams p{x, w, nullptr, y, B, C, H, W, OH, OW, stride, pad_t, pad_l};
     if (int rc = check(p, K, "srbh_dwconv_fwd")) return rc;
+    {
+        DWLds q;
+        q.src = x; q.w = w; q.out = y; q.planes = (long)B * C; q.C = C; q.SH = H; q.SW = W; q.OUTH = OH; q.OUTW = OW;
+        q.PH = (OH - 1) * stride + K; q.PW = (OW - 1) * stride + K; q.ss = 1; q.soy = pad_t; q.sox = pad_l; q.os = stride; q.by = 0; q.bx = 0;
+        q.P = lds_planes(OH * OW);
+        const size_t lds = (size_t)q.P * (q.PH * q.PW + K * K) * 4;
+        if (lds <= DW_LDS_MAX && DW_LDS_FORMS) {
+            const dim3 grid((unsigned)((q.planes + q.P - 1) / q.P));
+            if (K == 3) hipLaunchKernelGGL((dw_lds_kernel<3, 0>), grid, dim3(256), lds, (hipStream_t)stream, q);
+            else hipLaunchKernelGGL((dw_lds_kernel<5, 0>), grid, dim3(256), lds, (hipStream_t)stream, q);
+            SRBH_HIP(hipGetLastError());
+            return SRBH_OK;
+        }
+    }
     const int g = grid_for((long)B * C * OH * OW);
     if (K == 3)
         hipLaunchKernelGGL(dw_fwd_kernel<3>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
@@ -280,6 +397,22 @@ extern "C" int srbh_dwconv_bwd_data(const float* dy, const float* w, float* dx, 
     SRBH_REQUIRE(dy && w && dx, "srbh_dwconv_bwd_data: null pointer");
     DWParams p{nullptr, w, dy, dx, B, C, H, W, OH, OW, stride, pad_t, pad_l};
     if (int rc = check(p, K, "srbh_dwconv_bwd_data")) return rc;
+    {
+        DWLds q;
+        q.src = dy; q.w = w; q.out = dx; q.planes = (long)B * C; q.C = C; q.SH = OH; q.SW = OW; q.OUTH = H; q.OUTW = W;
+        // (rows / columns of x that no output covers -- possible at stride 2 -- read the zero slack and get dx = 0)
+        q.PH = (OH - 1) * stride + 2 * (K - 1) + stride + 1; q.PW = (OW - 1) * stride + 2 * (K - 1) + stride + 1;
+        q.ss = stride; q.soy = K - 1; q.sox = K - 1; q.os = 1; q.by = pad_t + K - 1; q.bx = pad_l + K - 1;
+        q.P = lds_planes(H * W);
+        const size_t lds = (size_t)q.P * (q.PH * q.PW + K * K) * 4;
+        if (lds <= DW_LDS_MAX && DW_LDS_FORMS && H - 1 + pad_t + K - 1 < q.PH && W - 1 + pad_l + K - 1 < q.PW) {
+            const dim3 grid((unsigned)((q.planes + q.P - 1) / q.P));
+            if (K == 3) hipLaunchKernelGGL((dw_lds_kernel<3, 1>), grid, dim3(256), lds, (hipStream_t)stream, q);
+            else hipLaunchKernelGGL((dw_lds_kernel<5, 1>), grid, dim3(256), lds, (hipStream_t)stream, q);
+            SRBH_HIP(hipGetLastError());
+            return SRBH_OK;
+        }
+    }
     const int g = grid_for((long)B * C * H * W);
     if (K == 3)
         hipLaunchKernelGGL(dw_bwd_data_kernel<3>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
@@ -301,7 +434,12 @@ extern "C" int srbh_dwconv_bwd_weight(const float* x, const float* dy, float* dw
     DWParams p{x, nullptr, dy, dw, B, C, H, W, OH, OW, stride, pad_t, pad_l};
     if (int rc = check(p, K, "srbh_dwconv_bwd_weight")) return rc;
     const int splits = srbh_dwconv_bwd_weight_splits(B, C);
-    if (K == 3)
+    const int PH = (OH - 1) * stride + K, PW = (OW - 1) * stride + K, P = lds_planes(OH * OW);
+    const size_t lds = (size_t)P * (PH * PW + OH * OW) * 4;
+    if (lds <= DW_LDS_MAX && DW_LDS_FORMS) {
+        if (K == 3) hipLaunchKernelGGL(dw_lds_wgrad_kernel<3>, dim3(C, splits), dim3(256), lds, (hipStream_t)stream, p, ws, splits, PH, PW, P);
+        else hipLaunchKernelGGL(dw_lds_wgrad_kernel<5>, dim3(C, splits), dim3(256), lds, (hipStream_t)stream, p, ws, splits, PH, PW, P);
+    } else if (K == 3)
         hipLaunchKernelGGL(dw_bwd_weight_kernel<3>, dim3(C, splits), dim3(256), 0, (hipStream_t)stream, p, ws, splits);
     else
         hipLaunchKernelGGL(dw_bwd_weight_kernel<5>, dim3(C, splits), dim3(256), 0, (hipStream_t)stream, p, ws, splits);
