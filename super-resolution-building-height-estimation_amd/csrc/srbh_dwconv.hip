@@ -142,6 +142,8 @@ __global__ __launch_bounds__(256) void dw_lds_kernel(const DWLds p) {
     float* wl = sm + p.P * plane_sz;
     const long p0 = (long)blockIdx.x * p.P;
     const int np = (int)((p.planes - p0) < p.P ? (p.planes - p0) : p.P);
+    // (zero fill, then scatter the source elements: a single pass over the PADDED index space -- a division and a predicated gather per
+    //  padded element -- was measured slower on every shape)
     for (int e = t; e < p.P * plane_sz; e += 256) sm[e] = 0.f;
     for (int e = t; e < np * K * K; e += 256) wl[e] = p.w[(long)((p0 + e / (K * K)) % p.C) * K * K + e % (K * K)];
     __syncthreads();
@@ -436,14 +438,17 @@ extern "C" int srbh_dwconv_bwd_weight(const float* x, const float* dy, float* dw
     const int splits = srbh_dwconv_bwd_weight_splits(B, C);
     const int PH = (OH - 1) * stride + K, PW = (OW - 1) * stride + K, P = lds_planes(OH * OW);
     const size_t lds = (size_t)P * (PH * PW + OH * OW) * 4;
-    if (lds <= DW_LDS_MAX && DW_LDS_FORMS) {
-        if (K == 3) hipLaunchKernelGGL(dw_lds_wgrad_kernel<3>, dim3(C, splits), dim3(256), lds, (hipStream_t)stream, p, ws, splits, PH, PW, P);
-        else hipLaunchKernelGGL(dw_lds_wgrad_kernel<5>, dim3(C, splits), dim3(256), lds, (hipStream_t)stream, p, ws, splits, PH, PW, P);
+    float* const part = splits == 1 ? dw : ws;                       // (one slice: its sums ARE the gradient, no reduce launch)
+    // (the staged form pays for 5x5 and for small planes; a 3x3 over >= 256-pixel planes is as fast from L1: measured per shape)
+    if (lds <= DW_LDS_MAX && DW_LDS_FORMS && (K == 5 || OH * OW < 256)) {
+        if (K == 3) hipLaunchKernelGGL(dw_lds_wgrad_kernel<3>, dim3(C, splits), dim3(256), lds, (hipStream_t)stream, p, part, splits, PH, PW, P);
+        else hipLaunchKernelGGL(dw_lds_wgrad_kernel<5>, dim3(C, splits), dim3(256), lds, (hipStream_t)stream, p, part, splits, PH, PW, P);
     } else if (K == 3)
-        hipLaunchKernelGGL(dw_bwd_weight_kernel<3>, dim3(C, splits), dim3(256), 0, (hipStream_t)stream, p, ws, splits);
+        hipLaunchKernelGGL(dw_bwd_weight_kernel<3>, dim3(C, splits), dim3(256), 0, (hipStream_t)stream, p, part, splits);
     else
-        hipLaunchKernelGGL(dw_bwd_weight_kernel<5>, dim3(C, splits), dim3(256), 0, (hipStream_t)stream, p, ws, splits);
+        hipLaunchKernelGGL(dw_bwd_weight_kernel<5>, dim3(C, splits), dim3(256), 0, (hipStream_t)stream, p, part, splits);
     SRBH_HIP(hipGetLastError());
+    if (splits == 1) return SRBH_OK;
     const int n = C * K * K;
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, dw, n, splits);
     SRBH_HIP(hipGetLastError());
