@@ -819,9 +819,20 @@ extern "C" int srbh_act16_wgrad_b16(const void* x, int x_chunks_total, int cin, 
     p.tiles_per_xcd = (p.ntiles + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
     const int nob = cout / 16;
-    const int gx = p.ntiles < 512 ? (p.ntiles + 7) / 8 * 8 : 512;
+    int gx = p.ntiles < 512 ? (p.ntiles + 7) / 8 * 8 : 512;
     SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_b16_kernel<3, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WG16<3>::LDS_B)));
-    p.zchunk = p.ntiles <= 256 ? 1 : 0;
+    static const int zchunk_max = getenv("SRBH_WG_ZCHUNK_MAX") ? atoi(getenv("SRBH_WG_ZCHUNK_MAX")) : 256;
+    p.zchunk = p.ntiles <= zchunk_max ? 1 : 0;
+    if (p.zchunk) {
+        // Every workgroup column (blockIdx.x) owns a full set of partial sums: with one column per tile the reduce reads gx * |dW| floats
+        // -- 56 MB for the 192 -> 64 conv at batch 8, 13 us per call on the stream that bounds the backward.  The grid already has
+        // nob * cin/16 workgroups per column, so columns walk several tiles each as long as ~768 workgroups remain (swept at batch 8: 22.5 ms per generator step with one column per tile, 22.1 / 20.7 / 21.1 / 22.2 at 1 536 / 768 / 512 / 256).
+        static const int want_wgs = getenv("SRBH_WG_COLUMNS_WGS") ? atoi(getenv("SRBH_WG_COLUMNS_WGS")) : 768;
+        const int per_col = nob * (cin / 16);
+        int cols = ((want_wgs + per_col - 1) / per_col + 7) / 8 * 8;
+        cols = cols < 8 ? 8 : cols;
+        if (cols < gx) gx = cols;
+    }
     hipLaunchKernelGGL((hwgrad_b16_kernel<3, 1, 1>), dim3(gx, nob, p.zchunk ? cin / 16 : 1), dim3(256), WG16<3>::LDS_B, st, p);
     SRBH_HIP(hipGetLastError());
     constexpr int SLICES = 16;
