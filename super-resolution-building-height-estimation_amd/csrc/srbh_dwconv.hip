@@ -341,6 +341,55 @@ __global__ __launch_bounds__(256) void se_gate_scale_kernel(float* __restrict__ 
     for (int i = lane; i < hw; i += 64) yp[i] *= g;
 }
 
+// small planes (hw = 1 .. 32, a power of two): a wave per plane would be mostly empty lanes (4 of 64 at 2x2, 172 k waves per call);
+// planes are contiguous, so a wave takes 64 consecutive elements = 64 / hw whole planes and reduces inside hw-lane segments
+__global__ __launch_bounds__(256) void affine_act_pool_small_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, float* __restrict__ y,
+                                                                   float* __restrict__ pooled, long planes, int C, int hw, int act) {
+    const int lane = threadIdx.x & 63;
+    const long idx = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
+    const long pl = idx / hw;
+    float u = 0.f;
+    if (pl < planes) {
+        const int c = (int)(pl % C);
+        u = fmaf(x[idx], scale[c], shift[c]);
+        if (act == 1) u = u / (1.f + __expf(-u));
+        else if (act == 2) u = fmaxf(u, 0.f);
+        y[idx] = u;
+    }
+    for (int o = 1; o < hw; o <<= 1) u += __shfl_xor(u, o, 64);
+    if (pl < planes && (lane & (hw - 1)) == 0) pooled[pl] = u / (float)hw;
+}
+
+// gate + scale for planes of 4 / 16 / 64 / 256 elements: a workgroup takes 1024 consecutive elements (a float4 per thread); the hw / 4
+// threads that hold one plane compute its gate together (same reason)
+__global__ __launch_bounds__(256) void se_gate_scale_quad_kernel(float* __restrict__ y, const float* __restrict__ hidden,
+                                                                const float* __restrict__ w2, const float* __restrict__ b2, long planes,
+                                                                int C, int SQ, int hw) {
+    const int t = threadIdx.x, G = hw >> 2, sub = t & (G - 1);
+    const long e = (long)blockIdx.x * 1024 + 4 * t;
+    const long pl = e / hw;
+    const bool ok = pl < planes;
+    const int c = ok ? (int)(pl % C) : 0;
+    const long b = ok ? pl / C : 0;
+    const float* wr = w2 + (long)c * SQ;
+    const float* hr = hidden + b * SQ;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    int j = sub;
+    for (; j + 3 * G < SQ; j += 4 * G) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = fmaf(wr[j + u * G], hr[j + u * G], a[u]);
+    }
+    for (; j < SQ; j += G) a[0] = fmaf(wr[j], hr[j], a[0]);
+    float acc = (a[0] + a[1]) + (a[2] + a[3]);
+    for (int o = 1; o < G; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (!ok) return;
+    const float g = 1.f / (1.f + __expf(-(acc + b2[c])));
+    floatx4 v = *(floatx4*)(y + e);
+    v *= g;
+    *(floatx4*)(y + e) = v;
+}
+
 int check(const DWParams& p, int K, const char* what) {
     SRBH_REQUIRE(K == 3 || K == 5, "%s: kernel size must be 3 or 5", what);
     SRBH_REQUIRE(p.stride == 1 || p.stride == 2, "%s: stride must be 1 or 2", what);
@@ -486,8 +535,12 @@ extern "C" int srbh_affine_act_pool_nchw(const float* x, const float* scale, con
     SRBH_REQUIRE(x && scale && shift && y && pooled, "srbh_affine_act_pool_nchw: null pointer");
     SRBH_REQUIRE(B > 0 && C > 0 && HW > 0 && act >= 0 && act <= 2, "srbh_affine_act_pool_nchw: bad arguments");
     const long planes = (long)B * C;
-    hipLaunchKernelGGL(affine_act_pool_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y,
-                       pooled, planes, C, HW, act);
+    if (HW < 64 && (HW & (HW - 1)) == 0)
+        hipLaunchKernelGGL(affine_act_pool_small_kernel, dim3((unsigned)((planes * HW + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, scale,
+                           shift, y, pooled, planes, C, HW, act);
+    else
+        hipLaunchKernelGGL(affine_act_pool_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y,
+                           pooled, planes, C, HW, act);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }
@@ -506,8 +559,12 @@ extern "C" int srbh_se_gate_scale(float* y, const float* hidden, const float* w2
     SRBH_REQUIRE(y && hidden && w2 && b2, "srbh_se_gate_scale: null pointer");
     SRBH_REQUIRE(B > 0 && C > 0 && SQ > 0 && HW > 0, "srbh_se_gate_scale: bad shape");
     const long planes = (long)B * C;
-    hipLaunchKernelGGL(se_gate_scale_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y, hidden, w2, b2,
-                       planes, C, SQ, HW);
+    if ((HW == 4 || HW == 16 || HW == 64 || HW == 256) && ((uintptr_t)y & 15) == 0)
+        hipLaunchKernelGGL(se_gate_scale_quad_kernel, dim3((unsigned)((planes * HW + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, y, hidden,
+                           w2, b2, planes, C, SQ, HW);
+    else
+        hipLaunchKernelGGL(se_gate_scale_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y, hidden, w2, b2,
+                           planes, C, SQ, HW);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }
