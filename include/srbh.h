@@ -225,6 +225,12 @@ typedef struct srbh_hconv_args {
      * fp16.  Such a tensor is NHWC with 2-byte elements; its *_ld stays in ELEMENTS.  An fp16 src0 takes no pre_scale / pre_relu (the
      * producer applied them), an fp16 out no PixelShuffle store and no statistics; channel counts and strides multiples of 4. */
     int io_h16;
+    /* backward-statistics epilogue (srbh_hconv_h16, the persistent 16 -> 16 3x3 kernel only; SR/HRfuse.py:146-157 in reverse): the conv
+     * output is the gradient da of a = relu(bn(c)).  With bstat_c (the BatchNorm input, NHWC fp32 [B][H][W][16]), the batch mean / invstd
+     * and the folded affine (ms, mh: a > 0 <=> c*ms + mh > 0; both NULL = no ReLU) given, `stats` receives sum(dz) and sum(dz * xhat),
+     * dz = da where the ReLU was active -- exactly what srbh_bn_bwd_reduce computes in a pass of its own (pass the same buffer to
+     * srbh_bn_bwd_finalize).  No res1; cout == 16. */
+    const float* bstat_c; const float* bstat_mean; const float* bstat_invstd; const float* bstat_ms; const float* bstat_mh;
 } srbh_hconv_args;
 #define SRBH_IO_SRC0_H16 1
 #define SRBH_IO_SRC1_H16 2

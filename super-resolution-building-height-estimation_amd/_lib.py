@@ -83,6 +83,7 @@ class HConvArgs(C.Structure):
         ("res2", C.c_void_p), ("res2_ld", C.c_int), ("res2_scale", C.c_float),
         ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("post_relu", C.c_int),
         ("io_h16", C.c_int),
+        ("bstat_c", C.c_void_p), ("bstat_mean", C.c_void_p), ("bstat_invstd", C.c_void_p), ("bstat_ms", C.c_void_p), ("bstat_mh", C.c_void_p),
     ]
 
 

@@ -74,6 +74,15 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
     for (int dx = 0; dx < 3; ++dx) bbase[dx] = (wave * COLS + dx + l15) * 32 + ((kk ^ ((((dx + l15) >> 3) & 1) << 1)) << 3);
 
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    floatx4 b_ms = {0.f, 0.f, 0.f, 0.f}, b_mh = {1.f, 1.f, 1.f, 1.f}, b_mean = {0.f, 0.f, 0.f, 0.f}, b_inv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bstat_c) {
+        b_mean = *(const floatx4*)(p.bstat_mean + kk * 4);
+        b_inv = *(const floatx4*)(p.bstat_invstd + kk * 4);
+        if (p.bstat_ms) {               // (no mask given: every element passes, b_mh = 1 > 0)
+            b_ms = *(const floatx4*)(p.bstat_ms + kk * 4);
+            b_mh = *(const floatx4*)(p.bstat_mh + kk * 4);
+        }
+    }
     typedef typename std::conditional<S16 != 0, float2v, floatx4>::type ldv_t;      // a staging unit in flight: 8 or 16 bytes
     // loads in flight: the fp32 form holds ONE tile ahead (7 x 16 bytes per thread); a 16-bit source is half the bytes per tile, so at
     // the same depth only half the bytes were in flight per CU and the walk ran at the same ~85 us for half the traffic (load latency x
@@ -146,6 +155,11 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
         const long pix0 = ((long)img * p.H + ty * 4 + wave) * p.W + tx * 64 + l15;
         // this tile's residual first, then the next tile's input: the epilogue can wait for the residual alone
         floatx4 rres[4];
+        if (p.bstat_c) {        // backward-statistics epilogue: the BatchNorm input c rides in the residual's registers (host: no res1 then)
+            const float* rp = p.bstat_c + pix0 * 16 + kk * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rres[i] = *(const floatx4*)(rp + i * 16 * 16);
+        }
         if (p.res1) {
             if constexpr (res16) {
                 const char* rp = (const char*)p.res1 + (pix0 * p.res1_ld + kk * 4) * 2;
@@ -192,7 +206,15 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
             }
-            if (p.stats) {
+            if (p.bstat_c) {            // sum(dz), sum(dz * xhat) with dz = v where relu(bn(c)) is active (srbh_bn_bwd_reduce's sums)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float c = rres[i][q];
+                    const float dz = fmaf(c, b_ms[q], b_mh[q]) > 0.f ? v[q] : 0.f;
+                    ssum[q] += dz;
+                    ssq[q] = fmaf(dz, (c - b_mean[q]) * b_inv[q], ssq[q]);
+                }
+            } else if (p.stats) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     ssum[q] += v[q];

@@ -101,6 +101,7 @@ struct HParams {
     const float* res2; int res2_ld; float res2_scale;
     const float* post_scale; const float* post_shift; int post_relu;
     int io_h16;                                        // SRBH_IO_*: which of src0 / src1 / res1 / out hold fp16 elements (OPT 1 only)
+    const float* bstat_c; const float* bstat_mean; const float* bstat_invstd; const float* bstat_ms; const float* bstat_mh;   // hconv16_kernel: backward-statistics epilogue
 };
 
 // NOB = cout/16 (1, 2 or 4), KS = 3 or 1, RPW = output rows per wave (2: 8-row tiles, 54 KiB of LDS, 2 workgroups per CU;
@@ -729,6 +730,10 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
     p.res2 = a->res2; p.res2_ld = a->res2_ld; p.res2_scale = a->res2_scale;
     p.post_scale = a->post_scale; p.post_shift = a->post_shift; p.post_relu = a->post_relu;
     p.io_h16 = a->io_h16;
+    p.bstat_c = a->bstat_c; p.bstat_mean = a->bstat_mean; p.bstat_invstd = a->bstat_invstd; p.bstat_ms = a->bstat_ms; p.bstat_mh = a->bstat_mh;
+    if (a->bstat_c)
+        SRBH_REQUIRE(a->stats && a->bstat_mean && a->bstat_invstd && !a->res1 && a->cout == 16 && (a->bstat_ms == nullptr) == (a->bstat_mh == nullptr) &&
+                     ((uintptr_t)a->bstat_c & 15) == 0, "srbh_hconv: backward-statistics epilogue needs stats, mean, invstd, no residual, cout == 16");
     if (a->io_h16) {
         SRBH_REQUIRE(opt != 0, "srbh_hconv: 16-bit tensors in memory (io_h16) need srbh_hconv_h16 (element type = operand type: fp16 / bf16)");
         SRBH_REQUIRE((a->io_h16 & ~15) == 0, "srbh_hconv_h16: unknown io_h16 bits");
@@ -785,6 +790,7 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
         SRBH_HIP(hipGetLastError());
         return SRBH_OK;
     }
+    SRBH_REQUIRE(!a->bstat_c, "srbh_hconv: the backward-statistics epilogue exists in the persistent 16 -> 16 3x3 kernel only (16-bit operand modes, W %% 64 == 0, H %% 4 == 0)");
     // (the template stages a 16-bit source as it is: no transform on the way)
     SRBH_REQUIRE(!src16 || (!a->pre_scale && !a->pre_relu), "srbh_hconv_h16: a 16-bit src0 takes a pre-affine / ReLU only in the 16 -> 16 3x3 form");
     if (opt == 1) SRBH_H16_DISPATCH(1);
@@ -843,6 +849,7 @@ extern "C" int srbh_hconv_entry_h16(const srbh_hconv_args* c1, const srbh_hconv_
     p.ld0 = ld0; p.ld1 = ld1; p.out_ld = out1_ld; p.out_coff = c1->out_coff;
     p.post_lrelu = 0; p.res1 = nullptr; p.res1_ld = 0; p.res1_scale = 1.f; p.res2 = nullptr; p.res2_ld = 0; p.res2_scale = 1.f;
     p.post_scale = c1->post_scale; p.post_shift = c1->post_shift; p.post_relu = c1->post_relu; p.io_h16 = c1->io_h16 & SRBH_IO_OUT_H16;
+    p.bstat_c = p.bstat_mean = p.bstat_invstd = p.bstat_ms = p.bstat_mh = nullptr;
     p.tiles_x = c1->W / 64;
     p.tiles_per_img = p.tiles_x * (c1->H / 4);
     p.ntiles = p.tiles_per_img * c1->B;

@@ -43,9 +43,10 @@ class _PackedGrad:
         return self.w
 
 
-def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None, h16=False, out_b16=False, res_ld=0):
+def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None, h16=False, out_b16=False, res_ld=0, bstat=None):
     """data-gradient conv (bf16 operands when h16): `srcs[0]` / `res` may be bf16 tensors (internal gradient tensors of a block),
-    out_b16 writes one"""
+    out_b16 writes one.  bstat = (c, mean, invstd, ms, mh, stats): the BatchNorm-backward sums of the conv's OUTPUT in its epilogue
+    (srbh_hconv_args.bstat_*)"""
     L = _lib.lib()
     x0 = srcs[0]
     B, c0, Hh, Ww = x0.shape
@@ -69,6 +70,11 @@ def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None, h1
                 | (8 if out_b16 else 0))
     if a.io_h16 and not h16:
         raise RuntimeError("libsrbh data gradient: bf16 tensors need the bf16-operand mode")
+    if bstat is not None:
+        c, mean, invstd, ms, mh, st = bstat
+        a.bstat_c, a.bstat_mean, a.bstat_invstd = c.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+        a.bstat_ms, a.bstat_mh = (None, None) if ms is None else (ms.data_ptr(), mh.data_ptr())
+        a.stats = st.data_ptr()
     if h16:      # (data gradients: bf16 operands -- fp32's exponent range, no loss scaling needed)
         _lib.check(L.srbh_hconv_h16(C.byref(a), 1, _lib.stream_ptr()), "hconv_h16(bf16)")
     else:
@@ -76,13 +82,22 @@ def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None, h1
     return out
 
 
-def conv_dgrad(g, weight, cache: _PackedGrad, res=None, out_b16=False, res_ld=0, gen_src=None):
+def bstat_fusable(g, weight, c):
+    """can conv_dgrad(g, weight) also produce the BatchNorm-backward sums of its output w.r.t. the BatchNorm input `c`?  (the persistent
+    16 -> 16 3x3 kernel in the 16-bit operand mode, fp32 `c`)"""
+    cout, cin, ks, _ = weight.shape
+    B, _, Hh, Ww = g.shape
+    return (FUSE_BN_REDUCE and H.head_h16() and cout == 16 and cin == 16 and ks == 3 and Ww % 64 == 0 and Hh % 4 == 0 and c.dtype == torch.float32
+            and H.bn_sync_world() <= 1)
+
+
+def conv_dgrad(g, weight, cache: _PackedGrad, res=None, out_b16=False, res_ld=0, gen_src=None, bstat=None):
     """dX = conv^T(g, W) (+ res): the forward kernel with transposed + flipped weights; `res` (NHWC, same shape as dX) is the
     gradient arriving over a skip connection, added in the epilogue instead of by a separate pass.  16-bit operands (bf16:
     gradients need fp32's exponent range) only in the explicit "f16" head precision mode (H.set_head_precision)."""
     cout, cin, ks, _ = weight.shape
     h16 = H.head_h16()
-    return _hconv_raw([g], cache.get(weight, h16, gen_src), None, cin, ks, res=res, h16=h16, out_b16=out_b16 and h16, res_ld=res_ld)
+    return _hconv_raw([g], cache.get(weight, h16, gen_src), None, cin, ks, res=res, h16=h16, out_b16=out_b16 and h16, res_ld=res_ld, bstat=bstat)
 
 
 def conv_wgrad(srcs, pre, g, cout, ks):
@@ -110,6 +125,9 @@ def conv_wgrad(srcs, pre, g, cout, ks):
     return dw
 
 
+FUSE_BN_REDUCE = __import__("os").environ.get("SRBH_FUSE_BN_REDUCE", "1") == "1"      # (0: the separate reduce pass, A/B aid)
+
+
 def _stats_buf(Cc, dev):
     return torch.empty(_lib.lib().srbh_bn_stats_bytes(Cc) // 8, dtype=torch.float64, device=dev)
 
@@ -127,15 +145,16 @@ def channel_sum(g):
     return out
 
 
-def bn_backward(g, c, mean, invstd, gamma, mask, training, relu_ref=None, out_b16=False):
+def bn_backward(g, c, mean, invstd, gamma, mask, training, relu_ref=None, out_b16=False, stats_ready=None):
     """BatchNorm (+ optional ReLU mask [c*ms+mh > 0]) backward.  Returns (dc, dgamma, dbeta).
+    stats_ready: the statistics buffer the producer of `g` filled in its epilogue (conv_dgrad(..., bstat=...)): the reduce pass is skipped.
     relu_ref: the gradient first passes the block-closing ReLU (dz = g where relu_ref > 0) inside the reduce pass; returns
     (dc, dgamma, dbeta, dz).  16-bit tensors (TRAIN_IO16): g may be bf16, c fp16; out_b16 writes dz / dc as bf16."""
     L = _lib.lib()
     B, Cc, Hh, Ww = c.shape
     n = B * Hh * Ww
     dev = c.device
-    st = _stats_buf(Cc, dev)
+    st = _stats_buf(Cc, dev) if stats_ready is None else stats_ready
     ms, mh = (mask[0].data_ptr(), mask[1].data_ptr()) if mask is not None else (None, None)
     dz = None
     vec = Cc % 4 == 0 and 256 % (Cc // 4) == 0
@@ -144,7 +163,9 @@ def bn_backward(g, c, mean, invstd, gamma, mask, training, relu_ref=None, out_b1
     if (io_c or out_b16 or g.dtype == torch.bfloat16) and not vec:
         raise NotImplementedError("libsrbh BatchNorm backward: 16-bit tensors need C % 4 == 0 and 256 % (C/4) == 0")
     odt = torch.bfloat16 if out_b16 else torch.float32
-    if use_io:
+    if stats_ready is not None:
+        assert relu_ref is None
+    elif use_io:
         if relu_ref is not None:
             dz = H.empty_nhwc(B, Cc, Hh, Ww, dev, odt)
         io = io_c | (4 if g.dtype == torch.bfloat16 else 0) | (1 if out_b16 else 0)
@@ -313,9 +334,15 @@ class _BasicBlockFn(torch.autograd.Function):
         # through the final ReLU (folded into bn2's reduce pass) -> bn2 -> conv2
         dc2, dg2, db2, dz = bn_backward(H.to_nhwc(g), c2, m2, i2, g2, None, tr, relu_ref=out, out_b16=b16)
         dw2 = conv_wgrad([c1], (s1, h1, True), dc2, w2.shape[0], 3)
-        da1 = conv_dgrad(dc2, w2, caches[1], out_b16=b16)
-        # relu -> bn1 -> conv1   (mask: bn1(c1) > 0)
-        dc1, dg1, db1 = bn_backward(da1, c1, m1, i1, g1, (s1, h1), tr, out_b16=b16)
+        # relu -> bn1 -> conv1   (mask: bn1(c1) > 0): bn1's backward sums come out of conv2's data-gradient epilogue when that is the
+        # persistent 16 -> 16 kernel (one read of c1 there instead of a reduce pass over da1 and c1)
+        if bstat_fusable(dc2, w2, c1):
+            st1 = _stats_buf(c1.shape[1], c1.device)
+            da1 = conv_dgrad(dc2, w2, caches[1], out_b16=b16, bstat=(c1, m1, i1, s1, h1, st1))
+            dc1, dg1, db1 = bn_backward(da1, c1, m1, i1, g1, (s1, h1), tr, out_b16=b16, stats_ready=st1)
+        else:
+            da1 = conv_dgrad(dc2, w2, caches[1], out_b16=b16)
+            dc1, dg1, db1 = bn_backward(da1, c1, m1, i1, g1, (s1, h1), tr, out_b16=b16)
         dw1 = conv_wgrad(srcs, None, dc1, w1.shape[0], 3)
         need_dx = ctx.needs_input_grad[1] or (nsrc > 1 and ctx.needs_input_grad[2])
         dwd = dgd = dbd = None

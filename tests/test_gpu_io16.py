@@ -90,3 +90,27 @@ def test_bn_add_relu_fp16_tensors():
     c16 = _as16(H, c, torch.float16)
     assert _rel(H.bn_add_relu(c16, k["s1"], k["h1"], out), H.bn_add_relu(c, k["s1"], k["h1"], out)) == 0.0
     assert _rel(H.bn_add_relu(c16, k["s1"], k["h1"], c16, k["gamma"], k["mean"]), H.bn_add_relu(c, k["s1"], k["h1"], c, k["gamma"], k["mean"])) == 0.0
+
+
+@pytest.mark.parametrize("out_b16,with_mask", [(True, True), (False, True), (True, False)])
+def test_bn_backward_sums_from_the_data_gradient_epilogue(out_b16, with_mask):
+    """conv_dgrad(..., bstat=...) (srbh_hconv_args.bstat_*: the persistent 16 -> 16 kernel accumulates sum(dz), sum(dz * xhat) of its OWN
+    output in the epilogue) against the separate srbh_bn_bwd_reduce pass over the same conv's output: the BatchNorm backward that follows
+    must give the same dgamma / dbeta / dc.  (fp32 output: the sums are over identical values, only the summation order differs; bf16
+    output: the epilogue sums the unrounded values, the reduce pass the rounded ones.)"""
+    from srbh_amd import hrfuse_autograd as HA
+    H, g, c, _, k = _setup()
+    cv = torch.nn.Conv2d(16, 16, 3, 1, 1, bias=False).to(DEV)
+    g16 = _as16(H, g, torch.bfloat16)
+    mask = (k["s1"], k["h1"]) if with_mask else None
+    assert HA.bstat_fusable(g16, cv.weight, c)
+    da = HA.conv_dgrad(g16, cv.weight, HA._PackedGrad(), out_b16=out_b16)
+    want = HA.bn_backward(da, c, k["mean"], k["invstd"], k["gamma"], mask, True, out_b16=out_b16)
+    st = HA._stats_buf(16, c.device)
+    da2 = HA.conv_dgrad(g16, cv.weight, HA._PackedGrad(), out_b16=out_b16,
+                        bstat=(c, k["mean"], k["invstd"], None if mask is None else mask[0], None if mask is None else mask[1], st))
+    assert torch.equal(da2, da)                                          # the conv's own output is untouched by the extra epilogue
+    got = HA.bn_backward(da2, c, k["mean"], k["invstd"], k["gamma"], mask, True, out_b16=out_b16, stats_ready=st)
+    tol = 2e-3 if out_b16 else 2e-5
+    assert _rel(got[1], want[1]) <= tol and _rel(got[2], want[2]) <= tol      # dgamma, dbeta
+    assert _rel(got[0], want[0]) <= (3e-3 if out_b16 else 2e-5)               # dc
