@@ -22,7 +22,9 @@
 // 16-bit quads (one rounding in the epilogue; BatchNorm statistics are still taken from the fp32 values).  Used for the fp16
 // activations of the inference chain and for the saved activations (fp16) / internal gradient tensors (bf16) of the training step.
 // IO (compile-time, so that the all-fp32 form keeps its registers): bit 0 = the residual, bit 1 = the output is a 16-bit tensor
-template <int OPT, int S16, int IO>
+// BS (compile-time for the same reason: as a run-time flag the epilogue cost every instantiation 8-20 spilled registers):
+// 0 = none, 1 = BatchNorm-backward sums with the c*ms + mh mask (c in the residual's registers)
+template <int OPT, int S16, int IO, int BS = 0>
 __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
     static_assert(OPT == 1 || OPT == 2, "16-bit operand forms only");
     constexpr int ROWS = 6, COLS = 66, NIT = (ROWS * COLS * 4 + 255) / 256;        // 7 staging units per thread (the last one partial)
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
 
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
     floatx4 b_ms = {0.f, 0.f, 0.f, 0.f}, b_mh = {1.f, 1.f, 1.f, 1.f}, b_mean = {0.f, 0.f, 0.f, 0.f}, b_inv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bstat_c) {
+    if constexpr (BS != 0) {
         b_mean = *(const floatx4*)(p.bstat_mean + kk * 4);
         b_inv = *(const floatx4*)(p.bstat_invstd + kk * 4);
         if (p.bstat_ms) {               // (no mask given: every element passes, b_mh = 1 > 0)
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
         const long pix0 = ((long)img * p.H + ty * 4 + wave) * p.W + tx * 64 + l15;
         // this tile's residual first, then the next tile's input: the epilogue can wait for the residual alone
         floatx4 rres[4];
-        if (p.bstat_c) {        // backward-statistics epilogue: the BatchNorm input c rides in the residual's registers (host: no res1 then)
+        if constexpr (BS == 1) { // backward-statistics epilogue: the BatchNorm input c rides in the residual's registers (host: no res1 then)
             const float* rp = p.bstat_c + pix0 * 16 + kk * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) rres[i] = *(const floatx4*)(rp + i * 16 * 16);
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
             }
-            if (p.bstat_c) {            // sum(dz), sum(dz * xhat) with dz = v where relu(bn(c)) is active (srbh_bn_bwd_reduce's sums)
+            if constexpr (BS == 1) { // sum(dz), sum(dz * xhat) with dz = v where relu(bn(c)) is active (srbh_bn_bwd_reduce's sums)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float c = rres[i][q];

@@ -781,6 +781,17 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
 #define SRBH_K16(O_, S_, I_) hipLaunchKernelGGL((hconv16_kernel<O_, S_, I_>), dim3(per_xcd * 8), dim3(256), LDS16, st, p)
 #define SRBH_K16_IO(O_, S_) do { switch (io) { case 0: SRBH_K16(O_, S_, 0); break; case 1: SRBH_K16(O_, S_, 1); break; \
                                                case 2: SRBH_K16(O_, S_, 2); break; default: SRBH_K16(O_, S_, 3); } } while (0)
+        if (a->bstat_c) {       // backward-statistics epilogues: the bf16-operand (data gradient) forms only
+            SRBH_REQUIRE(opt == 2, "srbh_hconv_h16: the backward-statistics epilogue belongs to the bf16 data-gradient form");
+#define SRBH_K16_BS(S_, I_) hipLaunchKernelGGL((hconv16_kernel<2, S_, I_, 1>), dim3(per_xcd * 8), dim3(256), LDS16, st, p)
+            if (src16 && o16) SRBH_K16_BS(1, 2);
+            else if (src16) SRBH_K16_BS(1, 0);
+            else if (o16) SRBH_K16_BS(0, 2);
+            else SRBH_K16_BS(0, 0);
+#undef SRBH_K16_BS
+            SRBH_HIP(hipGetLastError());
+            return SRBH_OK;
+        }
         if (opt == 1 && !src16) SRBH_K16_IO(1, 0);
         else if (opt == 1) SRBH_K16_IO(1, 1);
         else if (!src16) SRBH_K16_IO(2, 0);
