@@ -317,6 +317,23 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
         totals["covered_ms_per_step"] = round(cum, 3)
         totals["kernels"] = top
         line["head_roofline"] = totals
+        # the encoder / decoder calls of the same step (libsrbh entry points only: the decoders' 3x3 convs are MIOpen's), same method
+        with KernelProfile(group="encdec") as kp2:
+            for _ in range(2):
+                ts(fixed)
+        rows2, tot2 = kp2.table(steps=2)
+        agg = {}
+        for r in rows2:                                   # per entry point (the per-shape rows are ~300: one per layer and direction)
+            a = agg.setdefault(r["kernel"].split(" ")[0], [0.0, 0.0, 0.0])
+            a[0] += r["calls_per_step"]
+            a[1] += r["ms_per_step"]
+            a[2] += r["algorithmic_MB_per_call"] * r["calls_per_step"]
+        tot2["by_entry_point"] = [{"entry": k, "calls_per_step": round(v[0], 1), "ms_per_step": round(v[1], 3), "us_per_call": round(v[1] / max(v[0], 1e-9) * 1e3, 1),
+                                   "algorithmic_MB_per_step": round(v[2], 1)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])]
+        tot2["note"] = ("libsrbh encoder / decoder calls of the step (training BatchNorm + activation, squeeze-excite, 1x1 and depthwise convs, "
+                        "upsample + concat), HIP events around each call; planes are 2x2 .. 64x64, so these are latency chains of 5-25 us: "
+                        "the HBM fraction is small by construction and is NOT their roofline (DESIGN.md 3.10); MIOpen's 3x3 decoder convs are not in this table")
+        line["encdec_kernels"] = tot2
     if with_cpu and world == 1:
         line["cpu_baseline"] = cpu_baseline_train(sd)
     return line

@@ -281,7 +281,7 @@ extern "C" int srbh_pwconv_fwd_wt(const float* x, const float* wt, float* y, int
 
 extern "C" int srbh_transpose_many(const srbh_transpose_desc* table_dev, int n, void* stream) {
     SRBH_REQUIRE(table_dev && n > 0 && n <= 65535, "srbh_transpose_many: bad arguments");
-    hipLaunchKernelGGL(transpose_many_kernel, dim3(32, n), dim3(256), 0, (hipStream_t)stream, table_dev);
+    hipLaunchKernelGGL(transpose_many_kernel, dim3(256, n), dim3(256), 0, (hipStream_t)stream, table_dev);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }

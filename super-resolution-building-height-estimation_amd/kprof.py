@@ -117,19 +117,55 @@ def _model(name, args):
     if name == "srbh_cedice_grad":
         Bn, Cc, hw = args[1], args[2], args[3]
         return f"loss cedice_grad C={Cc}", Bn * hw * (8 * Cc + 12)
+    return _model_encdec(name, args)
+
+
+def _model_encdec(name, args):
+    """encoder / decoder calls (group "encdec"): planes of 2x2 .. 64x64 -- latency chains, priced with their bytes all the same"""
+    if name in ("srbh_bn_act_train_fwd", "srbh_bn_act_train_bwd"):
+        a = args[0]._obj
+        n = a.B * a.C * a.HW * 4
+        if name.endswith("fwd"):
+            return (f"bn_act_train_fwd act={a.act}{' +res' if a.res else ''}{' +pool' if a.pooled else ''} C={a.C} HW={a.HW}", n * (3 if a.res else 2))
+        return f"bn_act_train_bwd act={a.act}{' +gate' if a.gate else ''} C={a.C} HW={a.HW}", n * (3 if a.dx else 2)
+    if name == "srbh_se_train_fwd":
+        B, Cc, SQ, HW = args[9], args[10], args[11], args[12]
+        return f"se_train_fwd C={Cc} SQ={SQ} HW={HW}", B * Cc * HW * 8 + 2 * Cc * SQ * 4
+    if name == "srbh_se_train_bwd":
+        B, Cc, SQ, HW = args[18], args[19], args[20], args[21]
+        return f"se_train_bwd C={Cc} SQ={SQ} HW={HW}", B * Cc * HW * 8 + 4 * Cc * SQ * 4
+    if name in ("srbh_pwconv_fwd", "srbh_pwconv_fwd_wt", "srbh_pwconv_bwd_data"):
+        B, Cin, Cout, HW = args[3], args[4], args[5], args[6]
+        return f"{name[5:]} {Cin}->{Cout} HW={HW}", (B * HW * (Cin + Cout) + Cin * Cout) * 4
+    if name == "srbh_pwconv_bwd_weight":
+        B, Cin, Cout, HW = args[4], args[5], args[6], args[7]
+        return f"pwconv_bwd_weight {Cin}->{Cout} HW={HW}", (B * HW * (Cin + Cout) + Cin * Cout) * 4
+    if name in ("srbh_dwconv_fwd", "srbh_dwconv_bwd_data"):
+        B, Cc, Hh, Ww, K, st, OH, OW = args[3], args[4], args[5], args[6], args[7], args[8], args[11], args[12]
+        return f"{name[5:]} C={Cc} k{K} s{st} @{Hh}x{Ww}", B * Cc * (Hh * Ww + OH * OW) * 4
+    if name == "srbh_dwconv_bwd_weight":
+        B, Cc, Hh, Ww, K, st, OH, OW = args[4], args[5], args[6], args[7], args[8], args[9], args[12], args[13]
+        return f"dwconv_bwd_weight C={Cc} k{K} s{st} @{Hh}x{Ww}", B * Cc * (Hh * Ww + OH * OW) * 4
+    if name in ("srbh_up2_cat_fwd", "srbh_up2_cat_bwd"):
+        B, Cx, Cs, Hh, Ww = args[3], args[4], args[5], args[6], args[7]
+        return f"{name[5:]} {Cx}+{Cs} @{Hh}x{Ww}", B * (Cx * Hh * Ww + (Cx + 2 * Cs) * 4 * Hh * Ww) * 4
+    if name == "srbh_transpose_many":
+        return "transpose_many (all 1x1 weights)", 0
     return None
 
 
 class KernelProfile:
-    def __init__(self):
+    def __init__(self, group="head"):
+        """group: "head" = the head / loss entry points (the whole-head roofline); "encdec" = the encoder / decoder entry points"""
         self.calls = []          # (desc, bytes, ev0, ev1)
         self._saved = {}
+        self.group = group
 
     def __enter__(self):
         L = _lib.lib()
         for name in _lib.SIGNATURES:
             fn = getattr(L, name)
-            if _model_names(name):
+            if _model_names(name) if self.group == "head" else _encdec_names(name):
                 self._saved[name] = fn
                 setattr(L, name, self._wrap(name, fn))
         return self
@@ -184,3 +220,9 @@ class KernelProfile:
 def _model_names(name):
     return name.startswith(("srbh_hconv_f32", "srbh_hconv_h16", "srbh_hconv_entry", "srbh_hconv_wgrad", "srbh_bn_", "srbh_relu_mask",
                             "srbh_add_inplace", "srbh_ps2_inverse", "srbh_nchw_to_nhwc", "srbh_wmse", "srbh_cedice"))
+
+
+def _encdec_names(name):
+    return name.startswith(("srbh_bn_act_train_fwd", "srbh_bn_act_train_bwd", "srbh_se_train_fwd", "srbh_se_train_bwd", "srbh_pwconv_fwd",
+                            "srbh_pwconv_bwd_data", "srbh_pwconv_bwd_weight", "srbh_dwconv_fwd", "srbh_dwconv_bwd_data", "srbh_dwconv_bwd_weight",
+                            "srbh_up2_cat", "srbh_transpose_many")) and not name.endswith(("_supported", "_ws_bytes", "_ws_floats", "_splits"))
