@@ -35,6 +35,8 @@ def _hconv_bytes(a, opt16):
         n += px * a.cout * e(4)
     if a.res2:
         n += px * a.cout * 4
+    if getattr(a, "bstat_c", None):               # backward-statistics epilogue: one more fp32 tensor read
+        n += px * a.cout * 4
     return n
 
 
@@ -43,7 +45,7 @@ def _desc_hconv(name, a):
     if a.pixelshuffle2:
         t += " ps2"
     if a.stats:
-        t += " +stats"
+        t += " +bwd-stats" if getattr(a, "bstat_c", None) else " +stats"
     if a.res1:
         t += " +res"
     if a.io_h16:
@@ -218,6 +220,8 @@ class KernelProfile:
 
 
 def _model_names(name):
+    if name.startswith("srbh_bn_act_train"):       # (encoder / decoder BatchNorm: group "encdec")
+        return False
     return name.startswith(("srbh_hconv_f32", "srbh_hconv_h16", "srbh_hconv_entry", "srbh_hconv_wgrad", "srbh_bn_", "srbh_relu_mask",
                             "srbh_add_inplace", "srbh_ps2_inverse", "srbh_nchw_to_nhwc", "srbh_wmse", "srbh_cedice"))
 
