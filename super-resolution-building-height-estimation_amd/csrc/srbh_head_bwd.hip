@@ -691,6 +691,28 @@ __global__ void ps2_inverse_kernel(const float* __restrict__ gps, float* __restr
     g[idx] = gps[(((long)b * 2 * H + 2 * y + i) * (2 * W) + 2 * x + j) * C + cc];
 }
 
+// the same permutation, 16 elements per thread (C % 4 == 0): a thread takes 4 channels of the 4 sub-pixels of one output pixel as four
+// 16-byte loads, transposes 4x4 in registers and writes 16 consecutive output channels as four 16-byte stores (the one-element form
+// spends ~30 integer instructions per 4 bytes: 226 us for 537 MB)
+__global__ __launch_bounds__(256) void ps2_inverse4_kernel(const float* __restrict__ gps, float* __restrict__ g, long total, int H, int W, int C) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int C4 = C >> 2;
+    const int cq = (int)(idx % C4);
+    long r = idx / C4;
+    const int x = (int)(r % W);
+    r /= W;
+    const int y = (int)(r % H);
+    const long b = r / H;
+    floatx4 v[4];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+        v[sub] = *(const floatx4*)(gps + (((b * 2 * H + 2 * y + (sub >> 1)) * (2 * W) + 2 * x + (sub & 1)) * C + 4 * cq));
+    float* o = g + (((b * H + y) * W + x) * 4L * C + 16 * cq);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *(floatx4*)(o + 4 * k) = floatx4{v[0][k], v[1][k], v[2][k], v[3][k]};
+}
+
 int grid_for(long n) {
     long b = (n + 255) / 256;
     return (int)(b < 2048 ? (b > 0 ? b : 1) : 2048);
@@ -980,6 +1002,12 @@ extern "C" int srbh_bn_bwd_apply(const float* g, const float* c, const float* me
 extern "C" int srbh_ps2_inverse(const float* g_ps, float* g, int B, int H, int W, int C, void* stream) {
     SRBH_REQUIRE(g_ps && g && B > 0 && H > 0 && W > 0 && C > 0, "srbh_ps2_inverse: bad arguments");
     long total = (long)B * H * W * 4 * C;
+    if ((C & 3) == 0 && (((uintptr_t)g_ps | (uintptr_t)g) & 15) == 0) {
+        const long n16 = total / 16;
+        hipLaunchKernelGGL(ps2_inverse4_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_ps, g, n16, H, W, C);
+        SRBH_HIP(hipGetLastError());
+        return SRBH_OK;
+    }
     hipLaunchKernelGGL(ps2_inverse_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_ps, g, B, H, W, C);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;

@@ -114,3 +114,13 @@ def test_bn_backward_sums_from_the_data_gradient_epilogue(out_b16, with_mask):
     tol = 2e-3 if out_b16 else 2e-5
     assert _rel(got[1], want[1]) <= tol and _rel(got[2], want[2]) <= tol      # dgamma, dbeta
     assert _rel(got[0], want[0]) <= (3e-3 if out_b16 else 2e-5)               # dc
+
+
+@pytest.mark.parametrize("Bn,Cc,Hh,Ww", [(2, 16, 8, 12), (1, 4, 3, 5), (2, 6, 4, 4)])
+def test_ps2_inverse_is_pixel_unshuffle(Bn, Cc, Hh, Ww):
+    """srbh_ps2_inverse (the gradient's way back through nn.PixelShuffle(2), SR/HRfuse.py:23) == F.pixel_unshuffle, bit for bit: the
+    16-elements-per-thread form (C % 4 == 0) and the one-element form (C = 6)"""
+    from srbh_amd import hrfuse as H, hrfuse_autograd as HA
+    g = torch.randn(Bn, Cc, 2 * Hh, 2 * Ww, device=DEV)
+    got = HA.ps2_inverse(H.to_nhwc(g))
+    assert torch.equal(got, torch.nn.functional.pixel_unshuffle(g, 2))
