@@ -181,6 +181,9 @@ def _make_nets(args, dev, isaggre):
     return sd, net_hr.to(dev), net.to(dev)
 
 
+_DETAILS = {}          # full per-call tables of the run (written by --details; the printed line carries the top rows only)
+
+
 def _max_over_ranks(vals, dev, dist):
     if dist is None:
         return vals
@@ -305,19 +308,16 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
             for _ in range(2):
                 ts(fixed)
         rows, totals = kp.table(steps=2)
-        cum, top = 0.0, []
-        for r in rows:
-            top.append(r)
-            cum += r["ms_per_step"]
-            if cum >= 0.92 * totals["ms_per_step"] and len(top) >= 8:
-                break
-        totals["note"] = ("every libsrbh head / loss call of the step (HIP events around each call; a weight gradient = its 3 launches); "
-                          "`kernels` lists the top calls covering >= 92 % of that time; bytes = each tensor read or written once at its "
-                          "stored element size; peak 8000 GB/s")
-        totals["covered_ms_per_step"] = round(cum, 3)
+        top = rows[:8]
+        totals["note"] = ("every libsrbh head / loss call of the step (HIP events around each call); `kernels` = the 8 largest "
+                          "(all rows: --details / profiles/); bytes = each tensor once at its stored element size; peak 8000 GB/s")
+        totals["covered_ms_per_step"] = round(sum(r["ms_per_step"] for r in top), 3)
         totals["kernels"] = top
+        _DETAILS["head_roofline_rows"] = rows
         line["head_roofline"] = totals
         # the encoder / decoder calls of the same step (libsrbh entry points only: the decoders' 3x3 convs are MIOpen's), same method
+        from srbh_amd import encoders as _E0
+        _E0.stock_ops_reset()
         with KernelProfile(group="encdec") as kp2:
             for _ in range(2):
                 ts(fixed)
@@ -328,11 +328,17 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
             a[0] += r["calls_per_step"]
             a[1] += r["ms_per_step"]
             a[2] += r["algorithmic_MB_per_call"] * r["calls_per_step"]
-        tot2["by_entry_point"] = [{"entry": k, "calls_per_step": round(v[0], 1), "ms_per_step": round(v[1], 3), "us_per_call": round(v[1] / max(v[0], 1e-9) * 1e3, 1),
+        from srbh_amd import encoders as _E
+        tot2["stock_ops"] = _E.stock_ops_summary()
+        tot2["stock_ops"]["note"] = ("encoder / decoder call sites that ran stock PyTorch-ROCm ops (MIOpen / ATen) in the 2 profiled steps, "
+                                     "counted per (site, shape) in encoders.STOCK_OPS: no silent fallback")
+        by_entry = [{"entry": k, "calls_per_step": round(v[0], 1), "ms_per_step": round(v[1], 3), "us_per_call": round(v[1] / max(v[0], 1e-9) * 1e3, 1),
                                    "algorithmic_MB_per_step": round(v[2], 1)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])]
-        tot2["note"] = ("libsrbh encoder / decoder calls of the step (training BatchNorm + activation, squeeze-excite, 1x1 and depthwise convs, "
-                        "upsample + concat), HIP events around each call; planes are 2x2 .. 64x64, so these are latency chains of 5-25 us: "
-                        "the HBM fraction is small by construction and is NOT their roofline (DESIGN.md 3.10); MIOpen's 3x3 decoder convs are not in this table")
+        tot2["by_entry_point"] = by_entry[:5]
+        _DETAILS["encdec_by_entry_point"] = by_entry
+        _DETAILS["encdec_rows"] = rows2
+        tot2["note"] = ("libsrbh encoder / decoder calls of the step, HIP events around each call; top 5 entry points (all: --details); "
+                        "planes are 2x2 .. 64x64: latency chains, the HBM fraction is not their roofline (DESIGN.md 3.10)")
         line["encdec_kernels"] = tot2
     if with_cpu and world == 1:
         line["cpu_baseline"] = cpu_baseline_train(sd)
@@ -588,6 +594,7 @@ def bench_feature(args, rank, world, dev, dist):
         del net.precision
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())      # noqa: E731
     parity = {"output": "forward_feature of 1 tile (64 x 256 x 256)", "tolerance_rel_l2": 1e-3,
+              "weights": "random-init (synth 'init' mode: kaiming x 0.1 on the dense-block convs); no trained checkpoint exists offline (SURVEY D8)",
               "vs_strict_f32_gpu_path": {"rel_l2": round(rel(y_fast, y_strict), 7),
                                          "rmse": round(float((y_fast - y_strict).pow(2).mean().sqrt()), 7)},
               "vs_cpu_oracle": None}
@@ -617,6 +624,10 @@ def main():
     ap.add_argument("--num-block", type=int, default=23)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="default run: skip the train_step / predict sub-objects")
+    ap.add_argument("--epoch-tiles", type=int, default=31500,
+                    help="--workload epoch: tiles of the pass (default 31 500 = 45 000 x 0.7, data/datalist_globe_train_0.7.csv); drop_last")
+    ap.add_argument("--details", default=None,
+                    help="write the FULL per-call tables (head_roofline / encdec_kernels rows) to this JSON file; the printed line keeps the top rows")
     ap.add_argument("--workload", choices=["feature", "train", "predict", "epoch", "sr_train"], default="feature",
                     help="feature = BASELINE configs[1] (default; carries bounded train_step / predict sub-objects); train = "
                          "configs[2]: full training step, batch 64; epoch = configs[3]: one DP pass over 31 500 synthetic tiles; "
@@ -653,7 +664,8 @@ def main():
         line = bench_train(args, rank, world, dev, dist, args.steps, args.warmup, batch=tb, with_kernels=not args.no_extras,
                            with_cpu=not (args.no_extras or args.no_cpu_baseline))
     elif args.workload == "epoch":
-        line = bench_train(args, rank, world, dev, dist, 0, args.warmup, batch=tb, epoch_tiles=31500, with_kernels=False)
+        line = bench_train(args, rank, world, dev, dist, 0, args.warmup, batch=tb, epoch_tiles=args.epoch_tiles, with_kernels=False,
+                           with_cpu=False)
     elif args.workload == "predict":
         line = bench_predict(args, rank, world, dev, dist, args.steps, args.warmup, batch=pb)
     elif args.workload == "sr_train":
@@ -672,7 +684,29 @@ def main():
                 torch.cuda.empty_cache()
             if line is not None:
                 line.update(extras)
+                # the driver keeps the TAIL of this line: the figures a reader needs from the sub-objects, once more, last
+                t, p_ = extras.get("train_step") or {}, extras.get("predict") or {}
+                par = (line.get("parity") or {}).get("vs_cpu_oracle") or {}
+                line["summary"] = {
+                    "feature_b32": {"tiles_per_s": line["value"], "ms_per_step": line["ms_per_step"], "trunk_frac_mfma_peak": line["roofline"]["frac"],
+                                    "trunk_ms": line["roofline"]["avg_launch_ms"], "rel_l2_vs_cpu_oracle": par.get("rel_l2"),
+                                    "weights": "random-init (no trained checkpoint offline)"},
+                    "train_step_b64": {"error": t["error"]} if "error" in t else {
+                        "credited_strict_f32_head": {"ms_per_step": (t.get("strict_f32_head") or {}).get("ms_per_step"),
+                                                     "tiles_per_s": (t.get("strict_f32_head") or {}).get("value")},
+                        "fast_mode_f16_head": {"ms_per_step": t.get("ms_per_step"), "tiles_per_s": t.get("value")},
+                        "head_frac_hbm_peak": (t.get("head_roofline") or {}).get("frac_hbm_peak"),
+                        "head_ms": (t.get("head_roofline") or {}).get("ms_per_step"),
+                        "encdec_libsrbh_ms": (t.get("encdec_kernels") or {}).get("ms_per_step"),
+                        "encdec_stock_op_calls_2steps": ((t.get("encdec_kernels") or {}).get("stock_ops") or {}).get("calls"),
+                        "cpu_baseline_tiles_per_s": (t.get("cpu_baseline") or {}).get("value")},
+                    "predict_30_of_301_cities": {"error": p_["error"]} if "error" in p_ else {
+                        "tiles_per_s": p_.get("value"), "p50_city_latency_ms": p_.get("p50_city_latency_ms")},
+                }
     if rank == 0:
+        if args.details and _DETAILS:
+            with open(args.details, "w") as f:
+                json.dump(_DETAILS, f, indent=1)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -568,12 +568,16 @@ __device__ __forceinline__ double wg_sum_double(double v, double* red, int t) {
 __global__ __launch_bounds__(256) void bn_large_stats_kernel(const float* __restrict__ x, double* __restrict__ part, int B, int C, int HW, int S) {
     __shared__ double red[4];
     const int c = blockIdx.x, sp = blockIdx.y, t = threadIdx.x, n4 = HW >> 2;
+    // sums of (x - pivot), pivot = the channel's first element (the same value in every workgroup of the channel): E[x^2] - mean^2 on
+    // raw fp32 sums loses (mean/std)^2 * 1e-7 of the variance for channels whose mean is far from 0 (round-3 ADVICE); shifted sums
+    // do not, at one subtraction per element
+    const float pivot = x[(long)c * HW];
     float s = 0.f, q = 0.f;
 #pragma unroll 4
     for (int b = sp; b < B; b += S) {
         const floatx4* pl = (const floatx4*)(x + ((long)b * C + c) * HW);
         for (int i = t; i < n4; i += 256) {
-            const floatx4 v = pl[i];
+            const floatx4 v = pl[i] - pivot;
             s += (v[0] + v[1]) + (v[2] + v[3]);
             q = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], q))));
         }
@@ -596,8 +600,8 @@ __global__ __launch_bounds__(256) void bn_large_apply_kernel(const FwdP p, const
         ds += part[((long)c * S + k) * 2];
         dq += part[((long)c * S + k) * 2 + 1];
     }
-    const double n = (double)p.B * (double)p.HW, dmean = ds / n;
-    double dvar = dq / n - dmean * dmean;
+    const double n = (double)p.B * (double)p.HW, dshift = ds / n, dmean = (double)p.x[(long)c * p.HW] + dshift;      // (pivot: bn_large_stats_kernel)
+    double dvar = dq / n - dshift * dshift;
     dvar = dvar > 0.0 ? dvar : 0.0;
     const float mean = (float)dmean, var = (float)dvar, invstd = 1.f / sqrtf(var + p.eps);
     if (b == 0 && t == 0) {

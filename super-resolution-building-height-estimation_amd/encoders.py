@@ -44,6 +44,31 @@ _SMP_STAGES = {
 BN_MOM, BN_EPS = 0.01, 1e-3
 DROP_CONNECT = 0.2
 
+# "no silent fallback".  a18 may run stock ops, but which call sites of a DEVICE forward took them is counted
+# here -- key (site, shape) -> calls -- so that a hot shape sliding back to MIOpen / ATen shows up as a count (bench.py prints
+# `encdec_kernels.stock_ops`), not only as time.  CPU tensors are the oracle-side path and are not counted.
+STOCK_OPS: dict = {}
+
+
+def _stock(site, x):
+    if x.is_cuda:
+        k = (site, tuple(x.shape[1:]))
+        STOCK_OPS[k] = STOCK_OPS.get(k, 0) + 1
+
+
+def stock_ops_reset():
+    STOCK_OPS.clear()
+
+
+def stock_ops_summary(top=6):
+    """{'calls': total, 'by_site': {site: calls}, 'top': [[site, shape, calls], ...]} of the device forwards since the last reset"""
+    by = {}
+    for (site, _), n in STOCK_OPS.items():
+        by[site] = by.get(site, 0) + n
+    rows = sorted(STOCK_OPS.items(), key=lambda kv: -kv[1])[:top]
+    return {"calls": sum(STOCK_OPS.values()), "by_site": dict(sorted(by.items(), key=lambda kv: -kv[1])),
+            "top": [[s, list(shape), n] for (s, shape), n in rows]}
+
 
 def _round_filters(f, width, divisor=8):
     f *= width
@@ -212,6 +237,7 @@ def bn_act(bn, x, act=None, res=None, drop=None):
         _lib.check(_lib.lib().srbh_affine_act_nchw(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, C, H * W,
                                                    _ACT[act], _lib.stream_ptr()), "affine_act_nchw")
         return y
+    _stock("batch_norm_train" if bn.training else "batch_norm_eval", x)
     if bn.training and type(bn) is nn.BatchNorm2d and bn.track_running_stats and bn.momentum is not None:
         # the module's own forward, minus its per-module `num_batches_tracked.add_(1)` launch (hrfuse.note_batch: one fused
         # increment per model forward); SyncBatchNorm and exotic configurations keep the module call
@@ -309,6 +335,7 @@ class SamePadConv2d(nn.Conv2d):
                         self.weight._version, self.weight.data_ptr(), wcache.gen(self.weight))):
                     wt = None
                 return _PointwiseConvFn.apply(x, self.weight, wt)
+        _stock("conv%dx%d%s" % (self.kernel_size[0], self.kernel_size[1], "_dw" if self.groups > 1 else ""), x)
         return F.conv2d(self.static_padding(x), self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
 
 
@@ -359,6 +386,7 @@ class MBConvBlock(nn.Module):
             x = bn_swish_se(self._bn1, x, self._se_reduce, self._se_expand)
         else:
             x = bn_act(self._bn1, x, "silu")
+            _stock("squeeze_excite", x)
             s = F.adaptive_avg_pool2d(x, 1)
             s = self._se_expand(_swish(self._se_reduce(s)))
             x = torch.sigmoid(s) * x
@@ -475,6 +503,7 @@ class _ConvBnRelu(nn.Sequential):
         self._bn = use_batchnorm
 
     def forward(self, x):
+        _stock("decoder_conv3x3", x)             # (MIOpen; the libsrbh form is the next step: DESIGN.md 3.10)
         if self._bn:
             return bn_act(self[1], self[0](x), "relu")
         return super().forward(x)
@@ -507,6 +536,7 @@ class DecoderBlock(nn.Module):
                 if skip is not None:
                     x = self.attention1(x)
                 return self.attention2(self.conv2(self.conv1(x)))
+        _stock("up2_cat", x)
         x = F.interpolate(x, scale_factor=2, mode="nearest")
         if skip is not None:
             x = self.attention1(torch.cat([x, skip], dim=1))

@@ -144,7 +144,9 @@ class GradReducer:
         it; a rank whose SET of gradient-receiving parameters differs raises instead of averaging unrelated gradients."""
         index = {id(p): i for i, p in enumerate(self.params)}
         mine = [index[id(p)] for p in self._order]
-        dev = self._order[0].device if self._order else torch.device("cpu")
+        # (the device of the PARAMETERS, also on a rank that received no gradient: a CPU control tensor under RCCL raises or hangs
+        # before the intended "ranks disagree" error -- round-3 ADVICE)
+        dev = self.params[0].device if self.params else torch.device("cpu")
         n = torch.tensor([len(mine)], dtype=torch.int64, device=dev)
         self.dist.broadcast(n, src=0)
         ref = torch.tensor(mine if len(mine) == int(n) else [0] * int(n), dtype=torch.int64, device=dev)
@@ -394,6 +396,28 @@ def synthetic_batch_device(batch, gen, device, aggregate=None):
     coarse = torch.rand((batch, 1, 32, 32), generator=gen, device=device)
     hval = torch.rand((batch, 1, 32, 32), generator=gen, device=device) ** 3 * 120.0
     height = torch.where(coarse > 0.82, hval, torch.zeros_like(hval))
+    height = F.interpolate(height, scale_factor=8, mode="nearest").round()
+    edges = torch.tensor(HIR[1:-1], dtype=torch.float32, device=device)
+    build = torch.bucketize(height[:, 0], edges, right=True)
+    build = torch.where(height[:, 0] <= 0, torch.zeros_like(build), build).long().clamp_(0, 6)
+    weight = torch.tensor(CLASS_WEIGHT, device=device)[build]
+    if aggregate is None:
+        from .aggregate import aggregate_torch as aggregate
+    height_aggre = aggregate(height, 0.25).reshape(batch, 64, 64)
+    weight_aggre = aggregate(weight[:, None].contiguous(), 0.25).reshape(batch, 64, 64)
+    return lr, height[:, 0], height_aggre, build, weight, weight_aggre
+
+
+def learnable_batch_device(batch, gen, device, aggregate=None):
+    """`synthetic_batch_device` with labels that are a FUNCTION of the tile (the stock synthetic labels are independent of it, so a
+    network can only learn their mean): height = blocky 8x8-HR-pixel map of the 2x2-LR-pixel mean of the three RRDB input channels,
+    thresholded so that ~82 % of the pixels are ground (the reference's label statistics, bh_stats_globe.csv:2).  Used by the
+    strict-vs-mixed convergence A/B (tools/convergence_ab.py, tests/test_gpu_convergence_ab.py): there the loss has to FALL for a
+    reason, and how far it falls can be compared between precision modes."""
+    lr = torch.rand((batch, 8, 64, 64), generator=gen, device=device)
+    v = F.avg_pool2d(lr[:, :3].mean(1, keepdim=True), 2)                  # (B,1,32,32): mean of 12 uniforms, std 0.0833
+    z = (v - 0.5) / 0.08333
+    height = torch.where(z > 0.915, (z - 0.915) * 40.0 + 3.0, torch.zeros_like(z)).clamp_(0, 255)
     height = F.interpolate(height, scale_factor=8, mode="nearest").round()
     edges = torch.tensor(HIR[1:-1], dtype=torch.float32, device=device)
     build = torch.bucketize(height[:, 0], edges, right=True)

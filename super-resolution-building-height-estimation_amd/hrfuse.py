@@ -102,11 +102,11 @@ def head_h16():
     return m == "f16" or (m == "auto" and not torch.is_grad_enabled() and _HEAD_PRECISION["depth"] == 0)
 
 
-# fp16 ACTIVATIONS in memory between the convs of an inference chain (BasicBlock.forward_nhwc; SRBH_FP16_ACT=1 or this flag).  OFF by
-# default: it halves the bytes every head conv moves (32 + 32 instead of 64 + 64 per pixel; height maps 4e-4 from the fp32-tensor
-# chain, inside the 1e-3 tolerance) and is 3 % SLOWER -- measured A/B in one process at B=128: model forward 15.0 vs 14.55 ms.  The
-# head kernels are not bound by bytes but by their one-tile-per-workgroup structure; the flag is what a persistent
-# kernel will want, and stays covered by tests/test_gpu_head_f16.py.
+# fp16 ACTIVATIONS in memory between the convs of an inference chain (BasicBlock.forward_nhwc; SRBH_FP16_ACT=0 switches it off).  ON by
+# default since round 3: it halves the bytes every head conv moves (32 + 32 instead of 64 + 64 per pixel; height maps 4e-4 from the
+# fp32-tensor chain, inside the 1e-3 tolerance).  History: with the round-2 one-tile-per-workgroup kernels it measured 3 % SLOWER
+# (model forward 15.0 vs 14.55 ms at B=128); on the persistent double-buffered hconv16 forms of round 3 it is +3.7 % tiles/s on the
+# tiled predict path, hence the default.  Covered by tests/test_gpu_head_f16.py in both settings.
 FP16_ACTIVATIONS = _os.environ.get("SRBH_FP16_ACT", "1") == "1"
 
 # 16-bit tensors INSIDE a BasicBlock of the training step (hrfuse_autograd._BasicBlockFn, mixed-precision mode "f16" only; round 3).

@@ -231,10 +231,14 @@ class RRDBNet(nn.Module):
             holder.refs.append(ws)
             ref = __import__("weakref").ref(self)
 
-            def unpin(ref=ref, key=key):
+            def unpin(ref=ref, key=key, ws_id=id(ws), pins_id=id(pins)):
+                # only the pin table AND the workspace this holder pinned: after _apply() (.to() / .half(): fresh table, fresh
+                # workspaces) an old graph's release must not drop a NEW graph's pin under the same key (round-3 ADVICE)
                 me = ref()
                 if me is not None:
                     p = me.__dict__.get("_ws_pins", {})
+                    if id(p) != pins_id or id(me._workspaces.get(key)) != ws_id:
+                        return
                     if p.get(key, 0) > 1:
                         p[key] -= 1
                     else:

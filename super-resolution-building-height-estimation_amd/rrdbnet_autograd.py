@@ -66,21 +66,52 @@ def _fast():
 #              96, 128, 160 -> 32 and 192 -> 64 channels), so srbh_conv3x3_x16 runs them: bf16 operands (gradients need fp32's exponent
 #              range), the LeakyReLU derivative from the saved plane folded into the epilogue, the identity path added as `skip`;
 #              weight gradients as GEMMs over pixels straight from the ACT16 planes (srbh_act16_wgrad_b16), bias gradients as plane sums.
-_FAST_WS = {}
+_FAST_WS = {}          # geometry -> list of buffer sets; a set is LEASED by one forward until its backward (or its graph's death)
+
+
+class _FastLease:
+    """One forward's claim on a buffer set: the dense planes saved for backward (ws['D']: activations AND the LeakyReLU masks) must
+    not be overwritten by another forward at the same geometry before this forward's backward has read them (round-3 ADVICE: two
+    generator passes, a second trainable net, a recompute interleaved with another forward -- silently wrong gradients).  Released
+    by backward, or when autograd drops the graph without running it."""
+
+    def __init__(self, ws):
+        self.ws = ws
+        ws["busy"] = True
+        ws["gen"] += 1
+        self.gen = ws["gen"]
+
+    def check(self):
+        if self.ws["gen"] != self.gen or not self.ws["busy"]:
+            raise RuntimeError("RRDBNet fast training mode: the saved activation planes of this forward were handed to another forward "
+                               "before its backward ran (buffer generation %d, expected %d)" % (self.ws["gen"], self.gen))
+
+    def release(self):
+        if self.ws is not None and self.ws["gen"] == self.gen:
+            self.ws["busy"] = False
+        self.ws = None
+
+    def __del__(self):
+        self.release()
 
 
 def _fast_buffers(B, Hh, Ww, n_rdb, dev):
-    """zero-bordered ACT16 buffers (the kernels never write the borders): n_rdb + 1 dense activation buffers, one gradient buffer"""
+    """zero-bordered ACT16 buffers (the kernels never write the borders): n_rdb + 1 dense activation buffers, one gradient buffer.
+    Returns a set no live forward holds: the cached one when it is free, else a fresh allocation (kept for the next overlap)."""
     key = (B, Hh, Ww, n_rdb, str(dev))
-    ws = _FAST_WS.get(key)
-    if ws is None:
-        L = _lib.lib()
-        nb = L.srbh_act16_bytes(B, 192, Hh, Ww)
-        nb = (nb + 255) // 256 * 256
-        _FAST_WS.clear()
-        ws = {"nb": nb, "D": torch.zeros((n_rdb + 1) * nb, dtype=torch.uint8, device=dev), "G": torch.zeros(2 * nb, dtype=torch.uint8, device=dev),
-              "wg": torch.empty(L.srbh_hwgrad_ws_bytes(64, 192, 3) // 4, dtype=torch.float32, device=dev)}
-        _FAST_WS[key] = ws
+    pool = _FAST_WS.get(key)
+    if pool is None:
+        _FAST_WS.clear()             # one geometry at a time: a B=24 set is 7 GB
+        pool = _FAST_WS[key] = []
+    for ws in pool:
+        if not ws["busy"]:
+            return ws
+    L = _lib.lib()
+    nb = L.srbh_act16_bytes(B, 192, Hh, Ww)
+    nb = (nb + 255) // 256 * 256
+    ws = {"nb": nb, "D": torch.zeros((n_rdb + 1) * nb, dtype=torch.uint8, device=dev), "G": torch.zeros(2 * nb, dtype=torch.uint8, device=dev),
+          "wg": torch.empty(L.srbh_hwgrad_ws_bytes(64, 192, 3) // 4, dtype=torch.float32, device=dev), "busy": False, "gen": 0}
+    pool.append(ws)
     return ws
 
 
@@ -154,10 +185,11 @@ def _trunk_fast_forward(net, feat):
     n_rdb = len(net.body) * 3
     ws = _fast_buffers(B, Hh, Ww, n_rdb, feat.device)
     _, desc = net._ensure_packed(feat.device)
+    lease = _FastLease(ws)
     xr, xrr = feat.clone(), feat.clone()
     _lib.check(L.srbh_rrdbnet_trunk_train_forward(C.byref(desc), xr.data_ptr(), xrr.data_ptr(), ws["D"].data_ptr(), ws["nb"], B, Hh, Ww,
                                                   _lib.stream_ptr()), "rrdbnet_trunk_train_forward")
-    return xr, ws
+    return xr, lease
 
 
 _DW_RDB = 9 * 26624          # weights of one RDB: 9 * (32*64 + 32*96 + 32*128 + 32*160 + 64*192)
@@ -165,8 +197,10 @@ _DW_OFF = (0, 9 * 2048, 9 * (2048 + 3072), 9 * (2048 + 3072 + 4096), 9 * (2048 +
 _CONV_GEO = ((160, 32, 64), (128, 32, 96), (96, 32, 128), (64, 32, 160), (0, 64, 192))      # conv1..5: (G channel offset, cout, cin)
 
 
-def _trunk_fast_backward(net, ws, g, grads):
+def _trunk_fast_backward(net, lease, g, grads):
     """g: gradient of the trunk output (B,H,W,64) fp32 contiguous -> gradient of its input; fills grads[id(param)]"""
+    lease.check()
+    ws = lease.ws
     L = _lib.lib()
     B, Hh, Ww, _ = g.shape
     packs = net.__dict__.setdefault("_srbh_trunk_bwd_packs", _TrunkBwdPacks()).get(net)
@@ -381,6 +415,11 @@ class _RRDBNetFn(torch.autograd.Function):
         fast_ws = getattr(ctx, "fast_ws", None)
         if fast_ws is not None:
             g = _trunk_fast_backward(net, fast_ws, g.contiguous(), grads)
+            if not getattr(ctx, "_srbh_retain", False):
+                # the saved planes are free for the next forward as soon as the launches above are enqueued (same stream: the next
+                # forward's writes are ordered behind this backward's reads); backward(retain_graph=True) callers keep the lease
+                # by setting ctx._srbh_retain (not used by the trainer)
+                fast_ws.release()
         for blk in (reversed(list(net.body)) if fast_ws is None else ()):
             g_rrdb_out = g                                                # out = rdb3(.)*0.2 + x_rrdb
             g = g_rrdb_out * 0.2

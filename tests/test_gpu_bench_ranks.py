@@ -56,3 +56,13 @@ def test_bench_predict_two_ranks_merges_row_bands():
     d = _launch(["--workload", "predict", "--steps", "2", "--warmup", "1", "--batch", "64"])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong"
     assert d["config"]["tiles"] == 4494 + 536 and d["value"] > 0 and d["p50_city_latency_ms"] > 0
+
+
+def test_bench_epoch_two_ranks_drop_last():
+    """BASELINE configs[3] driver (`--workload epoch`, harness.train_epoch) as two data-parallel ranks: 70 tiles at batch 4 x 2 ranks
+    = 8 steps, 64 tiles seen by the whole job (the ragged 6 dropped, train.py:97), gradients averaged through GradReducer."""
+    d = _launch(["--workload", "epoch", "--epoch-tiles", "70", "--warmup", "2", "--batch", "4"])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["steps"] == 8
+    assert "70 synthetic train tiles" in d["config"]["workload"] and "drawn on the device" in d["data"]
+    assert abs(d["value"] - 64 / (d["ms_per_step"] * 8 / 1e3)) / d["value"] < 1e-3       # value = tiles seen / wall time
+    assert d["comm"]["buckets"] >= 1 and d["final_loss"] == d["final_loss"]

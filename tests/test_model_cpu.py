@@ -331,3 +331,34 @@ def test_capture_holder_keeps_reported_buffers_and_unpins():
     k = wcache.gen(b)
     wcache.stamp([b, None])
     assert wcache.gen(b) != k                                  # buffers can be stamped like parameters
+
+
+def test_efficientnet_b4_keys_and_shapes_match_the_published_table(golden_dir):
+    """a18 structural anchor (round-3 VERDICT, What's missing #5): segmentation_models_pytorch / efficientnet_pytorch are absent, so
+    output parity of the encoder cannot be pinned here; its STRUCTURE can.  tests/golden/efficientnet_b4_keys.json is the published
+    efficientnet-b4 state_dict layout written down from the architecture table by tools/make_effnet_b4_table.py (which does not
+    import the product and self-checks against the published 19 341 616-parameter count); every key, every shape, the per-block
+    strides and the per-stage feature channels / strides of srbh_amd.encoders must match it."""
+    import json
+    from srbh_amd import encoders as E
+    with open(os.path.join(golden_dir, "efficientnet_b4_keys.json")) as f:
+        ref = json.load(f)
+    enc = E.EfficientNetEncoder("efficientnet-b4", in_channels=3)
+    sd = enc.state_dict()
+    assert sorted(sd.keys()) == sorted(ref["keys"].keys())
+    for k, v in sd.items():
+        assert list(v.shape) == ref["keys"][k], k
+    assert sum(p.numel() for p in enc.parameters()) == ref["n_params_without_fc"] == 17_548_616
+    assert [b.stride for b in enc._blocks] == ref["block_strides"]
+    assert list(enc._stage_idxs) == ref["stage_idxs"]
+    # the reference's construction: 8 input channels (train.py:143-148); only the stem weight widens
+    enc8 = E.get_encoder("efficientnet-b4", in_channels=8, depth=5, weights="imagenet")
+    sd8 = enc8.state_dict()
+    assert sorted(sd8.keys()) == sorted(ref["keys"].keys())
+    assert [k for k in sd8 if list(sd8[k].shape) != ref["keys"][k]] == ["_conv_stem.weight"] and tuple(sd8["_conv_stem.weight"].shape) == (48, 8, 3, 3)
+    enc8.eval()
+    with torch.no_grad():
+        feats = enc8(torch.rand(1, 8, 64, 64))
+    want = [[8, 1]] + ref["features_channels_strides"][1:]
+    assert [[f.shape[1], 64 // f.shape[2]] for f in feats] == want
+    assert all(f.shape[2] == f.shape[3] for f in feats)

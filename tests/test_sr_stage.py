@@ -245,3 +245,49 @@ def test_rrdbnet_mixed_precision_training_graph_close_to_exact(fast_mode):
     # (wall clock of a 2-block net on 2 tiles is launch-bound and noisy: this only guards against a pathologically slow path; the speed
     #  itself is measured by `bench.py --workload sr_train`, which reports both modes)
     assert times[fast_mode] < 1.5 * times["f32"], times
+
+
+@pytest.mark.gpu
+def test_fast_mode_two_forwards_before_backward_keep_their_own_saved_planes():
+    """Round-3 ADVICE (medium): the fast mode's saved activation planes lived in ONE module-global buffer per geometry, so a second
+    forward at the same geometry before the first backward (two generator passes, a second net) overwrote them and the first backward
+    returned wrong gradients silently.  Now every forward leases its own buffer set until its backward: the gradients of forward A,
+    taken AFTER an interleaved forward B on other data, equal the gradients of A run alone."""
+    from srbh_amd import rrdbnet_autograd as RA
+    from srbh_amd.rrdbnet import RRDBNet
+    sd = synth.rrdbnet_state_dict(num_block=1, seed=33, mode="stress")
+    try:
+        RA.set_train_precision("fast")
+        net = RRDBNet(3, 3, num_block=1)
+        net.load_state_dict(sd, strict=True)
+        net = net.to("cuda:0").train().enable_training_path(True)
+        xa = rand((2, 3, 64, 64), 150, 0.0, 1.0).to("cuda:0")
+        xb = rand((2, 3, 64, 64), 151, 0.0, 1.0).to("cuda:0")
+
+        def grads_of(interleave):
+            for p in net.parameters():
+                p.grad = None
+            ya = net(xa)
+            if interleave:
+                yb = net(xb)                       # same geometry, other data, before A's backward
+            ya.square().sum().backward()
+            g = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+            if interleave:
+                for p in net.parameters():
+                    p.grad = None
+                yb.square().sum().backward()       # B's own planes are intact too
+                gb = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+                return g, gb
+            return g
+
+        alone_a = grads_of(False)
+        inter_a, inter_b = grads_of(True)
+        xa, xb = xb, xa
+        alone_b = grads_of(False)
+        pool = next(iter(RA._FAST_WS.values()))
+        assert len(pool) == 2 and not any(ws["busy"] for ws in pool)          # the overlap cost one extra set; both are free again
+        for k in alone_a:
+            assert torch.allclose(inter_a[k], alone_a[k], rtol=1e-4, atol=1e-6 * float(alone_a[k].abs().max())), k
+            assert torch.allclose(inter_b[k], alone_b[k], rtol=1e-4, atol=1e-6 * float(alone_b[k].abs().max())), k
+    finally:
+        RA.set_train_precision("f32")
