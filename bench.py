@@ -611,8 +611,26 @@ def bench_feature(args, rank, world, dev, dist):
     return line
 
 
-def _compact(d, drop=("higher_is_better", "vs_baseline", "warmup", "unit", "scaling")):
-    return {k: v for k, v in d.items() if k not in drop} if d else d
+def _compact(d, drop=("higher_is_better", "vs_baseline", "warmup", "unit", "scaling", "whole_step")):
+    """sub-object of the default line: the standalone `--workload train|predict` lines keep every field and note; here the notes go
+    (they are in those lines and in DESIGN.md) and the per-call tables keep 5 rows, so that the whole line stays under the driver's
+    8 KB tail"""
+    if not d:
+        return d
+    out = {k: v for k, v in d.items() if k not in drop}
+    for k in ("head_roofline", "encdec_kernels", "strict_f32_head", "comm"):
+        if isinstance(out.get(k), dict):
+            out[k] = {kk: vv for kk, vv in out[k].items() if kk != "note"}
+    if isinstance(out.get("head_roofline"), dict) and "kernels" in out["head_roofline"]:
+        out["head_roofline"]["kernels"] = [{kk: r[kk] for kk in ("kernel", "calls_per_step", "ms_per_step", "frac_hbm_peak") if kk in r}
+                                           for r in out["head_roofline"]["kernels"][:5]]
+    if isinstance(out.get("encdec_kernels"), dict):
+        so = out["encdec_kernels"].get("stock_ops")
+        if isinstance(so, dict):
+            out["encdec_kernels"]["stock_ops"] = {"calls": so.get("calls"), "by_site": so.get("by_site")}
+    if isinstance(out.get("kernels"), list):
+        out["kernels"] = [{kk: r[kk] for kk in ("kernel", "avg_launch_ms", "achieved", "unit", "frac") if kk in r} for r in out["kernels"]]
+    return out
 
 
 def main():

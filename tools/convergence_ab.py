@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(mode, steps, batch, num_block, eval_every, lr, dev):
+def run(mode, steps, batch, num_block, eval_every, lr, dev, drop_seed=None):
     from srbh_amd import synth
     from srbh_amd.harness import TrainStep, learnable_batch_device
     from srbh_amd.models import SRRegress_Cls_feature
@@ -29,6 +29,8 @@ def run(mode, steps, batch, num_block, eval_every, lr, dev):
     net_hr.load_state_dict(synth.rrdbnet_state_dict(num_block=num_block, seed=1337, mode="init"))
     torch.manual_seed(1337)                                   # same initial weights AND the same drop-connect draws in both runs
     net = SRRegress_Cls_feature("efficientnet-b4", in_channels=8, super_in=64, super_mid=16, upscale=4, isaggre=True, chans_build=7)
+    if drop_seed is not None:                                # control run: same weights, same batches, OTHER drop-connect draws
+        torch.manual_seed(drop_seed)
     ts = TrainStep(net_hr.to(dev), net.to(dev), dev, lr=lr, head_precision=mode, status_every=0)
     gen = torch.Generator(device=dev)
     held = []
@@ -64,8 +66,20 @@ def run(mode, steps, batch, num_block, eval_every, lr, dev):
             "wall_s": round(time.perf_counter() - t0, 2)}
 
 
-def summarise(a, b, tail=50):
+def summarise(a, b, tail=50, control=None):
+    """a = strict, b = mixed, control = strict again with other drop-connect draws (the seed-noise yardstick: two runs of the SAME
+    arithmetic differ by this much after `steps` steps)"""
     mean = lambda v: sum(v) / len(v)                      # noqa: E731
+    if control is not None:
+        s = summarise(a, b, tail)
+        c = summarise(a, control, tail)
+        s["seed_noise_control"] = {"what": "strict f32 vs strict f32 with other drop-connect draws", "loss_tail_mean": c["loss_tail_mean"],
+                                   "loss_tail_rel_gap": c["loss_tail_rel_gap"], "train_rmse_tail_rel_gap": c["train_rmse_tail_rel_gap"],
+                                   "heldout_rmse_final": c["heldout_rmse_final"], "heldout_rmse_final_rel_gap": c["heldout_rmse_final_rel_gap"]}
+        s["mixed_over_strict"] = {"loss_tail": round(s["loss_tail_mean"][1] / s["loss_tail_mean"][0], 4),
+                                  "train_rmse_tail": round(s["train_rmse_tail_mean"][1] / s["train_rmse_tail_mean"][0], 4),
+                                  "heldout_rmse_final": round(s["heldout_rmse_final"][1] / s["heldout_rmse_final"][0], 4)}
+        return s
     la, lb = mean(a["loss"][-tail:]), mean(b["loss"][-tail:])
     ra, rb = mean(a["train_height_rmse"][-tail:]), mean(b["train_height_rmse"][-tail:])
     ea, eb = a["heldout_eval_height_rmse"][-1][1], b["heldout_eval_height_rmse"][-1][1]
@@ -91,11 +105,14 @@ def main():
     a = run("f32", args.steps, args.batch, args.num_block, args.eval_every, args.lr, dev)
     torch.cuda.empty_cache()
     b = run("f16", args.steps, args.batch, args.num_block, args.eval_every, args.lr, dev)
-    out = {"config": vars(args), "summary": summarise(a, b, tail=min(50, args.steps // 2)), "strict_f32": a, "mixed_f16": b}
+    torch.cuda.empty_cache()
+    c = run("f32", args.steps, args.batch, args.num_block, args.eval_every, args.lr, dev, drop_seed=4242)
+    out = {"config": vars(args), "summary": summarise(a, b, tail=min(50, args.steps // 2), control=c), "strict_f32": a, "mixed_f16": b,
+           "strict_f32_other_dropconnect_seed": c}
     if args.out:
         with open(args.out, "w") as f:
             json.dump(out, f)
-    print(json.dumps({"config": out["config"], "summary": out["summary"], "wall_s": [a["wall_s"], b["wall_s"]]}))
+    print(json.dumps({"config": out["config"], "summary": out["summary"], "wall_s": [a["wall_s"], b["wall_s"], c["wall_s"]]}))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,156 @@
+// mfma_ceiling.hip -- what can v_mfma_f32_32x32x16_f16 deliver on THIS chip under ITS power cap?  (round-3 VERDICT, task 2(i))
+//
+// The trunk kernel's roofline is quoted against 2.5 PFLOP/s = 256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz.  A package that is
+// power-limited never runs the matrix cores at 2.4 GHz on real data, so the reachable ceiling is lower; this tool measures it:
+// one wave per SIMD (the trunk's occupancy), 256 workgroups, launches of a few ms back to back for seconds, operands held in
+// registers (no LDS, no memory in the loop), wall clock by HIP events, shader clock from s_memtime / s_memrealtime inside the kernel.
+//   mode mfma      : MFMAs only, 4 independent accumulators (back-to-back issue), operands cycle through 8 A x 8 B fragments
+//   mode mfma+lds  : the same MFMAs with the trunk's LDS read mix (0.75 ds_read_b128 per MFMA, conflict-free pattern) feeding them
+//   mode duty<p>   : MFMA bursts with idle gaps (s_sleep) so that the matrix core is busy ~p % of the cycles: what the chip gives
+//                    back in clock when the kernel idles (the trunk: 59 % busy)
+// operand data: zeros | random fp16 in [-0.5, 0.5) | a dump of real trunk activations / weights (tools/dump_trunk_operands.py)
+//   hipcc --offload-arch=gfx950 -O3 tools/mfma_ceiling.hip -o tools/mfma_ceiling ; tools/mfma_ceiling [acts.bin weights.bin]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cstring>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct Out { unsigned long long cyc, real; };
+
+// MODE 0: MFMA only; 1: MFMA + LDS reads (9 per 12 MFMAs); 2: duty-cycled MFMA (sleep after each burst of 32)
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void ceiling_kernel(const half8* __restrict__ wsrc, const half8* __restrict__ asrc, int nfrag, int iters, int sleep_n,
+                                                         Out* out, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    half8 A[8], B[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        A[k] = wsrc[((blockIdx.x * 4 + wave) * 8 + k) % nfrag * 64 + lane];
+        B[k] = asrc[((blockIdx.x * 4 + wave) * 8 + k) % nfrag * 64 + lane];
+    }
+    if (MODE == 1) {      // LDS filled with the activation data: 36 KiB of fragments per wave
+        for (int i = tid; i < 144 * 64; i += 256) ((half8*)smem)[i] = asrc[(blockIdx.x * 144 + i / 64) % nfrag * 64 + (i & 63)];
+        __syncthreads();
+    }
+    floatx16 c[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c[a][q] = 0.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    if (MODE == 1) {
+        // the trunk's group: 9 reads (6 pixel-row + 3 weight fragments) feed 12 MFMAs; double-buffered, one read per MFMA shadow
+        half8 v[2][9];
+        const char* base = smem + wave * 36 * 1024 + lane * 16;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) v[0][r] = *(const half8*)(base + r * 1024);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {      // 4 groups per iteration = 48 MFMAs
+#pragma unroll
+                for (int m = 0; m < 12; ++m) {
+                    c[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v[u & 1][6 + m / 4], v[u & 1][(m & 3) + m / 4], c[m & 3], 0, 0, 0);
+                    if (m < 9) v[(u + 1) & 1][m] = *(const half8*)(base + (u * 9 + m) * 1024);      // (immediate offsets, as in the trunk)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int m = 0; m < 48; ++m) c[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[m & 7], B[(m + m / 8) & 7], c[m & 3], 0, 0, 0);
+            if (MODE == 2) {
+                for (int s = 0; s < sleep_n; ++s) __builtin_amdgcn_s_sleep(8);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) { out[blockIdx.x].cyc = t1 - t0; out[blockIdx.x].real = r1 - r0; }
+    float s = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += c[a][q];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+static std::vector<_Float16> load_or_make(const char* path, size_t n, int kind, unsigned seed) {
+    std::vector<_Float16> v(n);
+    if (path) {
+        FILE* f = fopen(path, "rb");
+        if (!f) { fprintf(stderr, "cannot open %s\n", path); exit(1); }
+        std::vector<_Float16> raw;
+        fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
+        raw.resize(sz / 2);
+        if (fread(raw.data(), 2, raw.size(), f) != raw.size()) { fprintf(stderr, "short read %s\n", path); exit(1); }
+        fclose(f);
+        for (size_t i = 0; i < n; ++i) v[i] = raw[i % raw.size()];
+        return v;
+    }
+    unsigned h = seed;
+    for (size_t i = 0; i < n; ++i) {
+        h = h * 1664525u + 1013904223u;
+        v[i] = kind == 0 ? (_Float16)0.f : (_Float16)(((h >> 8) & 0xffff) / 65536.f - 0.5f);
+    }
+    return v;
+}
+
+template <int MODE>
+static void run(const char* name, const half8* dw, const half8* da, int nfrag, int sleep_n, double seconds) {
+    Out* dout; float* sink;
+    hipMalloc(&dout, 256 * sizeof(Out)); hipMalloc(&sink, 4);
+    const int lds = MODE == 1 ? 144 * 1024 : 0;
+    if (lds) hipFuncSetAttribute((const void*)ceiling_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int iters = MODE == 2 ? 2000 : 4000;                    // 48 MFMAs x 32 cyc x 4000 = 6.1 M cycles ~ 3 ms
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    // warm the power state: run for `seconds`, time the second half
+    int launches = 0; float ms = 0;
+    for (int phase = 0; phase < 2; ++phase) {
+        hipEventRecord(e0);
+        int n = 0; float acc = 0;
+        do {
+            for (int k = 0; k < 20; ++k) hipLaunchKernelGGL((ceiling_kernel<MODE>), dim3(256), dim3(256), lds, 0, dw, da, nfrag, iters, sleep_n, dout, sink);
+            n += 20;
+            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&acc, e0, e1);
+        } while (acc < seconds * 500.0);
+        launches = n; ms = acc;
+    }
+    Out h[256]; hipMemcpy(h, dout, sizeof(h), hipMemcpyDeviceToHost);
+    double cyc = 0, real = 0;
+    for (int i = 0; i < 256; ++i) { cyc += (double)h[i].cyc; real += (double)h[i].real; }
+    cyc /= 256; real /= 256;
+    const double mfmas = (double)iters * 48, flop = mfmas * 32768.0 * 4 * 256;      // per launch: 4 waves x 256 workgroups
+    const double ms_l = ms / launches, tf = flop / (ms_l * 1e-3) / 1e12, mhz = cyc / real * 100.0;
+    printf("%-34s %7.3f ms/launch  %7.1f TF/s = %.3f of 2500   sclk %6.0f MHz   matrix-core busy %5.1f %% of kernel cycles   (kernel %0.3f ms by counters)\n",
+           name, ms_l, tf, tf / 2500.0, mhz, 100.0 * mfmas * 32.0 / cyc, real / 100e6 * 1e3);
+    fflush(stdout);
+    hipFree(dout); hipFree(sink);
+}
+
+int main(int argc, char** argv) {
+    const int nfrag = 4096;                                       // 4096 fragments x 64 lanes x 8 halfs = 4 MiB per operand set
+    const size_t n = (size_t)nfrag * 64 * 8;
+    const double seconds = getenv("CEIL_SECONDS") ? atof(getenv("CEIL_SECONDS")) : 6.0;
+    for (int kind = 0; kind < 3; ++kind) {
+        if (kind == 2 && argc < 3) break;
+        const char* label = kind == 0 ? "zeros" : kind == 1 ? "random fp16 [-0.5,0.5)" : "real trunk dump";
+        std::vector<_Float16> a = load_or_make(kind == 2 ? argv[1] : nullptr, n, kind, 1u), w = load_or_make(kind == 2 ? argv[2] : nullptr, n, kind, 7u);
+        half8 *da, *dw;
+        hipMalloc(&da, n * 2); hipMalloc(&dw, n * 2);
+        hipMemcpy(da, a.data(), n * 2, hipMemcpyHostToDevice); hipMemcpy(dw, w.data(), n * 2, hipMemcpyHostToDevice);
+        printf("---- operand data: %s\n", label);
+        run<0>("mfma only", dw, da, nfrag, 0, seconds);
+        run<1>("mfma + 0.75 ds_read_b128 / mfma", dw, da, nfrag, 0, seconds);
+        if (kind != 0) {
+            run<2>("mfma bursts, sleep 1x", dw, da, nfrag, 1, seconds);
+            run<2>("mfma bursts, sleep 2x", dw, da, nfrag, 2, seconds);
+            run<2>("mfma bursts, sleep 4x", dw, da, nfrag, 4, seconds);
+        }
+        hipFree(da); hipFree(dw);
+    }
+    return 0;
+}
