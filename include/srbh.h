@@ -91,6 +91,9 @@ typedef struct srbh_conv3x3_args {
     int out16_chunk0;
     float* out32;           /* NHWC32 or NULL */
     int out32_c;
+    int out16_nhwc;         /* 1: `out16` is a dense fp16 NHWC tensor [B][H][W][32*out16_chunks_total] (no border), this conv's channels
+                             * at chunk out16_chunk0 -- the hand-off format of the head's 16-bit kernels (SRBH_IO_SRC0_H16).  64 -> 64
+                             * convs without residual epilogue only (the persistent tail kernel); anything else is an error */
 } srbh_conv3x3_args;
 
 int srbh_conv3x3_f16(const srbh_conv3x3_args* a, void* stream);
@@ -141,7 +144,10 @@ typedef struct srbh_rrdbnet_desc {
 size_t srbh_rrdbnet_workspace_bytes(int B, int H, int W, int want_forward);
 /* x: NCHW fp32 (B,num_in_ch,H,W).  out: NHWC32 (B,4H,4W,64) for forward_feature (want_forward=0,
  * no activation after conv_hr -- SR/rrdbnet_arch.py:238) or (B,4H,4W,num_out_ch) for forward
- * (want_forward=1, lrelu(conv_hr) then conv_last -- :221-222).
+ * (want_forward=1, lrelu(conv_hr) then conv_last -- :221-222).  want_forward=2: forward_feature with `out` a dense fp16 NHWC
+ * tensor (B,4H,4W,64) -- the same values rounded once (RNE) in conv_hr's epilogue: what the head's fp16-operand kernels would make
+ * of the fp32 tensor while staging it, so the height maps of the fp16 head mode are bit-identical and conv_hr writes / the block
+ * entry reads half the bytes (harness paths only; the nn.Module API returns fp32).
  * ws: srbh_rrdbnet_workspace_bytes() bytes that were ZERO when first handed to this (B,H,W) geometry
  * (the kernels never write the zero borders, so the same workspace can be reused across calls). */
 int srbh_rrdbnet_forward(const srbh_rrdbnet_desc* d, const float* x, float* out, int B, int H, int W,

@@ -66,7 +66,7 @@ class ConvArgs(C.Structure):
         ("res2_scale", C.c_float), ("res2", C.c_void_p), ("res2_update", C.c_int),
         ("skip", C.c_void_p),
         ("out16", C.c_void_p), ("out16_chunks_total", C.c_int), ("out16_chunk0", C.c_int),
-        ("out32", C.c_void_p), ("out32_c", C.c_int),
+        ("out32", C.c_void_p), ("out32_c", C.c_int), ("out16_nhwc", C.c_int),
     ]
 
 

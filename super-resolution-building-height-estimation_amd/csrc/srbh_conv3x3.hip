@@ -65,6 +65,8 @@ static int conv3x3_impl(const srbh_conv3x3_args* a, const int bf16, const void* 
         const int rc = ptail_run(a, stream, &used);
         if (rc != SRBH_OK || used) return rc;
     }
+    SRBH_REQUIRE(!a->out16_nhwc, "srbh_conv3x3_f16: out16_nhwc (dense fp16 NHWC output) exists for 64 -> 64 convs without residual / skip "
+                                 "epilogue and without an fp32 output only (the persistent tail kernel)");
     SRBH_REQUIRE(!ext || !a->upsample2x, "srbh_conv3x3_x16: the gradient forms have no nearest-x2 read");
     SRBH_REQUIRE(!mask16 || (mask_chunk0 >= 0 && mask_chunk0 + a->cout / 32 <= mask_chunks_total), "srbh_conv3x3_x16: mask chunk range outside its buffer");
 

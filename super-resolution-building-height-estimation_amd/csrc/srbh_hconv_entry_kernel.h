@@ -19,9 +19,12 @@ struct EParams {
 };
 
 // O16 (compile-time): both outputs are 16-bit tensors (fp16 for OPT 1)
-template <int OPT, int O16>
+// S16 (compile-time, OPT 1): the sources hold fp16 elements (SRBH_IO_SRC0_H16 [| SRBH_IO_SRC1_H16]): staged verbatim -- 8-byte loads,
+// no rounding, half the registers in flight (the fp32-source forms spill 24 VGPRs under this launch bound; this one does not)
+template <int OPT, int O16, int S16 = 0>
 __global__ __launch_bounds__(256, 3) void hconv_entry_kernel(const EParams e) {
     static_assert(OPT == 1 || OPT == 2, "16-bit operand forms only");
+    static_assert(S16 == 0 || OPT == 1, "16-bit sources: fp16 only (element type = operand type)");
     const HParams& p = e.a;
     constexpr int ROWS = 6, COLS = 66, NIT = (ROWS * COLS * 4 + 255) / 256;
     constexpr int STAGE_B = ROWS * COLS * 32;
@@ -68,7 +71,8 @@ __global__ __launch_bounds__(256, 3) void hconv_entry_kernel(const EParams e) {
     for (int dx = 0; dx < 3; ++dx) bbase[dx] = (wave * COLS + dx + l15) * 32 + ((kk ^ ((((dx + l15) >> 3) & 1) << 1)) << 3);
 
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f}, dsum[4] = {0.f, 0.f, 0.f, 0.f}, dsq[4] = {0.f, 0.f, 0.f, 0.f};
-    floatx4 ld[NIT];
+    typedef typename std::conditional<S16 != 0, short4v, floatx4>::type ld_t;
+    ld_t ld[NIT];
     auto issue = [&](const int t, const int c) {
         const int img = t / p.tiles_per_img;
         const int trem = t - img * p.tiles_per_img;
@@ -76,7 +80,9 @@ __global__ __launch_bounds__(256, 3) void hconv_entry_kernel(const EParams e) {
         const int Y0 = ty * 4, X0 = tx * 64;
         const bool in0 = c * 16 < p.c0;
         const int ldp = in0 ? p.ld0 : p.ld1;
-        const float* tp = (in0 ? p.src0 + c * 16 : p.src1 + (c * 16 - p.c0)) + (((long)img * p.H + (Y0 - 1)) * p.W + (X0 - 1)) * ldp + cg * 4;
+        const long eoff = (((long)img * p.H + (Y0 - 1)) * p.W + (X0 - 1)) * ldp + cg * 4 + (in0 ? c * 16 : c * 16 - p.c0);      // in elements
+        const float* tp = (in0 ? p.src0 : p.src1) + eoff;
+        const short* tp16 = (const short*)(in0 ? p.src0 : p.src1) + eoff;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int r = (urow >> (3 * it)) & 7;
@@ -84,16 +90,25 @@ __global__ __launch_bounds__(256, 3) void hconv_entry_kernel(const EParams e) {
             if ((ucol1 >> it) & 1) ok = ok && X0 > 0;
             if ((ucol1 >> (8 + it)) & 1) ok = ok && X0 + 64 < p.W;
             if (it == NIT - 1) ok = ok && last_unit;
-            ld[it] = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (ok) ld[it] = *(const floatx4*)(tp + upix[it] * ldp);
+            if constexpr (S16 != 0) {
+                ld[it] = short4v{0, 0, 0, 0};
+                if (ok) ld[it] = *(const short4v*)(tp16 + upix[it] * ldp);
+            } else {
+                ld[it] = floatx4{0.f, 0.f, 0.f, 0.f};
+                if (ok) ld[it] = *(const floatx4*)(tp + upix[it] * ldp);
+            }
         }
     };
     auto commit = [&](char* stage) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (it < NIT - 1 || last_unit) {
-                const float t4[4] = {ld[it][0], ld[it][1], ld[it][2], ld[it][3]};
-                *(short4v*)(stage + ulds[it]) = round4<OPT>(t4);
+                if constexpr (S16 != 0) {
+                    *(short4v*)(stage + ulds[it]) = ld[it];
+                } else {
+                    const float t4[4] = {ld[it][0], ld[it][1], ld[it][2], ld[it][3]};
+                    *(short4v*)(stage + ulds[it]) = round4<OPT>(t4);
+                }
             }
         }
     };

@@ -837,13 +837,17 @@ extern "C" int srbh_hconv_entry_h16(const srbh_hconv_args* c1, const srbh_hconv_
     const int out1_ld = c1->out_ld > 0 ? c1->out_ld : c1->cout, out2_ld = ds->out_ld > 0 ? ds->out_ld : ds->cout;
     const bool plain = !c1->pre_scale && !c1->pre_relu && !ds->pre_scale && !ds->pre_relu && !c1->pixelshuffle2 && !ds->pixelshuffle2 &&
                        !c1->res1 && !ds->res1 && !c1->res2 && !ds->res2 && !c1->post_lrelu && !ds->post_lrelu && !ds->post_relu &&
-                       !(c1->io_h16 & ~SRBH_IO_OUT_H16) && c1->io_h16 == ds->io_h16 && (!c1->stats == !ds->stats);
+                       !(c1->io_h16 & SRBH_IO_RES1_H16) && c1->io_h16 == ds->io_h16 && (!c1->stats == !ds->stats);
+    // 16-bit sources: every source the entry reads holds fp16 (the element type of the fp16-operand form), staged verbatim
+    const int srcbits = c1->io_h16 & (SRBH_IO_SRC0_H16 | SRBH_IO_SRC1_H16);
+    const bool es16 = srcbits != 0;
+    const bool src_ok = !es16 || (!bf16 && srcbits == (SRBH_IO_SRC0_H16 | (c1->c1 ? SRBH_IO_SRC1_H16 : 0)));
     const bool shape = c1->ksize == 3 && ds->ksize == 1 && c1->cout == 16 && ds->cout == 16 && c1->c0 > 0 && (c1->c0 & 15) == 0 &&
                        (c1->c1 & 15) == 0 && cin <= 80 && (c1->c1 == 0 || c1->src1) && c1->B > 0 && (c1->W & 63) == 0 && (c1->H & 3) == 0 &&
                        (ld0 & 3) == 0 && (c1->c1 == 0 || (ld1 & 3) == 0) && (out1_ld & 3) == 0 && (out2_ld & 3) == 0 &&
                        (c1->out_coff & 3) == 0 && (ds->out_coff & 3) == 0 &&
-                       (((uintptr_t)c1->src0 | (uintptr_t)c1->src1) & 15) == 0 && (((uintptr_t)c1->out | (uintptr_t)ds->out) & 7) == 0;
-    if (!(wgs >= 8 && same && plain && shape && c1->src0 && c1->w && ds->w && c1->out && ds->out)) {
+                       (((uintptr_t)c1->src0 | (uintptr_t)c1->src1) & (es16 ? 7 : 15)) == 0 && (((uintptr_t)c1->out | (uintptr_t)ds->out) & 7) == 0;
+    if (!(wgs >= 8 && same && plain && shape && src_ok && c1->src0 && c1->w && ds->w && c1->out && ds->out)) {
         if (int rc = hconv_impl(c1, stream, bf16 ? 2 : 1)) return rc;
         return hconv_impl(ds, stream, bf16 ? 2 : 1);
     }
@@ -875,7 +879,9 @@ extern "C" int srbh_hconv_entry_h16(const srbh_hconv_args* c1, const srbh_hconv_
     const int per_xcd = p.tiles_per_xcd < wgs / 8 ? p.tiles_per_xcd : wgs / 8;
     const int lds_b = 2 * 6 * 66 * 32 + e.nchunk * 640 * 8;
     const bool eo16 = (c1->io_h16 & SRBH_IO_OUT_H16) != 0;
-    if (bf16 && eo16) hipLaunchKernelGGL((hconv_entry_kernel<2, 1>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);
+    if (es16 && eo16) hipLaunchKernelGGL((hconv_entry_kernel<1, 1, 1>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);
+    else if (es16) hipLaunchKernelGGL((hconv_entry_kernel<1, 0, 1>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);
+    else if (bf16 && eo16) hipLaunchKernelGGL((hconv_entry_kernel<2, 1>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);
     else if (bf16) hipLaunchKernelGGL((hconv_entry_kernel<2, 0>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);
     else if (eo16) hipLaunchKernelGGL((hconv_entry_kernel<1, 1>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);
     else hipLaunchKernelGGL((hconv_entry_kernel<1, 0>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);

@@ -336,7 +336,10 @@ __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
                             a = widen_h4(*(const float2w*)((const char*)p.src0 + (long)img * p.x_img_b + (long)(ch >> 5) * p.x_plane_b +
                                                           (long)(y + 1) * p.x_row_b + (x + 1) * 64 + (ch & 31) * 2));
                         } else if (ch < p.c0) {
-                            a = *(const floatx4*)(p.src0 + (rowbase + x) * p.ld0 + ch);
+                            if (p.io & SRBH_WG_SRC0_H16)     // (uniform: fp16 elements in memory, e.g. RRDBNet features handed over as fp16)
+                                a = widen_h4(*(const float2w*)((const short*)p.src0 + (rowbase + x) * p.ld0 + ch));
+                            else
+                                a = *(const floatx4*)(p.src0 + (rowbase + x) * p.ld0 + ch);
                             if (p.pre_scale) a = a * *(const floatx4*)(p.pre_scale + ch) + *(const floatx4*)(p.pre_shift + ch);
                             if (p.pre_relu) {
 #pragma unroll
@@ -757,7 +760,8 @@ int wgrad_impl(const srbh_hwgrad_args* a, void* stream, bool b16, const char* wh
     const bool k16 = b16 && k16_wgs >= 8 && k16_wgs <= WS_SLOTS && a->ksize == 3 && a->c0 == 16 && a->c1 == 0 && (a->cout == 16 || narrow) &&
                      (a->W & 63) == 0 && (a->H & 3) == 0 && (p.ld0 & 3) == 0 && ((uintptr_t)a->src0 & (xs16 ? 7 : 15)) == 0 &&
                      ((uintptr_t)a->dy & (narrow ? 3 : ds16 ? 7 : 15)) == 0;
-    SRBH_REQUIRE(!xs16 || k16, "srbh_hconv_wgrad_b16: an fp16 source tensor is supported by the 16 -> 16 3x3 form only");
+    SRBH_REQUIRE(!xs16 || k16 || (b16 && can16 && ((uintptr_t)a->src0 & 7) == 0),
+                 "srbh_hconv_wgrad_b16: an fp16 source tensor needs the bf16-operand forms (4-aligned channels, 16-channel output blocks)");
     SRBH_REQUIRE(!ds16 || k16 || can16, "srbh_hconv_wgrad_b16: a bf16 dY needs 4-aligned channels / 16-channel output blocks");
     if (k16) {
         p.tiles_x = a->W / 64;

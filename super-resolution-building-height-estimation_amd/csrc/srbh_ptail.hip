@@ -29,6 +29,8 @@ struct TParams {
     char* out16;                // ACT16 output (2 planes) or nullptr
     long out16_img_b;
     int out16_plane_b, out16_row_b;
+    int out16_pix_b, out16_border;   // ACT16: 64-byte pixel records behind a 1-pixel border; NHWC16 (srbh_conv3x3_args::out16_nhwc): dense
+                                     // fp16 [B][H][W][C] records of out16_pix_b bytes, no border, "plane" = 64 bytes (the next 32 channels)
     float* out32;               // fp32 NHWC (64 channels) output or nullptr
 };
 
@@ -200,8 +202,8 @@ __global__ __launch_bounds__(256, 1) void ptail_kernel(const TParams p) {
                         typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
                         const uintx4 raw = {s0[0], s1[0], s0[1], s1[1]};
                         if (valid)
-                            *(uintx4*)(p.out16 + (long)img * p.out16_img_b + (long)mb * p.out16_plane_b + (long)(Y + 1) * p.out16_row_b +
-                                       (X + 1) * PIX_B + m * 32 + hi * 16) = raw;
+                            *(uintx4*)(p.out16 + (long)img * p.out16_img_b + (long)mb * p.out16_plane_b + (long)(Y + p.out16_border) * p.out16_row_b +
+                                       (X + p.out16_border) * p.out16_pix_b + m * 32 + hi * 16) = raw;
                     }
                 }
             }
@@ -241,7 +243,8 @@ int ptail_run(const srbh_conv3x3_args* a, hipStream_t stream, int* used) {
     if (a->in_chunks != 2 || a->cout != 64 || a->res1 || a->res2 || a->skip) return SRBH_OK;
     if (a->out32 && a->out32_c != 64) return SRBH_OK;
     const int tiles_x = (a->W + TILE_W - 1) / TILE_W, tiles_y = (a->H + TILE_H - 1) / TILE_H;
-    if ((long)tiles_x * tiles_y * a->B < 512) return SRBH_OK;   // too few tiles per CU to amortise the resident weights
+    if (a->out16_nhwc && (!a->out16 || a->out32)) return SRBH_OK;
+    if ((long)tiles_x * tiles_y * a->B < 512 && !a->out16_nhwc) return SRBH_OK;   // too few tiles per CU to amortise the resident weights (the NHWC16 store exists only here)
     const int inH = a->upsample2x ? a->H / 2 : a->H, inW = a->upsample2x ? a->W / 2 : a->W;
     const Act16Geo gi = act16_geo(a->B, a->in_chunks_total, inH, inW);
     TParams p{};
@@ -257,8 +260,18 @@ int ptail_run(const srbh_conv3x3_args* a, hipStream_t stream, int* used) {
     p.tiles_per_img = tiles_x * tiles_y;
     p.ntiles = p.tiles_per_img * a->B;
     p.lrelu = a->lrelu;
-    if (a->out16) {
+    if (a->out16 && a->out16_nhwc) {
+        const int C = a->out16_chunks_total * 32;
+        p.out16 = (char*)a->out16 + (long)a->out16_chunk0 * 64;
+        p.out16_pix_b = C * 2;
+        p.out16_row_b = a->W * C * 2;
+        p.out16_img_b = (long)a->H * a->W * C * 2;
+        p.out16_plane_b = 64;
+        p.out16_border = 0;
+    } else if (a->out16) {
         const Act16Geo go = act16_geo(a->B, a->out16_chunks_total, a->H, a->W);
+        p.out16_pix_b = PIX_B;
+        p.out16_border = 1;
         p.out16 = (char*)a->out16 + (long)a->out16_chunk0 * go.plane_b;
         p.out16_img_b = go.img_b;
         p.out16_plane_b = go.plane_b;

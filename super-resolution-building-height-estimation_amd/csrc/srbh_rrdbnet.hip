@@ -43,7 +43,7 @@ WsLayout ws_layout(int B, int H, int W, int want_forward) {
     L.u2 = off; off = align256(off + act16_geo(B, 2, 2 * H, 2 * W).total_b);
     L.u3 = off; off = align256(off + act16_geo(B, 2, 4 * H, 4 * W).total_b);
     L.u4 = off;
-    if (want_forward) off = align256(off + act16_geo(B, 2, 4 * H, 4 * W).total_b);
+    if (want_forward == 1) off = align256(off + act16_geo(B, 2, 4 * H, 4 * W).total_b);      // (2 = forward_feature as fp16: no conv_last)
     L.aux = off;   // persistent-trunk layer table, progress counters, error word
     off = align256(off + ptrunk_aux_bytes(B, (H + TILE_H - 1) / TILE_H));
     L.total = off;
@@ -146,6 +146,11 @@ extern "C" int srbh_rrdbnet_forward(const srbh_rrdbnet_desc* d, const float* x, 
         SRBH_HIP(hipGetLastError());
         return SRBH_OK;
     };
+    if (want_forward == 2) {      // forward_feature as a dense fp16 NHWC tensor (the 16-bit head kernels stage it verbatim)
+        a.out16 = out; a.out16_chunks_total = 2; a.out16_chunk0 = 0; a.out16_nhwc = 1;
+        if ((rc = srbh_conv3x3_f16(&a, stream))) return rc;
+        return guard(32);         // (64 halves = 32 words per pixel)
+    }
     if (!want_forward) {
         a.out32 = out; a.out32_c = 64;
         if ((rc = srbh_conv3x3_f16(&a, stream))) return rc;

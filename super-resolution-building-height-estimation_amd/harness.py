@@ -241,6 +241,26 @@ class GradReducer:
         return best
 
 
+# RRDBNet features handed to the head as an fp16 channels_last tensor whenever the head's convolutions run their fp16-operand forms
+# (inference chain, TrainStep's 'f16' mode): conv_hr rounds once in its epilogue -- exactly what the head's entry kernel did while
+# staging the fp32 tensor, so the forward values do not change by a bit -- and conv_hr's write, the entry's read and the two entry
+# weight gradients' reads halve (round-3 VERDICT, What's weak #7).  SRBH_FEATURE_H16=0: the fp32 hand-off (A/B aid).
+FEATURE_H16 = os.environ.get("SRBH_FEATURE_H16", "1") == "1"
+
+
+def features_for_head(net_hr, x, h16=None):
+    """net_hr.forward_feature(x) in the element type the head will stage: fp16 when its fp16-operand kernels are active (h16: the
+    caller's hrfuse.head_h16() in the grad mode the HEAD will run in; None = right now) and the trunk is on its fast path, else the
+    fp32 tensor of the nn.Module API"""
+    from . import hrfuse as _H
+    if h16 is None:
+        h16 = _H.head_h16()
+    if (FEATURE_H16 and h16 and hasattr(net_hr, "_use_strict") and not net_hr._use_strict()
+            and not (getattr(net_hr, "_train_path", False) and torch.is_grad_enabled())):
+        return net_hr.forward_feature(x, out_dtype=torch.float16)
+    return net_hr.forward_feature(x)
+
+
 class TrainStep:
     """train.py:133-179,243-256: frozen RRDBNet feature extractor + trainable SRRegress_Cls_feature, three
     uncertainty-weighted losses, Adam(lr 1e-3, wd 1e-4) with the log_vars as an extra param group.
@@ -328,7 +348,9 @@ class TrainStep:
             # pinned, so calling net_hr at other geometries between replays cannot free them) -- wcache.Holder
             self._holder = wcache.Holder()
             with wcache.capturing(self._holder):
-                self.net_hr.forward_feature(self._static[0].index_select(1, self._rgb_idx))   # eager: reports packs + workspace
+                h16 = self._H.head_h16()
+                with torch.no_grad():
+                    features_for_head(self.net_hr, self._static[0].index_select(1, self._rgb_idx), h16)   # eager: reports packs + workspace
                 torch.cuda.synchronize()
                 with torch.cuda.graph(self._graph):
                     self._static_out = self._step(self._static, in_graph=True)
@@ -364,8 +386,9 @@ class TrainStep:
 
     def _step(self, batch, in_graph=False):
         lr, height, height_aggre, build, weight, weight_aggre = batch
+        h16 = self._H.head_h16()              # (in the grad mode the head runs in: 'auto' trains exact-fp32 and takes fp32 features)
         with torch.no_grad():
-            hr_fea = self.net_hr.forward_feature(lr.index_select(1, self._rgb_idx))
+            hr_fea = features_for_head(self.net_hr, lr.index_select(1, self._rgb_idx), h16)
         height_pred, build_pred, height_pred_aggre = self.net(lr, hr_fea)
         loss = (self.criterion[0](height_pred.squeeze(1), height, weight)
                 + self.criterion[1](height_pred_aggre.squeeze(1), height_aggre, weight_aggre)
@@ -468,12 +491,12 @@ class _PredictGraph:
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    model(self.x, net_hr.forward_feature(self.x[:, :3]))
+                    model(self.x, features_for_head(net_hr, self.x[:, :3]))
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self.out = model(self.x, net_hr.forward_feature(self.x[:, :3]))
+                self.out = model(self.x, features_for_head(net_hr, self.x[:, :3]))
 
     @staticmethod
     def weights_key(net_hr, model, batch, dev):
@@ -526,7 +549,7 @@ def predict_tiles(net_hr, model, tiles, posall, mosaic, batch=32, rank=0, world=
             q = batch if not pad_to else min(batch, (k + pad_to - 1) // pad_to * pad_to)
             if q > k:
                 x = torch.cat([x, x.new_zeros((q - k,) + tuple(x.shape[1:]))], 0)
-        hr_fea = net_hr.forward_feature(x[:, :3])
+        hr_fea = features_for_head(net_hr, x[:, :3])
         out = model(x, hr_fea)
         mosaic.add(out[0][:k], out[1][:k], posall[s:e])
     if hi > lo and hasattr(net_hr, "check_status"):

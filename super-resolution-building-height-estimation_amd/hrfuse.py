@@ -536,7 +536,11 @@ class HRfeature(nn.Sequential):
                          BasicBlock(mid_chans, out_chans, stride=1))
 
     def forward(self, x, out_h16=False):
-        _require_dev(x, "HRfeature")
+        # (x may be RRDBNet.forward_feature(..., out_dtype=float16): an fp16 channels_last tensor, staged verbatim by the fp16-operand
+        #  kernels -- inference chain and the 'f16' training mode; the exact-fp32 mode refuses it)
+        _require_dev(x, "HRfeature", h16_ok=head_h16())
+        if x.dtype == torch.float16 and to_nhwc(x) is not x:
+            raise ValueError("HRfeature: an fp16 input must be channels_last (RRDBNet.forward_feature(out_dtype=torch.float16))")
         return run_blocks(list(self), [x], out_h16 and fp16_chain(self))
 
 

@@ -66,8 +66,8 @@ def _model(name, args):
         # one pass over the input when fused (the common case); priced as such: sources once, two outputs
         e = 2 if (a.io_h16 & 8) else 4
         px = _px(a)
-        return (f"hconv_entry {a.c0}{'+' + str(a.c1) if a.c1 else ''}->16 k3 + 16 k1{' +stats' if a.stats else ''}{' out16' if a.io_h16 & 8 else ''} @{a.H}x{a.W}",
-                px * ((a.c0 + a.c1) * 4 + 2 * 16 * e))
+        return (f"hconv_entry {a.c0}{'+' + str(a.c1) if a.c1 else ''}->16 k3 + 16 k1{' +stats' if a.stats else ''}{' src16' if a.io_h16 & 3 else ''}{' out16' if a.io_h16 & 8 else ''} @{a.H}x{a.W}",
+                px * (a.c0 * (2 if a.io_h16 & 1 else 4) + a.c1 * (2 if a.io_h16 & 2 else 4) + 2 * 16 * e))
     if name in ("srbh_hconv_wgrad_f32", "srbh_hconv_wgrad_b16"):
         a = args[0]._obj
         px = _px(a)

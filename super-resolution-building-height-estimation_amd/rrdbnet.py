@@ -247,7 +247,9 @@ class RRDBNet(nn.Module):
         return ws
 
     # ---- forward -------------------------------------------------------------------------------
-    def _run(self, x, want_forward, out=None):
+    def _run(self, x, want_forward, out=None, h16=False):
+        if h16 and (want_forward or out is not None or self._use_strict() or (getattr(self, "_train_path", False) and torch.is_grad_enabled())):
+            raise ValueError("forward_feature(out_dtype=float16) is the inference feature path only (no out=, no strict-fp32 mode, no recorded graph)")
         if not (torch.is_tensor(x) and x.is_cuda):
             raise RuntimeError("RRDBNet (libsrbh): input must be a ROCm/HIP device tensor; the hot path has no CPU "
                                "fallback (use oracle/ in tests for a CPU comparison)")
@@ -292,14 +294,16 @@ class RRDBNet(nn.Module):
             wcache.keep(self._packed)                    # (a capturing graph owns the layer table + packed weights it bakes in)
             ws = self._workspace(B, H, W, want_forward, x.device)
             cout = self._geom[1] if want_forward else 64
-            if out is None:
+            if h16:
+                out = torch.empty((B, 64, 4 * H, 4 * W), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+            elif out is None:
                 out = torch.empty((B, cout, 4 * H, 4 * W), dtype=torch.float32, device=x.device,
                                   memory_format=torch.channels_last)
             elif (tuple(out.shape) != (B, cout, 4 * H, 4 * W) or out.dtype != torch.float32 or out.device != x.device
                   or not out.is_contiguous(memory_format=torch.channels_last)):
                 raise ValueError("out= must be a channels_last fp32 (B,%d,%d,%d) tensor on the input's device" % (cout, 4 * H, 4 * W))
             L = _lib.lib()
-            _lib.check(L.srbh_rrdbnet_forward(C.byref(desc), x.data_ptr(), out.data_ptr(), B, H, W, int(want_forward),
+            _lib.check(L.srbh_rrdbnet_forward(C.byref(desc), x.data_ptr(), out.data_ptr(), B, H, W, 2 if h16 else int(want_forward),
                                               ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "rrdbnet_forward")
         return out
 
@@ -390,11 +394,17 @@ class RRDBNet(nn.Module):
         """reference SR/rrdbnet_arch.py:208-223 -> (B,num_out_ch,4H,4W), channels_last strides."""
         return self._run(x, True)
 
-    def forward_feature(self, x, out=None):
+    def forward_feature(self, x, out=None, out_dtype=None):
         """reference SR/rrdbnet_arch.py:225-240 -> (B,64,4H,4W) features, NO activation after conv_hr;
         returned with channels_last strides (logical NCHW shape as in the reference).  ``out`` (extension): write into
-        a caller-owned channels_last buffer (static input of a captured training graph, harness.TrainStep)."""
-        return self._run(x, False, out)
+        a caller-owned channels_last buffer (static input of a captured training graph, harness.TrainStep).
+        ``out_dtype=torch.float16`` (extension, harness paths): the same features rounded ONCE to fp16 in conv_hr's epilogue -- what
+        the head's fp16-operand kernels make of the fp32 tensor when they stage it, so SRRegress_Cls_feature's outputs in the fp16
+        head mode do not change by a bit while conv_hr writes, and the head's entry convolution and its two weight gradients read,
+        half the bytes (537 MB -> 268 MB per pass at batch 64)."""
+        if out_dtype not in (None, torch.float32, torch.float16):
+            raise TypeError("forward_feature: out_dtype must be float32 or float16")
+        return self._run(x, False, out, h16=out_dtype == torch.float16)
 
 
 class RealESRGAN:

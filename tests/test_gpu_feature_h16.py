@@ -1,0 +1,116 @@
+"""GPU: RRDBNet features handed to the head as an fp16 channels_last tensor (RRDBNet.forward_feature(out_dtype=float16),
+harness.features_for_head; round-3 VERDICT What's weak #7).  conv_hr (SR/rrdbnet_arch.py:238) rounds ONCE in its epilogue -- the
+rounding the head's fp16-operand entry kernel (SR/HRfuse.py:142-159: conv1 + downsample[0] of HRfeature's first BasicBlock) applied
+while staging the fp32 tensor -- so every forward value of the fp16 head mode is unchanged, bit for bit."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+DEV = "cuda:0"
+
+
+def _nets(num_block=1, seed=5):
+    from oracle import synth
+    from srbh_amd.models import SRRegress_Cls_feature
+    from srbh_amd.rrdbnet import RRDBNet
+    net_hr = RRDBNet(3, 3, num_block=num_block)
+    net_hr.load_state_dict(synth.rrdbnet_state_dict(num_block=num_block, seed=seed, mode="stress"))
+    torch.manual_seed(seed)
+    net = SRRegress_Cls_feature("efficientnet-b4", in_channels=8, super_in=64, super_mid=16, upscale=4, isaggre=True, chans_build=7)
+    return net_hr.to(DEV).eval(), net.to(DEV)
+
+
+@pytest.mark.parametrize("B", [1, 3, 5])          # (1, 3: fewer than 512 tiles -- the NHWC16 store exists in the persistent tail kernel only)
+def test_feature_h16_is_the_fp32_feature_rounded_once(B):
+    from oracle import synth
+    net_hr, _ = _nets()
+    x = synth.tiles(B, 8, 64, seed=3)[:, :3].contiguous().to(DEV)
+    with torch.no_grad():
+        y32 = net_hr.forward_feature(x)
+        y16 = net_hr.forward_feature(x, out_dtype=torch.float16)
+    assert y16.dtype == torch.float16 and y16.shape == y32.shape and y16.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(y16, y32.half())
+    net_hr.check_status()
+    with pytest.raises(ValueError):
+        net_hr.forward_feature(x, out=torch.empty_like(y32), out_dtype=torch.float16)
+    net_hr.precision = "f32"
+    with pytest.raises(ValueError):
+        net_hr.forward_feature(x, out_dtype=torch.float16)
+
+
+def test_eval_outputs_do_not_change_by_a_bit():
+    from oracle import synth
+    from srbh_amd import harness
+    from srbh_amd import hrfuse as H
+    net_hr, net = _nets()
+    net.eval()
+    x = synth.tiles(4, 8, 64, seed=9).to(DEV)
+    with torch.no_grad():
+        assert H.head_h16()                                  # 'auto' + no_grad: the fp16-operand inference chain
+        f16 = harness.features_for_head(net_hr, x[:, :3].contiguous())
+        assert f16.dtype == torch.float16
+        a = net(x, f16)
+        b = net(x, net_hr.forward_feature(x[:, :3].contiguous()))
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    # the exact-fp32 head refuses an fp16 tensor instead of silently widening it
+    with H.head_precision("f32"), torch.no_grad(), pytest.raises(TypeError):
+        net(x, f16)
+
+
+def test_entry_kernel_and_weight_gradients_from_fp16_features():
+    """The training-mode entry (conv1 3x3 + downsample 1x1 over the 64-channel features, with BatchNorm statistics): outputs and
+    statistics from the fp16 tensor are bit-identical to those from the fp32 tensor it was rounded from; the two entry weight
+    gradients (bf16 operands) see fp16 -> bf16 instead of fp32 -> bf16: a double rounding inside a bf16 product."""
+    from srbh_amd import hrfuse as H
+    from srbh_amd import hrfuse_autograd as HA
+    _, net = _nets()
+    blk = net.hrfeat[0]
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((3, 64, 64, 128), generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    x16 = x.half()
+    dy = (torch.randn((3, 16, 64, 128), generator=g) * 1e-3).to(DEV).contiguous(memory_format=torch.channels_last)
+    with H.head_precision("f16"), torch.no_grad():
+        c1, s1, d, sd = H.hconv_entry([x], blk.conv1, blk._p1, blk.downsample[0], blk._pd, want_stats=True)
+        c2, s2, d2, sd2 = H.hconv_entry([x16], blk.conv1, blk._p1, blk.downsample[0], blk._pd, want_stats=True)
+        assert torch.equal(c1, c2) and torch.equal(d, d2) and torch.equal(s1, s2) and torch.equal(sd, sd2)
+        for ks in (3, 1):
+            for gy in (dy, dy.bfloat16()):
+                a = HA.conv_wgrad([x16], None, gy, 16, ks).double()
+                b = HA.conv_wgrad([x], None, gy, 16, ks).double()
+                assert float((a - b).norm() / b.norm()) < 2e-3, (ks, gy.dtype)
+                ref = HA.conv_wgrad([x16.float().contiguous(memory_format=torch.channels_last)], None, gy, 16, ks).double()
+                assert float((a - ref).norm() / ref.norm()) < 1e-6, (ks, gy.dtype)       # (fp16 -> bf16 of the SAME values: same products)
+
+
+def test_train_step_runs_on_fp16_features(monkeypatch):
+    """TrainStep(head_precision='f16') end to end on the fp16 hand-off: same loss as with the fp32 hand-off up to the step's own
+    run-to-run noise (training-mode BatchNorm statistics are atomics: two runs of ONE configuration already differ by ~4e-3 in the
+    height maps), weights stay finite, the exact-fp32 mode keeps taking fp32 features."""
+    from srbh_amd import encoders, harness
+    monkeypatch.setattr(encoders, "DROP_CONNECT", 0.0)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(harness, "FEATURE_H16", mode)
+        net_hr, net = _nets()
+        seen = []
+        orig = net.hrfeat.forward
+        net.hrfeat.forward = lambda x, out_h16=False, _o=orig, _s=seen: (_s.append(x.dtype), _o(x, out_h16))[1]
+        ts = harness.TrainStep(net_hr, net, DEV, lr=1e-4, status_every=0)
+        batch = harness.synthetic_batch(4, 21, DEV)
+        losses = [float(ts(batch)[0]) for _ in range(3)]
+        assert seen == [torch.float16 if mode else torch.float32] * 3
+        assert all(torch.isfinite(p).all() for p in net.parameters())
+        res[mode] = losses
+    for a, b in zip(res[True], res[False]):
+        assert abs(a - b) <= 2e-2 * abs(b), (res[True], res[False])
+    net_hr, net = _nets()
+    seen = []
+    orig = net.hrfeat.forward
+    net.hrfeat.forward = lambda x, out_h16=False, _o=orig, _s=seen: (_s.append(x.dtype), _o(x, out_h16))[1]
+    harness.TrainStep(net_hr, net, DEV, lr=1e-4, status_every=0, head_precision="f32")(harness.synthetic_batch(2, 3, DEV))
+    assert seen == [torch.float32]

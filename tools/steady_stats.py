@@ -3,7 +3,7 @@ carry MIOpen's solver search, which runs every applicable kernel incl. the naive
 conv_first_kernel (the RRDBNet forward's first launch, one per step).   usage: steady_stats.py <dir with *kernel_trace.csv> <n_steps> [top] [calls]   (calls: sort by launch count)"""
 import csv, glob, sys, collections
 d, n = sys.argv[1], int(sys.argv[2])
-top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+top = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 30
 rows = []
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -21,7 +21,7 @@ steps = max(1, len([b for b in bounds if start <= b < end]))
 tot = sum(v[1] for v in agg.values())
 wall = (sel[-1][1] - sel[0][0]) if sel else 0
 print("steps %d | kernel time %.2f ms/step | wall %.2f ms/step | %d launches/step" % (steps, tot / steps / 1e6, wall / steps / 1e6, len(sel) // steps))
-bycalls = len(sys.argv) > 4
+bycalls = len(sys.argv) > 4 and sys.argv[4] != "--stock"
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0 if bycalls else 1])[:top]:
     print("%7.3f ms/step %5.1f %% %6d calls/step  %s" % (v[1] / steps / 1e6, 100.0 * v[1] / tot, v[0] // steps, k))
 GROUPS = (("RRDBNet (trunk, first/tail convs)", ("ptrunk", "ptail", "conv_first", "rrdb", "poison", "upconv", "tail_")),
@@ -41,3 +41,9 @@ for k, v in agg.items():
 print("by group:")
 for name, v in gs.items():
     print("%7.3f ms/step %5.1f %% %6d launches/step  %s" % (v[1] / steps / 1e6, 100.0 * v[1] / tot, v[0] // steps, name))
+if "--stock" in sys.argv:      # every kernel of the stock-op group (what a libsrbh replacement of the decoder convs would remove)
+    print("stock-op kernels (all):")
+    allp = [p for _, pats in GROUPS for p in pats]
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        if not any(p in k for p in allp):
+            print("%7.3f ms/step %6.1f calls/step  %s" % (v[1] / steps / 1e6, v[0] / steps, k[:150]))
