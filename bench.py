@@ -418,6 +418,7 @@ def bench_predict(args, rank, world, dev, dist, n_cities, warmup, batch=128, sma
                                f"seed 2024{', the ones closest to the median size' if small else ''}), batch {batch}/GPU (BASELINE.json configs[4])",
                    "cities": len(todo), "tiles": total, "parallelism": f"each city's cells sharded x{world}, integer mosaic row bands sent to rank 0"},
         "p50_city_latency_ms": round(lat[mid] * 1e3, 2), "p50_city_tiles": todo[mid],
+        "p95_city_latency_ms": round(lat[order[min(len(order) - 1, int(0.95 * len(order)))]] * 1e3, 2),
         "max_city_latency_ms": round(max(lat) * 1e3, 2), "max_city_tiles": max(todo),
         "large_cities": {"n_over_10k_cells": sum(1 for c in todo if c > 10000),
                          "tiles_per_s": round(sum(c for c in todo if c > 10000) / max(1e-9, sum(l for c, l in zip(todo, lat) if c > 10000)), 2)

@@ -512,6 +512,17 @@ int srbh_height_metric_sums(const float* pred, const float* ref, const long long
 int srbh_confusion_add(const long long* pred, const long long* label, long n, int num_class,
                        unsigned long long* cm, int* bad_flag, void* stream);
 
+/* ---- 3x3 convolutions of the two U-Net decoders (mymodels.py:245-258 builds them, :279 / :287 call them; smp UnetDecoder blocks:
+ * nearest x2 -> concat skip -> [Conv3x3 (no bias) + BatchNorm + ReLU] x 2) on NCHW fp32 tensors, square planes 4x4 ... 64x64, 16-bit
+ * matrix-core operands, fp32 accumulation (csrc/srbh_dconv.hip).  Weights: srbh_hpack_conv_h16(w, Cout, Cin, 3, transpose_flip, bf16, ...).
+ *   srbh_dconv_fwd(bf16 = 0): y = conv3x3(x, w), fp16 operands;
+ *   srbh_dconv_fwd(bf16 = 1) with the transposed + flipped pack (hpack cout := forward Cin, cin := forward Cout): dX = conv^T(dY, W);
+ *   srbh_dconv_wgrad: dW = sum_pixels dY (x) shifted X, bf16 operands, deterministic (ws: srbh_dconv_wgrad_ws_floats floats). */
+int srbh_dconv_supported(int B, int Cin, int Cout, int H, int W);
+int srbh_dconv_fwd(const float* x, const void* wpack, float* y, int B, int Cin, int Cout, int H, int W, int bf16, void* stream);
+size_t srbh_dconv_wgrad_ws_floats(int B, int Cin, int Cout, int H, int W);
+int srbh_dconv_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int Cout, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libsrbh.so")
 _DEV_LIB = os.environ.get("SRBH_LIB_PATH")      # developer A/B only (tools/ab_variants.sh): load another build of the same ABI
-SOURCES = ["srbh_conv3x3.hip", "srbh_aux.hip", "srbh_rrdbnet.hip", "srbh_ptrunk.hip", "srbh_ptail.hip", "srbh_head.hip", "srbh_head_bwd.hip", "srbh_mosaic.hip", "srbh_loader.hip", "srbh_loss.hip", "srbh_dwconv.hip", "srbh_mbconv.hip", "srbh_pwconv.hip"]
+SOURCES = ["srbh_conv3x3.hip", "srbh_aux.hip", "srbh_rrdbnet.hip", "srbh_ptrunk.hip", "srbh_ptail.hip", "srbh_head.hip", "srbh_head_bwd.hip", "srbh_mosaic.hip", "srbh_loader.hip", "srbh_loss.hip", "srbh_dwconv.hip", "srbh_mbconv.hip", "srbh_pwconv.hip", "srbh_dconv.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # NOTE: `-mllvm -amdgpu-mfma-vgpr-form=1` (accumulators in VGPRs: no v_accvgpr copies at K-loop back-edges).  Round 1 saw the
 # first persistent trunk kernel produce non-deterministic garbage with it; round 3 re-ran it on the current kernel (ptrunk3:
@@ -192,6 +192,10 @@ SIGNATURES = {
     "srbh_se_train_bwd_ws_floats": (_sz, [_i, _i, _i]),
     "srbh_up2_cat_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "srbh_up2_cat_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "srbh_dconv_supported": (_i, [_i, _i, _i, _i, _i]),
+    "srbh_dconv_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "srbh_dconv_wgrad_ws_floats": (_sz, [_i, _i, _i, _i, _i]),
+    "srbh_dconv_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "srbh_pwconv_supported": (_i, [_i, _i, _i, _i]),
     "srbh_pwconv_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_pwconv_fwd_wt": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),

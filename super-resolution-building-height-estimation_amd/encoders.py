@@ -493,6 +493,105 @@ def get_encoder(name, in_channels=3, depth=5, weights=None, **kwargs):
     return enc
 
 
+# 3x3 convolutions of the U-Net decoders on libsrbh (csrc/srbh_dconv.hip) whenever the 16-bit operand policy of the head is active
+# (hrfuse.head_h16(): the inference chain, TrainStep's 'f16' mode): fp16 forward, bf16 data / weight gradients, fp32 accumulation,
+# NCHW fp32 tensors in and out.  The exact-fp32 modes keep the stock convolution (MIOpen), counted in STOCK_OPS.  SRBH_DCONV=0: never.
+DCONV = __import__("os").environ.get("SRBH_DCONV", "1") == "1"
+
+
+class _DecoderConvPacks:
+    """fragment-order 16-bit images of one decoder conv weight: fp16 for the forward, bf16 transposed + flipped for the data gradient;
+    remade when the weight changes (version / address / generation stamp: fused optimizers and graph replays do not bump _version)"""
+
+    def __init__(self):
+        self.kf = self.kb = None
+        self.f = self.b = None
+
+    @staticmethod
+    def _key(w):
+        return (w._version, w.data_ptr(), wcache.gen(w), str(w.device))
+
+    def fwd(self, w):
+        from . import _lib
+        k = self._key(w)
+        if k != self.kf:
+            L = _lib.lib()
+            cout, cin = w.shape[:2]
+            wc = w.detach().float().contiguous()
+            self.f = torch.empty(L.srbh_hpack_h16_bytes(cout, cin, 3) // 2, dtype=torch.int16, device=w.device)
+            _lib.check(L.srbh_hpack_conv_h16(wc.data_ptr(), cout, cin, 3, 0, 0, self.f.data_ptr(), _lib.stream_ptr()), "hpack_conv_h16")
+            self.kf = k
+        wcache.keep(self.f)
+        return self.f
+
+    def bwd(self, w):
+        from . import _lib
+        k = self._key(w)
+        if k != self.kb:
+            L = _lib.lib()
+            cout, cin = w.shape[:2]
+            wc = w.detach().float().contiguous()
+            self.b = torch.empty(L.srbh_hpack_h16_bytes(cin, cout, 3) // 2, dtype=torch.int16, device=w.device)
+            _lib.check(L.srbh_hpack_conv_h16(wc.data_ptr(), cin, cout, 3, 1, 1, self.b.data_ptr(), _lib.stream_ptr()), "hpack_conv_h16")
+            self.kb = k
+        wcache.keep(self.b)
+        return self.b
+
+
+class _DecoderConvFn(torch.autograd.Function):
+    """y = conv3x3(x, w) (stride 1, padding 1, no bias) on libsrbh: one launch forward, one for the input gradient, two (partials +
+    ordered reduce) for the weight gradient -- MIOpen: fp32 Winograd + NHWC implicit-GEMM weight gradients behind batched transposes
+    and zero fills, ~6 launches per conv and step."""
+
+    @staticmethod
+    def forward(ctx, x, weight, packs):
+        from . import _lib
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().srbh_dconv_fwd(x.data_ptr(), packs.fwd(weight).data_ptr(), y.data_ptr(), B, Cin, Cout, H, W, 0,
+                                             _lib.stream_ptr()), "dconv_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.packs = packs
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        x, weight = ctx.saved_tensors
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        dy = dy.contiguous()
+        L = _lib.lib()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(L.srbh_dconv_fwd(dy.data_ptr(), ctx.packs.bwd(weight).data_ptr(), dx.data_ptr(), B, Cout, Cin, H, W, 1,
+                                        _lib.stream_ptr()), "dconv_fwd (data gradient)")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            ws = torch.empty(L.srbh_dconv_wgrad_ws_floats(B, Cin, Cout, H, W), dtype=torch.float32, device=x.device)
+            _lib.check(L.srbh_dconv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, Cin, Cout, H, W, _lib.stream_ptr()),
+                       "dconv_wgrad")
+        return dx, dw, None
+
+
+def decoder_conv(conv, x):
+    """conv(x) for a decoder 3x3 conv: libsrbh when the 16-bit operand policy is active and the shape is taken, else the module"""
+    if (DCONV and x.is_cuda and x.dtype == torch.float32 and conv.bias is None and conv.weight.dtype == torch.float32 and x.dim() == 4
+            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.groups == 1):
+        from . import _lib
+        from . import hrfuse as _H
+        if _H.head_h16() and _lib.lib().srbh_dconv_supported(x.shape[0], x.shape[1], conv.weight.shape[0], x.shape[2], x.shape[3]):
+            packs = conv.__dict__.get("_srbh_dconv_packs")
+            if packs is None:
+                packs = conv.__dict__["_srbh_dconv_packs"] = _DecoderConvPacks()
+            return _DecoderConvFn.apply(x, conv.weight, packs)
+    _stock("decoder_conv3x3", x)             # (MIOpen: the exact-fp32 modes, CPU tensors are not counted)
+    return conv(x)
+
+
 class _ConvBnRelu(nn.Sequential):
     def __init__(self, cin, cout, use_batchnorm=True):
         mods = [nn.Conv2d(cin, cout, 3, padding=1, bias=not use_batchnorm)]
@@ -503,9 +602,8 @@ class _ConvBnRelu(nn.Sequential):
         self._bn = use_batchnorm
 
     def forward(self, x):
-        _stock("decoder_conv3x3", x)             # (MIOpen; the libsrbh form is the next step: DESIGN.md 3.10)
         if self._bn:
-            return bn_act(self[1], self[0](x), "relu")
+            return bn_act(self[1], decoder_conv(self[0], x), "relu")
         return super().forward(x)
 
 
