@@ -255,11 +255,14 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const DWGParams p) {
             v.r[d] = (rok && x0 + 4 < W) ? xb[yy * W + 4] : 0.f;
         }
     };
+    // a wave walks a CONTIGUOUS range of K steps: consecutive 16-pixel groups of a row share cache lines, and the rows y - 1 / y / y + 1 of
+    // one step are y / y + 1 / y + 2 of a later one (L1 / L2 hits instead of three far-apart fetches per step)
+    const long per = (steps + KS - 1) / KS, s_lo = ks * per, s_hi = s_lo + per < steps ? s_lo + per : steps;
     Ld cur, nxt;
-    if (ks < steps) load(ks, cur);
-    for (long st = ks; st < steps; st += KS) {
-        const bool more = st + KS < steps;
-        if (more) load(st + KS, nxt);
+    if (s_lo < s_hi) load(s_lo, cur);
+    for (long st = s_lo; st < s_hi; ++st) {
+        const bool more = st + 1 < s_hi;
+        if (more) load(st + 1, nxt);
         short4v a[MO];
 #pragma unroll
         for (int mo = 0; mo < MO; ++mo) a[mo] = cvt4<1>(cur.a[mo][0], cur.a[mo][1], cur.a[mo][2], cur.a[mo][3]);
@@ -295,27 +298,40 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const DWGParams p) {
     }
 }
 
-// partial [split][tile = tco * cib + tci][mo][tap][16 co][16 ci] -> dW [Cout][Cin][3][3], splits summed in a fixed order
+// partial [split][tile = tco * cib + tci][mo][tap][16 co][16 ci] -> dW [Cout][Cin][3][3], splits summed in a fixed order.
+// Thread = one element of the partial layout (coalesced reads; the scattered 4-byte writes are few); the four waves of a workgroup take
+// every fourth split with two independent chains each and fold through LDS -- a single chain over 512 splits was a 100 us latency chain
+// of its own (the 16 -> 16 conv at 64x64: one dW block, 512 K-splits).
 template <int MO>
 __global__ __launch_bounds__(256) void dconv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cout, int Cin, int cib,
                                                                  int ntile, int nsplit) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)Cout * Cin * 9;
-    if (i >= total) return;
-    const int tap = (int)(i % 9);
-    const long r = i / 9;
-    const int ci = (int)(r % Cin), co = (int)(r / Cin);
-    const int tco = co / (16 * MO), mo = (co / 16) % MO, tci = ci / 16;
-    const long off = ((long)(tco * cib + tci) * MO + mo) * 9 * 256 + (long)tap * 256 + (co & 15) * 16 + (ci & 15);
+    __shared__ float red[4][64];
+    const int ln = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const long stride = (long)ntile * MO * 9 * 256;
+    const long j = (long)blockIdx.x * 64 + ln;
     float a0 = 0.f, a1 = 0.f;
-    int s = 0;
-    for (; s + 1 < nsplit; s += 2) {
-        a0 += part[s * stride + off];
-        a1 += part[(s + 1) * stride + off];
+    if (j < stride) {
+        int s = sg;
+        for (; s + 4 < nsplit; s += 8) {
+            a0 += part[s * stride + j];
+            a1 += part[(s + 4) * stride + j];
+        }
+        if (s < nsplit) a0 += part[s * stride + j];
     }
-    if (s < nsplit) a0 += part[s * stride + off];
-    dw[i] = a0 + a1;
+    red[sg][ln] = a0 + a1;
+    __syncthreads();
+    if (sg == 0 && j < stride) {
+        const float v = (red[0][ln] + red[1][ln]) + (red[2][ln] + red[3][ln]);
+        const int cil = (int)(j & 15), col = (int)((j >> 4) & 15);
+        long f = j >> 8;
+        const int tap = (int)(f % 9);
+        f /= 9;
+        const int mo = (int)(f % MO);
+        const int tile = (int)(f / MO);
+        const int tco = tile / cib, tci = tile - tco * cib;
+        const int co = (tco * MO + mo) * 16 + col, ci = tci * 16 + cil;
+        if (co < Cout && ci < Cin) dw[((long)co * Cin + ci) * 9 + tap] = v;
+    }
 }
 
 int log2_exact(int v) {
@@ -438,9 +454,9 @@ extern "C" int srbh_dconv_wgrad(const float* x, const float* dy, float* dw, floa
     }
 #undef SRBH_DWG
     SRBH_HIP(hipGetLastError());
-    const long total = (long)Cout * Cin * 9;
-    if (mo == 2) hipLaunchKernelGGL(dconv_wgrad_reduce_kernel<2>, dim3((total + 255) / 256), dim3(256), 0, st, ws, dw, Cout, Cin, p.cib, ntile, p.nsplit);
-    else hipLaunchKernelGGL(dconv_wgrad_reduce_kernel<1>, dim3((total + 255) / 256), dim3(256), 0, st, ws, dw, Cout, Cin, p.cib, ntile, p.nsplit);
+    const long total = (long)ntile * mo * 9 * 256;
+    if (mo == 2) hipLaunchKernelGGL(dconv_wgrad_reduce_kernel<2>, dim3((total + 63) / 64), dim3(256), 0, st, ws, dw, Cout, Cin, p.cib, ntile, p.nsplit);
+    else hipLaunchKernelGGL(dconv_wgrad_reduce_kernel<1>, dim3((total + 63) / 64), dim3(256), 0, st, ws, dw, Cout, Cin, p.cib, ntile, p.nsplit);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }
