@@ -311,6 +311,10 @@ int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream);
  * same workspace and fixed summation order.  Needs c0, c1, the pixel strides % 4 == 0, cout % 16 == 0 and 16-byte aligned
  * pointers; a layer outside that (the 1- / 7-channel output convs) is computed by the fp32 kernel. */
 int srbh_hconv_wgrad_b16(const srbh_hwgrad_args* a, void* stream);
+/* The two weight gradients of a BasicBlock ENTRY (SR/HRfuse.py:142-159: conv1 = 3x3, downsample[0] = 1x1, same input) in ONE pass over
+ * that input: a3 / a1 = the arguments the two srbh_hconv_wgrad_b16 calls would take.  Fused when they describe the same sources, shape
+ * and element types (cout a multiple of 16, 4-aligned channels); otherwise it runs the two calls.  Same results either way. */
+int srbh_hconv_wgrad_entry_b16(const srbh_hwgrad_args* a3, const srbh_hwgrad_args* a1, void* stream);
 /* out = g where ref > 0 else 0   (ReLU backward with the saved output, SR/HRfuse.py:157) */
 int srbh_relu_mask_mul(const float* g, const float* ref, float* out, long n, void* stream);
 int srbh_add_inplace(float* a, const float* b, long n, void* stream);

@@ -168,6 +168,7 @@ SIGNATURES = {
     "srbh_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_hconv_wgrad_f32": (_i, [C.POINTER(HWGradArgs), _vp]),
     "srbh_hconv_wgrad_b16": (_i, [C.POINTER(HWGradArgs), _vp]),
+    "srbh_hconv_wgrad_entry_b16": (_i, [C.POINTER(HWGradArgs), C.POINTER(HWGradArgs), _vp]),
     "srbh_relu_mask_mul": (_i, [_vp, _vp, _vp, C.c_long, _vp]),
     "srbh_add_inplace": (_i, [_vp, _vp, C.c_long, _vp]),
     "srbh_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp, _vp]),

@@ -41,6 +41,9 @@ struct WGParams {
     long x_img_b, dy_img_b;
     int x_plane_b, x_row_b, dy_plane_b, dy_row_b, dy_ch0;
     int zchunk;           // 1: the 16-channel input chunk is blockIdx.z (few tiles per launch: one (tile set, oc block, chunk) per workgroup)
+    // fused block-entry form (hwgrad_b16_kernel<3, DS, 0, 1>): the 1x1 downsample conv's dY over the SAME input -- one more accumulator on
+    // the centre-tap fragment; its partial sums go to ws2 (layout of a ksize = 1 call)
+    const float* dy2; float* ws2;
 };
 
 // 4 elements of a 16-bit tensor (raw bits in a float2w) -> fp32: fp16 activations / bf16 gradients
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(256) void hwgrad_f32_kernel(const WGParams p) {
         floatx4 acc[TAPS];
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp) acc[tp] = floatx4{0.f, 0.f, 0.f, 0.f};
+        floatx4 acc2 = {0.f, 0.f, 0.f, 0.f};
         // XCD-aware walk (see hconv_f32_kernel): XCD x = blockIdx % 8 owns the contiguous tiles [x*per_xcd, (x+1)*per_xcd), its
         // gridDim/8 workgroups sweep them side by side, so the tiles' shared halo rows are re-read from that XCD's L2
         const int t_end = min((int)(blockIdx.x & 7) * p.tiles_per_xcd + p.tiles_per_xcd, p.ntiles);
@@ -278,18 +282,25 @@ struct WG16 {
     static constexpr int SX = KS == 3 ? 388 : 260;     // dwords per staged X channel (>= ROWS*QX*2, = 4 mod 64)
     static constexpr int SD = 260;                     // dwords per staged dY channel (8 rows x 64 pixels / 2 + 4)
     static constexpr int LDS_B = (16 * SX + 16 * SD) * 4;   // >= the flush buffer (4 waves x TAPS x 256 floats)
+    static constexpr int LDS_B2 = (16 * SX + 32 * SD) * 4;  // + the second dY tile of the fused block-entry form (>= 4 x (TAPS + 1) x 256 floats)
 };
 
 // DS = 1: dY holds bf16 elements in memory (an internal gradient tensor of the training step): its bits are the operand
 // XM = 1: both tensors are ACT16 chunk planes (WGParams::x_* / dy_*): X fp16, dY bf16 (DS must be 1)
-template <int KS, int DS, int XM = 0>
+// D2 = 1 (KS = 3, XM = 0): fused BasicBlock entry (SR/HRfuse.py:142-159): conv1 (3x3) and downsample[0] (1x1) read the same input, so
+//   their weight gradients share the staged X tile -- the 1x1 gradient is one more MFMA per K step on the centre-tap fragment with its
+//   own dY (p.dy2, same element type and channel count as dy); what bounds these kernels is the X staging (fp32 / fp16 -> bf16, 4x4
+//   register transposes into channel-major rows), which the separate 1x1 launch repeated in full.
+template <int KS, int DS, int XM = 0, int D2 = 0>
 __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
+    static_assert(D2 == 0 || (KS == 3 && XM == 0), "the fused entry form is the 3x3 NHWC kernel");
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     using G = WG16<KS>;
     constexpr int TAPS = G::TAPS, HALO = G::HALO, ROWS = G::ROWS, QX = G::QX, SX = G::SX, SD = G::SD;
     static_assert(G::LDS_B >= 4 * TAPS * 256 * 4, "flush buffer must fit");
     unsigned* s_x = (unsigned*)wsm;                 // [16 ci][SX]
     unsigned* s_dy = s_x + 16 * SX;                 // [16 oc][SD]
+    unsigned* s_dy2 = s_dy + 16 * SD;               // [16 oc][SD] (D2)
     float* s_red = wsm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kk = lane >> 4;
@@ -304,6 +315,7 @@ __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
         floatx4 acc[TAPS];
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp) acc[tp] = floatx4{0.f, 0.f, 0.f, 0.f};
+        floatx4 acc2 = {0.f, 0.f, 0.f, 0.f};
         // XCD-aware walk (see hconv_f32_kernel): XCD x = blockIdx % 8 owns the contiguous tiles [x*per_xcd, (x+1)*per_xcd), its
         // gridDim/8 workgroups sweep them side by side, so the tiles' shared halo rows are re-read from that XCD's L2
         const int t_end = min((int)(blockIdx.x & 7) * p.tiles_per_xcd + p.tiles_per_xcd, p.ntiles);
@@ -318,6 +330,7 @@ __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
             typedef typename std::conditional<DS != 0, float2w, floatx4>::type ldv_t;
             floatx4 lx[NIX][4];
             ldv_t ld[NID][4];
+            ldv_t ld2[D2 ? NID : 1][4];
 #pragma unroll
             for (int it = 0; it < NIX; ++it) {
                 const int u = tid + it * 256;
@@ -370,6 +383,12 @@ __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
                         }
                     }
                     ld[it][i] = a;
+                    if constexpr (D2 != 0) {
+                        ldv_t a2 = ldv_t{};
+                        if (y < p.H && x0 + i < p.W)
+                            a2 = *(const ldv_t*)((const char*)p.dy2 + ((((long)img * p.H + y) * p.W + x0 + i) * p.cout_total + ob * 16 + cg * 4) * (DS ? 2 : 4));
+                        ld2[it][i] = a2;
+                    }
                 }
             }
             __syncthreads();                       // the previous tile's fragment reads are done
@@ -395,6 +414,13 @@ __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
                     else
                         *(uint2w*)(s_dy + (cg * 4 + j) * SD + q * 2) =
                             uint2w{bf16_pair(ld[it][0][j], ld[it][1][j]), bf16_pair(ld[it][2][j], ld[it][3][j])};
+                    if constexpr (D2 != 0) {
+                        if constexpr (DS != 0)
+                            *(uint2w*)(s_dy2 + (cg * 4 + j) * SD + q * 2) = uint2w{b16_field_pair(ld2[it][0], ld2[it][1], j), b16_field_pair(ld2[it][2], ld2[it][3], j)};
+                        else
+                            *(uint2w*)(s_dy2 + (cg * 4 + j) * SD + q * 2) =
+                                uint2w{bf16_pair(ld2[it][0][j], ld2[it][1][j]), bf16_pair(ld2[it][2][j], ld2[it][3][j])};
+                    }
                 }
             }
             __syncthreads();
@@ -417,6 +443,12 @@ __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
                         acc[dy * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, b0), acc[dy * 3 + 0], 0, 0, 0);
                         acc[dy * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, cur), acc[dy * 3 + 1], 0, 0, 0);
                         acc[dy * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, b2), acc[dy * 3 + 2], 0, 0, 0);
+                        if constexpr (D2 != 0) {
+                            if (dy == 1) {
+                                const uint2w d2 = *(const uint2w*)(s_dy2 + l15 * SD + (row * 16 + g * 4 + kk) * 2);
+                                acc2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4w, d2), __builtin_bit_cast(short4w, cur), acc2, 0, 0, 0);
+                            }
+                        }
                     } else {
                         acc[0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, cur), acc[0], 0, 0, 0);
                     }
@@ -434,6 +466,13 @@ __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
             p.ws[(((long)blockIdx.x * gridDim.y + ob) * nchunk + c) * (TAPS * 256) + u] = v;
         }
         __syncthreads();                           // s_red aliases the staging buffers of the next chunk
+        if constexpr (D2 != 0) {                   // the 1x1 gradient's partial sums, in the layout of a ksize = 1 call
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_red[(wave * 16 + kk * 4 + r) * 16 + l15] = acc2[r];
+            __syncthreads();
+            p.ws2[(((long)blockIdx.x * gridDim.y + ob) * nchunk + c) * 256 + tid] = s_red[tid] + s_red[256 + tid] + s_red[512 + tid] + s_red[768 + tid];
+            __syncthreads();
+        }
     }
 }
 
@@ -818,6 +857,66 @@ int wgrad_impl(const srbh_hwgrad_args* a, void* stream, bool b16, const char* wh
     return SRBH_OK;
 }
 }  // namespace
+
+/* Weight gradients of a BasicBlock ENTRY (SR/HRfuse.py:142-159: conv1 = 3x3 and downsample[0] = 1x1 over the same input) in one pass
+ * over that input: a3 = the 3x3 call's arguments, a1 = the 1x1 call's (same sources, shape, cout, element types; its own dy / dw / ws).
+ * bf16 operands.  Shapes the fused kernel does not take run as the two separate calls -- same results either way. */
+extern "C" int srbh_hconv_wgrad_entry_b16(const srbh_hwgrad_args* a3, const srbh_hwgrad_args* a1, void* stream) {
+    SRBH_REQUIRE(a3 && a1, "srbh_hconv_wgrad_entry_b16: null arguments");
+    static const int fuse = getenv("SRBH_WGRAD_ENTRY_FUSE") ? atoi(getenv("SRBH_WGRAD_ENTRY_FUSE")) : 1;
+    const int ld0 = a3->src0_ld > 0 ? a3->src0_ld : a3->c0, ld1 = a3->src1_ld > 0 ? a3->src1_ld : a3->c1;
+    const int dld0 = a1->src0_ld > 0 ? a1->src0_ld : a1->c0, dld1 = a1->src1_ld > 0 ? a1->src1_ld : a1->c1;
+    const bool ds16 = (a3->io & SRBH_WG_DY_B16) != 0;
+    const bool same = a3->src0 == a1->src0 && a3->src1 == a1->src1 && a3->c0 == a1->c0 && a3->c1 == a1->c1 && ld0 == dld0 && ld1 == dld1 &&
+                      a3->B == a1->B && a3->H == a1->H && a3->W == a1->W && a3->cout == a1->cout && a3->io == a1->io &&
+                      a3->pre_scale == a1->pre_scale && a3->pre_shift == a1->pre_shift && a3->pre_relu == a1->pre_relu;
+    const bool shape = a3->ksize == 3 && a1->ksize == 1 && a3->src0 && a3->dy && a1->dy && a3->dw && a1->dw && a3->ws && a1->ws &&
+                       a3->c0 > 0 && (a3->c0 & 3) == 0 && (a3->c1 & 3) == 0 && (a3->c1 == 0 || a3->src1) && (ld0 & 3) == 0 && (a3->c1 == 0 || (ld1 & 3) == 0) &&
+                       a3->cout > 0 && a3->cout <= 64 && (a3->cout & 15) == 0 && a3->B > 0 && a3->H > 0 && a3->W > 0 &&
+                       !(a3->c0 == 16 && a3->c1 == 0) &&                /* (the 16 -> 16 layer has its own kernel) */
+                       (a3->io & ~(SRBH_WG_SRC0_H16 | SRBH_WG_DY_B16)) == 0 &&
+                       ((uintptr_t)a3->src0 & ((a3->io & SRBH_WG_SRC0_H16) ? 7 : 15)) == 0 && ((uintptr_t)a3->src1 & 15) == 0 &&
+                       (((uintptr_t)a3->dy | (uintptr_t)a1->dy) & (ds16 ? 7 : 15)) == 0;
+    if (!(fuse && same && shape)) {
+        if (int rc = wgrad_impl(a3, stream, true, "srbh_hconv_wgrad_b16")) return rc;
+        return wgrad_impl(a1, stream, true, "srbh_hconv_wgrad_b16");
+    }
+    WGParams p = {};
+    p.src0 = a3->src0; p.src1 = a3->src1; p.c0 = a3->c0; p.c1 = a3->c1; p.ld0 = ld0; p.ld1 = ld1;
+    p.pre_scale = a3->pre_scale; p.pre_shift = a3->pre_shift; p.pre_relu = a3->pre_relu;
+    p.dy = a3->dy; p.cout_total = a3->cout; p.dw = a3->dw; p.ws = a3->ws; p.io = a3->io; p.zchunk = 0;
+    p.dy2 = a1->dy; p.ws2 = a1->ws;
+    p.B = a3->B; p.H = a3->H; p.W = a3->W;
+    p.tiles_x = (a3->W + HT_W - 1) / HT_W;
+    p.tiles_per_img = p.tiles_x * ((a3->H + HT_H - 1) / HT_H);
+    p.ntiles = p.tiles_per_img * a3->B;
+    p.tiles_per_xcd = (p.ntiles + 7) / 8;
+    hipStream_t st = (hipStream_t)stream;
+    const int cin = a3->c0 + a3->c1, nob = a3->cout / 16, nchunk = (cin + 15) / 16;
+    const int gx = p.ntiles < 512 ? (p.ntiles + 7) / 8 * 8 : 512;
+    if (ds16) {
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_b16_kernel<3, 1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WG16<3>::LDS_B2)));
+        hipLaunchKernelGGL((hwgrad_b16_kernel<3, 1, 0, 1>), dim3(gx, nob), dim3(256), WG16<3>::LDS_B2, st, p);
+    } else {
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_b16_kernel<3, 0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WG16<3>::LDS_B2)));
+        hipLaunchKernelGGL((hwgrad_b16_kernel<3, 0, 0, 1>), dim3(gx, nob), dim3(256), WG16<3>::LDS_B2, st, p);
+    }
+    SRBH_HIP(hipGetLastError());
+    constexpr int SLICES = 16;
+    const int per = (gx + SLICES - 1) / SLICES;
+    for (int k = 0; k < 2; ++k) {           // the two ordered reduces (3x3, then 1x1): as behind the separate calls
+        const int taps = k == 0 ? 9 : 1;
+        const srbh_hwgrad_args* a = k == 0 ? a3 : a1;
+        const long U = (long)nob * nchunk * taps * 256;
+        float* tmp = a->ws + (long)WS_SLOTS * U;
+        hipLaunchKernelGGL(hwgrad_reduce1_kernel, dim3((unsigned)((U + 255) / 256), SLICES), dim3(256), 0, st, a->ws, tmp, U, gx, per);
+        SRBH_HIP(hipGetLastError());
+        const int total = a->cout * cin * taps;
+        hipLaunchKernelGGL(hwgrad_reduce2_kernel, dim3((total + 255) / 256), dim3(256), 0, st, tmp, a->dw, U, SLICES, nchunk, taps, a->cout, cin);
+        SRBH_HIP(hipGetLastError());
+    }
+    return SRBH_OK;
+}
 
 extern "C" int srbh_hconv_wgrad_f32(const srbh_hwgrad_args* a, void* stream) { return wgrad_impl(a, stream, false, "srbh_hconv_wgrad_f32"); }
 

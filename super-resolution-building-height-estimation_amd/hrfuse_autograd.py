@@ -100,7 +100,7 @@ def conv_dgrad(g, weight, cache: _PackedGrad, res=None, out_b16=False, res_ld=0,
     return _hconv_raw([g], cache.get(weight, h16, gen_src), None, cin, ks, res=res, h16=h16, out_b16=out_b16 and h16, res_ld=res_ld, bstat=bstat)
 
 
-def conv_wgrad(srcs, pre, g, cout, ks):
+def _wgrad_args(srcs, pre, g, cout, ks):
     L = _lib.lib()
     x0 = srcs[0]
     B, c0, Hh, Ww = x0.shape
@@ -118,11 +118,29 @@ def conv_wgrad(srcs, pre, g, cout, ks):
     ws = torch.empty(L.srbh_hwgrad_ws_bytes(cout, c0 + c1, ks) // 4, dtype=torch.float32, device=x0.device)
     a.ws = ws.data_ptr()
     a.io = (1 if x0.dtype == torch.float16 else 0) | (2 if g.dtype == torch.bfloat16 else 0)
+    return a, dw, ws
+
+
+def conv_wgrad(srcs, pre, g, cout, ks):
+    L = _lib.lib()
+    a, dw, _ws = _wgrad_args(srcs, pre, g, cout, ks)
     if H.head_h16():       # mixed precision: bf16 operands (like the data gradients), fp32 accumulation
         _lib.check(L.srbh_hconv_wgrad_b16(C.byref(a), _lib.stream_ptr()), "hconv_wgrad_b16")
     else:
         _lib.check(L.srbh_hconv_wgrad_f32(C.byref(a), _lib.stream_ptr()), "hconv_wgrad_f32")
     return dw
+
+
+def conv_wgrad_entry(srcs, g3, g1, cout):
+    """(dW of the 3x3 conv1, dW of the 1x1 downsample conv) of a BasicBlock entry: both read the same input, so in the bf16-operand mode
+    they are ONE pass over it (srbh_hconv_wgrad_entry_b16: the 1x1 gradient is one more product on the staged tile); exact-fp32 mode, or
+    gradients of different element types: the two separate calls."""
+    if not (H.head_h16() and g3.dtype == g1.dtype):
+        return conv_wgrad(srcs, None, g3, cout, 3), conv_wgrad(srcs, None, g1, cout, 1)
+    a3, dw3, _w3 = _wgrad_args(srcs, None, g3, cout, 3)
+    a1, dw1, _w1 = _wgrad_args(srcs, None, g1, cout, 1)
+    _lib.check(_lib.lib().srbh_hconv_wgrad_entry_b16(C.byref(a3), C.byref(a1), _lib.stream_ptr()), "hconv_wgrad_entry_b16")
+    return dw3, dw1
 
 
 FUSE_BN_REDUCE = __import__("os").environ.get("SRBH_FUSE_BN_REDUCE", "1") == "1"      # (0: the separate reduce pass, A/B aid)
@@ -343,14 +361,16 @@ class _BasicBlockFn(torch.autograd.Function):
         else:
             da1 = conv_dgrad(dc2, w2, caches[1], out_b16=b16)
             dc1, dg1, db1 = bn_backward(da1, c1, m1, i1, g1, (s1, h1), tr, out_b16=b16)
-        dw1 = conv_wgrad(srcs, None, dc1, w1.shape[0], 3)
         need_dx = ctx.needs_input_grad[1] or (nsrc > 1 and ctx.needs_input_grad[2])
         dwd = dgd = dbd = None
         skip = dz if need_dx else None          # gradient arriving over the identity / downsample path
         if has_ds:
             dd, dgd, dbd = bn_backward(dz, d, md, idd, gd, None, tr, out_b16=b16)
-            dwd = conv_wgrad(srcs, None, dd, wd.shape[0], 1)
+            dw1, dwd = conv_wgrad_entry(srcs, dc1, dd, w1.shape[0]) if wd.shape[0] == w1.shape[0] else (
+                conv_wgrad(srcs, None, dc1, w1.shape[0], 3), conv_wgrad(srcs, None, dd, wd.shape[0], 1))
             skip = conv_dgrad(dd, wd, caches[2], out_b16=b16) if need_dx else None
+        else:
+            dw1 = conv_wgrad(srcs, None, dc1, w1.shape[0], 3)
         dx0 = dx1 = None
         c0 = srcs[0].shape[1]
         if need_dx and nsrc == 2 and c0 == 16 and srcs[1].shape[1] == 16 and w1.shape[0] == 16 and H.head_h16():

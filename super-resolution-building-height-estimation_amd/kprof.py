@@ -68,6 +68,14 @@ def _model(name, args):
         px = _px(a)
         return (f"hconv_entry {a.c0}{'+' + str(a.c1) if a.c1 else ''}->16 k3 + 16 k1{' +stats' if a.stats else ''}{' src16' if a.io_h16 & 3 else ''}{' out16' if a.io_h16 & 8 else ''} @{a.H}x{a.W}",
                 px * (a.c0 * (2 if a.io_h16 & 1 else 4) + a.c1 * (2 if a.io_h16 & 2 else 4) + 2 * 16 * e))
+    if name == "srbh_hconv_wgrad_entry_b16":
+        a, d = args[0]._obj, args[1]._obj
+        px = _px(a)
+        ex = 2 if (a.io & 1) else 4
+        ed = 2 if (a.io & 2) else 4
+        # one pass over the input when fused (the common case): sources once, two dY tensors
+        return (f"wgrad_entry_bf16 {a.c0}{'+' + str(a.c1) if a.c1 else ''}->{a.cout} k3 + k1{' io=' + str(a.io) if a.io else ''} @{a.H}x{a.W}",
+                px * (a.c0 * ex + a.c1 * 4 + 2 * a.cout * ed))
     if name in ("srbh_hconv_wgrad_f32", "srbh_hconv_wgrad_b16"):
         a = args[0]._obj
         px = _px(a)

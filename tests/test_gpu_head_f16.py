@@ -206,7 +206,7 @@ def test_mixed_precision_training_gradients_close_to_exact(monkeypatch, width, i
 
 
 def test_fp16_activation_chain_within_tolerance(monkeypatch):
-    """hrfuse.FP16_ACTIVATIONS (off by default: measured slower): every conv of the inference head reads / writes fp16 NHWC tensors
+    """hrfuse.FP16_ACTIVATIONS (the default since round 3): every conv of the inference head reads / writes fp16 NHWC tensors
     (srbh_hconv_args.io_h16), bn1 + ReLU in conv1's epilogue, fp16 residual stream.  Whole model, eval, no_grad: height / building
     maps within the 1e-3 tolerance of the CPU reference and 1e-3 of the fp32-tensor chain; the public modules still return fp32."""
     import copy
@@ -219,6 +219,7 @@ def test_fp16_activation_chain_within_tolerance(monkeypatch):
     with torch.no_grad():
         want = cpu_reference(copy.deepcopy(m), x, fea, False)
         m = m.to(DEV)
+        monkeypatch.setattr(H, "FP16_ACTIVATIONS", False)      # the fp32-tensor chain (the default is the fp16 chain since round 3)
         base = m(x.to(DEV), fea.to(DEV))
         monkeypatch.setattr(H, "FP16_ACTIVATIONS", True)
         got = m(x.to(DEV), fea.to(DEV))
@@ -257,3 +258,30 @@ def test_block_entry_fused_conv_pair_equals_the_two_convs(c0, c1, hw, stats):
     if stats:
         fold = lambda t: t.view(-1, 2, 16).sum(0)
         assert O.rel_l2(fold(s1).cpu(), fold(sa).cpu()) <= 1e-6 and O.rel_l2(fold(s2).cpu(), fold(sb).cpu()) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c0,c1,x16,g16", [(64, 0, False, False), (64, 0, True, True), (16, 16, False, True), (16, 16, False, False), (32, 0, False, True)])
+def test_fused_entry_weight_gradients_equal_the_two_separate_calls(c0, c1, x16, g16):
+    """srbh_hconv_wgrad_entry_b16 (round 4): conv1's 3x3 and downsample[0]'s 1x1 weight gradients of a BasicBlock entry
+    (SR/HRfuse.py:142-159) in ONE pass over the shared input -- the same bf16 products in the same order as the two separate
+    srbh_hconv_wgrad_b16 calls: bit-identical results; ragged size included."""
+    from srbh_amd import hrfuse as H
+    from srbh_amd import hrfuse_autograd as HA
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(c0 + c1)
+    B, Hh, Ww = 2, 20, 72                        # (not multiples of the 8 x 64 tile)
+    nhwc = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)        # noqa: E731
+    x0 = nhwc(torch.randn((B, c0, Hh, Ww), generator=g))
+    if x16:
+        x0 = x0.half()
+    srcs = [x0] + ([nhwc(torch.randn((B, c1, Hh, Ww), generator=g))] if c1 else [])
+    g3 = nhwc(torch.randn((B, 16, Hh, Ww), generator=g) * 1e-3)
+    g1 = nhwc(torch.randn((B, 16, Hh, Ww), generator=g) * 1e-3)
+    if g16:
+        g3, g1 = g3.bfloat16(), g1.bfloat16()
+    with H.head_precision("f16"), torch.no_grad():
+        d3, d1 = HA.conv_wgrad_entry(srcs, g3, g1, 16)
+        r3, r1 = HA.conv_wgrad(srcs, None, g3, 16, 3), HA.conv_wgrad(srcs, None, g1, 16, 1)
+    assert torch.equal(d3, r3) and torch.equal(d1, r1)
+    assert float(d3.abs().max()) > 0 and float(d1.abs().max()) > 0
