@@ -578,6 +578,11 @@ def bench_feature(args, rank, world, dev, dist):
                      "traffic": traffic,
                      "traffic_source": (f"{traffic_src} (RECORDED: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                         "command, FETCH doubled per the guide; not measured in this run)") if traffic_src else None,
+                     "power_capped_peak": {
+                         "what": "tools/mfma_ceiling.hip on this package (RECORDED, profiles/r04k_mfma_ceiling.txt): v_mfma_f32_32x32x16_f16 back to back, one wave "
+                                 "per SIMD, 256 CUs, real trunk operands, seconds-long runs: MFMA only / + the trunk's LDS read mix / + its weight LDS-DMA stream",
+                         "tflops": [1659.6, 1563.3, 1516.1], "frac_of_2500": [0.664, 0.625, 0.606], "sclk_mhz": [1640, 1557, 1561],
+                         "frac_of_measured_ceiling": round(trunk_tflops / 1516.1, 4) if trunk_tflops else None},
                      "kernel": f"{kname} (persistent trunk: 345 dense-block 3x3 convs in one launch)",
                      "avg_launch_ms": round(trunk_ms, 4) if trunk_ms else None,
                      "algorithmic_gflop_per_launch": round(trunk_gflop_tile * B, 1),

@@ -6,6 +6,10 @@
 // registers (no LDS, no memory in the loop), wall clock by HIP events, shader clock from s_memtime / s_memrealtime inside the kernel.
 //   mode mfma      : MFMAs only, 4 independent accumulators (back-to-back issue), operands cycle through 8 A x 8 B fragments
 //   mode mfma+lds  : the same MFMAs with the trunk's LDS read mix (0.75 ds_read_b128 per MFMA, conflict-free pattern) feeding them
+//   mode mfma+lds+wdma : the same plus the trunk's WEIGHT stream: 18 KiB per 72 MFMAs and workgroup by LDS-DMA (global_load_lds_dwordx4)
+//                    from a 33 MB buffer every workgroup walks in step (69 RDBs x 479 KB of fp16 weights: L2 hits after the first
+//                    workgroup of an XCD, as in the trunk).  256 workgroups x all weights is what ANY B = 32 launch with one 8 x 64
+//                    tile per CU has to move through L2 -> LDS, so this is the ceiling of the tiling, not of the kernel
 //   mode duty<p>   : MFMA bursts with idle gaps (s_sleep) so that the matrix core is busy ~p % of the cycles: what the chip gives
 //                    back in clock when the kernel idles (the trunk: 59 % busy)
 // operand data: zeros | random fp16 in [-0.5, 0.5) | a dump of real trunk activations / weights (tools/dump_trunk_operands.py)
@@ -20,10 +24,10 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 struct Out { unsigned long long cyc, real; };
 
-// MODE 0: MFMA only; 1: MFMA + LDS reads (9 per 12 MFMAs); 2: duty-cycled MFMA (sleep after each burst of 32)
+// MODE 0: MFMA only; 1: MFMA + LDS reads (9 per 12 MFMAs); 2: duty-cycled MFMA (sleep after each burst of 32); 3: as 1 + the weight LDS-DMA stream
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void ceiling_kernel(const half8* __restrict__ wsrc, const half8* __restrict__ asrc, int nfrag, int iters, int sleep_n,
-                                                         Out* out, float* sink) {
+                                                         Out* out, float* sink, const char* wstream = nullptr, long wstream_b = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     half8 A[8], B[8];
@@ -32,7 +36,7 @@ __global__ __launch_bounds__(256, 1) void ceiling_kernel(const half8* __restrict
         A[k] = wsrc[((blockIdx.x * 4 + wave) * 8 + k) % nfrag * 64 + lane];
         B[k] = asrc[((blockIdx.x * 4 + wave) * 8 + k) % nfrag * 64 + lane];
     }
-    if (MODE == 1) {      // LDS filled with the activation data: 36 KiB of fragments per wave
+    if (MODE == 1 || MODE == 3) {      // LDS filled with the activation data: 36 KiB of fragments per wave
         for (int i = tid; i < 144 * 64; i += 256) ((half8*)smem)[i] = asrc[(blockIdx.x * 144 + i / 64) % nfrag * 64 + (i & 63)];
         __syncthreads();
     }
@@ -42,23 +46,42 @@ __global__ __launch_bounds__(256, 1) void ceiling_kernel(const half8* __restrict
 #pragma unroll
         for (int q = 0; q < 16; ++q) c[a][q] = 0.f;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    if (MODE == 1) {
+    if (MODE == 1 || MODE == 3) {
         // the trunk's group: 9 reads (6 pixel-row + 3 weight fragments) feed 12 MFMAs; double-buffered, one read per MFMA shadow
         half8 v[2][9];
         const char* base = smem + wave * 36 * 1024 + lane * 16;
 #pragma unroll
         for (int r = 0; r < 9; ++r) v[0][r] = *(const half8*)(base + r * 1024);
-        for (int it = 0; it < iters; ++it) {
+        // MODE 3: position in the weight stream (an SGPR pair), advanced by one 18 KiB chunk per 72 MFMAs
+        unsigned long long wpos = (unsigned long long)wstream, wend = wpos + (unsigned long long)wstream_b - 18 * 1024;
+        const unsigned lds_w = __builtin_amdgcn_readfirstlane(144 * 1024 + wave * 1024);   // weight stage: 16 KiB behind the activation image
+        const unsigned vo = lane * 16;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        constexpr int NG = MODE == 3 ? 6 : 4;                            // groups per iteration (MODE 3: one 72-MFMA step, as the trunk's)
+        const int n_it = MODE == 3 ? iters * 4 / 6 : iters;
+        for (int it = 0; it < n_it; ++it) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {      // 4 groups per iteration = 48 MFMAs
+            for (int u = 0; u < NG; ++u) {
 #pragma unroll
                 for (int m = 0; m < 12; ++m) {
                     c[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v[u & 1][6 + m / 4], v[u & 1][(m & 3) + m / 4], c[m & 3], 0, 0, 0);
-                    if (m < 9) v[(u + 1) & 1][m] = *(const half8*)(base + (u * 9 + m) * 1024);      // (immediate offsets, as in the trunk)
+                    if (m < 9) v[(u + 1) & 1][m] = *(const half8*)(base + ((u & 3) * 9 + m) * 1024);      // (immediate offsets, as in the trunk)
+                    if (MODE == 3 && m == 10 && u < 5) {
+                        // 18 KiB per workgroup and step = 4.5 KiB per wave: 4 full statements + 1 that only waves 0, 1 issue, one statement
+                        // behind an MFMA of 5 of the 6 groups -- the trunk's own statement incl. its wait states, everything else compile-time
+                        const unsigned long long sb = wpos + (u < 4 ? u * 4096 + wv * 1024 : 16384 + wv * 1024);
+                        if (u < 4 || wv < 2)
+                            asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_w + (u & 3) * 4096), "v"(vo), "s"(sb) : "memory", "m0");
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if (MODE == 3) {
+                wpos = wpos + 18 * 1024 <= wend ? wpos + 18 * 1024 : (unsigned long long)wstream;
+                asm volatile("s_waitcnt vmcnt(5)" ::: "memory");         // (at most one step of statements in flight, as behind the trunk's step barrier)
+            }
         }
+        if (MODE == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -103,7 +126,16 @@ template <int MODE>
 static void run(const char* name, const half8* dw, const half8* da, int nfrag, int sleep_n, double seconds) {
     Out* dout; float* sink;
     hipMalloc(&dout, 256 * sizeof(Out)); hipMalloc(&sink, 4);
-    const int lds = MODE == 1 ? 144 * 1024 : 0;
+    const int lds = (MODE == 1 || MODE == 3) ? 160 * 1024 : 0;
+    static char* wstream = nullptr;
+    const long wstream_b = 69L * 479232;                           // 69 RDBs x 9 x 26 624 fp16 weights
+    if (MODE == 3 && !wstream) {                                   // the weight stream: the weight operand data repeated
+        hipMalloc(&wstream, wstream_b + 65536);
+        for (long o = 0; o < wstream_b; o += (long)nfrag * 1024) {
+            const long nb = o + (long)nfrag * 1024 <= wstream_b ? (long)nfrag * 1024 : wstream_b - o;
+            hipMemcpy(wstream + o, dw, nb, hipMemcpyDeviceToDevice);
+        }
+    }
     if (lds) hipFuncSetAttribute((const void*)ceiling_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int iters = MODE == 2 ? 2000 : 4000;                    // 48 MFMAs x 32 cyc x 4000 = 6.1 M cycles ~ 3 ms
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -113,7 +145,7 @@ static void run(const char* name, const half8* dw, const half8* da, int nfrag, i
         hipEventRecord(e0);
         int n = 0; float acc = 0;
         do {
-            for (int k = 0; k < 20; ++k) hipLaunchKernelGGL((ceiling_kernel<MODE>), dim3(256), dim3(256), lds, 0, dw, da, nfrag, iters, sleep_n, dout, sink);
+            for (int k = 0; k < 20; ++k) hipLaunchKernelGGL((ceiling_kernel<MODE>), dim3(256), dim3(256), lds, 0, dw, da, nfrag, iters, sleep_n, dout, sink, (const char*)wstream, wstream_b);
             n += 20;
             hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&acc, e0, e1);
         } while (acc < seconds * 500.0);
@@ -123,7 +155,7 @@ static void run(const char* name, const half8* dw, const half8* da, int nfrag, i
     double cyc = 0, real = 0;
     for (int i = 0; i < 256; ++i) { cyc += (double)h[i].cyc; real += (double)h[i].real; }
     cyc /= 256; real /= 256;
-    const double mfmas = (double)iters * 48, flop = mfmas * 32768.0 * 4 * 256;      // per launch: 4 waves x 256 workgroups
+    const double mfmas = MODE == 3 ? (double)(iters * 4 / 6) * 72 : (double)iters * 48, flop = mfmas * 32768.0 * 4 * 256;      // per launch: 4 waves x 256 workgroups
     const double ms_l = ms / launches, tf = flop / (ms_l * 1e-3) / 1e12, mhz = cyc / real * 100.0;
     printf("%-34s %7.3f ms/launch  %7.1f TF/s = %.3f of 2500   sclk %6.0f MHz   matrix-core busy %5.1f %% of kernel cycles   (kernel %0.3f ms by counters)\n",
            name, ms_l, tf, tf / 2500.0, mhz, 100.0 * mfmas * 32.0 / cyc, real / 100e6 * 1e3);
@@ -145,6 +177,7 @@ int main(int argc, char** argv) {
         printf("---- operand data: %s\n", label);
         run<0>("mfma only", dw, da, nfrag, 0, seconds);
         run<1>("mfma + 0.75 ds_read_b128 / mfma", dw, da, nfrag, 0, seconds);
+        run<3>("mfma + lds + weight LDS-DMA stream", dw, da, nfrag, 0, seconds);
         if (kind != 0) {
             run<2>("mfma bursts, sleep 1x", dw, da, nfrag, 1, seconds);
             run<2>("mfma bursts, sleep 2x", dw, da, nfrag, 2, seconds);
