@@ -522,6 +522,14 @@ int srbh_confusion_add(const long long* pred, const long long* label, long n, in
  *   srbh_dconv_fwd(bf16 = 0): y = conv3x3(x, w), fp16 operands;
  *   srbh_dconv_fwd(bf16 = 1) with the transposed + flipped pack (hpack cout := forward Cin, cin := forward Cout): dX = conv^T(dY, W);
  *   srbh_dconv_wgrad: dW = sum_pixels dY (x) shifted X, bf16 operands, deterministic (ws: srbh_dconv_wgrad_ws_floats floats). */
+typedef struct srbh_dconv_pack_desc {
+    const float* w;      /* OIHW fp32 (cout, cin, 3, 3) */
+    void* fwd;           /* fp16 image for srbh_dconv_fwd(bf16 = 0) */
+    void* bwd;           /* bf16 transposed + flipped image for the data gradient */
+    int cout, cin;
+} srbh_dconv_pack_desc;
+/* both images of n weights in ONE launch (table in device memory); each image = srbh_hpack_h16_bytes(cout, cin, 3) bytes */
+int srbh_dconv_pack_many(const srbh_dconv_pack_desc* table, int n, void* stream);
 int srbh_dconv_supported(int B, int Cin, int Cout, int H, int W);
 int srbh_dconv_fwd(const float* x, const void* wpack, float* y, int B, int Cin, int Cout, int H, int W, int bf16, void* stream);
 size_t srbh_dconv_wgrad_ws_floats(int B, int Cin, int Cout, int H, int W);

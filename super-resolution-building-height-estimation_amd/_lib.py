@@ -193,6 +193,7 @@ SIGNATURES = {
     "srbh_se_train_bwd_ws_floats": (_sz, [_i, _i, _i]),
     "srbh_up2_cat_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "srbh_up2_cat_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "srbh_dconv_pack_many": (_i, [_vp, _i, _vp]),
     "srbh_dconv_supported": (_i, [_i, _i, _i, _i, _i]),
     "srbh_dconv_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "srbh_dconv_wgrad_ws_floats": (_sz, [_i, _i, _i, _i, _i]),

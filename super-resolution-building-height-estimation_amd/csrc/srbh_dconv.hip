@@ -334,6 +334,31 @@ __global__ __launch_bounds__(256) void dconv_wgrad_reduce_kernel(const float* __
     }
 }
 
+// both 16-bit images of MANY decoder conv weights in one launch (a training step changes all of them: 40 convs x 2 packs were 80
+// launches of ~4.6 us): blockIdx.y = conv, fragment order of srbh_hpack_conv_h16 ([chunk][tap][ob][lane][4]);
+// fwd = fp16 of W[oc][ic][tap], bwd = bf16 of the transposed + flipped weight (its "cout" = Cin, "cin" = Cout)
+__device__ __forceinline__ short pack_elem(const float* __restrict__ w, long idx, int cout, int cin, int nob, int transpose_flip, int bf16) {
+    const int j = idx & 3, lane = (idx >> 2) & 63;
+    long f = idx >> 8;
+    const int ob = (int)(f % nob);
+    f /= nob;
+    const int tap = (int)(f % 9), chunk = (int)(f / 9);
+    const int oc = ob * 16 + (lane & 15), ic = chunk * 16 + (lane >> 4) * 4 + j;
+    float v = 0.f;
+    if (oc < cout && ic < cin) v = transpose_flip ? w[((long)ic * cout + oc) * 9 + (8 - tap)] : w[((long)oc * cin + ic) * 9 + tap];
+    if (bf16) return bf16_rne(v);
+    return __builtin_bit_cast(short, (_Float16)v);
+}
+__global__ __launch_bounds__(256) void dconv_pack_many_kernel(const srbh_dconv_pack_desc* __restrict__ table) {
+    const srbh_dconv_pack_desc d = table[blockIdx.y];
+    const int nob_f = (d.cout + 15) / 16, nch_f = (d.cin + 15) / 16;
+    const long tot = (long)nch_f * 9 * nob_f * 256;           // (the same count for both images: chunks x blocks swap roles)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+        ((short*)d.fwd)[i] = pack_elem(d.w, i, d.cout, d.cin, nob_f, 0, 0);
+        ((short*)d.bwd)[i] = pack_elem(d.w, i, d.cin, d.cout, nch_f, 1, 1);
+    }
+}
+
 int log2_exact(int v) {
     for (int l = 0; l < 16; ++l)
         if ((1 << l) == v) return l;
@@ -392,6 +417,14 @@ int wgrad_split(int B, int Cin, int Cout, int W, int mo) {
 }
 
 }  // namespace
+
+/* table: n descriptors in DEVICE memory; fwd / bwd: srbh_hpack_h16_bytes(cout, cin, 3) bytes each (the two images have the same size) */
+extern "C" int srbh_dconv_pack_many(const srbh_dconv_pack_desc* table, int n, void* stream) {
+    SRBH_REQUIRE(table && n > 0, "srbh_dconv_pack_many: bad arguments");
+    hipLaunchKernelGGL(dconv_pack_many_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, table);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
 
 extern "C" int srbh_dconv_supported(int B, int Cin, int Cout, int H, int W) {
     const int lw = log2_exact(W);

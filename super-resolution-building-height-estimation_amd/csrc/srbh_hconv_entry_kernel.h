@@ -21,8 +21,11 @@ struct EParams {
 // O16 (compile-time): both outputs are 16-bit tensors (fp16 for OPT 1)
 // S16 (compile-time, OPT 1): the sources hold fp16 elements (SRBH_IO_SRC0_H16 [| SRBH_IO_SRC1_H16]): staged verbatim -- 8-byte loads,
 // no rounding, half the registers in flight (the fp32-source forms spill 24 VGPRs under this launch bound; this one does not)
+#ifndef SRBH_ENTRY_WGS_PER_CU
+#define SRBH_ENTRY_WGS_PER_CU 3      // (A/B aid: 2 = 256 registers per lane, no spills, but two workgroups per CU instead of three)
+#endif
 template <int OPT, int O16, int S16 = 0>
-__global__ __launch_bounds__(256, 3) void hconv_entry_kernel(const EParams e) {
+__global__ __launch_bounds__(256, SRBH_ENTRY_WGS_PER_CU) void hconv_entry_kernel(const EParams e) {
     static_assert(OPT == 1 || OPT == 2, "16-bit operand forms only");
     static_assert(S16 == 0 || OPT == 1, "16-bit sources: fp16 only (element type = operand type)");
     const HParams& p = e.a;

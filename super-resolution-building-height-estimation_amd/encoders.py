@@ -538,6 +538,49 @@ class _DecoderConvPacks:
         return self.b
 
 
+class DecoderPackTable:
+    """Both 16-bit images of every 3x3 conv of a decoder in ONE flat buffer, refreshed by ONE launch (srbh_dconv_pack_many) at the start
+    of a forward whenever a weight changed -- in training that is once per step (per-conv packing was 2 launches per conv and step:
+    80 launches, 0.44 ms, profiles/r04m_train_steady_kernel_stats.txt).  Fills the convs' _DecoderConvPacks in place."""
+
+    def __init__(self, convs):
+        self.convs = list(convs)
+        self.key = None
+        self.flat = self.table = None
+        self.ptrs = None
+
+    def refresh(self, device):
+        from . import _lib
+        import numpy as np
+        key = (tuple(_DecoderConvPacks._key(c.weight) for c in self.convs), str(device))
+        if key == self.key:
+            wcache.keep(self.flat, self.table)
+            return
+        L = _lib.lib()
+        ptrs = tuple(c.weight.data_ptr() for c in self.convs)
+        if self.flat is None or self.flat.device != device or ptrs != self.ptrs:
+            sizes = [L.srbh_hpack_h16_bytes(c.weight.shape[0], c.weight.shape[1], 3) // 2 for c in self.convs]
+            self.flat = torch.empty(2 * sum(sizes), dtype=torch.int16, device=device)
+            desc = np.zeros(len(self.convs), dtype=np.dtype([("w", "<u8"), ("fwd", "<u8"), ("bwd", "<u8"), ("cout", "<i4"), ("cin", "<i4")]))
+            o = 0
+            self.views = []
+            for i, (c, n) in enumerate(zip(self.convs, sizes)):
+                f, b = self.flat[o:o + n], self.flat[o + n:o + 2 * n]
+                desc[i] = (c.weight.data_ptr(), f.data_ptr(), b.data_ptr(), c.weight.shape[0], c.weight.shape[1])
+                self.views.append((f, b))
+                o += 2 * n
+            self.table = torch.from_numpy(desc.view(np.uint8).copy()).to(device)
+            self.ptrs = ptrs
+        _lib.check(L.srbh_dconv_pack_many(self.table.data_ptr(), len(self.convs), _lib.stream_ptr()), "dconv_pack_many")
+        for c, (f, b), k in zip(self.convs, self.views, key[0]):
+            pk = c.__dict__.get("_srbh_dconv_packs")
+            if pk is None:
+                pk = c.__dict__["_srbh_dconv_packs"] = _DecoderConvPacks()
+            pk.f, pk.b, pk.kf, pk.kb = f, b, k, k
+        self.key = key
+        wcache.keep(self.flat, self.table)
+
+
 class _DecoderConvFn(torch.autograd.Function):
     """y = conv3x3(x, w) (stride 1, padding 1, no bias) on libsrbh: one launch forward, one for the input gradient, two (partials +
     ordered reduce) for the weight gradient -- MIOpen: fp32 Winograd + NHWC implicit-GEMM weight gradients behind batched transposes
@@ -660,6 +703,15 @@ class UnetDecoder(nn.Module):
     def forward(self, *features):
         feats = features[1:][::-1]
         x = self.center(feats[0])
+        if DCONV and x.is_cuda and x.dtype == torch.float32:
+            from . import hrfuse as _H
+            if _H.head_h16():            # the decoder convs will run on libsrbh: one pack launch for all ten (when a weight changed)
+                pt = self.__dict__.get("_srbh_dpt")
+                if pt is None:
+                    pt = self.__dict__["_srbh_dpt"] = DecoderPackTable(
+                        b_[0] for blk in self.blocks for b_ in (blk.conv1, blk.conv2) if isinstance(b_[0], nn.Conv2d) and b_[0].bias is None)
+                if pt.convs and all(c.weight.dtype == torch.float32 for c in pt.convs):
+                    pt.refresh(x.device)
         skips = feats[1:]
         for i, blk in enumerate(self.blocks):
             x = blk(x, skips[i] if i < len(skips) else None)

@@ -107,3 +107,33 @@ def test_policy_and_fallbacks():
             key = conv._srbh_dconv_packs.kf
             E.decoder_conv(conv, x)
             assert conv._srbh_dconv_packs.kf == key          # unchanged weight: the pack is reused
+
+
+def test_pack_table_equals_per_conv_packs():
+    """DecoderPackTable: both images of all ten convs of a decoder in one launch == the per-conv srbh_hpack_conv_h16 packs, refreshed
+    only when a weight changed; a decoder forward in the 16-bit mode uses it and matches the stock decoder at the fp16 level"""
+    from srbh_amd import encoders as E
+    from srbh_amd import hrfuse as H
+    from srbh_amd import wcache
+    torch.manual_seed(3)
+    dec = E.UnetDecoder((8, 48, 32, 56, 160, 448), (256, 128, 64, 32, 16)).to(DEV).eval()
+    feats = [torch.randn(2, c, 64 // s, 64 // s, device=DEV) for c, s in zip((8, 48, 32, 56, 160, 448), (1, 2, 4, 8, 16, 32))]
+    with torch.no_grad():
+        with H.head_precision("f32"):
+            want = dec(*feats)
+        with H.head_precision("f16"):
+            got = dec(*feats)
+            pt = dec._srbh_dpt
+            assert len(pt.convs) == 10 and pt.key is not None
+            for c in pt.convs:
+                ref = E._DecoderConvPacks()
+                pk = c._srbh_dconv_packs
+                assert torch.equal(pk.f, ref.fwd(c.weight)) and torch.equal(pk.b, ref.bwd(c.weight))
+            k0 = pt.key
+            dec(*feats)
+            assert pt.key is k0                      # nothing changed: no new pack launch
+            pt.convs[3].weight.data.mul_(2.0)
+            wcache.stamp([pt.convs[3].weight])
+            dec(*feats)
+            assert pt.key != k0 and torch.equal(pt.convs[3]._srbh_dconv_packs.f, E._DecoderConvPacks().fwd(pt.convs[3].weight))
+    assert rel(got, want) <= 3e-3

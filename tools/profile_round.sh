@@ -28,9 +28,11 @@ leg() {         # leg '<shell command>': any other step, exit status checked
     local rc=$?
     if [ $rc -ne 0 ]; then echo "!! FAILED LEG (rc=$rc): $1"; FAILED="$FAILED [${1:0:80}]"; fi
 }
-bench_leg $O/${TAG}_bench_feature_b32.json.log
+bench_leg $O/${TAG}_bench_feature_b32.json.log --details $O/${TAG}_bench_details.json
 bench_leg $O/${TAG}_bench_train_b64.json.log --workload train --no-cpu-baseline
 bench_leg $O/${TAG}_bench_predict_12cities.json.log --workload predict --steps 12 --warmup 2
+bench_leg $O/${TAG}_bench_epoch.json.log --workload epoch
+SRBH_TRUNK_PRECISION=f32 bench_leg $O/${TAG}_bench_feature_b32_strict_f32_trunk.json.log --steps 3 --warmup 1 --no-extras --no-cpu-baseline
 bench_leg $O/${TAG}_bench_sr_train_b8.json.log --workload sr_train --steps 6 --warmup 2
 SRBH_SR_BENCH_MODES=fast,mixed bench_leg $O/${TAG}_bench_sr_train_b24.json.log --workload sr_train --steps 6 --warmup 2 --batch 24
 leg 'timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- python bench.py --no-cpu-baseline --no-extras > $O/${TAG}_stats.log 2>&1'
@@ -40,7 +42,7 @@ leg 'timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -
 leg 'python tools/pmc_traffic.py $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_hbm_traffic.json'
 if [ "$MODE" != "quick" ]; then
 leg 'timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/${TAG}_tr -- python bench.py --workload train --steps 6 --warmup 3 --no-extras > /dev/null 2>&1'
-leg 'python tools/steady_stats.py /tmp/${TAG}_tr 4 40 > $O/${TAG}_train_steady_kernel_stats.txt'
+leg 'python tools/steady_stats.py /tmp/${TAG}_tr 4 60 --stock > $O/${TAG}_train_steady_kernel_stats.txt'
 leg 'python tools/gap_stats.py /tmp/${TAG}_tr 4 12 >> $O/${TAG}_train_steady_kernel_stats.txt'
 # head kernels: HBM bytes per launch (FETCH_SIZE / WRITE_SIZE, one pass each) and SQ counters
 leg 'timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/${TAG}_hf -- python tools/head_kernels.py 64 3 > /dev/null 2>&1'
