@@ -132,7 +132,12 @@ def _run(backend, B=4):
     return res, ref, gmax
 
 
-def test_real_trainstep_dp2_on_one_gpu_gloo():
+@pytest.mark.parametrize("headp,tol", [("f32", 3e-2), ("f16", 8e-2)])
+def test_real_trainstep_dp2_on_one_gpu_gloo(headp, tol, monkeypatch):
+    # f32: the exact-arithmetic yardstick of the collectives; f16 (TrainStep's default): bf16 gradient operands in the head and, since
+    # round 4, in the decoder convs -- a 1e-7 summation-order difference upstream flips bf16 roundings (2^-9 steps) which the ~100
+    # training-mode BatchNorms over 4 tiles amplify further: the same machinery, a wider band
+    monkeypatch.setenv("SRBH_TEST_HEADP", headp)
     res, ref, gmax = _run("gloo")
     import numpy as np
     # the averaged gradients (third step: launched from autograd hooks, bucket by bucket) == the single-process gradients of
@@ -149,7 +154,7 @@ def test_real_trainstep_dp2_on_one_gpu_gloo():
     # parameter by +-lr, and a network with ~100 training-mode BatchNorms over 4 tiles turns 1e-4 relative parameter noise into
     # 30 % gradient differences -- measured; that chaos is the model's, not the collective's).  What is left is summation order
     # (atomics in the BatchNorm partial sums, gloo's reduction order) amplified through those BatchNorms: <= 3e-2 per sub-module.
-    assert sum(len(v) for v in by.values()) > 20 and all(m[1] <= 3e-2 for m in med.values()), med
+    assert sum(len(v) for v in by.values()) > 20 and all(m[1] <= tol for m in med.values()), med
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs >= 2 GPUs (fires on the first multi-GPU box)")
