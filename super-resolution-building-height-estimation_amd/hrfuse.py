@@ -447,8 +447,10 @@ class BasicBlock(nn.Module):
                 and all(t.shape[1] % 4 == 0 for t in srcs)):
             s1, h1, _, _ = bn_scale_shift(self.bn1, None, n, False)
             s2, h2, _, _ = bn_scale_shift(self.bn2, None, n, False)
-            if self.downsample is not None and all(t.dtype == torch.float32 for t in srcs):
-                sd, hd, _, _ = bn_scale_shift(self.downsample[1], None, n, False)      # conv1 + the 1x1 downsample conv: one pass over the input
+            if self.downsample is not None and len({t.dtype for t in srcs}) == 1:
+                # conv1 + the 1x1 downsample conv: one pass over the input (sources of ONE element type: all fp32, or -- round 4: the fp16
+                # feature hand-off -- all fp16; a mixed pair takes the two launches below)
+                sd, hd, _, _ = bn_scale_shift(self.downsample[1], None, n, False)
                 a1, _, idt, _ = hconv_entry(srcs, self.conv1, self._p1, self.downsample[0], self._pd, postd=(sd, hd), post1=(s1, h1),
                                             post1_relu=True, out_h16=True)
             elif self.downsample is not None:

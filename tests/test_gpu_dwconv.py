@@ -65,6 +65,15 @@ def test_bad_arguments_are_errors():
 def test_fused_inference_batchnorm_agrees_with_the_stock_path():
     """encoder + U-Net decoder in eval mode: BatchNorm(+SiLU/ReLU) as one libsrbh affine pass vs MIOpen's inference BN"""
     from srbh_amd import encoders
+    from srbh_amd import hrfuse as H
+    # (exact-fp32 decoder convs: with the round-4 fp16-operand decoder convs a 1e-7 difference between the two BatchNorm paths flips
+    #  fp16 roundings downstream and shows as 3e-5 -- this test is about the BatchNorm kernels)
+    with H.head_precision("f32"):
+        _fused_bn_body()
+
+
+def _fused_bn_body():
+    from srbh_amd import encoders
     torch.manual_seed(5)
     enc = encoders.get_encoder("efficientnet-b4", in_channels=8, depth=5, weights=None).to(DEV)
     dec = encoders.UnetDecoder(enc.out_channels, (256, 128, 64, 32, 16), n_blocks=5, use_batchnorm=True, center=False,

@@ -43,9 +43,10 @@ def test_eval_batch128_tiles_are_independent():
             f2 = net_hr.forward_feature(pair[:, :3])
             assert torch.equal(f2[0], fea[t]), t                       # the trunk is batch-size independent bit for bit
             h2, b2 = model(pair, f2)
-            # the stock-op encoder / decoders may pick other algorithms per batch size: tolerance, not equality
-            assert O.rel_l2(h2[0].cpu(), h[t].cpu()) <= 1e-4, t
-            assert O.rel_l2(b2[0].cpu(), b[t].cpu()) <= 1e-4, t
+            # the stock-op stem conv may pick another algorithm per batch size: tolerance, not equality (round 4: the decoder convs
+            # run fp16 operands in this mode, so a last-bit difference upstream flips fp16 roundings: 2e-4, still well inside 1e-3)
+            assert O.rel_l2(h2[0].cpu(), h[t].cpu()) <= 5e-4, t
+            assert O.rel_l2(b2[0].cpu(), b[t].cpu()) <= 5e-4, t
 
 
 def test_train_batch64_is_permutation_equivariant(monkeypatch):

@@ -230,7 +230,10 @@ def test_fp16_activation_chain_within_tolerance(monkeypatch):
     for a, b, c, name in zip(got, want, base, ("height", "build", "aggre")):
         assert a.dtype == torch.float32
         assert O.rel_l2(a.cpu(), b) <= TOL_HEAD, name
-        assert 0 < O.rel_l2(a.cpu(), c.cpu()) <= TOL_HEAD, name        # (> 0: the fp16 chain really ran)
+        d = O.rel_l2(a.cpu(), c.cpu())
+        assert d <= TOL_HEAD, name
+        if name != "aggre":                      # (aggre comes from decoder1 alone: no head chain in it, and the decoders are deterministic now)
+            assert d > 0, name                   # the fp16 chain really ran
 
 
 @pytest.mark.parametrize("c0,c1,hw,stats", [(64, 0, (8, 64), True), (16, 16, (12, 128), False), (64, 16, (4, 64), True), (16, 0, (8, 70), False)])
