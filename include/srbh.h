@@ -278,6 +278,12 @@ int srbh_bn_add_relu(const float* a, const float* a_scale, const float* a_shift,
 #define SRBH_BAR_IDT_H16 2
 int srbh_bn_add_relu_io(const void* a, const float* a_scale, const float* a_shift, const void* idt,
                         const float* i_scale, const float* i_shift, float* out, long npix, int C, int io, void* stream);
+/* ... and ALSO writing the ReLU's activity pattern as bits (round 4): per 64 consecutive 4-channel groups four 64-bit words (word j bit l:
+ * element j of group 64 k + l is > 0), srbh_relu_bits_bytes(npix, C) bytes, C % 4 == 0.  srbh_bn_bwd_reduce_io(SRBH_BN_REF_BITS) takes it
+ * in place of the fp32 block output: the backward's reduce pass reads 1 bit per element instead of 4 bytes. */
+size_t srbh_relu_bits_bytes(long npix, int C);
+int srbh_bn_add_relu_bits(const void* a, const float* a_scale, const float* a_shift, const void* idt, const float* i_scale,
+                          const float* i_shift, float* out, void* bits, long npix, int C, int io, void* stream);
 /* aggregate_torch (aggregate_utils.py:29-41): data [N][H][W] fp32 -> out [N][H/step][W/step] */
 int srbh_aggregate(const float* data, float* out, int N, int H, int W, int step, void* stream);
 /* F.interpolate(scale_factor=2, mode='nearest') on NHWC fp32 (SR/rrdbnet_arch.py:236-237); H, W = output size */
@@ -340,6 +346,7 @@ int srbh_bn_bwd_apply(const float* g, const float* c, const float* mean, const f
 #define SRBH_BN_OUT_B16 1
 #define SRBH_BN_C_H16 2
 #define SRBH_BN_G_B16 4
+#define SRBH_BN_REF_BITS 8   /* srbh_bn_bwd_reduce_io: relu_ref points at srbh_bn_add_relu_bits' bit buffer, not at an fp32 tensor */
 int srbh_bn_bwd_reduce_io(const void* g, const float* relu_ref, void* dz_out, const void* c, const float* mean, const float* invstd,
                           const float* mask_scale, const float* mask_shift, long npix, int C, double* stats, int io, void* stream);
 int srbh_bn_bwd_apply_io(const void* g, const void* c, const float* mean, const float* invstd, const float* mask_scale,

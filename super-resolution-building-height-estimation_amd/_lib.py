@@ -163,6 +163,8 @@ SIGNATURES = {
     "srbh_bn_eval_scale_shift": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "srbh_bn_add_relu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp]),
     "srbh_bn_add_relu_io": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _i, _vp]),
+    "srbh_relu_bits_bytes": (_sz, [C.c_long, _i]),
+    "srbh_bn_add_relu_bits": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _i, _vp]),
     "srbh_aggregate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_nearest2x_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -568,10 +568,12 @@ __global__ void bn_eval_kernel(int C, const float* gamma, const float* beta, con
 
 // out = relu(a*sa + ha + (idt*si + hi))   (C multiple of 4; NHWC fp32)
 // AH / IH: `a` / `idt` hold fp16 elements in memory (the saved activations of the training step, round 3)
+// bits (may be NULL): the ReLU's activity pattern for the backward pass -- per 64 consecutive 4-channel groups four 64-bit words, word j
+// bit l = (element j of group 64 k + l is > 0): the reduce pass of the BatchNorm backward then reads 1 bit instead of the fp32 output
 template <int AH, int IH>
 __global__ void bn_add_relu_kernel(const void* __restrict__ a, const float* sa, const float* ha,
                                    const void* __restrict__ idt, const float* si, const float* hi, floatx4* out,
-                                   long n4, int C) {
+                                   long n4, int C, unsigned long long* __restrict__ bits = nullptr) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long stride = (long)gridDim.x * blockDim.x;
     for (; i < n4; i += stride) {
@@ -587,6 +589,13 @@ __global__ void bn_add_relu_kernel(const void* __restrict__ a, const float* sa, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
         out[i] = v;
+        if (bits) {          // (grid stride and block size are multiples of 64: a wave's 64 groups are 64 k .. 64 k + 63, lane = bit)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned long long m = __ballot(v[q] > 0.f);
+                if ((threadIdx.x & 63) == 0) bits[(i >> 6) * 4 + q] = m;
+            }
+        }
     }
 }
 
@@ -908,13 +917,13 @@ extern "C" int srbh_bn_eval_scale_shift(int C, const float* gamma, const float* 
 }
 
 static int bn_add_relu_impl(const void* a, const float* a_scale, const float* a_shift, const void* idt, const float* i_scale,
-                            const float* i_shift, float* out, long npix, int C, int io, void* stream) {
+                            const float* i_shift, float* out, long npix, int C, int io, void* stream, unsigned long long* bits = nullptr) {
     SRBH_REQUIRE(a && a_scale && a_shift && idt && out && npix > 0 && C > 0 && C % 4 == 0, "srbh_bn_add_relu: bad arguments");
     SRBH_REQUIRE((io & ~3) == 0, "srbh_bn_add_relu_io: unknown io bits");
     long n4 = npix * C / 4;
     int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
 #define SRBH_BAR(A_, I_) hipLaunchKernelGGL((bn_add_relu_kernel<A_, I_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, a_scale, a_shift, \
-                                            idt, i_scale, i_shift, (floatx4*)out, n4, C)
+                                            idt, i_scale, i_shift, (floatx4*)out, n4, C, bits)
     switch (io) { case 0: SRBH_BAR(0, 0); break; case 1: SRBH_BAR(1, 0); break; case 2: SRBH_BAR(0, 1); break; default: SRBH_BAR(1, 1); break; }
 #undef SRBH_BAR
     SRBH_HIP(hipGetLastError());
@@ -930,6 +939,17 @@ extern "C" int srbh_bn_add_relu(const float* a, const float* a_scale, const floa
 extern "C" int srbh_bn_add_relu_io(const void* a, const float* a_scale, const float* a_shift, const void* idt,
                                    const float* i_scale, const float* i_shift, float* out, long npix, int C, int io, void* stream) {
     return bn_add_relu_impl(a, a_scale, a_shift, idt, i_scale, i_shift, out, npix, C, io, stream);
+}
+
+/* the same pass, also writing the ReLU's activity bits (srbh_relu_bits_bytes(npix, C) bytes) for srbh_bn_bwd_reduce_io(SRBH_BN_REF_BITS) */
+extern "C" size_t srbh_relu_bits_bytes(long npix, int C) {
+    if (npix <= 0 || C <= 0 || (C & 3)) return 0;
+    return (size_t)((npix * (C >> 2) + 63) / 64) * 4 * sizeof(unsigned long long);
+}
+extern "C" int srbh_bn_add_relu_bits(const void* a, const float* a_scale, const float* a_shift, const void* idt,
+                                     const float* i_scale, const float* i_shift, float* out, void* bits, long npix, int C, int io, void* stream) {
+    SRBH_REQUIRE(bits && ((uintptr_t)bits & 7) == 0, "srbh_bn_add_relu_bits: bits buffer missing / unaligned");
+    return bn_add_relu_impl(a, a_scale, a_shift, idt, i_scale, i_shift, out, npix, C, io, stream, (unsigned long long*)bits);
 }
 
 extern "C" int srbh_aggregate(const float* data, float* out, int N, int H, int W, int step, void* stream) {

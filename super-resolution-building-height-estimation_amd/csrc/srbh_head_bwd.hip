@@ -636,7 +636,8 @@ __device__ __forceinline__ floatx4 ld4(const T* base, const long i) {
     else if constexpr (B16 == 1) return widen_h4(((const float2w*)base)[i]);
     else return widen_b4(((const float2w*)base)[i]);
 }
-template <int GB, int CH, int OB>
+// RB = 1: relu_ref is the ReLU's activity bit pattern written by bn_add_relu (4 words per 64 groups) instead of the fp32 block output
+template <int GB, int CH, int OB, int RB = 0>
 __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const void* __restrict__ g, const void* __restrict__ c, const float* mean,
                                                               const float* invstd, const float* ms, const float* mh,
                                                               const floatx4* __restrict__ relu_ref, void* __restrict__ dz_out,
@@ -655,9 +656,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(const void* __restr
     for (; i < n4; i += stride) {
         floatx4 dy = ld4<GB ? 2 : 0>(g, i);
         if (relu_ref) {
-            const floatx4 r = relu_ref[i];
+            if constexpr (RB != 0) {
+                const unsigned long long* mw = (const unsigned long long*)relu_ref + (i >> 6) * 4;
+                const int sh = (int)(i & 63);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dy[j] = r[j] > 0.f ? dy[j] : 0.f;
+                for (int j = 0; j < 4; ++j) dy[j] = ((mw[j] >> sh) & 1ull) ? dy[j] : 0.f;
+            } else {
+                const floatx4 r = relu_ref[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dy[j] = r[j] > 0.f ? dy[j] : 0.f;
+            }
             if (dz_out) {
                 if constexpr (OB != 0) {
                     const float2w nb = narrow_b4(dy);
@@ -1003,15 +1011,25 @@ static int bn_bwd_reduce_impl(const void* g, const float* relu_ref, void* dz_out
                               const float* mask_scale, const float* mask_shift, long npix, int C, double* stats, void* stream, int io = 0) {
     hipStream_t st = (hipStream_t)stream;
     if (int rc = zero_async(stats, (size_t)NSLOT * 2 * C * sizeof(double), st)) return rc;
-    const bool gb = (io & SRBH_BN_G_B16) != 0, ch = (io & SRBH_BN_C_H16) != 0, ob = (io & SRBH_BN_OUT_B16) != 0;
+    const bool gb = (io & SRBH_BN_G_B16) != 0, ch = (io & SRBH_BN_C_H16) != 0, ob = (io & SRBH_BN_OUT_B16) != 0, rb = (io & SRBH_BN_REF_BITS) != 0;
     const bool v4 = (C & 3) == 0 && (256 % (C >> 2)) == 0 && ((uintptr_t)g & (gb ? 7 : 15)) == 0 && ((uintptr_t)c & (ch ? 7 : 15)) == 0 &&
-                    ((uintptr_t)dz_out & (ob ? 7 : 15)) == 0 && (((uintptr_t)relu_ref | (uintptr_t)mean | (uintptr_t)invstd |
+                    ((uintptr_t)dz_out & (ob ? 7 : 15)) == 0 && ((uintptr_t)relu_ref & (rb ? 7 : 15)) == 0 && (((uintptr_t)mean | (uintptr_t)invstd |
                      (uintptr_t)mask_scale | (uintptr_t)mask_shift) & 15) == 0;
+    SRBH_REQUIRE(!rb || (relu_ref && v4), "srbh_bn_bwd_reduce_io: SRBH_BN_REF_BITS needs relu_ref (the bit buffer) and the vector form");
     SRBH_REQUIRE(!io || v4, "srbh_bn_bwd_reduce: 16-bit tensors need the vector form (C %% 4 == 0, 256 %% (C/4) == 0, aligned)");
     if (v4) {
         const long n4 = npix * (C >> 2);
 #define SRBH_BNR(G_, C_, O_) hipLaunchKernelGGL((bn_bwd_reduce4_kernel<G_, C_, O_>), dim3(grid4_for(n4)), dim3(256), 2 * C * sizeof(float), st, \
                                                 g, c, mean, invstd, mask_scale, mask_shift, (const floatx4*)relu_ref, dz_out, n4, C, stats)
+        if (rb) {
+#define SRBH_BNRB(G_, C_, O_) hipLaunchKernelGGL((bn_bwd_reduce4_kernel<G_, C_, O_, 1>), dim3(grid4_for(n4)), dim3(256), 2 * C * sizeof(float), st, \
+                                                 g, c, mean, invstd, mask_scale, mask_shift, (const floatx4*)relu_ref, dz_out, n4, C, stats)
+            switch ((gb ? 4 : 0) | (ch ? 2 : 0) | (ob ? 1 : 0)) {
+                case 0: SRBH_BNRB(0, 0, 0); break; case 1: SRBH_BNRB(0, 0, 1); break; case 2: SRBH_BNRB(0, 1, 0); break; case 3: SRBH_BNRB(0, 1, 1); break;
+                case 4: SRBH_BNRB(1, 0, 0); break; case 5: SRBH_BNRB(1, 0, 1); break; case 6: SRBH_BNRB(1, 1, 0); break; default: SRBH_BNRB(1, 1, 1); break;
+            }
+#undef SRBH_BNRB
+        } else
         switch ((gb ? 4 : 0) | (ch ? 2 : 0) | (ob ? 1 : 0)) {
             case 0: SRBH_BNR(0, 0, 0); break; case 1: SRBH_BNR(0, 0, 1); break; case 2: SRBH_BNR(0, 1, 0); break; case 3: SRBH_BNR(0, 1, 1); break;
             case 4: SRBH_BNR(1, 0, 0); break; case 5: SRBH_BNR(1, 0, 1); break; case 6: SRBH_BNR(1, 1, 0); break; default: SRBH_BNR(1, 1, 1); break;
@@ -1053,7 +1071,7 @@ extern "C" int srbh_bn_bwd_reduce_io(const void* g, const float* relu_ref, void*
     SRBH_REQUIRE(!c || (mean && invstd), "srbh_bn_bwd_reduce_io: c needs mean/invstd");
     SRBH_REQUIRE(!mask_scale || (c && mask_shift), "srbh_bn_bwd_reduce_io: mask needs c and mask_shift");
     SRBH_REQUIRE(!(relu_ref && mask_scale), "srbh_bn_bwd_reduce_io: either the block-closing ReLU (relu_ref) or the bn1 mask");
-    SRBH_REQUIRE((io & ~7) == 0, "srbh_bn_bwd_reduce_io: unknown io bits");
+    SRBH_REQUIRE((io & ~15) == 0, "srbh_bn_bwd_reduce_io: unknown io bits");
     return bn_bwd_reduce_impl(g, relu_ref, dz_out, c, mean, invstd, mask_scale, mask_shift, npix, C, stats, stream, io);
 }
 

@@ -325,11 +325,23 @@ class defer_batch_counters:
         return False
 
 
-def bn_add_relu(a, sa, ha, idt, si=None, hi=None):
-    """out = relu(a * sa + ha + [idt * si + hi | idt]) (fp32 NHWC); `a` / `idt` may be fp16 tensors (the training step's saved activations)"""
+RELU_BITS = _os.environ.get("SRBH_RELU_BITS", "1") == "1"     # training: the block-closing ReLU's pattern saved as bits for the backward
+
+
+def bn_add_relu(a, sa, ha, idt, si=None, hi=None, want_bits=False):
+    """out = relu(a * sa + ha + [idt * si + hi | idt]) (fp32 NHWC); `a` / `idt` may be fp16 tensors (the training step's saved activations).
+    want_bits (training, C % 4 == 0): returns (out, bits) -- the ReLU's activity pattern, 1 bit per element, which the backward's reduce pass
+    reads instead of the fp32 output (hrfuse_autograd.bn_backward(relu_ref=bits))."""
     B, Cc, H, W = a.shape
     out = empty_nhwc(B, Cc, H, W, a.device)
     io = (1 if a.dtype == torch.float16 else 0) | (2 if idt.dtype == torch.float16 else 0)
+    if want_bits:
+        L = _lib.lib()
+        bits = torch.empty(L.srbh_relu_bits_bytes(B * H * W, Cc) // 8, dtype=torch.int64, device=a.device)
+        _lib.check(L.srbh_bn_add_relu_bits(a.data_ptr(), sa.data_ptr(), ha.data_ptr(), idt.data_ptr(),
+                                           None if si is None else si.data_ptr(), None if hi is None else hi.data_ptr(),
+                                           out.data_ptr(), bits.data_ptr(), B * H * W, Cc, io, _lib.stream_ptr()), "bn_add_relu_bits")
+        return out, bits
     _lib.check(_lib.lib().srbh_bn_add_relu_io(a.data_ptr(), sa.data_ptr(), ha.data_ptr(), idt.data_ptr(),
                                               None if si is None else si.data_ptr(), None if hi is None else hi.data_ptr(),
                                               out.data_ptr(), B * H * W, Cc, io, _lib.stream_ptr()), "bn_add_relu")

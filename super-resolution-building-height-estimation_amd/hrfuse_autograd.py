@@ -177,7 +177,10 @@ def bn_backward(g, c, mean, invstd, gamma, mask, training, relu_ref=None, out_b1
     dz = None
     vec = Cc % 4 == 0 and 256 % (Cc // 4) == 0
     io_c = 2 if c.dtype == torch.float16 else 0
-    use_io = vec and (io_c or out_b16 or g.dtype == torch.bfloat16)
+    ref_bits = relu_ref is not None and relu_ref.dtype == torch.int64
+    use_io = vec and (io_c or out_b16 or g.dtype == torch.bfloat16 or ref_bits)
+    if ref_bits and not vec:
+        raise NotImplementedError("libsrbh BatchNorm backward: the ReLU bit pattern needs C % 4 == 0 and 256 % (C/4) == 0")
     if (io_c or out_b16 or g.dtype == torch.bfloat16) and not vec:
         raise NotImplementedError("libsrbh BatchNorm backward: 16-bit tensors need C % 4 == 0 and 256 % (C/4) == 0")
     odt = torch.bfloat16 if out_b16 else torch.float32
@@ -187,6 +190,8 @@ def bn_backward(g, c, mean, invstd, gamma, mask, training, relu_ref=None, out_b1
         if relu_ref is not None:
             dz = H.empty_nhwc(B, Cc, Hh, Ww, dev, odt)
         io = io_c | (4 if g.dtype == torch.bfloat16 else 0) | (1 if out_b16 else 0)
+        if relu_ref is not None and relu_ref.dtype == torch.int64:      # the ReLU pattern as bits (hrfuse.bn_add_relu(want_bits=True))
+            io |= 8
         _lib.check(L.srbh_bn_bwd_reduce_io(g.data_ptr(), None if relu_ref is None else relu_ref.data_ptr(),
                                            None if dz is None else dz.data_ptr(), c.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                            ms, mh, n, Cc, st.data_ptr(), io, _lib.stream_ptr()), "bn_bwd_reduce_io")
@@ -330,11 +335,15 @@ class _BasicBlockFn(torch.autograd.Function):
             sd, hd, md, idd = H.bn_scale_shift(blk.downsample[1], std, n, tr)
             if not tr:
                 md, idd = _bn_eval_stats(blk.downsample[1])
-            out = H.bn_add_relu(c2, s2, h2, d, sd, hd)
+        Cc2 = c2.shape[1]
+        bits = H.RELU_BITS and Cc2 % 4 == 0 and 256 % (Cc2 // 4) == 0
+        if blk.downsample is not None:
+            r = H.bn_add_relu(c2, s2, h2, d, sd, hd, want_bits=bits)
         else:
-            out = H.bn_add_relu(c2, s2, h2, srcs[0])
+            r = H.bn_add_relu(c2, s2, h2, srcs[0], want_bits=bits)
+        out, ref = r if bits else (r, r)         # what the backward's ReLU mask is read from: 1 bit per element, or the fp32 output
         ctx.blk, ctx.tr, ctx.nsrc = blk, tr, len(srcs)
-        ctx.save_for_backward(*srcs, c1, c2, out, s1, h1, m1, i1, m2, i2, w1, g1, w2, g2,
+        ctx.save_for_backward(*srcs, c1, c2, ref, s1, h1, m1, i1, m2, i2, w1, g1, w2, g2,
                               *([d, md, idd, wd, gd] if d is not None else []))
         return out
 

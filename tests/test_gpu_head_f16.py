@@ -288,3 +288,34 @@ def test_fused_entry_weight_gradients_equal_the_two_separate_calls(c0, c1, x16, 
         r3, r1 = HA.conv_wgrad(srcs, None, g3, 16, 3), HA.conv_wgrad(srcs, None, g1, 16, 1)
     assert torch.equal(d3, r3) and torch.equal(d1, r1)
     assert float(d3.abs().max()) > 0 and float(d1.abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,shape,b16", [(16, (2, 24, 72), False), (16, (3, 8, 64), True), (64, (1, 12, 20), False), (4, (2, 5, 7), True)])
+def test_relu_bit_pattern_equals_the_fp32_reference_in_the_backward_reduce(C, shape, b16):
+    """Round 4: bn_add_relu also writes the block-closing ReLU's activity pattern as bits (srbh_bn_add_relu_bits); the BatchNorm backward's
+    reduce pass (srbh_bn_bwd_reduce_io + SRBH_BN_REF_BITS) masks with them instead of reading the fp32 block output: same dz, same dc,
+    same dgamma / dbeta, bit for bit; sizes that are not multiples of 64 groups included."""
+    from srbh_amd import hrfuse as H
+    from srbh_amd import hrfuse_autograd as HA
+    dev = "cuda:0"
+    B, Hh, Ww = shape
+    g = torch.Generator().manual_seed(C + Hh)
+    nhwc = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)        # noqa: E731
+    a, idt = nhwc(torch.randn((B, C, Hh, Ww), generator=g)), nhwc(torch.randn((B, C, Hh, Ww), generator=g))
+    sa, ha = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+    out0 = H.bn_add_relu(a, sa, ha, idt)
+    out1, bits = H.bn_add_relu(a, sa, ha, idt, want_bits=True)
+    assert torch.equal(out0, out1) and bits.dtype == torch.int64
+    assert 0.2 < float((out0 > 0).float().mean()) < 0.8
+    gy = nhwc(torch.randn((B, C, Hh, Ww), generator=g))
+    mean, invstd, gamma = (torch.randn(C, generator=g) * 0.1).to(dev), (torch.rand(C, generator=g) + 0.5).to(dev), (torch.rand(C, generator=g) + 0.5).to(dev)
+    r0 = HA.bn_backward(gy, a, mean, invstd, gamma, None, True, relu_ref=out0, out_b16=b16)
+    r1 = HA.bn_backward(gy, a, mean, invstd, gamma, None, True, relu_ref=bits, out_b16=b16)
+    dc0, dg0, db0, dz0 = r0
+    dc1, dg1, db1, dz1 = r1
+    assert dz0.dtype == dz1.dtype and torch.equal(dz0, dz1)          # the masked gradient: elementwise, identical
+    assert float((dz0.float() == 0).float().mean()) > 0.2            # ... and really masked
+    # the sums go through atomics (order-dependent last bits), and dc carries their means: close, not identical
+    assert torch.allclose(dg0, dg1, rtol=1e-4, atol=1e-5) and torch.allclose(db0, db1, rtol=1e-4, atol=1e-5)
+    assert dc0.dtype == dc1.dtype and torch.allclose(dc0.float(), dc1.float(), rtol=2e-2 if b16 else 1e-4, atol=1e-4)
