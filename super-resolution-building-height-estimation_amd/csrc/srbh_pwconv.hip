@@ -24,7 +24,10 @@
 namespace {
 using namespace srbh;
 typedef float floatx4 __attribute__((ext_vector_type(4)));
-constexpr int UK = 8;               // K steps per round of loads
+#ifndef SRBH_PW_UK
+#define SRBH_PW_UK 8
+#endif
+constexpr int UK = SRBH_PW_UK;      // K steps per round of loads
 
 // KW waves share one tile and split its K range between them (partials folded through LDS in a fixed order): the deep products at 2x2 and
 // 4x4 (K up to 2688 with only ~300 tiles) are otherwise one long chain of load rounds on a quarter of the SIMDs.  KW = 1: the 4 waves
