@@ -304,10 +304,13 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
         # the WHOLE head (+ losses) of this very step against the HBM roofline: every libsrbh call of two extra steps bracketed by
         # HIP events and priced with the algorithmic bytes its arguments imply (srbh_amd/kprof.py); outside the timed region
         from srbh_amd.kprof import KernelProfile
+        _lib.path_counters(reset=True)
         with KernelProfile() as kp:
             for _ in range(2):
                 ts(fixed)
         rows, totals = kp.table(steps=2)
+        # which FORM of the head entry points ran in those 2 steps (persistent kernel vs template, fused vs split): no silent fallback
+        line["head_paths_2steps"] = _lib.path_counters()
         top = rows[:8]
         totals["note"] = ("every libsrbh head / loss call of the step (HIP events around each call); `kernels` = the 8 largest "
                           "(all rows: --details / profiles/); bytes = each tensor once at its stored element size; peak 8000 GB/s")
@@ -402,7 +405,10 @@ def bench_predict(args, rank, world, dev, dist, n_cities, warmup, batch=128, sma
 
     for i, n in enumerate(warm):
         city(n, 99 + i)
+    from srbh_amd import _lib as _L
+    _L.path_counters(reset=True)
     lat = [city(n, 2024 + i) for i, n in enumerate(todo)]
+    head_paths = _L.path_counters()          # (graph replays launch without passing the C entry points: these are the eager tail batches + captures)
     torch.backends.cudnn.benchmark = False
     if rank != 0:
         return None
@@ -423,7 +429,8 @@ def bench_predict(args, rank, world, dev, dist, n_cities, warmup, batch=128, sma
         "large_cities": {"n_over_10k_cells": sum(1 for c in todo if c > 10000),
                          "tiles_per_s": round(sum(c for c in todo if c > 10000) / max(1e-9, sum(l for c, l in zip(todo, lat) if c > 10000)), 2)
                          if any(c > 10000 for c in todo) else None},
-        "tail_shapes_run": sorted({(c % batch + 31) // 32 * 32 for c in todo if c % batch}) if pad_to else None}
+        "tail_shapes_run": sorted({(c % batch + 31) // 32 * 32 for c in todo if c % batch}) if pad_to else None,
+        "head_paths_eager_calls": {k: v for k, v in head_paths.items() if v}}
 
 
 def bench_sr_train(args, rank, world, dev, dist, steps, warmup, batch=8):

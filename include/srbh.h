@@ -39,6 +39,19 @@ extern "C" {
 /* ---- library ------------------------------------------------------------------------------ */
 int srbh_version(void);
 const char* srbh_last_error(void);
+/* Diagnostics: which form of the head entry points ran since the last reset (SURVEY 8b "no silent fallback": the choice between a
+ * specialised persistent kernel and the general template, or one fused pass and two launches, depends on shapes / element types and is
+ * invisible in the results).  out[i] for i < n in the order below; returns the number of counters. */
+#define SRBH_PATH_HCONV16 0             /* srbh_hconv_h16 -> persistent 16 -> 16 3x3 kernel */
+#define SRBH_PATH_HCONV_TEMPLATE 1      /* srbh_hconv_f32 / _h16 -> one-tile-per-workgroup template */
+#define SRBH_PATH_ENTRY_FUSED 2         /* srbh_hconv_entry_h16 -> one pass */
+#define SRBH_PATH_ENTRY_SPLIT 3         /* ... -> two template launches */
+#define SRBH_PATH_WGRAD16 4             /* srbh_hconv_wgrad_b16 -> persistent 16 -> 16 kernel */
+#define SRBH_PATH_WGRAD_B16_GENERIC 5
+#define SRBH_PATH_WGRAD_F32 6
+#define SRBH_PATH_WGRAD_ENTRY_FUSED 7   /* srbh_hconv_wgrad_entry_b16 -> one pass */
+#define SRBH_PATH_WGRAD_ENTRY_SPLIT 8
+int srbh_path_counters(unsigned long long* out, int n, int reset);
 
 /* ---- layout helpers (used by tests and by the Python mirror at module boundaries) ------------ */
 /* bytes of an ACT16 buffer including the read slack the tiled kernels need */

@@ -55,6 +55,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+PATH_NAMES = ("hconv16", "hconv_template", "entry_fused", "entry_split", "wgrad16", "wgrad_b16_generic", "wgrad_f32", "wgrad_entry_fused",
+              "wgrad_entry_split")
+
+
+def path_counters(reset=False):
+    """{form: launches since the last reset} of the head entry points that choose between kernel forms (include/srbh.h SRBH_PATH_*)"""
+    buf = (C.c_ulonglong * len(PATH_NAMES))()
+    lib().srbh_path_counters(buf, len(PATH_NAMES), int(reset))
+    return {k: int(v) for k, v in zip(PATH_NAMES, buf)}
+
+
 # ---- C structs (mirror include/srbh.h) ------------------------------------------------------------
 class ConvArgs(C.Structure):
     _fields_ = [
@@ -136,6 +147,7 @@ _vp, _i, _sz, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_float
 SIGNATURES = {
     "srbh_version": (_i, []),
     "srbh_last_error": (C.c_char_p, []),
+    "srbh_path_counters": (_i, [_vp, _i, _i]),
     "srbh_act16_bytes": (_sz, [_i, _i, _i, _i]),
     "srbh_nchw32_to_act16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_act16_to_nchw32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -5,6 +5,7 @@ namespace srbh {
 
 static thread_local char g_err[512] = "";
 
+unsigned long long g_path_counters[PATH_N] = {};
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -38,6 +39,13 @@ int zero_async(void* p, size_t bytes, hipStream_t st) {
 using namespace srbh;
 
 extern "C" int srbh_version(void) { return 100; }
+/* out[0..n): launches per form since the last reset (order: srbh.h SRBH_PATH_*); reset != 0 clears them.  Host-side counters, not
+ * thread-safe beyond "approximately right": a diagnostic. */
+extern "C" int srbh_path_counters(unsigned long long* out, int n, int reset) {
+    for (int i = 0; i < n && i < srbh::PATH_N; ++i) if (out) out[i] = srbh::g_path_counters[i];
+    if (reset) for (int i = 0; i < srbh::PATH_N; ++i) srbh::g_path_counters[i] = 0;
+    return srbh::PATH_N;
+}
 extern "C" const char* srbh_last_error(void) { return g_err; }
 
 extern "C" size_t srbh_act16_bytes(int B, int C, int H, int W) {

@@ -780,6 +780,7 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
     if (opt != 0 && k16_wgs >= 8 && a->ksize == 3 && (full16 || narrow) && a->c0 == 16 && a->c1 == 0 && (W & 63) == 0 && (H & 3) == 0 &&
         !a->pixelshuffle2 && !a->res2 && !a->post_lrelu && (p.ld0 & 3) == 0 &&
         (!a->res1 || (a->res1_ld & 3) == 0) && ((uintptr_t)a->src0 & (src16 ? 7 : 15)) == 0 && ((uintptr_t)a->res1 & (r16 ? 7 : 15)) == 0) {
+        count_path(PATH_HCONV16);
         p.tiles_x = W / 64;
         p.tiles_per_img = p.tiles_x * (H / 4);
         p.ntiles = p.tiles_per_img * B;
@@ -810,6 +811,7 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
         SRBH_HIP(hipGetLastError());
         return SRBH_OK;
     }
+    count_path(PATH_HCONV_TEMPLATE);
     SRBH_REQUIRE(!a->bstat_c, "srbh_hconv: the backward-statistics epilogue exists in the persistent 16 -> 16 3x3 kernel only (16-bit operand modes, W %% 64 == 0, H %% 4 == 0)");
     // (the template stages a 16-bit source as it is: no transform on the way)
     SRBH_REQUIRE(!src16 || (!a->pre_scale && !a->pre_relu), "srbh_hconv_h16: a 16-bit src0 takes a pre-affine / ReLU only in the 16 -> 16 3x3 form");
@@ -857,9 +859,11 @@ extern "C" int srbh_hconv_entry_h16(const srbh_hconv_args* c1, const srbh_hconv_
                        (c1->out_coff & 3) == 0 && (ds->out_coff & 3) == 0 &&
                        (((uintptr_t)c1->src0 | (uintptr_t)c1->src1) & (es16 ? 7 : 15)) == 0 && (((uintptr_t)c1->out | (uintptr_t)ds->out) & 7) == 0;
     if (!(wgs >= 8 && same && plain && shape && src_ok && c1->src0 && c1->w && ds->w && c1->out && ds->out)) {
+        count_path(PATH_ENTRY_SPLIT);
         if (int rc = hconv_impl(c1, stream, bf16 ? 2 : 1)) return rc;
         return hconv_impl(ds, stream, bf16 ? 2 : 1);
     }
+    count_path(PATH_ENTRY_FUSED);
     SRBH_REQUIRE(!c1->post_scale || c1->post_shift, "srbh_hconv_entry_h16: post_scale needs post_shift");
     SRBH_REQUIRE(!ds->post_scale || ds->post_shift, "srbh_hconv_entry_h16: post_scale needs post_shift");
     hipStream_t st = (hipStream_t)stream;

@@ -810,6 +810,7 @@ int wgrad_impl(const srbh_hwgrad_args* a, void* stream, bool b16, const char* wh
     SRBH_REQUIRE(!xs16 || k16 || (b16 && can16 && ((uintptr_t)a->src0 & 7) == 0),
                  "srbh_hconv_wgrad_b16: an fp16 source tensor needs the bf16-operand forms (4-aligned channels, 16-channel output blocks)");
     SRBH_REQUIRE(!ds16 || k16 || can16, "srbh_hconv_wgrad_b16: a bf16 dY needs 4-aligned channels / 16-channel output blocks");
+    count_path(k16 ? PATH_WGRAD16 : (b16 && can16) ? PATH_WGRAD_B16_GENERIC : PATH_WGRAD_F32);
     if (k16) {
         p.tiles_x = a->W / 64;
         p.tiles_per_img = p.tiles_x * (a->H / 4);
@@ -886,9 +887,11 @@ extern "C" int srbh_hconv_wgrad_entry_b16(const srbh_hwgrad_args* a3, const srbh
                        ((uintptr_t)a3->src0 & ((a3->io & SRBH_WG_SRC0_H16) ? 7 : 15)) == 0 && ((uintptr_t)a3->src1 & 15) == 0 &&
                        (((uintptr_t)a3->dy | (uintptr_t)a1->dy) & (ds16 ? 7 : 15)) == 0;
     if (!(fuse && same && shape)) {
+        count_path(PATH_WGRAD_ENTRY_SPLIT);
         if (int rc = wgrad_impl(a3, stream, true, "srbh_hconv_wgrad_b16")) return rc;
         return wgrad_impl(a1, stream, true, "srbh_hconv_wgrad_b16");
     }
+    count_path(PATH_WGRAD_ENTRY_FUSED);
     WGParams p = {};
     p.src0 = a3->src0; p.src1 = a3->src1; p.c0 = a3->c0; p.c1 = a3->c1; p.ld0 = ld0; p.ld1 = ld1;
     p.pre_scale = a3->pre_scale; p.pre_shift = a3->pre_shift; p.pre_relu = a3->pre_relu;

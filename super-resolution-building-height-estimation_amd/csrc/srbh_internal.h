@@ -14,6 +14,15 @@ constexpr int TILE_W = 64;      // output columns per workgroup
 constexpr int TILE_H = 8;       // output rows per workgroup
 
 void set_error(const char* fmt, ...);
+// Which form of a head entry point ran (srbh_path_counters): several C entry points choose between a specialised persistent kernel and
+// the general template (or between one fused pass and two launches) from the shapes they are given -- same results, different speed.
+// SURVEY 8(b) "no silent fallback": the choice is counted, bench.py prints the counts (`train_step.head_paths`), so a hot shape
+// sliding back to the slow form shows as a count, not only as time.  (Round 4: the fp16 feature hand-off had sent the inference
+// chain's 64-channel block entry back to two template launches -- found only in a kernel trace.)
+enum PathCounter { PATH_HCONV16 = 0, PATH_HCONV_TEMPLATE, PATH_ENTRY_FUSED, PATH_ENTRY_SPLIT, PATH_WGRAD16, PATH_WGRAD_B16_GENERIC,
+                   PATH_WGRAD_F32, PATH_WGRAD_ENTRY_FUSED, PATH_WGRAD_ENTRY_SPLIT, PATH_N };
+extern unsigned long long g_path_counters[PATH_N];
+inline void count_path(int i) { ++g_path_counters[i]; }
 // Stream-ordered zero fill of `bytes` (a multiple of 4) by a KERNEL.  Not hipMemsetAsync: captured into a HIP graph, a memset node is
 // not kept in order with the kernels of the previous replay of the same graph (srbh_ptrunk.hip, ptrunk_reset_kernel), and every
 // libsrbh call must stay correct inside back-to-back graph replays (harness.TrainStep(graph=True), predict_tiles).

@@ -120,3 +120,32 @@ def test_train_step_runs_on_fp16_features(monkeypatch):
     net.hrfeat.forward = lambda x, out_h16=False, _o=orig, _s=seen: (_s.append(x.dtype), _o(x, out_h16))[1]
     harness.TrainStep(net_hr, net, DEV, lr=1e-4, status_every=0, head_precision="f32")(harness.synthetic_batch(2, 3, DEV))
     assert seen == [torch.float32]
+
+
+def test_no_head_entry_point_falls_back_to_its_slow_form(monkeypatch):
+    """srbh_path_counters (round 4): the head entry points that choose between a specialised kernel and the template -- or one fused pass
+    and two launches -- count their choice.  With the shapes of the model (64-channel fp16 features, 16 + 16 fp32 fuse entries) NO block
+    entry may run split, neither forward (eval chain and training) nor in the weight gradients; the fp16 feature hand-off had silently
+    split the inference chain's 64-channel entry until a kernel trace showed it."""
+    from oracle import synth
+    from srbh_amd import _lib, encoders, harness
+    monkeypatch.setattr(encoders, "DROP_CONNECT", 0.0)
+    net_hr, net = _nets()
+    x = synth.tiles(2, 8, 64, seed=9).to(DEV)
+    net.eval()
+    with torch.no_grad():
+        net(x, harness.features_for_head(net_hr, x[:, :3].contiguous()))       # warm-up (packs)
+        _lib.path_counters(reset=True)
+        net(x, harness.features_for_head(net_hr, x[:, :3].contiguous()))
+    c = _lib.path_counters(reset=True)
+    assert c["entry_fused"] == 3 and c["entry_split"] == 0, c                  # hrfeat.0, reg.fuse.0, seg.fuse.0
+    assert c["hconv16"] >= 14, c                                               # conv2 of 9 blocks + conv1 of 6 + the two conv_last
+    ts = harness.TrainStep(net_hr, net, DEV, lr=1e-4, status_every=0)
+    batch = harness.synthetic_batch(2, 3, DEV)
+    ts(batch)
+    _lib.path_counters(reset=True)
+    ts(batch)
+    c = _lib.path_counters(reset=True)
+    assert c["entry_fused"] == 3 and c["entry_split"] == 0, c
+    assert c["wgrad_entry_fused"] == 3 and c["wgrad_entry_split"] == 0 and c["wgrad_f32"] == 0, c
+    assert c["wgrad16"] >= 15, c
