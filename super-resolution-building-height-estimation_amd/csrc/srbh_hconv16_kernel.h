@@ -24,9 +24,13 @@
 // IO (compile-time, so that the all-fp32 form keeps its registers): bit 0 = the residual, bit 1 = the output is a 16-bit tensor
 // BS (compile-time for the same reason: as a run-time flag the epilogue cost every instantiation 8-20 spilled registers):
 // 0 = none, 1 = BatchNorm-backward sums with the c*ms + mh mask (c in the residual's registers)
-template <int OPT, int S16, int IO, int BS = 0>
+// NIN (compile-time): 1 = NARROW input, c0 < 16 fp32 channels with pixel stride ld0 = any (the data gradients of the 1- / 7-channel output
+//   convs: conv^T(dY[7], W) -- they ran the one-tile-per-workgroup template at 0.19-0.20 of the HBM roofline): a staging unit is four
+//   scalar loads of the channels that exist, the rest of the 16-channel chunk is zero (the pack pads the weights the same way)
+template <int OPT, int S16, int IO, int BS = 0, int NIN = 0>
 __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
     static_assert(OPT == 1 || OPT == 2, "16-bit operand forms only");
+    static_assert(NIN == 0 || (S16 == 0 && BS == 0), "narrow input: fp32 source, plain epilogue");
     constexpr int ROWS = 6, COLS = 66, NIT = (ROWS * COLS * 4 + 255) / 256;        // 7 staging units per thread (the last one partial)
     constexpr int STAGE_B = ROWS * COLS * 32;                                       // 12 672 bytes per stage
     extern __shared__ __attribute__((aligned(16))) float hsm[];
@@ -112,7 +116,16 @@ __global__ __launch_bounds__(256, 3) void hconv16_kernel(const HParams p) {
             if constexpr (S16) ld[SL][it] = float2v{0.f, 0.f};
             else ld[SL][it] = floatx4{0.f, 0.f, 0.f, 0.f};
             if (ok) {
-                ld[SL][it] = *(const ldv_t*)(tp + (long)uoff[it] * (S16 ? 2 : 4));
+                if constexpr (NIN != 0) {
+                    const float* q = (const float*)tp + uoff[it];
+                    floatx4 v4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (cg * 4 + j < p.c0) v4[j] = q[j];
+                    ld[SL][it] = v4;
+                } else {
+                    ld[SL][it] = *(const ldv_t*)(tp + (long)uoff[it] * (S16 ? 2 : 4));
+                }
                 okmask[SL] |= 1u << it;
             }
         }

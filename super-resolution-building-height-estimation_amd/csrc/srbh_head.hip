@@ -777,9 +777,11 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
     const bool src16 = (a->io_h16 & SRBH_IO_SRC0_H16) != 0, o16 = (a->io_h16 & SRBH_IO_OUT_H16) != 0, r16 = (a->io_h16 & SRBH_IO_RES1_H16) != 0;
     const bool full16 = a->cout == 16 && (p.out_ld & 3) == 0 && (p.out_coff & 3) == 0 && ((uintptr_t)a->out & (o16 ? 7 : 15)) == 0;
     const bool narrow = a->cout < 16 && !a->stats && !a->res1 && !o16;         // conv_last (1 / 7 channels): scalar stores
-    if (opt != 0 && k16_wgs >= 8 && a->ksize == 3 && (full16 || narrow) && a->c0 == 16 && a->c1 == 0 && (W & 63) == 0 && (H & 3) == 0 &&
-        !a->pixelshuffle2 && !a->res2 && !a->post_lrelu && (p.ld0 & 3) == 0 &&
-        (!a->res1 || (a->res1_ld & 3) == 0) && ((uintptr_t)a->src0 & (src16 ? 7 : 15)) == 0 && ((uintptr_t)a->res1 & (r16 ? 7 : 15)) == 0) {
+    // narrow INPUT (the data gradients of the 1- / 7-channel output convs): fp32 source of < 16 channels, any pixel stride
+    const bool nin = a->c0 < 16 && a->c1 == 0 && !src16 && !a->pre_scale && !a->pre_relu && !a->bstat_c && full16 && ((uintptr_t)a->src0 & 3) == 0;
+    if (opt != 0 && k16_wgs >= 8 && a->ksize == 3 && (full16 || narrow) && (a->c0 == 16 || nin) && a->c1 == 0 && (W & 63) == 0 && (H & 3) == 0 &&
+        !a->pixelshuffle2 && !a->res2 && !a->post_lrelu && (nin || (p.ld0 & 3) == 0) &&
+        (!a->res1 || (a->res1_ld & 3) == 0) && (nin || ((uintptr_t)a->src0 & (src16 ? 7 : 15)) == 0) && ((uintptr_t)a->res1 & (r16 ? 7 : 15)) == 0) {
         count_path(PATH_HCONV16);
         p.tiles_x = W / 64;
         p.tiles_per_img = p.tiles_x * (H / 4);
@@ -802,6 +804,12 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
             SRBH_HIP(hipGetLastError());
             return SRBH_OK;
         }
+        if (nin) {
+#define SRBH_K16_NIN(O_, I_) hipLaunchKernelGGL((hconv16_kernel<O_, 0, I_, 0, 1>), dim3(per_xcd * 8), dim3(256), LDS16, st, p)
+            if (opt == 1) { switch (io) { case 0: SRBH_K16_NIN(1, 0); break; case 1: SRBH_K16_NIN(1, 1); break; case 2: SRBH_K16_NIN(1, 2); break; default: SRBH_K16_NIN(1, 3); } }
+            else { switch (io) { case 0: SRBH_K16_NIN(2, 0); break; case 1: SRBH_K16_NIN(2, 1); break; case 2: SRBH_K16_NIN(2, 2); break; default: SRBH_K16_NIN(2, 3); } }
+#undef SRBH_K16_NIN
+        } else
         if (opt == 1 && !src16) SRBH_K16_IO(1, 0);
         else if (opt == 1) SRBH_K16_IO(1, 1);
         else if (!src16) SRBH_K16_IO(2, 0);

@@ -319,3 +319,31 @@ def test_relu_bit_pattern_equals_the_fp32_reference_in_the_backward_reduce(C, sh
     # the sums go through atomics (order-dependent last bits), and dc carries their means: close, not identical
     assert torch.allclose(dg0, dg1, rtol=1e-4, atol=1e-5) and torch.allclose(db0, db1, rtol=1e-4, atol=1e-5)
     assert dc0.dtype == dc1.dtype and torch.allclose(dc0.float(), dc1.float(), rtol=2e-2 if b16 else 1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cout_fwd", [7, 1, 12])
+def test_narrow_input_data_gradient_on_the_persistent_kernel(cout_fwd):
+    """The data gradients of the 1- / 7-channel output convs (conv_last of the two fuse heads, SR/HRfuse.py:188-189: dX = conv^T(dY[7], W))
+    on the persistent 16 -> 16 kernel's narrow-input form (round 4; they ran the template at 0.2 of the HBM roofline): bf16 operands against
+    a float64 transposed convolution of the same rounded operands, with a skip gradient added, and the form is COUNTED as hconv16."""
+    import torch.nn.functional as F
+    from srbh_amd import _lib
+    from srbh_amd import hrfuse as H
+    from srbh_amd import hrfuse_autograd as HA
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(cout_fwd)
+    conv = torch.nn.Conv2d(16, cout_fwd, 3, 1, 1).to(dev)
+    dy = (torch.randn((2, cout_fwd, 8, 128), generator=g) * 1e-3).to(dev).contiguous(memory_format=torch.channels_last)
+    res = torch.randn((2, 16, 8, 128), generator=g).to(dev).contiguous(memory_format=torch.channels_last) * 1e-3
+    with H.head_precision("f16"), torch.no_grad():
+        _lib.path_counters(reset=True)
+        dx = HA.conv_dgrad(dy, conv.weight, HA._PackedGrad())
+        dxr = HA.conv_dgrad(dy, conv.weight, HA._PackedGrad(), res=res)
+        c = _lib.path_counters(reset=True)
+    assert c["hconv16"] == 2 and c["hconv_template"] == 0, c
+    b = lambda t: t.detach().bfloat16().double()             # noqa: E731
+    want = F.conv_transpose2d(b(dy), b(conv.weight), None, 1, 1)
+    rel = lambda a, w: float((a.double() - w).norm() / w.norm())      # noqa: E731
+    assert rel(dx, want) <= 2e-6
+    assert rel(dxr, want + res.double()) <= 2e-6
