@@ -536,6 +536,32 @@ int srbh_height_metric_sums(const float* pred, const float* ref, const long long
 int srbh_confusion_add(const long long* pred, const long long* label, long n, int num_class,
                        unsigned long long* cm, int* bad_flag, void* stream);
 
+/* ---- The middle of an MBConv block in ONE launch per direction (round 4; efficientnet_pytorch MBConvBlock.forward between the expand and
+ * the project conv, run by smp's encoder at mymodels.py:276): BatchNorm0 (training) + SiLU -> depthwise KxK, stride 1, "same" zero padding ->
+ * BatchNorm1 (training) + SiLU (+ the plane means squeeze-and-excitation pools).  fp32 NCHW, square planes 2x2 / 4x4 / 8x8, K = 3 | 5.
+ * forward: reads e_pre (the expand conv's output), writes d_pre (the depthwise output, kept for the backward), y and pooled, both
+ * BatchNorms' batch statistics and running statistics.  backward: dout = gradient of y * gate (the excite gate [B][C]), dpooled = gradient
+ * of the plane means [B][C]; writes de_pre (may be NULL), the depthwise weight gradient [C][K][K] and the four affine gradients. */
+typedef struct srbh_mbmid_args {
+    const float* e_pre; const float* wdw;
+    const float* gamma0; const float* beta0; float* running_mean0; float* running_var0; float* mean0; float* invstd0;
+    const float* gamma1; const float* beta1; float* running_mean1; float* running_var1; float* mean1; float* invstd1;
+    float* d_pre; float* y; float* pooled;
+    float momentum0, eps0, momentum1, eps1;
+    int B, C, H, W, K;
+} srbh_mbmid_args;
+typedef struct srbh_mbmid_bwd_args {
+    const float* dout; const float* gate; const float* dpooled;
+    const float* d_pre; const float* e_pre; const float* wdw;
+    const float* gamma0; const float* beta0; const float* mean0; const float* invstd0;
+    const float* gamma1; const float* beta1; const float* mean1; const float* invstd1;
+    float* de_pre; float* dwdw; float* dgamma0; float* dbeta0; float* dgamma1; float* dbeta1;
+    int B, C, H, W, K;
+} srbh_mbmid_bwd_args;
+int srbh_mbconv_mid_supported(int B, int C, int H, int W, int K, int stride);
+int srbh_mbconv_mid_fwd(const srbh_mbmid_args* a, void* stream);
+int srbh_mbconv_mid_bwd(const srbh_mbmid_bwd_args* a, void* stream);
+
 /* ---- 3x3 convolutions of the two U-Net decoders (mymodels.py:245-258 builds them, :279 / :287 call them; smp UnetDecoder blocks:
  * nearest x2 -> concat skip -> [Conv3x3 (no bias) + BatchNorm + ReLU] x 2) on NCHW fp32 tensors, square planes 4x4 ... 64x64, 16-bit
  * matrix-core operands, fp32 accumulation (csrc/srbh_dconv.hip).  Weights: srbh_hpack_conv_h16(w, Cout, Cin, 3, transpose_flip, bf16, ...).

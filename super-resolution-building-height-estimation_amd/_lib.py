@@ -119,6 +119,18 @@ class BnActArgs(C.Structure):
     ]
 
 
+class MbMidArgs(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("e_pre", "wdw", "gamma0", "beta0", "running_mean0", "running_var0", "mean0", "invstd0",
+                                           "gamma1", "beta1", "running_mean1", "running_var1", "mean1", "invstd1", "d_pre", "y", "pooled")]
+                + [(n, C.c_float) for n in ("momentum0", "eps0", "momentum1", "eps1")] + [(n, C.c_int) for n in ("B", "C", "H", "W", "K")])
+
+
+class MbMidBwdArgs(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("dout", "gate", "dpooled", "d_pre", "e_pre", "wdw", "gamma0", "beta0", "mean0", "invstd0",
+                                           "gamma1", "beta1", "mean1", "invstd1", "de_pre", "dwdw", "dgamma0", "dbeta0", "dgamma1", "dbeta1")]
+                + [(n, C.c_int) for n in ("B", "C", "H", "W", "K")])
+
+
 class BnActBwdArgs(C.Structure):
     _fields_ = [
         ("dy", C.c_void_p), ("x", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
@@ -207,6 +219,9 @@ SIGNATURES = {
     "srbh_se_train_bwd_ws_floats": (_sz, [_i, _i, _i]),
     "srbh_up2_cat_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "srbh_up2_cat_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "srbh_mbconv_mid_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "srbh_mbconv_mid_fwd": (_i, [C.POINTER(MbMidArgs), _vp]),
+    "srbh_mbconv_mid_bwd": (_i, [C.POINTER(MbMidBwdArgs), _vp]),
     "srbh_dconv_pack_many": (_i, [_vp, _i, _vp]),
     "srbh_dconv_supported": (_i, [_i, _i, _i, _i, _i]),
     "srbh_dconv_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -263,6 +263,266 @@ __global__ __launch_bounds__(64 * NW) void bn_act_train_bwd_kernel(const BwdP p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The MIDDLE of an MBConv block as ONE launch per direction (round 4; efficientnet_pytorch MBConvBlock.forward between the expand and
+// the project conv, as smp's encoder runs it at mymodels.py:276): BatchNorm0 + SiLU -> depthwise KxK (stride 1, "same" padding) ->
+// BatchNorm1 + SiLU (+ the plane means squeeze-excite pools).  Everything in there is per CHANNEL, and in the geometry above a workgroup
+// holds ALL B images of its channels in LDS -- so the three launches of the forward (bn_act, depthwise, bn_act + pool) and the four of
+// the backward (bn_act backward with the excite gate, depthwise data and weight gradient, bn_act backward) need nothing from another
+// workgroup: one read of the expand conv's output, one write each of the depthwise output (kept for the backward) and of y; the
+// backward reads both back, recomputes SiLU(bn0(.)) instead of keeping it, and writes only the gradient of the expand conv's output.
+// Planes of 2x2, 4x4 and 8x8 (blocks 6..31 of EfficientNet-B4 at 64x64 tiles, without the three stride-2 blocks).
+struct MidFwdP {
+    const float* e_pre; const float* wdw;
+    const float* g0; const float* b0; float* rm0; float* rv0; float* mean0; float* invstd0;
+    const float* g1; const float* b1; float* rm1; float* rv1; float* mean1; float* invstd1;
+    float* d_pre; float* y; float* pooled;
+    float mom0, eps0, mom1, eps1;
+    int B, C, HW, logw;
+};
+
+// two-pass statistics of this thread's channel over cache[b][lane], b = wave, wave + NW, ... (as bn_act_train_fwd_kernel)
+__device__ __forceinline__ void channel_stats(const float* cache, int B, float s, float invN, float eps, int seg, int slot, float (*red)[64],
+                                              int wave, int lane, float& mean, float& var, float& invstd) {
+    mean = channel_sum(s, seg, slot, red, wave, lane) * invN;
+    float q = 0.f;
+    for (int b = wave; b < B; b += NW) {
+        const float v = cache[b * 64 + lane];
+        q = fmaf(v - mean, v - mean, q);
+    }
+    var = channel_sum(q, seg, slot, red, wave, lane) * invN;
+    invstd = 1.f / sqrtf(var + eps);
+}
+
+template <int K>
+__global__ __launch_bounds__(64 * NW) void mbconv_mid_fwd_kernel(const MidFwdP p) {
+    extern __shared__ __attribute__((aligned(16))) float cache[];      // [B][64] e_pre -> SiLU(bn0) | [B][64] depthwise output
+    __shared__ float red[NW][64];
+    constexpr int R = K / 2, KK = K * K;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int HW = p.HW, W = 1 << p.logw;
+    const int seg = HW >= 64 ? 64 : HW;
+    const int slot = lane / HW, pos = lane & (HW - 1), py = pos >> p.logw, px = pos & (W - 1);
+    const int c0 = blockIdx.x * (64 / HW), c = c0 + slot;
+    const bool cok = c < p.C;
+    const float invN = 1.f / ((float)p.B * (float)HW), n = (float)p.B * (float)HW;
+    const long off = (long)c0 * HW + lane, bstride = (long)p.C * HW;
+    float* const dch = cache + p.B * 64;
+    const float g0 = cok ? p.g0[c] : 0.f, b0 = cok ? p.b0[c] : 0.f, g1 = cok ? p.g1[c] : 0.f, b1 = cok ? p.b1[c] : 0.f;
+    const float rm0 = cok ? p.rm0[c] : 0.f, rv0 = cok ? p.rv0[c] : 0.f, rm1 = cok ? p.rm1[c] : 0.f, rv1 = cok ? p.rv1[c] : 0.f;
+    float wk[KK];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) wk[k] = cok ? p.wdw[(long)c * KK + k] : 0.f;
+    // ---- BatchNorm0: statistics of the expand conv's output
+    float s = 0.f;
+    for (int b0i = wave; b0i < p.B; b0i += NW * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0i + NW * u;
+            v[u] = (cok && b < p.B) ? p.e_pre[b * bstride + off] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0i + NW * u;
+            if (b < p.B) cache[b * 64 + lane] = v[u];
+            s += v[u];
+        }
+    }
+    float mean, var, invstd;
+    channel_stats(cache, p.B, s, invN, p.eps0, seg, slot, red, wave, lane, mean, var, invstd);
+    if (cok && wave == 0 && pos == 0) {
+        p.mean0[c] = mean;
+        p.invstd0[c] = invstd;
+        p.rm0[c] = (1.f - p.mom0) * rm0 + p.mom0 * mean;
+        p.rv0[c] = (1.f - p.mom0) * rv0 + p.mom0 * (n > 1.f ? var * n / (n - 1.f) : var);
+    }
+    {
+        const float sc = g0 * invstd, sh = b0 - mean * sc;
+        for (int b = wave; b < p.B; b += NW) cache[b * 64 + lane] = cok ? act_f<1>(fmaf(cache[b * 64 + lane], sc, sh)) : 0.f;
+    }
+    __syncthreads();
+    // ---- depthwise K x K, stride 1, zero padding R: neighbours of this lane's pixel inside its own plane
+    s = 0.f;
+    for (int b = wave; b < p.B; b += NW) {
+        const float* pl = cache + b * 64 + slot * HW;
+        float acc = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < K; ++dy) {
+            const int yy = py + dy - R;
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) {
+                const int xx = px + dx - R;
+                if ((unsigned)yy < (unsigned)W && (unsigned)xx < (unsigned)W) acc = fmaf(wk[dy * K + dx], pl[(yy << p.logw) + xx], acc);
+            }
+        }
+        dch[b * 64 + lane] = acc;
+        if (cok) p.d_pre[b * bstride + off] = acc;
+        s += acc;
+    }
+    // ---- BatchNorm1 + SiLU + plane means
+    channel_stats(dch, p.B, s, invN, p.eps1, seg, slot, red, wave, lane, mean, var, invstd);
+    if (cok && wave == 0 && pos == 0) {
+        p.mean1[c] = mean;
+        p.invstd1[c] = invstd;
+        p.rm1[c] = (1.f - p.mom1) * rm1 + p.mom1 * mean;
+        p.rv1[c] = (1.f - p.mom1) * rv1 + p.mom1 * (n > 1.f ? var * n / (n - 1.f) : var);
+    }
+    const float sc1 = g1 * invstd, sh1 = b1 - mean * sc1, invHW = 1.f / (float)HW;
+    for (int b = wave; b < p.B; b += NW) {
+        const float v = act_f<1>(fmaf(dch[b * 64 + lane], sc1, sh1));
+        if (cok) p.y[b * bstride + off] = v;
+        float w = v;
+        for (int o = 1; o < seg; o <<= 1) w += __shfl_xor(w, o, 64);
+        if (cok && pos == 0) p.pooled[(long)b * p.C + c] = w * invHW;
+    }
+}
+
+struct MidBwdP {
+    const float* dout; const float* gate; const float* dpooled;      // gradient of y * gate; excite gate [B][C]; gradient of the plane means [B][C]
+    const float* d_pre; const float* e_pre; const float* wdw;
+    const float* g0; const float* b0; const float* mean0; const float* invstd0;
+    const float* g1; const float* b1; const float* mean1; const float* invstd1;
+    float* de_pre; float* dwdw; float* dg0; float* db0; float* dg1; float* db1;
+    int B, C, HW, logw;
+};
+
+template <int K>
+__global__ __launch_bounds__(64 * NW) void mbconv_mid_bwd_kernel(const MidBwdP p) {
+    extern __shared__ __attribute__((aligned(16))) float cache[];      // A: dz1 -> dd_pre | Bc: xhat1 -> SiLU(bn0) -> dz0 | Cc: xhat0
+    __shared__ float red[NW][64];
+    __shared__ float redw[NW][K * K][16];
+    constexpr int R = K / 2, KK = K * K;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int HW = p.HW, W = 1 << p.logw;
+    const int seg = HW >= 64 ? 64 : HW;
+    const int slot = lane / HW, pos = lane & (HW - 1), py = pos >> p.logw, px = pos & (W - 1);
+    const int cpw = 64 / HW, c0 = blockIdx.x * cpw, c = c0 + slot;
+    const bool cok = c < p.C;
+    const float invN = 1.f / ((float)p.B * (float)HW), invHW = 1.f / (float)HW;
+    const long off = (long)c0 * HW + lane, bstride = (long)p.C * HW;
+    float* const A = cache;
+    float* const Bc = cache + p.B * 64;
+    float* const Cc = cache + 2 * p.B * 64;
+    const float g0 = cok ? p.g0[c] : 0.f, b0 = cok ? p.b0[c] : 0.f, g1 = cok ? p.g1[c] : 0.f, b1 = cok ? p.b1[c] : 0.f;
+    const float m0 = cok ? p.mean0[c] : 0.f, i0 = cok ? p.invstd0[c] : 0.f, m1 = cok ? p.mean1[c] : 0.f, i1 = cok ? p.invstd1[c] : 0.f;
+    float wk[KK];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) wk[k] = cok ? p.wdw[(long)c * KK + k] : 0.f;
+    // ---- BatchNorm1 backward through SiLU and the excite gate (bn_act_train_bwd_kernel<1> with gate / dpooled)
+    float s1 = 0.f, s2 = 0.f;
+    for (int b0i = wave; b0i < p.B; b0i += NW * U) {
+        float xv[U], dv[U], ev[U], gt[U], dpo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0i + NW * u;
+            const bool ok = cok && b < p.B;
+            xv[u] = ok ? p.d_pre[b * bstride + off] : 0.f;
+            dv[u] = ok ? p.dout[b * bstride + off] : 0.f;
+            ev[u] = ok ? p.e_pre[b * bstride + off] : 0.f;
+            gt[u] = ok ? p.gate[(long)b * p.C + c] : 1.f;
+            dpo[u] = ok ? p.dpooled[(long)b * p.C + c] * invHW : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0i + NW * u;
+            if (b >= p.B) continue;
+            const float xh = (xv[u] - m1) * i1;
+            const float dz = cok ? fmaf(dv[u], gt[u], dpo[u]) * act_grad<1>(fmaf(xh, g1, b1)) : 0.f;
+            s2 = fmaf(dz, xh, s2);
+            s1 += dz;
+            A[b * 64 + lane] = dz;
+            Bc[b * 64 + lane] = xh;
+            Cc[b * 64 + lane] = (ev[u] - m0) * i0;                 // xhat0 (the depthwise conv's input is SiLU(xhat0 g0 + b0))
+        }
+    }
+    float sum_dz = channel_sum(s1, seg, slot, red, wave, lane);
+    float sum_dzx = channel_sum(s2, seg, slot, red, wave, lane);
+    if (cok && wave == 0 && pos == 0) {
+        p.db1[c] = sum_dz;
+        p.dg1[c] = sum_dzx;
+    }
+    {
+        const float k1 = sum_dz * invN, k2 = sum_dzx * invN, gi = g1 * i1;
+        for (int b = wave; b < p.B; b += NW) {
+            const float dd = cok ? gi * (A[b * 64 + lane] - k1 - Bc[b * 64 + lane] * k2) : 0.f;     // gradient of the depthwise output
+            A[b * 64 + lane] = dd;
+            Bc[b * 64 + lane] = cok ? act_f<1>(fmaf(Cc[b * 64 + lane], g0, b0)) : 0.f;              // the depthwise input, recomputed
+        }
+    }
+    __syncthreads();
+    // ---- depthwise weight gradient: dw[c][tap] = sum over (b, p) of dd[b][c][p] * in[b][c][p + tap]
+    {
+        float pw[KK];
+#pragma unroll
+        for (int k = 0; k < KK; ++k) pw[k] = 0.f;
+        for (int b = wave; b < p.B; b += NW) {
+            const float dd = A[b * 64 + lane];
+            const float* pl = Bc + b * 64 + slot * HW;
+#pragma unroll
+            for (int dy = 0; dy < K; ++dy) {
+                const int yy = py + dy - R;
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx) {
+                    const int xx = px + dx - R;
+                    if ((unsigned)yy < (unsigned)W && (unsigned)xx < (unsigned)W) pw[dy * K + dx] = fmaf(dd, pl[(yy << p.logw) + xx], pw[dy * K + dx]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            float v = pw[k];
+            for (int o = 1; o < seg; o <<= 1) v += __shfl_xor(v, o, 64);
+            if (pos == 0) redw[wave][k][slot] = v;
+        }
+        __syncthreads();
+        for (int u = t; u < KK * cpw; u += 64 * NW) {
+            const int k = u / cpw, sl = u - k * cpw;
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; w += 2) {
+                a += redw[w][k][sl];
+                b += redw[w + 1][k][sl];
+            }
+            if (c0 + sl < p.C) p.dwdw[(long)(c0 + sl) * KK + k] = a + b;
+        }
+    }
+    // ---- depthwise data gradient, then BatchNorm0 backward through SiLU
+    s1 = 0.f;
+    s2 = 0.f;
+    __syncthreads();              // (Bc is overwritten below: every wave is past the weight gradient's reads)
+    for (int b = wave; b < p.B; b += NW) {
+        const float* pl = A + b * 64 + slot * HW;
+        float acc = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < K; ++dy) {
+            const int yy = py - dy + R;
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) {
+                const int xx = px - dx + R;
+                if ((unsigned)yy < (unsigned)W && (unsigned)xx < (unsigned)W) acc = fmaf(wk[dy * K + dx], pl[(yy << p.logw) + xx], acc);
+            }
+        }
+        const float xh = Cc[b * 64 + lane];
+        const float dz = cok ? acc * act_grad<1>(fmaf(xh, g0, b0)) : 0.f;
+        s2 = fmaf(dz, xh, s2);
+        s1 += dz;
+        Bc[b * 64 + lane] = dz;          // (own element)
+    }
+    sum_dz = channel_sum(s1, seg, slot, red, wave, lane);
+    sum_dzx = channel_sum(s2, seg, slot, red, wave, lane);
+    if (cok && wave == 0 && pos == 0) {
+        p.db0[c] = sum_dz;
+        p.dg0[c] = sum_dzx;
+    }
+    if (!p.de_pre) return;
+    {
+        const float k1 = sum_dz * invN, k2 = sum_dzx * invN, gi = g0 * i0;
+        for (int b = wave; b < p.B; b += NW)
+            if (cok) p.de_pre[b * bstride + off] = gi * (Bc[b * 64 + lane] - k1 - Cc[b * 64 + lane] * k2);
+    }
+}
+
 // squeeze-excite backward, step 1: draw[b][c] = sum over the plane of dout * y, y = act(bn(x)) recomputed from the saved conv output
 // (the forward scaled y in place, it is not kept).  Planes are contiguous, so a wave takes 64 consecutive elements = 64 / hw whole
 // planes when hw < 64 (a wave per 4-element plane would be 172 k nearly empty waves at 2x2), else one plane per wave.
@@ -720,6 +980,65 @@ int se_chunks(int C) {                      // channel chunks of the squeeze-exc
 int row_width(int HW) { return HW == 256 ? 256 : ((HW == 64 || HW == 16 || HW == 4 || HW == 1) ? 64 : 0); }
 size_t fwd_lds(int B, int RW) { return (size_t)B * RW * 4; }
 }  // namespace
+
+static int mid_logw(int H, int W) { return (H == W && (W == 2 || W == 4 || W == 8)) ? (W == 2 ? 1 : W == 4 ? 2 : 3) : -1; }
+
+/* 1 when the fused MBConv middle kernels take the shape: square planes of 2x2, 4x4 or 8x8, depthwise kernel 3 or 5 with stride 1, and
+ * three copies of the workgroup's B x 64-float run within LDS */
+extern "C" int srbh_mbconv_mid_supported(int B, int C, int H, int W, int K, int stride) {
+    return B > 0 && C > 0 && mid_logw(H, W) > 0 && (K == 3 || K == 5) && stride == 1 && (size_t)3 * B * 64 * 4 <= (size_t)MAX_LDS_B - 32 * 1024;
+}
+
+extern "C" int srbh_mbconv_mid_fwd(const srbh_mbmid_args* a, void* stream) {
+    SRBH_REQUIRE(a && a->e_pre && a->wdw && a->gamma0 && a->beta0 && a->gamma1 && a->beta1 && a->running_mean0 && a->running_var0 &&
+                 a->running_mean1 && a->running_var1 && a->mean0 && a->invstd0 && a->mean1 && a->invstd1 && a->d_pre && a->y && a->pooled,
+                 "srbh_mbconv_mid_fwd: null pointer");
+    SRBH_REQUIRE(srbh_mbconv_mid_supported(a->B, a->C, a->H, a->W, a->K, 1), "srbh_mbconv_mid_fwd: unsupported shape B=%d C=%d %dx%d k%d", a->B, a->C, a->H, a->W, a->K);
+    MidFwdP p;
+    p.e_pre = a->e_pre; p.wdw = a->wdw;
+    p.g0 = a->gamma0; p.b0 = a->beta0; p.rm0 = a->running_mean0; p.rv0 = a->running_var0; p.mean0 = a->mean0; p.invstd0 = a->invstd0;
+    p.g1 = a->gamma1; p.b1 = a->beta1; p.rm1 = a->running_mean1; p.rv1 = a->running_var1; p.mean1 = a->mean1; p.invstd1 = a->invstd1;
+    p.d_pre = a->d_pre; p.y = a->y; p.pooled = a->pooled;
+    p.mom0 = a->momentum0; p.eps0 = a->eps0; p.mom1 = a->momentum1; p.eps1 = a->eps1;
+    p.B = a->B; p.C = a->C; p.HW = a->H * a->W; p.logw = mid_logw(a->H, a->W);
+    const int cpw = 64 / p.HW;
+    const size_t lds = (size_t)2 * p.B * 64 * 4;
+    const dim3 grid((p.C + cpw - 1) / cpw);
+    if (a->K == 3) {
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)mbconv_mid_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_B - 32 * 1024)));
+        hipLaunchKernelGGL(mbconv_mid_fwd_kernel<3>, grid, dim3(64 * NW), lds, (hipStream_t)stream, p);
+    } else {
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)mbconv_mid_fwd_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_B - 32 * 1024)));
+        hipLaunchKernelGGL(mbconv_mid_fwd_kernel<5>, grid, dim3(64 * NW), lds, (hipStream_t)stream, p);
+    }
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_mbconv_mid_bwd(const srbh_mbmid_bwd_args* a, void* stream) {
+    SRBH_REQUIRE(a && a->dout && a->gate && a->dpooled && a->d_pre && a->e_pre && a->wdw && a->gamma0 && a->beta0 && a->mean0 && a->invstd0 &&
+                 a->gamma1 && a->beta1 && a->mean1 && a->invstd1 && a->dwdw && a->dgamma0 && a->dbeta0 && a->dgamma1 && a->dbeta1,
+                 "srbh_mbconv_mid_bwd: null pointer");
+    SRBH_REQUIRE(srbh_mbconv_mid_supported(a->B, a->C, a->H, a->W, a->K, 1), "srbh_mbconv_mid_bwd: unsupported shape B=%d C=%d %dx%d k%d", a->B, a->C, a->H, a->W, a->K);
+    MidBwdP p;
+    p.dout = a->dout; p.gate = a->gate; p.dpooled = a->dpooled; p.d_pre = a->d_pre; p.e_pre = a->e_pre; p.wdw = a->wdw;
+    p.g0 = a->gamma0; p.b0 = a->beta0; p.mean0 = a->mean0; p.invstd0 = a->invstd0;
+    p.g1 = a->gamma1; p.b1 = a->beta1; p.mean1 = a->mean1; p.invstd1 = a->invstd1;
+    p.de_pre = a->de_pre; p.dwdw = a->dwdw; p.dg0 = a->dgamma0; p.db0 = a->dbeta0; p.dg1 = a->dgamma1; p.db1 = a->dbeta1;
+    p.B = a->B; p.C = a->C; p.HW = a->H * a->W; p.logw = mid_logw(a->H, a->W);
+    const int cpw = 64 / p.HW;
+    const size_t lds = (size_t)3 * p.B * 64 * 4;
+    const dim3 grid((p.C + cpw - 1) / cpw);
+    if (a->K == 3) {
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)mbconv_mid_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_B - 32 * 1024)));
+        hipLaunchKernelGGL(mbconv_mid_bwd_kernel<3>, grid, dim3(64 * NW), lds, (hipStream_t)stream, p);
+    } else {
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)mbconv_mid_bwd_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, MAX_LDS_B - 32 * 1024)));
+        hipLaunchKernelGGL(mbconv_mid_bwd_kernel<5>, grid, dim3(64 * NW), lds, (hipStream_t)stream, p);
+    }
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
 
 extern "C" int srbh_bn_act_train_supported(int B, int C, int HW) {
     const int RW = row_width(HW);

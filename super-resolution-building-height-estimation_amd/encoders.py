@@ -376,7 +376,16 @@ class MBConvBlock(nn.Module):
 
     def forward(self, x, drop_connect_rate=None, drop_mask=None):
         inputs = x
-        if self.expand != 1:
+        if self.expand != 1 and x.is_cuda and self._bn0.training:
+            e_pre = self._expand_conv(x)
+            MBm = _mbconv_train(self._bn0, e_pre)
+            if (MBm is not None and MBm.se_supported(self._se_reduce, self._se_expand)
+                    and MBm.mid_supported(self._bn0, self._bn1, self._depthwise_conv, e_pre)):
+                # the block's middle as one libsrbh launch per direction (+ squeeze-excite's small kernels): csrc/srbh_mbconv.hip
+                x = MBm.mid_se_train(self._bn0, e_pre, self._depthwise_conv, self._bn1, self._se_reduce, self._se_expand)
+                return self._tail(x, inputs, drop_connect_rate, drop_mask)
+            x = bn_act(self._bn0, e_pre, "silu")
+        elif self.expand != 1:
             x = bn_act(self._bn0, self._expand_conv(x), "silu")
         x = self._depthwise_conv(x)
         MB = _mbconv_train(self._bn1, x)
@@ -390,6 +399,9 @@ class MBConvBlock(nn.Module):
             s = F.adaptive_avg_pool2d(x, 1)
             s = self._se_expand(_swish(self._se_reduce(s)))
             x = torch.sigmoid(s) * x
+        return self._tail(x, inputs, drop_connect_rate, drop_mask)
+
+    def _tail(self, x, inputs, drop_connect_rate, drop_mask):
         skip = self.stride == 1 and self.inp == self.out
         if skip and not (self.training and drop_connect_rate):
             return bn_act(self._bn2, self._project_conv(x), res=inputs)      # inference: BatchNorm + skip connection in one pass

@@ -146,6 +146,99 @@ class _BnSwishSEFn(torch.autograd.Function):
         return dx, dgamma, dbeta, dw1, db1, dw2, db2, None
 
 
+MID_FUSED = os.environ.get("SRBH_MBCONV_MID", "1") == "1"
+
+
+def mid_supported(bn0, bn1, dw, x) -> bool:
+    """the fused MBConv middle (BatchNorm0 + SiLU -> depthwise -> BatchNorm1 + SiLU + pool, one launch each way) takes this block"""
+    if not (MID_FUSED and supported(bn0, x) and type(bn1) is nn.BatchNorm2d and bn1.training and bn1.affine and bn1.track_running_stats
+            and bn1.momentum is not None and getattr(dw, "_depthwise", False) and dw.weight.dtype == torch.float32):
+        return False
+    B, Cc, H, W = x.shape
+    pl, pr, pt, pb = dw._pad
+    K = dw.weight.shape[-1]
+    return (dw.stride[0] == 1 and pl == pr == pt == pb == K // 2 and bn1.num_features == Cc
+            and bool(_lib.lib().srbh_mbconv_mid_supported(B, Cc, H, W, K, 1)))
+
+
+class _MidSEFn(torch.autograd.Function):
+    """BatchNorm0 + SiLU -> depthwise conv -> BatchNorm1 + SiLU -> squeeze-and-excitation of one MBConv block (efficientnet_pytorch
+    MBConvBlock.forward): srbh_mbconv_mid_fwd + srbh_se_train_fwd forward, srbh_se_train_bwd + srbh_mbconv_mid_bwd backward -- the
+    separate Functions ran bn_act, depthwise, bn_act + pool, squeeze-excite (4 + 2 launches) and their backwards (4 + ~5)."""
+
+    @staticmethod
+    def forward(ctx, e_pre, g0, b0, wdw, g1, b1, w1, bb1, w2, bb2, bn0, bn1):
+        e_pre = e_pre.contiguous()
+        wdw = wdw.contiguous()
+        B, Cc, H, W = e_pre.shape
+        SQ = w1.shape[0]
+        K = wdw.shape[-1]
+        dev = e_pre.device
+        d_pre = torch.empty_like(e_pre)
+        y = torch.empty_like(e_pre)
+        stats = torch.empty(4 * Cc, dtype=torch.float32, device=dev)           # mean0 | invstd0 | mean1 | invstd1
+        small = torch.empty(2 * B * Cc + 2 * B * SQ, dtype=torch.float32, device=dev)     # pooled | gate | hidden | hidden_pre
+        pooled, gate = small[:B * Cc], small[B * Cc:2 * B * Cc]
+        hidden, hidden_pre = small[2 * B * Cc:2 * B * Cc + B * SQ], small[2 * B * Cc + B * SQ:]
+        sp = stats.data_ptr()
+        a = _lib.MbMidArgs(e_pre=e_pre.data_ptr(), wdw=wdw.data_ptr(), gamma0=g0.data_ptr(), beta0=b0.data_ptr(),
+                           running_mean0=bn0.running_mean.data_ptr(), running_var0=bn0.running_var.data_ptr(), mean0=sp, invstd0=sp + 4 * Cc,
+                           gamma1=g1.data_ptr(), beta1=b1.data_ptr(), running_mean1=bn1.running_mean.data_ptr(),
+                           running_var1=bn1.running_var.data_ptr(), mean1=sp + 8 * Cc, invstd1=sp + 12 * Cc, d_pre=d_pre.data_ptr(),
+                           y=y.data_ptr(), pooled=pooled.data_ptr(), momentum0=float(bn0.momentum), eps0=float(bn0.eps),
+                           momentum1=float(bn1.momentum), eps1=float(bn1.eps), B=B, C=Cc, H=H, W=W, K=K)
+        L = _lib.lib()
+        _lib.check(L.srbh_mbconv_mid_fwd(C.byref(a), _lib.stream_ptr()), "mbconv_mid_fwd")
+        _lib.check(L.srbh_se_train_fwd(y.data_ptr(), pooled.data_ptr(), w1.data_ptr(), bb1.data_ptr(), w2.data_ptr(), bb2.data_ptr(),
+                                       hidden.data_ptr(), hidden_pre.data_ptr(), gate.data_ptr(), B, Cc, SQ, H * W, _lib.stream_ptr()), "se_train_fwd")
+        ctx.save_for_backward(e_pre, d_pre, g0, b0, wdw, g1, b1, stats, small, w1, w2)
+        ctx.geo = (B, Cc, SQ, H, W, K)
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        e_pre, d_pre, g0, b0, wdw, g1, b1, stats, small, w1, w2 = ctx.saved_tensors
+        B, Cc, SQ, H, W, K = ctx.geo
+        HW = H * W
+        dev = e_pre.device
+        dout = dout.contiguous()
+        mean0, invstd0, mean1, invstd1 = stats[:Cc], stats[Cc:2 * Cc], stats[2 * Cc:3 * Cc], stats[3 * Cc:]
+        pooled, gate = small[:B * Cc], small[B * Cc:2 * B * Cc]
+        hidden, hidden_pre = small[2 * B * Cc:2 * B * Cc + B * SQ], small[2 * B * Cc + B * SQ:]
+        L = _lib.lib()
+        ws = torch.empty(L.srbh_se_train_bwd_ws_floats(B, Cc, SQ) + B * Cc, dtype=torch.float32, device=dev)
+        dpooled = ws[-B * Cc:]
+        dw1 = torch.empty_like(w1)
+        dw2 = torch.empty_like(w2)
+        db1 = torch.empty(SQ, dtype=torch.float32, device=dev)
+        db2 = torch.empty(Cc, dtype=torch.float32, device=dev)
+        _lib.check(L.srbh_se_train_bwd(dout.data_ptr(), d_pre.data_ptr(), g1.data_ptr(), b1.data_ptr(), mean1.data_ptr(), invstd1.data_ptr(),
+                                       pooled.data_ptr(), hidden.data_ptr(), hidden_pre.data_ptr(), gate.data_ptr(), w1.data_ptr(),
+                                       w2.data_ptr(), ws.data_ptr(), dpooled.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
+                                       db2.data_ptr(), B, Cc, SQ, HW, 1, _lib.stream_ptr()), "se_train_bwd")
+        de = torch.empty_like(e_pre) if ctx.needs_input_grad[0] else None
+        dwdw = torch.empty_like(wdw)
+        aff = torch.empty(4 * Cc, dtype=torch.float32, device=dev)            # dgamma0 | dbeta0 | dgamma1 | dbeta1
+        ap = aff.data_ptr()
+        a = _lib.MbMidBwdArgs(dout=dout.data_ptr(), gate=gate.data_ptr(), dpooled=dpooled.data_ptr(), d_pre=d_pre.data_ptr(),
+                              e_pre=e_pre.data_ptr(), wdw=wdw.data_ptr(), gamma0=g0.data_ptr(), beta0=b0.data_ptr(), mean0=mean0.data_ptr(),
+                              invstd0=invstd0.data_ptr(), gamma1=g1.data_ptr(), beta1=b1.data_ptr(), mean1=mean1.data_ptr(),
+                              invstd1=invstd1.data_ptr(), de_pre=_ptr(de), dwdw=dwdw.data_ptr(), dgamma0=ap, dbeta0=ap + 4 * Cc,
+                              dgamma1=ap + 8 * Cc, dbeta1=ap + 12 * Cc, B=B, C=Cc, H=H, W=W, K=K)
+        _lib.check(L.srbh_mbconv_mid_bwd(C.byref(a), _lib.stream_ptr()), "mbconv_mid_bwd")
+        return (de, aff[:Cc], aff[Cc:2 * Cc], dwdw, aff[2 * Cc:3 * Cc], aff[3 * Cc:], dw1, db1, dw2, db2, None, None)
+
+
+def mid_se_train(bn0, e_pre, dw, bn1, se_reduce, se_expand):
+    """swish(bn0(e_pre)) -> depthwise conv -> swish(bn1(.)) -> squeeze-and-excitation, training mode, as two launches forward and two
+    backward (plus squeeze-excite's own small kernels)"""
+    y = _MidSEFn.apply(e_pre, bn0.weight, bn0.bias, dw.weight, bn1.weight, bn1.bias, se_reduce.weight, se_reduce.bias,
+                       se_expand.weight, se_expand.bias, bn0, bn1)
+    _note(bn0)
+    _note(bn1)
+    return y
+
+
 def bn_act_train(bn, x, act=None, res=None, drop=None):
     """y = act(batch_norm(x)) [* drop[b]] [+ res]; `drop`: contiguous (B,) factors or None"""
     y = _BnActFn.apply(x, bn.weight, bn.bias, res, drop, bn, _ACT[act])

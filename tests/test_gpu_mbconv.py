@@ -145,9 +145,16 @@ def test_encoder_and_decoder_training_step_agrees_with_the_stock_path(monkeypatc
         calls["n"] += 1
         return real(*a, **k)
     monkeypatch.setattr(MB, "_fwd", counting)
+    real_mid = MB.mid_se_train
+
+    def counting_mid(*a, **k):
+        calls["mid"] = calls.get("mid", 0) + 1
+        return real_mid(*a, **k)
+    monkeypatch.setattr(MB, "mid_se_train", counting_mid)
     out = dec(*enc(x))
     out.square().mean().backward()
-    assert calls["n"] >= 105                     # every BatchNorm of the encoder and the decoder
+    # every BatchNorm of the encoder and the decoder: one launch each, or two of them inside one fused MBConv middle (round 4)
+    assert calls["n"] + 2 * calls.get("mid", 0) >= 105 and calls.get("mid", 0) >= 20, calls
     monkeypatch.setattr(MB, "ENABLED", False)
     out2 = dec2(*enc2(x))
     out2.square().mean().backward()
@@ -234,3 +241,48 @@ def test_transpose_many_and_encoder_refresh():
     assert rel(y, F.conv2d(xi.double(), c.weight.detach().double())) <= 2e-6
     enc(x)
     assert torch.equal(c.__dict__["_srbh_wt"], c.weight.detach().view(c.weight.shape[0], -1).t())
+
+
+@pytest.mark.parametrize("B,inp,H,K", [(64, 28, 4, 3), (7, 40, 4, 5), (64, 68, 2, 5), (5, 20, 8, 3), (33, 14, 8, 5), (3, 112, 2, 3)])
+def test_fused_mbconv_middle_equals_the_separate_kernels(B, inp, H, K, monkeypatch):
+    """srbh_mbconv_mid_fwd / _bwd (round 4): BatchNorm0 + SiLU -> depthwise -> BatchNorm1 + SiLU + pool of an MBConv block as ONE launch per
+    direction, against the same block on the separate kernels (bn_act, depthwise, bn_act + pool: each already pinned against the stock
+    ops above): block output, every parameter gradient, the input gradient and both BatchNorms' running statistics."""
+    from srbh_amd import encoders as E
+    from srbh_amd import mbconv_autograd as MB
+    torch.manual_seed(B + inp + K)
+    blk = E.MBConvBlock(inp, inp, K, 1, 6, 64).to(DEV).train()
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    ref = copy.deepcopy(blk)
+    x0 = torch.randn(B, inp, H, H, device=DEV)
+    gy = torch.randn(B, inp, H, H, device=DEV)
+    outs = []
+    for fused, m in ((True, blk), (False, ref)):
+        monkeypatch.setattr(MB, "MID_FUSED", fused)
+        x = x0.clone().requires_grad_(True)
+        y = m(x)
+        names = {type(f).__name__ for f in _graph_fns(y.grad_fn)}
+        assert ("_MidSEFnBackward" in names) == fused, names
+        y.backward(gy)
+        outs.append((y.detach(), x.grad, {k: p.grad for k, p in m.named_parameters()}, {k: b.clone() for k, b in m.named_buffers()}))
+    (y1, gx1, g1, b1), (y0, gx0, g0, b0) = outs
+    assert rel(y1, y0) <= 2e-6 and rel(gx1, gx0) <= 2e-5
+    for k in g0:
+        assert rel(g1[k], g0[k]) <= 5e-5, k
+    for k in b0:
+        if b0[k].dtype.is_floating_point:
+            assert rel(b1[k], b0[k]) <= 1e-6, k
+
+
+def _graph_fns(fn, seen=None):
+    seen = set() if seen is None else seen
+    if fn is None or fn in seen:
+        return seen
+    seen.add(fn)
+    for nxt, _ in fn.next_functions:
+        _graph_fns(nxt, seen)
+    return seen
