@@ -349,9 +349,11 @@ __global__ __launch_bounds__(64 * NW) void mbconv_mid_fwd_kernel(const MidFwdP p
         float acc = 0.f;
 #pragma unroll
         for (int dy = 0; dy < K; ++dy) {
+            if (dy - R >= W || R - dy >= W) continue;       // (uniform: a tap further out than the plane is wide never lands inside it -- 16 of the 25 taps at 2x2)
             const int yy = py + dy - R;
 #pragma unroll
             for (int dx = 0; dx < K; ++dx) {
+                if (dx - R >= W || R - dx >= W) continue;
                 const int xx = px + dx - R;
                 if ((unsigned)yy < (unsigned)W && (unsigned)xx < (unsigned)W) acc = fmaf(wk[dy * K + dx], pl[(yy << p.logw) + xx], acc);
             }
@@ -461,9 +463,11 @@ __global__ __launch_bounds__(64 * NW) void mbconv_mid_bwd_kernel(const MidBwdP p
             const float* pl = Bc + b * 64 + slot * HW;
 #pragma unroll
             for (int dy = 0; dy < K; ++dy) {
+                if (dy - R >= W || R - dy >= W) continue;
                 const int yy = py + dy - R;
 #pragma unroll
                 for (int dx = 0; dx < K; ++dx) {
+                    if (dx - R >= W || R - dx >= W) continue;
                     const int xx = px + dx - R;
                     if ((unsigned)yy < (unsigned)W && (unsigned)xx < (unsigned)W) pw[dy * K + dx] = fmaf(dd, pl[(yy << p.logw) + xx], pw[dy * K + dx]);
                 }
@@ -472,7 +476,9 @@ __global__ __launch_bounds__(64 * NW) void mbconv_mid_bwd_kernel(const MidBwdP p
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
             float v = pw[k];
-            for (int o = 1; o < seg; o <<= 1) v += __shfl_xor(v, o, 64);
+            const int ty = k / K - R, tx = k % K - R;
+            if (ty < W && -ty < W && tx < W && -tx < W)          // (uniform; a tap that never lands inside the plane stays 0)
+                for (int o = 1; o < seg; o <<= 1) v += __shfl_xor(v, o, 64);
             if (pos == 0) redw[wave][k][slot] = v;
         }
         __syncthreads();
@@ -496,9 +502,11 @@ __global__ __launch_bounds__(64 * NW) void mbconv_mid_bwd_kernel(const MidBwdP p
         float acc = 0.f;
 #pragma unroll
         for (int dy = 0; dy < K; ++dy) {
+            if (dy - R >= W || R - dy >= W) continue;
             const int yy = py - dy + R;
 #pragma unroll
             for (int dx = 0; dx < K; ++dx) {
+                if (dx - R >= W || R - dx >= W) continue;
                 const int xx = px - dx + R;
                 if ((unsigned)yy < (unsigned)W && (unsigned)xx < (unsigned)W) acc = fmaf(wk[dy * K + dx], pl[(yy << p.logw) + xx], acc);
             }
