@@ -202,7 +202,7 @@ def test_rrdbnet_mixed_precision_training_graph_close_to_exact(fast_mode):
     64 x 64 tiles, the geometry that kernel family is written for.)
     rrdbnet_autograd.set_train_precision("mixed"): forward convs with fp16 operands, data / weight gradients with bf16 operands
     (fp32 accumulation, fp32 residual and LeakyReLU epilogues).  Against the exact-fp32 graph of the same 2-block net: output within
-    2e-3 (the inference trunk's own fp16-operand error level), every parameter gradient with cosine >= 0.995 and norm within 5 %,
+    1e-3 (measured 3.6e-4 for both modes, the inference trunk's own 3.3e-4 level: tools/sr_precision_probe.py), every parameter gradient with cosine >= 0.995 and norm within 5 %,
     and the mixed graph is not slower beyond noise (its speed is bench.py --workload sr_train's number)."""
     import time
     from srbh_amd import rrdbnet_autograd as RA
@@ -236,7 +236,7 @@ def test_rrdbnet_mixed_precision_training_graph_close_to_exact(fast_mode):
     (y0, gx0, g0), (y1, gx1, g1) = res["f32"], res[fast_mode]
     if fast_mode == "fast":
         assert RA._FAST_WS, "the fast trunk path did not run"
-    assert 1e-6 < O.rel_l2(y1, y0) <= 2e-3
+    assert 1e-6 < O.rel_l2(y1, y0) <= 1e-3
     cos = lambda a, b: float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm()).clamp_min(1e-300))
     assert cos(gx1, gx0) >= 0.995
     for k in g0:
