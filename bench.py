@@ -200,9 +200,11 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
     from srbh_amd.harness import TrainStep, synthetic_batch, train_epoch
     sd, net_hr, net = _make_nets(args, dev, True)
     sync_bn = os.environ.get("SRBH_SYNC_BN", "0") == "1"        # default: per-rank BatchNorm statistics
-    # SRBH_TRAIN_GRAPH=1 (one GPU, fixed batch): the whole step replayed as ONE HIP graph.  Measured equal to eager launches
-    # (53.0 ms both): with the fused optimizer the host keeps up, the step is bound by its ~1 700 kernels and the gaps between them.
-    use_graph = world == 1 and os.environ.get("SRBH_TRAIN_GRAPH", "0") == "1" and not epoch_tiles
+    # SRBH_TRAIN_GRAPH=1 (fixed batch): the step replayed as ONE HIP graph.  On one GPU measured equal to eager launches
+    # (53.0 ms both): with the fused optimizer the host keeps up, the step is bound by its ~1 300 kernels and the gaps between them.
+    # N > 1: the graph ends with backward, the all-reduce buckets + Adam follow eagerly (no overlap with backward) -- the switch for
+    # a node whose host cannot issue N eager steps at once (harness.TrainStep).
+    use_graph = os.environ.get("SRBH_TRAIN_GRAPH", "0") == "1" and not epoch_tiles and not (world > 1 and sync_bn)
     ts = TrainStep(net_hr, net, dev, world=world, sync_bn=sync_bn, timing=True, status_every=0, graph=use_graph)
     fixed = synthetic_batch(batch, 1337 + rank, dev)
     for _ in range(max(warmup, 5 if use_graph else (2 if world > 1 else 1))):          # (world > 1: step 1 records the bucket plan; graph: 3 eager steps, then the capture)
@@ -266,7 +268,8 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
         "config": {"workload": (f"one data-parallel pass over {epoch_tiles} synthetic train tiles (BASELINE.json configs[3]), " if epoch_tiles else "")
                                + f"full train step: RRDBNet fwd (no grad) + SRRegress_Cls_feature fwd/bwd + Adam, batch {batch}/GPU "
                                "(BASELINE.json configs[2])", "batch": batch, "global_batch": batch * world,
-                   "parallelism": f"dp{world} (bucketed RCCL grad all-reduce launched from autograd hooks)" if world > 1 else
+                   "parallelism": (f"dp{world} (fwd+bwd replayed as one HIP graph, then the bucketed RCCL grad all-reduce + Adam)" if use_graph else
+                                   f"dp{world} (bucketed RCCL grad all-reduce launched from autograd hooks)") if world > 1 else
                    ("1 GPU, the whole step replayed as one HIP graph" if use_graph else "1 GPU, eager launches")},
         "whole_step": {"gflop_per_tile": gf_tile, "achieved_tflops": round(gf_tile * tiles / elapsed / 1e3, 2),
                        "note": "mixes the MFMA-bound trunk with the HBM-bound head: not a roofline, see `kernels`"},

@@ -112,6 +112,7 @@ class GradReducer:
         self._hooks = []
         self.exposed_ms = []
         self.n_buckets = 0
+        self.paused = False          # True while TrainStep records its graph: the hooks fire during the capture and must not launch
         if world > 1:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -123,6 +124,8 @@ class GradReducer:
 
     # ---- autograd hook: runs as soon as p.grad is final for this backward
     def _on_grad(self, p):
+        if self.paused:
+            return
         if self.plan is None:
             self._order.append(p)
             return
@@ -277,6 +280,9 @@ class TrainStep:
         from . import hrfuse as _H
         if head_precision not in ("auto", "f16", "f32"):
             raise ValueError("head precision must be 'auto', 'f16' or 'f32'")
+        if graph and world > 1 and sync_bn:
+            raise ValueError("TrainStep(graph=True, sync_bn=True, world > 1): the BatchNorm all-reduces inside the forward are not captured; "
+                             "use graph=False")
         self._H = _H
         self.head_precision = head_precision
         if sync_bn and world > 1:
@@ -298,12 +304,12 @@ class TrainStep:
         # own calls are replay-safe (device state is cleared by kernels: hipMemsetAsync nodes of a replayed graph are not ordered
         # behind the previous replay's kernels on ROCm 7.2); the stock ops of the step still contain a few device-to-device memcpy
         # nodes (ATen clone / copy_), for which the same caution applies -- synchronise between replays if in doubt.
-        self.use_graph = bool(graph) and world == 1
+        self.use_graph = bool(graph)
         # fused=True on the GPU: the whole Adam update is a handful of multi-tensor launches (the default foreach path is ~50
         # launches and 5.5 ms of host time per step; with capturable=True its bias-correction pow even falls back to one launch
         # per parameter, +800 launches in the captured graph).  Same update rule (torch/optim/adam.py), fp32 state.
         fused = torch.device(device).type == "cuda"
-        self.optimizer = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=1e-4, capturable=self.use_graph, fused=fused)
+        self.optimizer = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=1e-4, capturable=self.use_graph and world == 1, fused=fused)
         self.optimizer.add_param_group({"params": [c.log_var for c in self.criterion], "lr": lr})
         self.rgbseq = [0, 1, 2]
         self._rgb_idx = torch.tensor(self.rgbseq, device=device)      # (a Python list index would be a host-to-device copy per step: not capturable)
@@ -352,11 +358,19 @@ class TrainStep:
                 with torch.no_grad():
                     features_for_head(self.net_hr, self._static[0].index_select(1, self._rgb_idx), h16)   # eager: reports packs + workspace
                 torch.cuda.synchronize()
-                with torch.cuda.graph(self._graph):
-                    self._static_out = self._step(self._static, in_graph=True)
+                if self.reducer is not None:
+                    self.reducer.paused = True
+                try:
+                    with torch.cuda.graph(self._graph):
+                        self._static_out = self._step(self._static, in_graph=True)
+                finally:
+                    if self.reducer is not None:
+                        self.reducer.paused = False
             self._stamped = [p for p in self.params()] + [b for b in self.net.buffers()]
         self._stage(batch)
         self._graph.replay()
+        if self.world > 1:            # the replay left this rank's gradients in the captured .grad tensors
+            self._reduce_and_update()
         # a replay updates the weights and the BatchNorm running statistics on the device without any Python-side trace (no
         # _version bump, no optimizer hook): stamp them, or eval / predict_tiles after training reuses the packed weights, folded
         # BatchNorm affines and captured predict graph of an earlier state (round-2 ADVICE)
@@ -380,6 +394,13 @@ class TrainStep:
             if d.dtype != torch.float32:
                 torch.add(s, 0, out=d)
 
+    def _reduce_and_update(self):
+        if self.reducer is not None:
+            self.reducer.finish()      # (buckets whose hooks did not fire -- all of them after a replay -- are launched here)
+        else:
+            allreduce_grads(self.params(), self.world)
+        self.optimizer.step()
+
     def static_batch(self):
         """graph mode: the tensors the captured step reads (None before the first call); a loader may fill them in place"""
         return getattr(self, "_static", None)
@@ -395,11 +416,9 @@ class TrainStep:
                 + self.criterion[2](build_pred, build, weight))
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        if self.reducer is not None:
-            self.reducer.finish()
-        else:
-            allreduce_grads(self.params(), self.world)
-        self.optimizer.step()
+        if in_graph and self.world > 1:
+            return loss.detach(), height_pred.detach()      # (the collectives and Adam follow each replay: _reduce_and_update)
+        self._reduce_and_update()
         if in_graph:
             return loss.detach(), height_pred.detach()
         self.steps += 1

@@ -23,8 +23,9 @@ def _free_port():
     return p
 
 
-def _launch(extra):
-    env = dict(os.environ, SRBH_BENCH_SHARED_DEVICE="1", SRBH_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
+def _launch(extra, **more_env):
+    env = dict(os.environ, **more_env)
+    env.update(SRBH_BENCH_SHARED_DEVICE="1", SRBH_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1",
                # two processes cannot both own every CU: the persistent trunk kernel needs all its workgroups co-resident, so
                # the shared-GPU test runs the per-layer launch sequence (bit-identical, tests/test_gpu_rrdbnet.py)
                SRBH_PERSISTENT="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -49,6 +50,14 @@ def test_bench_train_two_ranks_reports_comm():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0
     c = d["comm"]
     assert c["buckets"] >= 1 and c["grad_bytes"] > 80e6 and c["comm_ms"] > 0 and c["exposed_comm_ms"] >= 0
+    assert d["final_loss"] == d["final_loss"]
+
+
+def test_bench_train_two_ranks_graph_mode():
+    """SRBH_TRAIN_GRAPH=1 at N > 1: forward + backward replayed as one graph per rank, the buckets all-reduced after it"""
+    d = _launch(["--workload", "train", "--steps", "3", "--warmup", "5", "--batch", "4", "--no-extras"], SRBH_TRAIN_GRAPH="1")
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0
+    assert "one HIP graph" in d["config"]["parallelism"] and d["comm"]["buckets"] >= 1
     assert d["final_loss"] == d["final_loss"]
 
 
