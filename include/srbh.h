@@ -398,6 +398,17 @@ int srbh_affine_act_pool_nchw(const float* x, const float* scale, const float* s
 int srbh_se_hidden(const float* pooled, const float* w1, const float* b1, float* hidden, int B, int C, int SQ, void* stream);
 int srbh_se_gate_scale(float* y, const float* hidden, const float* w2, const float* b2, int B, int C, int SQ, int HW,
                        void* stream);
+/* (3') the gate on its own, gate [B][C] = sigmoid(b2[c] + w2 [C][SQ] . hidden[b]): the fused inference block hands it to the project conv
+ * (srbh_pwconv_fwd_epi) instead of rewriting the expanded tensor. */
+int srbh_se_gate(const float* hidden, const float* w2, const float* b2, float* gate, int B, int C, int SQ, void* stream);
+/* MBConv middle at inference as ONE launch (efficientnet_pytorch MBConvBlock.forward through mymodels.py:242-248, eval mode):
+ * y = swish(bn1(depthwise(swish(bn0(x))))) with both BatchNorms folded to (scale, shift) [C] (pre_scale / pre_shift null: the block has
+ * no expand conv, x is used as it is), pooled [B][C] = per-plane mean of y.  Geometry as srbh_dwconv_fwd; _supported tells whether
+ * the LDS-staged form takes the plane (else: the separate launches). */
+int srbh_dwconv_eval_supported(int B, int C, int H, int W, int K, int stride, int pad_t, int pad_l, int OH, int OW);
+int srbh_dwconv_eval_fwd(const float* x, const float* w, const float* pre_scale, const float* pre_shift, const float* scale,
+                         const float* shift, float* y, float* pooled, int B, int C, int H, int W, int K, int stride, int pad_t,
+                         int pad_l, int OH, int OW, void* stream);
 
 /* ---- TRAINING-mode BatchNorm + activation and squeeze-and-excitation of the MBConv / U-Net decoder blocks (csrc/srbh_mbconv.hip) ----
  * Replaces, for the encoder / decoders the reference builds at mymodels.py:242-258 and runs at mymodels.py:276-287, the stock
@@ -484,6 +495,11 @@ typedef struct srbh_transpose_desc {
 } srbh_transpose_desc;
 int srbh_transpose_many(const srbh_transpose_desc* table_dev, int n, void* stream);
 int srbh_pwconv_fwd_wt(const float* x, const float* wt, float* y, int B, int Cin, int Cout, int HW, void* stream);
+/* forward with a fused prologue / epilogue (inference MBConv project conv): y = act((W . (x * gate)) * scale[co] + shift[co]) [+ res];
+ * gate [B][Cin] (squeeze-excite, srbh_se_gate), scale / shift [Cout] (folded inference BatchNorm), res [B][Cout][HW] (skip connection):
+ * each may be null.  w_transposed: w is W^T [Cin][Cout] as for srbh_pwconv_fwd_wt.  act 0 none | 1 SiLU | 2 ReLU. */
+int srbh_pwconv_fwd_epi(const float* x, const float* w, int w_transposed, float* y, int B, int Cin, int Cout, int HW, const float* gate,
+                        const float* scale, const float* shift, const float* res, int act, void* stream);
 int srbh_pwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int HW, void* stream);
 size_t srbh_pwconv_bwd_weight_ws_floats(int B, int Cin, int Cout, int HW);
 int srbh_pwconv_bwd_weight(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int Cout, int HW, void* stream);

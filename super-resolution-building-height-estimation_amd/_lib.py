@@ -210,6 +210,9 @@ SIGNATURES = {
     "srbh_affine_act_pool_nchw": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_se_hidden": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srbh_se_gate_scale": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "srbh_se_gate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "srbh_dwconv_eval_supported": (_i, [_i] * 10),
+    "srbh_dwconv_eval_fwd": (_i, [_vp] * 8 + [_i] * 10 + [_vp]),
     "srbh_bn_act_train_supported": (_i, [_i, _i, _i]),
     "srbh_bn_act_train_ws_bytes": (_sz, [_i, _i, _i]),
     "srbh_bn_act_train_fwd": (_i, [C.POINTER(BnActArgs), _vp]),
@@ -230,6 +233,7 @@ SIGNATURES = {
     "srbh_pwconv_supported": (_i, [_i, _i, _i, _i]),
     "srbh_pwconv_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_pwconv_fwd_wt": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "srbh_pwconv_fwd_epi": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "srbh_transpose_many": (_i, [_vp, _i, _vp]),
     "srbh_pwconv_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_pwconv_bwd_weight_ws_floats": (_sz, [_i, _i, _i, _i]),

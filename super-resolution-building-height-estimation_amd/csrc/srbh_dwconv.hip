@@ -174,6 +174,129 @@ __global__ __launch_bounds__(256) void dw_lds_kernel(const DWLds p) {
     }
 }
 
+// ---- MBConv middle at inference, ONE launch (round 4): y = swish(bn1(dw(swish(bn0(e))))) plus the per-plane mean squeeze-excite pools,
+// with both inference BatchNorms folded to (scale, shift).  bn0 + swish is applied while the expand conv's output is staged (the zero
+// padding is the padding of the ACTIVATED tensor, as in the module chain), bn1 + swish + the pool on the accumulators: the three
+// elementwise passes of the unfused chain (affine_act, affine_act_pool over 6x-expanded tensors) and their two intermediates go away.
+// G = 2^k threads share one plane (G = min(256, outputs per plane)); the pool is a fixed butterfly over those lanes (+ an ordered LDS sum
+// across waves when G > 64): the same bits every run.
+struct DWEval {
+    const float* a0; const float* b0;      // bn0 folded (null: the block has no expand conv)
+    const float* a1; const float* b1;      // bn1 folded
+    float* pooled;                         // [planes] means of the activated output
+    int G;
+};
+__device__ __forceinline__ float silu_f(float u) { return u / (1.f + __expf(-u)); }
+template <int K>
+__global__ __launch_bounds__(256) void dw_lds_eval_kernel(const DWLds p, const DWEval q) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float red[4];
+    const int t = threadIdx.x, plane_sz = p.PH * p.PW;
+    float* wl = sm + p.P * plane_sz;
+    const long p0 = (long)blockIdx.x * p.P;
+    const int np = (int)((p.planes - p0) < p.P ? (p.planes - p0) : p.P);
+    for (int e = t; e < p.P * plane_sz; e += 256) sm[e] = 0.f;
+    for (int e = t; e < np * K * K; e += 256) wl[e] = p.w[(long)((p0 + e / (K * K)) % p.C) * K * K + e % (K * K)];
+    __syncthreads();
+    const int ssz = p.SH * p.SW;
+    const float* sp = p.src + p0 * ssz;
+    for (int e = t; e < np * ssz; e += 256) {
+        const int pl = e / ssz, r0 = e - pl * ssz, u = r0 / p.SW, v = r0 - u * p.SW;
+        const int r = u * p.ss + p.soy, c = v * p.ss + p.sox;
+        float x = sp[e];
+        if (q.a0) {
+            const int ch = (int)((p0 + pl) % p.C);
+            x = silu_f(fmaf(x, q.a0[ch], q.b0[ch]));
+        }
+        if (r < p.PH && c < p.PW) sm[pl * plane_sz + r * p.PW + c] = x;
+    }
+    __syncthreads();
+    const int osz = p.OUTH * p.OUTW, G = q.G, g = t & (G - 1), slot = t / G, R = 256 / G;
+    float* op = p.out + p0 * osz;
+    const float inv = 1.f / (float)osz;
+    for (int pl0 = 0; pl0 < p.P; pl0 += R) {                       // (uniform trip count: the barriers below are taken by every thread)
+        const int pl = pl0 + slot;
+        const bool ok = pl < np;
+        float sum = 0.f;
+        if (ok) {
+            const int ch = (int)((p0 + pl) % p.C);
+            const float s = q.a1[ch], h = q.b1[ch];
+            const float* wp = wl + pl * K * K;
+            for (int o = g; o < osz; o += G) {
+                const int oy = o / p.OUTW, ox = o - oy * p.OUTW;
+                const float* base = sm + pl * plane_sz + (oy * p.os + p.by) * p.PW + ox * p.os + p.bx;
+                float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < K; ++i)
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        if ((i * K + j) & 1) c1 = fmaf(base[i * p.PW + j], wp[i * K + j], c1);
+                        else c0 = fmaf(base[i * p.PW + j], wp[i * K + j], c0);
+                    }
+                const float y = silu_f(fmaf(c0 + c1, s, h));
+                op[(long)pl * osz + o] = y;
+                sum += y;
+            }
+        }
+        for (int o = (G < 64 ? G : 64) >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (G <= 64) {
+            if (ok && g == 0) q.pooled[p0 + pl] = sum * inv;
+        } else {
+            if ((t & 63) == 0) red[t >> 6] = sum;
+            __syncthreads();
+            if (ok && g == 0) {
+                float tot = 0.f;
+                for (int w = 0; w < G / 64; ++w) tot += red[(t >> 6) + w];
+                q.pooled[p0 + pl] = tot * inv;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+//  gate[b][c] = sigmoid(b2[c] + sum_j w2[c][j] * hidden[b][j]) on its own (the fused inference block multiplies it into the project conv's
+//  operand instead of rewriting the expanded tensor).  16 lanes share one channel: a wave walks 4 contiguous rows of w2 (coalesced; one
+//  thread per (b, c) read 64 different rows per load and ran 15 us), keeps its slice of the row in registers and loops over a chunk of
+//  images; fixed butterfly over the 16 lanes.
+constexpr int SE_GATE_IB = 8;          // images per workgroup row
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ hidden, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                     float* __restrict__ gate, int B, int C, int SQ) {
+    const int t = threadIdx.x, sub = t & 15;
+    const int c = blockIdx.x * 16 + (t >> 4);
+    const bool ok = c < C;
+    const float* wr = w2 + (long)(ok ? c : 0) * SQ;
+    const int b0 = blockIdx.y * SE_GATE_IB, b1 = b0 + SE_GATE_IB < B ? b0 + SE_GATE_IB : B;
+    const float bias = ok ? b2[c] : 0.f;
+    if (SQ <= 128) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = (ok && sub + 16 * u < SQ) ? wr[sub + 16 * u] : 0.f;
+        for (int b = b0; b < b1; ++b) {
+            const float* hr = hidden + (long)b * SQ;
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                a0 = fmaf(wv[u], sub + 16 * u < SQ ? hr[sub + 16 * u] : 0.f, a0);
+                a1 = fmaf(wv[u + 1], sub + 16 * (u + 1) < SQ ? hr[sub + 16 * (u + 1)] : 0.f, a1);
+            }
+            float acc = a0 + a1;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) acc += __shfl_xor(acc, o, 64);
+            if (ok && sub == 0) gate[(long)b * C + c] = 1.f / (1.f + __expf(-(acc + bias)));
+        }
+    } else {
+        for (int b = b0; b < b1; ++b) {
+            const float* hr = hidden + (long)b * SQ;
+            float acc = 0.f;
+            if (ok)
+                for (int j = sub; j < SQ; j += 16) acc = fmaf(wr[j], hr[j], acc);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) acc += __shfl_xor(acc, o, 64);
+            if (ok && sub == 0) gate[(long)b * C + c] = 1.f / (1.f + __expf(-(acc + bias)));
+        }
+    }
+}
+
 // weight gradient, LDS-staged: workgroup (c, slice) stages P images' zero-padded x planes and dy planes per round; thread = one output pixel
 template <int K>
 __global__ __launch_bounds__(256) void dw_lds_wgrad_kernel(const DWParams p, float* __restrict__ ws, int splits, int PH, int PW, int P) {
@@ -439,6 +562,54 @@ extern "C" int srbh_dwconv_fwd(const float* x, const float* w, float* y, int B, 
         hipLaunchKernelGGL(dw_fwd_kernel<3>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(dw_fwd_kernel<5>, dim3(g), dim3(256), 0, (hipStream_t)stream, p);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+static bool dw_eval_geometry(DWLds& q, int B, int C, int H, int W, int K, int stride, int pad_t, int pad_l, int OH, int OW, size_t& lds, int& G) {
+    q.planes = (long)B * C; q.C = C; q.SH = H; q.SW = W; q.OUTH = OH; q.OUTW = OW;
+    q.PH = (OH - 1) * stride + K; q.PW = (OW - 1) * stride + K; q.ss = 1; q.soy = pad_t; q.sox = pad_l; q.os = stride; q.by = 0; q.bx = 0;
+    q.P = lds_planes(OH * OW);
+    lds = (size_t)q.P * (q.PH * q.PW + K * K) * 4;
+    G = 1;
+    while (G < OH * OW && G < 256) G <<= 1;
+    return lds <= DW_LDS_MAX && (K == 3 || K == 5);
+}
+
+extern "C" int srbh_dwconv_eval_supported(int B, int C, int H, int W, int K, int stride, int pad_t, int pad_l, int OH, int OW) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || (stride != 1 && stride != 2)) return 0;
+    DWLds q;
+    size_t lds;
+    int G;
+    return dw_eval_geometry(q, B, C, H, W, K, stride, pad_t, pad_l, OH, OW, lds, G) ? 1 : 0;
+}
+
+extern "C" int srbh_dwconv_eval_fwd(const float* x, const float* w, const float* pre_scale, const float* pre_shift, const float* scale,
+                                    const float* shift, float* y, float* pooled, int B, int C, int H, int W, int K, int stride, int pad_t,
+                                    int pad_l, int OH, int OW, void* stream) {
+    SRBH_REQUIRE(x && w && scale && shift && y && pooled, "srbh_dwconv_eval_fwd: null pointer");
+    SRBH_REQUIRE((pre_scale == nullptr) == (pre_shift == nullptr), "srbh_dwconv_eval_fwd: pre_scale and pre_shift go together");
+    DWParams p{x, w, nullptr, y, B, C, H, W, OH, OW, stride, pad_t, pad_l};
+    if (int rc = check(p, K, "srbh_dwconv_eval_fwd")) return rc;
+    DWLds q;
+    size_t lds;
+    DWEval e{pre_scale, pre_shift, scale, shift, pooled, 1};
+    SRBH_REQUIRE(dw_eval_geometry(q, B, C, H, W, K, stride, pad_t, pad_l, OH, OW, lds, e.G), "srbh_dwconv_eval_fwd: plane too large for the "
+                 "LDS-staged form (srbh_dwconv_eval_supported)");
+    q.src = x; q.w = w; q.out = y;
+    const dim3 grid((unsigned)((q.planes + q.P - 1) / q.P));
+    if (K == 3) hipLaunchKernelGGL(dw_lds_eval_kernel<3>, grid, dim3(256), lds, (hipStream_t)stream, q, e);
+    else hipLaunchKernelGGL(dw_lds_eval_kernel<5>, grid, dim3(256), lds, (hipStream_t)stream, q, e);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_se_gate(const float* hidden, const float* w2, const float* b2, float* gate, int B, int C, int SQ, void* stream) {
+    SRBH_REQUIRE(hidden && w2 && b2 && gate, "srbh_se_gate: null pointer");
+    SRBH_REQUIRE(B > 0 && C > 0 && SQ > 0, "srbh_se_gate: bad shape");
+    SRBH_REQUIRE((B + SE_GATE_IB - 1) / SE_GATE_IB <= 65535, "srbh_se_gate: batch too large");
+    hipLaunchKernelGGL(se_gate_kernel, dim3((unsigned)((C + 15) / 16), (unsigned)((B + SE_GATE_IB - 1) / SE_GATE_IB)), dim3(256), 0,
+                       (hipStream_t)stream, hidden, w2, b2, gate, B, C, SQ);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }

@@ -27,7 +27,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #ifndef SRBH_PW_UK
 #define SRBH_PW_UK 8
 #endif
-constexpr int UK = SRBH_PW_UK;      // K steps per round of loads
+constexpr int UK = SRBH_PW_UK;      // K steps per round of loads (a multiple of 4)
 
 // KW waves share one tile and split its K range between them (partials folded through LDS in a fixed order): the deep products at 2x2 and
 // 4x4 (K up to 2688 with only ~300 tiles) are otherwise one long chain of load rounds on a quarter of the SIMDs.  KW = 1: the 4 waves
@@ -51,10 +51,20 @@ __device__ __forceinline__ void fold_k_slices(floatx4 (&acc)[NREG], float* red, 
         }
 }
 
-template <int MI, int NI, int TRANS_A, int KW>
+// EPI (inference MBConv blocks, round 4): the operand is multiplied by a per-(image, input channel) gate while it is loaded (squeeze-excite
+// folded into the project conv) and the result goes through y = act(acc * scale[m] + shift[m]) [+ res] (the folded inference BatchNorm, the
+// block's skip connection) before the one store.
+struct PwEpi {
+    const float* gate;       // [B][K] or null
+    const float* scale;      // [M] (null: no affine)
+    const float* shift;
+    const float* res;        // [B][M][HW] or null
+    int act;                 // 0 none, 1 SiLU, 2 ReLU
+};
+template <int MI, int NI, int TRANS_A, int KW, int EPI = 0>
 __global__ __launch_bounds__(KW == 16 ? 1024 : 256) void pw_gemm_kernel(const float* __restrict__ W, const float* __restrict__ In,
                                                                       float* __restrict__ Out, int M, int K, int HW, long ncols,
-                                                                      int tiles_m, int tiles_n) {
+                                                                      int tiles_m, int tiles_n, const PwEpi ep) {
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int lane = threadIdx.x & 63, l16 = lane & 15, kq = lane >> 4, wave = threadIdx.x >> 6;
     const int ks = KW == 1 ? 0 : wave;
@@ -76,6 +86,7 @@ __global__ __launch_bounds__(KW == 16 ? 1024 : 256) void pw_gemm_kernel(const fl
         ap[mi] = TRANS_A ? W + (long)kbeg * M + m : W + (long)m * K + kbeg;
     }
     const float* bp[NI];
+    const float* gp[NI];
     bool bok[NI];
     long obase[NI];
 #pragma unroll
@@ -85,6 +96,7 @@ __global__ __launch_bounds__(KW == 16 ? 1024 : 256) void pw_gemm_kernel(const fl
         const long b = n / HW;
         const int hw = (int)(n - b * HW);
         bp[ni] = In + (b * K + kbeg) * HW + hw;
+        gp[ni] = (EPI && ep.gate) ? ep.gate + (bok[ni] ? b : 0) * K + kbeg : nullptr;
         obase[ni] = b * M * HW + hw;
     }
     floatx4 acc[MI * NI];
@@ -99,6 +111,26 @@ __global__ __launch_bounds__(KW == 16 ? 1024 : 256) void pw_gemm_kernel(const fl
             for (int mi = 0; mi < MI; ++mi) a[mi][u] = (kok && aok[mi]) ? ap[mi][(u0 + u) * astride] : 0.f;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) b[ni][u] = (kok && bok[ni]) ? bp[ni][(long)(u0 + u) * HW] : 0.f;
+        }
+        if (EPI && ep.gate) {
+            // the gates of this lane's K run are contiguous floats: two (unaligned) 16-byte loads per round instead of one load per element
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                float gv[UK];
+                if (u0 + UK <= kcnt) {
+#pragma unroll
+                    for (int v = 0; v < UK / 4; ++v) {
+                        const f4u g4 = *(const f4u*)(gp[ni] + u0 + 4 * v);
+                        gv[4 * v] = g4[0]; gv[4 * v + 1] = g4[1]; gv[4 * v + 2] = g4[2]; gv[4 * v + 3] = g4[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < UK; ++u) gv[u] = u0 + u < kcnt ? gp[ni][u0 + u] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < UK; ++u) b[ni][u] *= gv[u];
+            }
         }
 #pragma unroll
         for (int u = 0; u < UK; ++u)
@@ -117,7 +149,16 @@ __global__ __launch_bounds__(KW == 16 ? 1024 : 256) void pw_gemm_kernel(const fl
             for (int r = 0; r < 4; ++r) {
                 if (KW > 1 && ((mi * NI + ni) * 4 + r) % KW != ks) continue;
                 const int m = (tm * MI + mi) * 16 + 4 * kq + r;
-                if (m < M && bok[ni]) Out[obase[ni] + (long)m * HW] = acc[mi * NI + ni][r];
+                if (m < M && bok[ni]) {
+                    float v = acc[mi * NI + ni][r];
+                    if (EPI) {
+                        if (ep.scale) v = fmaf(v, ep.scale[m], ep.shift[m]);
+                        if (ep.act == 1) v = v / (1.f + __expf(-v));
+                        else if (ep.act == 2) v = fmaxf(v, 0.f);
+                        if (ep.res) v += ep.res[obase[ni] + (long)m * HW];
+                    }
+                    Out[obase[ni] + (long)m * HW] = v;
+                }
             }
 }
 
@@ -248,13 +289,39 @@ template <int MI, int NI, int TRANS_A>
 int gemm_launch_kw(int kw, const float* W, const float* In, float* Out, int M, int K, int HW, long ncols, int tm, int tn, hipStream_t st) {
     const long tiles = (long)tm * tn;
     if (kw == 1)
-        hipLaunchKernelGGL((pw_gemm_kernel<MI, NI, TRANS_A, 1>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, W, In, Out, M, K, HW, ncols, tm, tn);
+        hipLaunchKernelGGL((pw_gemm_kernel<MI, NI, TRANS_A, 1>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, W, In, Out, M, K, HW, ncols, tm, tn, PwEpi{});
     else if (kw == 4)
-        hipLaunchKernelGGL((pw_gemm_kernel<MI, NI, TRANS_A, 4>), dim3((unsigned)tiles), dim3(256), 4 * MI * NI * 4 * 64 * 4, st, W, In, Out, M, K, HW, ncols, tm, tn);
+        hipLaunchKernelGGL((pw_gemm_kernel<MI, NI, TRANS_A, 4>), dim3((unsigned)tiles), dim3(256), 4 * MI * NI * 4 * 64 * 4, st, W, In, Out, M, K, HW, ncols, tm, tn, PwEpi{});
     else
-        hipLaunchKernelGGL((pw_gemm_kernel<MI, NI, TRANS_A, 16>), dim3((unsigned)tiles), dim3(1024), 16 * MI * NI * 4 * 64 * 4, st, W, In, Out, M, K, HW, ncols, tm, tn);
+        hipLaunchKernelGGL((pw_gemm_kernel<MI, NI, TRANS_A, 16>), dim3((unsigned)tiles), dim3(1024), 16 * MI * NI * 4 * 64 * 4, st, W, In, Out, M, K, HW, ncols, tm, tn, PwEpi{});
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
+}
+
+template <int MI, int NI, int TRANS_A>
+int gemm_launch_epi_kw(int kw, const float* W, const float* In, float* Out, int M, int K, int HW, long ncols, int tm, int tn, const PwEpi& ep,
+                       hipStream_t st) {
+    const long tiles = (long)tm * tn;
+    if (kw == 1)
+        hipLaunchKernelGGL((pw_gemm_kernel<MI, NI, TRANS_A, 1, 1>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, W, In, Out, M, K, HW, ncols, tm, tn, ep);
+    else if (kw == 4)
+        hipLaunchKernelGGL((pw_gemm_kernel<MI, NI, TRANS_A, 4, 1>), dim3((unsigned)tiles), dim3(256), 4 * MI * NI * 4 * 64 * 4, st, W, In, Out, M, K, HW, ncols, tm, tn, ep);
+    else
+        hipLaunchKernelGGL((pw_gemm_kernel<MI, NI, TRANS_A, 16, 1>), dim3((unsigned)tiles), dim3(1024), 16 * MI * NI * 4 * 64 * 4, st, W, In, Out, M, K, HW, ncols, tm, tn, ep);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+template <int TRANS_A>
+int gemm_launch_epi(const float* W, const float* In, float* Out, int M, int K, int HW, int B, const PwEpi& ep, hipStream_t st) {
+    const long ncols = (long)B * HW, m16 = (M + 15) / 16, n16 = (ncols + 15) / 16;
+    const int t = pick_tile(m16, n16);
+    const int MI = t == 2 ? 2 : 1, NI = t >= 1 ? 2 : 1;
+    const int tm = (int)((m16 + MI - 1) / MI), tn = (int)((n16 + NI - 1) / NI);
+    const int kw = t == 0 ? pick_kw((long)tm * tn, K) : 1;
+    if (t == 2) return gemm_launch_epi_kw<2, 2, TRANS_A>(1, W, In, Out, M, K, HW, ncols, tm, tn, ep, st);
+    if (t == 1) return gemm_launch_epi_kw<1, 2, TRANS_A>(1, W, In, Out, M, K, HW, ncols, tm, tn, ep, st);
+    return gemm_launch_epi_kw<1, 1, TRANS_A>(kw, W, In, Out, M, K, HW, ncols, tm, tn, ep, st);
 }
 
 template <int TRANS_A>
@@ -274,6 +341,16 @@ extern "C" int srbh_pwconv_fwd(const float* x, const float* w, float* y, int B, 
     SRBH_REQUIRE(x && w && y, "srbh_pwconv_fwd: null pointer");
     SRBH_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && HW > 0, "srbh_pwconv_fwd: bad shape");
     return gemm_launch<0>(w, x, y, Cout, Cin, HW, B, (hipStream_t)stream);
+}
+
+extern "C" int srbh_pwconv_fwd_epi(const float* x, const float* w, int w_transposed, float* y, int B, int Cin, int Cout, int HW,
+                                   const float* gate, const float* scale, const float* shift, const float* res, int act, void* stream) {
+    SRBH_REQUIRE(x && w && y, "srbh_pwconv_fwd_epi: null pointer");
+    SRBH_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && HW > 0, "srbh_pwconv_fwd_epi: bad shape");
+    SRBH_REQUIRE((scale == nullptr) == (shift == nullptr) && act >= 0 && act <= 2, "srbh_pwconv_fwd_epi: bad epilogue");
+    const PwEpi ep{gate, scale, shift, res, act};
+    return w_transposed ? gemm_launch_epi<1>(w, x, y, Cout, Cin, HW, B, ep, (hipStream_t)stream)
+                        : gemm_launch_epi<0>(w, x, y, Cout, Cin, HW, B, ep, (hipStream_t)stream);
 }
 
 extern "C" int srbh_pwconv_fwd_wt(const float* x, const float* wt, float* y, int B, int Cin, int Cout, int HW, void* stream) {

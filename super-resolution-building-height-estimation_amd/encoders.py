@@ -211,6 +211,10 @@ PWCONV = __import__("os").environ.get("SRBH_PWCONV", "1")      # "1" (default): 
 _ACT = {None: 0, "silu": 1, "relu": 2}
 FUSED_SE_EVAL = True       # squeeze-and-excitation of the MBConv blocks as three libsrbh launches at inference
 FUSED_BN_EVAL = True      # tests switch it off to compare with the stock inference-BatchNorm path
+# MBConv block at inference as 4-5 launches (round 4): expand 1x1 | bn0+swish -> depthwise -> bn1+swish -> pool in ONE kernel | SE hidden |
+# SE gate | project 1x1 with the gate on its operand and bn2 (+ skip) in its epilogue -- instead of 8 launches and ten passes over the
+# 6x-expanded tensor.  SRBH_MBCONV_EVAL=0: the separate launches (A/B aid, and what the parity tests compare against).
+MBCONV_EVAL = __import__("os").environ.get("SRBH_MBCONV_EVAL", "1") == "1"
 
 
 def bn_act(bn, x, act=None, res=None, drop=None):
@@ -330,13 +334,18 @@ class SamePadConv2d(nn.Conv2d):
                 and (PWCONV == "1" or (PWCONV == "train" and torch.is_grad_enabled()))):
             from . import _lib
             if _lib.lib().srbh_pwconv_supported(x.shape[0], x.shape[1], self.weight.shape[0], x.shape[2] * x.shape[3]):
-                wt = self.__dict__.get("_srbh_wt")           # (valid only for the weight state it was made from)
-                if wt is not None and (wt.device != x.device or self.__dict__.get("_srbh_wt_state") != (
-                        self.weight._version, self.weight.data_ptr(), wcache.gen(self.weight))):
-                    wt = None
-                return _PointwiseConvFn.apply(x, self.weight, wt)
+                return _PointwiseConvFn.apply(x, self.weight, _valid_wt(self, x.device))
         _stock("conv%dx%d%s" % (self.kernel_size[0], self.kernel_size[1], "_dw" if self.groups > 1 else ""), x)
         return F.conv2d(self.static_padding(x), self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
+
+
+def _valid_wt(conv, device):
+    """the transposed copy PointwiseTransposes made of conv.weight, if it still belongs to this state of the weight (else None)"""
+    wt = conv.__dict__.get("_srbh_wt")
+    if wt is not None and (wt.device != device or conv.__dict__.get("_srbh_wt_state") != (
+            conv.weight._version, conv.weight.data_ptr(), wcache.gen(conv.weight))):
+        wt = None
+    return wt
 
 
 def _swish(x):
@@ -374,8 +383,58 @@ class MBConvBlock(nn.Module):
         self._project_conv = SamePadConv2d(mid, out, 1, math.ceil(image_size / stride), bias=False)
         self._bn2 = nn.BatchNorm2d(out, momentum=BN_MOM, eps=BN_EPS)
 
+    def _eval_fused(self, x):
+        """the whole block at inference on libsrbh's fused kernels, or None when a shape / mode is not theirs"""
+        dw = self._depthwise_conv
+        if not (MBCONV_EVAL and FUSED_SE_EVAL and PWCONV == "1" and x.dim() == 4 and _fused_eval_ok(self._bn1, x) and not self._bn2.training
+                and (self.expand == 1 or not self._bn0.training) and dw._depthwise and self._project_conv._pointwise
+                and dw.weight.dtype == torch.float32 and self._se_reduce.weight.is_contiguous() and self._se_expand.weight.is_contiguous()):
+            return None
+        from . import _lib
+        L = _lib.lib()
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        mid, K, stride = dw.weight.shape[0], dw.weight.shape[-1], dw.stride[0]
+        pl, pr, pt, pb = dw._pad
+        OH, OW = (H + pt + pb - K) // stride + 1, (W + pl + pr - K) // stride + 1
+        pc = self._project_conv
+        out = pc.weight.shape[0]
+        if not (L.srbh_dwconv_eval_supported(B, mid, H, W, K, stride, pt, pl, OH, OW) and L.srbh_pwconv_supported(B, mid, out, OH * OW)):
+            return None
+        st, dev = _lib.stream_ptr(), x.device
+        if self.expand != 1:
+            e = self._expand_conv(x).contiguous()
+            a0, b0 = _bn_affine(self._bn0, dev)
+        else:
+            e, a0, b0 = x, None, None
+        a1, b1 = _bn_affine(self._bn1, dev)
+        y = torch.empty((B, mid, OH, OW), dtype=torch.float32, device=dev)
+        pooled = torch.empty((B, mid), dtype=torch.float32, device=dev)
+        _lib.check(L.srbh_dwconv_eval_fwd(e.data_ptr(), dw.weight.contiguous().data_ptr(), a0.data_ptr() if a0 is not None else None,
+                                          b0.data_ptr() if b0 is not None else None, a1.data_ptr(), b1.data_ptr(), y.data_ptr(),
+                                          pooled.data_ptr(), B, mid, H, W, K, stride, pt, pl, OH, OW, st), "dwconv_eval_fwd")
+        SQ = self._se_reduce.out_channels
+        hidden = torch.empty((B, SQ), dtype=torch.float32, device=dev)
+        _lib.check(L.srbh_se_hidden(pooled.data_ptr(), self._se_reduce.weight.data_ptr(), self._se_reduce.bias.data_ptr(), hidden.data_ptr(),
+                                    B, mid, SQ, st), "se_hidden")
+        gate = torch.empty((B, mid), dtype=torch.float32, device=dev)
+        _lib.check(L.srbh_se_gate(hidden.data_ptr(), self._se_expand.weight.data_ptr(), self._se_expand.bias.data_ptr(), gate.data_ptr(),
+                                  B, mid, SQ, st), "se_gate")
+        a2, b2 = _bn_affine(self._bn2, dev)
+        wt = _valid_wt(pc, dev)
+        w = wt if wt is not None else pc.weight.contiguous()
+        z = torch.empty((B, out, OH, OW), dtype=torch.float32, device=dev)
+        skip = self.stride == 1 and self.inp == self.out
+        _lib.check(L.srbh_pwconv_fwd_epi(y.data_ptr(), w.data_ptr(), 1 if wt is not None else 0, z.data_ptr(), B, mid, out, OH * OW,
+                                         gate.data_ptr(), a2.data_ptr(), b2.data_ptr(), x.data_ptr() if skip else None, 0, st), "pwconv_fwd_epi")
+        return z
+
     def forward(self, x, drop_connect_rate=None, drop_mask=None):
         inputs = x
+        if x.is_cuda and not self.training:
+            z = self._eval_fused(x)
+            if z is not None:
+                return z
         if self.expand != 1 and x.is_cuda and self._bn0.training:
             e_pre = self._expand_conv(x)
             MBm = _mbconv_train(self._bn0, e_pre)

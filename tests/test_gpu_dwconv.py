@@ -103,3 +103,106 @@ def _fused_bn_body():
             encoders.FUSED_BN_EVAL = True
     assert rel(a2, b2) <= 1e-5
 
+
+
+@pytest.mark.parametrize("B,C,H,K,stride", [(3, 24, 32, 3, 1), (2, 40, 32, 5, 2), (5, 96, 16, 3, 2), (7, 50, 8, 5, 1), (33, 48, 4, 5, 1),
+                                            (9, 130, 4, 3, 2), (66, 72, 2, 3, 1), (1, 16, 16, 5, 1)])
+@pytest.mark.parametrize("pre", [True, False])
+def test_fused_inference_depthwise_bn_swish_pool_kernel(B, C, H, K, stride, pre):
+    """srbh_dwconv_eval_fwd (round 4): swish(bn0) while staging, depthwise conv, swish(bn1) + per-plane mean in the epilogue == the torch
+    chain on the same folded affines; TF-'same' padding of the encoder (odd total padding at stride 2); ragged plane counts per
+    workgroup; the pooled means bit-identical between two runs (fixed reduction tree)."""
+    import math
+    from srbh_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(B * 131 + C)
+    x = torch.randn((B, C, H, H), generator=g).to(DEV)
+    w = (torch.randn((C, 1, K, K), generator=g) * 0.3).to(DEV)
+    a0, b0, a1, b1 = [(torch.rand(C, generator=g) + 0.5).to(DEV) if i % 2 == 0 else (torch.randn(C, generator=g) * 0.2).to(DEV) for i in range(4)]
+    OH = math.ceil(H / stride)
+    pad = max((OH - 1) * stride + K - H, 0)
+    pt = pad // 2
+    assert L.srbh_dwconv_eval_supported(B, C, H, H, K, stride, pt, pt, OH, OH)
+    y = torch.empty((B, C, OH, OH), device=DEV)
+    pooled = torch.empty((B, C), device=DEV)
+    args = (x.data_ptr(), w.data_ptr(), a0.data_ptr() if pre else None, b0.data_ptr() if pre else None, a1.data_ptr(), b1.data_ptr())
+    _lib.check(L.srbh_dwconv_eval_fwd(*args, y.data_ptr(), pooled.data_ptr(), B, C, H, H, K, stride, pt, pt, OH, OH, _lib.stream_ptr()), "dwconv_eval_fwd")
+    e = F.silu(x * a0.view(1, -1, 1, 1) + b0.view(1, -1, 1, 1)) if pre else x
+    z = F.conv2d(F.pad(e.double(), (pt, pad - pt, pt, pad - pt)), w.double(), None, stride, 0, 1, C)
+    want = F.silu(z * a1.double().view(1, -1, 1, 1) + b1.double().view(1, -1, 1, 1))
+    assert rel(y, want) <= 2e-6
+    assert float((pooled.double() - want.mean((2, 3))).abs().max()) <= 1e-5 * float(want.abs().max())
+    y2, pooled2 = torch.empty_like(y), torch.empty_like(pooled)
+    _lib.check(L.srbh_dwconv_eval_fwd(*args, y2.data_ptr(), pooled2.data_ptr(), B, C, H, H, K, stride, pt, pt, OH, OH, _lib.stream_ptr()), "dwconv_eval_fwd")
+    assert torch.equal(y, y2) and torch.equal(pooled, pooled2)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,HW", [(3, 144, 24, 1024), (2, 240, 40, 256), (5, 672, 112, 16), (7, 2688, 448, 4), (128, 960, 160, 16), (1, 24, 24, 64)])
+@pytest.mark.parametrize("transposed", [0, 1])
+def test_pointwise_conv_with_gate_bn_and_skip_epilogue(B, Cin, Cout, HW, transposed):
+    """srbh_pwconv_fwd_epi (round 4): the squeeze-excite gate multiplied into the operand, folded BatchNorm and the skip connection in the
+    epilogue == the separate passes; every tile form (16x16 with split K, 16x32, 32x32) through these shapes; each optional part absent."""
+    from srbh_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(Cin + HW)
+    x = torch.randn((B, Cin, HW), generator=g).to(DEV)
+    w = (torch.randn((Cout, Cin), generator=g) / Cin ** 0.5).to(DEV)
+    gate = torch.rand((B, Cin), generator=g).to(DEV)
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).to(DEV), torch.randn(Cout, generator=g).to(DEV)
+    res = torch.randn((B, Cout, HW), generator=g).to(DEV)
+    wp = w.t().contiguous() if transposed else w
+    for use_gate, use_bn, use_res, act in ((1, 1, 1, 0), (1, 1, 0, 0), (0, 1, 0, 1), (0, 0, 0, 0), (1, 0, 1, 2)):
+        y = torch.empty((B, Cout, HW), device=DEV)
+        _lib.check(L.srbh_pwconv_fwd_epi(x.data_ptr(), wp.data_ptr(), transposed, y.data_ptr(), B, Cin, Cout, HW, gate.data_ptr() if use_gate else None,
+                                         sc.data_ptr() if use_bn else None, sh.data_ptr() if use_bn else None, res.data_ptr() if use_res else None,
+                                         act, _lib.stream_ptr()), "pwconv_fwd_epi")
+        want = torch.einsum("oc,bcp->bop", w.double(), (x * gate.unsqueeze(2)).double() if use_gate else x.double())
+        if use_bn:
+            want = want * sc.double().view(1, -1, 1) + sh.double().view(1, -1, 1)
+        want = F.silu(want) if act == 1 else (F.relu(want) if act == 2 else want)
+        if use_res:
+            want = want + res.double()
+        assert rel(y, want) <= 3e-6, (use_gate, use_bn, use_res, act)
+
+
+def test_fused_inference_mbconv_block_agrees_with_the_separate_launches():
+    """encoders.MBCONV_EVAL (round 4): every MBConv block of EfficientNet-B4 in eval mode as expand | fused middle | SE hidden | SE gate |
+    gated project with bn2 + skip == the round-3 chain of separate libsrbh launches; batch sizes 1, 5 and 64; the encoder's launch count
+    drops accordingly (path taken in every block)."""
+    from srbh_amd import encoders, _lib
+    torch.manual_seed(11)
+    enc = encoders.get_encoder("efficientnet-b4", in_channels=8, depth=5, weights=None).to(DEV)
+    enc.train()
+    with torch.no_grad():
+        for _ in range(2):
+            enc(torch.rand((8, 8, 64, 64), device=DEV))          # non-trivial running statistics
+    enc.eval()
+    calls = {"n": 0}
+    real = encoders.MBConvBlock._eval_fused
+
+    def counting(self, x):
+        z = real(self, x)
+        calls["n"] += z is not None
+        return z
+    for B in (1, 5, 64):
+        x = torch.rand((B, 8, 64, 64), device=DEV)
+        with torch.no_grad():
+            encoders.MBConvBlock._eval_fused = counting
+            try:
+                calls["n"] = 0
+                a = enc(x)
+            finally:
+                encoders.MBConvBlock._eval_fused = real
+            assert calls["n"] == 32, calls
+            encoders.MBCONV_EVAL = False
+            try:
+                b = enc(x)
+            finally:
+                encoders.MBCONV_EVAL = True
+        assert len(a) == len(b)
+        for u, v in zip(a[1:], b[1:]):
+            assert rel(u, v) <= 1e-5, (B, tuple(u.shape), rel(u, v))
+    # a training-mode block keeps its training kernels
+    enc.train()
+    with torch.no_grad():
+        assert enc._blocks[3]._eval_fused(torch.rand((2, enc._blocks[3].inp, 16, 16), device=DEV)) is None
