@@ -489,6 +489,7 @@ def train_epoch(ts, n_tiles, batch, rank, world, device, seed=1337, max_steps=No
 
 
 PREDICT_GRAPH = os.environ.get("SRBH_PREDICT_GRAPH", "1") == "1"
+PREDICT_SPLIT = os.environ.get("SRBH_PREDICT_SPLIT", "1") == "1"      # encoder / decoders as their own graph on a second stream (0: one graph, A/B aid)
 
 
 class _PredictGraph:
@@ -513,9 +514,26 @@ class _PredictGraph:
                     model(self.x, features_for_head(net_hr, self.x[:, :3]))
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = model(self.x, features_for_head(net_hr, self.x[:, :3]))
+            # THREE graphs, not one (round 4): the encoder / decoders (~250 small launches, 2-3 ms per 128 tiles) replay on a second
+            # stream next to trunk + HRfeature on the main one, reg / seg follow the join.  Captured as ONE graph with a forked
+            # stream the branches do not overlap on ROCm 7.2 (tools/graph_branch_probe.py: two forked chains replay slower than the
+            # same chains on one stream); separate graph launches on separate streams do.  The persistent trunk owns every CU
+            # while it runs, so the encoder fills in around it (before, between its launches, under HRfeature).
+            self.split = PREDICT_SPLIT and all(hasattr(model, n) for n in ("forward_lr", "forward_hr", "forward_fuse"))
+            if self.split:
+                self.side = side
+                self.g_lr, self.g_hr, self.g_fuse = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_lr):
+                    self.lr_out = model.forward_lr(self.x)
+                with torch.cuda.graph(self.g_hr):
+                    self.hr_out = model.forward_hr(features_for_head(net_hr, self.x[:, :3]))
+                with torch.cuda.graph(self.g_fuse):
+                    height, build = model.forward_fuse(self.lr_out[0], self.lr_out[1], self.hr_out)
+                self.out = (height, build) + ((self.lr_out[2],) if self.lr_out[2] is not None else ())
+            else:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.out = model(self.x, features_for_head(net_hr, self.x[:, :3]))
 
     @staticmethod
     def weights_key(net_hr, model, batch, dev):
@@ -530,7 +548,16 @@ class _PredictGraph:
         self.x[:k].copy_(x_src, non_blocking=True)
         if k < self.x.shape[0]:
             self.x[k:].zero_()
-        self.graph.replay()
+        if not self.split:
+            self.graph.replay()
+            return self.out
+        cur = torch.cuda.current_stream(self.x.device)
+        self.side.wait_stream(cur)                   # the batch is staged, the previous batch's reg / seg have read lr_out
+        with torch.cuda.stream(self.side):
+            self.g_lr.replay()
+        self.g_hr.replay()
+        cur.wait_stream(self.side)
+        self.g_fuse.replay()
         return self.out
 
 

@@ -76,6 +76,24 @@ class SRRegress_Cls_feature(torch.nn.Module):
             return height, build, height_aggre
         return height, build
 
+    # the three independent-until-the-end parts of forward (mymodels.py:270-293): harness._PredictGraph records each into its own HIP
+    # graph and replays the first on a second stream (a forked capture inside ONE graph does not run its branches concurrently on
+    # ROCm 7.2: tools/graph_branch_probe.py)
+    def forward_lr(self, x):
+        """encoder + both U-Net decoders on the 64x64 tile: (height_fea, build_fea, height_aggre | None)"""
+        encode_fea = self.encoder(x)
+        height_fea = self.decoder1(*encode_fea)
+        build_fea = self.decoder2(*encode_fea)
+        return height_fea, build_fea, (self._aggre(height_fea) if self.isaggre else None)
+
+    def forward_hr(self, super_fea):
+        """the RRDBNet features through HRfeature (fp16 NHWC inside the inference chain; reg / seg read it as such)"""
+        return self.hrfeat(super_fea, out_h16=HRFEAT_OUT_H16)
+
+    def forward_fuse(self, height_fea, build_fea, super_fea):
+        """reg / seg on forward_lr's and forward_hr's results: (height, build)"""
+        return self.reg(height_fea, super_fea), self.seg(build_fea, super_fea)
+
     def _forward_two_streams(self, x, super_fea):
         """Same ops, two HIP streams: the EfficientNet encoder and the two U-Net decoders are ~500 small stock-op launches at
         64x64 and below (dispatch-latency bound, a few CUs each), the 256x256 HR head is a handful of chip-filling kernels;
@@ -88,17 +106,13 @@ class SRRegress_Cls_feature(torch.nn.Module):
             self.__dict__["_side_stream"] = side
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            encode_fea = self.encoder(x)
-            height_fea = self.decoder1(*encode_fea)
-            build_fea = self.decoder2(*encode_fea)
-            height_aggre = self._aggre(height_fea) if self.isaggre else None
-        super_fea = self.hrfeat(super_fea, out_h16=HRFEAT_OUT_H16)     # (fp16 NHWC inside the inference chain; reg / seg read it as such)
+            height_fea, build_fea, height_aggre = self.forward_lr(x)
+        super_fea = self.forward_hr(super_fea)
         cur.wait_stream(side)
         for t in (height_fea, build_fea, height_aggre):      # produced on `side`, consumed on `cur`: keep the allocator from recycling early
             if t is not None:
                 t.record_stream(cur)
-        height = self.reg(height_fea, super_fea)
-        build = self.seg(build_fea, super_fea)
+        height, build = self.forward_fuse(height_fea, build_fea, super_fea)
         if self.isaggre:
             return height, build, height_aggre
         return height, build

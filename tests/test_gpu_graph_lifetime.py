@@ -89,6 +89,31 @@ def test_multi_city_sequence_graph_path_equals_eager(monkeypatch):
     assert not net_hr.__dict__["_ws_pins"].get(key128)
 
 
+def test_predict_graph_split_over_two_streams_equals_the_single_graph(monkeypatch):
+    """round 4: harness._PredictGraph replays the encoder / decoders as their own graph on a second stream next to trunk + HRfeature,
+    reg / seg after the join (harness.PREDICT_SPLIT).  Same kernels on the same inputs: the mosaics of a three-city sequence equal the
+    single-graph replay's bit for bit (isaggre model: the third output crosses the streams too), twice over (buffer reuse across
+    batches: the join orders the next batch's staging behind the previous batch's readers)."""
+    from srbh_amd import harness
+    net_hr, model = _nets(isaggre=True)
+    model.eval()
+    sizes = [3 * 128, 128 + 40, 2 * 128]
+    res = {}
+    for split in (True, False, True):
+        monkeypatch.setattr(harness, "PREDICT_SPLIT", split)
+        model.__dict__["_srbh_predict_graph"] = None
+        got = _run_cities(net_hr, model, sizes, graph=True)
+        pg = model.__dict__["_srbh_predict_graph"]
+        assert pg is not None and pg.split == split and len(pg.out) == 3
+        res.setdefault(split, []).append(got)
+    model.__dict__["_srbh_predict_graph"] = None
+    for a, b in ((res[True][0], res[False][0]), (res[True][0], res[True][1])):
+        for i, (g, w) in enumerate(zip(a, b)):
+            for u, v in zip(g, w):
+                assert torch.equal(u, v), f"city {i}"
+    net_hr.check_status()
+
+
 def test_workspace_budget_evicts_lru_but_never_a_pinned_one(monkeypatch):
     from srbh_amd import wcache
     from srbh_amd.rrdbnet import RRDBNet
