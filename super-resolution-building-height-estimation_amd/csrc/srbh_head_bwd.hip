@@ -476,6 +476,181 @@ __global__ __launch_bounds__(256) void hwgrad_b16_kernel(const WGParams p) {
     }
 }
 
+// Fused BasicBlock-entry weight gradient with the CHUNK loop inside the tile walk (round 4).  hwgrad_b16_kernel<3, DS, 0, 1> walks all its
+// tiles once per 16-channel chunk of the input: the 64-channel entry (HRfeature: cin = 64, fp16 features) re-staged both dY tiles four times
+// and touched 32 bytes of every 128-byte pixel row per pass -- 891 us for 805 MB (0.11 of the HBM peak, profiles/r04p).  Here a tile's dY /
+// dY2 are staged once, the NC chunks of X follow one another through the same LDS buffer (chunk c + 1's global loads are issued before
+// chunk c's MFMAs: the rows' other three 32-byte quarters come out of L2 while they are hot), and NC x 10 accumulators stay in registers.
+// Same tile walk, same wave -> row assignment, same flush: every partial sum is the bit pattern the chunk-outer kernel writes.
+template <int DS, int NC>
+__global__ __launch_bounds__(256) void hwgrad_entry_b16_kernel(const WGParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    using G = WG16<3>;
+    constexpr int TAPS = G::TAPS, HALO = G::HALO, ROWS = G::ROWS, QX = G::QX, SX = G::SX, SD = G::SD;
+    unsigned* s_x = (unsigned*)wsm;                 // [16 ci][SX]
+    unsigned* s_dy = s_x + 16 * SX;                 // [16 oc][SD]
+    unsigned* s_dy2 = s_dy + 16 * SD;               // [16 oc][SD]
+    float* s_red = wsm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kk = lane >> 4;
+    const int cin = p.c0 + p.c1;
+    const int ob = blockIdx.y;
+    floatx4 acc[NC][TAPS];
+    floatx4 acc2[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) acc[c][tp] = floatx4{0.f, 0.f, 0.f, 0.f};
+        acc2[c] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    constexpr int NIX = (ROWS * QX * 4 + 255) / 256, NID = HT_H * 16 * 4 / 256;
+    typedef typename std::conditional<DS != 0, float2w, floatx4>::type ldv_t;
+    const int t_end = min((int)(blockIdx.x & 7) * p.tiles_per_xcd + p.tiles_per_xcd, p.ntiles);
+    for (int t = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3); t < t_end; t += gridDim.x >> 3) {
+        const int img = t / p.tiles_per_img;
+        const int trem = t - img * p.tiles_per_img;
+        const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+        const int Y0 = ty * HT_H, X0 = tx * HT_W;
+        floatx4 lx[NIX][4];
+        auto load_x = [&](const int c) {
+#pragma unroll
+            for (int it = 0; it < NIX; ++it) {
+                const int u = tid + it * 256;
+                const int cg = u & 3, q = u >> 2;
+                const int r = q / QX, qc = q - r * QX;
+                const int y = Y0 + r - HALO, x0 = X0 - G::XOFF + qc * 4;
+                const int ch = c * 16 + cg * 4;
+                const bool rowok = u < ROWS * QX * 4 && y >= 0 && y < p.H && ch < cin;
+                const long rowbase = ((long)img * p.H + y) * p.W;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    floatx4 a = {0.f, 0.f, 0.f, 0.f};
+                    const int x = x0 + i;
+                    if (rowok && x >= 0 && x < p.W) {
+                        if (ch < p.c0) {
+                            if (p.io & SRBH_WG_SRC0_H16)
+                                a = widen_h4(*(const float2w*)((const short*)p.src0 + (rowbase + x) * p.ld0 + ch));
+                            else
+                                a = *(const floatx4*)(p.src0 + (rowbase + x) * p.ld0 + ch);
+                            if (p.pre_scale) a = a * *(const floatx4*)(p.pre_scale + ch) + *(const floatx4*)(p.pre_shift + ch);
+                            if (p.pre_relu) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) a[j] = fmaxf(a[j], 0.f);
+                            }
+                        } else {
+                            a = *(const floatx4*)(p.src1 + (rowbase + x) * p.ld1 + (ch - p.c0));
+                        }
+                    }
+                    lx[it][i] = a;
+                }
+            }
+        };
+        auto store_x = [&]() {
+#pragma unroll
+            for (int it = 0; it < NIX; ++it) {
+                const int u = tid + it * 256;
+                if (u < ROWS * QX * 4) {
+                    const int cg = u & 3, q = u >> 2;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *(uint2w*)(s_x + (cg * 4 + j) * SX + q * 2) =
+                            uint2w{bf16_pair(lx[it][0][j], lx[it][1][j]), bf16_pair(lx[it][2][j], lx[it][3][j])};
+                }
+            }
+        };
+        {
+            ldv_t ld[NID][4], ld2[NID][4];
+            load_x(0);
+#pragma unroll
+            for (int it = 0; it < NID; ++it) {
+                const int u = tid + it * 256;
+                const int cg = u & 3, q = u >> 2;
+                const int y = Y0 + (q >> 4), x0 = X0 + (q & 15) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ldv_t a = ldv_t{}, a2 = ldv_t{};
+                    if (y < p.H && x0 + i < p.W) {
+                        const long off = ((((long)img * p.H + y) * p.W + x0 + i) * p.cout_total + ob * 16 + cg * 4) * (DS ? 2 : 4);
+                        a = *(const ldv_t*)((const char*)p.dy + off);
+                        a2 = *(const ldv_t*)((const char*)p.dy2 + off);
+                    }
+                    ld[it][i] = a;
+                    ld2[it][i] = a2;
+                }
+            }
+            __syncthreads();                       // the previous tile's fragment reads are done
+            store_x();
+#pragma unroll
+            for (int it = 0; it < NID; ++it) {
+                const int u = tid + it * 256;
+                const int cg = u & 3, q = u >> 2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (DS != 0) {
+                        *(uint2w*)(s_dy + (cg * 4 + j) * SD + q * 2) = uint2w{b16_field_pair(ld[it][0], ld[it][1], j), b16_field_pair(ld[it][2], ld[it][3], j)};
+                        *(uint2w*)(s_dy2 + (cg * 4 + j) * SD + q * 2) = uint2w{b16_field_pair(ld2[it][0], ld2[it][1], j), b16_field_pair(ld2[it][2], ld2[it][3], j)};
+                    } else {
+                        *(uint2w*)(s_dy + (cg * 4 + j) * SD + q * 2) = uint2w{bf16_pair(ld[it][0][j], ld[it][1][j]), bf16_pair(ld[it][2][j], ld[it][3][j])};
+                        *(uint2w*)(s_dy2 + (cg * 4 + j) * SD + q * 2) = uint2w{bf16_pair(ld2[it][0][j], ld2[it][1][j]), bf16_pair(ld2[it][2][j], ld2[it][3][j])};
+                    }
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c + 1 < NC) load_x(c + 1);          // (in flight under this chunk's MFMAs)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int row = wave * 2 + (ks >> 2), g = ks & 3;
+                const uint2w a2 = *(const uint2w*)(s_dy + l15 * SD + (row * 16 + g * 4 + kk) * 2);
+                const short4w a = __builtin_bit_cast(short4w, a2);
+                const unsigned* bp = s_x + l15 * SX + (row * QX + (G::XOFF >> 2) + g * 4 + kk) * 2;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const unsigned* rp = bp + dy * QX * 2;
+                    const uint2w cur = *(const uint2w*)rp;
+                    const unsigned pv = rp[-1], nx = rp[2];
+                    const unsigned mid = __builtin_amdgcn_alignbit(cur[1], cur[0], 16);
+                    const uint2w b0 = {__builtin_amdgcn_alignbit(cur[0], pv, 16), mid};
+                    const uint2w b2 = {mid, __builtin_amdgcn_alignbit(nx, cur[1], 16)};
+                    acc[c][dy * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, b0), acc[c][dy * 3 + 0], 0, 0, 0);
+                    acc[c][dy * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, cur), acc[c][dy * 3 + 1], 0, 0, 0);
+                    acc[c][dy * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, b2), acc[c][dy * 3 + 2], 0, 0, 0);
+                    if (dy == 1) {
+                        const uint2w d2 = *(const uint2w*)(s_dy2 + l15 * SD + (row * 16 + g * 4 + kk) * 2);
+                        acc2[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4w, d2), __builtin_bit_cast(short4w, cur), acc2[c], 0, 0, 0);
+                    }
+                }
+            }
+            if (c + 1 < NC) {
+                __syncthreads();                   // every wave has read chunk c's fragments
+                store_x();
+                __syncthreads();
+            }
+        }
+    }
+    // flush, chunk by chunk, in the layout of the chunk-outer kernel
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_red[((wave * TAPS + tp) * 16 + kk * 4 + r) * 16 + l15] = acc[c][tp][r];
+        __syncthreads();
+        for (int u = tid; u < TAPS * 256; u += 256) {
+            const float v = s_red[u] + s_red[TAPS * 256 + u] + s_red[2 * TAPS * 256 + u] + s_red[3 * TAPS * 256 + u];
+            p.ws[(((long)blockIdx.x * gridDim.y + ob) * NC + c) * (TAPS * 256) + u] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_red[(wave * 16 + kk * 4 + r) * 16 + l15] = acc2[c][r];
+        __syncthreads();
+        p.ws2[(((long)blockIdx.x * gridDim.y + ob) * NC + c) * 256 + tid] = s_red[tid] + s_red[256 + tid] + s_red[512 + tid] + s_red[768 + tid];
+    }
+}
+
 #include "srbh_hwgrad16_kernel.h"
 
 // Sum of the workgroups' partials in a fixed order (deterministic), two stages so that enough loads are in flight:
@@ -905,7 +1080,16 @@ extern "C" int srbh_hconv_wgrad_entry_b16(const srbh_hwgrad_args* a3, const srbh
     hipStream_t st = (hipStream_t)stream;
     const int cin = a3->c0 + a3->c1, nob = a3->cout / 16, nchunk = (cin + 15) / 16;
     const int gx = p.ntiles < 512 ? (p.ntiles + 7) / 8 * 8 : 512;
-    if (ds16) {
+    // (fuse == 2: the chunk-outer kernel also where the chunk-inner one applies -- same-box A/B aid)
+#define SRBH_ENTRY_INNER(DS_, NC_)                                                                                                              \
+    do {                                                                                                                                       \
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_entry_b16_kernel<DS_, NC_>, hipFuncAttributeMaxDynamicSharedMemorySize, WG16<3>::LDS_B2))); \
+        hipLaunchKernelGGL((hwgrad_entry_b16_kernel<DS_, NC_>), dim3(gx, nob), dim3(256), WG16<3>::LDS_B2, st, p);                                \
+    } while (0)
+    if (fuse == 1 && (nchunk == 2 || nchunk == 4)) {
+        if (ds16) { if (nchunk == 4) SRBH_ENTRY_INNER(1, 4); else SRBH_ENTRY_INNER(1, 2); }
+        else { if (nchunk == 4) SRBH_ENTRY_INNER(0, 4); else SRBH_ENTRY_INNER(0, 2); }
+    } else if (ds16) {
         SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_b16_kernel<3, 1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WG16<3>::LDS_B2)));
         hipLaunchKernelGGL((hwgrad_b16_kernel<3, 1, 0, 1>), dim3(gx, nob), dim3(256), WG16<3>::LDS_B2, st, p);
     } else {
