@@ -43,7 +43,9 @@ __device__ __forceinline__ short bf16_rne(float v) {
 template <int BF16>
 __device__ __forceinline__ short4v cvt4(const float a, const float b, const float c, const float d) {
     if constexpr (BF16 != 0) {
-        return short4v{bf16_rne(a), bf16_rne(b), bf16_rne(c), bf16_rne(d)};
+        typedef unsigned uint2p __attribute__((ext_vector_type(2)));
+        const uint2p pk = {bf16x2_rne(a, b), bf16x2_rne(c, d)};
+        return __builtin_bit_cast(short4v, pk);
     } else {
         const half4 h = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
         return __builtin_bit_cast(short4v, h);

@@ -38,12 +38,9 @@ __device__ __forceinline__ short4v round4(const float (&v)[4]) {
         for (int j = 0; j < 4; ++j) h[j] = (_Float16)v[j];
         r = __builtin_bit_cast(short4v, h);
     } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned u = __builtin_bit_cast(unsigned, v[j]);
-            const unsigned rounded = u + 0x7fffu + ((u >> 16) & 1u);          // round to nearest even (NaN/Inf do not occur here)
-            r[j] = (short)(rounded >> 16);
-        }
+        typedef unsigned uint2p __attribute__((ext_vector_type(2)));
+        const uint2p pk = {bf16x2_rne(v[0], v[1]), bf16x2_rne(v[2], v[3])};        // round to nearest even
+        r = __builtin_bit_cast(short4v, pk);
     }
     return r;
 }

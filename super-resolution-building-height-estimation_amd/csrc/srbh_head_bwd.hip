@@ -62,14 +62,7 @@ __device__ __forceinline__ floatx4 widen_b4(const float2w raw) {
                    __builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
 }
 __device__ __forceinline__ float2w narrow_b4(const floatx4 v) {      // fp32 -> bf16 (RNE), 4 elements as raw bits
-    const uint4q uv = __builtin_bit_cast(uint4q, v);
-    unsigned r[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned u = uv[j];
-        r[j] = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-    }
-    const uint2q o = {r[0] | (r[1] << 16), r[2] | (r[3] << 16)};
+    const uint2q o = {bf16x2_rne(v[0], v[1]), bf16x2_rne(v[2], v[3])};
     return __builtin_bit_cast(float2w, o);
 }
 // the 16-bit element j (0..3) of two raw quads a, b -> one dword (a's element in the low half)
@@ -266,12 +259,7 @@ __global__ __launch_bounds__(256) void hwgrad_f32_kernel(const WGParams p) {
 typedef short short4w __attribute__((ext_vector_type(4)));
 typedef unsigned uint2w __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ unsigned bf16_pair(float lo, float hi) {
-    unsigned a = __builtin_bit_cast(unsigned, lo), b = __builtin_bit_cast(unsigned, hi);
-    a += 0x7fffu + ((a >> 16) & 1u);
-    b += 0x7fffu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xffff0000u);
-}
+__device__ __forceinline__ unsigned bf16_pair(float lo, float hi) { return bf16x2_rne(lo, hi); }
 
 template <int KS>
 struct WG16 {

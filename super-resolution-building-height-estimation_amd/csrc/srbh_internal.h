@@ -83,4 +83,16 @@ int ptail_run(const srbh_conv3x3_args* a, hipStream_t stream, int* used);
 int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr, float* xrr, int B, int H, int W,
                void* aux, hipStream_t stream, int* used, int* final_cur);
 
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+// two fp32 -> one dword of bf16 (lo in the low half), round to nearest even: ONE v_cvt_pk_bf16_f32 on gfx950 (the integer sequence
+// u + 0x7fff + ((u >> 16) & 1) >> 16 it replaces is 4 VALU ops per element in kernels whose staging is VALU-bound; same bits for every
+// finite input and the infinities)
+__device__ __forceinline__ unsigned bf16x2_rne(float lo, float hi) {
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    const f2_t f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, b2_t));
+}
+#endif
 }  // namespace srbh
