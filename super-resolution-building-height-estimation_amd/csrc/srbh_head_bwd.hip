@@ -639,6 +639,165 @@ __global__ __launch_bounds__(256) void hwgrad_entry_b16_kernel(const WGParams p)
     }
 }
 
+// HRfeature's entry (cin = 64, the RRDBNet features handed over as fp16 NHWC: 128 bytes per pixel): the chunked kernels above read 32 bytes
+// of every pixel row per pass -- each load instruction touches 16 different 128-byte lines -- and ran at 0.11 of the HBM peak.  Here a lane
+// loads 16 bytes (8 channels) and 8 lanes cover a pixel's whole row, ALL FOUR chunks of a tile are staged at once (64 channel rows in LDS,
+// 130 KB with the two dY tiles: one workgroup per CU), and the next tile's global loads are issued before this tile's MFMAs (register
+// prefetch: 96 + 32 registers) -- the one workgroup per CU has nothing else to hide the load latency behind.  Same walk, wave -> row
+// assignment, products and flush as hwgrad_entry_b16_kernel<DS, 4>: bit-identical partial sums.
+struct WG64 {
+    using G = WG16<3>;
+    static constexpr int NIT = (G::ROWS * G::QX * 8 + 255) / 256;           // 16-byte units of the X tile per thread
+    static constexpr int LDS_B = (64 * G::SX + 32 * G::SD) * 4;
+};
+typedef unsigned uint4w __attribute__((ext_vector_type(4)));
+typedef _Float16 half8w __attribute__((ext_vector_type(8)));
+template <int DS>
+__global__ __launch_bounds__(256) void hwgrad_entry64_b16_kernel(const WGParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    using G = WG16<3>;
+    constexpr int TAPS = G::TAPS, ROWS = G::ROWS, QX = G::QX, SX = G::SX, SD = G::SD, NIT = WG64::NIT, NID = HT_H * 16 * 4 / 256, NC = 4;
+    static_assert(WG64::LDS_B >= 4 * TAPS * 256 * 4, "flush buffer must fit");
+    unsigned* s_x = (unsigned*)wsm;                 // [64 ci][SX]
+    unsigned* s_dy = s_x + 64 * SX;                 // [16 oc][SD]
+    unsigned* s_dy2 = s_dy + 16 * SD;
+    float* s_red = wsm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kk = lane >> 4;
+    const int ob = blockIdx.y;
+    typedef typename std::conditional<DS != 0, float2w, floatx4>::type ldv_t;
+    floatx4 acc[NC][TAPS];
+    floatx4 acc2[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) acc[c][tp] = floatx4{0.f, 0.f, 0.f, 0.f};
+        acc2[c] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    uint4w lx[NIT][4];
+    ldv_t ld[NID][4], ld2[NID][4];
+    auto load_tile = [&](const int t) {
+        const int img = t / p.tiles_per_img;
+        const int trem = t - img * p.tiles_per_img;
+        const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+        const int Y0 = ty * HT_H, X0 = tx * HT_W;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int u = tid + it * 256;
+            const int pc = u & 7, q = u >> 3;
+            const int r = q / QX, qc = q - r * QX;
+            const int y = Y0 + r - 1, x0 = X0 - G::XOFF + qc * 4;
+            const bool rowok = u < ROWS * QX * 8 && y >= 0 && y < p.H;
+            const short* rowp = (const short*)p.src0 + (((long)img * p.H + y) * p.W) * 64 + pc * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint4w a = {0u, 0u, 0u, 0u};
+                const int x = x0 + i;
+                if (rowok && x >= 0 && x < p.W) a = *(const uint4w*)(rowp + (long)x * 64);
+                lx[it][i] = a;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NID; ++it) {
+            const int u = tid + it * 256;
+            const int cg = u & 3, q = u >> 2;
+            const int y = Y0 + (q >> 4), x0 = X0 + (q & 15) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ldv_t a = ldv_t{}, a2 = ldv_t{};
+                if (y < p.H && x0 + i < p.W) {
+                    const long off = ((((long)img * p.H + y) * p.W + x0 + i) * p.cout_total + ob * 16 + cg * 4) * (DS ? 2 : 4);
+                    a = *(const ldv_t*)((const char*)p.dy + off);
+                    a2 = *(const ldv_t*)((const char*)p.dy2 + off);
+                }
+                ld[it][i] = a;
+                ld2[it][i] = a2;
+            }
+        }
+    };
+    const int t_end = min((int)(blockIdx.x & 7) * p.tiles_per_xcd + p.tiles_per_xcd, p.ntiles);
+    const int t_step = gridDim.x >> 3;
+    int t = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3);
+    if (t < t_end) load_tile(t);
+    for (; t < t_end; t += t_step) {
+        __syncthreads();                           // the previous tile's fragment reads are done
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int u = tid + it * 256;
+            if (u < ROWS * QX * 8) {
+                const int pc = u & 7, q = u >> 3;
+                const half8w h0 = __builtin_bit_cast(half8w, lx[it][0]), h1 = __builtin_bit_cast(half8w, lx[it][1]);
+                const half8w h2 = __builtin_bit_cast(half8w, lx[it][2]), h3 = __builtin_bit_cast(half8w, lx[it][3]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    *(uint2w*)(s_x + (pc * 8 + j) * SX + q * 2) =
+                        uint2w{bf16_pair((float)h0[j], (float)h1[j]), bf16_pair((float)h2[j], (float)h3[j])};
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NID; ++it) {
+            const int u = tid + it * 256;
+            const int cg = u & 3, q = u >> 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (DS != 0) {
+                    *(uint2w*)(s_dy + (cg * 4 + j) * SD + q * 2) = uint2w{b16_field_pair(ld[it][0], ld[it][1], j), b16_field_pair(ld[it][2], ld[it][3], j)};
+                    *(uint2w*)(s_dy2 + (cg * 4 + j) * SD + q * 2) = uint2w{b16_field_pair(ld2[it][0], ld2[it][1], j), b16_field_pair(ld2[it][2], ld2[it][3], j)};
+                } else {
+                    *(uint2w*)(s_dy + (cg * 4 + j) * SD + q * 2) = uint2w{bf16_pair(ld[it][0][j], ld[it][1][j]), bf16_pair(ld[it][2][j], ld[it][3][j])};
+                    *(uint2w*)(s_dy2 + (cg * 4 + j) * SD + q * 2) = uint2w{bf16_pair(ld2[it][0][j], ld2[it][1][j]), bf16_pair(ld2[it][2][j], ld2[it][3][j])};
+                }
+            }
+        }
+        __syncthreads();
+        if (t + t_step < t_end) load_tile(t + t_step);      // in flight under this tile's 4 x 80 MFMAs
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int row = wave * 2 + (ks >> 2), g = ks & 3;
+                const uint2w a2 = *(const uint2w*)(s_dy + l15 * SD + (row * 16 + g * 4 + kk) * 2);
+                const short4w a = __builtin_bit_cast(short4w, a2);
+                const unsigned* bp = s_x + (c * 16 + l15) * SX + (row * QX + (G::XOFF >> 2) + g * 4 + kk) * 2;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const unsigned* rp = bp + dy * QX * 2;
+                    const uint2w cur = *(const uint2w*)rp;
+                    const unsigned pv = rp[-1], nx = rp[2];
+                    const unsigned mid = __builtin_amdgcn_alignbit(cur[1], cur[0], 16);
+                    const uint2w b0 = {__builtin_amdgcn_alignbit(cur[0], pv, 16), mid};
+                    const uint2w b2 = {mid, __builtin_amdgcn_alignbit(nx, cur[1], 16)};
+                    acc[c][dy * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, b0), acc[c][dy * 3 + 0], 0, 0, 0);
+                    acc[c][dy * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, cur), acc[c][dy * 3 + 1], 0, 0, 0);
+                    acc[c][dy * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, b2), acc[c][dy * 3 + 2], 0, 0, 0);
+                    if (dy == 1) {
+                        const uint2w d2 = *(const uint2w*)(s_dy2 + l15 * SD + (row * 16 + g * 4 + kk) * 2);
+                        acc2[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(short4w, d2), __builtin_bit_cast(short4w, cur), acc2[c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_red[((wave * TAPS + tp) * 16 + kk * 4 + r) * 16 + l15] = acc[c][tp][r];
+        __syncthreads();
+        for (int u = tid; u < TAPS * 256; u += 256) {
+            const float v = s_red[u] + s_red[TAPS * 256 + u] + s_red[2 * TAPS * 256 + u] + s_red[3 * TAPS * 256 + u];
+            p.ws[(((long)blockIdx.x * gridDim.y + ob) * NC + c) * (TAPS * 256) + u] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_red[(wave * 16 + kk * 4 + r) * 16 + l15] = acc2[c][r];
+        __syncthreads();
+        p.ws2[(((long)blockIdx.x * gridDim.y + ob) * NC + c) * 256 + tid] = s_red[tid] + s_red[256 + tid] + s_red[512 + tid] + s_red[768 + tid];
+    }
+}
+
 #include "srbh_hwgrad16_kernel.h"
 
 // Sum of the workgroups' partials in a fixed order (deterministic), two stages so that enough loads are in flight:
@@ -1074,7 +1233,17 @@ extern "C" int srbh_hconv_wgrad_entry_b16(const srbh_hwgrad_args* a3, const srbh
         SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_entry_b16_kernel<DS_, NC_>, hipFuncAttributeMaxDynamicSharedMemorySize, WG16<3>::LDS_B2))); \
         hipLaunchKernelGGL((hwgrad_entry_b16_kernel<DS_, NC_>), dim3(gx, nob), dim3(256), WG16<3>::LDS_B2, st, p);                                \
     } while (0)
-    if (fuse == 1 && (nchunk == 2 || nchunk == 4)) {
+    // (fuse == 3: without the whole-row 64-channel kernel -- A/B aid)
+    if ((fuse == 1) && a3->c0 == 64 && a3->c1 == 0 && ld0 == 64 && (a3->io & SRBH_WG_SRC0_H16) && !a3->pre_scale && !a3->pre_relu &&
+        ((uintptr_t)a3->src0 & 15) == 0) {
+        if (ds16) {
+            SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_entry64_b16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WG64::LDS_B)));
+            hipLaunchKernelGGL((hwgrad_entry64_b16_kernel<1>), dim3(gx, nob), dim3(256), WG64::LDS_B, st, p);
+        } else {
+            SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_entry64_b16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WG64::LDS_B)));
+            hipLaunchKernelGGL((hwgrad_entry64_b16_kernel<0>), dim3(gx, nob), dim3(256), WG64::LDS_B, st, p);
+        }
+    } else if ((fuse == 1 || fuse == 3) && (nchunk == 2 || nchunk == 4)) {
         if (ds16) { if (nchunk == 4) SRBH_ENTRY_INNER(1, 4); else SRBH_ENTRY_INNER(1, 2); }
         else { if (nchunk == 4) SRBH_ENTRY_INNER(0, 4); else SRBH_ENTRY_INNER(0, 2); }
     } else if (ds16) {

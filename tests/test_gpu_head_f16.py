@@ -264,16 +264,19 @@ def test_block_entry_fused_conv_pair_equals_the_two_convs(c0, c1, hw, stats):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("c0,c1,x16,g16", [(64, 0, False, False), (64, 0, True, True), (16, 16, False, True), (16, 16, False, False), (32, 0, False, True)])
-def test_fused_entry_weight_gradients_equal_the_two_separate_calls(c0, c1, x16, g16):
+@pytest.mark.parametrize("c0,c1,x16,g16,shape", [(64, 0, False, False, (2, 20, 72)), (64, 0, True, True, (2, 20, 72)), (16, 16, False, True, (2, 20, 72)),
+                                                 (16, 16, False, False, (2, 20, 72)), (32, 0, False, True, (2, 20, 72)),
+                                                 (64, 0, True, False, (2, 20, 72)), (64, 0, True, True, (5, 250, 200)), (16, 16, False, True, (5, 250, 200))])
+def test_fused_entry_weight_gradients_equal_the_two_separate_calls(c0, c1, x16, g16, shape):
     """srbh_hconv_wgrad_entry_b16 (round 4): conv1's 3x3 and downsample[0]'s 1x1 weight gradients of a BasicBlock entry
     (SR/HRfuse.py:142-159) in ONE pass over the shared input -- the same bf16 products in the same order as the two separate
-    srbh_hconv_wgrad_b16 calls: bit-identical results; ragged size included."""
+    srbh_hconv_wgrad_b16 calls: bit-identical results; ragged size included.  The chunk-inner kernel (2 / 4 chunks) and the whole-row
+    kernel of the 64-channel fp16 features (its register prefetch of the next tile: 640 tiles on 512 workgroups) are these calls' paths."""
     from srbh_amd import hrfuse as H
     from srbh_amd import hrfuse_autograd as HA
     dev = "cuda:0"
     g = torch.Generator().manual_seed(c0 + c1)
-    B, Hh, Ww = 2, 20, 72                        # (not multiples of the 8 x 64 tile)
+    B, Hh, Ww = shape                            # (not multiples of the 8 x 64 tile)
     nhwc = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)        # noqa: E731
     x0 = nhwc(torch.randn((B, c0, Hh, Ww), generator=g))
     if x16:
