@@ -439,15 +439,28 @@ def synthetic_batch_device(batch, gen, device, aggregate=None):
     hval = torch.rand((batch, 1, 32, 32), generator=gen, device=device) ** 3 * 120.0
     height = torch.where(coarse > 0.82, hval, torch.zeros_like(hval))
     height = F.interpolate(height, scale_factor=8, mode="nearest").round()
-    edges = torch.tensor(HIR[1:-1], dtype=torch.float32, device=device)
+    edges, class_weight = _label_consts(device)
     build = torch.bucketize(height[:, 0], edges, right=True)
     build = torch.where(height[:, 0] <= 0, torch.zeros_like(build), build).long().clamp_(0, 6)
-    weight = torch.tensor(CLASS_WEIGHT, device=device)[build]
+    weight = class_weight[build]
     if aggregate is None:
         from .aggregate import aggregate_torch as aggregate
     height_aggre = aggregate(height, 0.25).reshape(batch, 64, 64)
     weight_aggre = aggregate(weight[:, None].contiguous(), 0.25).reshape(batch, 64, 64)
     return lr, height[:, 0], height_aggre, build, weight, weight_aggre
+
+
+_LABEL_CONSTS = {}
+
+
+def _label_consts(device):
+    """(class edges, class weights) on the device, made once: a torch.tensor(list, device=...) per step is a pageable host-to-device
+    copy that stalls the issuing thread -- inside the epoch loop that is the thread queueing the training step's launches"""
+    key = str(torch.device(device))
+    c = _LABEL_CONSTS.get(key)
+    if c is None:
+        c = _LABEL_CONSTS[key] = (torch.tensor(HIR[1:-1], dtype=torch.float32, device=device), torch.tensor(CLASS_WEIGHT, device=device))
+    return c
 
 
 def learnable_batch_device(batch, gen, device, aggregate=None):
@@ -461,10 +474,10 @@ def learnable_batch_device(batch, gen, device, aggregate=None):
     z = (v - 0.5) / 0.08333
     height = torch.where(z > 0.915, (z - 0.915) * 40.0 + 3.0, torch.zeros_like(z)).clamp_(0, 255)
     height = F.interpolate(height, scale_factor=8, mode="nearest").round()
-    edges = torch.tensor(HIR[1:-1], dtype=torch.float32, device=device)
+    edges, class_weight = _label_consts(device)
     build = torch.bucketize(height[:, 0], edges, right=True)
     build = torch.where(height[:, 0] <= 0, torch.zeros_like(build), build).long().clamp_(0, 6)
-    weight = torch.tensor(CLASS_WEIGHT, device=device)[build]
+    weight = class_weight[build]
     if aggregate is None:
         from .aggregate import aggregate_torch as aggregate
     height_aggre = aggregate(height, 0.25).reshape(batch, 64, 64)
