@@ -431,8 +431,15 @@ __global__ __launch_bounds__(256) void hconv_f32_kernel(const HParams p) {
                     const float* s = ps2_lds + (dy * 32 + px2) * PS2_PITCH + c4;
                     floatx4 t;
                     t[0] = s[0]; t[1] = s[1]; t[2] = s[2]; t[3] = s[3];
-                    if (Xg + (px2 >> 1) < p.W)
-                        *(floatx4*)(p.out + (((long)img * 2 * p.H + 2 * Y + dy) * (2 * p.W) + 2 * Xg + px2) * 16 + c4) = t;
+                    if (Xg + (px2 >> 1) < p.W) {
+                        const long o = (((long)img * 2 * p.H + 2 * Y + dy) * (2 * p.W) + 2 * Xg + px2) * 16 + c4;
+                        if (out16) {      // fp16 NHWC output (inference chain, round 4): the one rounding the consumer's staging would do
+                            const float t4[4] = {t[0], t[1], t[2], t[3]};
+                            *(short4v*)((short*)p.out + o) = round4<OPT == 0 ? 1 : OPT>(t4);
+                        } else {
+                            *(floatx4*)(p.out + o) = t;
+                        }
+                    }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the next group's writes
@@ -743,7 +750,7 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
     if (a->io_h16) {
         SRBH_REQUIRE(opt != 0, "srbh_hconv: 16-bit tensors in memory (io_h16) need srbh_hconv_h16 (element type = operand type: fp16 / bf16)");
         SRBH_REQUIRE((a->io_h16 & ~15) == 0, "srbh_hconv_h16: unknown io_h16 bits");
-        SRBH_REQUIRE(!(a->io_h16 & SRBH_IO_OUT_H16) || (!a->pixelshuffle2 && a->cout % 4 == 0 && p.out_ld % 4 == 0 && a->out_coff % 4 == 0),
+        SRBH_REQUIRE(!(a->io_h16 & SRBH_IO_OUT_H16) || ((!a->pixelshuffle2 || (HCONV_PS2_STAGE && a->cout == 64 && !a->res1)) && a->cout % 4 == 0 && p.out_ld % 4 == 0 && a->out_coff % 4 == 0),
                      "srbh_hconv_h16: a 16-bit output needs 4-aligned channels and no PixelShuffle store");
         SRBH_REQUIRE(!(a->io_h16 & SRBH_IO_RES1_H16) || (a->res1 && !a->res2), "srbh_hconv_h16: fp16 residual: res1 only");
         // the 16-bit staging of fp16 sources exists in the vectorised path only

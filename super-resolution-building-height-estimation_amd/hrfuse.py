@@ -196,8 +196,8 @@ def _hconv_args(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False,
     if any(t is not None and t.dtype == torch.bfloat16 for t in (x0, srcs[1] if c1 else None, res)):
         raise TypeError("libsrbh hconv (forward, fp16 operands): 16-bit tensors must be float16 (bfloat16 is the gradient kernels' type)")
     a.io_h16 = io
-    out = (empty_nhwc(B, cout // 4, 2 * H, 2 * W, x0.device) if ps2
-           else empty_nhwc(B, cout, H, W, x0.device, torch.float16 if out_h16 else torch.float32))
+    odt = torch.float16 if out_h16 else torch.float32
+    out = empty_nhwc(B, cout // 4, 2 * H, 2 * W, x0.device, odt) if ps2 else empty_nhwc(B, cout, H, W, x0.device, odt)
     a.out = out.data_ptr()
     if post is not None:
         a.post_scale, a.post_shift = post[0].data_ptr(), post[1].data_ptr()
@@ -400,7 +400,10 @@ class Upsampler(nn.Sequential):
         self._hip_ok = (scale & (scale - 1)) == 0 and not bn and not act
         self._packs = {}
 
-    def forward(self, x):
+    def forward(self, x, out_h16=False):
+        """out_h16 (inference chain, fp16-operand mode, n_feats == 16): the up-sampled tensor -- and the intermediate one -- as fp16 NHWC:
+        the PixelShuffle store rounds once where the consuming conv's staging would (same numbers), and every tensor written here is read
+        again at half the bytes"""
         _require_dev(x, "Upsampler")
         if not self._hip_ok:
             raise NotImplementedError("libsrbh Upsampler supports power-of-two scales without bn/act "
@@ -409,9 +412,10 @@ class Upsampler(nn.Sequential):
             from . import hrfuse_autograd as AG
             return AG.upsampler_forward(self, x)
         x = to_nhwc(x)
+        h16 = bool(out_h16) and fp16_chain(self) and all(m.out_channels == 64 for m in self if isinstance(m, nn.Conv2d))
         for i, mod in enumerate(self):
             if isinstance(mod, nn.Conv2d):
-                x, _ = hconv([x], mod, self._packs.setdefault(i, _PackedConv()), ps2=True)
+                x, _ = hconv([x], mod, self._packs.setdefault(i, _PackedConv()), ps2=True, out_h16=h16)
         return x
 
 
@@ -585,7 +589,7 @@ class HRfuse_residual(nn.Module):
     def forward(self, x_lr, x_hr):
         _require_dev(x_lr, "HRfuse_residual")
         _require_dev(x_hr, "HRfuse_residual", h16_ok=fp16_chain(self))      # (HRfeature(..., out_h16=True) inside the inference chain)
-        x_lr = self.upsampler(x_lr)
+        x_lr = self.upsampler(x_lr, out_h16=x_hr.dtype == torch.float16)    # (same element type as x_hr: the fused fp16 entry kernel)
         x = run_blocks(list(self.fuse), [x_lr, x_hr], fp16_chain(self))      # (conv_last reads the chain's fp16 output)
         return _LastConv.run(self, self.conv_last, x)
 

@@ -24,10 +24,11 @@ import os as _os
 # (inference: measured +12 % on the tiled-predict path; the training step is bound by the host's op dispatch and gains nothing),
 # "1" = always, "0" = never
 SIDE_STREAM = _os.environ.get("SRBH_SIDE_STREAM", "auto")
-# hrfeat's output as an fp16 tensor inside the inference chain (1) or fp32 (0, default since round 3: reg / seg read it next to the fp32
-# up-sampler output, and the fused block-entry kernel -- conv1 + the 1x1 downsample conv in one pass -- takes sources of ONE element type;
-# the two separate template launches it fell back to cost more than the fp16 tensor saved)
-HRFEAT_OUT_H16 = _os.environ.get("SRBH_HRFEAT_OUT_H16", "0") == "1"
+# hrfeat's output as an fp16 tensor inside the inference chain (1, default since round 4) or fp32 (0).  Round 3 had it off: reg / seg read
+# it next to the fp32 up-sampler output, and the fused block-entry kernel takes sources of ONE element type.  Since round 4 the
+# up-sampler's PixelShuffle store writes fp16 too (hrfuse.Upsampler.forward(out_h16=True)), so both sources of the reg / seg entries
+# are fp16: the same numbers (each value is rounded once, where the consumer's staging would round it), ~2 GB less traffic per 128 tiles.
+HRFEAT_OUT_H16 = _os.environ.get("SRBH_HRFEAT_OUT_H16", "1") == "1"
 
 
 class SRRegress_Cls_feature(torch.nn.Module):

@@ -149,3 +149,33 @@ def test_no_head_entry_point_falls_back_to_its_slow_form(monkeypatch):
     assert c["entry_fused"] == 3 and c["entry_split"] == 0, c
     assert c["wgrad_entry_fused"] == 3 and c["wgrad_entry_split"] == 0 and c["wgrad_f32"] == 0, c
     assert c["wgrad16"] >= 15, c
+
+
+def test_fp16_hrfeat_and_upsampler_hand_offs_do_not_change_a_bit(monkeypatch):
+    """Round 4: inside the inference chain HRfeature's output and the Upsampler's PixelShuffle outputs (SR/HRfuse.py:17-44,173-190) are
+    written as fp16 NHWC tensors -- each value rounded once, where the consuming conv's staging rounded the fp32 tensor -- so that both
+    sources of the reg / seg entry blocks are fp16 and go through the fused fp16 entry kernel: every output equals the fp32 hand-off's,
+    bit for bit; the Upsampler alone: fp16 result == the fp32 result rounded once."""
+    from oracle import synth
+    from srbh_amd import _lib, harness, models
+    from srbh_amd import hrfuse as H
+    net_hr, net = _nets()
+    net.eval()
+    x = synth.tiles(4, 8, 64, seed=13).to(DEV)
+    with torch.no_grad():
+        f16 = harness.features_for_head(net_hr, x[:, :3].contiguous())
+        net(x, f16)
+        torch.cuda.synchronize()
+        monkeypatch.setattr(models, "HRFEAT_OUT_H16", False)
+        b = net(x, f16)
+        monkeypatch.setattr(models, "HRFEAT_OUT_H16", True)
+        _lib.path_counters(reset=True)
+        a = net(x, f16)
+        paths = _lib.path_counters()
+        for u, v in zip(a, b):
+            assert u.dtype == torch.float32 and torch.equal(u, v)
+        assert paths["entry_fused"] >= 3 and paths["entry_split"] == 0, paths      # hrfeat's entry and both fuse entries: ONE launch each
+        lr16 = torch.randn((3, 16, 64, 64), device=DEV)
+        up = net.reg.upsampler
+        y32, y16 = up(lr16), up(lr16, out_h16=True)
+        assert y16.dtype == torch.float16 and y16.shape == (3, 16, 256, 256) and torch.equal(y16, y32.half())
