@@ -208,6 +208,8 @@ int srbh_hpack_conv_f32(const float* w_oihw, int cout, int cin, int ksize, int t
 
 /* bytes of the per-channel sum / sum-of-squares partial buffer written by srbh_hconv_f32 (C = cout padded to 16) */
 size_t srbh_bn_stats_bytes(int C);
+/* 1 when srbh_hconv_h16 takes pixelshuffle2 == 2 at this input size (W % 64 == 0, H % 4 == 0) */
+int srbh_hconv_up_supported(int H, int W);
 
 /* y = conv_{ksize}(cat(pre(src0), src1)) + bias, stride 1, zero padding ksize/2
  *   pre(x) = relu?(x*pre_scale[c] + pre_shift[c])  -- BatchNorm(+ReLU) of the producer folded into this consumer
@@ -225,7 +227,9 @@ typedef struct srbh_hconv_args {
     int cout;             /* 1..32 or 49..64 */
     int ksize;            /* 3 or 1 */
     int B, H, W;
-    int pixelshuffle2;
+    int pixelshuffle2;    /* 1: PixelShuffle(2) store (SR/HRfuse.py:23), out = (B, cout/4, 2H, 2W) NHWC.  2 (srbh_hconv_h16, fp16 operands, 16 -> 64, 3x3, no
+                           * pre / post ops, srbh_hconv_up_supported(H, W)): the same, with `w` / `bias` packed SUB-PIXEL-MAJOR -- row ob*16 + kk*4 + q of the
+                           * pack (srbh_hpack_conv_h16 of the permuted weight) holds conv channel (kk*4 + ob)*4 + q -- for the persistent Upsampler kernel */
     float* out;
     double* stats;
     /* optional extensions (0 / NULL = off), used by the strict fp32 trunk: strided views into wider NHWC buffers,

@@ -178,6 +178,7 @@ SIGNATURES = {
     "srbh_hpack_bytes": (_sz, [_i, _i, _i]),
     "srbh_hpack_conv_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "srbh_bn_stats_bytes": (_sz, [_i]),
+    "srbh_hconv_up_supported": (_i, [_i, _i]),
     "srbh_hconv_f32": (_i, [C.POINTER(HConvArgs), _vp]),
     "srbh_hpack_h16_bytes": (_sz, [_i, _i, _i]),
     "srbh_hpack_conv_h16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

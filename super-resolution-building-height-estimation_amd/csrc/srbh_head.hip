@@ -651,6 +651,7 @@ __global__ void nearest2x_kernel(const floatx4* __restrict__ src, floatx4* __res
 
 #include "srbh_hconv16_kernel.h"
 #include "srbh_hconv_entry_kernel.h"
+#include "srbh_hconv_up_kernel.h"
 
 template <int NOB, int KS, int RPW, int OPT = 0>
 int launch_hconv(HParams& p, int B, int H, int W, hipStream_t st) {
@@ -701,6 +702,8 @@ extern "C" int srbh_hpack_conv_f32(const float* w, int cout, int cin, int ksize,
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }
+
+extern "C" int srbh_hconv_up_supported(int H, int W) { return H > 0 && W > 0 && (W & 63) == 0 && (H & 3) == 0; }
 
 extern "C" size_t srbh_bn_stats_bytes(int C) { return C > 0 ? (size_t)NSLOT * 2 * C * sizeof(double) : 0; }
 
@@ -776,6 +779,26 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
         return nob == 1 ? launch_hconv<1, 1, 1, OPT_>(p, B, H, W, st)                                                       \
                         : (nob == 2 ? launch_hconv<2, 1, 1, OPT_>(p, B, H, W, st) : launch_hconv<4, 1, 1, OPT_>(p, B, H, W, st)); \
     } while (0)
+    if (a->pixelshuffle2 == 2) {      // the Upsampler conv with sub-pixel-major weight rows: its own persistent kernel (srbh_hconv_up_kernel.h)
+        const bool s16 = (a->io_h16 & SRBH_IO_SRC0_H16) != 0, o16u = (a->io_h16 & SRBH_IO_OUT_H16) != 0;
+        SRBH_REQUIRE(opt == 1 && a->ksize == 3 && a->c0 == 16 && a->c1 == 0 && a->cout == 64 && !a->pre_scale && !a->pre_relu && !a->res1 && !a->res2 &&
+                     !a->stats && !a->post_scale && !a->post_relu && !a->post_lrelu && !a->bstat_c && srbh_hconv_up_supported(H, W) && (p.ld0 & 3) == 0 &&
+                     ((uintptr_t)a->src0 & (s16 ? 7 : 15)) == 0 && ((uintptr_t)a->out & (o16u ? 7 : 15)) == 0 && (a->io_h16 & ~(SRBH_IO_SRC0_H16 | SRBH_IO_OUT_H16)) == 0,
+                     "srbh_hconv_h16: pixelshuffle2 == 2 (sub-pixel-major pack) is the fp16 16 -> 64 3x3 form without pre / post ops, W %% 64 == 0, H %% 4 == 0");
+        static const int up_wgs = getenv("SRBH_HCONV_UP_WGS") ? atoi(getenv("SRBH_HCONV_UP_WGS")) : 768;
+        p.tiles_x = W / 64;
+        p.tiles_per_img = p.tiles_x * (H / 4);
+        p.ntiles = p.tiles_per_img * B;
+        p.tiles_per_xcd = (p.ntiles + 7) / 8;
+        const int per_xcd = p.tiles_per_xcd < up_wgs / 8 ? p.tiles_per_xcd : up_wgs / 8;
+        constexpr int LDSUP = 2 * 6 * 66 * 32 + 36 * 64 * 8;
+        if (s16 && o16u) hipLaunchKernelGGL((hconv_up_kernel<1, 1>), dim3(per_xcd * 8), dim3(256), LDSUP, st, p);
+        else if (s16) hipLaunchKernelGGL((hconv_up_kernel<1, 0>), dim3(per_xcd * 8), dim3(256), LDSUP, st, p);
+        else if (o16u) hipLaunchKernelGGL((hconv_up_kernel<0, 1>), dim3(per_xcd * 8), dim3(256), LDSUP, st, p);
+        else hipLaunchKernelGGL((hconv_up_kernel<0, 0>), dim3(per_xcd * 8), dim3(256), LDSUP, st, p);
+        SRBH_HIP(hipGetLastError());
+        return SRBH_OK;
+    }
     // the dominant layer shape has its own persistent, double-buffered kernel (srbh_hconv16_kernel.h)
     static const int k16_wgs = getenv("SRBH_HCONV16_WGS") ? atoi(getenv("SRBH_HCONV16_WGS")) : 768;     // 0 = always the template
     const bool src16 = (a->io_h16 & SRBH_IO_SRC0_H16) != 0, o16 = (a->io_h16 & SRBH_IO_OUT_H16) != 0, r16 = (a->io_h16 & SRBH_IO_RES1_H16) != 0;

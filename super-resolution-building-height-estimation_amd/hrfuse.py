@@ -137,14 +137,20 @@ class _PackedConv:
         self.w = None
         self.b = None
 
-    def get(self, conv: nn.Conv2d, h16=False):
+    def get(self, conv: nn.Conv2d, h16=False, up=False):
+        """up: the Upsampler kernel's SUB-PIXEL-MAJOR row order (include/srbh.h, srbh_hconv_args.pixelshuffle2 == 2): packed row
+        ob*16 + kk*4 + q = conv channel (kk*4 + ob)*4 + q of a 64-channel weight (and bias)"""
         w = conv.weight
-        key = (w._version, w.data_ptr(), None if conv.bias is None else (conv.bias._version, conv.bias.data_ptr()), bool(h16),
+        key = (w._version, w.data_ptr(), None if conv.bias is None else (conv.bias._version, conv.bias.data_ptr()), bool(h16), bool(up),
                wcache.gen(w, conv.bias))            # (fused optimizers do not bump _version, see wcache.py)
         if key != self.key:
             L = _lib.lib()
             cout, cin, ks, _ = w.shape
             wc = w.detach().float().contiguous()
+            perm = None
+            if up:
+                perm = _up_perm(w.device)
+                wc = wc.index_select(0, perm)
             if h16:
                 buf = torch.empty(L.srbh_hpack_h16_bytes(cout, cin, ks) // 2, dtype=torch.float16, device=w.device)
                 _lib.check(L.srbh_hpack_conv_h16(wc.data_ptr(), cout, cin, ks, 0, 0, buf.data_ptr(), _lib.stream_ptr()), "hpack_conv_h16")
@@ -155,11 +161,27 @@ class _PackedConv:
             b = None
             if conv.bias is not None:
                 b = torch.zeros((cout + 15) // 16 * 16, dtype=torch.float32, device=w.device)
-                b[:cout] = conv.bias.detach().float()
+                b[:cout] = conv.bias.detach().float() if perm is None else conv.bias.detach().float().index_select(0, perm)
             # (no host sync: `wc` is recycled by torch's stream-ordered allocator, and the pack kernel runs on that stream)
             self.key, self.w, self.b = key, buf, b
         wcache.keep(self.w, self.b)
         return self.w, self.b
+
+
+# the Upsampler's 16 -> 64 conv + PixelShuffle(2) on its own persistent kernel (csrc/srbh_hconv_up_kernel.h) whenever the fp16-operand forms
+# run and the shape is the kernel's; SRBH_HCONV_UP=0: the template with its LDS-ordered PixelShuffle store (A/B aid; same bits)
+HCONV_UP = _os.environ.get("SRBH_HCONV_UP", "1") == "1"
+_UP_PERM = {}
+
+
+def _up_perm(device):
+    """perm[ob*16 + kk*4 + q] = (kk*4 + ob)*4 + q: which conv channel sits in which row of the sub-pixel-major pack"""
+    key = str(device)
+    t = _UP_PERM.get(key)
+    if t is None:
+        t = _UP_PERM[key] = torch.tensor([(kk * 4 + ob) * 4 + q for ob in range(4) for kk in range(4) for q in range(4)], dtype=torch.int64,
+                                         device=device)
+    return t
 
 
 def _hconv_args(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_stats=False, post=None, res=None,
@@ -177,7 +199,9 @@ def _hconv_args(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False,
     if cin != c0 + c1:
         raise ValueError(f"conv expects {cin} input channels, got {c0}+{c1}")
     h16 = head_h16()
-    w, b = packed.get(conv, h16)
+    up = bool(ps2 and h16 and HCONV_UP and pre is None and post is None and res is None and not want_stats and not post_relu and cout == 64
+              and c0 == 16 and c1 == 0 and ks == 3 and L.srbh_hconv_up_supported(H, W))
+    w, b = packed.get(conv, h16, up)
     a = _lib.HConvArgs()
     a.src0, a.c0 = x0.data_ptr(), c0
     if pre is not None:
@@ -188,7 +212,7 @@ def _hconv_args(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False,
     a.bias = b.data_ptr() if b is not None else None
     a.cout, a.ksize = cout, ks
     a.B, a.H, a.W = B, H, W
-    a.pixelshuffle2 = int(ps2)
+    a.pixelshuffle2 = 2 if up else int(ps2)
     io = ((1 if x0.dtype in _T16 else 0) | (2 if c1 and srcs[1].dtype in _T16 else 0)
           | (4 if res is not None and res.dtype in _T16 else 0) | (8 if out_h16 else 0))
     if io and not h16:

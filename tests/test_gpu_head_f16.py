@@ -350,3 +350,46 @@ def test_narrow_input_data_gradient_on_the_persistent_kernel(cout_fwd):
     rel = lambda a, w: float((a.double() - w).norm() / w.norm())      # noqa: E731
     assert rel(dx, want) <= 2e-6
     assert rel(dxr, want + res.double()) <= 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,hw", [(2, 64), (3, 32), (1, 128), (5, 64)])
+def test_upsampler_persistent_kernel_equals_the_template(B, hw, monkeypatch):
+    """Round 4: the Upsampler's conv3x3 16 -> 64 + PixelShuffle(2) (SR/HRfuse.py:17-44) on hconv_up_kernel -- persistent walk, weights
+    packed sub-pixel-major so that the PixelShuffle store needs no LDS pass (srbh_hconv_args.pixelshuffle2 == 2) -- against the template
+    kernel with the standard pack: the same products in the same order, bit-identical, for fp32 and fp16 outputs and fp16 intermediates;
+    a 32 x 32 input takes the template for its first conv (W % 64 != 0) and the new kernel for the second; the training-mode forward
+    (fp16 operands) goes through the same kernel and its gradients do not change."""
+    from srbh_amd import hrfuse as H
+    dev = "cuda:0"
+    torch.manual_seed(B * 7 + hw)
+    up = H.Upsampler(scale=4, n_feats=16).to(dev).eval()
+    with torch.no_grad():
+        for p in up.parameters():
+            p.mul_(3.0)                              # (biases and weights of visible size)
+    x = torch.randn((B, 16, hw, hw), device=dev)
+    outs = {}
+    for flag in (True, False):
+        monkeypatch.setattr(H, "HCONV_UP", flag)
+        for m in up._packs.values():
+            m.key = None
+        with torch.no_grad():
+            outs[flag] = (up(x), up(x, out_h16=True))
+    assert outs[True][0].shape == (B, 16, 4 * hw, 4 * hw) and outs[True][1].dtype == torch.float16
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    assert float(outs[True][0].abs().max()) > 0.1
+    # training mode, fp16-operand head: forward through the same kernel, gradients from the unchanged gradient kernels
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(H, "HCONV_UP", flag)
+        up.train()
+        for p in up.parameters():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        with H.head_precision("f16"):
+            y = up(xg)
+            y.square().sum().backward()
+        res[flag] = (y.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in up.parameters()])
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for a, b in zip(res[True][2], res[False][2]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
