@@ -252,7 +252,10 @@ typedef struct srbh_hconv_args {
      * output is the gradient da of a = relu(bn(c)).  With bstat_c (the BatchNorm input, NHWC fp32 [B][H][W][16]), the batch mean / invstd
      * and the folded affine (ms, mh: a > 0 <=> c*ms + mh > 0; both NULL = no ReLU) given, `stats` receives sum(dz) and sum(dz * xhat),
      * dz = da where the ReLU was active -- exactly what srbh_bn_bwd_reduce computes in a pass of its own (pass the same buffer to
-     * srbh_bn_bwd_finalize).  No res1; cout == 16. */
+     * srbh_bn_bwd_finalize).  No res1; cout == 16.  With a bf16 output (SRBH_IO_OUT_H16) the sums are taken from the fp32 accumulators
+     * BEFORE the one rounding of the store, whereas the separate reduce pass (srbh_bn_bwd_reduce_io) sums the rounded tensor: dgamma /
+     * dbeta / the mean terms of the two paths differ by bf16 rounding noise averaged over B*H*W elements (not bit-comparable;
+     * tests/test_gpu_io16.py bounds it) -- fp16 also drops the out "no PixelShuffle" rule for the full 16 -> 64 conv (see pixelshuffle2). */
     const float* bstat_c; const float* bstat_mean; const float* bstat_invstd; const float* bstat_ms; const float* bstat_mh;
 } srbh_hconv_args;
 #define SRBH_IO_SRC0_H16 1
