@@ -927,6 +927,21 @@ extern "C" int srbh_hconv_entry_h16(const srbh_hconv_args* c1, const srbh_hconv_
     const int per_xcd = p.tiles_per_xcd < wgs / 8 ? p.tiles_per_xcd : wgs / 8;
     const int lds_b = 2 * 6 * 66 * 32 + e.nchunk * 640 * 8;
     const bool eo16 = (c1->io_h16 & SRBH_IO_OUT_H16) != 0;
+    static const int e64 = getenv("SRBH_HCONV_ENTRY64") ? atoi(getenv("SRBH_HCONV_ENTRY64")) : 1;     // 0: the chunked kernel (A/B aid)
+    if (e64 && es16 && !bf16 && c1->c0 == 64 && c1->c1 == 0 && ld0 == 64 && ((uintptr_t)c1->src0 & 15) == 0) {
+        // HRfeature's entry on whole 128-byte pixel rows, one workgroup per CU (srbh_hconv_entry_kernel.h)
+        constexpr int LDS64 = 2 * 4 * 6 * 66 * 32 + 4 * 640 * 8;
+        const int px64 = p.tiles_per_xcd < 32 ? p.tiles_per_xcd : 32;
+        if (eo16) {
+            SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hconv_entry64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64)));
+            hipLaunchKernelGGL((hconv_entry64_kernel<1>), dim3(px64 * 8), dim3(256), LDS64, st, e);
+        } else {
+            SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hconv_entry64_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64)));
+            hipLaunchKernelGGL((hconv_entry64_kernel<0>), dim3(px64 * 8), dim3(256), LDS64, st, e);
+        }
+        SRBH_HIP(hipGetLastError());
+        return SRBH_OK;
+    }
     if (es16 && eo16) hipLaunchKernelGGL((hconv_entry_kernel<1, 1, 1>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);
     else if (es16) hipLaunchKernelGGL((hconv_entry_kernel<1, 0, 1>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);
     else if (bf16 && eo16) hipLaunchKernelGGL((hconv_entry_kernel<2, 1>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);

@@ -179,3 +179,33 @@ def test_fp16_hrfeat_and_upsampler_hand_offs_do_not_change_a_bit(monkeypatch):
         up = net.reg.upsampler
         y32, y16 = up(lr16), up(lr16, out_h16=True)
         assert y16.dtype == torch.float16 and y16.shape == (3, 16, 256, 256) and torch.equal(y16, y32.half())
+
+
+@pytest.mark.parametrize("B,Hh,Ww,stats,o16", [(2, 8, 128, True, False), (3, 12, 64, False, True), (5, 256, 256, True, False), (1, 4, 64, False, False)])
+def test_whole_row_entry_kernel_equals_the_chunked_entry(B, Hh, Ww, stats, o16):
+    """Round 4: HRfeature's entry (SR/HRfuse.py:142-159, 64 fp16 channels) on hconv_entry64_kernel -- 16-byte loads, 8 lanes per 128-byte
+    pixel row, all four chunks of a tile staged at once -- against the chunked fused kernel fed with the SAME values as an fp32 tensor
+    (which it rounds to the same halves): both outputs bit-identical (fp32 and fp16 outputs, with and without the BatchNorm statistics),
+    the statistics equal up to their order of addition; 5 x 256 x 256 = 1 280 tiles on 256 workgroups walks several tiles per workgroup."""
+    import torch.nn as nn
+    from srbh_amd import _lib
+    from srbh_amd import hrfuse as H
+    g = torch.Generator().manual_seed(B * 100 + Ww)
+    x16 = (torch.randn((B, 64, Hh, Ww), generator=g) * 0.7).to(DEV).half().contiguous(memory_format=torch.channels_last)
+    x32 = x16.float().contiguous(memory_format=torch.channels_last)
+    conv1, convd = nn.Conv2d(64, 16, 3, 1, 1, bias=False).to(DEV), nn.Conv2d(64, 16, 1, bias=False).to(DEV)
+    post = ((torch.rand(16, generator=g) + 0.5).to(DEV), torch.randn(16, generator=g).to(DEV))
+    with H.head_precision("f16"), torch.no_grad():
+        kw = dict(want_stats=stats, out_h16=o16) if stats or o16 else {}
+        if not stats:
+            kw.update(post1=post, post1_relu=True, postd=post)
+        _lib.path_counters(reset=True)
+        a = H.hconv_entry([x16], conv1, H._PackedConv(), convd, H._PackedConv(), **kw)
+        b = H.hconv_entry([x32], conv1, H._PackedConv(), convd, H._PackedConv(), **kw)
+        assert _lib.path_counters()["entry_fused"] == 2
+    assert a[0].dtype == (torch.float16 if o16 else torch.float32)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and float(a[0].float().abs().max()) > 0
+    if stats:
+        fold = lambda t: t.view(-1, 2, 16).sum(0)
+        for u, v in ((a[1], b[1]), (a[3], b[3])):
+            assert torch.allclose(fold(u), fold(v), rtol=2e-5, atol=1e-3), (fold(u) - fold(v)).abs().max()     # (fp32 partial sums per workgroup, other tile sets)
