@@ -601,6 +601,10 @@ typedef struct srbh_dconv_pack_desc {
 int srbh_dconv_pack_many(const srbh_dconv_pack_desc* table, int n, void* stream);
 int srbh_dconv_supported(int B, int Cin, int Cout, int H, int W);
 int srbh_dconv_fwd(const float* x, const void* wpack, float* y, int B, int Cin, int Cout, int H, int W, int bf16, void* stream);
+/* the same conv with y = act(conv * scale[co] + shift[co]) in its store: a decoder block's inference BatchNorm (folded, srbh_bn_eval_scale_shift)
+ * and ReLU (act 2; 0 = none) without a pass of their own (smp DecoderBlock's Conv2dReLU, mymodels.py:245-258 in eval mode) */
+int srbh_dconv_fwd_epi(const float* x, const void* wpack, float* y, int B, int Cin, int Cout, int H, int W, int bf16, const float* scale,
+                       const float* shift, int act, void* stream);
 size_t srbh_dconv_wgrad_ws_floats(int B, int Cin, int Cout, int H, int W);
 int srbh_dconv_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int Cout, int H, int W, void* stream);
 

@@ -229,6 +229,7 @@ SIGNATURES = {
     "srbh_dconv_pack_many": (_i, [_vp, _i, _vp]),
     "srbh_dconv_supported": (_i, [_i, _i, _i, _i, _i]),
     "srbh_dconv_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "srbh_dconv_fwd_epi": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "srbh_dconv_wgrad_ws_floats": (_sz, [_i, _i, _i, _i, _i]),
     "srbh_dconv_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "srbh_pwconv_supported": (_i, [_i, _i, _i, _i]),

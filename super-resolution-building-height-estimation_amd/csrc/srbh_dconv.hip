@@ -62,6 +62,9 @@ struct DCParams {
     const short* w;       // [chunk][tap][ob][lane][4]
     float* y;             // [B][Cout][W][W]
     int B, Cin, Cout, nchunk, nob;
+    const float* scale;   // [Cout] folded inference BatchNorm (null: none)
+    const float* shift;
+    int act;              // 0 none | 2 ReLU (after the affine)
 };
 
 // square planes W x W, W = 1 << LOGW (4 ... 64); NPX pixels per workgroup (64 | 256), 16 MB output channels per workgroup
@@ -211,7 +214,12 @@ __global__ __launch_bounds__(256) void dconv_kernel(const DCParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = (ob0 + mb) * 16 + kg * 4 + r;
-                if (ok && co < p.Cout) p.y[obase + (long)co * PP] = acc[mb][nb][r];
+                if (ok && co < p.Cout) {
+                    float v = acc[mb][nb][r];
+                    if (p.scale) v = fmaf(v, p.scale[co], p.shift[co]);      // (inference: BatchNorm + ReLU of the decoder block in the conv's store)
+                    if (p.act == 2) v = fmaxf(v, 0.f);
+                    p.y[obase + (long)co * PP] = v;
+                }
             }
     }
 }
@@ -437,12 +445,25 @@ extern "C" int srbh_dconv_supported(int B, int Cin, int Cout, int H, int W) {
  * wpack = srbh_hpack_conv_h16(w, Cout, Cin, 3, transpose_flip, bf16, ...).  bf16 = 0: fp16 operands (forward); bf16 = 1: bf16
  * operands -- with the transposed + flipped pack of the forward weight (cout := forward Cin, cin := forward Cout) this is the data
  * gradient dX = conv^T(dY, W). */
+static int dconv_fwd_impl(const float* x, const void* wpack, float* y, int B, int Cin, int Cout, int H, int W, int bf16, const float* scale,
+                          const float* shift, int act, void* stream);
 extern "C" int srbh_dconv_fwd(const float* x, const void* wpack, float* y, int B, int Cin, int Cout, int H, int W, int bf16, void* stream) {
+    return dconv_fwd_impl(x, wpack, y, B, Cin, Cout, H, W, bf16, nullptr, nullptr, 0, stream);
+}
+/* the same conv with y = act(conv * scale[co] + shift[co]) in its store (inference: the decoder block's BatchNorm folded to an affine, + ReLU) */
+extern "C" int srbh_dconv_fwd_epi(const float* x, const void* wpack, float* y, int B, int Cin, int Cout, int H, int W, int bf16, const float* scale,
+                                  const float* shift, int act, void* stream) {
+    SRBH_REQUIRE((scale == nullptr) == (shift == nullptr) && (act == 0 || act == 2), "srbh_dconv_fwd_epi: bad epilogue");
+    return dconv_fwd_impl(x, wpack, y, B, Cin, Cout, H, W, bf16, scale, shift, act, stream);
+}
+static int dconv_fwd_impl(const float* x, const void* wpack, float* y, int B, int Cin, int Cout, int H, int W, int bf16, const float* scale,
+                          const float* shift, int act, void* stream) {
     SRBH_REQUIRE(x && wpack && y, "srbh_dconv_fwd: null pointer");
     SRBH_REQUIRE(srbh_dconv_supported(B, Cin, Cout, H, W), "srbh_dconv_fwd: unsupported geometry B=%d Cin=%d Cout=%d H=%d W=%d (square planes 4..64)", B, Cin, Cout, H, W);
     DCParams p;
     p.x = x; p.w = (const short*)wpack; p.y = y;
     p.B = B; p.Cin = Cin; p.Cout = Cout; p.nchunk = (Cin + 15) / 16; p.nob = (Cout + 15) / 16;
+    p.scale = scale; p.shift = shift; p.act = act;
     const FwdPlan pl = plan_fwd(B, Cout, W);
     hipStream_t st = (hipStream_t)stream;
     switch (log2_exact(W)) {

@@ -706,6 +706,31 @@ def decoder_conv(conv, x):
     return conv(x)
 
 
+DCONV_EVAL_EPI = __import__("os").environ.get("SRBH_DCONV_EVAL_EPI", "1") == "1"      # inference: BatchNorm + ReLU in the decoder conv's store
+
+
+def _decoder_conv_bn_relu_eval(conv, bn, x):
+    """inference: relu(bn(conv(x))) of a decoder block as ONE libsrbh launch (srbh_dconv_fwd_epi), or None when not applicable"""
+    if not (DCONV and DCONV_EVAL_EPI and _fused_eval_ok(bn, x) and x.dim() == 4 and conv.bias is None and conv.weight.dtype == torch.float32
+            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.groups == 1):
+        return None
+    from . import _lib
+    from . import hrfuse as _H
+    B, Cin, H, W = x.shape
+    Cout = conv.weight.shape[0]
+    if not (_H.head_h16() and _lib.lib().srbh_dconv_supported(B, Cin, Cout, H, W)):
+        return None
+    packs = conv.__dict__.get("_srbh_dconv_packs")
+    if packs is None:
+        packs = conv.__dict__["_srbh_dconv_packs"] = _DecoderConvPacks()
+    scale, shift = _bn_affine(bn, x.device)
+    x = x.contiguous()
+    y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().srbh_dconv_fwd_epi(x.data_ptr(), packs.fwd(conv.weight).data_ptr(), y.data_ptr(), B, Cin, Cout, H, W, 0, scale.data_ptr(),
+                                             shift.data_ptr(), 2, _lib.stream_ptr()), "dconv_fwd_epi")
+    return y
+
+
 class _ConvBnRelu(nn.Sequential):
     def __init__(self, cin, cout, use_batchnorm=True):
         mods = [nn.Conv2d(cin, cout, 3, padding=1, bias=not use_batchnorm)]
@@ -717,6 +742,10 @@ class _ConvBnRelu(nn.Sequential):
 
     def forward(self, x):
         if self._bn:
+            if not self[1].training and x.is_cuda:
+                y = _decoder_conv_bn_relu_eval(self[0], self[1], x)
+                if y is not None:
+                    return y
             return bn_act(self[1], decoder_conv(self[0], x), "relu")
         return super().forward(x)
 

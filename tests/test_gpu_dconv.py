@@ -137,3 +137,37 @@ def test_pack_table_equals_per_conv_packs():
             dec(*feats)
             assert pt.key != k0 and torch.equal(pt.convs[3]._srbh_dconv_packs.f, E._DecoderConvPacks().fwd(pt.convs[3].weight))
     assert rel(got, want) <= 3e-3
+
+
+@pytest.mark.parametrize("B", [1, 5, 32])
+def test_inference_batchnorm_relu_in_the_conv_store(B, monkeypatch):
+    """Round 4: in eval mode a decoder block's BatchNorm (folded) + ReLU ride in the conv's store (srbh_dconv_fwd_epi) instead of a pass of
+    their own: the whole U-Net decoder against the conv + separate affine pass (same fma, same bits expected; bound 1e-6), all ten conv
+    shapes of the model, non-trivial running statistics; the call count says every block took the fused form."""
+    from srbh_amd import encoders as E
+    from srbh_amd import hrfuse as H
+    torch.manual_seed(3)
+    enc_ch = (8, 48, 32, 56, 160, 448)
+    dec = E.UnetDecoder(enc_ch, (256, 128, 64, 32, 16), n_blocks=5, use_batchnorm=True, center=False, attention_type=None).to(DEV)
+    feats = [torch.randn((B, c, 64 >> i, 64 >> i), device=DEV) for i, c in enumerate(enc_ch)]
+    dec.train()
+    with torch.no_grad(), H.head_precision("f16"):
+        for _ in range(2):
+            dec(*[f[:max(2, B)] if B >= 2 else torch.cat([f, f]) for f in feats])
+    dec.eval()
+    calls = {"n": 0}
+    real = E._decoder_conv_bn_relu_eval
+
+    def counting(conv, bn, x):
+        y = real(conv, bn, x)
+        calls["n"] += y is not None
+        return y
+    with torch.no_grad():
+        assert H.head_h16()
+        monkeypatch.setattr(E, "_decoder_conv_bn_relu_eval", counting)
+        a = dec(*feats)
+        assert calls["n"] == 10, calls
+        monkeypatch.setattr(E, "DCONV_EVAL_EPI", False)
+        b = dec(*feats)
+        assert calls["n"] == 10
+    assert a.shape == (B, 16, 64, 64) and rel(a, b) <= 1e-6 and float(a.min()) >= 0.0
