@@ -708,7 +708,7 @@ def main():
         line = bench_feature(args, rank, world, dev, dist)
         if not args.no_extras and args.num_block == 23 and args.batch == 32:
             extras = {}
-            for key, fn in (("train_step", lambda: bench_train(args, rank, world, dev, dist, 5, 2, batch=64,
+            for key, fn in (("train_step", lambda: bench_train(args, rank, world, dev, dist, 10, 5, batch=64,      # (5 warm-up steps: with 2 the step still ran 1.6 ms above its steady state)
                                                                 with_cpu=not args.no_cpu_baseline)),
                             ("predict", lambda: bench_predict(args, rank, world, dev, dist, 30, 1, batch=128))):
                 try:
