@@ -639,6 +639,154 @@ __global__ __launch_bounds__(256) void hwgrad_entry_b16_kernel(const WGParams p)
     }
 }
 
+// Weight gradient of a conv with ONE input chunk and NOB output blocks (the Upsampler's 16 -> 64 convs, SR/HRfuse.py:17-44: dY = the
+// PixelShuffle-inverted gradient, 64 channels): hwgrad_b16_kernel runs grid.y = NOB workgroups per tile, each staging the same X tile
+// (the fp32 -> bf16 4x4 register transposes that bound these kernels).  Here the X tile is staged once and the NOB dY blocks follow one
+// another through the dY buffer (block ob + 1's loads issued before block ob's MFMAs), NOB x 9 accumulators in registers.  Same walk,
+// wave -> row assignment, products and flush layout as the chunk-outer kernel with grid.y = NOB: bit-identical partial sums.
+template <int DS, int NOB>
+__global__ __launch_bounds__(256) void hwgrad_ob_b16_kernel(const WGParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    using G = WG16<3>;
+    constexpr int TAPS = G::TAPS, HALO = G::HALO, ROWS = G::ROWS, QX = G::QX, SX = G::SX, SD = G::SD;
+    unsigned* s_x = (unsigned*)wsm;                 // [16 ci][SX]
+    unsigned* s_dy = s_x + 16 * SX;                 // [16 oc][SD]
+    float* s_red = wsm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kk = lane >> 4;
+    const int cin = p.c0;
+    floatx4 acc[NOB][TAPS];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) acc[ob][tp] = floatx4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NIX = (ROWS * QX * 4 + 255) / 256, NID = HT_H * 16 * 4 / 256;
+    typedef typename std::conditional<DS != 0, float2w, floatx4>::type ldv_t;
+    const int t_end = min((int)(blockIdx.x & 7) * p.tiles_per_xcd + p.tiles_per_xcd, p.ntiles);
+    for (int t = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3); t < t_end; t += gridDim.x >> 3) {
+        const int img = t / p.tiles_per_img;
+        const int trem = t - img * p.tiles_per_img;
+        const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+        const int Y0 = ty * HT_H, X0 = tx * HT_W;
+        ldv_t ld[NID][4];
+        auto load_dy = [&](const int ob) {
+#pragma unroll
+            for (int it = 0; it < NID; ++it) {
+                const int u = tid + it * 256;
+                const int cg = u & 3, q = u >> 2;
+                const int y = Y0 + (q >> 4), x0 = X0 + (q & 15) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ldv_t a = ldv_t{};
+                    if (y < p.H && x0 + i < p.W)
+                        a = *(const ldv_t*)((const char*)p.dy + ((((long)img * p.H + y) * p.W + x0 + i) * p.cout_total + ob * 16 + cg * 4) * (DS ? 2 : 4));
+                    ld[it][i] = a;
+                }
+            }
+        };
+        auto store_dy = [&]() {
+#pragma unroll
+            for (int it = 0; it < NID; ++it) {
+                const int u = tid + it * 256;
+                const int cg = u & 3, q = u >> 2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (DS != 0)
+                        *(uint2w*)(s_dy + (cg * 4 + j) * SD + q * 2) = uint2w{b16_field_pair(ld[it][0], ld[it][1], j), b16_field_pair(ld[it][2], ld[it][3], j)};
+                    else
+                        *(uint2w*)(s_dy + (cg * 4 + j) * SD + q * 2) = uint2w{bf16_pair(ld[it][0][j], ld[it][1][j]), bf16_pair(ld[it][2][j], ld[it][3][j])};
+                }
+            }
+        };
+        {
+            floatx4 lx[NIX][4];
+#pragma unroll
+            for (int it = 0; it < NIX; ++it) {
+                const int u = tid + it * 256;
+                const int cg = u & 3, q = u >> 2;
+                const int r = q / QX, qc = q - r * QX;
+                const int y = Y0 + r - HALO, x0 = X0 - G::XOFF + qc * 4;
+                const int ch = cg * 4;
+                const bool rowok = u < ROWS * QX * 4 && y >= 0 && y < p.H && ch < cin;
+                const long rowbase = ((long)img * p.H + y) * p.W;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    floatx4 a = {0.f, 0.f, 0.f, 0.f};
+                    const int x = x0 + i;
+                    if (rowok && x >= 0 && x < p.W) {
+                        if (p.io & SRBH_WG_SRC0_H16)
+                            a = widen_h4(*(const float2w*)((const short*)p.src0 + (rowbase + x) * p.ld0 + ch));
+                        else
+                            a = *(const floatx4*)(p.src0 + (rowbase + x) * p.ld0 + ch);
+                        if (p.pre_scale) a = a * *(const floatx4*)(p.pre_scale + ch) + *(const floatx4*)(p.pre_shift + ch);
+                        if (p.pre_relu) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) a[j] = fmaxf(a[j], 0.f);
+                        }
+                    }
+                    lx[it][i] = a;
+                }
+            }
+            load_dy(0);
+            __syncthreads();                       // the previous tile's fragment reads are done
+#pragma unroll
+            for (int it = 0; it < NIX; ++it) {
+                const int u = tid + it * 256;
+                if (u < ROWS * QX * 4) {
+                    const int cg = u & 3, q = u >> 2;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *(uint2w*)(s_x + (cg * 4 + j) * SX + q * 2) =
+                            uint2w{bf16_pair(lx[it][0][j], lx[it][1][j]), bf16_pair(lx[it][2][j], lx[it][3][j])};
+                }
+            }
+            store_dy();
+            __syncthreads();
+        }
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+            if (ob + 1 < NOB) load_dy(ob + 1);      // (in flight under this block's MFMAs)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int row = wave * 2 + (ks >> 2), g = ks & 3;
+                const uint2w a2 = *(const uint2w*)(s_dy + l15 * SD + (row * 16 + g * 4 + kk) * 2);
+                const short4w a = __builtin_bit_cast(short4w, a2);
+                const unsigned* bp = s_x + l15 * SX + (row * QX + (G::XOFF >> 2) + g * 4 + kk) * 2;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const unsigned* rp = bp + dy * QX * 2;
+                    const uint2w cur = *(const uint2w*)rp;
+                    const unsigned pv = rp[-1], nx = rp[2];
+                    const unsigned mid = __builtin_amdgcn_alignbit(cur[1], cur[0], 16);
+                    const uint2w b0 = {__builtin_amdgcn_alignbit(cur[0], pv, 16), mid};
+                    const uint2w b2 = {mid, __builtin_amdgcn_alignbit(nx, cur[1], 16)};
+                    acc[ob][dy * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, b0), acc[ob][dy * 3 + 0], 0, 0, 0);
+                    acc[ob][dy * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, cur), acc[ob][dy * 3 + 1], 0, 0, 0);
+                    acc[ob][dy * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, __builtin_bit_cast(short4w, b2), acc[ob][dy * 3 + 2], 0, 0, 0);
+                }
+            }
+            if (ob + 1 < NOB) {
+                __syncthreads();                   // every wave has read block ob's dY fragments
+                store_dy();
+                __syncthreads();
+            }
+        }
+    }
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        __syncthreads();
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_red[((wave * TAPS + tp) * 16 + kk * 4 + r) * 16 + l15] = acc[ob][tp][r];
+        __syncthreads();
+        for (int u = tid; u < TAPS * 256; u += 256) {
+            const float v = s_red[u] + s_red[TAPS * 256 + u] + s_red[2 * TAPS * 256 + u] + s_red[3 * TAPS * 256 + u];
+            p.ws[((long)blockIdx.x * NOB + ob) * (TAPS * 256) + u] = v;          // (= the chunk-outer layout with grid.y = NOB, nchunk = 1)
+        }
+    }
+}
+
 // HRfeature's entry (cin = 64, the RRDBNet features handed over as fp16 NHWC: 128 bytes per pixel): the chunked kernels above read 32 bytes
 // of every pixel row per pass -- each load instruction touches 16 different 128-byte lines -- and ran at 0.11 of the HBM peak.  Here a lane
 // loads 16 bytes (8 channels) and 8 lanes cover a pixel's whole row, ALL FOUR chunks of a tile are staged at once (64 channel rows in LDS,
@@ -1133,6 +1281,7 @@ int wgrad_impl(const srbh_hwgrad_args* a, void* stream, bool b16, const char* wh
                  "srbh_hconv_wgrad_b16: an fp16 source tensor needs the bf16-operand forms (4-aligned channels, 16-channel output blocks)");
     SRBH_REQUIRE(!ds16 || k16 || can16, "srbh_hconv_wgrad_b16: a bf16 dY needs 4-aligned channels / 16-channel output blocks");
     count_path(k16 ? PATH_WGRAD16 : (b16 && can16) ? PATH_WGRAD_B16_GENERIC : PATH_WGRAD_F32);
+    static const int ob_inner = getenv("SRBH_WGRAD_OB_INNER") ? atoi(getenv("SRBH_WGRAD_OB_INNER")) : 1;      // 0: grid.y = output blocks (A/B aid)
     if (k16) {
         p.tiles_x = a->W / 64;
         p.tiles_per_img = p.tiles_x * (a->H / 4);
@@ -1152,6 +1301,16 @@ int wgrad_impl(const srbh_hwgrad_args* a, void* stream, bool b16, const char* wh
         else if (ds16) SRBH_WG16(0, 1);
         else SRBH_WG16(0, 0);
 #undef SRBH_WG16
+    } else
+    if (b16 && can16 && a->ksize == 3 && a->c1 == 0 && cin <= 16 && nob == 4 && ob_inner) {
+        // one input chunk, four output blocks (the Upsampler's 16 -> 64 convs): X staged once per tile, the dY blocks inside the walk
+        if (ds16) {
+            SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_ob_b16_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, WG16<3>::LDS_B)));
+            hipLaunchKernelGGL((hwgrad_ob_b16_kernel<1, 4>), dim3(gx), dim3(256), WG16<3>::LDS_B, st, p);
+        } else {
+            SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hwgrad_ob_b16_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, WG16<3>::LDS_B)));
+            hipLaunchKernelGGL((hwgrad_ob_b16_kernel<0, 4>), dim3(gx), dim3(256), WG16<3>::LDS_B, st, p);
+        }
     } else
     if (b16 && can16) {
 #define SRBH_WGB(K_, D_)                                                                                                               \

@@ -392,4 +392,34 @@ def test_upsampler_persistent_kernel_equals_the_template(B, hw, monkeypatch):
         res[flag] = (y.detach().clone(), xg.grad.clone(), [p.grad.clone() for p in up.parameters()])
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
     for a, b in zip(res[True][2], res[False][2]):
-        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+        # (weight gradients are deterministic; the bias gradients come out of atomically added partial sums -- order-dependent last bits
+        #  of sums of ~1e5 terms, bounded against the LARGEST element: an element-wise rtol failed for small sums in ~1 of 7 runs)
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Hh,Ww,g16", [(2, 20, 72, False), (3, 64, 64, False), (5, 250, 200, False), (2, 24, 64, True)])
+def test_upsampler_weight_gradient_with_the_output_blocks_inside_the_walk(B, Hh, Ww, g16):
+    """Round 4: the 16 -> 64 weight gradient (the Upsampler convs, SR/HRfuse.py:17-44) on hwgrad_ob_b16_kernel -- X staged once per tile, the
+    four dY blocks inside the tile walk -- against float64 products of the SAME bf16-rounded operands (what remains is fp32 summation
+    order); ragged sizes, 640 tiles on 512 workgroups, fp32 and bf16 dY."""
+    import torch.nn.functional as F
+    from srbh_amd import hrfuse as H
+    from srbh_amd import hrfuse_autograd as HA
+    from srbh_amd import _lib
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(B + Ww)
+    nhwc = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)        # noqa: E731
+    x = nhwc(torch.randn((B, 16, Hh, Ww), generator=g))
+    gy = nhwc(torch.randn((B, 64, Hh, Ww), generator=g) * 1e-2)
+    if g16:
+        gy = gy.bfloat16()
+    with H.head_precision("f16"), torch.no_grad():
+        _lib.path_counters(reset=True)
+        dw = HA.conv_wgrad([x], None, gy, 64, 3)
+        assert _lib.path_counters()["wgrad_b16_generic"] == 1
+    xr, gr = x.bfloat16().double(), gy.bfloat16().double()
+    w0 = torch.zeros((64, 16, 3, 3), dtype=torch.float64, device=dev, requires_grad=True)
+    F.conv2d(xr, w0, padding=1).mul(gr).sum().backward()
+    assert dw.shape == (64, 16, 3, 3)
+    assert float((dw.double() - w0.grad).norm() / w0.grad.norm()) <= 1e-5
