@@ -208,4 +208,5 @@ def test_whole_row_entry_kernel_equals_the_chunked_entry(B, Hh, Ww, stats, o16):
     if stats:
         fold = lambda t: t.view(-1, 2, 16).sum(0)
         for u, v in ((a[1], b[1]), (a[3], b[3])):
-            assert torch.allclose(fold(u), fold(v), rtol=2e-5, atol=1e-3), (fold(u) - fold(v)).abs().max()     # (fp32 partial sums per workgroup, other tile sets)
+            # (fp32 partial sums per workgroup over other tile sets; bounded against the largest moment, not element-wise)
+            assert float((fold(u) - fold(v)).abs().max()) <= 1e-5 * float(fold(v).abs().max())

@@ -320,8 +320,11 @@ def test_relu_bit_pattern_equals_the_fp32_reference_in_the_backward_reduce(C, sh
     assert dz0.dtype == dz1.dtype and torch.equal(dz0, dz1)          # the masked gradient: elementwise, identical
     assert float((dz0.float() == 0).float().mean()) > 0.2            # ... and really masked
     # the sums go through atomics (order-dependent last bits), and dc carries their means: close, not identical
-    assert torch.allclose(dg0, dg1, rtol=1e-4, atol=1e-5) and torch.allclose(db0, db1, rtol=1e-4, atol=1e-5)
-    assert dc0.dtype == dc1.dtype and torch.allclose(dc0.float(), dc1.float(), rtol=2e-2 if b16 else 1e-4, atol=1e-4)
+    # (bounded against the LARGEST element: a sum that happens to land near zero carries the same absolute noise as the others, and an
+    #  element-wise rtol on it failed once in a few full-suite runs)
+    close = lambda u, v, tol: float((u.double() - v.double()).abs().max()) <= tol * float(v.double().abs().max())      # noqa: E731
+    assert close(dg0, dg1, 1e-4) and close(db0, db1, 1e-4)
+    assert dc0.dtype == dc1.dtype and close(dc0.float(), dc1.float(), 2e-2 if b16 else 1e-4)
 
 
 @pytest.mark.gpu
