@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 GFLOP_PER_TILE_FEATURE = 146.630   # 2*9*Cin*Cout*H*W over the 350 convs of forward_feature
+GFLOP_PER_TILE_PREDICT = 155.65    # + eval head 8.12 + encoder / decoders ~0.9
 PEAK_F16_TFLOPS = 2500.0           # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md), never the sparse figure
 PEAK_F32_MFMA_TFLOPS = 157.3       # dense fp32 matrix rate
 PEAK_HBM_GBS = 8000.0              # HBM3E
@@ -55,15 +56,24 @@ def _host_cores():
     return cores
 
 
-def _recorded_traffic():
+def _recorded_traffic(kernel_name):
     """HBM bytes per trunk launch from the newest PMC summary under profiles/ (tools/pmc_traffic.py: separate rocprofv3
-    --pmc passes of this very command, FETCH_SIZE doubled per the guide).  A recorded constant, NOT measured in this run."""
+    --pmc passes of this very command, FETCH_SIZE doubled per the guide).  A recorded constant, NOT measured in this run:
+    a file whose dominant kernel is not the kernel this run launched (`srbh_trunk_kernel_name()`) is REFUSED (-> null),
+    so the figure cannot silently outlive the kernel it was measured on."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
     for f in reversed(files):
         try:
-            return json.load(open(f))["dominant_kernel_hbm_bytes_per_launch"], "profiles/" + os.path.basename(f)
+            rec = json.load(open(f))
+            val = rec["dominant_kernel_hbm_bytes_per_launch"]
         except Exception:
             continue
+        names = [k.split(" grid=")[0] for k, e in sorted(rec.get("kernels", {}).items(), key=lambda kv: -kv[1].get("launches", 0))
+                 if "ptrunk" in k and "reset" not in k]
+        rec_name = rec.get("dominant_kernel", names[0] if names else None)
+        if rec_name is None or kernel_name is None or rec_name.split("<")[0] != kernel_name.split("<")[0]:
+            return None, f"profiles/{os.path.basename(f)} REFUSED: recorded on '{rec_name}', this run launched '{kernel_name}'"
+        return val, "profiles/" + os.path.basename(f)
     return None, None
 
 
@@ -184,6 +194,31 @@ def _make_nets(args, dev, isaggre):
 _DETAILS = {}          # full per-call tables of the run (written by --details; the printed line carries the top rows only)
 
 
+def _dist_info(dist):
+    """what the process group actually is: proves which backend carried the collectives and how many ranks it saw"""
+    if dist is None:
+        return {"backend": None, "world_size_seen": 1, "rccl_version": None}
+    ver = None
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        pass
+    return {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "rccl_version": ver}
+
+
+def _recorded_301():
+    """the builder's own full-size configs[4] run (all 301 cities), newest file under profiles/: a RECORDED figure, named as such"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_predict_301cities.json.log")))
+    for f in reversed(files):
+        try:
+            rec = json.loads([ln for ln in open(f).read().splitlines() if ln.startswith("{")][-1])
+            return {"file": "profiles/" + os.path.basename(f), "tiles_per_s": rec.get("value"),
+                    "p50_city_latency_ms": rec.get("p50_city_latency_ms"), "note": "RECORDED builder run, not measured in this run"}
+        except Exception:
+            continue
+    return None
+
+
 def _max_over_ranks(vals, dev, dist):
     if dist is None:
         return vals
@@ -280,6 +315,7 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
                                            "the mode the <=5e-5 gradient-parity tests pin); the headline's 'f16' mode keeps outputs <= 1e-3 but "
                                            "its gradients are only direction-accurate (cos >= 0.99, median rel 3e-2 vs the exact graph)"}
     if comm:
+        comm.update(_dist_info(dist))
         line["comm"] = comm
     if with_kernels:
         # per-kernel rooflines: the trunk launch inside THIS step (HIP events via libsrbh's hook), the head kernels on their own
@@ -287,15 +323,19 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
         from srbh_amd import _lib
         L = _lib.lib()
         ks = []
+        acc = 0.0
         if L.srbh_trunk_timing(1) == 0:
-            acc = 0.0
-            for _ in range(3):
-                with torch.no_grad():
-                    net_hr.forward_feature(fixed[0][:, :3])
-                ms = ctypes.c_float(0.0)
-                _lib.check(L.srbh_trunk_last_ms(ctypes.byref(ms)), "srbh_trunk_last_ms")
-                acc += ms.value
+            try:
+                for _ in range(3):
+                    with torch.no_grad():
+                        net_hr.forward_feature(fixed[0][:, :3])
+                    ms = ctypes.c_float(0.0)
+                    _lib.check(L.srbh_trunk_last_ms(ctypes.byref(ms)), "srbh_trunk_last_ms")
+                    acc += ms.value
+            except RuntimeError:      # SRBH_PERSISTENT=0 (per-layer launches: no single trunk kernel to time) -> no trunk row
+                acc = 0.0
             L.srbh_trunk_timing(0)
+        if acc > 0.0:
             tg = args.num_block * 3 * 4096 * 18 * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64) / 1e9 * batch
             ks.append({"kernel": f"persistent trunk (345 dense-block convs), B={batch}", "bound": "mfma", "avg_launch_ms": round(acc / 3, 4),
                        "algorithmic_gflop_per_launch": round(tg, 1), "achieved": round(tg / (acc / 3), 2), "peak": PEAK_F16_TFLOPS,
@@ -304,6 +344,7 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
         with _H.head_precision(ts.head_precision):
             ks += head_kernel_rooflines(dev, batch)
         line["kernels"] = ks
+    if with_kernels and world == 1:       # (N > 1: the other ranks have returned -- a further step's all-reduce would have no partner)
         # the WHOLE head (+ losses) of this very step against the HBM roofline: every libsrbh call of two extra steps bracketed by
         # HIP events and priced with the algorithmic bytes its arguments imply (srbh_amd/kprof.py); outside the timed region
         from srbh_amd.kprof import KernelProfile
@@ -433,6 +474,12 @@ def bench_predict(args, rank, world, dev, dist, n_cities, warmup, batch=128, sma
                          "tiles_per_s": round(sum(c for c in todo if c > 10000) / max(1e-9, sum(l for c, l in zip(todo, lat) if c > 10000)), 2)
                          if any(c > 10000 for c in todo) else None},
         "tail_shapes_run": sorted({(c % batch + 31) // 32 * 32 for c in todo if c % batch}) if pad_to else None,
+        "roofline": {"bound": "mfma", "achieved": round(total / elapsed / world * GFLOP_PER_TILE_PREDICT / 1e3, 2), "peak": PEAK_F16_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(total / elapsed / world * GFLOP_PER_TILE_PREDICT / 1e3 / PEAK_F16_TFLOPS, 4),
+                     "gflop_per_tile": GFLOP_PER_TILE_PREDICT, "trunk_share_of_flops": round(135.44 / GFLOP_PER_TILE_PREDICT, 3),
+                     "note": "whole predict path PER GPU (RRDBNet forward_feature 146.63 + eval head 8.12 + encoder/decoders 0.9 GFLOP per tile, "
+                             "SURVEY 8d) incl. tile generation hand-off, quantise and mosaic: not one kernel; the trunk kernel's own fraction is the headline's `roofline`"},
+        "dist": _dist_info(dist),
         "head_paths_eager_calls": {k: v for k, v in head_paths.items() if v}}
 
 
@@ -553,7 +600,8 @@ def bench_feature(args, rank, world, dev, dist):
     L = _lib.lib()
     trunk_gflop_tile = args.num_block * 3 * 4096 * 18 * (64 * 32 + 96 * 32 + 128 * 32 + 160 * 32 + 192 * 64) / 1e9
     trunk_ms = None
-    if L.srbh_trunk_timing(1) == 0:
+    strict = bool(net._use_strict())          # SRBH_TRUNK_PRECISION=f32 / net.precision: exact-fp32 matrix cores, one launch per conv
+    if not strict and L.srbh_trunk_timing(1) == 0:
         acc, nrep = 0.0, max(5, min(20, args.steps))
         try:
             for _ in range(nrep):
@@ -566,37 +614,44 @@ def bench_feature(args, rank, world, dev, dist):
             trunk_ms = None
         L.srbh_trunk_timing(0)
     trunk_tflops = trunk_gflop_tile * B / (trunk_ms / 1e3) / 1e3 if trunk_ms else None
-    traffic, traffic_src = (None, None)
-    if B == 32 and args.num_block == 23:
-        traffic, traffic_src = _recorded_traffic()
     kname = "unknown"
     try:
         kname = L.srbh_trunk_kernel_name().decode()
     except Exception:
         pass
+    traffic, traffic_src = (None, None)
+    if B == 32 and args.num_block == 23 and not strict and trunk_ms:
+        traffic, traffic_src = _recorded_traffic(kname)
+    if strict:
+        dtype = "f32 operands / f32 accumulate (v_mfma_f32_16x16x4_f32, one launch per conv), f32 residual stream"
+        peak = PEAK_F32_MFMA_TFLOPS
+    else:
+        dtype = "f16 operands / f32 accumulate (MFMA), f32 residual stream"
+        peak = PEAK_F16_TFLOPS
     line = {
         "metric": "tiles/sec (64x64x8ch->256x256 height)", "value": round(tiles / elapsed, 2), "unit": "tiles/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f16 operands / f32 accumulate (MFMA), f32 residual stream",
+        "vs_baseline": None, "dtype": dtype,
         "data": "synthetic uniform[0,1) tiles, random-init weights (no datasets/checkpoints offline)",
         "config": {"workload": f"RRDBNet x4 ({args.num_block} RRDB, 64 feat) forward_feature, batch {B} tiles/GPU, "
                                "64x64x3 -> 64x256x256 (BASELINE.json configs[1])",
                    "global_batch": B * world, "parallelism": f"tile-sharded x{world} (no data-path collective)"},
-        "roofline": {"bound": "mfma", "achieved": round(trunk_tflops, 2) if trunk_tflops else None, "peak": PEAK_F16_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(trunk_tflops / PEAK_F16_TFLOPS, 4) if trunk_tflops else None,
+        "roofline": {"bound": "mfma", "achieved": round(trunk_tflops, 2) if trunk_tflops else None, "peak": peak,
+                     "unit": "TFLOP/s", "frac": round(trunk_tflops / peak, 4) if trunk_tflops else None,
                      "traffic": traffic,
-                     "traffic_source": (f"{traffic_src} (RECORDED: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                        "command, FETCH doubled per the guide; not measured in this run)") if traffic_src else None,
-                     "power_capped_peak": {
+                     "traffic_source": ((f"{traffic_src} (RECORDED: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                         "command, FETCH doubled per the guide; not measured in this run)") if traffic is not None else traffic_src),
+                     "power_capped_peak": None if strict else {
                          "what": "tools/mfma_ceiling.hip on this package (RECORDED, profiles/r04k_mfma_ceiling.txt): v_mfma_f32_32x32x16_f16 back to back, one wave "
                                  "per SIMD, 256 CUs, real trunk operands, seconds-long runs: MFMA only / + the trunk's LDS read mix / + its weight LDS-DMA stream",
                          "tflops": [1659.6, 1563.3, 1516.1], "frac_of_2500": [0.664, 0.625, 0.606], "sclk_mhz": [1640, 1557, 1561],
                          "frac_of_measured_ceiling": round(trunk_tflops / 1516.1, 4) if trunk_tflops else None},
-                     "kernel": f"{kname} (persistent trunk: 345 dense-block 3x3 convs in one launch)",
+                     "kernel": ("hconv_f32_kernel per conv (strict fp32: no single dominant kernel; see whole_forward)" if strict else
+                                f"{kname} (persistent trunk: 345 dense-block 3x3 convs in one launch)"),
                      "avg_launch_ms": round(trunk_ms, 4) if trunk_ms else None,
                      "algorithmic_gflop_per_launch": round(trunk_gflop_tile * B, 1),
-                     "whole_forward": {"achieved": round(tflops, 2), "frac": round(tflops / PEAK_F16_TFLOPS, 4),
+                     "whole_forward": {"achieved": round(tflops, 2), "frac": round(tflops / peak, 4),
                                        "gflop": round(achieved * B, 1), "ms": round(step_s_events * 1e3, 4)}},
     }
     # strict-fp32 GPU path (exact-fp32 matrix cores, one launch per conv) on ONE tile of the sample the CPU leg uses: the on-device
@@ -710,7 +765,7 @@ def main():
             extras = {}
             for key, fn in (("train_step", lambda: bench_train(args, rank, world, dev, dist, 10, 5, batch=64,      # (5 warm-up steps: with 2 the step still ran 1.6 ms above its steady state)
                                                                 with_cpu=not args.no_cpu_baseline)),
-                            ("predict", lambda: bench_predict(args, rank, world, dev, dist, 30, 1, batch=128))):
+                            ("predict", lambda: bench_predict(args, rank, world, dev, dist, int(os.environ.get("SRBH_BENCH_PREDICT_CITIES", "30")), 1, batch=128))):
                 try:
                     extras[key] = _compact(fn())
                 except Exception as e:          # the headline must survive a failing extra (and say so)
@@ -735,7 +790,16 @@ def main():
                         "encdec_stock_op_calls_2steps": ((t.get("encdec_kernels") or {}).get("stock_ops") or {}).get("calls"),
                         "cpu_baseline_tiles_per_s": (t.get("cpu_baseline") or {}).get("value")},
                     "predict_30_of_301_cities": {"error": p_["error"]} if "error" in p_ else {
-                        "tiles_per_s": p_.get("value"), "p50_city_latency_ms": p_.get("p50_city_latency_ms")},
+                        "tiles_per_s": p_.get("value"), "p50_city_latency_ms": p_.get("p50_city_latency_ms"),
+                        "frac_mfma_peak_per_gpu": (p_.get("roofline") or {}).get("frac"),
+                        "all_301_cities_source": _recorded_301()},
+                    # the fwd+bwd curve of BASELINE's metric at THIS N (configs[2] at N=1, configs[3]'s step at N>1) and what the process
+                    # group was: a SCALE record carries the gradient all-reduce whatever the headline workload is
+                    "dp_train": {"error": t["error"]} if "error" in t else dict(
+                        {"tiles_per_s": t.get("value"), "ms_per_step": t.get("ms_per_step"), "n_gpus": world,
+                         "comm_ms": (t.get("comm") or {}).get("comm_ms"), "exposed_comm_ms": (t.get("comm") or {}).get("exposed_comm_ms"),
+                         "buckets": (t.get("comm") or {}).get("buckets"), "grad_bytes": (t.get("comm") or {}).get("grad_bytes")},
+                        **_dist_info(dist)),
                 }
     if rank == 0:
         if args.details and _DETAILS:
