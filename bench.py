@@ -678,6 +678,26 @@ def bench_feature(args, rank, world, dev, dist):
                                    "max_abs_over_absmax": round(float((y_fast - y_ref).abs().max() / y_ref.abs().max()), 7),
                                    "strict_f32_gpu_path_rel_l2": round(rel(y_strict, y_ref), 9),
                                    "ref_rms": round(float(y_ref.pow(2).mean().sqrt()), 5)}
+    if not args.no_extras and args.num_block == 23 and not strict:
+        # the same comparison over several draws (weights x {init, stress} x inputs) against the strict-fp32 GPU path -- itself pinned to
+        # ~1e-6 of the CPU oracle (above and tests/test_gpu_rrdbnet.py); the full sweep against the oracle is tests/test_gpu_parity_sweep.py
+        sw = []
+        xs = torch.cat([_synth.tiles(1, 8, 64, seed=s_)[:, :3] for s_ in (1337, 77)]).contiguous().to(dev)
+        for mode in ("init", "stress"):
+            for ws in (1337, 1, 2, 3):
+                net.load_state_dict(_synth.rrdbnet_state_dict(num_block=args.num_block, seed=ws, mode=mode), strict=True)
+                with torch.no_grad():
+                    yf = net.forward_feature(xs).float()
+                    net.precision = "f32"
+                    ys = net.forward_feature(xs).float()
+                    del net.precision
+                sw += [rel(yf[i:i + 1], ys[i:i + 1]) for i in range(xs.shape[0])]
+        net.check_status()
+        net.load_state_dict(sd, strict=True)
+        sw.sort()
+        parity["sweep_max_rel_l2"] = round(sw[-1], 7)
+        parity["sweep"] = {"draws": len(sw), "what": "4 weight seeds x {init, stress} x 2 input tiles, fast path vs strict-fp32 GPU path",
+                           "min": round(sw[0], 7), "median": round(sw[len(sw) // 2], 7), "max": round(sw[-1], 7)}
     line["parity"] = parity
     return line
 
@@ -779,6 +799,7 @@ def main():
                 line["summary"] = {
                     "feature_b32": {"tiles_per_s": line["value"], "ms_per_step": line["ms_per_step"], "trunk_frac_mfma_peak": line["roofline"]["frac"],
                                     "trunk_ms": line["roofline"]["avg_launch_ms"], "rel_l2_vs_cpu_oracle": par.get("rel_l2"),
+                                    "sweep_max_rel_l2": (line.get("parity") or {}).get("sweep_max_rel_l2"),
                                     "weights": "random-init (no trained checkpoint offline)"},
                     "train_step_b64": {"error": t["error"]} if "error" in t else {
                         "credited_strict_f32_head": {"ms_per_step": (t.get("strict_f32_head") or {}).get("ms_per_step"),

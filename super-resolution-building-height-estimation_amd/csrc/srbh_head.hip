@@ -797,6 +797,7 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
         else if (o16u) hipLaunchKernelGGL((hconv_up_kernel<0, 1>), dim3(per_xcd * 8), dim3(256), LDSUP, st, p);
         else hipLaunchKernelGGL((hconv_up_kernel<0, 0>), dim3(per_xcd * 8), dim3(256), LDSUP, st, p);
         SRBH_HIP(hipGetLastError());
+        count_path(PATH_HCONV_UP);
         return SRBH_OK;
     }
     // the dominant layer shape has its own persistent, double-buffered kernel (srbh_hconv16_kernel.h)

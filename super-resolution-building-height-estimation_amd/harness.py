@@ -251,14 +251,18 @@ class GradReducer:
 FEATURE_H16 = os.environ.get("SRBH_FEATURE_H16", "1") == "1"
 
 
-def features_for_head(net_hr, x, h16=None):
+def features_for_head(net_hr, x, h16=None, model=None):
     """net_hr.forward_feature(x) in the element type the head will stage: fp16 when its fp16-operand kernels are active (h16: the
-    caller's hrfuse.head_h16() in the grad mode the HEAD will run in; None = right now) and the trunk is on its fast path, else the
-    fp32 tensor of the nn.Module API"""
+    caller's hrfuse.head_h16() in the grad mode the HEAD will run in; None = right now), the trunk is on its fast path AND the
+    consumer is this package's head (`model.hrfeat` an hrfuse.HRfeature: any other module -- the reference / oracle nn.Module, a user
+    head -- keeps getting the fp32 tensor of the nn.Module API); SRBH_PTAIL=0 (no fp16 store outside the persistent tail kernel)
+    also falls back to fp32 instead of raising."""
     from . import hrfuse as _H
     if h16 is None:
         h16 = _H.head_h16()
-    if (FEATURE_H16 and h16 and hasattr(net_hr, "_use_strict") and not net_hr._use_strict()
+    consumer_ok = model is None or isinstance(getattr(model, "hrfeat", None), _H.HRfeature)
+    if (FEATURE_H16 and h16 and consumer_ok and os.environ.get("SRBH_PTAIL", "1") != "0"
+            and hasattr(net_hr, "_use_strict") and not net_hr._use_strict()
             and not (getattr(net_hr, "_train_path", False) and torch.is_grad_enabled())):
         return net_hr.forward_feature(x, out_dtype=torch.float16)
     return net_hr.forward_feature(x)
@@ -356,7 +360,7 @@ class TrainStep:
             with wcache.capturing(self._holder):
                 h16 = self._H.head_h16()
                 with torch.no_grad():
-                    features_for_head(self.net_hr, self._static[0].index_select(1, self._rgb_idx), h16)   # eager: reports packs + workspace
+                    features_for_head(self.net_hr, self._static[0].index_select(1, self._rgb_idx), h16, model=self.net)   # eager: reports packs + workspace
                 torch.cuda.synchronize()
                 if self.reducer is not None:
                     self.reducer.paused = True
@@ -409,7 +413,7 @@ class TrainStep:
         lr, height, height_aggre, build, weight, weight_aggre = batch
         h16 = self._H.head_h16()              # (in the grad mode the head runs in: 'auto' trains exact-fp32 and takes fp32 features)
         with torch.no_grad():
-            hr_fea = features_for_head(self.net_hr, lr.index_select(1, self._rgb_idx), h16)
+            hr_fea = features_for_head(self.net_hr, lr.index_select(1, self._rgb_idx), h16, model=self.net)
         height_pred, build_pred, height_pred_aggre = self.net(lr, hr_fea)
         loss = (self.criterion[0](height_pred.squeeze(1), height, weight)
                 + self.criterion[1](height_pred_aggre.squeeze(1), height_aggre, weight_aggre)
@@ -524,7 +528,7 @@ class _PredictGraph:
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    model(self.x, features_for_head(net_hr, self.x[:, :3]))
+                    model(self.x, features_for_head(net_hr, self.x[:, :3], model=model))
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             # THREE graphs, not one (round 4): the encoder / decoders (~250 small launches, 2-3 ms per 128 tiles) replay on a second
@@ -539,14 +543,14 @@ class _PredictGraph:
                 with torch.cuda.graph(self.g_lr):
                     self.lr_out = model.forward_lr(self.x)
                 with torch.cuda.graph(self.g_hr):
-                    self.hr_out = model.forward_hr(features_for_head(net_hr, self.x[:, :3]))
+                    self.hr_out = model.forward_hr(features_for_head(net_hr, self.x[:, :3], model=model))
                 with torch.cuda.graph(self.g_fuse):
                     height, build = model.forward_fuse(self.lr_out[0], self.lr_out[1], self.hr_out)
                 self.out = (height, build) + ((self.lr_out[2],) if self.lr_out[2] is not None else ())
             else:
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):
-                    self.out = model(self.x, features_for_head(net_hr, self.x[:, :3]))
+                    self.out = model(self.x, features_for_head(net_hr, self.x[:, :3], model=model))
 
     @staticmethod
     def weights_key(net_hr, model, batch, dev):
@@ -608,7 +612,7 @@ def predict_tiles(net_hr, model, tiles, posall, mosaic, batch=32, rank=0, world=
             q = batch if not pad_to else min(batch, (k + pad_to - 1) // pad_to * pad_to)
             if q > k:
                 x = torch.cat([x, x.new_zeros((q - k,) + tuple(x.shape[1:]))], 0)
-        hr_fea = features_for_head(net_hr, x[:, :3])
+        hr_fea = features_for_head(net_hr, x[:, :3], model=model)
         out = model(x, hr_fea)
         mosaic.add(out[0][:k], out[1][:k], posall[s:e])
     if hi > lo and hasattr(net_hr, "check_status"):

@@ -136,6 +136,7 @@ class _PackedConv:
         self.key = None
         self.w = None
         self.b = None
+        self._other = None        # the pack in the OTHER row order (up / not up): calls that alternate between the two forms do not repack
 
     def get(self, conv: nn.Conv2d, h16=False, up=False):
         """up: the Upsampler kernel's SUB-PIXEL-MAJOR row order (include/srbh.h, srbh_hconv_args.pixelshuffle2 == 2): packed row
@@ -143,7 +144,11 @@ class _PackedConv:
         w = conv.weight
         key = (w._version, w.data_ptr(), None if conv.bias is None else (conv.bias._version, conv.bias.data_ptr()), bool(h16), bool(up),
                wcache.gen(w, conv.bias))            # (fused optimizers do not bump _version, see wcache.py)
+        if key != self.key and self._other is not None and self._other[0] == key:       # one slot per pack order
+            self._other, (self.key, self.w, self.b) = (self.key, self.w, self.b), self._other
         if key != self.key:
+            if self.key is not None and self.key[4] != key[4]:
+                self._other = (self.key, self.w, self.b)
             L = _lib.lib()
             cout, cin, ks, _ = w.shape
             wc = w.detach().float().contiguous()

@@ -82,6 +82,10 @@ class _FastLease:
         self.gen = ws["gen"]
 
     def check(self):
+        if self.ws is None:
+            raise RuntimeError("RRDBNet fast training mode: this forward's saved activation planes were released by its first backward "
+                               "(a second backward through the same graph, e.g. retain_graph=True, needs a new forward; the exact 'f32' "
+                               "training mode keeps its tensors and supports it)")
         if self.ws["gen"] != self.gen or not self.ws["busy"]:
             raise RuntimeError("RRDBNet fast training mode: the saved activation planes of this forward were handed to another forward "
                                "before its backward ran (buffer generation %d, expected %d)" % (self.ws["gen"], self.gen))

@@ -324,7 +324,10 @@ def test_relu_bit_pattern_equals_the_fp32_reference_in_the_backward_reduce(C, sh
     #  element-wise rtol on it failed once in a few full-suite runs)
     close = lambda u, v, tol: float((u.double() - v.double()).abs().max()) <= tol * float(v.double().abs().max())      # noqa: E731
     assert close(dg0, dg1, 1e-4) and close(db0, db1, 1e-4)
-    assert dc0.dtype == dc1.dtype and close(dc0.float(), dc1.float(), 2e-2 if b16 else 1e-4)
+    # dc is elementwise in (dz, c) given the statistics: the two runs differ only through the atomically summed means, so a masking or
+    # summation bug in the bit path shows up as a LARGE relative difference -- rel-L2, not a max-normalised bound (round-4 ADVICE)
+    rel = float((dc0.double() - dc1.double()).norm() / dc1.double().norm())
+    assert dc0.dtype == dc1.dtype and rel <= (5e-3 if b16 else 1e-3), rel
 
 
 @pytest.mark.gpu
