@@ -101,6 +101,108 @@ __global__ __launch_bounds__(256, 1) void ceiling_kernel(const half8* __restrict
     if (s == 12345.678f) sink[0] = s;
 }
 
+// ---- operand-ORDER modes (round 5; round-4 VERDICT task 2(i)): the same back-to-back MFMA stream, registers only, 4 independent
+// accumulators, but WHICH operand changes between consecutive MFMAs is the variable.  If the matrix core's input latches / operand
+// delivery cost less when an operand repeats, the power-capped clock -- and so the ceiling -- moves with the order.
+//   ORD 0: both change every MFMA (= "mfma only" above)      ORD 1/2/3: A (weights) held for 2 / 4 / 8 MFMAs, B changes every MFMA
+//   ORD 4: B (pixels) held for 4, A changes every MFMA        ORD 5: snake -- consecutive MFMAs always share ONE operand, alternately A and B
+//   ORD 6: the trunk's exact cout-32 group order: A[m / 4] (3 fragments), P[(m & 3) + m / 4] (6 fragments), 12 MFMAs, A held x4
+//   ORD 7: the same 12 MFMAs B-stationary: pixel row r = i + dy held over its (up to 3) uses, A changes
+// SHAPE 0: v_mfma_f32_32x32x16_f16 (16 acc registers, 32 cycles)   SHAPE 1: v_mfma_f32_16x16x32_f16 (4 acc registers, 16 cycles; same
+// FLOPs per operand byte pair... half the FLOPs per instruction, so twice the operand traffic per FLOP)
+typedef float floatx4c __attribute__((ext_vector_type(4)));
+template <int ORD, int SHAPE>
+__global__ __launch_bounds__(256, 1) void order_kernel(const half8* __restrict__ wsrc, const half8* __restrict__ asrc, int nfrag, int iters, Out* out, float* sink) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    half8 A[8], B[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        A[k] = wsrc[((blockIdx.x * 4 + wave) * 8 + k) % nfrag * 64 + lane];
+        B[k] = asrc[((blockIdx.x * 4 + wave) * 8 + k) % nfrag * 64 + lane];
+    }
+    floatx16 c[4];
+    floatx4c d[8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c[a][q] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[a][q] = 0.f;
+    auto idx = [](const int m, int& ia, int& ib) {
+        if (ORD == 0) { ia = m & 7; ib = (m + m / 8) & 7; }
+        else if (ORD == 1) { ia = (m / 2) & 7; ib = m & 7; }
+        else if (ORD == 2) { ia = (m / 4) & 7; ib = m & 7; }
+        else if (ORD == 3) { ia = (m / 8) & 7; ib = (m + m / 8) & 7; }
+        else if (ORD == 4) { ia = m & 7; ib = (m / 4) & 7; }
+        else if (ORD == 5) { ia = ((m + 1) / 2) & 7; ib = (m / 2) & 7; }
+        else if (ORD == 6) { const int g = m % 12; ia = g / 4 + 3 * ((m / 12) & 1); ib = (g & 3) + g / 4; }
+        else {   // ORD 7: rows r = 0..5 of a group, (dy, i = r - dy) for dy with 0 <= i <= 3
+            constexpr int RR[12] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 5}, DY[12] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 1, 2, 2};
+            const int g = m % 12; ib = RR[g]; ia = DY[g] + 3 * ((m / 12) & 1);
+        }
+    };
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 48; ++m) {
+            int ia, ib;
+            idx(m, ia, ib);
+            if (SHAPE == 0) {
+                // accumulator: ORD 6 / 7 use the trunk's (one per output row i); the others rotate 4
+                int ac = m & 3;
+                if (ORD == 6) ac = (m % 12) & 3;
+                if (ORD == 7) { constexpr int RR[12] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 5}, DY[12] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 1, 2, 2}; ac = RR[m % 12] - DY[m % 12]; }
+                c[ac] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[ia], B[ib], c[ac], 0, 0, 0);
+            } else {
+                d[m & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ia], B[ib], d[m & 7], 0, 0, 0);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) { out[blockIdx.x].cyc = t1 - t0; out[blockIdx.x].real = r1 - r0; }
+    float s = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += c[a][q];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s += d[a][q];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+template <int ORD, int SHAPE>
+static void run_order(const char* name, const half8* dw, const half8* da, int nfrag, double seconds) {
+    Out* dout; float* sink;
+    hipMalloc(&dout, 256 * sizeof(Out)); hipMalloc(&sink, 4);
+    const int iters = SHAPE == 0 ? 4000 : 8000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    int launches = 0; float ms = 0;
+    for (int phase = 0; phase < 2; ++phase) {
+        hipEventRecord(e0);
+        int n = 0; float acc = 0;
+        do {
+            for (int k = 0; k < 20; ++k) hipLaunchKernelGGL((order_kernel<ORD, SHAPE>), dim3(256), dim3(256), 0, 0, dw, da, nfrag, iters, dout, sink);
+            n += 20;
+            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&acc, e0, e1);
+        } while (acc < seconds * 500.0);
+        launches = n; ms = acc;
+    }
+    Out h[256]; hipMemcpy(h, dout, sizeof(h), hipMemcpyDeviceToHost);
+    double cyc = 0, real = 0;
+    for (int i = 0; i < 256; ++i) { cyc += (double)h[i].cyc; real += (double)h[i].real; }
+    cyc /= 256; real /= 256;
+    const double per = SHAPE == 0 ? 32768.0 : 16384.0, cycm = SHAPE == 0 ? 32.0 : 16.0;
+    const double mfmas = (double)iters * 48, flop = mfmas * per * 4 * 256;
+    const double ms_l = ms / launches, tf = flop / (ms_l * 1e-3) / 1e12, mhz = cyc / real * 100.0;
+    printf("%-46s %7.3f ms/launch  %7.1f TF/s = %.3f of 2500   sclk %6.0f MHz   matrix-core busy %5.1f %%\n", name, ms_l, tf, tf / 2500.0, mhz, 100.0 * mfmas * cycm / cyc);
+    fflush(stdout);
+    hipFree(dout); hipFree(sink);
+}
+
 static std::vector<_Float16> load_or_make(const char* path, size_t n, int kind, unsigned seed) {
     std::vector<_Float16> v(n);
     if (path) {
@@ -178,7 +280,20 @@ int main(int argc, char** argv) {
         run<0>("mfma only", dw, da, nfrag, 0, seconds);
         run<1>("mfma + 0.75 ds_read_b128 / mfma", dw, da, nfrag, 0, seconds);
         run<3>("mfma + lds + weight LDS-DMA stream", dw, da, nfrag, 0, seconds);
-        if (kind != 0) {
+        if (kind != 0 && !getenv("CEIL_SKIP_ORDER")) {
+            run_order<0, 0>("order: 32x32x16 both operands change", dw, da, nfrag, seconds);
+            run_order<1, 0>("order: 32x32x16 A held x2", dw, da, nfrag, seconds);
+            run_order<2, 0>("order: 32x32x16 A held x4", dw, da, nfrag, seconds);
+            run_order<3, 0>("order: 32x32x16 A held x8", dw, da, nfrag, seconds);
+            run_order<4, 0>("order: 32x32x16 B held x4", dw, da, nfrag, seconds);
+            run_order<5, 0>("order: 32x32x16 snake (share one operand)", dw, da, nfrag, seconds);
+            run_order<6, 0>("order: 32x32x16 trunk cout-32 group (A x4)", dw, da, nfrag, seconds);
+            run_order<7, 0>("order: 32x32x16 trunk group, B-stationary", dw, da, nfrag, seconds);
+            run_order<0, 1>("order: 16x16x32 both operands change", dw, da, nfrag, seconds);
+            run_order<2, 1>("order: 16x16x32 A held x4", dw, da, nfrag, seconds);
+            run_order<4, 1>("order: 16x16x32 B held x4", dw, da, nfrag, seconds);
+        }
+        if (kind != 0 && !getenv("CEIL_SKIP_DUTY")) {
             run<2>("mfma bursts, sleep 1x", dw, da, nfrag, 1, seconds);
             run<2>("mfma bursts, sleep 2x", dw, da, nfrag, 2, seconds);
             run<2>("mfma bursts, sleep 4x", dw, da, nfrag, 4, seconds);
