@@ -21,7 +21,7 @@ import math
 
 import torch
 import torch.nn.functional as F
-from . import wcache
+from . import sidework, wcache
 from torch import nn
 
 # (width, depth, resolution, dropout) -- EfficientNet paper table / efficientnet_pytorch.utils.efficientnet_params
@@ -117,8 +117,9 @@ class _DepthwiseConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             ws = torch.empty(_lib.lib().srbh_dwconv_bwd_weight_splits(B, C) * C * K * K, dtype=torch.float32, device=x.device)
-            _lib.check(_lib.lib().srbh_dwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, C, H, W, K,
-                                                         stride, pt, pl, OH, OW, _lib.stream_ptr()), "dwconv_bwd_weight")
+            with sidework.side(x, dy, dw, ws):         # a leaf of the graph: next to the data-gradient chain, not in it
+                _lib.check(_lib.lib().srbh_dwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, C, H, W, K,
+                                                             stride, pt, pl, OH, OW, _lib.stream_ptr()), "dwconv_bwd_weight")
         return dx, dw, None, None
 
 
@@ -159,8 +160,9 @@ class _PointwiseConvFn(torch.autograd.Function):
             dw = torch.empty_like(weight)
             n = L.srbh_pwconv_bwd_weight_ws_floats(B, Cin, Cout, H * W)
             ws = torch.empty(n, dtype=torch.float32, device=x.device) if n else None
-            _lib.check(L.srbh_pwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr() if n else None, B, Cin, Cout, H * W,
-                                                _lib.stream_ptr()), "pwconv_bwd_weight")
+            with sidework.side(x, dy, dw, ws):
+                _lib.check(L.srbh_pwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr() if n else None, B, Cin, Cout, H * W,
+                                                    _lib.stream_ptr()), "pwconv_bwd_weight")
         return dx, dw, None
 
 
@@ -686,8 +688,9 @@ class _DecoderConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             ws = torch.empty(L.srbh_dconv_wgrad_ws_floats(B, Cin, Cout, H, W), dtype=torch.float32, device=x.device)
-            _lib.check(L.srbh_dconv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, Cin, Cout, H, W, _lib.stream_ptr()),
-                       "dconv_wgrad")
+            with sidework.side(x, dy, dw, ws):
+                _lib.check(L.srbh_dconv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, Cin, Cout, H, W, _lib.stream_ptr()),
+                           "dconv_wgrad")
         return dx, dw, None
 
 

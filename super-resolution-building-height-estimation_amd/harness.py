@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import wcache
+from . import sidework, wcache
 
 HIR = (0, 3, 12, 21, 30, 60, 90, 256)                       # train.py:55
 # hierweight(bh_stats_globe, HIR) as probed on the reference data; synthetic labels reuse it
@@ -138,6 +138,7 @@ class GradReducer:
 
     def _launch(self, b):
         flat = b["flat"]
+        sidework.join()           # weight gradients computed on the side stream (sidework.py): final before this bucket is packed
         torch._foreach_copy_([flat[o:o + n].view_as(q.grad) for q, o, n in b["items"]], [q.grad for q, _, _ in b["items"]])
         self._work.append((b, self.dist.all_reduce(flat, async_op=True)))
 
@@ -420,6 +421,7 @@ class TrainStep:
                 + self.criterion[2](build_pred, build, weight))
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        sidework.join()           # (the end-of-backward callback already did: a no-op unless that callback was skipped)
         if in_graph and self.world > 1:
             return loss.detach(), height_pred.detach()      # (the collectives and Adam follow each replay: _reduce_and_update)
         self._reduce_and_update()

@@ -1,0 +1,101 @@
+"""GPU: weight-gradient launches of the encoder / decoders on the side stream (srbh_amd/sidework.py, round 5) give the gradients of the
+in-place launches, are final on the usual stream when backward() returns (the end-of-backward join), survive a caching-allocator
+that is busy recycling, and the whole-model training step is unchanged by the switch.  The reference obtains these gradients from
+torch autograd over smp's EfficientNet-B4 / UnetDecoder (mymodels.py:242-258,276-287)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _chain(seed):
+    """a chain of 1x1 / depthwise / decoder convs: many small weight-gradient launches behind one another"""
+    from srbh_amd import encoders as E
+    g = torch.Generator().manual_seed(seed)
+    ws = [torch.randn((48, 24, 1, 1), generator=g) * 0.2, torch.randn((48, 1, 3, 3), generator=g) * 0.3, torch.randn((24, 48, 1, 1), generator=g) * 0.2,
+          torch.randn((144, 24, 1, 1), generator=g) * 0.2, torch.randn((144, 1, 5, 5), generator=g) * 0.2, torch.randn((24, 144, 1, 1), generator=g) * 0.1]
+    ws = [w.to(DEV).requires_grad_(True) for w in ws]
+    x = torch.randn((16, 24, 8, 8), generator=g).to(DEV).requires_grad_(True)
+
+    def run():
+        h = x
+        for i in range(0, len(ws), 3):
+            e = E._PointwiseConvFn.apply(h, ws[i])
+            k = ws[i + 1].shape[-1]
+            d = E._DepthwiseConvFn.apply(torch.tanh(e), ws[i + 1], 1, (k // 2,) * 4)
+            h = E._PointwiseConvFn.apply(torch.tanh(d), ws[i + 2]) + h
+        return h
+
+    return x, ws, run
+
+
+def _grads(run, x, ws, gy):
+    for t in [x] + ws:
+        t.grad = None
+    run().backward(gy)
+    # read on the CURRENT stream right after backward() returned: exactly what optimizer.step() does
+    return [t.grad.clone() for t in [x] + ws]
+
+
+def test_side_stream_weight_gradients_equal_in_place_launches(monkeypatch):
+    from srbh_amd import sidework
+    x, ws, run = _chain(3)
+    gy = torch.randn((16, 24, 8, 8), generator=torch.Generator().manual_seed(9)).to(DEV)
+    monkeypatch.setattr(sidework, "ENABLED", False)
+    want = _grads(run, x, ws, gy)
+    monkeypatch.setattr(sidework, "ENABLED", True)
+    got = _grads(run, x, ws, gy)
+    assert any(st["stream"] is not None for st in sidework._STATE.values())        # the side stream was created, i.e. used
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)          # same kernels, same fixed summation order: bit-identical
+
+
+def test_side_stream_results_are_final_after_backward_under_allocator_pressure(monkeypatch):
+    """many passes back to back with buffers of the same sizes allocated and freed in between (the allocator would hand a tensor the
+    side stream still reads to the next allocation if it were not marked), every pass compared with the in-place result"""
+    from srbh_amd import sidework
+    x, ws, run = _chain(5)
+    gy = torch.randn((16, 24, 8, 8), generator=torch.Generator().manual_seed(11)).to(DEV)
+    monkeypatch.setattr(sidework, "ENABLED", False)
+    want = _grads(run, x, ws, gy)
+    monkeypatch.setattr(sidework, "ENABLED", True)
+    for it in range(25):
+        junk = [torch.full_like(t, float(it)) for t in want]          # same-size blocks churning through the pool
+        got = _grads(run, x, ws, gy)
+        del junk
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), it
+
+
+def test_train_step_is_unchanged_by_the_side_stream(monkeypatch):
+    """the whole SRRegress_Cls_feature training step (harness.TrainStep, one step from the same start) with and without the side stream:
+    the loss and every parameter gradient agree to the noise of the step's own atomically summed BatchNorm statistics"""
+    from srbh_amd import encoders, harness, sidework, synth
+    from srbh_amd.models import SRRegress_Cls_feature
+    from srbh_amd.rrdbnet import RRDBNet
+    monkeypatch.setattr(encoders, "DROP_CONNECT", 0.0)
+    sd = synth.rrdbnet_state_dict(num_block=1, seed=3, mode="init")
+    out = {}
+    for flag in (False, True):
+        monkeypatch.setattr(sidework, "ENABLED", flag)
+        net_hr = RRDBNet(3, 3, num_block=1)
+        net_hr.load_state_dict(sd)
+        torch.manual_seed(5)
+        net = SRRegress_Cls_feature("efficientnet-b4", in_channels=8, super_in=64, super_mid=16, upscale=4, isaggre=True, chans_build=7)
+        ts = harness.TrainStep(net_hr.to(DEV), net.to(DEV), DEV, lr=1e-4, status_every=0)
+        batch = harness.synthetic_batch(4, 21, DEV)
+        loss = float(ts(batch)[0])
+        torch.cuda.synchronize()
+        out[flag] = (loss, {k: v.grad.detach().clone() for k, v in net.named_parameters() if v.grad is not None})
+    (l0, g0), (l1, g1) = out[False], out[True]
+    assert abs(l0 - l1) <= 1e-4 * abs(l0), (l0, l1)
+    assert g0.keys() == g1.keys() and len(g0) > 600
+    top = max(float(v.double().norm()) for v in g0.values())
+    worst = max(_rel(g1[k], g0[k]) for k in g0 if float(g0[k].double().norm()) > 1e-6 * top)
+    assert worst <= 2e-3, worst
