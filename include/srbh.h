@@ -258,6 +258,10 @@ typedef struct srbh_hconv_args {
      * dbeta / the mean terms of the two paths differ by bf16 rounding noise averaged over B*H*W elements (not bit-comparable;
      * tests/test_gpu_io16.py bounds it) -- fp16 also drops the out "no PixelShuffle" rule for the full 16 -> 64 conv (see pixelshuffle2). */
     const float* bstat_c; const float* bstat_mean; const float* bstat_invstd; const float* bstat_ms; const float* bstat_mh;
+    /* nonzero: the caller guarantees that `stats` is all zero already (a buffer last consumed by srbh_bn_finalize_clear /
+     * srbh_bn_bwd_finalize_clear, or freshly zeroed): this call then launches no zero fill of its own (round 5: 49 one-line fills per
+     * training step sat as dependent launches in front of their convolutions) */
+    int stats_clean;
 } srbh_hconv_args;
 #define SRBH_IO_SRC0_H16 1
 #define SRBH_IO_SRC1_H16 2
@@ -286,6 +290,11 @@ int srbh_hconv_entry_h16(const srbh_hconv_args* c1, const srbh_hconv_args* ds, i
 int srbh_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta, float eps,
                      float momentum, float* running_mean, float* running_var, float* scale, float* shift,
                      float* save_mean, float* save_invstd, void* stream);
+/* The same, and the partial-sum buffer is ZEROED behind the read (self-cleaning: the next producer may pass stats_clean = 1).  One
+ * launch, one block: the zero fill is ordered behind this kernel's own reads of every slot. */
+int srbh_bn_finalize_clear(double* stats, int C, double count, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                           float* save_mean, float* save_invstd, void* stream);
 /* eval-mode BatchNorm folded to scale/shift from the running statistics */
 int srbh_bn_eval_scale_shift(int C, const float* gamma, const float* beta, const float* running_mean,
                              const float* running_var, float eps, float* scale, float* shift, void* stream);
@@ -356,6 +365,9 @@ int srbh_bn_bwd_reduce_relu(const float* g, const float* relu_ref, float* dz_out
 /* dgamma = sum dy*xhat, dbeta = sum dy, and the constants of dc = coef*(dy - k1 - xhat*k2) (coef may be NULL) */
 int srbh_bn_bwd_finalize(const double* stats, int C, double count, const float* gamma, const float* invstd,
                          float* dgamma, float* dbeta, float* coef, float* k1, float* k2, void* stream);
+/* srbh_bn_bwd_finalize + zero fill of `stats` behind the read (see srbh_bn_finalize_clear) */
+int srbh_bn_bwd_finalize_clear(double* stats, int C, double count, const float* gamma, const float* invstd,
+                               float* dgamma, float* dbeta, float* coef, float* k1, float* k2, void* stream);
 int srbh_bn_bwd_apply(const float* g, const float* c, const float* mean, const float* invstd, const float* mask_scale,
                       const float* mask_shift, const float* coef, const float* k1, const float* k2, float* out, long npix,
                       int C, void* stream);
@@ -368,6 +380,7 @@ int srbh_bn_bwd_apply(const float* g, const float* c, const float* mean, const f
 #define SRBH_BN_C_H16 2
 #define SRBH_BN_G_B16 4
 #define SRBH_BN_REF_BITS 8   /* srbh_bn_bwd_reduce_io: relu_ref points at srbh_bn_add_relu_bits' bit buffer, not at an fp32 tensor */
+#define SRBH_BN_STATS_CLEAN 16   /* srbh_bn_bwd_reduce_io: `stats` is all zero already (see srbh_hconv_args.stats_clean): no zero fill here */
 int srbh_bn_bwd_reduce_io(const void* g, const float* relu_ref, void* dz_out, const void* c, const float* mean, const float* invstd,
                           const float* mask_scale, const float* mask_shift, long npix, int C, double* stats, int io, void* stream);
 int srbh_bn_bwd_apply_io(const void* g, const void* c, const float* mean, const float* invstd, const float* mask_scale,

@@ -95,6 +95,7 @@ class HConvArgs(C.Structure):
         ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("post_relu", C.c_int),
         ("io_h16", C.c_int),
         ("bstat_c", C.c_void_p), ("bstat_mean", C.c_void_p), ("bstat_invstd", C.c_void_p), ("bstat_ms", C.c_void_p), ("bstat_mh", C.c_void_p),
+        ("stats_clean", C.c_int),
     ]
 
 
@@ -185,6 +186,7 @@ SIGNATURES = {
     "srbh_hconv_h16": (_i, [C.POINTER(HConvArgs), _i, _vp]),
     "srbh_hconv_entry_h16": (_i, [C.POINTER(HConvArgs), C.POINTER(HConvArgs), _i, _vp]),
     "srbh_bn_finalize": (_i, [_vp, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "srbh_bn_finalize_clear": (_i, [_vp, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srbh_bn_eval_scale_shift": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "srbh_bn_add_relu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp]),
     "srbh_bn_add_relu_io": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _i, _vp]),
@@ -201,6 +203,7 @@ SIGNATURES = {
     "srbh_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp, _vp]),
     "srbh_bn_bwd_reduce_relu": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp, _vp]),
     "srbh_bn_bwd_finalize": (_i, [_vp, _i, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "srbh_bn_bwd_finalize_clear": (_i, [_vp, _i, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "srbh_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp]),
     "srbh_bn_bwd_reduce_io": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp, _i, _vp]),
     "srbh_bn_bwd_apply_io": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _i, _vp]),

@@ -533,9 +533,10 @@ __global__ void hpack_h16_kernel(const float* __restrict__ w, short* __restrict_
 }
 
 // ---- BatchNorm: partial sums -> scale/shift (+ running stats) ------------------------------------------------------
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, double count, const float* gamma,
+// clear != 0 (one block of 64 threads, C <= 64): the slots this thread summed are zeroed behind the read (self-cleaning buffer)
+__global__ void bn_finalize_kernel(double* __restrict__ stats, int C, double count, const float* gamma,
                                    const float* beta, float eps, float momentum, float* running_mean,
-                                   float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd) {
+                                   float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd, int clear) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s = 0, q = 0;
@@ -543,6 +544,11 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, doub
         s += stats[(long)k * 2 * C + c];
         q += stats[(long)k * 2 * C + C + c];
     }
+    if (clear)
+        for (int k = 0; k < NSLOT; ++k) {
+            stats[(long)k * 2 * C + c] = 0.0;
+            stats[(long)k * 2 * C + C + c] = 0.0;
+        }
     double mean = s / count;
     double var = q / count - mean * mean;   // biased, as used for normalisation
     if (var < 0) var = 0;
@@ -767,7 +773,7 @@ static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
     p.B = a->B; p.H = a->H; p.W = a->W; p.ps2 = a->pixelshuffle2;
     p.out = a->out; p.stats = a->stats;
     hipStream_t st = (hipStream_t)stream;
-    if (a->stats) { if (int rc = zero_async(a->stats, srbh_bn_stats_bytes(p.cout), st)) return rc; }
+    if (a->stats && !a->stats_clean) { if (int rc = zero_async(a->stats, srbh_bn_stats_bytes(p.cout), st)) return rc; }
     const int B = a->B, H = a->H, W = a->W;
     // 16-bit operand forms: 4-row tiles (12.7 KiB staged tile; measured level with the 8-row form on single-chunk convs and
     // 10-25 % ahead on the multi-chunk ones)
@@ -922,8 +928,8 @@ extern "C" int srbh_hconv_entry_h16(const srbh_hconv_args* c1, const srbh_hconv_
     e.out2 = ds->out; e.out2_ld = out2_ld; e.out2_coff = ds->out_coff; e.stats2 = ds->stats;
     e.nchunk = cin / 16;
     if (c1->stats) {
-        if (int rc = zero_async(c1->stats, srbh_bn_stats_bytes(16), st)) return rc;
-        if (int rc = zero_async(ds->stats, srbh_bn_stats_bytes(16), st)) return rc;
+        if (!c1->stats_clean) { if (int rc = zero_async(c1->stats, srbh_bn_stats_bytes(16), st)) return rc; }
+        if (!ds->stats_clean) { if (int rc = zero_async(ds->stats, srbh_bn_stats_bytes(16), st)) return rc; }
     }
     const int per_xcd = p.tiles_per_xcd < wgs / 8 ? p.tiles_per_xcd : wgs / 8;
     const int lds_b = 2 * 6 * 66 * 32 + e.nchunk * 640 * 8;
@@ -957,7 +963,16 @@ extern "C" int srbh_bn_finalize(const double* stats, int C, double count, const 
                                 float eps, float momentum, float* running_mean, float* running_var, float* scale,
                                 float* shift, float* save_mean, float* save_invstd, void* stream) {
     SRBH_REQUIRE(stats && C > 0 && C <= 64 && count > 0 && scale && shift, "srbh_bn_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (double*)stats, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd, 0);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_bn_finalize_clear(double* stats, int C, double count, const float* gamma, const float* beta,
+                                      float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                                      float* shift, float* save_mean, float* save_invstd, void* stream) {
+    SRBH_REQUIRE(stats && C > 0 && C <= 64 && count > 0 && scale && shift, "srbh_bn_finalize_clear: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd, 1);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }

@@ -1062,8 +1062,8 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* _
 
 // per-channel constants of the BatchNorm backward: dgamma, dbeta and (coef, k1, k2) with
 // dc = coef * (dy - k1 - xhat * k2);   training: coef = gamma*invstd, k1 = sum(dy)/N, k2 = sum(dy*xhat)/N
-__global__ void bn_bwd_finalize_kernel(const double* stats, int C, double count, const float* gamma, const float* invstd,
-                                       float* dgamma, float* dbeta, float* coef, float* k1, float* k2) {
+__global__ void bn_bwd_finalize_kernel(double* stats, int C, double count, const float* gamma, const float* invstd,
+                                       float* dgamma, float* dbeta, float* coef, float* k1, float* k2, int clear) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s = 0, q = 0;
@@ -1071,6 +1071,11 @@ __global__ void bn_bwd_finalize_kernel(const double* stats, int C, double count,
         s += stats[(long)k * 2 * C + c];
         q += stats[(long)k * 2 * C + C + c];
     }
+    if (clear)       // self-cleaning buffer (one block, C <= 64): this thread zeroes exactly the slots it summed
+        for (int k = 0; k < NSLOT; ++k) {
+            stats[(long)k * 2 * C + c] = 0.0;
+            stats[(long)k * 2 * C + C + c] = 0.0;
+        }
     if (dgamma) dgamma[c] = (float)q;
     if (dbeta) dbeta[c] = (float)s;
     if (coef) {
@@ -1513,7 +1518,8 @@ extern "C" int srbh_add_inplace(float* a, const float* b, long n, void* stream) 
 static int bn_bwd_reduce_impl(const void* g, const float* relu_ref, void* dz_out, const void* c, const float* mean, const float* invstd,
                               const float* mask_scale, const float* mask_shift, long npix, int C, double* stats, void* stream, int io = 0) {
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = zero_async(stats, (size_t)NSLOT * 2 * C * sizeof(double), st)) return rc;
+    if (!(io & SRBH_BN_STATS_CLEAN)) { if (int rc = zero_async(stats, (size_t)NSLOT * 2 * C * sizeof(double), st)) return rc; }
+    io &= ~SRBH_BN_STATS_CLEAN;
     const bool gb = (io & SRBH_BN_G_B16) != 0, ch = (io & SRBH_BN_C_H16) != 0, ob = (io & SRBH_BN_OUT_B16) != 0, rb = (io & SRBH_BN_REF_BITS) != 0;
     const bool v4 = (C & 3) == 0 && (256 % (C >> 2)) == 0 && ((uintptr_t)g & (gb ? 7 : 15)) == 0 && ((uintptr_t)c & (ch ? 7 : 15)) == 0 &&
                     ((uintptr_t)dz_out & (ob ? 7 : 15)) == 0 && ((uintptr_t)relu_ref & (rb ? 7 : 15)) == 0 && (((uintptr_t)mean | (uintptr_t)invstd |
@@ -1574,7 +1580,7 @@ extern "C" int srbh_bn_bwd_reduce_io(const void* g, const float* relu_ref, void*
     SRBH_REQUIRE(!c || (mean && invstd), "srbh_bn_bwd_reduce_io: c needs mean/invstd");
     SRBH_REQUIRE(!mask_scale || (c && mask_shift), "srbh_bn_bwd_reduce_io: mask needs c and mask_shift");
     SRBH_REQUIRE(!(relu_ref && mask_scale), "srbh_bn_bwd_reduce_io: either the block-closing ReLU (relu_ref) or the bn1 mask");
-    SRBH_REQUIRE((io & ~15) == 0, "srbh_bn_bwd_reduce_io: unknown io bits");
+    SRBH_REQUIRE((io & ~31) == 0, "srbh_bn_bwd_reduce_io: unknown io bits");
     return bn_bwd_reduce_impl(g, relu_ref, dz_out, c, mean, invstd, mask_scale, mask_shift, npix, C, stats, stream, io);
 }
 
@@ -1601,8 +1607,18 @@ extern "C" int srbh_bn_bwd_finalize(const double* stats, int C, double count, co
                                     float* dgamma, float* dbeta, float* coef, float* k1, float* k2, void* stream) {
     SRBH_REQUIRE(stats && C > 0 && C <= 64 && count > 0, "srbh_bn_bwd_finalize: bad arguments");
     SRBH_REQUIRE(!coef || (invstd && k1 && k2), "srbh_bn_bwd_finalize: coef needs invstd, k1, k2");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (double*)stats, C, count, gamma, invstd,
+                       dgamma, dbeta, coef, k1, k2, 0);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_bn_bwd_finalize_clear(double* stats, int C, double count, const float* gamma, const float* invstd,
+                                          float* dgamma, float* dbeta, float* coef, float* k1, float* k2, void* stream) {
+    SRBH_REQUIRE(stats && C > 0 && C <= 64 && count > 0, "srbh_bn_bwd_finalize_clear: bad arguments");
+    SRBH_REQUIRE(!coef || (invstd && k1 && k2), "srbh_bn_bwd_finalize_clear: coef needs invstd, k1, k2");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, C, count, gamma, invstd,
-                       dgamma, dbeta, coef, k1, k2);
+                       dgamma, dbeta, coef, k1, k2, 1);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }

@@ -189,6 +189,43 @@ def _up_perm(device):
     return t
 
 
+# ---- BatchNorm partial-sum buffers: a pool of ZEROED buffers (round 5) -------------------------------------------------------------
+# Every statistics producer (conv epilogues, the BatchNorm-backward reduce pass) used to zero its buffer with a launch of its own:
+# 49 one-line kernels per training step, each a dependent launch in front of a convolution.  Now the consumer cleans up: the
+# finalize kernels zero the slots behind their read (srbh_bn_finalize_clear / srbh_bn_bwd_finalize_clear) and the buffer goes back
+# to a per-(size, device, stream) free list; a producer that takes it from there passes stats_clean = 1 and launches no fill.
+# Outside the pool (stream capture: the buffers would belong to the graph's private pool; SRBH_STATS_POOL=0) nothing changes.
+STATS_POOL = _os.environ.get("SRBH_STATS_POOL", "1") == "1"
+_STATS_FREE = {}
+
+
+def stats_acquire(C16, device):
+    """-> a float64 partial-sum buffer for C16 channels; `buf._srbh_clean` tells the producer whether it is known to be all zero"""
+    n = _lib.lib().srbh_bn_stats_bytes(C16) // 8
+    dev = torch.device(device)
+    if not STATS_POOL or dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
+        buf = torch.empty(n, dtype=torch.float64, device=dev)
+        buf._srbh_clean = False
+        return buf
+    key = (n, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    free = _STATS_FREE.setdefault(key, [])
+    buf = free.pop() if free else torch.zeros(n, dtype=torch.float64, device=dev)
+    buf._srbh_clean = True
+    buf._srbh_key = key
+    return buf
+
+
+def stats_clean(buf):
+    return bool(getattr(buf, "_srbh_clean", False))
+
+
+def stats_release(buf):
+    """call right after a *_finalize_clear on `buf` was queued (same stream): the buffer is zero again for whoever takes it next"""
+    key = getattr(buf, "_srbh_key", None)
+    if key is not None and stats_clean(buf) and len(_STATS_FREE.setdefault(key, [])) < 64:
+        _STATS_FREE[key].append(buf)
+
+
 def _hconv_args(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_stats=False, post=None, res=None,
                 post_relu=False, out_h16=False):
     """conv(cat(srcs)) through srbh_hconv_f32.  srcs: list of 1..2 NHWC tensors; pre=(scale, shift, relu) is
@@ -235,8 +272,8 @@ def _hconv_args(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False,
     a.post_relu = int(post_relu)
     stats = None
     if want_stats:
-        stats = torch.empty(L.srbh_bn_stats_bytes((cout + 15) // 16 * 16) // 8, dtype=torch.float64, device=x0.device)
-        a.stats = stats.data_ptr()
+        stats = stats_acquire((cout + 15) // 16 * 16, x0.device)
+        a.stats, a.stats_clean = stats.data_ptr(), int(stats_clean(stats))
     return a, out, stats, h16, (w, b)          # (w, b: keep the packed buffers alive until the launch is issued)
 
 
@@ -311,9 +348,11 @@ def bn_scale_shift(bn: nn.BatchNorm2d, stats, count, training):
             count = count * _BN_SYNC["world"]
         rm = bn.running_mean.data_ptr() if bn.track_running_stats else None
         rv = bn.running_var.data_ptr() if bn.track_running_stats else None
-        _lib.check(L.srbh_bn_finalize(stats.data_ptr(), Cc, float(count), g.data_ptr(), bta.data_ptr(), bn.eps, mom,
-                                      rm, rv, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                      _lib.stream_ptr()), "bn_finalize")
+        fin = L.srbh_bn_finalize_clear if stats_clean(stats) else L.srbh_bn_finalize
+        _lib.check(fin(stats.data_ptr(), Cc, float(count), g.data_ptr(), bta.data_ptr(), bn.eps, mom,
+                       rm, rv, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                       _lib.stream_ptr()), "bn_finalize")
+        stats_release(stats)
         if bn.track_running_stats and bn.num_batches_tracked is not None:
             note_batch(bn)
         return scale, shift, mean, invstd

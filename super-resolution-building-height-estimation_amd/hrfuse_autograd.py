@@ -74,7 +74,7 @@ def _hconv_raw(srcs, w_packed, bias, cout, ks, pre=None, ps2=False, res=None, h1
         c, mean, invstd, ms, mh, st = bstat
         a.bstat_c, a.bstat_mean, a.bstat_invstd = c.data_ptr(), mean.data_ptr(), invstd.data_ptr()
         a.bstat_ms, a.bstat_mh = (None, None) if ms is None else (ms.data_ptr(), mh.data_ptr())
-        a.stats = st.data_ptr()
+        a.stats, a.stats_clean = st.data_ptr(), int(H.stats_clean(st))
     if h16:      # (data gradients: bf16 operands -- fp32's exponent range, no loss scaling needed)
         _lib.check(L.srbh_hconv_h16(C.byref(a), 1, _lib.stream_ptr()), "hconv_h16(bf16)")
     else:
@@ -147,7 +147,17 @@ FUSE_BN_REDUCE = __import__("os").environ.get("SRBH_FUSE_BN_REDUCE", "1") == "1"
 
 
 def _stats_buf(Cc, dev):
-    return torch.empty(_lib.lib().srbh_bn_stats_bytes(Cc) // 8, dtype=torch.float64, device=dev)
+    return H.stats_acquire(Cc, dev)          # (zeroed pool: hrfuse.stats_acquire; released by _bwd_finalize(last=True))
+
+
+def _bwd_finalize(st, Cc, count, gamma, invstd, dgamma, dbeta, coef, k1, k2, what, last=True):
+    """srbh_bn_bwd_finalize; the LAST read of a pooled buffer also zeroes it and hands it back to the pool"""
+    L = _lib.lib()
+    p = lambda t: None if t is None else t.data_ptr()      # noqa: E731
+    fin = L.srbh_bn_bwd_finalize_clear if (last and H.stats_clean(st)) else L.srbh_bn_bwd_finalize
+    _lib.check(fin(st.data_ptr(), Cc, float(count), p(gamma), p(invstd), p(dgamma), p(dbeta), p(coef), p(k1), p(k2), _lib.stream_ptr()), what)
+    if last:
+        H.stats_release(st)
 
 
 def channel_sum(g):
@@ -158,8 +168,7 @@ def channel_sum(g):
     _lib.check(L.srbh_bn_bwd_reduce(g.data_ptr(), None, None, None, None, None, B * Hh * Ww, Cc, st.data_ptr(),
                                     _lib.stream_ptr()), "bn_bwd_reduce")
     out = torch.empty(Cc, dtype=torch.float32, device=g.device)
-    _lib.check(L.srbh_bn_bwd_finalize(st.data_ptr(), Cc, 1.0, None, None, None, out.data_ptr(), None, None, None,
-                                      _lib.stream_ptr()), "bn_bwd_finalize")
+    _bwd_finalize(st, Cc, 1.0, None, None, None, out, None, None, None, "bn_bwd_finalize")
     return out
 
 
@@ -189,7 +198,7 @@ def bn_backward(g, c, mean, invstd, gamma, mask, training, relu_ref=None, out_b1
     elif use_io:
         if relu_ref is not None:
             dz = H.empty_nhwc(B, Cc, Hh, Ww, dev, odt)
-        io = io_c | (4 if g.dtype == torch.bfloat16 else 0) | (1 if out_b16 else 0)
+        io = io_c | (4 if g.dtype == torch.bfloat16 else 0) | (1 if out_b16 else 0) | (16 if H.stats_clean(st) else 0)
         if relu_ref is not None and relu_ref.dtype == torch.int64:      # the ReLU pattern as bits (hrfuse.bn_add_relu(want_bits=True))
             io |= 8
         _lib.check(L.srbh_bn_bwd_reduce_io(g.data_ptr(), None if relu_ref is None else relu_ref.data_ptr(),
@@ -214,17 +223,14 @@ def bn_backward(g, c, mean, invstd, gamma, mask, training, relu_ref=None, out_b1
     coef = torch.empty(Cc, dtype=torch.float32, device=dev)
     k1 = torch.empty(Cc, dtype=torch.float32, device=dev)
     k2 = torch.empty(Cc, dtype=torch.float32, device=dev)
-    _lib.check(L.srbh_bn_bwd_finalize(st.data_ptr(), Cc, float(n), gamma.data_ptr(), invstd.data_ptr(), dgamma.data_ptr(),
-                                      dbeta.data_ptr(), coef.data_ptr(), k1.data_ptr(), k2.data_ptr(), _lib.stream_ptr()),
-               "bn_bwd_finalize")
-    if training and H.bn_sync_world() > 1:
+    sync = training and H.bn_sync_world() > 1
+    _bwd_finalize(st, Cc, n, gamma, invstd, dgamma, dbeta, coef, k1, k2, "bn_bwd_finalize", last=not sync)
+    if sync:
         # synchronised statistics: dgamma / dbeta above stay the LOCAL sums (they are averaged with the other gradients),
         # the mean terms of dx are those of the global batch
         H.bn_allreduce_(st)
         scratch = torch.empty(2 * Cc, dtype=torch.float32, device=dev)
-        _lib.check(L.srbh_bn_bwd_finalize(st.data_ptr(), Cc, float(n * H.bn_sync_world()), gamma.data_ptr(), invstd.data_ptr(),
-                                          scratch.data_ptr(), scratch.data_ptr() + 4 * Cc, coef.data_ptr(), k1.data_ptr(),
-                                          k2.data_ptr(), _lib.stream_ptr()), "bn_bwd_finalize(sync)")
+        _bwd_finalize(st, Cc, n * H.bn_sync_world(), gamma, invstd, scratch[:Cc], scratch[Cc:], coef, k1, k2, "bn_bwd_finalize(sync)")
     if not training:       # frozen statistics: the mean terms vanish
         k1.zero_()
         k2.zero_()

@@ -115,7 +115,7 @@ def _model(name, args):
     if name == "srbh_nchw_to_nhwc_f32":
         B, Cc, H, W = args[2], args[3], args[4], args[5]
         return f"nchw_to_nhwc C={Cc} @{H}x{W}", B * Cc * H * W * 8
-    if name in ("srbh_bn_finalize", "srbh_bn_bwd_finalize", "srbh_bn_eval_scale_shift"):
+    if name in ("srbh_bn_finalize", "srbh_bn_bwd_finalize", "srbh_bn_finalize_clear", "srbh_bn_bwd_finalize_clear", "srbh_bn_eval_scale_shift"):
         return name[5:], 0
     if name == "srbh_wmse_sum":
         return "loss wmse_sum", args[3] * 12

@@ -22,7 +22,10 @@ import os
 
 import torch
 
-ENABLED = os.environ.get("SRBH_WGRAD_SIDE", "1") == "1"
+# OFF by default: the same-box A/B of the training step (profiles/r05b_ab_wgrad_side.txt) measured 33.26 ms without and 33.41 / 33.57 ms
+# with the side stream -- the ~100 cross-stream event pairs cost the main queue more than the overlap returns on this driver (the step
+# equals its kernel chain either way: eager == one captured graph, profiles/r05c_ab_train_graph.txt).  Kept as a tested switch.
+ENABLED = os.environ.get("SRBH_WGRAD_SIDE", "0") == "1"
 _STATE = {}          # device index -> {"stream": Stream, "dirty": bool}
 
 
