@@ -351,6 +351,32 @@ int srbh_hconv_wgrad_b16(const srbh_hwgrad_args* a, void* stream);
  * that input: a3 / a1 = the arguments the two srbh_hconv_wgrad_b16 calls would take.  Fused when they describe the same sources, shape
  * and element types (cout a multiple of 16, 4-aligned channels); otherwise it runs the two calls.  Same results either way. */
 int srbh_hconv_wgrad_entry_b16(const srbh_hwgrad_args* a3, const srbh_hwgrad_args* a1, void* stream);
+/* The backward of ONE 3x3, 16 -> 16 convolution of a BasicBlock behind its BatchNorm, in one pass (round 5; reference graph:
+ * SR/HRfuse.py:142-159 through torch autograd).  With y = bn(conv(x')), g = dL/dy and the constants of srbh_bn_bwd_finalize,
+ *     dc = coef * (g' - k1 - xhat * k2),  g' = g where c*mask_scale + mask_shift > 0 (mask optional),  xhat = (c - mean) * invstd
+ * is formed while the window is staged (rounded once to bf16, as srbh_bn_bwd_apply_io's bf16 store did) and feeds BOTH
+ *     dw[oc][ci][tap] = sum_px dc[px][oc] * x'[px + tap][ci],   x' = relu?(x*pre_scale + pre_shift) rounded to bf16   (srbh_hconv_wgrad_b16)
+ *     dx[px][ci]      = conv^T(dc, W) [+ res]                                                                          (srbh_hconv_h16, bf16)
+ * without dc ever being written: 160 - 256 bytes per pixel instead of the 352 of apply + weight gradient + data gradient.
+ * g / res: bf16 NHWC [B][H][W][16];  c / x / bstat_c: fp32 NHWC [B][H][W][16];  w: srbh_hpack_conv_h16(transpose_flip = 1, bf16 = 1);
+ * dx: bf16 (dx_b16) or fp32;  dw: OIHW fp32 [16][16][3][3];  ws: srbh_hwgrad_ws_bytes(16, 16, 3).
+ * stats (optional, srbh_bn_stats_bytes(16)): the BatchNorm-backward sums of dx as the gradient of relu?(bn'(bstat_c)) -- srbh_hconv_args'
+ * bstat epilogue -- taken from the fp32 accumulators; no res then.  W % 64 == 0, H % 4 == 0 (srbh_hbwd16_supported). */
+typedef struct srbh_hbwd16_args {
+    const void* g; const float* c;
+    const float* mean; const float* invstd; const float* coef; const float* k1; const float* k2;
+    const float* mask_scale; const float* mask_shift;
+    const float* x; const float* pre_scale; const float* pre_shift; int pre_relu;
+    const void* w;
+    int B, H, W;
+    void* dx; int dx_b16;
+    const void* res;
+    const float* bstat_c; const float* bstat_mean; const float* bstat_invstd; const float* bstat_ms; const float* bstat_mh;
+    double* stats; int stats_clean;
+    float* dw; float* ws;
+} srbh_hbwd16_args;
+int srbh_hbwd16_supported(int H, int W);
+int srbh_hbwd16(const srbh_hbwd16_args* a, void* stream);
 /* out = g where ref > 0 else 0   (ReLU backward with the saved output, SR/HRfuse.py:157) */
 int srbh_relu_mask_mul(const float* g, const float* ref, float* out, long n, void* stream);
 int srbh_add_inplace(float* a, const float* b, long n, void* stream);

@@ -99,6 +99,15 @@ class HConvArgs(C.Structure):
     ]
 
 
+class HBwd16Args(C.Structure):
+    _fields_ = ([("g", C.c_void_p), ("c", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("coef", C.c_void_p), ("k1", C.c_void_p),
+                 ("k2", C.c_void_p), ("mask_scale", C.c_void_p), ("mask_shift", C.c_void_p), ("x", C.c_void_p), ("pre_scale", C.c_void_p),
+                 ("pre_shift", C.c_void_p), ("pre_relu", C.c_int), ("w", C.c_void_p), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                 ("dx", C.c_void_p), ("dx_b16", C.c_int), ("res", C.c_void_p), ("bstat_c", C.c_void_p), ("bstat_mean", C.c_void_p),
+                 ("bstat_invstd", C.c_void_p), ("bstat_ms", C.c_void_p), ("bstat_mh", C.c_void_p), ("stats", C.c_void_p), ("stats_clean", C.c_int),
+                 ("dw", C.c_void_p), ("ws", C.c_void_p)])
+
+
 class HWGradArgs(C.Structure):
     _fields_ = [
         ("src0", C.c_void_p), ("c0", C.c_int),
@@ -198,6 +207,8 @@ SIGNATURES = {
     "srbh_hconv_wgrad_f32": (_i, [C.POINTER(HWGradArgs), _vp]),
     "srbh_hconv_wgrad_b16": (_i, [C.POINTER(HWGradArgs), _vp]),
     "srbh_hconv_wgrad_entry_b16": (_i, [C.POINTER(HWGradArgs), C.POINTER(HWGradArgs), _vp]),
+    "srbh_hbwd16_supported": (_i, [_i, _i]),
+    "srbh_hbwd16": (_i, [C.POINTER(HBwd16Args), _vp]),
     "srbh_relu_mask_mul": (_i, [_vp, _vp, _vp, C.c_long, _vp]),
     "srbh_add_inplace": (_i, [_vp, _vp, C.c_long, _vp]),
     "srbh_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp, _vp]),

@@ -947,6 +947,7 @@ __global__ __launch_bounds__(256) void hwgrad_entry64_b16_kernel(const WGParams 
 }
 
 #include "srbh_hwgrad16_kernel.h"
+#include "srbh_hbwd16_kernel.h"
 
 // Sum of the workgroups' partials in a fixed order (deterministic), two stages so that enough loads are in flight:
 //   stage 1: tmp[s][u] = sum of the partials x in slice s (x = s*per .. s*per+per-1), grid (U/256, slices);
@@ -1490,6 +1491,60 @@ extern "C" int srbh_act16_wgrad_b16(const void* x, int x_chunks_total, int cin, 
     hipLaunchKernelGGL(hwgrad_reduce1_kernel, dim3((unsigned)((U + 255) / 256), SLICES), dim3(256), 0, st, ws, tmp, U, gx, per);
     SRBH_HIP(hipGetLastError());
     hipLaunchKernelGGL(hwgrad_reduce2_kernel, dim3((total + 255) / 256), dim3(256), 0, st, tmp, dw, U, SLICES, nchunk, taps, cout, cin);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_hbwd16_supported(int H, int W) { return H > 0 && W > 0 && (W & 63) == 0 && (H & 3) == 0; }
+
+/* One pass for the backward of a 3x3, 16 -> 16 conv behind its BatchNorm (srbh_hbwd16_kernel.h): dc never reaches memory. */
+extern "C" int srbh_hbwd16(const srbh_hbwd16_args* a, void* stream) {
+    SRBH_REQUIRE(a && a->g && a->c && a->mean && a->invstd && a->coef && a->k1 && a->k2 && a->x && a->w && a->dx && a->dw && a->ws,
+                 "srbh_hbwd16: null pointer");
+    SRBH_REQUIRE(a->B > 0 && srbh_hbwd16_supported(a->H, a->W), "srbh_hbwd16: W %% 64 == 0 and H %% 4 == 0 (srbh_hbwd16_supported)");
+    SRBH_REQUIRE((a->mask_scale == nullptr) == (a->mask_shift == nullptr) && (a->pre_scale == nullptr) == (a->pre_shift == nullptr),
+                 "srbh_hbwd16: scale / shift come in pairs");
+    SRBH_REQUIRE(!a->stats || (a->bstat_c && a->bstat_mean && a->bstat_invstd && !a->res && (a->bstat_ms == nullptr) == (a->bstat_mh == nullptr)),
+                 "srbh_hbwd16: the statistics epilogue needs bstat_c / mean / invstd and takes no skip gradient");
+    SRBH_REQUIRE((((uintptr_t)a->g | (uintptr_t)a->res) & 7) == 0 && (((uintptr_t)a->c | (uintptr_t)a->x | (uintptr_t)a->bstat_c | (uintptr_t)a->w) & 15) == 0 &&
+                 ((uintptr_t)a->dx & (a->dx_b16 ? 7 : 15)) == 0, "srbh_hbwd16: misaligned tensor");
+    hipStream_t st = (hipStream_t)stream;
+    HBParams p;
+    p.g = a->g; p.c = a->c; p.mean = a->mean; p.invstd = a->invstd; p.coef = a->coef; p.k1 = a->k1; p.k2 = a->k2;
+    p.ms = a->mask_scale; p.mh = a->mask_shift;
+    p.x = a->x; p.pre_scale = a->pre_scale; p.pre_shift = a->pre_shift; p.pre_relu = a->pre_relu;
+    p.w = a->w; p.dx = a->dx; p.dx_b16 = a->dx_b16; p.res = a->res;
+    p.bstat_c = a->bstat_c; p.bstat_mean = a->bstat_mean; p.bstat_invstd = a->bstat_invstd; p.bstat_ms = a->bstat_ms; p.bstat_mh = a->bstat_mh;
+    p.stats = a->stats; p.ws = a->ws;
+    p.B = a->B; p.H = a->H; p.W = a->W;
+    p.tiles_x = a->W / 64;
+    p.tiles_per_img = p.tiles_x * (a->H / 4);
+    p.ntiles = p.tiles_per_img * a->B;
+    p.tiles_per_xcd = (p.ntiles + 7) / 8;
+    static const int wgs = getenv("SRBH_HBWD16_WGS") ? atoi(getenv("SRBH_HBWD16_WGS")) : 512;
+    SRBH_REQUIRE(wgs >= 8 && wgs <= WS_SLOTS, "SRBH_HBWD16_WGS must be 8 .. %d", WS_SLOTS);
+    const int per_xcd = p.tiles_per_xcd < wgs / 8 ? p.tiles_per_xcd : wgs / 8;
+    const int gx = per_xcd * 8;
+    if (a->stats && !a->stats_clean) { if (int rc = zero_async(a->stats, (size_t)NSLOT * 2 * 16 * sizeof(double), st)) return rc; }
+#define SRBH_HB(B_, M_)                                                                                                            \
+    do {                                                                                                                      \
+        SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hbwd16_kernel<B_, M_>, hipFuncAttributeMaxDynamicSharedMemorySize, HB16::LDS_B))); \
+        hipLaunchKernelGGL((hbwd16_kernel<B_, M_>), dim3(gx), dim3(256), HB16::LDS_B, st, p);                                   \
+    } while (0)
+    if (a->stats && a->mask_scale) SRBH_HB(1, 1);
+    else if (a->stats) SRBH_HB(1, 0);
+    else if (a->mask_scale) SRBH_HB(0, 1);
+    else SRBH_HB(0, 0);
+#undef SRBH_HB
+    SRBH_HIP(hipGetLastError());
+    // the workgroups' weight-gradient partials -> dW (the ordered two-stage reduce of srbh_hconv_wgrad_b16)
+    constexpr int SLICES = 16;
+    const long U = 9 * 256;
+    float* tmp = a->ws + (long)WS_SLOTS * U;
+    const int per = (gx + SLICES - 1) / SLICES;
+    hipLaunchKernelGGL(hwgrad_reduce1_kernel, dim3((unsigned)((U + 255) / 256), SLICES), dim3(256), 0, st, a->ws, tmp, U, gx, per);
+    SRBH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(hwgrad_reduce2_kernel, dim3((16 * 16 * 9 + 255) / 256), dim3(256), 0, st, tmp, a->dw, U, SLICES, 1, 9, 16, 16);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }

@@ -144,6 +144,56 @@ def conv_wgrad_entry(srcs, g3, g1, cout):
 
 
 FUSE_BN_REDUCE = __import__("os").environ.get("SRBH_FUSE_BN_REDUCE", "1") == "1"      # (0: the separate reduce pass, A/B aid)
+# the backward of a 16 -> 16 conv behind its BatchNorm as ONE pass (srbh_hbwd16: dc never written); SRBH_HBWD16=0: apply + weight gradient +
+# data gradient as three launches (A/B aid)
+HBWD16 = __import__("os").environ.get("SRBH_HBWD16", "1") == "1"
+
+
+def hbwd16_ok(c, x, weight):
+    """shapes / element types srbh_hbwd16 takes (the gradient tensor is the bf16 one this backward writes itself): fp32 BatchNorm input and
+    conv input, 16 -> 16 3x3, no synchronised statistics"""
+    B, Cc, Hh, Ww = c.shape
+    return (HBWD16 and H.head_h16() and c.dtype == torch.float32 and x.dtype == torch.float32 and tuple(weight.shape) == (16, 16, 3, 3)
+            and Cc == 16 and tuple(x.shape) == tuple(c.shape) and H.bn_sync_world() <= 1 and bool(_lib.lib().srbh_hbwd16_supported(Hh, Ww)))
+
+
+def hbwd16(g, c, mean, invstd, consts, mask, x, pre, weight, cache, res=None, out_b16=False, bstat=None, gen_src=None):
+    """(dx, dw[, stats]) of conv behind BatchNorm in one pass: dc = coef*(g' - k1 - xhat*k2) formed while staged, dw = wgrad(x', dc),
+    dx = conv^T(dc, W) (+ res).  consts = (coef, k1, k2) of bn_backward(apply=False); mask = (ms, mh) of the ReLU behind the BatchNorm or
+    None; pre = (scale, shift, relu) of the conv's forward operand transform or None; bstat = (c', mean', invstd', ms', mh', stats):
+    the BatchNorm-backward sums of dx (no res then)."""
+    L = _lib.lib()
+    B, Cc, Hh, Ww = c.shape
+    dev = c.device
+    a = _lib.HBwd16Args()
+    a.g, a.c = g.data_ptr(), c.data_ptr()
+    a.mean, a.invstd = mean.data_ptr(), invstd.data_ptr()
+    a.coef, a.k1, a.k2 = consts[0].data_ptr(), consts[1].data_ptr(), consts[2].data_ptr()
+    if mask is not None:
+        a.mask_scale, a.mask_shift = mask[0].data_ptr(), mask[1].data_ptr()
+    a.x = x.data_ptr()
+    if pre is not None:
+        a.pre_scale, a.pre_shift, a.pre_relu = pre[0].data_ptr(), pre[1].data_ptr(), int(pre[2])
+    wp = cache.get(weight, True, gen_src)
+    a.w = wp.data_ptr()
+    a.B, a.H, a.W = B, Hh, Ww
+    dx = H.empty_nhwc(B, 16, Hh, Ww, dev, torch.bfloat16 if out_b16 else torch.float32)
+    a.dx, a.dx_b16 = dx.data_ptr(), int(out_b16)
+    if res is not None:
+        if res.dtype != torch.bfloat16:
+            raise TypeError("srbh_hbwd16: the skip gradient must be a bf16 tensor")
+        a.res = res.data_ptr()
+    if bstat is not None:
+        bc, bm, bi, bms, bmh, st = bstat
+        a.bstat_c, a.bstat_mean, a.bstat_invstd = bc.data_ptr(), bm.data_ptr(), bi.data_ptr()
+        if bms is not None:
+            a.bstat_ms, a.bstat_mh = bms.data_ptr(), bmh.data_ptr()
+        a.stats, a.stats_clean = st.data_ptr(), int(H.stats_clean(st))
+    dw = torch.empty((16, 16, 3, 3), dtype=torch.float32, device=dev)
+    ws = torch.empty(L.srbh_hwgrad_ws_bytes(16, 16, 3) // 4, dtype=torch.float32, device=dev)
+    a.dw, a.ws = dw.data_ptr(), ws.data_ptr()
+    _lib.check(L.srbh_hbwd16(C.byref(a), _lib.stream_ptr()), "hbwd16")
+    return dx, dw
 
 
 def _stats_buf(Cc, dev):
@@ -172,11 +222,12 @@ def channel_sum(g):
     return out
 
 
-def bn_backward(g, c, mean, invstd, gamma, mask, training, relu_ref=None, out_b16=False, stats_ready=None):
+def bn_backward(g, c, mean, invstd, gamma, mask, training, relu_ref=None, out_b16=False, stats_ready=None, apply=True):
     """BatchNorm (+ optional ReLU mask [c*ms+mh > 0]) backward.  Returns (dc, dgamma, dbeta).
     stats_ready: the statistics buffer the producer of `g` filled in its epilogue (conv_dgrad(..., bstat=...)): the reduce pass is skipped.
     relu_ref: the gradient first passes the block-closing ReLU (dz = g where relu_ref > 0) inside the reduce pass; returns
-    (dc, dgamma, dbeta, dz).  16-bit tensors (TRAIN_IO16): g may be bf16, c fp16; out_b16 writes dz / dc as bf16."""
+    (dc, dgamma, dbeta, dz).  16-bit tensors (TRAIN_IO16): g may be bf16, c fp16; out_b16 writes dz / dc as bf16.
+    apply=False: no apply pass -- the first element returned is (coef, k1, k2), the per-channel constants of dc = coef*(dy - k1 - xhat*k2)."""
     L = _lib.lib()
     B, Cc, Hh, Ww = c.shape
     n = B * Hh * Ww
@@ -234,6 +285,9 @@ def bn_backward(g, c, mean, invstd, gamma, mask, training, relu_ref=None, out_b1
     if not training:       # frozen statistics: the mean terms vanish
         k1.zero_()
         k2.zero_()
+    if not apply:          # the consumer forms dc itself (hbwd16: srbh_hbwd16): (coef, k1, k2) instead of the tensor
+        consts = (coef, k1, k2)
+        return (consts, dgamma, dbeta, dz) if relu_ref is not None else (consts, dgamma, dbeta)
     dc = H.empty_nhwc(B, Cc, Hh, Ww, dev, odt)
     if use_io:
         io = io_c | (4 if g.dtype == torch.bfloat16 else 0) | (1 if out_b16 else 0)
@@ -365,11 +419,28 @@ class _BasicBlockFn(torch.autograd.Function):
         caches = blk.__dict__.setdefault("_srbh_gcaches", [_PackedGrad(), _PackedGrad(), _PackedGrad()])
         b16 = bool(getattr(ctx, "io16", False)) and H.head_h16()       # gradient tensors internal to this backward: bf16
         # through the final ReLU (folded into bn2's reduce pass) -> bn2 -> conv2
-        dc2, dg2, db2, dz = bn_backward(H.to_nhwc(g), c2, m2, i2, g2, None, tr, relu_ref=out, out_b16=b16)
-        dw2 = conv_wgrad([c1], (s1, h1, True), dc2, w2.shape[0], 3)
+        g = H.to_nhwc(g)
+        fuse2 = b16 and tr and FUSE_BN_REDUCE and hbwd16_ok(c2, c1, w2)
+        consts1 = None
+        if fuse2:
+            # conv2's whole backward behind bn2 in ONE pass (srbh_hbwd16): dc2 is never written; bn1's backward sums come out of its epilogue
+            k2c, dg2, db2, dz = bn_backward(g, c2, m2, i2, g2, None, tr, relu_ref=out, out_b16=True, apply=False)
+            st1 = _stats_buf(16, c1.device)
+            da1, dw2 = hbwd16(dz, c2, m2, i2, k2c, None, c1, (s1, h1, True), w2, caches[1], out_b16=True, bstat=(c1, m1, i1, s1, h1, st1))
+            plain = (not has_ds and nsrc == 1 and ctx.needs_input_grad[1] and hbwd16_ok(c1, srcs[0], w1))
+            r1 = bn_backward(da1, c1, m1, i1, g1, (s1, h1), tr, out_b16=True, stats_ready=st1, apply=not plain)
+            if plain:
+                consts1, dg1, db1 = r1
+            else:
+                dc1, dg1, db1 = r1
+        else:
+            dc2, dg2, db2, dz = bn_backward(g, c2, m2, i2, g2, None, tr, relu_ref=out, out_b16=b16)
+            dw2 = conv_wgrad([c1], (s1, h1, True), dc2, w2.shape[0], 3)
         # relu -> bn1 -> conv1   (mask: bn1(c1) > 0): bn1's backward sums come out of conv2's data-gradient epilogue when that is the
         # persistent 16 -> 16 kernel (one read of c1 there instead of a reduce pass over da1 and c1)
-        if bstat_fusable(dc2, w2, c1):
+        if fuse2:
+            pass
+        elif bstat_fusable(dc2, w2, c1):
             st1 = _stats_buf(c1.shape[1], c1.device)
             da1 = conv_dgrad(dc2, w2, caches[1], out_b16=b16, bstat=(c1, m1, i1, s1, h1, st1))
             dc1, dg1, db1 = bn_backward(da1, c1, m1, i1, g1, (s1, h1), tr, out_b16=b16, stats_ready=st1)
@@ -378,6 +449,11 @@ class _BasicBlockFn(torch.autograd.Function):
             dc1, dg1, db1 = bn_backward(da1, c1, m1, i1, g1, (s1, h1), tr, out_b16=b16)
         need_dx = ctx.needs_input_grad[1] or (nsrc > 1 and ctx.needs_input_grad[2])
         dwd = dgd = dbd = None
+        if consts1 is not None:
+            # plain 16-channel block: conv1's backward behind bn1 in one pass as well: dc1 never written, the skip gradient dz added in the
+            # epilogue, dx leaves as the fp32 tensor autograd carries
+            dx0, dw1 = hbwd16(da1, c1, m1, i1, consts1, (s1, h1), srcs[0], None, w1, caches[0], res=dz, out_b16=False)
+            return (None, dx0, None, dw1, dg1, db1, dw2, dg2, db2, None, None, None)
         skip = dz if need_dx else None          # gradient arriving over the identity / downsample path
         if has_ds:
             dd, dgd, dbd = bn_backward(dz, d, md, idd, gd, None, tr, out_b16=b16)

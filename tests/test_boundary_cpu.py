@@ -53,7 +53,8 @@ def test_ctypes_struct_matches_header_field_order():
     from srbh_amd import _lib
     pairs = {"srbh_conv3x3_args": _lib.ConvArgs, "srbh_hconv_args": _lib.HConvArgs, "srbh_hwgrad_args": _lib.HWGradArgs,
              "srbh_bnact_args": _lib.BnActArgs, "srbh_bnact_bwd_args": _lib.BnActBwdArgs, "srbh_conv_w": _lib.ConvW,
-             "srbh_rrdbnet_desc": _lib.RRDBNetDesc, "srbh_mbmid_args": _lib.MbMidArgs, "srbh_mbmid_bwd_args": _lib.MbMidBwdArgs}
+             "srbh_rrdbnet_desc": _lib.RRDBNetDesc, "srbh_mbmid_args": _lib.MbMidArgs, "srbh_mbmid_bwd_args": _lib.MbMidBwdArgs,
+             "srbh_hbwd16_args": _lib.HBwd16Args}
     for struct, cls in pairs.items():
         assert _header_fields(struct) == [n.rstrip("_") for n, _ in cls._fields_], struct
     assert _header_fields("srbh_transpose_desc") == ["src", "dst", "rows", "cols"]       # (built as a numpy record in encoders.py)
