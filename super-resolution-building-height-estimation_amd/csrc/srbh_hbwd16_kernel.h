@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
         const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
         const long pix0 = ((long)img * p.H + ty * 4 + wave) * p.W + tx * 64 + l15;
         // epilogue operands of THIS tile first (c of the statistics / the skip gradient), then the next tile's window
-        floatx4 rres[4];
+        floatx4 rres[BS != 0 ? 4 : 1];
+        float2w rraw[BS != 0 ? 1 : 4];           // (the skip gradient: raw bf16 quads, widened in the epilogue)
         if constexpr (BS != 0) {
             const float* rp = p.bstat_c + pix0 * 16 + kk * 4;
 #pragma unroll
@@ -220,10 +221,7 @@ __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
         } else if (p.res) {
             const char* rp = (const char*)p.res + (pix0 * 16 + kk * 4) * 2;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float2w raw = *(const float2w*)(rp + (long)i * 16 * 16 * 2);
-                rres[i][0] = raw[0]; rres[i][1] = raw[1];
-            }
+            for (int i = 0; i < 4; ++i) rraw[i] = *(const float2w*)(rp + (long)i * 16 * 16 * 2);
         }
         if (t + t_step < t_end) issue(t + t_step);
         __syncthreads();           // stage `buf` complete; every wave is past the MFMAs of the tile before (other stage)
@@ -274,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
                     ssq[q] = fmaf(dz, (c - b_mean[q]) * b_inv[q], ssq[q]);
                 }
             } else if (p.res) {
-                v = v + widen_b4(float2w{rres[i][0], rres[i][1]});
+                v = v + widen_b4(rraw[i]);
             }
             if (p.dx_b16) *(float2w*)((char*)p.dx + ((pix0 + i * 16) * 16 + kk * 4) * 2) = narrow_b4(v);
             else *(floatx4*)((float*)p.dx + (pix0 + i * 16) * 16 + kk * 4) = v;

@@ -76,6 +76,13 @@ def _model(name, args):
         # one pass over the input when fused (the common case): sources once, two dY tensors
         return (f"wgrad_entry_bf16 {a.c0}{'+' + str(a.c1) if a.c1 else ''}->{a.cout} k3 + k1{' io=' + str(a.io) if a.io else ''} @{a.H}x{a.W}",
                 px * (a.c0 * ex + a.c1 * 4 + 2 * a.cout * ed))
+    if name == "srbh_hbwd16":
+        a = args[0]._obj
+        px = a.B * a.H * a.W
+        # each tensor once at its stored element size: g bf16, c / x fp32, dx bf16 | fp32, the statistics epilogue's c fp32 or the skip gradient bf16
+        nbytes = px * 16 * (2 + 4 + 4 + (2 if a.dx_b16 else 4) + (4 if a.stats else 0) + (2 if a.res else 0))
+        return (f"hbwd16 (BN apply + wgrad + dgrad, one pass) 16->16 k3{' +bwd-stats' if a.stats else ''}{' +mask' if a.mask_scale else ''}{' +res' if a.res else ''} "
+                f"out={'bf16' if a.dx_b16 else 'fp32'} @{a.H}x{a.W}", nbytes)
     if name in ("srbh_hconv_wgrad_f32", "srbh_hconv_wgrad_b16"):
         a = args[0]._obj
         px = _px(a)
@@ -89,6 +96,9 @@ def _model(name, args):
     if name == "srbh_bn_add_relu_io":
         npix, Cc, io = args[7], args[8], args[9]
         return f"bn_add_relu C={Cc}{' io=' + str(io) if io else ''}", npix * Cc * ((2 if io & 1 else 4) + (2 if io & 2 else 4) + 4)
+    if name == "srbh_bn_add_relu_bits":      # (+ the ReLU's activity pattern, 1 bit per element)
+        npix, Cc, io = args[8], args[9], args[10]
+        return f"bn_add_relu+bits C={Cc}{' io=' + str(io) if io else ''}", npix * Cc * ((2 if io & 1 else 4) + (2 if io & 2 else 4) + 4) + npix * Cc // 8
     if name == "srbh_bn_bwd_reduce":
         g, c, npix, Cc = args[0], args[1], args[6], args[7]
         return f"bn_bwd_reduce C={Cc}{'' if c else ' (bias grad)'}", npix * Cc * (4 + (4 if c else 0))
@@ -161,6 +171,17 @@ def _model_encdec(name, args):
         return f"{name[5:]} {Cx}+{Cs} @{Hh}x{Ww}", B * (Cx * Hh * Ww + (Cx + 2 * Cs) * 4 * Hh * Ww) * 4
     if name == "srbh_transpose_many":
         return "transpose_many (all 1x1 weights)", 0
+    if name in ("srbh_mbconv_mid_fwd", "srbh_mbconv_mid_bwd"):          # BatchNorm0 + SiLU -> depthwise -> BatchNorm1 + SiLU (+ pool), one launch
+        a = args[0]._obj
+        n = a.B * a.C * a.H * a.W * 4
+        # forward: e_pre read, d_pre + y written; backward: dout, d_pre, e_pre read, de_pre written
+        return f"{name[5:]} C={a.C} k{a.K} @{a.H}x{a.W}", n * (3 if name.endswith("fwd") else 4)
+    if name == "srbh_dconv_fwd":
+        B, Cin, Cout, Hh, Ww, b16 = args[3], args[4], args[5], args[6], args[7], args[8]
+        return f"dconv_{'dgrad' if b16 else 'fwd'} {Cin}->{Cout} @{Hh}x{Ww}", (B * Hh * Ww * (Cin + Cout) + 9 * Cin * Cout) * 4
+    if name == "srbh_dconv_wgrad":
+        B, Cin, Cout, Hh, Ww = args[4], args[5], args[6], args[7], args[8]
+        return f"dconv_wgrad {Cin}->{Cout} @{Hh}x{Ww}", (B * Hh * Ww * (Cin + Cout) + 9 * Cin * Cout) * 4
     return None
 
 
@@ -230,11 +251,12 @@ class KernelProfile:
 def _model_names(name):
     if name.startswith("srbh_bn_act_train"):       # (encoder / decoder BatchNorm: group "encdec")
         return False
-    return name.startswith(("srbh_hconv_f32", "srbh_hconv_h16", "srbh_hconv_entry", "srbh_hconv_wgrad", "srbh_bn_", "srbh_relu_mask",
+    return name.startswith(("srbh_hconv_f32", "srbh_hconv_h16", "srbh_hconv_entry", "srbh_hconv_wgrad", "srbh_hbwd16", "srbh_bn_", "srbh_relu_mask",
                             "srbh_add_inplace", "srbh_ps2_inverse", "srbh_nchw_to_nhwc", "srbh_wmse", "srbh_cedice"))
 
 
 def _encdec_names(name):
-    return name.startswith(("srbh_bn_act_train_fwd", "srbh_bn_act_train_bwd", "srbh_se_train_fwd", "srbh_se_train_bwd", "srbh_pwconv_fwd",
-                            "srbh_pwconv_bwd_data", "srbh_pwconv_bwd_weight", "srbh_dwconv_fwd", "srbh_dwconv_bwd_data", "srbh_dwconv_bwd_weight",
-                            "srbh_up2_cat", "srbh_transpose_many")) and not name.endswith(("_supported", "_ws_bytes", "_ws_floats", "_splits"))
+    return (name.startswith(("srbh_bn_act_train_fwd", "srbh_bn_act_train_bwd", "srbh_se_train_fwd", "srbh_se_train_bwd", "srbh_pwconv_fwd",
+                             "srbh_pwconv_bwd_data", "srbh_pwconv_bwd_weight", "srbh_dwconv_fwd", "srbh_dwconv_bwd_data", "srbh_dwconv_bwd_weight",
+                             "srbh_up2_cat", "srbh_transpose_many", "srbh_mbconv_mid_fwd", "srbh_mbconv_mid_bwd", "srbh_dconv_fwd", "srbh_dconv_wgrad"))
+            and name != "srbh_dconv_fwd_epi" and not name.endswith(("_supported", "_ws_bytes", "_ws_floats", "_splits")))
