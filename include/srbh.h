@@ -361,7 +361,7 @@ int srbh_hconv_wgrad_entry_b16(const srbh_hwgrad_args* a3, const srbh_hwgrad_arg
  * g / res: bf16 NHWC [B][H][W][16];  c / x / bstat_c: fp32 NHWC [B][H][W][16];  w: srbh_hpack_conv_h16(transpose_flip = 1, bf16 = 1);
  * dx: bf16 (dx_b16) or fp32;  dw: OIHW fp32 [16][16][3][3];  ws: srbh_hwgrad_ws_bytes(16, 16, 3).
  * stats (optional, srbh_bn_stats_bytes(16)): the BatchNorm-backward sums of dx as the gradient of relu?(bn'(bstat_c)) -- srbh_hconv_args'
- * bstat epilogue -- taken from the fp32 accumulators; no res then.  W % 64 == 0, H % 4 == 0 (srbh_hbwd16_supported). */
+ * bstat epilogue -- taken from the fp32 accumulators; no res then (but see relu_bits).  W % 64 == 0, H % 4 == 0 (srbh_hbwd16_supported). */
 typedef struct srbh_hbwd16_args {
     const void* g; const float* c;
     const float* mean; const float* invstd; const float* coef; const float* k1; const float* k2;
@@ -374,6 +374,11 @@ typedef struct srbh_hbwd16_args {
     const float* bstat_c; const float* bstat_mean; const float* bstat_invstd; const float* bstat_ms; const float* bstat_mh;
     double* stats; int stats_clean;
     float* dw; float* ws;
+    /* optional (conv1's use inside a chain of blocks, hrfuse_autograd._BlockChainFn): dx (+ res) is the gradient of the PREVIOUS block's output
+     * out' = relu(bn2'(c2') + idt').  With relu_bits (srbh_bn_add_relu_bits' buffer of that block) dx is masked with that ReLU, written as
+     * bf16 (dx_b16 must be 1) and `stats` receives the BatchNorm-backward sums of bn2' (bstat_c = c2', bstat_mean / bstat_invstd its batch
+     * statistics, no bstat_ms) over the rounded values: the previous block's srbh_bn_bwd_reduce_io pass, without the fp32 tensor. */
+    const void* relu_bits;
 } srbh_hbwd16_args;
 int srbh_hbwd16_supported(int H, int W);
 int srbh_hbwd16(const srbh_hbwd16_args* a, void* stream);

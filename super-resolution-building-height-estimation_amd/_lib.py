@@ -105,7 +105,7 @@ class HBwd16Args(C.Structure):
                  ("pre_shift", C.c_void_p), ("pre_relu", C.c_int), ("w", C.c_void_p), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
                  ("dx", C.c_void_p), ("dx_b16", C.c_int), ("res", C.c_void_p), ("bstat_c", C.c_void_p), ("bstat_mean", C.c_void_p),
                  ("bstat_invstd", C.c_void_p), ("bstat_ms", C.c_void_p), ("bstat_mh", C.c_void_p), ("stats", C.c_void_p), ("stats_clean", C.c_int),
-                 ("dw", C.c_void_p), ("ws", C.c_void_p)])
+                 ("dw", C.c_void_p), ("ws", C.c_void_p), ("relu_bits", C.c_void_p)])
 
 
 class HWGradArgs(C.Structure):

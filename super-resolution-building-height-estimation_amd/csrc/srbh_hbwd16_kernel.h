@@ -18,6 +18,9 @@
 // Same operand rounding and MFMA order per output element as the separate kernels (the walk, the fragments and the accumulation order
 // are theirs): results agree with the three-launch path to the last bits of the fp32 apply arithmetic (tests/test_gpu_hbwd16.py).
 // Restrictions (host: srbh_hbwd16_supported): 16 channels everywhere, W % 64 == 0, H % 4 == 0, dense NHWC tensors.
+#ifndef HB16_LATE
+#define HB16_LATE 0          // (measured: 329 / 342 / 338 us for 0 / 1 / 2, profiles/r05k_time_hbwd16_chain.txt -- the spills are not these registers)
+#endif
 struct HB16 {
     static constexpr int QX = WG16T::QX, SX = WG16T::SX, SD = WG16T::SD;      // 18 quads per row, channel strides of the two channel-major copies
     static constexpr int ROWS = 6, COLS = 66;
@@ -38,11 +41,16 @@ struct HBParams {
     const void* res;          // bf16 [B][H][W][16] or null
     const float* bstat_c; const float* bstat_mean; const float* bstat_invstd; const float* bstat_ms; const float* bstat_mh;
     double* stats;
+    const unsigned long long* relu_bits;   // BS = 2: activity pattern of the ReLU the output gradient passes next (srbh_bn_add_relu_bits' layout)
     float* ws;
     int B, H, W, tiles_x, tiles_per_img, ntiles, tiles_per_xcd;
 };
 
-// BS: 1 = BatchNorm-backward sums of the OUTPUT gradient in the epilogue (conv2's use), 0 = none;  MK: 1 = g is masked with c*ms + mh > 0
+// BS: 0 = none; 1 = BatchNorm-backward sums of the OUTPUT gradient in the epilogue (conv2's use: the gradient of relu(bn'(bstat_c)));
+//     2 = the output gradient (+ res) is the gradient of the PREVIOUS block's output out' = relu(bn2'(c2') + idt'): it is masked with that ReLU's
+//         bit pattern, written as bf16 and summed for bn2' (sum dz', sum dz' xhat2' over the rounded values) -- exactly what that block's
+//         srbh_bn_bwd_reduce_io(SRBH_BN_REF_BITS | SRBH_BN_OUT_B16) pass would compute from the fp32 tensor this kernel then never writes
+// MK: 1 = g is masked with c*ms + mh > 0
 template <int BS, int MK>
 __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
     extern __shared__ __attribute__((aligned(16))) float hbsm[];
@@ -74,8 +82,8 @@ __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
             case C_PSH: v = p.pre_scale ? p.pre_shift[ch] : 0.f; break;
             case C_BMEAN: v = (BS != 0) ? p.bstat_mean[ch] : 0.f; break;
             case C_BINV: v = (BS != 0) ? p.bstat_invstd[ch] : 0.f; break;
-            case C_BMS: v = (BS != 0 && p.bstat_ms) ? p.bstat_ms[ch] : 0.f; break;
-            default: v = (BS != 0 && p.bstat_ms) ? p.bstat_mh[ch] : 1.f; break;       // (no mask given: every element passes, 1 > 0)
+            case C_BMS: v = (BS == 1 && p.bstat_ms) ? p.bstat_ms[ch] : 0.f; break;
+            default: v = (BS == 1 && p.bstat_ms) ? p.bstat_mh[ch] : 1.f; break;       // (no mask given: every element passes, 1 > 0)
         }
         cst[row * 16 + ch] = v;
     }
@@ -213,16 +221,22 @@ __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
         const long pix0 = ((long)img * p.H + ty * 4 + wave) * p.W + tx * 64 + l15;
         // epilogue operands of THIS tile first (c of the statistics / the skip gradient), then the next tile's window
         floatx4 rres[BS != 0 ? 4 : 1];
-        float2w rraw[BS != 0 ? 1 : 4];           // (the skip gradient: raw bf16 quads, widened in the epilogue)
-        if constexpr (BS != 0) {
+        float2w rraw[BS != 1 ? 4 : 1];           // (the skip gradient: raw bf16 quads, widened in the epilogue)
+        // HB16_LATE (BS = 2 only, where both are needed: 24 registers across the MFMAs cost 16 spills): 1 = the skip gradient, 2 = the skip
+        // gradient and c' are requested BEHIND the MFMAs (their latency is then covered by the other wave of the SIMD only)
+        auto load_c = [&]() {
             const float* rp = p.bstat_c + pix0 * 16 + kk * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) rres[i] = *(const floatx4*)(rp + i * 16 * 16);
-        } else if (p.res) {
+        };
+        auto load_res = [&]() {
             const char* rp = (const char*)p.res + (pix0 * 16 + kk * 4) * 2;
 #pragma unroll
             for (int i = 0; i < 4; ++i) rraw[i] = *(const float2w*)(rp + (long)i * 16 * 16 * 2);
-        }
+        };
+        constexpr int LATE = BS == 2 ? HB16_LATE : 0;
+        if constexpr (BS != 0 && LATE < 2) load_c();
+        if constexpr (BS != 1 && LATE < 1) { if (p.res) load_res(); }
         if (t + t_step < t_end) issue(t + t_step);
         __syncthreads();           // stage `buf` complete; every wave is past the MFMAs of the tile before (other stage)
         // ---- weight gradient: 4 pixel groups x 3 rows x 3 shifts (hwgrad16_kernel's loop)
@@ -259,10 +273,12 @@ __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
             }
         }
         // ---- epilogue of the data gradient
+        if constexpr (BS != 0 && LATE >= 2) load_c();
+        if constexpr (BS != 1 && LATE >= 1) { if (p.res) load_res(); }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             floatx4 v = acc[i];
-            if constexpr (BS != 0) {
+            if constexpr (BS == 1) {
                 const floatx4 b_ms = cq(C_BMS, kk), b_mh = cq(C_BMH, kk), b_mean = cq(C_BMEAN, kk), b_inv = cq(C_BINV, kk);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -271,6 +287,24 @@ __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
                     ssum[q] += dz;
                     ssq[q] = fmaf(dz, (c - b_mean[q]) * b_inv[q], ssq[q]);
                 }
+            } else if constexpr (BS == 2) {
+                if (p.res) v = v + widen_b4(rraw[i]);
+                // the 64 4-channel groups of this wave's 16 pixels share four 64-bit words (wave-uniform address: scalar loads)
+                const long grp0 = __builtin_amdgcn_readfirstlane((int)(((pix0 - l15) + i * 16) >> 4));
+                const unsigned long long* mw = p.relu_bits + grp0 * 4;
+                const int sh = l15 * 4 + kk;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ((mw[q] >> sh) & 1ull) ? v[q] : 0.f;
+                const float2w nb = narrow_b4(v);
+                *(float2w*)((char*)p.dx + ((pix0 + i * 16) * 16 + kk * 4) * 2) = nb;
+                const floatx4 dzr = widen_b4(nb);          // the sums are taken over the values the consumer reads
+                const floatx4 b_mean = cq(C_BMEAN, kk), b_inv = cq(C_BINV, kk);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ssum[q] += dzr[q];
+                    ssq[q] = fmaf(dzr[q], (rres[i][q] - b_mean[q]) * b_inv[q], ssq[q]);
+                }
+                continue;
             } else if (p.res) {
                 v = v + widen_b4(rraw[i]);
             }

@@ -1504,8 +1504,10 @@ extern "C" int srbh_hbwd16(const srbh_hbwd16_args* a, void* stream) {
     SRBH_REQUIRE(a->B > 0 && srbh_hbwd16_supported(a->H, a->W), "srbh_hbwd16: W %% 64 == 0 and H %% 4 == 0 (srbh_hbwd16_supported)");
     SRBH_REQUIRE((a->mask_scale == nullptr) == (a->mask_shift == nullptr) && (a->pre_scale == nullptr) == (a->pre_shift == nullptr),
                  "srbh_hbwd16: scale / shift come in pairs");
-    SRBH_REQUIRE(!a->stats || (a->bstat_c && a->bstat_mean && a->bstat_invstd && !a->res && (a->bstat_ms == nullptr) == (a->bstat_mh == nullptr)),
-                 "srbh_hbwd16: the statistics epilogue needs bstat_c / mean / invstd and takes no skip gradient");
+    SRBH_REQUIRE(!a->stats || (a->bstat_c && a->bstat_mean && a->bstat_invstd && (a->relu_bits || !a->res) && (a->bstat_ms == nullptr) == (a->bstat_mh == nullptr)),
+                 "srbh_hbwd16: the statistics epilogue needs bstat_c / mean / invstd and takes no skip gradient (unless relu_bits)");
+    SRBH_REQUIRE(!a->relu_bits || (a->stats && a->dx_b16 && !a->bstat_ms && ((uintptr_t)a->relu_bits & 7) == 0),
+                 "srbh_hbwd16: relu_bits needs stats + bstat_c / mean / invstd of the previous block's bn2, a bf16 dx and no bstat mask");
     SRBH_REQUIRE((((uintptr_t)a->g | (uintptr_t)a->res) & 7) == 0 && (((uintptr_t)a->c | (uintptr_t)a->x | (uintptr_t)a->bstat_c | (uintptr_t)a->w) & 15) == 0 &&
                  ((uintptr_t)a->dx & (a->dx_b16 ? 7 : 15)) == 0, "srbh_hbwd16: misaligned tensor");
     hipStream_t st = (hipStream_t)stream;
@@ -1515,7 +1517,7 @@ extern "C" int srbh_hbwd16(const srbh_hbwd16_args* a, void* stream) {
     p.x = a->x; p.pre_scale = a->pre_scale; p.pre_shift = a->pre_shift; p.pre_relu = a->pre_relu;
     p.w = a->w; p.dx = a->dx; p.dx_b16 = a->dx_b16; p.res = a->res;
     p.bstat_c = a->bstat_c; p.bstat_mean = a->bstat_mean; p.bstat_invstd = a->bstat_invstd; p.bstat_ms = a->bstat_ms; p.bstat_mh = a->bstat_mh;
-    p.stats = a->stats; p.ws = a->ws;
+    p.stats = a->stats; p.ws = a->ws; p.relu_bits = (const unsigned long long*)a->relu_bits;
     p.B = a->B; p.H = a->H; p.W = a->W;
     p.tiles_x = a->W / 64;
     p.tiles_per_img = p.tiles_x * (a->H / 4);
@@ -1531,7 +1533,9 @@ extern "C" int srbh_hbwd16(const srbh_hbwd16_args* a, void* stream) {
         SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)hbwd16_kernel<B_, M_>, hipFuncAttributeMaxDynamicSharedMemorySize, HB16::LDS_B))); \
         hipLaunchKernelGGL((hbwd16_kernel<B_, M_>), dim3(gx), dim3(256), HB16::LDS_B, st, p);                                   \
     } while (0)
-    if (a->stats && a->mask_scale) SRBH_HB(1, 1);
+    if (a->relu_bits && a->mask_scale) SRBH_HB(2, 1);
+    else if (a->relu_bits) SRBH_HB(2, 0);
+    else if (a->stats && a->mask_scale) SRBH_HB(1, 1);
     else if (a->stats) SRBH_HB(1, 0);
     else if (a->mask_scale) SRBH_HB(0, 1);
     else SRBH_HB(0, 0);

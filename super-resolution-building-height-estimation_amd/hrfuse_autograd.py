@@ -157,11 +157,12 @@ def hbwd16_ok(c, x, weight):
             and Cc == 16 and tuple(x.shape) == tuple(c.shape) and H.bn_sync_world() <= 1 and bool(_lib.lib().srbh_hbwd16_supported(Hh, Ww)))
 
 
-def hbwd16(g, c, mean, invstd, consts, mask, x, pre, weight, cache, res=None, out_b16=False, bstat=None, gen_src=None):
+def hbwd16(g, c, mean, invstd, consts, mask, x, pre, weight, cache, res=None, out_b16=False, bstat=None, gen_src=None, relu_bits=None):
     """(dx, dw[, stats]) of conv behind BatchNorm in one pass: dc = coef*(g' - k1 - xhat*k2) formed while staged, dw = wgrad(x', dc),
     dx = conv^T(dc, W) (+ res).  consts = (coef, k1, k2) of bn_backward(apply=False); mask = (ms, mh) of the ReLU behind the BatchNorm or
     None; pre = (scale, shift, relu) of the conv's forward operand transform or None; bstat = (c', mean', invstd', ms', mh', stats):
-    the BatchNorm-backward sums of dx (no res then)."""
+    the BatchNorm-backward sums of dx (no res then).  relu_bits (with bstat = the PREVIOUS block's (c2', mean2', invstd2', None, None, stats) and
+    out_b16): dx + res is masked with that block's closing ReLU, written as bf16 and summed for its bn2 -- its reduce pass, fused."""
     L = _lib.lib()
     B, Cc, Hh, Ww = c.shape
     dev = c.device
@@ -189,6 +190,8 @@ def hbwd16(g, c, mean, invstd, consts, mask, x, pre, weight, cache, res=None, ou
         if bms is not None:
             a.bstat_ms, a.bstat_mh = bms.data_ptr(), bmh.data_ptr()
         a.stats, a.stats_clean = st.data_ptr(), int(H.stats_clean(st))
+    if relu_bits is not None:       # dx (+ res) continues through the previous block's closing ReLU and bn2: masked bf16 + that BatchNorm's sums
+        a.relu_bits = relu_bits.data_ptr()
     dw = torch.empty((16, 16, 3, 3), dtype=torch.float32, device=dev)
     ws = torch.empty(L.srbh_hwgrad_ws_bytes(16, 16, 3) // 4, dtype=torch.float32, device=dev)
     a.dw, a.ws = dw.data_ptr(), ws.data_ptr()
@@ -369,6 +372,36 @@ class _BasicBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, blk, x0, x1, w1, g1, b1, w2, g2, b2, wd, gd, bd):
+        return _bb_forward(ctx, blk, x0, x1, w1, g1, b1, w2, g2, b2, wd, gd, bd)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bb_backward(ctx, g)
+
+
+class _Handoff:
+    """what a plain block's conv1 backward hands to the block in front of it inside a chain instead of an fp32 gradient tensor: the gradient
+    already through that block's closing ReLU (bf16) and the partial sums of its bn2 backward"""
+
+    def __init__(self, dz, stats):
+        self.dz, self.stats = dz, stats
+
+
+def _fuse2_ok(ctx):
+    """this block's backward takes conv2 behind bn2 as one srbh_hbwd16 pass (and can therefore start from a _Handoff)"""
+    sv = ctx.saved_tensors
+    nsrc = ctx.nsrc
+    c1, c2, ref = sv[nsrc], sv[nsrc + 1], sv[nsrc + 2]
+    w2 = sv[nsrc + 11]
+    return (bool(getattr(ctx, "io16", False)) and H.head_h16() and ctx.tr and FUSE_BN_REDUCE and hbwd16_ok(c2, c1, w2)
+            and ref.dtype == torch.int64)
+
+
+class _BBBodies:
+    """(namespace of the two bodies; _BasicBlockFn and _BlockChainFn call them with a ctx or a ctx-like object)"""
+
+    @staticmethod
+    def forward(ctx, blk, x0, x1, w1, g1, b1, w2, g2, b2, wd, gd, bd):
         blk._check()
         tr = blk.training
         srcs = [H.to_nhwc(x0.detach())] + ([H.to_nhwc(x1.detach())] if x1 is not None else [])
@@ -408,7 +441,9 @@ class _BasicBlockFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, handoff=None, prev=None):
+        """handoff: a _Handoff from the block behind this one in a chain (then g is None); prev: the ctx of the block in FRONT of this one in
+        a chain -- if both blocks qualify, dx0 comes back as a _Handoff for it instead of an fp32 tensor"""
         blk, tr, nsrc = ctx.blk, ctx.tr, ctx.nsrc
         sv = ctx.saved_tensors
         srcs = list(sv[:nsrc])
@@ -419,12 +454,18 @@ class _BasicBlockFn(torch.autograd.Function):
         caches = blk.__dict__.setdefault("_srbh_gcaches", [_PackedGrad(), _PackedGrad(), _PackedGrad()])
         b16 = bool(getattr(ctx, "io16", False)) and H.head_h16()       # gradient tensors internal to this backward: bf16
         # through the final ReLU (folded into bn2's reduce pass) -> bn2 -> conv2
-        g = H.to_nhwc(g)
         fuse2 = b16 and tr and FUSE_BN_REDUCE and hbwd16_ok(c2, c1, w2)
         consts1 = None
+        if handoff is not None:
+            assert fuse2 and g is None
+            dz = handoff.dz      # (already through this block's closing ReLU; bn2's sums came with it)
+            k2c, dg2, db2 = bn_backward(dz, c2, m2, i2, g2, None, tr, out_b16=True, stats_ready=handoff.stats, apply=False)
+        else:
+            g = H.to_nhwc(g)
         if fuse2:
             # conv2's whole backward behind bn2 in ONE pass (srbh_hbwd16): dc2 is never written; bn1's backward sums come out of its epilogue
-            k2c, dg2, db2, dz = bn_backward(g, c2, m2, i2, g2, None, tr, relu_ref=out, out_b16=True, apply=False)
+            if handoff is None:
+                k2c, dg2, db2, dz = bn_backward(g, c2, m2, i2, g2, None, tr, relu_ref=out, out_b16=True, apply=False)
             st1 = _stats_buf(16, c1.device)
             da1, dw2 = hbwd16(dz, c2, m2, i2, k2c, None, c1, (s1, h1, True), w2, caches[1], out_b16=True, bstat=(c1, m1, i1, s1, h1, st1))
             plain = (not has_ds and nsrc == 1 and ctx.needs_input_grad[1] and hbwd16_ok(c1, srcs[0], w1))
@@ -452,6 +493,14 @@ class _BasicBlockFn(torch.autograd.Function):
         if consts1 is not None:
             # plain 16-channel block: conv1's backward behind bn1 in one pass as well: dc1 never written, the skip gradient dz added in the
             # epilogue, dx leaves as the fp32 tensor autograd carries
+            if prev is not None and CHAIN_HANDOFF and _fuse2_ok(prev):
+                # the block in front takes this gradient straight through its closing ReLU and bn2's reduce: masked bf16 + sums, no fp32 tensor
+                psv, pn = prev.saved_tensors, prev.nsrc
+                pc2, pref, pm2, pi2 = psv[pn + 1], psv[pn + 2], psv[pn + 7], psv[pn + 8]
+                st2p = _stats_buf(16, c1.device)
+                dzp, dw1 = hbwd16(da1, c1, m1, i1, consts1, (s1, h1), srcs[0], None, w1, caches[0], res=dz, out_b16=True,
+                                  bstat=(pc2, pm2, pi2, None, None, st2p), relu_bits=pref)
+                return (None, _Handoff(dzp, st2p), None, dw1, dg1, db1, dw2, dg2, db2, None, None, None)
             dx0, dw1 = hbwd16(da1, c1, m1, i1, consts1, (s1, h1), srcs[0], None, w1, caches[0], res=dz, out_b16=False)
             return (None, dx0, None, dw1, dg1, db1, dw2, dg2, db2, None, None, None)
         skip = dz if need_dx else None          # gradient arriving over the identity / downsample path
@@ -483,9 +532,72 @@ class _BasicBlockFn(torch.autograd.Function):
         return (None, dx0, dx1, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd)
 
 
+_bb_forward, _bb_backward = _BBBodies.forward, _BBBodies.backward
+# a Sequential of BasicBlocks as ONE autograd node (round 5): the gradient between two blocks never exists as an fp32 tensor when both take
+# the fused passes -- the conv1 backward of the later block writes it masked, as bf16, together with the earlier block's bn2 sums
+# (srbh_hbwd16 relu_bits form).  SRBH_BLOCK_CHAIN=0: one node per block (A/B aid; same arithmetic up to bf16 rounding of that gradient)
+BLOCK_CHAIN = __import__("os").environ.get("SRBH_BLOCK_CHAIN", "1") == "1"
+CHAIN_HANDOFF = __import__("os").environ.get("SRBH_CHAIN_HANDOFF", "1") == "1"
+
+
+class _SubCtx:
+    """what the block bodies need of an autograd ctx"""
+
+    def __init__(self, needs):
+        self.needs_input_grad = needs
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+def _block_params(blk):
+    ds = blk.downsample
+    return [blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias] + (
+        [] if ds is None else [ds[0].weight, ds[1].weight, ds[1].bias])
+
+
+class _BlockChainFn(torch.autograd.Function):
+    """blocks[-1](... blocks[0](cat(x0, x1))) (nn.Sequential of BasicBlocks: SR/HRfuse.py:164-169,181-183), the per-block bodies unchanged"""
+
+    @staticmethod
+    def forward(ctx, blocks, x0, x1, *params):
+        subs, off, cur0, cur1 = [], 0, x0, x1
+        for k, blk in enumerate(blocks):
+            n = 6 if blk.downsample is None else 9
+            pr = list(params[off:off + n]) + [None] * (9 - n)
+            off += n
+            need0 = True if k > 0 else bool(ctx.needs_input_grad[1])
+            need1 = bool(k == 0 and x1 is not None and ctx.needs_input_grad[2])
+            sub = _SubCtx((False, need0, need1) + (True,) * 9)
+            cur0, cur1 = _bb_forward(sub, blk, cur0, cur1, *pr), None
+            subs.append(sub)
+        ctx.subs, ctx.counts = subs, [6 if b.downsample is None else 9 for b in blocks]
+        return cur0
+
+    @staticmethod
+    def backward(ctx, g):
+        subs = ctx.subs
+        pgrads = [None] * len(subs)
+        handoff, dx0, dx1 = None, None, None
+        for k in range(len(subs) - 1, -1, -1):
+            r = _bb_backward(subs[k], None if handoff is not None else g, handoff=handoff, prev=subs[k - 1] if k > 0 else None)
+            pgrads[k] = list(r[3:3 + ctx.counts[k]])
+            if isinstance(r[1], _Handoff):
+                handoff, g = r[1], None
+            else:
+                handoff, g = None, r[1]
+            dx0, dx1 = r[1], r[2]
+        flat = [t for pg in pgrads for t in pg]
+        return (None, dx0, dx1, *flat)
+
+
 def blocks_forward(blocks, inputs):
     x0 = inputs[0]
     x1 = inputs[1] if len(inputs) > 1 else None
+    blocks = list(blocks)
+    if BLOCK_CHAIN and len(blocks) > 1:
+        return _BlockChainFn.apply(blocks, x0, x1, *[p for b in blocks for p in _block_params(b)])
     for blk in blocks:
         ds = blk.downsample
         x0 = _BasicBlockFn.apply(blk, x0, x1, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight,

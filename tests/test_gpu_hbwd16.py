@@ -124,3 +124,34 @@ def test_basicblock_backward_fused_equals_separate(inplanes, monkeypatch):
         out[flag] = [x.grad.clone()] + [p_.grad.clone() for p_ in blk.parameters()]
     for a, b in zip(out[True], out[False]):
         assert _rel(a, b) <= 5e-3, _rel(a, b)          # (bf16 gradient tensors: rare one-ulp flips of dc / da1 between the two paths)
+
+
+def test_block_chain_handoff_equals_one_node_per_block(monkeypatch):
+    """three BasicBlocks (32 -> 16 entry, two plain ones: HRfuse_residual.fuse, SR/HRfuse.py:181-183) as ONE autograd node with the masked
+    bf16 hand-off between blocks (srbh_hbwd16 relu_bits form) against one node per block: the hand-off writes exactly the bits the
+    reduce pass would have made of the fp32 gradient, so every gradient agrees to the noise of the atomically summed statistics"""
+    from srbh_amd import hrfuse as H
+    from srbh_amd import hrfuse_autograd as HA
+    torch.manual_seed(11)
+    blocks = [H.BasicBlock(32, 16).to(DEV).train(), H.BasicBlock(16, 16).to(DEV).train(), H.BasicBlock(16, 16).to(DEV).train()]
+    gen = torch.Generator().manual_seed(4)
+    xa, xb = torch.randn((2, 16, 8, 128), generator=gen).to(DEV), torch.randn((2, 16, 8, 128), generator=gen).to(DEV)
+    gy = torch.randn((2, 16, 8, 128), generator=gen).to(DEV) * 1e-3
+    out = {}
+    for mode in ("nodes", "chain", "chain_nohandoff"):
+        monkeypatch.setattr(HA, "BLOCK_CHAIN", mode != "nodes")
+        monkeypatch.setattr(HA, "CHAIN_HANDOFF", mode == "chain")
+        for b in blocks:
+            for p_ in b.parameters():
+                p_.grad = None
+        a, b_ = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+        with H.head_precision("f16"):
+            y = HA.blocks_forward(blocks, [a, b_])
+            y.backward(gy)
+        torch.cuda.synchronize()
+        out[mode] = [y.detach().clone(), a.grad.clone(), b_.grad.clone()] + [p_.grad.clone() for b in blocks for p_ in b.parameters()]
+    assert len(out["chain"]) == 3 + 9 + 6 + 6
+    for mode in ("chain", "chain_nohandoff"):
+        for u, v in zip(out[mode], out["nodes"]):
+            assert _rel(u, v) <= 2e-3, (mode, _rel(u, v))
+    assert torch.equal(out["chain"][0], out["nodes"][0])          # the forward is the same launches

@@ -50,5 +50,15 @@ with H.head_precision("f16"), torch.no_grad():
     t1s = T(lambda: sep(None, (s1, h1, True), None, True, (x, m1, i1, s1, h1, st)))
     t2 = T(lambda: HA.hbwd16(gy, c, mean, invstd, consts, (s1, h1), x, None, w, pg, res=res, out_b16=False))
     t2s = T(lambda: sep((s1, h1), None, res, False, None))
+    # the chain hand-off form: conv1's backward also does the previous block's reduce pass (masked bf16 out + bn2' sums)
+    out0, bits = H.bn_add_relu(c, s1, h1, x, want_bits=True)
+    st2 = HA._stats_buf(16, dev)
+    t3 = T(lambda: HA.hbwd16(gy, c, mean, invstd, consts, (s1, h1), x, None, w, pg, res=res, out_b16=True, bstat=(c, m1, i1, None, None, st2), relu_bits=bits))
+    gfp = torch.randn_like(c)
+
+    def reduce_pass():
+        HA.bn_backward(gfp, c, m1, i1, v(), None, True, relu_ref=bits, out_b16=True, apply=False)
+    t3r = T(reduce_pass)
+print(f"B={B} conv1 form + the previous block's reduce pass: fused {t3:.1f} us | conv1 form {t2:.1f} + reduce pass {t3r:.1f} = {t2 + t3r:.1f} us")
 print(f"B={B} conv2 form: fused {t1:.1f} us ({px * 256 / t1 / 1e3:.0f} GB/s on 256 B/px incl. the epilogue's c) | three launches {t1s:.1f} us")
 print(f"B={B} conv1 form: fused {t2:.1f} us ({px * 256 / t2 / 1e3:.0f} GB/s on 256 B/px) | three launches {t2s:.1f} us")
