@@ -299,7 +299,15 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_HOST_SPIN_US = float(os.environ.get("SRBH_HOST_SPIN_US", "0"))      # developer probe (tools/r05_14.sh): burn host time per libsrbh call -- is a workload host-bound?
+
+
 def check(rc: int, what: str = "") -> None:
+    if _HOST_SPIN_US:
+        import time
+        t_end = time.perf_counter() + _HOST_SPIN_US * 1e-6
+        while time.perf_counter() < t_end:
+            pass
     if rc != 0:
         msg = lib().srbh_last_error().decode(errors="replace")
         raise RuntimeError(f"libsrbh {what} failed (rc={rc}): {msg}")

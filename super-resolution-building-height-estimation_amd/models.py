@@ -29,6 +29,8 @@ SIDE_STREAM = _os.environ.get("SRBH_SIDE_STREAM", "auto")
 # up-sampler's PixelShuffle store writes fp16 too (hrfuse.Upsampler.forward(out_h16=True)), so both sources of the reg / seg entries
 # are fp16: the same numbers (each value is rounded once, where the consumer's staging would round it), ~2 GB less traffic per 128 tiles.
 HRFEAT_OUT_H16 = _os.environ.get("SRBH_HRFEAT_OUT_H16", "1") == "1"
+# training: issue hrfeat before the encoder (their backward order is then encoder -> hrfeat; see _forward_impl).  0 = upstream's issue order (A/B aid)
+HRFEAT_FIRST = _os.environ.get("SRBH_HRFEAT_FIRST", "1") == "1"
 
 
 class SRRegress_Cls_feature(torch.nn.Module):
@@ -65,8 +67,17 @@ class SRRegress_Cls_feature(torch.nn.Module):
     def _forward_impl(self, x, super_fea):
         if x.is_cuda and (SIDE_STREAM == "1" or (SIDE_STREAM == "auto" and not torch.is_grad_enabled())):
             return self._forward_two_streams(x, super_fea)
-        encode_fea = self.encoder(x)
-        super_fea = self.hrfeat(super_fea, out_h16=HRFEAT_OUT_H16)     # (fp16 NHWC inside the inference chain; reg / seg read it as such)
+        # Same ops as upstream; only the ISSUE order of the two independent first ops differs under a recorded graph (HRFEAT_FIRST): autograd
+        # runs ready nodes newest-first, so with hrfeat recorded FIRST its backward -- 3 ms of chip-filling kernels -- runs LAST, behind the
+        # encoder's ~4 ms of 10-30 us kernels, and the next step's persistent trunk kernel starts on a chip whose clocks are up: measured
+        # (tools/trunk_gap_probe.py, profiles/r05l_trunk_gap_probe.txt) the two trunk launches take 7.86 ms back to back or behind HBM-bound
+        # kernels (8.04) but 9.19 ms behind 5 ms of tiny kernels (8.85 behind an idle gap): the power management has clocked the shader engines down.
+        if HRFEAT_FIRST and torch.is_grad_enabled():
+            super_fea = self.hrfeat(super_fea, out_h16=HRFEAT_OUT_H16)
+            encode_fea = self.encoder(x)
+        else:
+            encode_fea = self.encoder(x)
+            super_fea = self.hrfeat(super_fea, out_h16=HRFEAT_OUT_H16)     # (fp16 NHWC inside the inference chain; reg / seg read it as such)
         height_fea = self.decoder1(*encode_fea)
         if self.isaggre:
             height_aggre = self._aggre(height_fea)

@@ -15,3 +15,17 @@ for s, e, k in rows:
         gaps.append(((s - prev[1]) / 1e3, prev[2][:40]))
     prev = (s, e, k)
 print("kernel right before each trunk launch + gap (us), last 8:", gaps[-8:])
+# what ran in the 6 ms before the first trunk launch of the last step: total time per kernel family
+idx = [i for i, (s, e, k) in enumerate(rows) if "ptrunk3_kernel" in k]
+if len(idx) >= 2:
+    first = idx[-2]
+    t0 = rows[first][0]
+    fam = {}
+    for s, e, k in rows[:first]:
+        if e >= t0 - 6_000_000:
+            name = k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:48]
+            fam[name] = fam.get(name, 0.0) + (e - s) / 1e3
+    print("kernel time (us) in the 6 ms before the step's first trunk launch, by kernel:")
+    for name, us in sorted(fam.items(), key=lambda kv: -kv[1])[:12]:
+        print("  %8.1f  %s" % (us, name))
+    print("the 10 kernels right before it:", [rows[i][2].split("(")[0].replace("void ", "")[:32] for i in range(max(0, first - 10), first)])
