@@ -653,6 +653,21 @@ int srbh_dconv_fwd_epi(const float* x, const void* wpack, float* y, int B, int C
 size_t srbh_dconv_wgrad_ws_floats(int B, int Cin, int Cout, int H, int W);
 int srbh_dconv_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int Cout, int H, int W, void* stream);
 
+/* ---- Adam (train.py:170-179,254-256: torch.optim.Adam over the network's parameters + the loss log_vars) as ONE launch over every parameter
+ * tensor (csrc/srbh_optim.hip).  `table` (device memory): one entry per tensor -- p, m (exp_avg), v (exp_avg_sq) updated in place from the
+ * gradient g (NULL: the tensor is skipped this step), n elements, the tensor's learning rate and (L2) weight decay.  `chunks` (device memory,
+ * nchunks x 2 ints): (table index, slice) pairs, slice s covering elements [s * srbh_adam_chunk(), ...) of that tensor.  Arithmetic of
+ * torch/optim/adam.py (amsgrad = maximize = False): g += wd * p; m = lerp(m, g, 1 - beta1); v = beta2 v + (1 - beta2) g^2;
+ * p -= lr / bias_correction1 * m / (sqrt(v) / sqrt(bias_correction2) + eps), the bias corrections 1 - beta^t per tensor in the table. */
+typedef struct srbh_adam_entry {
+    float* p; const float* g; float* m; float* v;
+    long n;
+    float lr, wd;
+    float inv_bc1, inv_sqrt_bc2;     /* 1 / (1 - beta1^t), 1 / sqrt(1 - beta2^t) with t = THIS tensor's step count (torch counts steps per parameter) */
+} srbh_adam_entry;
+int srbh_adam_chunk(void);
+int srbh_adam_step(const srbh_adam_entry* table, const int* chunks, int nchunks, double beta1, double beta2, double eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libsrbh.so")
 _DEV_LIB = os.environ.get("SRBH_LIB_PATH")      # developer A/B only (tools/ab_variants.sh): load another build of the same ABI
-SOURCES = ["srbh_conv3x3.hip", "srbh_aux.hip", "srbh_rrdbnet.hip", "srbh_ptrunk.hip", "srbh_ptail.hip", "srbh_head.hip", "srbh_head_bwd.hip", "srbh_mosaic.hip", "srbh_loader.hip", "srbh_loss.hip", "srbh_dwconv.hip", "srbh_mbconv.hip", "srbh_pwconv.hip", "srbh_dconv.hip"]
+SOURCES = ["srbh_conv3x3.hip", "srbh_aux.hip", "srbh_rrdbnet.hip", "srbh_ptrunk.hip", "srbh_ptail.hip", "srbh_head.hip", "srbh_head_bwd.hip", "srbh_mosaic.hip", "srbh_loader.hip", "srbh_loss.hip", "srbh_dwconv.hip", "srbh_mbconv.hip", "srbh_pwconv.hip", "srbh_dconv.hip", "srbh_optim.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # NOTE: `-mllvm -amdgpu-mfma-vgpr-form=1` (accumulators in VGPRs: no v_accvgpr copies at K-loop back-edges).  Round 1 saw the
 # first persistent trunk kernel produce non-deterministic garbage with it; round 3 re-ran it on the current kernel (ptrunk3:
@@ -207,6 +207,8 @@ SIGNATURES = {
     "srbh_hconv_wgrad_f32": (_i, [C.POINTER(HWGradArgs), _vp]),
     "srbh_hconv_wgrad_b16": (_i, [C.POINTER(HWGradArgs), _vp]),
     "srbh_hconv_wgrad_entry_b16": (_i, [C.POINTER(HWGradArgs), C.POINTER(HWGradArgs), _vp]),
+    "srbh_adam_chunk": (_i, []),
+    "srbh_adam_step": (_i, [_vp, _vp, _i, C.c_double, C.c_double, C.c_double, _vp]),
     "srbh_hbwd16_supported": (_i, [_i, _i]),
     "srbh_hbwd16": (_i, [C.POINTER(HBwd16Args), _vp]),
     "srbh_relu_mask_mul": (_i, [_vp, _vp, _vp, C.c_long, _vp]),

@@ -314,7 +314,13 @@ class TrainStep:
         # launches and 5.5 ms of host time per step; with capturable=True its bias-correction pow even falls back to one launch
         # per parameter, +800 launches in the captured graph).  Same update rule (torch/optim/adam.py), fp32 state.
         fused = torch.device(device).type == "cuda"
-        self.optimizer = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=1e-4, capturable=self.use_graph and world == 1, fused=fused)
+        # round 5: the same update as ONE libsrbh launch over a device table of tensors (srbh_amd.optim.Adam, csrc/srbh_optim.hip) -- eager steps
+        # on a ROCm device; a captured step keeps torch's capturable optimizer (its step counter lives on the device).  SRBH_ADAM=0: torch's.
+        if fused and not self.use_graph and os.environ.get("SRBH_ADAM", "1") == "1":
+            from .optim import Adam as _Adam
+            self.optimizer = _Adam(net.parameters(), lr=lr, weight_decay=1e-4)
+        else:
+            self.optimizer = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=1e-4, capturable=self.use_graph and world == 1, fused=fused)
         self.optimizer.add_param_group({"params": [c.log_var for c in self.criterion], "lr": lr})
         self.rgbseq = [0, 1, 2]
         self._rgb_idx = torch.tensor(self.rgbseq, device=device)      # (a Python list index would be a host-to-device copy per step: not capturable)

@@ -59,6 +59,8 @@ def test_ctypes_struct_matches_header_field_order():
         assert _header_fields(struct) == [n.rstrip("_") for n, _ in cls._fields_], struct
     assert _header_fields("srbh_transpose_desc") == ["src", "dst", "rows", "cols"]       # (built as a numpy record in encoders.py)
     assert _header_fields("srbh_dconv_pack_desc") == ["w", "fwd", "bwd", "cout", "cin"]   # (ditto: encoders.DecoderPackTable)
+    from srbh_amd import optim
+    assert _header_fields("srbh_adam_entry") == list(optim._ENTRY.names) and optim._ENTRY.itemsize == 56        # (numpy record in optim.Adam)
 
 
 def test_rrdbnet_state_dict_layout_and_signature():
