@@ -52,6 +52,7 @@ const char* srbh_last_error(void);
 #define SRBH_PATH_WGRAD_ENTRY_FUSED 7   /* srbh_hconv_wgrad_entry_b16 -> one pass */
 #define SRBH_PATH_WGRAD_ENTRY_SPLIT 8
 #define SRBH_PATH_HCONV_UP 9             /* srbh_hconv_h16, pixelshuffle2 == 2 -> persistent Upsampler 16 -> 64 kernel */
+#define SRBH_PATH_HBWD16 10              /* srbh_hbwd16: BatchNorm apply + weight gradient + data gradient of a 16 -> 16 conv in one pass */
 int srbh_path_counters(unsigned long long* out, int n, int reset);
 
 /* ---- layout helpers (used by tests and by the Python mirror at module boundaries) ------------ */

@@ -56,7 +56,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 PATH_NAMES = ("hconv16", "hconv_template", "entry_fused", "entry_split", "wgrad16", "wgrad_b16_generic", "wgrad_f32", "wgrad_entry_fused",
-              "wgrad_entry_split", "hconv_up")
+              "wgrad_entry_split", "hconv_up", "hbwd16")
 
 
 def path_counters(reset=False):

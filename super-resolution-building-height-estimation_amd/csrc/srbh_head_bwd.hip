@@ -1541,6 +1541,7 @@ extern "C" int srbh_hbwd16(const srbh_hbwd16_args* a, void* stream) {
     else SRBH_HB(0, 0);
 #undef SRBH_HB
     SRBH_HIP(hipGetLastError());
+    count_path(PATH_HBWD16);
     // the workgroups' weight-gradient partials -> dW (the ordered two-stage reduce of srbh_hconv_wgrad_b16)
     constexpr int SLICES = 16;
     const long U = 9 * 256;

@@ -57,6 +57,15 @@
 #define P3_SPREAD 1
 #endif
 
+#ifndef P3_SEAM
+// 1 (round 5): the RDB seam without a cold stage.  conv5's epilogue ALSO ds_writes the own rows of the new x's first chunk into the resident
+// plane (phase-B stage 0, whose address range that is, is free during conv5's last step and epilogue), its last K step prefetches the next
+// conv1's first 18 KiB of weights into the part of phase-B stage 0 behind the plane (= phase-A stage 0's INPUT area, which conv1's step 0
+// does not read: it reads the resident plane), so that behind the neighbours' flags only the two halo rows are fetched (2 DMA statements
+// instead of 11 + 5), and the own rows of that chunk go to memory only where a neighbour reads them.  Same arithmetic, same bits.
+#define P3_SEAM 1
+#endif
+
 // PROF = 1 (developer timeline, SRBH_PT_PROF): s_memtime stamps per layer in ptrunk_kernel's 6-slot format
 template <int PROF>
 __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     };
     // ---- epilogue of conv5: x = 0.2 (acc + bias) + x in registers (+ the RRDB-level stream every third RDB), fp16 copy out
     // one row of x (channel block mb) -> fp16 fragments, kept (mb == 1) and stored where somebody reads them from memory
-    auto x_row_out = [&](const int mb, const int i, char* obase, const bool st) {
+    auto x_row_out = [&](const int mb, const int i, char* obase, const bool st, const bool to_lds = false) {
         const int Y = Y0 + wr * 4 + i;
         unsigned hp[4][2];
 #pragma unroll
@@ -534,6 +543,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             auto s1 = __builtin_amdgcn_permlane32_swap(hp[2 * m][1], hp[2 * m + 1][1], false, false);
             const uintx4 raw = {s0[0], s1[0], s0[1], s1[1]};
             if (mb == 1) x1p[i][m] = raw;
+            if (P3_SEAM && mb == 0 && to_lds) *(uintx4*)(smem + soff + sswz[m] + i * G::ROW_B) = raw;      // the next RDB's resident plane, own rows
             char* o = obase + (long)mb * pp.plane_b + (long)(Y + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16;
             if (st) {
                 if (wt)
@@ -587,7 +597,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                     tt += bias4[mb][g];
                     xres[mb][i][g] = tt * 0.2f + xres[mb][i][g];
                 }
-                if (!r2) x_row_out(mb, i, obase, mb == 0 || !x1_halo_only || halo);   // (RRDB-closing: the fp16 values are not final yet)
+                if (!r2) x_row_out(mb, i, obase, (!P3_SEAM && mb == 0) || !x1_halo_only || halo, x1_halo_only);   // (RRDB-closing: the fp16 values are not final yet)
             }
         }
         if (r2) {
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) xres[mb][i][g] = xres[mb][i][g] * 0.2f + a2[slot][mb][g];
-                    x_row_out(mb, i, obase, mb == 0 || !x1_halo_only || halo);
+                    x_row_out(mb, i, obase, (!P3_SEAM && mb == 0) || !x1_halo_only || halo, x1_halo_only);
                 }
                 // the RRDB-level stream goes back to memory (fragment order): private to this workgroup
                 const float* q = pp.xrr + rowb;
@@ -623,7 +633,9 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     // ---- prologue of the launch: conv1 of RDB 0 reads conv_first's output (no flag needed)
     char* dcur = pp.dense[0] + tile_off;    // tile origin of plane 0 in the running RDB's dense buffer
     char* dnxt = pp.dense[1] + tile_off;
-    stage_cold(dcur, smem, pp.layers[0].w, smem + stage_off(1, 0) + IN_EX, W5{});
+    // (P3_SEAM: conv1's step-0 weights live in phase-A stage 0's INPUT area -- step 0 reads the resident plane, not that area -- which is where
+    //  conv5's last step can prefetch them at the seam)
+    stage_cold(dcur, smem, pp.layers[0].w, smem + stage_off(1, 0) + (P3_SEAM ? 0 : IN_EX), W5{});
     const int nrdb = pp.nlayers / 5;
     for (int rdb = 0; rdb < nrdb && !aborted; ++rdb) {
         const PLayer* T = pp.layers + rdb * 5;
@@ -673,7 +685,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                         for (int m = 0; m < 2; ++m) X2r[1 + r][m] = pk[r][m];
                 }
             } else {
-                run_step(C1{}, I2{}, W5{}, acc, smem, smem + stage_off(1, gs & 1) + IN_EX, dcur + (long)pp.plane_b, wl + 18 * 1024,
+                run_step(C1{}, I2{}, W5{}, acc, smem, smem + stage_off(1, gs & 1) + ((P3_SEAM && kk == 0) ? 0 : IN_EX), dcur + (long)pp.plane_b, wl + 18 * 1024,
                          smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{});
             }
             ++gs;
@@ -808,7 +820,14 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             step_sync();
             {
                 const char* st = smem + stage_off(2, 1);
-                run_step(C2{}, I0{}, W0{}, acc, st, st + IN_EX, nullptr, nullptr, smem, x1p, NODEFER{});
+                if constexpr (P3_SEAM) {
+                    // the next conv1's first weight chunk -> smem + IN_EX (dst = smem: run_step puts weights at dst + IN_EX); the last RDB has no
+                    // successor: it prefetches its own first chunk again (a select, not a branch: one step body), nobody reads it
+                    const char* nw5 = rdb + 1 < nrdb ? T[5].w : T[0].w;
+                    run_step(C2{}, I0{}, W5{}, acc, st, st + IN_EX, nullptr, nw5, smem, x1p, NODEFER{});
+                } else {
+                    run_step(C2{}, I0{}, W0{}, acc, st, st + IN_EX, nullptr, nullptr, smem, x1p, NODEFER{});
+                }
             }
             const bool r2 = (rdb % 3) == 2;
             if (PROF) p2 = __builtin_amdgcn_s_memtime();
@@ -821,7 +840,15 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             if (rdb + 1 < nrdb) {
                 ensure_flags(L + 1);
                 if (aborted) break;
-                stage_cold(dnxt, smem, T[5].w, smem + stage_off(1, 0) + IN_EX, W5{});
+                if constexpr (P3_SEAM) {
+                    // own rows: written by the epilogue; weights: prefetched by the last step; left: the neighbours' two rows
+                    const unsigned long long ib = uni64((unsigned long long)dnxt);
+                    const unsigned din_w = __builtin_amdgcn_readfirstlane(lds_addr(smem) + wave * 1024);
+                    dma(SC1{}, ib, hoff[0], din_w + PIX_B);
+                    dma(SC1{}, ib, hoff[1], din_w + (G::ROWS - 1) * G::ROW_B + PIX_B);
+                } else {
+                    stage_cold(dnxt, smem, T[5].w, smem + stage_off(1, 0) + IN_EX, W5{});
+                }
             }
             if (PROF && tid == 0) {
                 unsigned long long* q = pp.prof + ((long)blockIdx.x * pp.nlayers + L) * 6;

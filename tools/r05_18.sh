@@ -1,0 +1,4 @@
+#!/bin/bash
+export TMPDIR=/tmp O=gpurun_out
+timeout 900 python -m pytest tests/test_gpu_rrdbnet.py tests/test_gpu_feature_h16.py -x -q 2>&1 | tail -6
+bash tools/ab_variants.sh seam0 2>&1 | tee $O/r05r_ab_seam.txt
