@@ -66,6 +66,31 @@
 #define P3_SEAM 1
 #endif
 
+#ifndef P3_WFLAGS
+// 1 (round 5): the neighbour-progress check is a property of the WAVE, inside the step that fetches the halo rows.  It used to be thread 0
+// polling the two progress words between two steps (an L2 round trip with the matrix core idle), an LDS word and two extra barriers, five
+// times per RDB.  Every wave issues a slice of each halo DMA statement, so every wave can check for itself: the two polls go out at the top
+// of the step as untracked loads, the step's other staging items (weights, the register-staged rows) and their MFMAs run, and the wave
+// looks at the result -- `s_waitcnt vmcnt(<DMA statements issued since>)` -- only in front of the halo statements, which are the LAST
+// staging items of such a step.  No LDS word, no barrier; a neighbour that is late makes the wave spin (bounded) where it stands.  A
+// timed-out spin sets the error word and the wave CARRIES ON (uniform control flow, every later spin ends at once on the error word): the
+// launch finishes with garbage that poison_on_error_kernel turns into NaN, as before.  Same arithmetic, same bits.
+#define P3_WFLAGS 1
+#endif
+
+#ifndef P3_PREREAD
+// 1 (round 5): the step barrier sits INSIDE the step, in front of the MFMA P3_PRE_AT of its last group, and the LDS reads of the NEXT step's
+// first group ride in the shadows behind it.  With the barrier between two steps every step opened with its first group's reads (9 / 12
+// ds_read_b128 per wave, four waves at once on a 128 B/clk port) in front of an idle matrix core.  At the barrier every wave has drained its
+// own LDS-DMA (vmcnt(0)) and its LDS reads (lgkmcnt(0): the last group's operands are in registers), so the stage the next step reads is
+// complete and the stage this step read is free for the next step's staging items -- the two facts the top-of-step barrier established.
+// Steps of one layer only (the epilogue separates layers).  Needs P3_WFLAGS (nothing may sit between two steps) and P3_SPREAD.
+#define P3_PREREAD 1
+#endif
+#ifndef P3_PRE_AT
+#define P3_PRE_AT 0
+#endif
+
 // PROF = 1 (developer timeline, SRBH_PT_PROF): s_memtime stamps per layer in ptrunk_kernel's 6-slot format
 template <int PROF>
 __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
@@ -189,6 +214,42 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         __syncthreads();
         if (bad) aborted = true;
     };
+    // P3_WFLAGS: per-wave form (f_up / f_dn are then wave-uniform copies kept by every wave)
+    int pq_up = 0, pq_dn = 0;
+    const int inf_up = up < 0 ? 0x7fffffff : 0, inf_dn = dn < 0 ? 0x7fffffff : 0;
+    auto poll_issue = [&]() {
+        const int* qu = pp.prog + (up >= 0 ? up : t);
+        const int* qd = pp.prog + (dn >= 0 ? dn : t);
+        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(pq_up) : "v"(qu) : "memory");
+        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(pq_dn) : "v"(qd) : "memory");
+    };
+    auto poll_spin = [&](const int need) {      // (rare: a neighbour is more than the poll's flight time behind)
+        unsigned spins = 0;
+        while (f_up < need || f_dn < need) {
+            f_up = max(__builtin_amdgcn_readfirstlane(__hip_atomic_load(pp.prog + (up >= 0 ? up : t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)), inf_up);
+            f_dn = max(__builtin_amdgcn_readfirstlane(__hip_atomic_load(pp.prog + (dn >= 0 ? dn : t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)), inf_dn);
+            if (f_up >= need && f_dn >= need) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT || __hip_atomic_load(pp.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(pp.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                f_up = f_dn = 0x7fffffff;       // carry on (garbage, reported): no wave of the launch waits again
+                break;
+            }
+        }
+    };
+    auto poll_check = [&](auto k_tag, const int need) {   // k = VMEM instructions this wave issued behind poll_issue()
+        constexpr int K = decltype(k_tag)::value;
+        static_assert(K == 0 || K == 5 || K == 9 || K == 12 || K == 16, "vmcnt immediates of poll_check");
+        if constexpr (K == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pq_up), "+v"(pq_dn)::"memory");
+        else if constexpr (K == 5) asm volatile("s_waitcnt vmcnt(5)" : "+v"(pq_up), "+v"(pq_dn)::"memory");
+        else if constexpr (K == 9) asm volatile("s_waitcnt vmcnt(9)" : "+v"(pq_up), "+v"(pq_dn)::"memory");
+        else if constexpr (K == 12) asm volatile("s_waitcnt vmcnt(12)" : "+v"(pq_up), "+v"(pq_dn)::"memory");
+        else asm volatile("s_waitcnt vmcnt(16)" : "+v"(pq_up), "+v"(pq_dn)::"memory");
+        // (branch-free: a missing neighbour polled the workgroup's own word and is "infinitely far ahead")
+        f_up = max(__builtin_amdgcn_readfirstlane(pq_up), inf_up);
+        f_dn = max(__builtin_amdgcn_readfirstlane(pq_dn), inf_dn);
+        if (min(f_up, f_dn) < need) poll_spin(need);
+    };
     bool wt = true;
     {
         int my_xcc;
@@ -308,12 +369,37 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         }
     };
 
+    auto publish_pending = [&]() {
+        if (pending_pub) {
+            publish(pub_val);
+            pending_pub = false;
+        }
+    };
+    unsigned long long t_sync = 0, t_vm = 0;   // PROF: cycles in the top-of-step waits (own DMA landing / barrier)
+    auto step_sync = [&]() {
+        unsigned long long w0 = 0, w1 = 0;
+        if (PROF) w0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of the step has landed ...
+        if (PROF) w1 = __builtin_amdgcn_s_memtime();
+        __syncthreads();                                   // ... and everybody else's; all waves are past the previous step
+        if (PROF) {
+            t_vm += w1 - w0;
+            t_sync += __builtin_amdgcn_s_memtime() - w1;
+        }
+    };
+
+    half8 Pq[2][G::NP], Aq[2][3][2];   // operand fragments of two MFMA groups (kernel scope: P3_PREREAD hands group 0's over a step boundary)
     // ---- one K step.  CB = cout/32 of the running layer.  What is staged for the NEXT step is a compile-time property:
     //   IN: 0 no input plane | 1 input plane by LDS-DMA (11 statements) | 2 input plane from registers (8 ds_write_b128 + 1
     //   border write + 2 halo DMA statements);   NW: weight DMA statements per wave (0 | 5 = 18 fragments | 9 = 36 fragments)
     auto run_step = [&](auto cb_tag, auto in_tag, auto nw_tag, floatx16 (&acc)[decltype(cb_tag)::value][4], const char* sbi, const char* sbw,
-                        const char* nsrc, const char* nw, char* dst, const uintx4 (&rsrc)[4][2], auto defer_tag) {
+                        const char* nsrc, const char* nw, char* dst, const uintx4 (&rsrc)[4][2], auto defer_tag, auto flag_tag, const int need,
+                        auto pre_tag, auto nxt_tag) {
         constexpr int CB = decltype(cb_tag)::value, IN = decltype(in_tag)::value, NW = decltype(nw_tag)::value;
+        // FL (P3_WFLAGS): this step fetches rows of a neighbour (the plane it stages is new on them): polls at the top, the check in front
+        // of the statements that carry those rows, which are then the LAST staging items of the step (need < 0: no check this time)
+        constexpr bool FL = P3_WFLAGS && decltype(flag_tag)::value != 0;
+        static_assert(!FL || IN != 0, "a flagged step stages an input plane");
         constexpr bool DEFER = decltype(defer_tag)::value;   // also work off the parked half of the previous layer's epilogue
         constexpr int NRD = G::NP + 3 * CB, NMF = 12 * CB;
         constexpr int NH = 2;                                           // halo DMA statements of a register-staged plane
@@ -332,18 +418,47 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         const unsigned long long wbase = uni64((unsigned long long)(nw + wave * 1024));
         const unsigned din_w = __builtin_amdgcn_readfirstlane(lds_addr(dst) + wave * 1024);
         const unsigned dw_w = din_w + IN_EX;
-        half8 P[2][G::NP];
-        half8 A[2][3][CB];
-        auto read_item = [&](const int g, const int r, const int set) {   // LDS read r (0..NRD-1) of group g
+        constexpr bool PRE = P3_PREREAD && decltype(pre_tag)::value != 0;   // group 0's operands were read by the previous step
+        constexpr bool NXT = P3_PREREAD && decltype(nxt_tag)::value != 0;   // this step holds the barrier and reads the next step's group 0
+        static_assert(!P3_PREREAD || (P3_WFLAGS && P3_SPREAD), "P3_PREREAD needs P3_WFLAGS and P3_SPREAD");
+        static_assert(P3_PRE_AT + NRD <= NMF, "the next step's first reads must fit behind the barrier");
+        half8 (&P)[2][G::NP] = Pq;
+        half8 (&A)[2][3][2] = Aq;
+        auto read_from = [&](const char* bi, const char* bw, const int g, const int r, const int set) {   // LDS read r (0..NRD-1) of group g
             const int ks = g / 3, dx = g - ks * 3;
             if (r < G::NP) {
-                P[set][r] = *(const half8*)(sbi + aoff[dx][ks] + r * G::ROW_B);
+                P[set][r] = *(const half8*)(bi + aoff[dx][ks] + r * G::ROW_B);
             } else {
                 const int q = r - G::NP, dy = q / CB, mb = q - dy * CB;
-                A[set][dy][mb] = *(const half8*)(sbw + woff + ((((dy * 3 + dx) * 2 + ks) * CB + mb) << 10));
+                A[set][dy][mb] = *(const half8*)(bw + woff + ((((dy * 3 + dx) * 2 + ks) * CB + mb) << 10));
             }
         };
+        auto read_item = [&](const int g, const int r, const int set) { read_from(sbi, sbw, g, r, set); };
         auto stage_item = [&](const int d) {
+            if constexpr (FL && IN == 2) {            // weights, the own rows from registers, the border, [check], the neighbours' rows
+                if (d < NW) {
+                    dma_item(std::integral_constant<int, 0>{}, nw_tag, d, ibase, wbase, din_w, dw_w);
+                } else if (d < NW + 8) {
+                    const int e = d - NW, i = e >> 1, m = e & 1;
+                    *(uintx4*)(dst + soff + sswz[m] + i * G::ROW_B) = rsrc[i][m];
+                } else if (d == NW + 8) {
+                    if (lane < 20) *(uintx4*)(dst + boff) = uintx4{0u, 0u, 0u, 0u};
+                } else {
+                    const int h = d - NW - 9;
+                    if (h == 0 && need >= 0) poll_check(std::integral_constant<int, NW>{}, need);
+                    dma(SC1{}, ibase, hoff[h], din_w + (h ? G::ROWS - 1 : 0) * G::ROW_B + PIX_B);
+                }
+                return;
+            }
+            if constexpr (FL && IN == 1) {            // weights, the statements of rows 1..8, [check], the four statements holding rows 0 and 9
+                if (d < NW) {
+                    dma_item(std::integral_constant<int, 11>{}, nw_tag, d + 11, ibase, wbase, din_w, dw_w);
+                } else {
+                    if (d == NW + 7 && need >= 0) poll_check(std::integral_constant<int, NW + 7>{}, need);
+                    dma_item(std::integral_constant<int, 11>{}, nw_tag, d - NW, ibase, wbase, din_w, dw_w);
+                }
+                return;
+            }
             if ((P3_ABL & 1) && d >= (IN == 1 ? 11 : IN == 2 ? NH : 0) && d < NDMA) return;
             if ((P3_ABL & 2) && d < (IN == 1 ? 11 : IN == 2 ? NH : 0)) return;
             if ((P3_ABL & 4) && d >= NDMA) return;
@@ -362,19 +477,33 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 dma_item(std::integral_constant<int, IN == 1 ? 11 : 0>{}, nw_tag, d, ibase, wbase, din_w, dw_w);
             }
         };
+        if constexpr (FL) poll_issue();
+        if constexpr (!PRE) {
 #pragma unroll
-        for (int r = 0; r < NRD; ++r) read_item(0, P3_SPREAD ? (CB == 1 ? ORD1[r % 9] : ORD2[r % 12]) : r, 0);
+            for (int r = 0; r < NRD; ++r) read_item(0, P3_SPREAD ? (CB == 1 ? ORD1[r % 9] : ORD2[r % 12]) : r, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
 #pragma unroll
             for (int m = 0; m < NMF; ++m) {
                 const int dy = m / (4 * CB), rem = m - dy * 4 * CB, i = rem / CB, mb = rem - i * CB;
+                if constexpr (NXT) {
+                    if (g == 5 && m == P3_PRE_AT) {      // the step barrier (see P3_PREREAD)
+                        step_sync();
+                        publish_pending();               // (the layer's first barrier carries the lazy publication of the previous layer's output)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
                 acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g & 1][dy][mb], P[g & 1][i + dy], acc[mb][i], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (P3_SPREAD) {
                     const int k = m / RSTRIDE;
                     if (g + 1 < 6 && m % RSTRIDE == 0 && k < NRD) read_item(g + 1, CB == 1 ? ORD1[k % 9] : ORD2[k % 12], (g + 1) & 1);
+                    if constexpr (NXT) {                 // the next step's group 0 (it reads what this step staged: dst, dst + IN_EX), one read per shadow
+                        const int k2 = m - P3_PRE_AT;
+                        if (g == 5 && k2 >= 0 && k2 < NRD) read_from(dst, dst + IN_EX, 0, CB == 1 ? ORD1[k2 % 9] : ORD2[k2 % 12], 0);
+                    }
                     // staging: one item per shadow for a cout-32 group (12), every other shadow of conv5's (the ones without a read)
                     const int sm = CB == 1 ? m : (m % 2 ? m / 2 : -1);
                     if (sm >= 0) {
@@ -419,6 +548,11 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     using W9 = std::integral_constant<int, 9>;
     using NODEFER = std::false_type;
     using DODEFER = std::true_type;
+    using F0 = std::integral_constant<int, 0>;   // flag_tag: no neighbour rows in what the step stages / the step checks the neighbours' progress
+    using F1 = std::integral_constant<int, 1>;
+    using Q0 = std::integral_constant<int, 0>;   // pre_tag / nxt_tag (P3_PREREAD)
+    using Q1 = std::integral_constant<int, 1>;
+    constexpr bool PR = P3_PREREAD != 0;
 
     // ---- layer prologue: drain the own DMA / stores, barrier, bias into LDS, lazy publish
     auto prologue = [&](const float* bias, const int nb, const int bias_lds) {
@@ -449,25 +583,6 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         __syncthreads();
         if (tid < nb) ((float*)(smem + bias_lds))[tid] = bias_v;
     };
-    auto publish_pending = [&]() {
-        if (pending_pub) {
-            publish(pub_val);
-            pending_pub = false;
-        }
-    };
-    unsigned long long t_sync = 0, t_vm = 0;   // PROF: cycles in the top-of-step waits (own DMA landing / barrier)
-    auto step_sync = [&]() {
-        unsigned long long w0 = 0, w1 = 0;
-        if (PROF) w0 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA of the step has landed ...
-        if (PROF) w1 = __builtin_amdgcn_s_memtime();
-        __syncthreads();                                   // ... and everybody else's; all waves are past the previous step
-        if (PROF) {
-            t_vm += w1 - w0;
-            t_sync += __builtin_amdgcn_s_memtime() - w1;
-        }
-    };
-
     // ---- epilogue of a cout-32 layer: bias, leaky ReLU, fp16, straight from the MFMA D layout (see ptrunk_kernel)
     auto epi32 = [&](floatx16 (&acc)[1][4], char* oplane, uintx4 (&keep)[4][2], const bool halo_only, auto park_tag) {
         constexpr bool PARK = decltype(park_tag)::value;   // rows 1, 2 are parked for the next layer's step 0 (defer_unit)
@@ -671,7 +786,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             // step 0: resident plane 0; stages chunk 1 (x's second half) from registers
             if (P3_DEFER && kk > 0) {   // ... and works off rows 1, 2 of the previous layer's epilogue in its empty MFMA shadows
                 run_step(C1{}, I2{}, W5{}, acc, smem, smem + stage_off(1, gs & 1) + IN_EX, dcur + (long)pp.plane_b, wl + 18 * 1024,
-                         smem + stage_off(1, (gs + 1) & 1), x1p, DODEFER{});
+                         smem + stage_off(1, (gs + 1) & 1), x1p, DODEFER{}, F0{}, 0, Q0{}, Q1{});
                 if (kk == 1) {
 #pragma unroll
                     for (int r = 0; r < 2; ++r)
@@ -686,58 +801,60 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 }
             } else {
                 run_step(C1{}, I2{}, W5{}, acc, smem, smem + stage_off(1, gs & 1) + ((P3_SEAM && kk == 0) ? 0 : IN_EX), dcur + (long)pp.plane_b, wl + 18 * 1024,
-                         smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{});
+                         smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{}, F0{}, 0, Q0{}, Q1{});
             }
             ++gs;
             // the layer's FIRST top-of-step barrier (P3_LAZYDRAIN: it carries the lazy publication of the previous layer's output:
             // its vmcnt(0) covers the epilogue stores that drained under step 0), in front of any neighbour check
-            bool synced = false;
-            if (P3_LAZYDRAIN) {
+            bool synced = PR;         // (P3_PREREAD: every step but a layer's last holds the barrier itself)
+            if (P3_LAZYDRAIN && !PR) {
                 step_sync();
                 publish_pending();
                 synced = true;
             }
             // The only NEW input plane of conv2..4 is the last chunk (index kk + 1): its halo rows are fetched during step kk, so
             // the neighbours' progress is checked right in front of that step (conv1's inputs were verified at the seam).
-            if (kk == 1) {
+            if (!P3_WFLAGS && kk == 1) {
                 ensure_flags(L);
                 if (aborted) return;
             }
             if (n >= 3) {      // step 1: chunk 1; stages chunk 2 (X1) from registers
                 if (!synced) step_sync();
-                synced = false;
+                synced = PR;
                 const char* st = smem + stage_off(1, gs & 1);
                 run_step(C1{}, I2{}, W5{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (18 * 1024),
-                         smem + stage_off(1, (gs + 1) & 1), X1r, NODEFER{});
+                         smem + stage_off(1, (gs + 1) & 1), X1r, NODEFER{}, std::integral_constant<int, kk == 1>{}, L, Q1{}, Q1{});
                 ++gs;
             }
             if (n >= 4) {      // step 2: chunk 2; stages chunk 3 (X2) from registers
-                if (kk == 2) {
+                if (!P3_WFLAGS && kk == 2) {
                     ensure_flags(L);
                     if (aborted) return;
                 }
-                step_sync();
+                if (!PR) step_sync();
                 const char* st = smem + stage_off(1, gs & 1);
                 run_step(C1{}, I2X{}, W5{}, acc, st, st + IN_EX, dcur + 3l * pp.plane_b, wl + 3 * (18 * 1024),
-                         smem + stage_off(1, (gs + 1) & 1), X2r, NODEFER{});
+                         smem + stage_off(1, (gs + 1) & 1), X2r, NODEFER{}, std::integral_constant<int, kk == 2>{}, L, Q1{}, Q1{});
                 ++gs;
             }
             if (n >= 5) {      // step 3 (conv4): chunk 3; stages chunk 4 (X3) by DMA
-                ensure_flags(L);
-                if (aborted) return;
-                step_sync();
+                if (!P3_WFLAGS) {
+                    ensure_flags(L);
+                    if (aborted) return;
+                }
+                if (!PR) step_sync();
                 const char* st = smem + stage_off(1, gs & 1);
                 run_step(C1{}, I1{}, W5{}, acc, st, st + IN_EX, dcur + 4l * pp.plane_b, wl + 4 * (18 * 1024),
-                         smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{});
+                         smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{}, F1{}, L, Q1{}, Q1{});
                 ++gs;
             }
             if (!synced) step_sync();
             {
                 const char* st = smem + stage_off(1, gs & 1);
                 if constexpr (decltype(last_nw_tag)::value == 5)   // conv1..3: the next layer's step 0 reads the resident plane: weights only
-                    run_step(C1{}, I0{}, W5{}, acc, st, st + IN_EX, nullptr, T[kk + 1].w, smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{});
+                    run_step(C1{}, I0{}, W5{}, acc, st, st + IN_EX, nullptr, T[kk + 1].w, smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{}, F0{}, 0, Q1{}, Q0{});
                 else              // conv4: conv5's chunk 0 IS the resident plane (phase-B stage 0 starts at the same address): 36 KiB of weights
-                    run_step(C1{}, I0{}, W9{}, acc, st, st + IN_EX, nullptr, T[4].w, smem + stage_off(2, 0), x1p, NODEFER{});
+                    run_step(C1{}, I0{}, W9{}, acc, st, st + IN_EX, nullptr, T[4].w, smem + stage_off(2, 0), x1p, NODEFER{}, F0{}, 0, Q1{}, Q0{});
                 ++gs;
             }
             if (P3_LAZYDRAIN) next_bias = bias_request(T[kk + 1].bias, kk == 3 ? 64 : 32);   // (older than the epilogue's stores)
@@ -793,40 +910,40 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                     for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
             {   // chunk 0 = the resident plane (in place: phase-B stage 0); stages chunk 1 from registers
                 const char* st = smem + stage_off(2, 0);
-                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + (long)pp.plane_b, wl + 36 * 1024, smem + stage_off(2, 1), x1p, NODEFER{});
+                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + (long)pp.plane_b, wl + 36 * 1024, smem + stage_off(2, 1), x1p, NODEFER{}, F0{}, 0, Q0{}, Q1{});
             }
-            step_sync();
-            if (P3_LAZYDRAIN) publish_pending();       // conv4's output: its stores drained under step 0
+            if (!PR) step_sync();
+            if (P3_LAZYDRAIN && !PR) publish_pending();       // conv4's output: its stores drained under step 0
             {   // chunk 1; stages chunk 2 (X1) from registers
                 const char* st = smem + stage_off(2, 1);
-                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (36 * 1024), smem + stage_off(2, 0), X1r, NODEFER{});
+                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (36 * 1024), smem + stage_off(2, 0), X1r, NODEFER{}, F0{}, 0, Q1{}, Q1{});
             }
-            step_sync();
+            if (!PR) step_sync();
             {   // chunk 2; stages chunk 3 (X2) from registers
                 const char* st = smem + stage_off(2, 0);
-                run_step(C2{}, I2X{}, W9{}, acc, st, st + IN_EX, dcur + 3l * pp.plane_b, wl + 3 * (36 * 1024), smem + stage_off(2, 1), X2r, NODEFER{});
+                run_step(C2{}, I2X{}, W9{}, acc, st, st + IN_EX, dcur + 3l * pp.plane_b, wl + 3 * (36 * 1024), smem + stage_off(2, 1), X2r, NODEFER{}, F0{}, 0, Q1{}, Q1{});
             }
             for (int c = 3; c < 5; ++c) {      // chunks 3, 4; stage X3, X4 by DMA
-                if (c == 4) {      // X4 (chunk 5) is conv4's output on the neighbours: checked in front of the step that fetches it
+                if (!P3_WFLAGS && c == 4) {      // X4 (chunk 5) is conv4's output on the neighbours: checked in front of the step that fetches it
                     ensure_flags(L);
                     if (aborted) break;
                 }
-                step_sync();
+                if (!PR) step_sync();
                 const char* st = smem + stage_off(2, c & 1);
                 run_step(C2{}, I1{}, W9{}, acc, st, st + IN_EX, dcur + (long)(c + 1) * pp.plane_b, wl + (long)(c + 1) * (36 * 1024),
-                         smem + stage_off(2, (c + 1) & 1), x1p, NODEFER{});
+                         smem + stage_off(2, (c + 1) & 1), x1p, NODEFER{}, F1{}, c == 4 ? L : -1, Q1{}, Q1{});
             }
             if (aborted) break;
-            step_sync();
+            if (!PR) step_sync();
             {
                 const char* st = smem + stage_off(2, 1);
                 if constexpr (P3_SEAM) {
                     // the next conv1's first weight chunk -> smem + IN_EX (dst = smem: run_step puts weights at dst + IN_EX); the last RDB has no
                     // successor: it prefetches its own first chunk again (a select, not a branch: one step body), nobody reads it
                     const char* nw5 = rdb + 1 < nrdb ? T[5].w : T[0].w;
-                    run_step(C2{}, I0{}, W5{}, acc, st, st + IN_EX, nullptr, nw5, smem, x1p, NODEFER{});
+                    run_step(C2{}, I0{}, W5{}, acc, st, st + IN_EX, nullptr, nw5, smem, x1p, NODEFER{}, F0{}, 0, Q1{}, Q0{});
                 } else {
-                    run_step(C2{}, I0{}, W0{}, acc, st, st + IN_EX, nullptr, nullptr, smem, x1p, NODEFER{});
+                    run_step(C2{}, I0{}, W0{}, acc, st, st + IN_EX, nullptr, nullptr, smem, x1p, NODEFER{}, F0{}, 0, Q1{}, Q0{});
                 }
             }
             const bool r2 = (rdb % 3) == 2;
@@ -838,8 +955,13 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             __syncthreads();
             publish(L + 1);
             if (rdb + 1 < nrdb) {
-                ensure_flags(L + 1);
-                if (aborted) break;
+                if constexpr (P3_WFLAGS) {
+                    poll_issue();
+                    poll_check(std::integral_constant<int, 0>{}, L + 1);
+                } else {
+                    ensure_flags(L + 1);
+                    if (aborted) break;
+                }
                 if constexpr (P3_SEAM) {
                     // own rows: written by the epilogue; weights: prefetched by the last step; left: the neighbours' two rows
                     const unsigned long long ib = uni64((unsigned long long)dnxt);
