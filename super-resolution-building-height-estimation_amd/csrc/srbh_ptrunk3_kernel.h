@@ -87,8 +87,29 @@
 // Steps of one layer only (the epilogue separates layers).  Needs P3_WFLAGS (nothing may sit between two steps) and P3_SPREAD.
 #define P3_PREREAD 1
 #endif
+#ifndef P3_PRELAYER
+// 1 (round 5): the same hand-over across a LAYER boundary inside an RDB (conv1 -> 2 -> 3 -> 4 -> 5).  A layer's last step holds a barrier in its
+// last group as well and reads the next layer's first operands (resident plane + the weights it has just fetched) behind it; they stay in
+// registers over the epilogue.  The layer prologue then has nothing left to wait for with a barrier: the stage the next step 0 overwrites was
+// last read before that barrier, and the bias goes into the OTHER of two LDS buffers (even / odd layer: the epilogue of the layer before may
+// still be reading its own), a barrier earlier than the epilogue that reads it.  conv5's bias area lies in phase A's stage 1, which conv4's
+// last step reads: it is written behind that step's barrier.  (The RDB seam keeps its barrier: conv1's step 0 reads the neighbours' rows.)
+// 2 = among the cout-32 layers only (1 also conv4 -> conv5: one VGPR spills).  MEASURED SLOWER, default off: same-box 3.740 / 3.726 ms
+// without, 3.753 / 3.757 with (2), 3.769 / 3.755 with (1) (profiles/r05v_ab_prelayer.txt) -- 36 more registers live across each epilogue
+// and the layer's last weight DMA has to land three groups earlier; bit-identical either way.
+#define P3_PRELAYER 0
+#endif
+#ifndef P3_CTAP
+// 1 (round 5): the centre-tap pixel fragments of a register-resident plane come from the registers.  For dx = 1 the B operand of the wave's own
+// rows (fragments 1..4 of the six) is exactly the 16 bytes per lane that x1p / X1r / X2r hold (the bytes the epilogue stored and the staging
+// wrote to LDS), so 8 of a step's 54 (72) ds_read_b128 disappear in the 12 of 20 steps that read chunk 1, X1 or X2.  A cout-32 step keeps the
+// LDS port busy for ~2.1 k of its 2.3 k MFMA cycles (54 reads x 29 cycles + 60 KB of LDS-DMA) -- but it does not pace it.  MEASURED NEUTRAL,
+// default off (it costs a second body for conv5's chunk-3 / chunk-4 steps): same-box 3.796 / 3.775 ms with, 3.765 / 3.806 without
+// (profiles/r05x_ab_ctap.txt); the ISA has the 96 reads less and 8 more v_mov; bit-identical.
+#define P3_CTAP 0
+#endif
 #ifndef P3_PRE_AT
-#define P3_PRE_AT 0
+#define P3_PRE_AT 2
 #endif
 
 // PROF = 1 (developer timeline, SRBH_PT_PROF): s_memtime stamps per layer in ptrunk_kernel's 6-slot format
@@ -394,7 +415,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     //   border write + 2 halo DMA statements);   NW: weight DMA statements per wave (0 | 5 = 18 fragments | 9 = 36 fragments)
     auto run_step = [&](auto cb_tag, auto in_tag, auto nw_tag, floatx16 (&acc)[decltype(cb_tag)::value][4], const char* sbi, const char* sbw,
                         const char* nsrc, const char* nw, char* dst, const uintx4 (&rsrc)[4][2], auto defer_tag, auto flag_tag, const int need,
-                        auto pre_tag, auto nxt_tag) {
+                        auto pre_tag, auto nxt_tag, auto rc_tag, const uintx4 (&rcur)[4][2]) {
         constexpr int CB = decltype(cb_tag)::value, IN = decltype(in_tag)::value, NW = decltype(nw_tag)::value;
         // FL (P3_WFLAGS): this step fetches rows of a neighbour (the plane it stages is new on them): polls at the top, the check in front
         // of the statements that carry those rows, which are then the LAST staging items of the step (need < 0: no check this time)
@@ -419,21 +440,28 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         const unsigned din_w = __builtin_amdgcn_readfirstlane(lds_addr(dst) + wave * 1024);
         const unsigned dw_w = din_w + IN_EX;
         constexpr bool PRE = P3_PREREAD && decltype(pre_tag)::value != 0;   // group 0's operands were read by the previous step
-        constexpr bool NXT = P3_PREREAD && decltype(nxt_tag)::value != 0;   // this step holds the barrier and reads the next step's group 0
+        constexpr int NXV = P3_PREREAD ? decltype(nxt_tag)::value : 0;       // 1: next step of this layer; 2 / 3: step 0 of the next layer (cout 32 / 64)
+        constexpr bool NXT = NXV != 0;                                        // this step holds the barrier and reads the next step's group 0
+        constexpr int NCB = NXV == 3 ? 2 : NXV == 2 ? 1 : CB;                 // cout / 32 of the step those reads belong to
+        constexpr int NRDN = G::NP + 3 * NCB;
+        constexpr int AT = P3_PRE_AT < NMF - NRDN ? P3_PRE_AT : NMF - NRDN;   // MFMA of the last group the barrier sits in front of
         static_assert(!P3_PREREAD || (P3_WFLAGS && P3_SPREAD), "P3_PREREAD needs P3_WFLAGS and P3_SPREAD");
-        static_assert(P3_PRE_AT + NRD <= NMF, "the next step's first reads must fit behind the barrier");
+        static_assert(AT >= 0, "the next step's first reads must fit behind the barrier");
         half8 (&P)[2][G::NP] = Pq;
         half8 (&A)[2][3][2] = Aq;
-        auto read_from = [&](const char* bi, const char* bw, const int g, const int r, const int set) {   // LDS read r (0..NRD-1) of group g
+        auto read_from = [&](auto rcb_tag, const char* bi, const char* bw, const int g, const int r, const int set) {   // LDS read r (0..NRD-1) of group g
+            constexpr int RCB = decltype(rcb_tag)::value;
             const int ks = g / 3, dx = g - ks * 3;
-            if (r < G::NP) {
+            if (P3_CTAP && decltype(rc_tag)::value != 0 && bi == sbi && dx == 1 && r >= 1 && r <= 4) {
+                P[set][r] = __builtin_bit_cast(half8, rcur[r - 1][ks]);     // (P3_CTAP: the lane's own pixel of an own row)
+            } else if (r < G::NP) {
                 P[set][r] = *(const half8*)(bi + aoff[dx][ks] + r * G::ROW_B);
             } else {
-                const int q = r - G::NP, dy = q / CB, mb = q - dy * CB;
-                A[set][dy][mb] = *(const half8*)(bw + woff + ((((dy * 3 + dx) * 2 + ks) * CB + mb) << 10));
+                const int q = r - G::NP, dy = q / RCB, mb = q - dy * RCB;
+                A[set][dy][mb] = *(const half8*)(bw + woff + ((((dy * 3 + dx) * 2 + ks) * RCB + mb) << 10));
             }
         };
-        auto read_item = [&](const int g, const int r, const int set) { read_from(sbi, sbw, g, r, set); };
+        auto read_item = [&](const int g, const int r, const int set) { read_from(cb_tag, sbi, sbw, g, r, set); };
         auto stage_item = [&](const int d) {
             if constexpr (FL && IN == 2) {            // weights, the own rows from registers, the border, [check], the neighbours' rows
                 if (d < NW) {
@@ -489,9 +517,9 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             for (int m = 0; m < NMF; ++m) {
                 const int dy = m / (4 * CB), rem = m - dy * 4 * CB, i = rem / CB, mb = rem - i * CB;
                 if constexpr (NXT) {
-                    if (g == 5 && m == P3_PRE_AT) {      // the step barrier (see P3_PREREAD)
+                    if (g == 5 && m == AT) {             // the step barrier (see P3_PREREAD)
                         step_sync();
-                        publish_pending();               // (the layer's first barrier carries the lazy publication of the previous layer's output)
+                        if constexpr (NXV == 1) publish_pending();   // (the layer's first barrier carries the lazy publication of the previous layer's output)
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -501,8 +529,10 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                     const int k = m / RSTRIDE;
                     if (g + 1 < 6 && m % RSTRIDE == 0 && k < NRD) read_item(g + 1, CB == 1 ? ORD1[k % 9] : ORD2[k % 12], (g + 1) & 1);
                     if constexpr (NXT) {                 // the next step's group 0 (it reads what this step staged: dst, dst + IN_EX), one read per shadow
-                        const int k2 = m - P3_PRE_AT;
-                        if (g == 5 && k2 >= 0 && k2 < NRD) read_from(dst, dst + IN_EX, 0, CB == 1 ? ORD1[k2 % 9] : ORD2[k2 % 12], 0);
+                        const int k2 = m - AT;
+                        // (a next LAYER's step 0 reads the resident plane -- phase B's stage 0 starts at the same address -- and the weights this step fetched)
+                        if (g == 5 && k2 >= 0 && k2 < NRDN)
+                            read_from(std::integral_constant<int, NCB>{}, NXV == 1 ? dst : smem, dst + IN_EX, 0, NCB == 1 ? ORD1[k2 % 9] : ORD2[k2 % 12], 0);
                     }
                     // staging: one item per shadow for a cout-32 group (12), every other shadow of conv5's (the ones without a read)
                     const int sm = CB == 1 ? m : (m % 2 ? m / 2 : -1);
@@ -552,7 +582,22 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     using F1 = std::integral_constant<int, 1>;
     using Q0 = std::integral_constant<int, 0>;   // pre_tag / nxt_tag (P3_PREREAD)
     using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>;
+    using Q3 = std::integral_constant<int, 3>;
+    using R0 = std::integral_constant<int, 0>;   // rc_tag: the plane the step READS has a register copy (rcur)
+    using R1 = std::integral_constant<int, P3_S1 ? 1 : 0>;
+    using R1X = std::integral_constant<int, (P3_S1 && P3_X2REG) ? 1 : 0>;
     constexpr bool PR = P3_PREREAD != 0;
+    constexpr bool PL = PR && P3_PRELAYER != 0 && P3_LAZYDRAIN != 0 && !P3_DEFER;
+    constexpr bool PL5 = PL && P3_PRELAYER == 1;      // ... also conv4 -> conv5 (P3_PRELAYER = 2: the cout-32 layers among themselves only)
+    // P3_PRELAYER: no barrier -- the wait leaves the epilogue's NST stores in flight and covers the bias load in front of them
+    auto bias_commit = [&](auto nst_tag, const float bias_v, const int nb, const int bias_lds) {
+        constexpr int NST = decltype(nst_tag)::value;
+        if constexpr (NST == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid < nb) ((float*)(smem + bias_lds))[tid] = bias_v;
+    };
 
     // ---- layer prologue: drain the own DMA / stores, barrier, bias into LDS, lazy publish
     auto prologue = [&](const float* bias, const int nb, const int bias_lds) {
@@ -584,11 +629,11 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         if (tid < nb) ((float*)(smem + bias_lds))[tid] = bias_v;
     };
     // ---- epilogue of a cout-32 layer: bias, leaky ReLU, fp16, straight from the MFMA D layout (see ptrunk_kernel)
-    auto epi32 = [&](floatx16 (&acc)[1][4], char* oplane, uintx4 (&keep)[4][2], const bool halo_only, auto park_tag) {
+    auto epi32 = [&](floatx16 (&acc)[1][4], char* oplane, uintx4 (&keep)[4][2], const bool halo_only, auto park_tag, const int bias_lds) {
         constexpr bool PARK = decltype(park_tag)::value;   // rows 1, 2 are parked for the next layer's step 0 (defer_unit)
         floatx4 bias4[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bias4[g] = *(const floatx4*)((const float*)(smem + A_BIAS_OFF) + g * 8 + hi * 4);
+        for (int g = 0; g < 4; ++g) bias4[g] = *(const floatx4*)((const float*)(smem + bias_lds) + g * 8 + hi * 4);
         // rows 0 and 3 first: one of them is the row a neighbour reads (its store is the one the publication waits for)
         if constexpr (PARK) {
 #pragma unroll
@@ -771,7 +816,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             if (P3_LAZYDRAIN && kk > 0) {
                 // stores of the previous layer's epilogue still in flight per wave: X1 / X2 go out as one halo row (2 x 16 B), X3 whole (8)
                 constexpr bool prev_halo_only = P3_SKIPST && P3_S1 && (kk - 1 == 0 || (P3_X2REG && kk - 1 == 1));
-                prologue_lazy(std::integral_constant<int, prev_halo_only ? 2 : 8>{}, next_bias, 32, A_BIAS_OFF);
+                if constexpr (PL) bias_commit(std::integral_constant<int, prev_halo_only ? 2 : 8>{}, next_bias, 32, A_BIAS_OFF + (kk & 1) * 128);
+                else prologue_lazy(std::integral_constant<int, prev_halo_only ? 2 : 8>{}, next_bias, 32, A_BIAS_OFF);
             } else {
                 prologue(T[kk].bias, 32, A_BIAS_OFF);
             }
@@ -786,7 +832,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             // step 0: resident plane 0; stages chunk 1 (x's second half) from registers
             if (P3_DEFER && kk > 0) {   // ... and works off rows 1, 2 of the previous layer's epilogue in its empty MFMA shadows
                 run_step(C1{}, I2{}, W5{}, acc, smem, smem + stage_off(1, gs & 1) + IN_EX, dcur + (long)pp.plane_b, wl + 18 * 1024,
-                         smem + stage_off(1, (gs + 1) & 1), x1p, DODEFER{}, F0{}, 0, Q0{}, Q1{});
+                         smem + stage_off(1, (gs + 1) & 1), x1p, DODEFER{}, F0{}, 0, Q0{}, Q1{}, R0{}, x1p);
                 if (kk == 1) {
 #pragma unroll
                     for (int r = 0; r < 2; ++r)
@@ -801,7 +847,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 }
             } else {
                 run_step(C1{}, I2{}, W5{}, acc, smem, smem + stage_off(1, gs & 1) + ((P3_SEAM && kk == 0) ? 0 : IN_EX), dcur + (long)pp.plane_b, wl + 18 * 1024,
-                         smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{}, F0{}, 0, Q0{}, Q1{});
+                         smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{}, F0{}, 0, std::integral_constant<int, (PL && kk > 0) ? 1 : 0>{}, Q1{}, R0{}, x1p);
             }
             ++gs;
             // the layer's FIRST top-of-step barrier (P3_LAZYDRAIN: it carries the lazy publication of the previous layer's output:
@@ -823,7 +869,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 synced = PR;
                 const char* st = smem + stage_off(1, gs & 1);
                 run_step(C1{}, I2{}, W5{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (18 * 1024),
-                         smem + stage_off(1, (gs + 1) & 1), X1r, NODEFER{}, std::integral_constant<int, kk == 1>{}, L, Q1{}, Q1{});
+                         smem + stage_off(1, (gs + 1) & 1), X1r, NODEFER{}, std::integral_constant<int, kk == 1>{}, L, Q1{}, Q1{}, R1{}, x1p);
                 ++gs;
             }
             if (n >= 4) {      // step 2: chunk 2; stages chunk 3 (X2) from registers
@@ -834,7 +880,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 if (!PR) step_sync();
                 const char* st = smem + stage_off(1, gs & 1);
                 run_step(C1{}, I2X{}, W5{}, acc, st, st + IN_EX, dcur + 3l * pp.plane_b, wl + 3 * (18 * 1024),
-                         smem + stage_off(1, (gs + 1) & 1), X2r, NODEFER{}, std::integral_constant<int, kk == 2>{}, L, Q1{}, Q1{});
+                         smem + stage_off(1, (gs + 1) & 1), X2r, NODEFER{}, std::integral_constant<int, kk == 2>{}, L, Q1{}, Q1{}, R1{}, X1r);
                 ++gs;
             }
             if (n >= 5) {      // step 3 (conv4): chunk 3; stages chunk 4 (X3) by DMA
@@ -845,16 +891,23 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 if (!PR) step_sync();
                 const char* st = smem + stage_off(1, gs & 1);
                 run_step(C1{}, I1{}, W5{}, acc, st, st + IN_EX, dcur + 4l * pp.plane_b, wl + 4 * (18 * 1024),
-                         smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{}, F1{}, L, Q1{}, Q1{});
+                         smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{}, F1{}, L, Q1{}, Q1{}, R1X{}, X2r);
                 ++gs;
             }
             if (!synced) step_sync();
             {
                 const char* st = smem + stage_off(1, gs & 1);
+                // (the last step reads chunk kk + 1: x's second half, X1, X2 -- register-resident -- or X3)
+                const auto& rlast = [&]() -> const uintx4 (&)[4][2] {
+                    if constexpr (kk == 0) return x1p;
+                    else if constexpr (kk == 1) return X1r;
+                    else return X2r;
+                }();
                 if constexpr (decltype(last_nw_tag)::value == 5)   // conv1..3: the next layer's step 0 reads the resident plane: weights only
-                    run_step(C1{}, I0{}, W5{}, acc, st, st + IN_EX, nullptr, T[kk + 1].w, smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{}, F0{}, 0, Q1{}, Q0{});
+                    run_step(C1{}, I0{}, W5{}, acc, st, st + IN_EX, nullptr, T[kk + 1].w, smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{}, F0{}, 0, Q1{}, std::integral_constant<int, PL ? 2 : 0>{},
+                             std::integral_constant<int, kk == 2 ? R1X::value : R1::value>{}, rlast);
                 else              // conv4: conv5's chunk 0 IS the resident plane (phase-B stage 0 starts at the same address): 36 KiB of weights
-                    run_step(C1{}, I0{}, W9{}, acc, st, st + IN_EX, nullptr, T[4].w, smem + stage_off(2, 0), x1p, NODEFER{}, F0{}, 0, Q1{}, Q0{});
+                    run_step(C1{}, I0{}, W9{}, acc, st, st + IN_EX, nullptr, T[4].w, smem + stage_off(2, 0), x1p, NODEFER{}, F0{}, 0, Q1{}, std::integral_constant<int, PL5 ? 3 : 0>{}, R0{}, x1p);
                 ++gs;
             }
             if (P3_LAZYDRAIN) next_bias = bias_request(T[kk + 1].bias, kk == 3 ? 64 : 32);   // (older than the epilogue's stores)
@@ -862,9 +915,9 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             uintx4 kept[4][2];
             const bool halo_only = P3_SKIPST && P3_S1 && (kk == 0 || (P3_X2REG && kk == 1));
             if constexpr (P3_DEFER && decltype(last_nw_tag)::value == 5)     // conv1..3: rows 1, 2 are finished by the next layer's step 0
-                epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept, halo_only, std::true_type{});
+                epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept, halo_only, std::true_type{}, A_BIAS_OFF);
             else
-                epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept, halo_only, std::false_type{});
+                epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept, halo_only, std::false_type{}, PL ? A_BIAS_OFF + (kk & 1) * 128 : A_BIAS_OFF);
             constexpr int NK = (P3_DEFER && decltype(last_nw_tag)::value == 5) ? 2 : 4;     // rows available now: 0 and 3, or all
             if (kk == 0) {
 #pragma unroll
@@ -896,7 +949,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             const char* wl = T[4].w;
             unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;
             if (PROF) p0 = __builtin_amdgcn_s_memtime();
-            if (P3_LAZYDRAIN) prologue_lazy(std::integral_constant<int, 8>{}, next_bias, 64, B_BIAS_OFF);   // (X4 went out whole: 8 stores per wave)
+            if constexpr (PL5) bias_commit(std::integral_constant<int, 8>{}, next_bias, 64, B_BIAS_OFF);
+            else if (P3_LAZYDRAIN) prologue_lazy(std::integral_constant<int, 8>{}, next_bias, 64, B_BIAS_OFF);   // (X4 went out whole: 8 stores per wave)
             else prologue(T[4].bias, 64, B_BIAS_OFF);
             if (PROF) p1 = __builtin_amdgcn_s_memtime();
             t_sync = 0;
@@ -910,19 +964,35 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                     for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
             {   // chunk 0 = the resident plane (in place: phase-B stage 0); stages chunk 1 from registers
                 const char* st = smem + stage_off(2, 0);
-                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + (long)pp.plane_b, wl + 36 * 1024, smem + stage_off(2, 1), x1p, NODEFER{}, F0{}, 0, Q0{}, Q1{});
+                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + (long)pp.plane_b, wl + 36 * 1024, smem + stage_off(2, 1), x1p, NODEFER{}, F0{}, 0, std::integral_constant<int, PL5 ? 1 : 0>{}, Q1{}, R0{}, x1p);
             }
             if (!PR) step_sync();
             if (P3_LAZYDRAIN && !PR) publish_pending();       // conv4's output: its stores drained under step 0
             {   // chunk 1; stages chunk 2 (X1) from registers
                 const char* st = smem + stage_off(2, 1);
-                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (36 * 1024), smem + stage_off(2, 0), X1r, NODEFER{}, F0{}, 0, Q1{}, Q1{});
+                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (36 * 1024), smem + stage_off(2, 0), X1r, NODEFER{}, F0{}, 0, Q1{}, Q1{}, R1{}, x1p);
             }
             if (!PR) step_sync();
             {   // chunk 2; stages chunk 3 (X2) from registers
                 const char* st = smem + stage_off(2, 0);
-                run_step(C2{}, I2X{}, W9{}, acc, st, st + IN_EX, dcur + 3l * pp.plane_b, wl + 3 * (36 * 1024), smem + stage_off(2, 1), X2r, NODEFER{}, F0{}, 0, Q1{}, Q1{});
+                run_step(C2{}, I2X{}, W9{}, acc, st, st + IN_EX, dcur + 3l * pp.plane_b, wl + 3 * (36 * 1024), smem + stage_off(2, 1), X2r, NODEFER{}, F0{}, 0, Q1{}, Q1{}, R1{}, X1r);
             }
+            if constexpr (P3_CTAP && P3_S1 && P3_X2REG && P3_WFLAGS) {
+                // two bodies: chunk 3 (X2) has a register copy and its step fetches nothing new from the neighbours; chunk 4 (X3) has none and its
+                // step fetches X4, conv4's output on the neighbours
+                {
+                    if (!PR) step_sync();
+                    const char* st = smem + stage_off(2, 1);
+                    run_step(C2{}, I1{}, W9{}, acc, st, st + IN_EX, dcur + 4l * pp.plane_b, wl + 4l * (36 * 1024),
+                             smem + stage_off(2, 0), x1p, NODEFER{}, F0{}, 0, Q1{}, Q1{}, R1X{}, X2r);
+                }
+                {
+                    if (!PR) step_sync();
+                    const char* st = smem + stage_off(2, 0);
+                    run_step(C2{}, I1{}, W9{}, acc, st, st + IN_EX, dcur + 5l * pp.plane_b, wl + 5l * (36 * 1024),
+                             smem + stage_off(2, 1), x1p, NODEFER{}, F1{}, L, Q1{}, Q1{}, R0{}, x1p);
+                }
+            } else
             for (int c = 3; c < 5; ++c) {      // chunks 3, 4; stage X3, X4 by DMA
                 if (!P3_WFLAGS && c == 4) {      // X4 (chunk 5) is conv4's output on the neighbours: checked in front of the step that fetches it
                     ensure_flags(L);
@@ -931,7 +1001,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 if (!PR) step_sync();
                 const char* st = smem + stage_off(2, c & 1);
                 run_step(C2{}, I1{}, W9{}, acc, st, st + IN_EX, dcur + (long)(c + 1) * pp.plane_b, wl + (long)(c + 1) * (36 * 1024),
-                         smem + stage_off(2, (c + 1) & 1), x1p, NODEFER{}, F1{}, c == 4 ? L : -1, Q1{}, Q1{});
+                         smem + stage_off(2, (c + 1) & 1), x1p, NODEFER{}, F1{}, c == 4 ? L : -1, Q1{}, Q1{}, R0{}, x1p);
             }
             if (aborted) break;
             if (!PR) step_sync();
@@ -941,9 +1011,9 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                     // the next conv1's first weight chunk -> smem + IN_EX (dst = smem: run_step puts weights at dst + IN_EX); the last RDB has no
                     // successor: it prefetches its own first chunk again (a select, not a branch: one step body), nobody reads it
                     const char* nw5 = rdb + 1 < nrdb ? T[5].w : T[0].w;
-                    run_step(C2{}, I0{}, W5{}, acc, st, st + IN_EX, nullptr, nw5, smem, x1p, NODEFER{}, F0{}, 0, Q1{}, Q0{});
+                    run_step(C2{}, I0{}, W5{}, acc, st, st + IN_EX, nullptr, nw5, smem, x1p, NODEFER{}, F0{}, 0, Q1{}, Q0{}, R0{}, x1p);
                 } else {
-                    run_step(C2{}, I0{}, W0{}, acc, st, st + IN_EX, nullptr, nullptr, smem, x1p, NODEFER{}, F0{}, 0, Q1{}, Q0{});
+                    run_step(C2{}, I0{}, W0{}, acc, st, st + IN_EX, nullptr, nullptr, smem, x1p, NODEFER{}, F0{}, 0, Q1{}, Q0{}, R0{}, x1p);
                 }
             }
             const bool r2 = (rdb % 3) == 2;
