@@ -21,6 +21,9 @@
 #ifndef HB16_LATE
 #define HB16_LATE 0          // (measured: 329 / 342 / 338 us for 0 / 1 / 2, profiles/r05k_time_hbwd16_chain.txt -- the spills are not these registers)
 #endif
+#ifndef HB16_BITS_VEC
+#define HB16_BITS_VEC 1      // 1: the ReLU bit words of a tile come by one vector load ahead of the MFMAs (0: 16 scalar loads in the epilogue)
+#endif
 struct HB16 {
     static constexpr int QX = WG16T::QX, SX = WG16T::SX, SD = WG16T::SD;      // 18 quads per row, channel strides of the two channel-major copies
     static constexpr int ROWS = 6, COLS = 66;
@@ -235,6 +238,11 @@ __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
             for (int i = 0; i < 4; ++i) rraw[i] = *(const float2w*)(rp + (long)i * 16 * 16 * 2);
         };
         constexpr int LATE = BS == 2 ? HB16_LATE : 0;
+        // BS = 2: the ReLU bit words of this wave's 4 x 16 pixels are 16 consecutive 64-bit words (128 bytes): ONE dword per lane, requested
+        // here with the other epilogue operands and handed out by v_readlane in the epilogue.  (As 16 scalar loads IN the epilogue, each
+        // with its own wait, they were most of the 130 us this form took longer than the plain one: 348 vs 214 us.)
+        unsigned bitsv = 0;
+        if constexpr (BS == 2 && HB16_BITS_VEC) bitsv = ((const unsigned*)(p.relu_bits + ((pix0 - l15) >> 4) * 4))[lane & 31];
         if constexpr (BS != 0 && LATE < 2) load_c();
         if constexpr (BS != 1 && LATE < 1) { if (p.res) load_res(); }
         if (t + t_step < t_end) issue(t + t_step);
@@ -290,11 +298,20 @@ __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
             } else if constexpr (BS == 2) {
                 if (p.res) v = v + widen_b4(rraw[i]);
                 // the 64 4-channel groups of this wave's 16 pixels share four 64-bit words (wave-uniform address: scalar loads)
-                const long grp0 = __builtin_amdgcn_readfirstlane((int)(((pix0 - l15) + i * 16) >> 4));
-                const unsigned long long* mw = p.relu_bits + grp0 * 4;
                 const int sh = l15 * 4 + kk;
+                if constexpr (HB16_BITS_VEC) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = ((mw[q] >> sh) & 1ull) ? v[q] : 0.f;
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned lo = __builtin_amdgcn_readlane(bitsv, i * 8 + q * 2), hi32 = __builtin_amdgcn_readlane(bitsv, i * 8 + q * 2 + 1);
+                        const unsigned w = sh < 32 ? lo : hi32;
+                        v[q] = ((w >> (sh & 31)) & 1u) ? v[q] : 0.f;
+                    }
+                } else {
+                    const long grp0 = __builtin_amdgcn_readfirstlane((int)(((pix0 - l15) + i * 16) >> 4));
+                    const unsigned long long* mw = p.relu_bits + grp0 * 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = ((mw[q] >> sh) & 1ull) ? v[q] : 0.f;
+                }
                 const float2w nb = narrow_b4(v);
                 *(float2w*)((char*)p.dx + ((pix0 + i * 16) * 16 + kk * 4) * 2) = nb;
                 const floatx4 dzr = widen_b4(nb);          // the sums are taken over the values the consumer reads
