@@ -227,6 +227,11 @@ def _max_over_ranks(vals, dev, dist):
     return [float(v) for v in t]
 
 
+def _pipe_images(dev):
+    from srbh_amd.harness import pipe_images
+    return pipe_images(dev)
+
+
 def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_tiles=None, with_cpu=True, with_kernels=True):
     """BASELINE configs[2]/[3]: RRDBNet forward (no grad) + SRRegress_Cls_feature forward/backward + Adam, `batch` tiles
     per GPU, gradients averaged over ranks by bucketed RCCL all-reduces launched from autograd hooks (overlapped with
@@ -242,8 +247,12 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
     use_graph = os.environ.get("SRBH_TRAIN_GRAPH", "0") == "1" and not epoch_tiles and not (world > 1 and sync_bn)
     ts = TrainStep(net_hr, net, dev, world=world, sync_bn=sync_bn, timing=True, status_every=0, graph=use_graph)
     fixed = synthetic_batch(batch, 1337 + rank, dev)
-    for _ in range(max(warmup, 5 if use_graph else (2 if world > 1 else 1))):          # (world > 1: step 1 records the bucket plan; graph: 3 eager steps, then the capture)
-        ts(fixed)
+    # the pipelined step (harness.TrainStep): the RRDBNet features of the NEXT batch are computed on a second stream beside this step's
+    # small-kernel phases.  Every timed step still contains one full trunk pass (that of the batch the following step consumes; the last
+    # one is computed and never used), and the final synchronize covers the second stream.  SRBH_TRAIN_PIPELINE=0: the serial step.
+    pipe = os.environ.get("SRBH_TRAIN_PIPELINE", "1") == "1" and not use_graph
+    for _ in range(max(warmup, 5 if use_graph else 2)):          # (world > 1: step 1 records the bucket plan; graph: 3 eager steps, then the capture; pipeline: step 1 fills it)
+        ts(fixed, next_batch=fixed if pipe else None)
     if use_graph:
         fixed = ts.static_batch()
     torch.cuda.synchronize()
@@ -255,8 +264,9 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
     if epoch_tiles:
         steps, tiles, loss = train_epoch(ts, epoch_tiles, batch, rank, world, dev)
     else:
+        p0 = ts.pipelined_steps
         for _ in range(steps):
-            loss, _ = ts(fixed)
+            loss, _ = ts(fixed, next_batch=fixed if pipe else None)
             if ts.reducer is not None:
                 exposed.append(ts.reducer._last_events)
         tiles = batch * world * steps
@@ -305,7 +315,10 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
                                "(BASELINE.json configs[2])", "batch": batch, "global_batch": batch * world,
                    "parallelism": (f"dp{world} (fwd+bwd replayed as one HIP graph, then the bucketed RCCL grad all-reduce + Adam)" if use_graph else
                                    f"dp{world} (bucketed RCCL grad all-reduce launched from autograd hooks)") if world > 1 else
-                   ("1 GPU, the whole step replayed as one HIP graph" if use_graph else "1 GPU, eager launches")},
+                   ("1 GPU, the whole step replayed as one HIP graph" if use_graph else "1 GPU, eager launches"),
+                   "pipeline": (f"RRDBNet features of batch k+1 on a second stream beside step k's encoder / decoder phases, {_pipe_images(dev)} images "
+                                f"per trunk launch ({ts.pipelined_steps - p0 if not epoch_tiles else ts.pipelined_steps} of the {steps} timed steps consumed prefetched features; "
+                                "one full trunk pass inside every timed step)") if pipe and ts.pipelined_steps else "none (serial step)"},
         "whole_step": {"gflop_per_tile": gf_tile, "achieved_tflops": round(gf_tile * tiles / elapsed / 1e3, 2),
                        "note": "mixes the MFMA-bound trunk with the HBM-bound head: not a roofline, see `kernels`"},
         "final_loss": float(loss)}

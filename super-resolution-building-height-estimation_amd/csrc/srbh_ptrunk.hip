@@ -1237,7 +1237,17 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
     hipLaunchKernelGGL(ptrunk_reset_kernel, dim3((B * tpi + 255) / 256), dim3(256), 0, stream, d_prog, d_xcc, d_err, B * tpi);
     SRBH_HIP(hipGetLastError());
     const Act16Geo g = act16_geo(B, 6, H, W);
-    const int imgs_per_launch = ncu / tpi;
+    // One workgroup per CU at most (co-residency).  SRBH_PT_IMAGES caps the images of one launch below that (developer / harness knob: a launch
+    // that leaves CUs free lets kernels of ANOTHER stream run beside the trunk -- it holds every byte of LDS of the CUs it sits on); the
+    // batch is then split evenly over the launches.
+    int imgs_per_launch = ncu / tpi;
+    if (const char* ie = getenv("SRBH_PT_IMAGES")) {
+        const int cap = atoi(ie);
+        if (cap > 0 && cap < imgs_per_launch) {
+            const int nl_ = (B + cap - 1) / cap;
+            imgs_per_launch = (B + nl_ - 1) / nl_;
+        }
+    }
     for (int b0 = 0; b0 < B; b0 += imgs_per_launch) {
         const int nb = (B - b0) < imgs_per_launch ? (B - b0) : imgs_per_launch;
         PParams pp;

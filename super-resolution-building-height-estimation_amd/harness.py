@@ -269,11 +269,47 @@ def features_for_head(net_hr, x, h16=None, model=None):
     return net_hr.forward_feature(x)
 
 
+class _Prefetch:
+    """RRDBNet features of a batch, being computed on the trunk stream: calling it makes the current stream wait for them"""
+
+    def __init__(self, lr, fea, done):
+        self.key = (lr.data_ptr(), lr._version, tuple(lr.shape))
+        self.fea, self.done = fea, done
+
+    def matches(self, lr):
+        return self.key == (lr.data_ptr(), lr._version, tuple(lr.shape))
+
+    def __call__(self):
+        cur = torch.cuda.current_stream(self.fea.device)
+        cur.wait_event(self.done)
+        self.fea.record_stream(cur)
+        return self.fea
+
+
+def pipe_images(device):
+    """images per trunk launch of a pipelined step: the persistent trunk kernel takes one CU per workgroup (8 per image) with all of its
+    LDS, so a launch on HALF of the CUs leaves the other half to the kernels it runs beside (SRBH_PIPE_IMAGES overrides).  Measured on
+    256 CUs at batch 64 (profiles/r05ac_ab_pipeline.txt; serial step 30.8 ms): 4 launches of 16 images 27.5 ms, 3 launches of 21-22
+    29.5 ms, launches of 32 (the whole chip: nothing else gets in) no gain, launches of <= 12 slower than the serial step."""
+    e = os.environ.get("SRBH_PIPE_IMAGES")
+    if e:
+        return max(1, int(e))
+    ncu = torch.cuda.get_device_properties(device).multi_processor_count
+    return max(1, ncu // 16)
+
+
 class TrainStep:
     """train.py:133-179,243-256: frozen RRDBNet feature extractor + trainable SRRegress_Cls_feature, three
     uncertainty-weighted losses, Adam(lr 1e-3, wd 1e-4) with the log_vars as an extra param group.
     world > 1: gradients are averaged by `GradReducer` (bucketed all-reduce launched from autograd hooks while backward
-    is still running); ``overlap=False`` selects the plain post-backward sweep."""
+    is still running); ``overlap=False`` selects the plain post-backward sweep.
+
+    ``step(batch, next_batch=...)`` (round 5, the pipelined step): the frozen RRDBNet's features of the NEXT batch are computed on a
+    second stream while this step's backward walks the encoder / decoders and the next step's forward walks them again -- two
+    chains of ~10-30 us kernels that leave most of the chip idle -- in launches of `pipe_images()` images, so that the trunk's
+    workgroups (one CU each) leave CUs to those chains.  The trunk goes out when backward has left the head's chip-filling kernels
+    (a post-accumulate hook on HRfeature's first weight).  Same arithmetic per batch; features are those of the batch they are
+    used for (matched by tensor identity + version)."""
 
     def __init__(self, net_hr, net, device, world=1, lr=1e-3, sync_bn=False, overlap=True, timing=False, status_every=100,
                  head_precision="f16", graph=False):
@@ -329,11 +365,53 @@ class TrainStep:
         self.status_every = status_every
         self._graph = None
         self._static = None
+        # pipelined step (see the class docstring): state of the feature prefetch
+        self._pf = None              # _Prefetch of the batch the next call is expected to bring
+        self._next = None            # the batch announced by the running call
+        self._trunk_stream = None
+        self._pipe_hook = None
+        self.pipelined_steps = 0     # steps that consumed prefetched features (bench / tests read it)
+
+    def _pipe_ok(self, h16):
+        """the prefetch computes what features_for_head would hand to this head: fp16 channels_last features on the fast trunk path"""
+        return (not self.use_graph and FEATURE_H16 and h16 and os.environ.get("SRBH_TRAIN_PIPELINE", "1") == "1"
+                and os.environ.get("SRBH_PTAIL", "1") != "0" and isinstance(getattr(self.net, "hrfeat", None), self._H.HRfeature)
+                and hasattr(self.net_hr, "_use_strict") and not self.net_hr._use_strict() and not getattr(self.net_hr, "_train_path", False))
+
+    def _launch_prefetch(self, nb):
+        lr = nb[0]
+        dev = lr.device
+        if self._trunk_stream is None:
+            self._trunk_stream = torch.cuda.Stream(device=dev)
+        sT, cur = self._trunk_stream, torch.cuda.current_stream(dev)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        sT.wait_event(ev)
+        with torch.cuda.stream(sT), torch.no_grad():
+            x3 = lr.index_select(1, self._rgb_idx)
+            B = x3.shape[0]
+            n = -(-B // pipe_images(dev))
+            fea = torch.empty((B, 64, 4 * x3.shape[2], 4 * x3.shape[3]), dtype=torch.float16, device=dev, memory_format=torch.channels_last)
+            i = 0
+            for k in range(n):
+                j = i + (B - i + (n - k) - 1) // (n - k)          # even split: 64 -> 22, 21, 21
+                self.net_hr.forward_feature(x3[i:j], out=fea[i:j], out_dtype=torch.float16)
+                i = j
+            done = torch.cuda.Event()
+            done.record(sT)
+        lr.record_stream(sT)
+        return _Prefetch(lr, fea, done)
+
+    def _on_head_backward_done(self, _param):
+        nb = self._next
+        if nb is not None and self._pf is None:
+            self._pf = self._launch_prefetch(nb)
 
     def params(self):
         return [p for g in self.optimizer.param_groups for p in g["params"]]
 
-    def __call__(self, batch):
+    def __call__(self, batch, next_batch=None):
+        self._next = next_batch
         with self._H.head_precision(self.head_precision):
             if self.use_graph:
                 return self._graph_step(batch)
@@ -419,14 +497,27 @@ class TrainStep:
     def _step(self, batch, in_graph=False):
         lr, height, height_aggre, build, weight, weight_aggre = batch
         h16 = self._H.head_h16()              # (in the grad mode the head runs in: 'auto' trains exact-fp32 and takes fp32 features)
-        with torch.no_grad():
-            hr_fea = features_for_head(self.net_hr, lr.index_select(1, self._rgb_idx), h16, model=self.net)
+        pipe = not in_graph and lr.is_cuda and self._pipe_ok(h16)
+        pf, self._pf = self._pf, None
+        if pipe and self._next is not None and self._pipe_hook is None:
+            self._pipe_hook = self.net.hrfeat[0].conv1.weight.register_post_accumulate_grad_hook(self._on_head_backward_done)
+        if not pipe:
+            self._next = None
+        if pf is not None and pipe and pf.matches(lr):
+            hr_fea = pf                       # a handle: the model issues the encoder / decoders first and waits in front of HRfeature
+            self.pipelined_steps += 1
+        else:
+            with torch.no_grad():
+                hr_fea = features_for_head(self.net_hr, lr.index_select(1, self._rgb_idx), h16, model=self.net)
         height_pred, build_pred, height_pred_aggre = self.net(lr, hr_fea)
         loss = (self.criterion[0](height_pred.squeeze(1), height, weight)
                 + self.criterion[1](height_pred_aggre.squeeze(1), height_aggre, weight_aggre)
                 + self.criterion[2](build_pred, build, weight))
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        if self._next is not None and self._pf is None:      # (the hook did not fire: no gradient reached HRfeature's first weight)
+            self._pf = self._launch_prefetch(self._next)
+        self._next = None
         sidework.join()           # (the end-of-backward callback already did: a no-op unless that callback was skipped)
         if in_graph and self.world > 1:
             return loss.detach(), height_pred.detach()      # (the collectives and Adam follow each replay: _reduce_and_update)
@@ -507,9 +598,17 @@ def train_epoch(ts, n_tiles, batch, rank, world, device, seed=1337, max_steps=No
         steps = min(steps, max_steps)
     gen = torch.Generator(device=device)
     loss = None
-    for i in range(steps):
+
+    def draw(i):
         gen.manual_seed(seed + 7919 * rank + 104729 * i)
-        loss, _ = ts(synthetic_batch_device(batch, gen, device, aggregate))
+        return synthetic_batch_device(batch, gen, device, aggregate)
+
+    # the batch of step i + 1 is drawn BEFORE step i runs (what a loader's prefetch queue does) so that the pipelined TrainStep can
+    # compute its RRDBNet features beside step i's backward
+    nxt = draw(0) if steps else None
+    for i in range(steps):
+        cur, nxt = nxt, (draw(i + 1) if i + 1 < steps else None)
+        loss, _ = ts(cur, next_batch=nxt)
     return steps, steps * batch * world, loss
 
 

@@ -65,6 +65,8 @@ class SRRegress_Cls_feature(torch.nn.Module):
             return self._forward_impl(x, super_fea)
 
     def _forward_impl(self, x, super_fea):
+        if callable(super_fea) and not torch.is_tensor(super_fea):
+            return self._forward_lr_first(x, super_fea)
         if x.is_cuda and (SIDE_STREAM == "1" or (SIDE_STREAM == "auto" and not torch.is_grad_enabled())):
             return self._forward_two_streams(x, super_fea)
         # Same ops as upstream; only the ISSUE order of the two independent first ops differs under a recorded graph (HRFEAT_FIRST): autograd
@@ -83,6 +85,23 @@ class SRRegress_Cls_feature(torch.nn.Module):
             height_aggre = self._aggre(height_fea)
         height = self.reg(height_fea, super_fea)
         build = self.decoder2(*encode_fea)
+        build = self.seg(build, super_fea)
+        if self.isaggre:
+            return height, build, height_aggre
+        return height, build
+
+    def _forward_lr_first(self, x, super_fea):
+        """Same ops as `forward`, for features that are STILL BEING COMPUTED on another stream (`super_fea` is a handle: calling it makes
+        the current stream wait and returns the tensor; harness.TrainStep's pipelined step).  Everything that does not need them is issued
+        first -- encoder and both decoders, ~400 small kernels -- so that (a) they run beside the trunk kernel, which leaves CUs free for
+        them, and (b) autograd, which runs ready nodes newest-first, runs their backward LAST: the small-kernel chains of one step's end and
+        the next step's start form one window for the next batch's trunk."""
+        encode_fea = self.encoder(x)
+        height_fea = self.decoder1(*encode_fea)
+        height_aggre = self._aggre(height_fea) if self.isaggre else None
+        build = self.decoder2(*encode_fea)
+        super_fea = self.hrfeat(super_fea(), out_h16=HRFEAT_OUT_H16)
+        height = self.reg(height_fea, super_fea)
         build = self.seg(build, super_fea)
         if self.isaggre:
             return height, build, height_aggre

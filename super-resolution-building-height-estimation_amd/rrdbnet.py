@@ -248,8 +248,8 @@ class RRDBNet(nn.Module):
 
     # ---- forward -------------------------------------------------------------------------------
     def _run(self, x, want_forward, out=None, h16=False):
-        if h16 and (want_forward or out is not None or self._use_strict() or (getattr(self, "_train_path", False) and torch.is_grad_enabled())):
-            raise ValueError("forward_feature(out_dtype=float16) is the inference feature path only (no out=, no strict-fp32 mode, no recorded graph)")
+        if h16 and (want_forward or self._use_strict() or (getattr(self, "_train_path", False) and torch.is_grad_enabled())):
+            raise ValueError("forward_feature(out_dtype=float16) is the inference feature path only (no strict-fp32 mode, no recorded graph)")
         if not (torch.is_tensor(x) and x.is_cuda):
             raise RuntimeError("RRDBNet (libsrbh): input must be a ROCm/HIP device tensor; the hot path has no CPU "
                                "fallback (use oracle/ in tests for a CPU comparison)")
@@ -294,14 +294,14 @@ class RRDBNet(nn.Module):
             wcache.keep(self._packed)                    # (a capturing graph owns the layer table + packed weights it bakes in)
             ws = self._workspace(B, H, W, want_forward, x.device)
             cout = self._geom[1] if want_forward else 64
-            if h16:
-                out = torch.empty((B, 64, 4 * H, 4 * W), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
-            elif out is None:
-                out = torch.empty((B, cout, 4 * H, 4 * W), dtype=torch.float32, device=x.device,
-                                  memory_format=torch.channels_last)
-            elif (tuple(out.shape) != (B, cout, 4 * H, 4 * W) or out.dtype != torch.float32 or out.device != x.device
+            odt = torch.float16 if h16 else torch.float32
+            if out is None:
+                out = torch.empty((B, cout, 4 * H, 4 * W), dtype=odt, device=x.device, memory_format=torch.channels_last)
+            elif (tuple(out.shape) != (B, cout, 4 * H, 4 * W) or out.dtype != odt or out.device != x.device
                   or not out.is_contiguous(memory_format=torch.channels_last)):
-                raise ValueError("out= must be a channels_last fp32 (B,%d,%d,%d) tensor on the input's device" % (cout, 4 * H, 4 * W))
+                # (a batch slice of a channels_last tensor is itself channels_last-contiguous: harness.TrainStep's prefetch fills one
+                #  tensor from several launches)
+                raise ValueError("out= must be a channels_last %s (B,%d,%d,%d) tensor on the input's device" % (odt, cout, 4 * H, 4 * W))
             L = _lib.lib()
             _lib.check(L.srbh_rrdbnet_forward(C.byref(desc), x.data_ptr(), out.data_ptr(), B, H, W, 2 if h16 else int(want_forward),
                                               ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "rrdbnet_forward")
