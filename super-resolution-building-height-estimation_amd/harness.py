@@ -390,11 +390,17 @@ class TrainStep:
         with torch.cuda.stream(sT), torch.no_grad():
             x3 = lr.index_select(1, self._rgb_idx)
             B = x3.shape[0]
-            n = -(-B // pipe_images(dev))
+            cap = pipe_images(dev)
+            n = -(-B // cap)
             fea = torch.empty((B, 64, 4 * x3.shape[2], 4 * x3.shape[3]), dtype=torch.float16, device=dev, memory_format=torch.channels_last)
+            # even split, in multiples of 8 images where the cap allows (the trunk's tile map keeps the row blocks of an image on one XCD
+            # when the launch has a multiple of 8 workgroups per row block index, i.e. whole images per XCD: 64 -> 24, 24, 16 under a cap of 24)
+            per = -(-B // n)
+            if cap >= 8:
+                per = min(cap // 8 * 8, -(-per // 8) * 8)
             i = 0
-            for k in range(n):
-                j = i + (B - i + (n - k) - 1) // (n - k)          # even split: 64 -> 22, 21, 21
+            while i < B:
+                j = min(B, i + per)
                 self.net_hr.forward_feature(x3[i:j], out=fea[i:j], out_dtype=torch.float16)
                 i = j
             done = torch.cuda.Event()
@@ -500,7 +506,9 @@ class TrainStep:
         pipe = not in_graph and lr.is_cuda and self._pipe_ok(h16)
         pf, self._pf = self._pf, None
         if pipe and self._next is not None and self._pipe_hook is None:
-            self._pipe_hook = self.net.hrfeat[0].conv1.weight.register_post_accumulate_grad_hook(self._on_head_backward_done)
+            # SRBH_PIPE_AT=reg: the trunk goes out one phase earlier (when backward leaves `reg`, beside HRfeature's backward as well) -- A/B aid
+            first = self.net.reg.fuse[0].conv1.weight if os.environ.get("SRBH_PIPE_AT", "hrfeat") == "reg" else self.net.hrfeat[0].conv1.weight
+            self._pipe_hook = first.register_post_accumulate_grad_hook(self._on_head_backward_done)
         if not pipe:
             self._next = None
         if pf is not None and pipe and pf.matches(lr):

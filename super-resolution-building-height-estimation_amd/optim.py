@@ -23,11 +23,17 @@ _ENTRY = np.dtype([("p", np.uint64), ("g", np.uint64), ("m", np.uint64), ("v", n
 
 
 class Adam(torch.optim.Optimizer):
+    _steps_dirty = False
+    _aux = None
+    _plan = None
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
             raise ValueError("Adam: bad hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self._plan = None          # (key, params, flat m, flat v, host table, device table, device chunk list, nchunks)
+        self._aux = None           # [plan, per-parameter step counts, (lr, wd, n) per group, lr per tensor, wd per tensor]
+        self._steps_dirty = False
         self._t = 0
 
     # ---- the static part: which tensors, where their moments live, the chunk list
@@ -35,12 +41,14 @@ class Adam(torch.optim.Optimizer):
         ps = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
         if not ps:
             return None
-        dev = ps[0].device
-        if dev.type != "cuda" or any(p.device != dev or p.dtype != torch.float32 or not p.is_contiguous() for p in ps):
-            raise NotImplementedError("srbh_amd.optim.Adam: contiguous fp32 parameters on one ROCm device")
         key = tuple((id(p), p.data_ptr(), p.numel()) for p in ps)
         if self._plan is not None and self._plan[0] == key:
             return self._plan
+        dev = ps[0].device
+        if dev.type != "cuda" or any(p.device != dev or p.dtype != torch.float32 or not p.is_contiguous() for p in ps):
+            raise NotImplementedError("srbh_amd.optim.Adam: contiguous fp32 parameters on one ROCm device")
+        self._sync_steps()                                     # (a re-plan adopts state[p]["step"]: bring it up to date first)
+        self._aux = None
         offs, total = [], 0
         for p in ps:
             offs.append(total)
@@ -90,30 +98,37 @@ class Adam(torch.optim.Optimizer):
         eps = self.param_groups[0]["eps"]
         if any(g["betas"] != (b1, b2) or g["eps"] != eps for g in self.param_groups):
             raise NotImplementedError("srbh_amd.optim.Adam: one (betas, eps) for all parameter groups")
-        i = 0
-        any_grad = False
-        bc_cache = {}
-        for g in self.param_groups:
-            lr, wd = float(g["lr"]), float(g["weight_decay"])
-            for p in g["params"]:
-                if not p.requires_grad:
-                    continue
-                gr = p.grad
-                if gr is not None and (gr.dtype != torch.float32 or not gr.is_contiguous() or gr.is_sparse):
+        # The per-step part of the table in array form (this loop is host time in front of the step's last launch: written element by
+        # element through the structured array it took 1.8 ms for SRRegress_Cls_feature's ~700 tensors -- tools/step_boundary_probe.py)
+        aux = self._aux
+        if aux is None or aux[0] is not plan:
+            steps = np.array([float(self.state[p].get("step", 0.0)) for p in ps], dtype=np.float64)
+            aux = self._aux = [plan, steps, None, None, None]
+        steps = aux[1]
+        hp = tuple((float(g["lr"]), float(g["weight_decay"]), sum(1 for p in g["params"] if p.requires_grad)) for g in self.param_groups)
+        if aux[2] != hp:                                   # (lr / weight decay per tensor: rebuilt when a scheduler changes a group)
+            aux[2] = hp
+            aux[3] = np.concatenate([np.full(n, lr, dtype=np.float32) for lr, _, n in hp])
+            aux[4] = np.concatenate([np.full(n, wd, dtype=np.float32) for _, wd, n in hp])
+        ptrs = np.zeros(len(ps), dtype=np.uint64)
+        f32 = torch.float32
+        for i, p in enumerate(ps):
+            gr = p.grad
+            if gr is not None:
+                if gr.dtype is not f32 or gr.is_sparse or not gr.is_contiguous():
                     raise NotImplementedError("srbh_amd.optim.Adam: dense contiguous fp32 gradients")
-                tab["g"][i] = 0 if gr is None else gr.data_ptr()
-                if gr is not None:
-                    st = self.state[p]
-                    t = int(st["step"]) + 1                # torch counts steps PER PARAMETER (one that got no gradient keeps its count)
-                    st["step"] = float(t)                  # (a host number: torch.optim.Adam.__setstate__ turns it into its tensor on load)
-                    bc = bc_cache.get(t)
-                    if bc is None:
-                        bc = bc_cache[t] = (1.0 / (1.0 - b1 ** t), 1.0 / math.sqrt(1.0 - b2 ** t))
-                    tab["lr"][i], tab["wd"][i], tab["inv_bc1"][i], tab["inv_sqrt_bc2"][i] = lr, wd, bc[0], bc[1]
-                    any_grad = True
-                i += 1
-        if not any_grad:
+                ptrs[i] = gr.data_ptr()
+        has = ptrs != 0
+        if not has.any():
             return loss
+        steps[has] += 1.0                                  # torch counts steps PER PARAMETER (one that got no gradient keeps its count)
+        t = np.maximum(steps, 1.0)
+        tab["g"] = ptrs
+        tab["lr"] = aux[3]
+        tab["wd"] = aux[4]
+        tab["inv_bc1"] = (1.0 / (1.0 - np.power(b1, t))).astype(np.float32)
+        tab["inv_sqrt_bc2"] = (1.0 / np.sqrt(1.0 - np.power(b2, t))).astype(np.float32)
+        self._steps_dirty = True                           # (state[p]["step"] is brought up to date when somebody looks: _sync_steps)
         self._t += 1
         dtab.copy_(host, non_blocking=True)               # (pinned -> device on the current stream, in front of the launch)
         ev = torch.cuda.Event()
@@ -124,12 +139,41 @@ class Adam(torch.optim.Optimizer):
         wcache.stamp(ps)                                   # weights changed behind the version counters (packed-weight caches, wcache.py)
         return loss
 
+    def _sync_steps(self):
+        """per-parameter step counts live in one array between steps; `state[p]["step"]` (torch's layout) is refreshed when somebody looks
+        (the `state` property below: `optimizer.state[p]`, `state_dict()`, a re-plan)"""
+        aux = getattr(self, "_aux", None)
+        dirty, self._steps_dirty = getattr(self, "_steps_dirty", False), False
+        if dirty and aux is not None and self._plan is not None and aux[0] is self._plan:
+            st = self._state
+            for p, t in zip(self._plan[1], aux[1]):
+                st[p]["step"] = float(t)                   # (a host number: torch.optim.Adam.__setstate__ turns it into its tensor on load)
+
+    @property
+    def state(self):
+        if self._steps_dirty:
+            self._sync_steps()
+        return self._state
+
+    @state.setter
+    def state(self, value):
+        self._state = value
+
+    def __setstate__(self, state):
+        super().__setstate__(state)                        # (torch updates __dict__ directly: move a loaded 'state' behind the property)
+        if "state" in self.__dict__:
+            self._state = self.__dict__.pop("state")
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        self._aux, self._steps_dirty = None, False
         self._plan = None                                  # the loaded moments are adopted into fresh flat buffers at the next step
         steps = [int(s["step"]) for s in self.state.values() if "step" in s]
         self._t = max(steps) if steps else 0
 
     def add_param_group(self, param_group):
+        if getattr(self, "_plan", None) is not None:
+            self._sync_steps()
         super().add_param_group(param_group)
+        self._aux = None
         self._plan = None

@@ -1,0 +1,3 @@
+#!/bin/bash
+export TMPDIR=/tmp O=gpurun_out
+timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
