@@ -261,10 +261,10 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
     torch.cuda.synchronize()
     exposed = []
     t0 = time.perf_counter()
+    p0 = ts.pipelined_steps
     if epoch_tiles:
         steps, tiles, loss = train_epoch(ts, epoch_tiles, batch, rank, world, dev)
     else:
-        p0 = ts.pipelined_steps
         for _ in range(steps):
             loss, _ = ts(fixed, next_batch=fixed if pipe else None)
             if ts.reducer is not None:
@@ -317,7 +317,7 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
                                    f"dp{world} (bucketed RCCL grad all-reduce launched from autograd hooks)") if world > 1 else
                    ("1 GPU, the whole step replayed as one HIP graph" if use_graph else "1 GPU, eager launches"),
                    "pipeline": (f"RRDBNet features of batch k+1 on a second stream beside step k's encoder / decoder phases, {_pipe_images(dev)} images "
-                                f"per trunk launch ({ts.pipelined_steps - p0 if not epoch_tiles else ts.pipelined_steps} of the {steps} timed steps consumed prefetched features; "
+                                f"per trunk launch ({ts.pipelined_steps - p0} of the {steps} timed steps consumed prefetched features; "
                                 "one full trunk pass inside every timed step)") if pipe and ts.pipelined_steps else "none (serial step)"},
         "whole_step": {"gflop_per_tile": gf_tile, "achieved_tflops": round(gf_tile * tiles / elapsed / 1e3, 2),
                        "note": "mixes the MFMA-bound trunk with the HBM-bound head: not a roofline, see `kernels`"},

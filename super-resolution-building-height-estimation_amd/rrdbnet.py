@@ -463,17 +463,19 @@ class RealESRGAN:
         self.schedulers = [torch.optim.lr_scheduler.MultiStepLR(o, milestones=[400000], gamma=0.5) for o in self.optimizers]
 
     def save(self, epoch, current_iter, respath):
+        """checkpoint envelopes of SR/rrdbnet_arch.py:623-633: net_g.tar {params, params_ema, epoch, current_iter}, net_d.tar {params, ...}"""
         import os
-        torch.save({"params": self.net_g.state_dict(),
-                    "params_ema": self.net_g_ema.state_dict() if hasattr(self, "net_g_ema") else None,
-                    "epoch": epoch, "current_iter": current_iter}, os.path.join(respath, "net_g.tar"))
-        torch.save({"params": self.net_d.state_dict(), "epoch": epoch, "current_iter": current_iter},
-                   os.path.join(respath, "net_d.tar"))
+        stamp = {"epoch": epoch, "current_iter": current_iter}
+        ema = getattr(self, "net_g_ema", None)
+        files = {"net_g.tar": {"params": self.net_g.state_dict(), "params_ema": None if ema is None else ema.state_dict()},
+                 "net_d.tar": {"params": self.net_d.state_dict()}}
+        for name, payload in files.items():
+            torch.save({**payload, **stamp}, os.path.join(respath, name))
 
     @torch.no_grad()
     def feed_data(self, data):
-        self.lq = data["lq"].to(self.device, non_blocking=True)
-        self.gt = data["gt"].to(self.device, non_blocking=True)
+        """SR/rrdbnet_arch.py:511-519: the batch on the device, plus the unsharp-masked target the pixel / perceptual terms compare against"""
+        self.lq, self.gt = (data[k].to(self.device, non_blocking=True) for k in ("lq", "gt"))
         self.gt_usm = self.usm_sharpener(self.gt)
 
     @torch.no_grad()
@@ -489,44 +491,43 @@ class RealESRGAN:
         wcache.stamp(ema.values())
 
     def optimize_parameters(self):
-        """one generator step + one discriminator step (SR/rrdbnet_arch.py:538-592)"""
-        from collections import OrderedDict as _OD
-        l1_gt = percep_gt = self.gt_usm
-        gan_gt = self.gt
-        for p in self.net_d.parameters():
-            p.requires_grad = False
-        self.optimizer_g.zero_grad()
-        self.output = self.net_g(self.lq)
-        loss_dict = _OD()
-        l_g_pix = self.cri_pix(self.output, l1_gt)
-        l_g_total = l_g_pix
-        loss_dict["l_g_pix"] = l_g_pix.item()
+        """One generator update, then one discriminator update (the protocol of SR/rrdbnet_arch.py:538-592; returns its `loss_dict`).
+        Both are the same procedure over a table of loss terms: set which network trains, zero its optimizer, evaluate every group of
+        terms (a group = one backward pass over the sum of its terms), step.  Generator terms: L1 to the sharpened target, the optional
+        perceptual plug-in, the GAN term through the FROZEN discriminator; discriminator terms: real target, then the detached output."""
+        from collections import OrderedDict
+        log = OrderedDict()
+
+        def update(optimizer, train_d, groups):
+            self.net_d.requires_grad_(train_d)
+            optimizer.zero_grad()
+            for group in groups:
+                total = 0.0
+                for key, term in group:
+                    value, extra = term()
+                    log[key] = value.item()
+                    log.update(extra)
+                    total = total + value
+                total.backward()
+            optimizer.step()
+
+        out = self.output = self.net_g(self.lq)
+        gen = [("l_g_pix", lambda: (self.cri_pix(out, self.gt_usm), {}))]
         if self.cri_perceptual is not None:
-            l_g_percep = self.cri_perceptual(self.output, percep_gt)
-            l_g_total = l_g_total + l_g_percep
-            loss_dict["l_g_percep"] = l_g_percep.item()
-        l_g_gan = self.cri_gan(self.net_d(self.output), True, is_disc=False)
-        l_g_total = l_g_total + l_g_gan
-        loss_dict["l_g_gan"] = l_g_gan.item()
-        l_g_total.backward()
-        self.optimizer_g.step()
-        for p in self.net_d.parameters():
-            p.requires_grad = True
-        self.optimizer_d.zero_grad()
-        real_d_pred = self.net_d(gan_gt)
-        l_d_real = self.cri_gan(real_d_pred, True, is_disc=True)
-        loss_dict["l_d_real"] = l_d_real.item()
-        loss_dict["out_d_real"] = torch.mean(real_d_pred.detach())
-        l_d_real.backward()
-        fake_d_pred = self.net_d(self.output.detach().clone())
-        l_d_fake = self.cri_gan(fake_d_pred, False, is_disc=True)
-        loss_dict["l_d_fake"] = l_d_fake.item()
-        loss_dict["out_d_fake"] = torch.mean(fake_d_pred.detach())
-        l_d_fake.backward()
-        self.optimizer_d.step()
+            gen.append(("l_g_percep", lambda: (self.cri_perceptual(out, self.gt_usm), {})))
+        gen.append(("l_g_gan", lambda: (self.cri_gan(self.net_d(out), True, is_disc=False), {})))
+        update(self.optimizer_g, False, [gen])
+
+        def judged(x, real, tag):
+            def term():
+                pred = self.net_d(x)
+                return self.cri_gan(pred, real, is_disc=True), {f"out_d_{tag}": pred.detach().mean()}
+            return [(f"l_d_{tag}", term)]
+
+        update(self.optimizer_d, True, [judged(self.gt, True, "real"), judged(out.detach().clone(), False, "fake")])
         if self.ema_decay > 0:
             self.model_ema(decay=self.ema_decay)
-        return loss_dict
+        return log
 
     def update_learning_rate(self, current_iter, warmup_iter=-1):
         if current_iter >= 0:

@@ -131,6 +131,20 @@ def test_training_convs_exact_against_float64(cin, cout, hw):
 
 
 @pytest.mark.gpu
+def test_discriminator_on_the_device_matches_the_reference_fixture(golden_dir):
+    """UNetDiscriminatorSN (SR/rrdbnet_arch.py:244-303) as the SR-stage trainer runs it -- on the ROCm device -- against the output the
+    imported reference produced on the CPU (g14 `disc_out`): forward <= 1e-5, and its loss-dict protocol keys in the reference's order."""
+    from srbh_amd.srgan import UNetDiscriminatorSN
+    g = _g14(golden_dir)
+    d = UNetDiscriminatorSN(3, num_feat=8, skip_connection=True).eval()
+    d.load_state_dict({k[len("disc_sd_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("disc_sd_")}, strict=True)
+    d = d.to("cuda:0")
+    with torch.no_grad():
+        y = d(rand((2, 3, 32, 32), 143, 0.0, 1.0).to("cuda:0"))
+    assert O.rel_l2(y.cpu(), torch.from_numpy(g["disc_out"])) <= 1e-5
+
+
+@pytest.mark.gpu
 def test_realesrgan_training_step_runs_and_learns():
     """RealESRGAN(is_train=True) (reference SR/rrdbnet_arch.py:437-592): feed_data -> optimize_parameters for a few iterations on
     one synthetic LR/HR pair: the pixel loss goes down, the EMA copy moves, the discriminator trains, save() writes both nets."""
@@ -148,7 +162,7 @@ def test_realesrgan_training_step_runs_and_learns():
         ld = m.optimize_parameters()
         m.update_learning_rate(it)
         losses.append(ld["l_g_pix"])
-        assert "l_g_gan" in ld and "l_d_real" in ld and "l_d_fake" in ld and "l_g_percep" not in ld
+        assert list(ld) == ["l_g_pix", "l_g_gan", "l_d_real", "out_d_real", "l_d_fake", "out_d_fake"]     # (the reference's keys, its order; no perceptual plug-in)
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
     assert not torch.equal(m.net_g_ema.conv_first.weight, ema0)
     with tempfile.TemporaryDirectory() as td:

@@ -9,7 +9,9 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-bounds = [i for i, r in enumerate(rows) if "conv_first_kernel" in r[2]]           # exactly one per RRDBNet forward = per step
+bounds = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]                   # a training step ends with libsrbh's one Adam launch
+if len(bounds) < 2:                                                                  # (other workloads: one conv_first per RRDBNet forward -- the pipelined training step has several)
+    bounds = [i for i, r in enumerate(rows) if "conv_first_kernel" in r[2]]
 start = bounds[-n - 1] if len(bounds) > n else bounds[0]
 end = bounds[-1]
 sel = rows[start:end]
