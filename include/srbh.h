@@ -383,6 +383,15 @@ typedef struct srbh_hbwd16_args {
 } srbh_hbwd16_args;
 int srbh_hbwd16_supported(int H, int W);
 int srbh_hbwd16(const srbh_hbwd16_args* a, void* stream);
+
+/* Deferred weight-gradient reduces (round 5; hrfuse_autograd._BlockChainFn.backward).  The reference gets dW from torch autograd
+ * (train.py:254-256); nothing reads it before the optimizer / the gradient all-reduce, so the ordered reduce of the per-workgroup partial sums
+ * need not sit between the chip-filling kernels of the head's backward.  Between srbh_hwgrad_defer(1) and srbh_hwgrad_flush the entry points
+ * srbh_hconv_wgrad_f32 / _b16 / _entry_b16 and srbh_hbwd16 launch their kernels but QUEUE that reduce (host thread local, any number of
+ * jobs); srbh_hwgrad_flush(stream) runs all queued reduces as one pair of launches (same order of additions per element) and ends the
+ * deferral.  The caller keeps every `ws` / `dw` of a queued job alive until the flush. */
+int srbh_hwgrad_defer(int on);
+int srbh_hwgrad_flush(void* stream);
 /* out = g where ref > 0 else 0   (ReLU backward with the saved output, SR/HRfuse.py:157) */
 int srbh_relu_mask_mul(const float* g, const float* ref, float* out, long n, void* stream);
 int srbh_add_inplace(float* a, const float* b, long n, void* stream);

@@ -211,6 +211,8 @@ SIGNATURES = {
     "srbh_adam_step": (_i, [_vp, _vp, _i, C.c_double, C.c_double, C.c_double, _vp]),
     "srbh_hbwd16_supported": (_i, [_i, _i]),
     "srbh_hbwd16": (_i, [C.POINTER(HBwd16Args), _vp]),
+    "srbh_hwgrad_defer": (_i, [_i]),
+    "srbh_hwgrad_flush": (_i, [_vp]),
     "srbh_relu_mask_mul": (_i, [_vp, _vp, _vp, C.c_long, _vp]),
     "srbh_add_inplace": (_i, [_vp, _vp, C.c_long, _vp]),
     "srbh_bn_bwd_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_long, _i, _vp, _vp]),

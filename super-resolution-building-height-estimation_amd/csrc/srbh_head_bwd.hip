@@ -12,6 +12,8 @@
 #include "srbh_internal.h"
 
 #include <type_traits>
+#include <vector>
+#include <algorithm>
 
 namespace {
 using namespace srbh;
@@ -983,6 +985,85 @@ __global__ void hwgrad_reduce2_kernel(const float* __restrict__ tmp, float* __re
     dw[idx] = v;
 }
 
+// ---- the same two stages for SEVERAL weight gradients in one launch each (round 5).  The partial sums of a weight gradient are not needed
+// before the optimizer (or a gradient all-reduce) reads dW, so the producers of one autograd node's backward can queue their reduce jobs
+// (srbh_hwgrad_defer) and ONE pair of launches does them all (srbh_hwgrad_flush): in the training step these 2 x 28 launches of ~6 us each sat
+// between the chip-filling kernels of the head's backward.  Same order of additions per element as the per-gradient kernels.
+struct RedJob {
+    const float* ws; float* tmp; float* dw;
+    long U;
+    int gx, nchunk, taps, cout, cin, per;
+};
+constexpr int RED_MAX = 24;
+struct RedMany { RedJob j[RED_MAX]; int n; };
+__global__ __launch_bounds__(256) void hwgrad_reduce1_many_kernel(const RedMany m) {
+    const RedJob& J = m.j[blockIdx.z];
+    const long u = (long)blockIdx.x * 256 + threadIdx.x;
+    if (u >= J.U) return;
+    const int x0 = blockIdx.y * J.per;
+    const int x1 = x0 + J.per < J.gx ? x0 + J.per : J.gx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int x = x0;
+    for (; x + 3 < x1; x += 4) {
+        a0 += J.ws[(long)x * J.U + u];
+        a1 += J.ws[(long)(x + 1) * J.U + u];
+        a2 += J.ws[(long)(x + 2) * J.U + u];
+        a3 += J.ws[(long)(x + 3) * J.U + u];
+    }
+    for (; x < x1; ++x) a0 += J.ws[(long)x * J.U + u];
+    J.tmp[(long)blockIdx.y * J.U + u] = (a0 + a1) + (a2 + a3);
+}
+__global__ __launch_bounds__(256) void hwgrad_reduce2_many_kernel(const RedMany m, int slices) {
+    const RedJob& J = m.j[blockIdx.y];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int total = J.cout * J.cin * J.taps;
+    if (idx >= total) return;
+    const int tp = idx % J.taps;
+    const int ci = (idx / J.taps) % J.cin;
+    const int oc = idx / (J.taps * J.cin);
+    const long u = ((long)(oc >> 4) * J.nchunk + (ci >> 4)) * (J.taps * 256) + tp * 256 + (oc & 15) * 16 + (ci & 15);
+    float v = 0.f;
+    for (int sidx = 0; sidx < slices; ++sidx) v += J.tmp[(long)sidx * J.U + u];
+    J.dw[idx] = v;
+}
+constexpr int RED_SLICES = 16;
+thread_local bool g_red_defer = false;
+thread_local std::vector<RedJob> g_red_queue;
+int reduce_flush(hipStream_t st) {
+    for (size_t b = 0; b < g_red_queue.size(); b += RED_MAX) {
+        RedMany m = {};
+        m.n = (int)std::min<size_t>(RED_MAX, g_red_queue.size() - b);
+        long umax = 0;
+        int tmax = 0;
+        for (int k = 0; k < m.n; ++k) {
+            m.j[k] = g_red_queue[b + k];
+            umax = std::max(umax, m.j[k].U);
+            tmax = std::max(tmax, m.j[k].cout * m.j[k].cin * m.j[k].taps);
+        }
+        hipLaunchKernelGGL(hwgrad_reduce1_many_kernel, dim3((unsigned)((umax + 255) / 256), RED_SLICES, m.n), dim3(256), 0, st, m);
+        SRBH_HIP(hipGetLastError());
+        hipLaunchKernelGGL(hwgrad_reduce2_many_kernel, dim3((tmax + 255) / 256, m.n), dim3(256), 0, st, m, RED_SLICES);
+        SRBH_HIP(hipGetLastError());
+    }
+    g_red_queue.clear();
+    return SRBH_OK;
+}
+// the two-stage ordered reduce of one weight gradient: now, or queued for srbh_hwgrad_flush
+int reduce_partials(const float* ws, float* dw, long U, int gx, int nchunk, int taps, int cout, int cin, hipStream_t st) {
+    float* tmp = (float*)ws + (long)WS_SLOTS * U;
+    const int per = (gx + RED_SLICES - 1) / RED_SLICES;
+    if (g_red_defer) {
+        g_red_queue.push_back(RedJob{ws, tmp, dw, U, gx, nchunk, taps, cout, cin, per});
+        return SRBH_OK;
+    }
+    hipLaunchKernelGGL(hwgrad_reduce1_kernel, dim3((unsigned)((U + 255) / 256), RED_SLICES), dim3(256), 0, st, ws, tmp, U, gx, per);
+    SRBH_HIP(hipGetLastError());
+    const int total = cout * cin * taps;
+    hipLaunchKernelGGL(hwgrad_reduce2_kernel, dim3((total + 255) / 256), dim3(256), 0, st, tmp, dw, U, RED_SLICES, nchunk, taps, cout, cin);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
 // one-stage form for few partial slots (gx <= 128: small batches, where the two-stage form is two launch latencies for 28 MB of L2 reads):
 // dw[oc][ci][tap] = sum over x = 0 .. gx-1 of ws[x][u], in that fixed order
 __global__ void hwgrad_reduce_direct_kernel(const float* __restrict__ ws, float* __restrict__ dw, long U, int gx, int nchunk, int taps, int cout,
@@ -1340,17 +1421,9 @@ int wgrad_impl(const srbh_hwgrad_args* a, void* stream, bool b16, const char* wh
         hipLaunchKernelGGL(hwgrad_f32_kernel<1>, dim3(gx, nob), dim3(256), LDS_B, st, p);
     }
     SRBH_HIP(hipGetLastError());
-    constexpr int SLICES = 16;
     const int taps = a->ksize * a->ksize, nchunk = (cin + 15) / 16;
     const long U = (long)nob * nchunk * taps * 256;
-    float* tmp = a->ws + (long)WS_SLOTS * U;
-    const int per = (gx + SLICES - 1) / SLICES;
-    hipLaunchKernelGGL(hwgrad_reduce1_kernel, dim3((unsigned)((U + 255) / 256), SLICES), dim3(256), 0, st, a->ws, tmp, U, gx, per);
-    SRBH_HIP(hipGetLastError());
-    const int total = a->cout * cin * taps;
-    hipLaunchKernelGGL(hwgrad_reduce2_kernel, dim3((total + 255) / 256), dim3(256), 0, st, tmp, a->dw, U, SLICES, nchunk, taps, a->cout, cin);
-    SRBH_HIP(hipGetLastError());
-    return SRBH_OK;
+    return reduce_partials(a->ws, a->dw, U, gx, nchunk, taps, a->cout, cin, st);
 }
 }  // namespace
 
@@ -1419,18 +1492,11 @@ extern "C" int srbh_hconv_wgrad_entry_b16(const srbh_hwgrad_args* a3, const srbh
         hipLaunchKernelGGL((hwgrad_b16_kernel<3, 0, 0, 1>), dim3(gx, nob), dim3(256), WG16<3>::LDS_B2, st, p);
     }
     SRBH_HIP(hipGetLastError());
-    constexpr int SLICES = 16;
-    const int per = (gx + SLICES - 1) / SLICES;
     for (int k = 0; k < 2; ++k) {           // the two ordered reduces (3x3, then 1x1): as behind the separate calls
         const int taps = k == 0 ? 9 : 1;
         const srbh_hwgrad_args* a = k == 0 ? a3 : a1;
         const long U = (long)nob * nchunk * taps * 256;
-        float* tmp = a->ws + (long)WS_SLOTS * U;
-        hipLaunchKernelGGL(hwgrad_reduce1_kernel, dim3((unsigned)((U + 255) / 256), SLICES), dim3(256), 0, st, a->ws, tmp, U, gx, per);
-        SRBH_HIP(hipGetLastError());
-        const int total = a->cout * cin * taps;
-        hipLaunchKernelGGL(hwgrad_reduce2_kernel, dim3((total + 255) / 256), dim3(256), 0, st, tmp, a->dw, U, SLICES, nchunk, taps, a->cout, cin);
-        SRBH_HIP(hipGetLastError());
+        if (int rc = reduce_partials(a->ws, a->dw, U, gx, nchunk, taps, a->cout, cin, st)) return rc;
     }
     return SRBH_OK;
 }
@@ -1542,16 +1608,21 @@ extern "C" int srbh_hbwd16(const srbh_hbwd16_args* a, void* stream) {
 #undef SRBH_HB
     SRBH_HIP(hipGetLastError());
     count_path(PATH_HBWD16);
-    // the workgroups' weight-gradient partials -> dW (the ordered two-stage reduce of srbh_hconv_wgrad_b16)
-    constexpr int SLICES = 16;
-    const long U = 9 * 256;
-    float* tmp = a->ws + (long)WS_SLOTS * U;
-    const int per = (gx + SLICES - 1) / SLICES;
-    hipLaunchKernelGGL(hwgrad_reduce1_kernel, dim3((unsigned)((U + 255) / 256), SLICES), dim3(256), 0, st, a->ws, tmp, U, gx, per);
-    SRBH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(hwgrad_reduce2_kernel, dim3((16 * 16 * 9 + 255) / 256), dim3(256), 0, st, tmp, a->dw, U, SLICES, 1, 9, 16, 16);
-    SRBH_HIP(hipGetLastError());
+    // the workgroups' weight-gradient partials -> dW (the ordered two-stage reduce of srbh_hconv_wgrad_b16; queued under srbh_hwgrad_defer)
+    return reduce_partials(a->ws, a->dw, 9 * 256, gx, 1, 9, 16, 16, st);
+}
+
+/* Between srbh_hwgrad_defer(1) and srbh_hwgrad_flush the weight-gradient entry points above (srbh_hconv_wgrad_f32 / _b16 / _entry_b16,
+ * srbh_hbwd16) run their kernels but QUEUE the ordered reduce of their partial sums; srbh_hwgrad_flush does every queued reduce in one pair
+ * of launches and ends the deferral.  The caller keeps every `ws` (and `dw`) alive until the flush.  Per host thread. */
+extern "C" int srbh_hwgrad_defer(int on) {
+    SRBH_REQUIRE(on || g_red_queue.empty(), "srbh_hwgrad_defer(0) with queued reduce jobs: call srbh_hwgrad_flush");
+    g_red_defer = on != 0;
     return SRBH_OK;
+}
+extern "C" int srbh_hwgrad_flush(void* stream) {
+    g_red_defer = false;
+    return reduce_flush((hipStream_t)stream);
 }
 
 extern "C" size_t srbh_hwgrad_ws_bytes(int cout, int cin, int ksize) {

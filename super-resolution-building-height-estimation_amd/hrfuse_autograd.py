@@ -100,6 +100,39 @@ def conv_dgrad(g, weight, cache: _PackedGrad, res=None, out_b16=False, res_ld=0,
     return _hconv_raw([g], cache.get(weight, h16, gen_src), None, cin, ks, res=res, h16=h16, out_b16=out_b16 and h16, res_ld=res_ld, bstat=bstat)
 
 
+# ---- deferred weight-gradient reduces (srbh_hwgrad_defer / srbh_hwgrad_flush, include/srbh.h): inside `deferred_wgrad_reduces()` every
+# weight-gradient call of this module queues the ordered reduce of its partial sums, and leaving the block runs all of them as ONE pair of
+# launches.  The workspaces of queued jobs are kept alive here until then (torch's stream-ordered allocator would hand a freed one to the
+# next kernel in front of the deferred reduce).  SRBH_WGRAD_DEFER=0: every call reduces at once (A/B aid).
+WGRAD_DEFER = __import__("os").environ.get("SRBH_WGRAD_DEFER", "1") == "1"
+_DEFER_KEEP = []
+_DEFER_DEPTH = [0]
+
+
+class deferred_wgrad_reduces:
+    def __enter__(self):
+        if WGRAD_DEFER:
+            if _DEFER_DEPTH[0] == 0:
+                _lib.check(_lib.lib().srbh_hwgrad_defer(1), "hwgrad_defer")
+            _DEFER_DEPTH[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        if WGRAD_DEFER:
+            _DEFER_DEPTH[0] -= 1
+            if _DEFER_DEPTH[0] == 0:
+                try:
+                    _lib.check(_lib.lib().srbh_hwgrad_flush(_lib.stream_ptr()), "hwgrad_flush")
+                finally:
+                    _DEFER_KEEP.clear()
+        return False
+
+
+def _keep_ws(*ts):
+    if _DEFER_DEPTH[0]:
+        _DEFER_KEEP.extend(ts)
+
+
 def _wgrad_args(srcs, pre, g, cout, ks):
     L = _lib.lib()
     x0 = srcs[0]
@@ -118,6 +151,7 @@ def _wgrad_args(srcs, pre, g, cout, ks):
     ws = torch.empty(L.srbh_hwgrad_ws_bytes(cout, c0 + c1, ks) // 4, dtype=torch.float32, device=x0.device)
     a.ws = ws.data_ptr()
     a.io = (1 if x0.dtype == torch.float16 else 0) | (2 if g.dtype == torch.bfloat16 else 0)
+    _keep_ws(ws, dw)
     return a, dw, ws
 
 
@@ -195,6 +229,7 @@ def hbwd16(g, c, mean, invstd, consts, mask, x, pre, weight, cache, res=None, ou
     dw = torch.empty((16, 16, 3, 3), dtype=torch.float32, device=dev)
     ws = torch.empty(L.srbh_hwgrad_ws_bytes(16, 16, 3) // 4, dtype=torch.float32, device=dev)
     a.dw, a.ws = dw.data_ptr(), ws.data_ptr()
+    _keep_ws(ws, dw)
     _lib.check(L.srbh_hbwd16(C.byref(a), _lib.stream_ptr()), "hbwd16")
     return dx, dw
 
@@ -376,7 +411,8 @@ class _BasicBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return _bb_backward(ctx, g)
+        with deferred_wgrad_reduces():
+            return _bb_backward(ctx, g)
 
 
 class _Handoff:
@@ -580,14 +616,15 @@ class _BlockChainFn(torch.autograd.Function):
         subs = ctx.subs
         pgrads = [None] * len(subs)
         handoff, dx0, dx1 = None, None, None
-        for k in range(len(subs) - 1, -1, -1):
-            r = _bb_backward(subs[k], None if handoff is not None else g, handoff=handoff, prev=subs[k - 1] if k > 0 else None)
-            pgrads[k] = list(r[3:3 + ctx.counts[k]])
-            if isinstance(r[1], _Handoff):
-                handoff, g = r[1], None
-            else:
-                handoff, g = None, r[1]
-            dx0, dx1 = r[1], r[2]
+        with deferred_wgrad_reduces():           # the ~7 weight gradients of the chain reduce their partial sums in one pair of launches at the end
+            for k in range(len(subs) - 1, -1, -1):
+                r = _bb_backward(subs[k], None if handoff is not None else g, handoff=handoff, prev=subs[k - 1] if k > 0 else None)
+                pgrads[k] = list(r[3:3 + ctx.counts[k]])
+                if isinstance(r[1], _Handoff):
+                    handoff, g = r[1], None
+                else:
+                    handoff, g = None, r[1]
+                dx0, dx1 = r[1], r[2]
         flat = [t for pg in pgrads for t in pg]
         return (None, dx0, dx1, *flat)
 

@@ -31,6 +31,7 @@ SIDE_STREAM = _os.environ.get("SRBH_SIDE_STREAM", "auto")
 HRFEAT_OUT_H16 = _os.environ.get("SRBH_HRFEAT_OUT_H16", "1") == "1"
 # training: issue hrfeat before the encoder (their backward order is then encoder -> hrfeat; see _forward_impl).  0 = upstream's issue order (A/B aid)
 HRFEAT_FIRST = _os.environ.get("SRBH_HRFEAT_FIRST", "1") == "1"
+DEC2_SIDE = _os.environ.get("SRBH_DEC2_SIDE", "0") == "1"       # pipelined step: decoder2 on its own stream beside decoder1 (A/B aid, see _forward_lr_first)
 
 
 class SRRegress_Cls_feature(torch.nn.Module):
@@ -97,9 +98,27 @@ class SRRegress_Cls_feature(torch.nn.Module):
         them, and (b) autograd, which runs ready nodes newest-first, runs their backward LAST: the small-kernel chains of one step's end and
         the next step's start form one window for the next batch's trunk."""
         encode_fea = self.encoder(x)
-        height_fea = self.decoder1(*encode_fea)
-        height_aggre = self._aggre(height_fea) if self.isaggre else None
-        build = self.decoder2(*encode_fea)
+        if DEC2_SIDE and x.is_cuda:
+            # the two decoders read the same features and are independent chains of small kernels: the second one on its own stream
+            # (autograd replays each op's backward on the stream its forward ran on: their backward overlaps the same way)
+            cur = torch.cuda.current_stream(x.device)
+            side = self.__dict__.get("_dec2_stream")
+            if side is None or side.device != x.device:
+                side = self.__dict__["_dec2_stream"] = torch.cuda.Stream(device=x.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                build = self.decoder2(*encode_fea)
+            for t in encode_fea:
+                if torch.is_tensor(t):
+                    t.record_stream(side)
+            height_fea = self.decoder1(*encode_fea)
+            height_aggre = self._aggre(height_fea) if self.isaggre else None
+            cur.wait_stream(side)
+            build.record_stream(cur)
+        else:
+            height_fea = self.decoder1(*encode_fea)
+            height_aggre = self._aggre(height_fea) if self.isaggre else None
+            build = self.decoder2(*encode_fea)
         super_fea = self.hrfeat(super_fea(), out_h16=HRFEAT_OUT_H16)
         height = self.reg(height_fea, super_fea)
         build = self.seg(build, super_fea)

@@ -155,3 +155,43 @@ def test_block_chain_handoff_equals_one_node_per_block(monkeypatch):
         for u, v in zip(out[mode], out["nodes"]):
             assert _rel(u, v) <= 2e-3, (mode, _rel(u, v))
     assert torch.equal(out["chain"][0], out["nodes"][0])          # the forward is the same launches
+
+
+def test_deferred_weight_gradient_reduces_equal_the_immediate_ones():
+    """srbh_hwgrad_defer / srbh_hwgrad_flush: several weight gradients (the generic bf16 kernel at 3x3 and 1x1, the fused entry pair,
+    srbh_hbwd16) queue their ordered reduce and ONE pair of launches does them all: every dW bit-identical to the call that reduces at once
+    (same kernels, same order of additions), workspaces kept alive until the flush."""
+    from srbh_amd import hrfuse as H
+    from srbh_amd import hrfuse_autograd as HA
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(5)
+    nh = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)      # noqa: E731
+    B, Hh, Ww = 2, 64, 64
+    x32 = nh(torch.randn((B, 32, Hh, Ww), generator=g))
+    x16 = nh(torch.randn((B, 16, Hh, Ww), generator=g))
+    c = nh(torch.randn((B, 16, Hh, Ww), generator=g))
+    dy = nh(torch.randn((B, 16, Hh, Ww), generator=g) * 1e-2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    v = lambda s=1.0: (torch.rand(16, generator=g) * s + 0.5).to(dev)          # noqa: E731
+    mean, invstd, consts = v(), v(), (v(), v(1e-5), v(1e-5))
+    w = (torch.randn((16, 16, 3, 3), generator=g) * 0.1).to(dev)
+
+    def all_grads():
+        pg = HA._PackedGrad()
+        out = [HA.conv_wgrad([x32], None, dy, 16, 3), HA.conv_wgrad([x32], None, dy, 16, 1)]
+        out += list(HA.conv_wgrad_entry([x32], dy, dy, 16))
+        out.append(HA.hbwd16(dy, c, mean, invstd, consts, None, x16, None, w, pg, out_b16=True)[1])
+        out.append(HA.conv_wgrad([x16], None, dy, 16, 3))
+        return out
+
+    with H.head_precision("f16"), torch.no_grad():
+        now = all_grads()
+        torch.cuda.synchronize()
+        with HA.deferred_wgrad_reduces():
+            later = all_grads()
+            # (allocations between the calls and the flush must not disturb the queued partial sums)
+            junk = [torch.full((1 << 20,), float("nan"), device=dev) for _ in range(8)]
+        torch.cuda.synchronize()
+        del junk
+    assert len(now) == len(later) == 6 and not HA._DEFER_KEEP and HA._DEFER_DEPTH[0] == 0
+    for a, b in zip(now, later):
+        assert a.shape == b.shape and bool(torch.isfinite(b).all()) and torch.equal(a, b)
