@@ -108,6 +108,17 @@
 // (profiles/r05x_ab_ctap.txt); the ISA has the 96 reads less and 8 more v_mov; bit-identical.
 #define P3_CTAP 0
 #endif
+#ifndef P3_R2LDS
+// 1 (round 5): the RRDB-closing epilogue (every third RDB: x = 0.2 x + x_rrdb, the RRDB-level fp32 stream lives in memory, 128 KiB per
+// workgroup) fetches three of its four rows by LDS-DMA at the START of the epilogue into LDS nobody reads at that point (the stage the last
+// step read + the unused tail of the other one: 96 KiB of [IN_EX + 18 KiB, B_BIAS_OFF) and one 1 KiB unit behind the bias), the fourth into
+// registers as before: all 32 KiB x 4 are in flight at once under the first pass instead of two rows ahead with two exposed latencies
+// (12.5 k cycles per RRDB-closing epilogue against 4.9 k for a plain one).  Costs one more workgroup barrier per RRDB.  Same arithmetic.
+// MEASURED SLOWER, default off (profiles/r05an_ab_r2lds.txt): 3.743 / 3.746 ms without, 3.803 / 3.819 with -- the RRDB-closing epilogue
+// takes 16.6 k cycles instead of 12.6 k (one wait for 32 KiB x 4 in flight is not shorter than two rows ahead: the burst of all 256
+// workgroups is bandwidth-bound either way) and the PLAIN epilogue 6.8 k instead of 5.0 k (24 spilled VGPRs at the kernel's pressure peak).
+#define P3_R2LDS 0
+#endif
 #ifndef P3_PRE_AT
 #define P3_PRE_AT 2
 #endif
@@ -729,6 +740,38 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         // up.  (Loading each row pair right before its use cost 17 k cycles per RRDB-closing epilogue against 3.6 k for a plain
         // one: two fully exposed memory latencies plus a wasted fp16 pass.)
         floatx4 a2[2][2][4];
+        // P3_R2LDS: where the 1 KiB unit k (= instruction (mb, g)) of row slot s of THIS wave sits in LDS
+        constexpr int R2_BASE = IN_EX + 18 * 1024, R2_UNITS = (B_BIAS_OFF - R2_BASE) / 1024, R2_SPILL = B_BIAS_OFF + 256;
+        static_assert(R2_UNITS == 95 && R2_SPILL + 1024 <= A_BIAS_OFF, "P3_R2LDS: three rows of the RRDB-level stream = 96 units: 95 in front of the bias, one behind it");
+        auto r2_off = [&](const int s_, const int k) {
+            const int L = (s_ * 4 + wave) * 8 + k;
+            return L < R2_UNITS ? R2_BASE + L * 1024 : R2_SPILL + (L - R2_UNITS) * 1024;
+        };
+        const bool r2lds = P3_R2LDS && r2 && !r2_pixel;       // (the first closing reads conv_first's pixel-order output: the register path)
+        if (r2lds) {
+            __syncthreads();                                  // every wave is past the last step's LDS reads (the rows land in that stage)
+            // rows 0, 3, 1: the order they are closed in; row 2 comes through registers (below).  A ROLLED loop over the rows: unrolled, the 24
+            // statements' scalar bases cost 50 more SGPR spills and 9 VGPR spills
+#pragma unroll 1
+            for (int s_ = 0; s_ < 3; ++s_) {
+                const int row = s_ == 0 ? 0 : s_ == 1 ? 3 : 1;
+                const long rowb = ((long)img * pp.H + Y0 + wr * 4 + row) * pp.W * 64;
+                const unsigned long long rb = uni64((unsigned long long)(pp.xrr + rowb + wc * 2048));
+                const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr(smem) + R2_BASE + (s_ * 4 + wave) * 8 * 1024);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    unsigned lo = lb + k * 1024;
+                    if (k == 7) lo = (s_ * 4 + wave) * 8 + 7 < R2_UNITS ? lo : (unsigned)__builtin_amdgcn_readfirstlane(lds_addr(smem) + R2_SPILL);   // (the one unit that does not fit)
+                    dma(NOSC{}, rb + k * 1024, woff, lo);
+                }
+            }
+        }
+        auto fetch_a2 = [&](const int slot, const int s_) {   // a row slot from LDS (this wave's own units)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) a2[slot][mb][g] = *(const floatx4*)(smem + r2_off(s_, mb * 4 + g) + lane * 16);
+        };
         auto load_a2 = [&](const int slot, const int i) {
             const long rowb = ((long)img * pp.H + Y0 + wr * 4 + i) * pp.W * 64;
             const float* q2 = pp.xrr + rowb + (r2_pixel ? X * 64 + hi * 4 : frag_lane);
@@ -744,8 +787,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             const int i = io == 0 ? 0 : io == 1 ? 3 : io - 1;
             // (a slot's loads go out right behind the first pass of its row: the row's 32 accumulator registers are dead by then,
             //  so the prefetch costs no registers at the kernel's pressure peak; they land under the first pass of rows 1, 2)
-            if (r2 && io == 1) load_a2(0, 0);
-            if (r2 && io == 2) load_a2(1, 3);
+            if (r2 && io == 1) load_a2(0, r2lds ? 2 : 0);
+            if (r2 && io == 2 && !r2lds) load_a2(1, 3);
             const bool halo = (i == 0 && wr == 0) || (i == 3 && wr == 1);   // (wave-uniform)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
@@ -781,12 +824,23 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                         asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(vo), "v"(xres[mb][i][g]), "s"(sb) : "memory");
                     }
             };
-            close_row(0, 0);
-            load_a2(0, 1);
-            close_row(1, 3);
-            load_a2(1, 2);
-            close_row(0, 1);
-            close_row(1, 2);
+            if (r2lds) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the 24 LDS-DMA statements (and row 2's loads): all went out before the first pass
+                fetch_a2(1, 0);
+                close_row(1, 0);
+                fetch_a2(1, 1);
+                close_row(1, 3);
+                fetch_a2(1, 2);
+                close_row(1, 1);
+                close_row(0, 2);
+            } else {
+                close_row(0, 0);
+                load_a2(0, 1);
+                close_row(1, 3);
+                load_a2(1, 2);
+                close_row(0, 1);
+                close_row(1, 2);
+            }
         }
     };
 
