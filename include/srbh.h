@@ -190,6 +190,11 @@ int srbh_rrdbnet_trunk_train_backward(int num_block, const void* dense_all, size
  * scheduling problem shows up as an error here instead of a hung GPU).  Set SRBH_PERSISTENT=0 to force per-layer launches. */
 int srbh_rrdbnet_last_status(const void* ws, int B, int H, int W, int want_forward, void* stream);
 
+/* Workgroups per launch of the persistent tail convs (conv_up1 / conv_up2 / conv_hr, SR/rrdbnet_arch.py:234-239) issued by the calling host
+ * thread: 0 = one per CU (default), n = at most n.  Each workgroup holds a CU's whole LDS for its walk; a caller that runs the feature
+ * extractor BESIDE other work (harness.TrainStep's prefetch stream) leaves CUs free with this.  Returns the previous value. */
+int srbh_ptail_wgs_cap(int cap);
+
 /* Measurement hook used by bench.py: when on, srbh_rrdbnet_forward() brackets the persistent trunk kernel (the dominant
  * kernel: the 345 dense-block convs, reference SR/rrdbnet_arch.py:136-167) with HIP events on `stream`;
  * srbh_trunk_last_ms() synchronises on the closing event and returns that launch's duration in milliseconds. */

@@ -268,6 +268,7 @@ SIGNATURES = {
     "srbh_normalize_clamp": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _i, _vp]),
     "srbh_rrdbnet_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "srbh_rrdbnet_last_status": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "srbh_ptail_wgs_cap": (_i, [_i]),
     "srbh_wmse_sum": (_i, [_vp, _vp, _vp, C.c_long, _vp, _vp]),
     "srbh_wmse_grad": (_i, [_vp, _vp, _vp, C.c_long, _vp, _vp, _vp]),
     "srbh_cedice_sums": (_i, [_vp, _i, _i, C.c_long, C.c_long, C.c_long, C.c_long, _vp, _vp, _vp, _vp]),

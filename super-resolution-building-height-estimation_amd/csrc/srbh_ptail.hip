@@ -211,6 +211,8 @@ __global__ __launch_bounds__(256, 1) void ptail_kernel(const TParams p) {
     }
 }
 
+thread_local int g_ptail_wgs_cap = 0;      // srbh_ptail_wgs_cap: workgroups per launch (0: one per CU)
+
 template <int UPS>
 int launch(const TParams& p0, hipStream_t stream) {
     constexpr int LDS_B = W_RES_B + 2 * TileGeo<UPS>::UNITS * 16;
@@ -220,7 +222,14 @@ int launch(const TParams& p0, hipStream_t stream) {
     int dev = 0;
     SRBH_HIP(hipGetDevice(&dev));
     if (!ncu_of[dev & 63]) SRBH_HIP(hipDeviceGetAttribute(&ncu_of[dev & 63], hipDeviceAttributeMultiprocessorCount, dev));
-    const int ncu = ncu_of[dev & 63];
+    int ncu = ncu_of[dev & 63];
+    // SRBH_PTAIL_WGS (harness knob, like SRBH_PT_IMAGES): fewer workgroups than CUs -- this kernel holds a whole CU's LDS per workgroup for
+    // its entire walk, so a full grid lets no kernel of another stream in while it runs
+    if (g_ptail_wgs_cap > 0 && g_ptail_wgs_cap < ncu) ncu = g_ptail_wgs_cap;
+    if (const char* we = getenv("SRBH_PTAIL_WGS")) {          // (developer A/B aid: overrides the caller's cap)
+        const int cap = atoi(we);
+        if (cap > 0 && cap < ncu_of[dev & 63]) ncu = cap;
+    }
     TParams p = p0;
     const int nwg = p.ntiles < ncu ? p.ntiles : ncu;
     p.tiles_per_wg = (p.ntiles + nwg - 1) / nwg;
@@ -231,6 +240,15 @@ int launch(const TParams& p0, hipStream_t stream) {
 }
 
 }  // namespace
+
+/* Workgroups per launch of the persistent tail convs (conv_up1 / conv_up2 / conv_hr of srbh_rrdbnet_forward) on the calling host thread: 0 = one
+ * per CU (default), n = at most n.  A workgroup of this kernel holds its CU's whole LDS for the entire walk, so a full grid lets no kernel of
+ * another stream in: harness.TrainStep caps it for the feature prefetch it runs beside the training step.  Returns the previous value. */
+extern "C" int srbh_ptail_wgs_cap(int cap) {
+    const int prev = g_ptail_wgs_cap;
+    g_ptail_wgs_cap = cap > 0 ? cap : 0;
+    return prev;
+}
 
 namespace srbh {
 

@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import sidework, wcache
+from . import _lib, sidework, wcache
 
 HIR = (0, 3, 12, 21, 30, 60, 90, 256)                       # train.py:55
 # hierweight(bh_stats_globe, HIR) as probed on the reference data; synthetic labels reuse it
@@ -382,7 +382,7 @@ class TrainStep:
         lr = nb[0]
         dev = lr.device
         if self._trunk_stream is None:
-            self._trunk_stream = torch.cuda.Stream(device=dev)
+            self._trunk_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SRBH_PIPE_PRIO", "0")))
         sT, cur = self._trunk_stream, torch.cuda.current_stream(dev)
         ev = torch.cuda.Event()
         ev.record(cur)
@@ -398,11 +398,19 @@ class TrainStep:
             per = -(-B // n)
             if cap >= 8:
                 per = min(cap // 8 * 8, -(-per // 8) * 8)
-            i = 0
-            while i < B:
-                j = min(B, i + per)
-                self.net_hr.forward_feature(x3[i:j], out=fea[i:j], out_dtype=torch.float16)
-                i = j
+            # the tail convs (persistent, a whole CU's LDS per workgroup) on 3/4 of the CUs: a full grid stalls the main stream's chain
+            # for its whole duration (same-box: 28.4 +- 2 ms with full grids, 27.0-27.6 with 192 of 256, profiles/r05ao_ab_ptail_wgs.txt)
+            L = _lib.lib()
+            ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+            prev = L.srbh_ptail_wgs_cap(int(os.environ.get("SRBH_PIPE_TAIL_WGS", ncu * 3 // 4)))
+            try:
+                i = 0
+                while i < B:
+                    j = min(B, i + per)
+                    self.net_hr.forward_feature(x3[i:j], out=fea[i:j], out_dtype=torch.float16)
+                    i = j
+            finally:
+                L.srbh_ptail_wgs_cap(prev)
             done = torch.cuda.Event()
             done.record(sT)
         lr.record_stream(sT)
