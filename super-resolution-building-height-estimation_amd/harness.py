@@ -530,7 +530,11 @@ class TrainStep:
                 + self.criterion[1](height_pred_aggre.squeeze(1), height_aggre, weight_aggre)
                 + self.criterion[2](build_pred, build, weight))
         self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        # one GPU: the encoder's 1x1 weight gradients are queued during backward and run as a handful of launches behind it (with a gradient
+        # all-reduce its hooks would read them too early; gradients are fresh tensors after zero_grad(set_to_none=True): nothing accumulates)
+        from .encoders import deferred_pointwise_wgrads
+        with deferred_pointwise_wgrads(self.world == 1 and not in_graph):
+            loss.backward()
         if self._next is not None and self._pf is None:      # (the hook did not fire: no gradient reached HRfeature's first weight)
             self._pf = self._launch_prefetch(self._next)
         self._next = None
