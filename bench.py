@@ -796,7 +796,7 @@ def main():
         line = bench_feature(args, rank, world, dev, dist)
         if not args.no_extras and args.num_block == 23 and args.batch == 32:
             extras = {}
-            for key, fn in (("train_step", lambda: bench_train(args, rank, world, dev, dist, 10, 5, batch=64,      # (5 warm-up steps: with 2 the step still ran 1.6 ms above its steady state)
+            for key, fn in (("train_step", lambda: bench_train(args, rank, world, dev, dist, 20, 8, batch=64,      # (8 warm-up + 20 timed steps: the pipelined step needs a few steps to settle; 5 + 10 read 1.8 ms above the 40-step figure)
                                                                 with_cpu=not args.no_cpu_baseline)),
                             ("predict", lambda: bench_predict(args, rank, world, dev, dist, int(os.environ.get("SRBH_BENCH_PREDICT_CITIES", "30")), 1, batch=128))):
                 try:

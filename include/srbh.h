@@ -568,6 +568,9 @@ int srbh_pwconv_fwd_wt(const float* x, const float* wt, float* y, int B, int Cin
 int srbh_pwconv_fwd_epi(const float* x, const float* w, int w_transposed, float* y, int B, int Cin, int Cout, int HW, const float* gate,
                         const float* scale, const float* shift, const float* res, int act, void* stream);
 int srbh_pwconv_bwd_data(const float* dy, const float* w, float* dx, int B, int Cin, int Cout, int HW, void* stream);
+/* the same with the gradient arriving over the MBConv block's skip connection (res: [B][Cin][HW], as dx) added in the store:
+ * dX = W^T dY + res (efficientnet_pytorch MBConvBlock.forward's `x = x + inputs`, differentiated) */
+int srbh_pwconv_bwd_data_res(const float* dy, const float* w, const float* res, float* dx, int B, int Cin, int Cout, int HW, void* stream);
 size_t srbh_pwconv_bwd_weight_ws_floats(int B, int Cin, int Cout, int HW);
 int srbh_pwconv_bwd_weight(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int Cout, int HW, void* stream);
 

@@ -256,6 +256,7 @@ SIGNATURES = {
     "srbh_pwconv_fwd_epi": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "srbh_transpose_many": (_i, [_vp, _i, _vp]),
     "srbh_pwconv_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "srbh_pwconv_bwd_data_res": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_pwconv_bwd_weight_ws_floats": (_sz, [_i, _i, _i, _i]),
     "srbh_pwconv_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_pwconv_wgrad_defer": (_i, [_i]),

@@ -419,6 +419,16 @@ extern "C" int srbh_pwconv_bwd_data(const float* dy, const float* w, float* dx, 
     return gemm_launch<1>(w, dy, dx, Cin, Cout, HW, B, (hipStream_t)stream);
 }
 
+/* dX = W^T dY + res: the input gradient with the gradient that arrives over the block's skip connection added in the store (the two used
+ * to meet in an element-wise add launched by autograd: ~25 launches of 7 us per step) */
+extern "C" int srbh_pwconv_bwd_data_res(const float* dy, const float* w, const float* res, float* dx, int B, int Cin, int Cout, int HW, void* stream) {
+    SRBH_REQUIRE(dy && w && res && dx, "srbh_pwconv_bwd_data_res: null pointer");
+    SRBH_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && HW > 0, "srbh_pwconv_bwd_data_res: bad shape");
+    PwEpi ep = {};
+    ep.res = res;
+    return gemm_launch_epi<1>(w, dy, dx, Cin, Cout, HW, B, ep, (hipStream_t)stream);
+}
+
 extern "C" size_t srbh_pwconv_bwd_weight_ws_floats(int B, int Cin, int Cout, int HW) {
     const WgradPlan p = wgrad_plan(Cout, Cin, B, HW);
     return p.S > 1 ? (size_t)p.S * Cout * Cin : 0;

@@ -132,6 +132,8 @@ class _DepthwiseConvFn(torch.autograd.Function):
 # 30.50 ms, pipelined step unchanged (profiles/r05as_ab_pw_wgrad_defer.txt) -- each of these launches already fills the chip with waves (the
 # split plan asks for ~4 600), so batching them saves their launch gaps, not their time; not worth a gradient that is invalid inside backward.
 PW_WGRAD_DEFER = os.environ.get("SRBH_PW_WGRAD_DEFER", "0") == "1"
+# the skip connection of an MBConv block taken through its expand conv's autograd node (see _PointwiseConvFn.forward); SRBH_SKIP_EXPAND=0: autograd's add
+SKIP_THROUGH_EXPAND = os.environ.get("SRBH_SKIP_EXPAND", "1") == "1"
 _PW_KEEP = []
 _PW_ON = [False]
 
@@ -164,11 +166,14 @@ class _PointwiseConvFn(torch.autograd.Function):
     for these shapes in batched transposes, zero fills and split-K atomics: ~390 launches / 4.1 ms of the training step."""
 
     @staticmethod
-    def forward(ctx, x, weight, wt=None):
-        """wt: the transposed weight [Cin][Cout] made by `PointwiseTransposes` for THIS state of `weight` (or None)"""
+    def forward(ctx, x, weight, wt=None, skip=False):
+        """wt: the transposed weight [Cin][Cout] made by `PointwiseTransposes` for THIS state of `weight` (or None).
+        skip: also return x itself (an alias) -- the block's skip connection taken THROUGH this node, so that in backward the gradient arriving
+        over the skip meets the conv's input gradient inside one kernel (srbh_pwconv_bwd_data_res) instead of in an add launched by autograd"""
         from . import _lib
         x = x.contiguous()
         weight = weight.contiguous()
+        ctx.skip = bool(skip)
         B, Cin, H, W = x.shape
         Cout = weight.shape[0]
         y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
@@ -177,10 +182,12 @@ class _PointwiseConvFn(torch.autograd.Function):
         else:
             _lib.check(_lib.lib().srbh_pwconv_fwd(x.data_ptr(), weight.data_ptr(), y.data_ptr(), B, Cin, Cout, H * W, _lib.stream_ptr()), "pwconv_fwd")
         ctx.save_for_backward(x, weight)
+        if ctx.skip:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         from . import _lib
         x, weight = ctx.saved_tensors
         B, Cin, H, W = x.shape
@@ -190,7 +197,12 @@ class _PointwiseConvFn(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.check(L.srbh_pwconv_bwd_data(dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), B, Cin, Cout, H * W, _lib.stream_ptr()), "pwconv_bwd_data")
+            if dskip is not None:
+                dskip = dskip.contiguous()
+                _lib.check(L.srbh_pwconv_bwd_data_res(dy.data_ptr(), weight.data_ptr(), dskip.data_ptr(), dx.data_ptr(), B, Cin, Cout, H * W,
+                                                      _lib.stream_ptr()), "pwconv_bwd_data_res")
+            else:
+                _lib.check(L.srbh_pwconv_bwd_data(dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), B, Cin, Cout, H * W, _lib.stream_ptr()), "pwconv_bwd_data")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             n = L.srbh_pwconv_bwd_weight_ws_floats(B, Cin, Cout, H * W)
@@ -200,7 +212,7 @@ class _PointwiseConvFn(torch.autograd.Function):
             with sidework.side(x, dy, dw, ws):
                 _lib.check(L.srbh_pwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr() if n else None, B, Cin, Cout, H * W,
                                                     _lib.stream_ptr()), "pwconv_bwd_weight")
-        return dx, dw, None
+        return dx, dw, None, None
 
 
 class PointwiseTransposes:
@@ -378,6 +390,18 @@ class SamePadConv2d(nn.Conv2d):
         return F.conv2d(self.static_padding(x), self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
 
 
+def _pointwise_with_skip(conv, x):
+    """(conv(x), x') for a block's expand conv whose input is also the block's skip connection: x' is x routed through the conv's autograd node
+    (None when the libsrbh 1x1 path does not take this call: the caller keeps using x)"""
+    if not (SKIP_THROUGH_EXPAND and conv._pointwise and x.is_cuda and x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and x.dim() == 4
+            and torch.is_grad_enabled() and x.requires_grad and PWCONV in ("1", "train")):
+        return conv(x), None
+    from . import _lib
+    if not _lib.lib().srbh_pwconv_supported(x.shape[0], x.shape[1], conv.weight.shape[0], x.shape[2] * x.shape[3]):
+        return conv(x), None
+    return _PointwiseConvFn.apply(x, conv.weight, _valid_wt(conv, x.device), True)
+
+
 def _valid_wt(conv, device):
     """the transposed copy PointwiseTransposes made of conv.weight, if it still belongs to this state of the weight (else None)"""
     wt = conv.__dict__.get("_srbh_wt")
@@ -475,7 +499,12 @@ class MBConvBlock(nn.Module):
             if z is not None:
                 return z
         if self.expand != 1 and x.is_cuda and self._bn0.training:
-            e_pre = self._expand_conv(x)
+            if self.stride == 1 and self.inp == self.out:
+                e_pre, through = _pointwise_with_skip(self._expand_conv, x)
+                if through is not None:
+                    inputs = through
+            else:
+                e_pre = self._expand_conv(x)
             MBm = _mbconv_train(self._bn0, e_pre)
             if (MBm is not None and MBm.se_supported(self._se_reduce, self._se_expand)
                     and MBm.mid_supported(self._bn0, self._bn1, self._depthwise_conv, e_pre)):

@@ -316,3 +316,32 @@ def test_deferred_pointwise_weight_gradients_equal_the_immediate_ones(monkeypatc
     assert not E._PW_KEEP and not E._PW_ON[0]
     for a, b in zip(w0 + x0, w1 + x1):
         assert bool(torch.isfinite(b).all()) and torch.equal(a, b)
+
+
+def test_skip_gradient_through_the_expand_conv_node():
+    """an MBConv block's skip connection routed through its expand conv's autograd node (_pointwise_with_skip): the gradient arriving over the
+    skip and the conv's input gradient meet inside srbh_pwconv_bwd_data_res instead of in an add launched by autograd -- same dX / dW as the
+    plain graph (conv(x) * a + x * b), every kernel form of the input gradient"""
+    import torch
+    from srbh_amd import encoders as E
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(4)
+    for B, ci, co, hw in [(8, 24, 144, 32), (8, 160, 960, 4), (8, 272, 1632, 2), (8, 448, 2688, 2), (4, 56, 336, 8)]:
+        conv = E.SamePadConv2d(ci, co, 1, hw, bias=False).to(dev)
+        x0 = torch.randn((B, ci, hw, hw), generator=g).to(dev)
+        a = torch.randn((B, co, hw, hw), generator=g).to(dev)
+        b = torch.randn((B, ci, hw, hw), generator=g).to(dev)
+        grads = []
+        for through in (False, True):
+            x = x0.clone().requires_grad_(True)
+            conv.weight.grad = None
+            xin = x * 1.0
+            if through:
+                y, s = E._pointwise_with_skip(conv, xin)
+                assert s is not None
+            else:
+                y, s = conv(xin), xin
+            ((y * a).sum() + (s * b).sum()).backward()
+            grads.append((x.grad.clone(), conv.weight.grad.clone()))
+        assert torch.equal(grads[0][1], grads[1][1])                                    # dW: the same kernel on the same operands
+        assert float((grads[0][0] - grads[1][0]).abs().max()) <= 2e-6 * float(grads[0][0].abs().max())   # dX: the add moved into the store
