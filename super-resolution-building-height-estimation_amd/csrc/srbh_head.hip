@@ -533,22 +533,18 @@ __global__ void hpack_h16_kernel(const float* __restrict__ w, short* __restrict_
 }
 
 // ---- BatchNorm: partial sums -> scale/shift (+ running stats) ------------------------------------------------------
-// clear != 0 (one block of 64 threads, C <= 64): the slots this thread summed are zeroed behind the read (self-cleaning buffer)
-__global__ void bn_finalize_kernel(double* __restrict__ stats, int C, double count, const float* gamma,
+// clear != 0 (one block of 256 threads, C <= 64): the slots a thread summed are zeroed behind the read (self-cleaning buffer)
+// (round 5: the NSLOT x 2 C partial sums are folded by the whole block -- group g of 256 / (2 C) takes the slots g, g + G, ... of one (moment,
+//  channel) value, all of a thread's loads in flight at once, then a fixed-order fold through LDS -- instead of C threads walking 128
+//  dependent-latency loads each: these one-block kernels sit between the head's chip-filling kernels 49 times per training step)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(double* __restrict__ stats, int C, double count, const float* gamma,
                                    const float* beta, float eps, float momentum, float* running_mean,
                                    float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd, int clear) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[256];
     double s = 0, q = 0;
-    for (int k = 0; k < NSLOT; ++k) {
-        s += stats[(long)k * 2 * C + c];
-        q += stats[(long)k * 2 * C + C + c];
-    }
-    if (clear)
-        for (int k = 0; k < NSLOT; ++k) {
-            stats[(long)k * 2 * C + c] = 0.0;
-            stats[(long)k * 2 * C + C + c] = 0.0;
-        }
+    srbh::fold_stat_slots(stats, C, clear, red, s, q);
+    const int c = threadIdx.x;
+    if (c >= C) return;
     double mean = s / count;
     double var = q / count - mean * mean;   // biased, as used for normalisation
     if (var < 0) var = 0;
@@ -963,7 +959,7 @@ extern "C" int srbh_bn_finalize(const double* stats, int C, double count, const 
                                 float eps, float momentum, float* running_mean, float* running_var, float* scale,
                                 float* shift, float* save_mean, float* save_invstd, void* stream) {
     SRBH_REQUIRE(stats && C > 0 && C <= 64 && count > 0 && scale && shift, "srbh_bn_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (double*)stats, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd, 0);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (double*)stats, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd, 0);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }
@@ -972,7 +968,7 @@ extern "C" int srbh_bn_finalize_clear(double* stats, int C, double count, const 
                                       float eps, float momentum, float* running_mean, float* running_var, float* scale,
                                       float* shift, float* save_mean, float* save_invstd, void* stream) {
     SRBH_REQUIRE(stats && C > 0 && C <= 64 && count > 0 && scale && shift, "srbh_bn_finalize_clear: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd, 1);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd, 1);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }

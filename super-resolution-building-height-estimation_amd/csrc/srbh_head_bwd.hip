@@ -1144,20 +1144,13 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* _
 
 // per-channel constants of the BatchNorm backward: dgamma, dbeta and (coef, k1, k2) with
 // dc = coef * (dy - k1 - xhat * k2);   training: coef = gamma*invstd, k1 = sum(dy)/N, k2 = sum(dy*xhat)/N
-__global__ void bn_bwd_finalize_kernel(double* stats, int C, double count, const float* gamma, const float* invstd,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(double* stats, int C, double count, const float* gamma, const float* invstd,
                                        float* dgamma, float* dbeta, float* coef, float* k1, float* k2, int clear) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[256];
     double s = 0, q = 0;
-    for (int k = 0; k < NSLOT; ++k) {
-        s += stats[(long)k * 2 * C + c];
-        q += stats[(long)k * 2 * C + C + c];
-    }
-    if (clear)       // self-cleaning buffer (one block, C <= 64): this thread zeroes exactly the slots it summed
-        for (int k = 0; k < NSLOT; ++k) {
-            stats[(long)k * 2 * C + c] = 0.0;
-            stats[(long)k * 2 * C + C + c] = 0.0;
-        }
+    srbh::fold_stat_slots(stats, C, clear, red, s, q);   // (one block of 256 threads, C <= 64; clear: the slots are zeroed behind the read)
+    const int c = threadIdx.x;
+    if (c >= C) return;
     if (dgamma) dgamma[c] = (float)q;
     if (dbeta) dbeta[c] = (float)s;
     if (coef) {
@@ -1738,7 +1731,7 @@ extern "C" int srbh_bn_bwd_finalize(const double* stats, int C, double count, co
                                     float* dgamma, float* dbeta, float* coef, float* k1, float* k2, void* stream) {
     SRBH_REQUIRE(stats && C > 0 && C <= 64 && count > 0, "srbh_bn_bwd_finalize: bad arguments");
     SRBH_REQUIRE(!coef || (invstd && k1 && k2), "srbh_bn_bwd_finalize: coef needs invstd, k1, k2");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (double*)stats, C, count, gamma, invstd,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (double*)stats, C, count, gamma, invstd,
                        dgamma, dbeta, coef, k1, k2, 0);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
@@ -1748,7 +1741,7 @@ extern "C" int srbh_bn_bwd_finalize_clear(double* stats, int C, double count, co
                                           float* dgamma, float* dbeta, float* coef, float* k1, float* k2, void* stream) {
     SRBH_REQUIRE(stats && C > 0 && C <= 64 && count > 0, "srbh_bn_bwd_finalize_clear: bad arguments");
     SRBH_REQUIRE(!coef || (invstd && k1 && k2), "srbh_bn_bwd_finalize_clear: coef needs invstd, k1, k2");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, C, count, gamma, invstd,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, C, count, gamma, invstd,
                        dgamma, dbeta, coef, k1, k2, 1);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;

@@ -85,6 +85,30 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
 
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+// BatchNorm partial sums [NS = 64 slots][2 moments][C] (double) -> the two totals of channel threadIdx.x (threads >= C get garbage), by ONE block
+// of 256 threads: thread t owns the value v = t % (2 C) (moment * C + channel) and the slots g, g + G, ... (g = t / (2 C), G = 256 / (2 C)
+// groups): all of its loads are in flight together, then the G partials are added in a fixed order through `red` (256 doubles of LDS).
+// clear: every slot is zeroed behind its read (self-cleaning buffer).  Deterministic.
+__device__ __forceinline__ void fold_stat_slots(double* stats, const int C, const int clear, double* red, double& s, double& q) {
+    constexpr int NS = 64;
+    const int t = threadIdx.x, V = 2 * C, G = 256 / V, v = t % V, g = t / V;
+    double part = 0.0;
+    if (g < G) {
+        for (int k = g; k < NS; k += G) part += stats[(long)k * V + v];
+        if (clear)
+            for (int k = g; k < NS; k += G) stats[(long)k * V + v] = 0.0;
+        red[g * V + v] = part;
+    }
+    __syncthreads();
+    s = 0.0;
+    q = 0.0;
+    if (t < C)
+        for (int k = 0; k < G; ++k) {
+            s += red[k * V + t];
+            q += red[k * V + C + t];
+        }
+}
+
 // two fp32 -> one dword of bf16 (lo in the low half), round to nearest even: ONE v_cvt_pk_bf16_f32 on gfx950 (the integer sequence
 // u + 0x7fff + ((u >> 16) & 1) >> 16 it replaces is 4 VALU ops per element in kernels whose staging is VALU-bound; same bits for every
 // finite input and the infinities)
