@@ -283,6 +283,15 @@ size_t srbh_hpack_h16_bytes(int cout, int cin, int ksize);
  * v_mfma_f32_16x16x16_bf16 (data gradients: per-pixel gradients of a mean-reduced loss sit far below fp16's normal range,
  * bf16 keeps fp32's exponent).  The pack and the conv must use the same setting. */
 int srbh_hpack_conv_h16(const float* w_oihw, int cout, int cin, int ksize, int transpose_flip, int bf16, void* packed, void* stream);
+/* n such packs in ONE launch: table_dev[i] = the arguments of call i (w, cout, cin, ksize, transpose_flip, bf16, packed), in device memory;
+ * max_elems = the largest srbh_hpack_h16_bytes(...) / 2 among them.  (hrfuse.py refreshes every registered head pack right behind
+ * optimizer.step(): the weights the reference's torch.optim.Adam has just changed, train.py:256.) */
+typedef struct srbh_hpack_desc {
+    const float* w;
+    void* out;
+    int cout, cin, ksize, transpose_flip, bf16, pad_;
+} srbh_hpack_desc;
+int srbh_hpack_conv_h16_many(const srbh_hpack_desc* table_dev, int n, long max_elems, void* stream);
 int srbh_hconv_h16(const srbh_hconv_args* a, int bf16, void* stream);
 /* The entry of a BasicBlock with a downsample branch (SR/HRfuse.py:142-159): conv1 (3x3, `c1`) and downsample[0] (1x1, `ds`) read the
  * SAME input -- the widest tensor of each head.  One fused pass (the 1x1 is the centre tap with other weights) when both produce 16

@@ -192,6 +192,7 @@ SIGNATURES = {
     "srbh_hconv_f32": (_i, [C.POINTER(HConvArgs), _vp]),
     "srbh_hpack_h16_bytes": (_sz, [_i, _i, _i]),
     "srbh_hpack_conv_h16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "srbh_hpack_conv_h16_many": (_i, [_vp, _i, C.c_long, _vp]),
     "srbh_hconv_h16": (_i, [C.POINTER(HConvArgs), _i, _vp]),
     "srbh_hconv_entry_h16": (_i, [C.POINTER(HConvArgs), C.POINTER(HConvArgs), _i, _vp]),
     "srbh_bn_finalize": (_i, [_vp, _i, C.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

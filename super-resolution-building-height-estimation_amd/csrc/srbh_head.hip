@@ -724,6 +724,40 @@ extern "C" int srbh_hpack_conv_h16(const float* w, int cout, int cin, int ksize,
     return SRBH_OK;
 }
 
+// several 16-bit weight packs in ONE launch (round 5): a training step re-packs every head conv weight twice (forward fp16, gradient bf16
+// transposed + flipped) because the optimizer has just changed it -- 56 launches of ~5 us between the head's kernels; hrfuse.py registers the
+// packs it makes and refreshes them all right behind the optimizer's step.  Same arithmetic per element as hpack_h16_kernel.
+__global__ __launch_bounds__(256) void hpack_h16_many_kernel(const srbh_hpack_desc* __restrict__ table) {
+    const srbh_hpack_desc d = table[blockIdx.y];
+    const int taps = d.ksize * d.ksize, nchunk = (d.cin + 15) / 16, nob = (d.cout + 15) / 16;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)nchunk * taps * nob * 64 * 4;
+    if (idx >= total) return;
+    const int j = idx & 3, lane = (idx >> 2) & 63;
+    long f = idx >> 8;
+    const int ob = f % nob; f /= nob;
+    const int tap = f % taps;
+    const int chunk = (int)(f / taps);
+    const int oc = ob * 16 + (lane & 15), ic = chunk * 16 + (lane >> 4) * 4 + j;
+    float v = 0.f;
+    if (oc < d.cout && ic < d.cin)
+        v = d.transpose_flip ? d.w[((long)ic * d.cout + oc) * taps + (taps - 1 - tap)] : d.w[((long)oc * d.cin + ic) * taps + tap];
+    short* out = (short*)d.out;
+    if (d.bf16) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        out[idx] = (short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    } else {
+        out[idx] = __builtin_bit_cast(short, (_Float16)v);
+    }
+}
+
+extern "C" int srbh_hpack_conv_h16_many(const srbh_hpack_desc* table_dev, int n, long max_elems, void* stream) {
+    SRBH_REQUIRE(table_dev && n > 0 && max_elems > 0, "srbh_hpack_conv_h16_many: bad arguments");
+    hipLaunchKernelGGL(hpack_h16_many_kernel, dim3((unsigned)((max_elems + 255) / 256), n), dim3(256), 0, (hipStream_t)stream, table_dev);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
 static int hconv_impl(const srbh_hconv_args* a, void* stream, const int opt) {
     const bool h16 = opt != 0;
     SRBH_REQUIRE(a && a->src0 && a->w && a->out, "srbh_hconv_f32: null pointer");

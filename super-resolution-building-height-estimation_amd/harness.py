@@ -404,11 +404,12 @@ class TrainStep:
             ncu = torch.cuda.get_device_properties(dev).multi_processor_count
             prev = L.srbh_ptail_wgs_cap(int(os.environ.get("SRBH_PIPE_TAIL_WGS", ncu * 3 // 4)))
             try:
-                i = 0
-                while i < B:
-                    j = min(B, i + per)
-                    self.net_hr.forward_feature(x3[i:j], out=fea[i:j], out_dtype=torch.float16)
-                    i = j
+                with self.net_hr.same_weights():          # (one walk over the 702 parameters for the launches of this prefetch, not one each)
+                    i = 0
+                    while i < B:
+                        j = min(B, i + per)
+                        self.net_hr.forward_feature(x3[i:j], out=fea[i:j], out_dtype=torch.float16)
+                        i = j
             finally:
                 L.srbh_ptail_wgs_cap(prev)
             done = torch.cuda.Event()

@@ -129,6 +129,81 @@ def fp16_chain(mod):
     return FP16_ACTIVATIONS and not mod.training and not torch.is_grad_enabled() and head_h16()
 
 
+# ---- the 16-bit packs of TRAINED weights, refreshed right behind the optimizer (round 5) ----------------------------------------------
+# In the training step every head conv weight is packed twice per step (forward: fp16, data gradient: bf16 transposed + flipped) because
+# the optimizer changed it: 56 launches of ~5 us, each in front of a chip-filling kernel.  A pack of a bias-free conv whose weight is a
+# Parameter registers itself here when it is made; wcache's optimizer post-step hook calls `repack_after_step`, which rewrites all registered
+# packs of the stepped parameters IN PLACE with one launch (srbh_hpack_conv_h16_many) and moves their cache keys to the new generation, so
+# that the next `.get()` finds them current.  A pack that is not registered (bias, fp32 form, a weight view) keeps repacking lazily.
+# SRBH_PACK_AFTER_STEP=0: off.
+PACK_AFTER_STEP = _os.environ.get("SRBH_PACK_AFTER_STEP", "1") == "1"
+
+
+class _PackRegistry:
+    def __init__(self):
+        self.entries = {}          # id(cache) -> dict(cache=weakref, param=weakref, buf, args, rekey)
+        self.tables = {}           # tuple(entry ids) -> (device table, max elements, keep-alive)
+
+    def register(self, cache, param, buf, args, rekey):
+        import weakref
+        if not (PACK_AFTER_STEP and isinstance(param, nn.Parameter) and param.dtype == torch.float32 and param.is_contiguous() and param.is_cuda):
+            return
+        self.entries[id(cache)] = dict(cache=weakref.ref(cache), param=weakref.ref(param), buf=buf, args=args, rekey=rekey,
+                                       ptr=param.data_ptr(), dev=param.device)
+        self.tables.clear()
+
+    def repack(self, params):
+        if not self.entries:
+            return
+        import numpy as np
+        ids = {id(p) for p in params}
+        live, dead = [], []
+        for k, e in self.entries.items():
+            c, p = e["cache"](), e["param"]()
+            if c is None or p is None or c.w is not e["buf"] or p.data_ptr() != e["ptr"]:
+                dead.append(k)                       # the module is gone, or the pack / the parameter storage was replaced (the lazy path re-registers)
+            elif id(p) in ids and not torch.cuda.is_current_stream_capturing():
+                live.append(k)
+        for k in dead:
+            del self.entries[k]
+        if dead:
+            self.tables.clear()
+        by_dev = {}
+        for k in live:
+            by_dev.setdefault(self.entries[k]["dev"], []).append(k)
+        L = _lib.lib()
+        for dev, keys in by_dev.items():
+            tk = tuple(keys)
+            t = self.tables.get(tk)
+            if t is None:
+                desc = np.zeros(len(keys), dtype=np.dtype([("w", "<u8"), ("out", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("ks", "<i4"), ("tf", "<i4"),
+                                                           ("bf", "<i4"), ("pad", "<i4")]))
+                mx = 0
+                for i, k in enumerate(keys):
+                    e = self.entries[k]
+                    co, ci, ks, tf, bf = e["args"]
+                    desc[i] = (e["ptr"], e["buf"].data_ptr(), co, ci, ks, tf, bf, 0)
+                    mx = max(mx, L.srbh_hpack_h16_bytes(co, ci, ks) // 2)
+                t = self.tables[tk] = (torch.from_numpy(desc.view(np.uint8).copy()).to(dev), mx)
+            with torch.cuda.device(dev):
+                _lib.check(L.srbh_hpack_conv_h16_many(t[0].data_ptr(), len(keys), t[1], _lib.stream_ptr()), "hpack_conv_h16_many")
+            for k in keys:
+                e = self.entries[k]
+                c = e["cache"]()
+                nk = e["rekey"]()
+                if c is not None and nk is not None:
+                    c.key = nk
+
+
+PACKS = _PackRegistry()
+
+
+def repack_after_step(optimizer):
+    """called by wcache's optimizer post-step hook, behind the generation stamp"""
+    if PACK_AFTER_STEP and PACKS.entries:
+        PACKS.repack([p for g in optimizer.param_groups for p in g["params"]])
+
+
 class _PackedConv:
     """HWPACK32 (or its fp16 form) of one conv weight (+ zero-padded bias), rebuilt when the parameter changes."""
 
@@ -169,6 +244,17 @@ class _PackedConv:
                 b[:cout] = conv.bias.detach().float() if perm is None else conv.bias.detach().float().index_select(0, perm)
             # (no host sync: `wc` is recycled by torch's stream-ordered allocator, and the pack kernel runs on that stream)
             self.key, self.w, self.b = key, buf, b
+            if h16 and not up and conv.bias is None:           # refreshed behind the optimizer's step from now on (PACKS)
+                import weakref
+                cref = weakref.ref(conv)
+
+                def rekey(cref=cref):
+                    cv = cref()
+                    if cv is None or cv.bias is not None:
+                        return None
+                    ww = cv.weight
+                    return (ww._version, ww.data_ptr(), None, True, False, wcache.gen(ww, None))
+                PACKS.register(self, w, buf, (cout, cin, ks, 0, 0), rekey)
         wcache.keep(self.w, self.b)
         return self.w, self.b
 

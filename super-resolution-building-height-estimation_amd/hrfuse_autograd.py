@@ -39,6 +39,14 @@ class _PackedGrad:
                            "hpack_conv_f32(T)")
             # (no host sync: `wc` is recycled by torch's stream-ordered allocator, and the pack kernel runs on that stream)
             self.key, self.w = key, buf
+            if h16 and gen_src is None and isinstance(weight, nn.Parameter):     # refreshed behind the optimizer's step from now on (hrfuse.PACKS)
+                import weakref
+                wref = weakref.ref(weight)
+
+                def rekey(wref=wref):
+                    ww = wref()
+                    return None if ww is None else (ww._version, ww.data_ptr(), True, wcache.gen(ww))
+                H.PACKS.register(self, weight, buf, (cin, cout, ks, 1, 1), rekey)
         wcache.keep(self.w)
         return self.w
 

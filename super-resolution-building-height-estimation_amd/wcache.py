@@ -36,6 +36,10 @@ def stamp(tensors) -> None:
 
 def _after_step(optimizer, args, kwargs):
     stamp(p for group in optimizer.param_groups for p in group["params"])
+    import sys
+    hr = sys.modules.get(__package__ + ".hrfuse")       # (only if the head module is in use: its registered 16-bit packs are refreshed in one launch)
+    if hr is not None:
+        hr.repack_after_step(optimizer)
 
 
 # ---- buffers a captured HIP graph points at ---------------------------------------------------------------------------

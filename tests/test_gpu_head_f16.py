@@ -429,3 +429,39 @@ def test_upsampler_weight_gradient_with_the_output_blocks_inside_the_walk(B, Hh,
     F.conv2d(xr, w0, padding=1).mul(gr).sum().backward()
     assert dw.shape == (64, 16, 3, 3)
     assert float((dw.double() - w0.grad).norm() / w0.grad.norm()) <= 1e-5
+
+
+def test_packs_refreshed_behind_the_optimizer_step_equal_the_lazy_packs():
+    """hrfuse.PACKS: the fp16 forward packs and bf16 gradient packs of the bias-free head convs register themselves when they are first made;
+    optimizer.step() -- through wcache's post-step hook -- rewrites all of them in ONE launch (srbh_hpack_conv_h16_many) and moves their keys
+    to the new generation: the next forward finds every pack current (no pack launch) and every buffer equals what the lazy per-conv pack
+    makes of the stepped weight, bit for bit."""
+    from srbh_amd import _lib, hrfuse as H, hrfuse_autograd as HA
+    dev = "cuda:0"
+    torch.manual_seed(2)
+    m = H.HRfeature(64, 16, 16).to(dev).train()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    x = torch.randn(2, 64, 64, 64, device=dev).contiguous(memory_format=torch.channels_last)
+    H.PACKS.entries.clear()
+    H.PACKS.tables.clear()
+    with H.head_precision("f16"):
+        for it in range(2):
+            opt.zero_grad(set_to_none=True)
+            m(x).square().mean().backward()
+            if it == 0:
+                n_reg = len(H.PACKS.entries)
+                assert n_reg >= 10, n_reg                      # 6 3x3 convs + the 1x1 downsample, forward and gradient packs
+            opt.step()
+        torch.cuda.synchronize()
+        assert len(H.PACKS.entries) == n_reg                   # the second step's forward / backward found every pack current: nothing re-registered
+        checked = 0
+        for e in H.PACKS.entries.values():
+            cache, p = e["cache"](), e["param"]()
+            co, ci, ks, tf, bf = e["args"]
+            want = torch.empty_like(e["buf"])
+            _lib.check(_lib.lib().srbh_hpack_conv_h16(p.detach().contiguous().data_ptr(), co, ci, ks, tf, bf, want.data_ptr(), _lib.stream_ptr()), "pack")
+            torch.cuda.synchronize()
+            assert torch.equal(e["buf"].view(torch.int16), want.view(torch.int16))
+            assert cache.key == e["rekey"]()                  # current for this state of the weight
+            checked += 1
+        assert checked == n_reg
