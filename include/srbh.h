@@ -178,9 +178,10 @@ int srbh_rrdbnet_forward(const srbh_rrdbnet_desc* d, const float* x, float* out,
  * flipped weight slices, at pack_off[0..4] inside a pack_stride-byte record); G = zero-bordered 6-plane ACT16 buffer(s) for the bf16
  * gradients [g5 | g4 | g3 | g2 | g1]: g_stride > 0 = two of them, g_stride bytes apart -- the weight / bias gradients of an RDB then
  * run on an internal side stream next to the gradient convs of the RDB below (joined before the call returns control of `stream`); dw_all = per RDB 239 616 floats (conv1..conv5, OIHW each), db_all = per RDB 192 floats in G's
- * channel order; wgrad_ws = srbh_hwgrad_ws_bytes(64, 192, 3) bytes. */
+ * channel order; wgrad_ws = srbh_rrdbnet_trunk_wgrad_ws_bytes() bytes. */
 int srbh_rrdbnet_trunk_train_forward(const srbh_rrdbnet_desc* d, float* xr, float* xrr, void* dense_all, size_t dense_stride, int B, int H,
                                      int W, void* stream);
+size_t srbh_rrdbnet_trunk_wgrad_ws_bytes(void);   /* size of wgrad_ws below: the five weight-gradient workspaces of a dense block side by side (their reduces run as one pair of launches) */
 int srbh_rrdbnet_trunk_train_backward(int num_block, const void* dense_all, size_t dense_stride, const void* packs, size_t pack_stride,
                                       const size_t* pack_off, float* g_a, float* g_b, float* g_c, float** g_out, void* G, size_t g_stride,
                                       float* dw_all, float* db_all, float* wgrad_ws, int B, int H, int W, void* stream);

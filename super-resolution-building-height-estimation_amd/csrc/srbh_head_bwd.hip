@@ -1540,6 +1540,8 @@ extern "C" int srbh_act16_wgrad_b16(const void* x, int x_chunks_total, int cin, 
     const int taps = 9, nchunk = cin / 16;
     const long U = (long)nob * nchunk * taps * 256;
     const int total = cout * cin * taps;
+    if (g_red_defer)          // (srbh_hwgrad_defer: the two-stage ordered reduce, queued -- srbh_rrdbnet_trunk_train_backward batches a dense block's five)
+        return reduce_partials(ws, dw, U, gx, nchunk, taps, cout, cin, st);
     if (gx <= 128) {
         hipLaunchKernelGGL(hwgrad_reduce_direct_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws, dw, U, gx, nchunk, taps, cout, cin);
         SRBH_HIP(hipGetLastError());

@@ -245,6 +245,14 @@ int side_init() {
 }
 }  // namespace
 
+/* bytes of `wgrad_ws` for srbh_rrdbnet_trunk_train_backward: the partial-sum workspaces of a dense block's five weight gradients side by side */
+extern "C" size_t srbh_rrdbnet_trunk_wgrad_ws_bytes(void) {
+    static const int COUT[5] = {32, 32, 32, 32, 64}, CIN[5] = {64, 96, 128, 160, 192};
+    size_t n = 0;
+    for (int k = 0; k < 5; ++k) n += srbh_hwgrad_ws_bytes(COUT[k], CIN[k], 3);
+    return n;
+}
+
 extern "C" int srbh_rrdbnet_trunk_train_backward(int num_block, const void* dense_all, size_t dense_stride, const void* packs, size_t pack_stride,
                                                  const size_t* pack_off, float* g_a, float* g_b, float* g_c, float** g_out, void* G, size_t g_stride,
                                                  float* dw_all, float* db_all, float* wgrad_ws, int B, int H, int W, void* stream) {
@@ -295,9 +303,17 @@ extern "C" int srbh_rrdbnet_trunk_train_backward(int num_block, const void* dens
                 if ((rc = srbh_conv3x3_x16(&a, 1, nullptr, 0, 0, stream))) return rc;
             }
             if ((rc = srbh_act16_channel_sum(Gi, B, H, W, 6, 0, 6, 1, db_all + (long)i * 192, ws_st))) return rc;
-            for (int k = 0; k < 5; ++k)
-                if ((rc = srbh_act16_wgrad_b16(D, 6, CIN[k], Gi, 6, CH0[k], COUT[k], B, H, W, dw_all + (long)i * DW_RDB + DWOFF[k], wgrad_ws, ws_st)))
-                    return rc;
+            // the five weight gradients of the dense block: each into its own slice of the workspace, their ordered reduces queued and done by
+            // ONE pair of launches (round 5: five reduce launches of ~9 us per block sat on the stream that bounds the backward)
+            static const bool batch_red = !(getenv("SRBH_SR_BATCH_REDUCE") && getenv("SRBH_SR_BATCH_REDUCE")[0] == '0');
+            if (batch_red && (rc = srbh_hwgrad_defer(1))) return rc;
+            size_t woff = 0;
+            for (int k = 0; k < 5; ++k) {
+                rc = srbh_act16_wgrad_b16(D, 6, CIN[k], Gi, 6, CH0[k], COUT[k], B, H, W, dw_all + (long)i * DW_RDB + DWOFF[k], wgrad_ws + woff, ws_st);
+                if (rc) { if (batch_red) srbh_hwgrad_flush(ws_st); return rc; }
+                if (batch_red) woff += srbh_hwgrad_ws_bytes(COUT[k], CIN[k], 3) / sizeof(float);
+            }
+            if (batch_red && (rc = srbh_hwgrad_flush(ws_st))) return rc;
             if (two) {
                 SRBH_HIP(hipEventRecord(g_side.done[gb], ws_st));
                 used[gb] = 1;

@@ -114,7 +114,7 @@ def _fast_buffers(B, Hh, Ww, n_rdb, dev):
     nb = L.srbh_act16_bytes(B, 192, Hh, Ww)
     nb = (nb + 255) // 256 * 256
     ws = {"nb": nb, "D": torch.zeros((n_rdb + 1) * nb, dtype=torch.uint8, device=dev), "G": torch.zeros(2 * nb, dtype=torch.uint8, device=dev),
-          "wg": torch.empty(L.srbh_hwgrad_ws_bytes(64, 192, 3) // 4, dtype=torch.float32, device=dev), "busy": False, "gen": 0}
+          "wg": torch.empty(L.srbh_rrdbnet_trunk_wgrad_ws_bytes() // 4, dtype=torch.float32, device=dev), "busy": False, "gen": 0}
     pool.append(ws)
     return ws
 
