@@ -181,6 +181,12 @@ int srbh_rrdbnet_forward(const srbh_rrdbnet_desc* d, const float* x, float* out,
  * channel order; wgrad_ws = srbh_rrdbnet_trunk_wgrad_ws_bytes() bytes. */
 int srbh_rrdbnet_trunk_train_forward(const srbh_rrdbnet_desc* d, float* xr, float* xrr, void* dense_all, size_t dense_stride, int B, int H,
                                      int W, void* stream);
+/* the same forward as ONE launch of the persistent trunk kernel (SR/rrdbnet_arch.py:136-167 x 69, as the inference trunk runs it) over a row
+ * of dense buffers, every plane stored whole for the backward, the fp32 output in xr (pixel order); bit-identical to the per-layer call.
+ * aux = srbh_rrdbnet_trunk_train_aux_bytes(B, H, W) bytes of scratch (0: geometry not taken); *used = 0: nothing ran, use the call above. */
+size_t srbh_rrdbnet_trunk_train_aux_bytes(int B, int H, int W);
+int srbh_rrdbnet_trunk_train_forward_persistent(const srbh_rrdbnet_desc* d, float* xr, float* xrr, void* dense_all, size_t dense_stride, int B, int H,
+                                                int W, void* aux, void* stream, int* used);
 size_t srbh_rrdbnet_trunk_wgrad_ws_bytes(void);   /* size of wgrad_ws below: the five weight-gradient workspaces of a dense block side by side (their reduces run as one pair of launches) */
 int srbh_rrdbnet_trunk_train_backward(int num_block, const void* dense_all, size_t dense_stride, const void* packs, size_t pack_stride,
                                       const size_t* pack_off, float* g_a, float* g_b, float* g_c, float** g_out, void* G, size_t g_stride,

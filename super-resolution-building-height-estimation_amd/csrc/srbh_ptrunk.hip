@@ -61,6 +61,10 @@ struct PParams {
     int force_wt;               // 1: always use write-through stores (debugging aid, env SRBH_PT_WT=1)
     int frag_res;               // 1: fp32 residual streams in fragment order inside the launch (W == TILE_W)
     unsigned long long* prof;   // debug (tools/convbench): [block][layer][4] s_memtime stamps, nullptr in production
+    // TRAINING forward (ptrunk3_kernel only; srbh_rrdbnet_trunk_train_forward_persistent): every RDB keeps its own dense buffer for the backward
+    long dense_stride;          // > 0: RDB i reads / writes dense[0] + i * dense_stride (its output x goes to RDB i + 1's buffer); 0: the two buffers alternate
+    int keep_all;               // 1: every plane is stored whole (the backward reads them), not only the rows a neighbour reads
+    int out_pixel;              // 1: the trunk's fp32 output goes to `xr` in pixel order (NHWC) behind the last RDB
 };
 
 constexpr unsigned SPIN_LIMIT = 4u << 20;
@@ -1180,8 +1184,10 @@ static int ptrunk2_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, f
 }
 
 // returns SRBH_OK and sets *used = 1 when the persistent path ran, *used = 0 when the shape is not eligible
+// train_stride > 0 = the TRAINING forward (srbh_rrdbnet_trunk_train_forward_persistent): dense0 is RDB 0's buffer of a row of buffers train_stride
+// bytes apart (dense1 ignored), every plane is stored whole, and the trunk's fp32 output goes to `xr` in pixel order; variant 3 only.
 int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr, float* xrr, int B, int H, int W,
-               void* aux, hipStream_t stream, int* used, int* final_cur) {
+               void* aux, hipStream_t stream, int* used, int* final_cur, long train_stride) {
     *used = 0;
     if (W > TILE_W || d->num_block <= 0 || d->num_block > MAX_BLOCKS) return SRBH_OK;
     int dev = 0;
@@ -1190,7 +1196,8 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
     SRBH_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     // variant 2 (two 4-row workgroups per CU, see ptrunk2_kernel) or variant 1 (one 8-row workgroup per CU)
     const char* ve = getenv("SRBH_PT_VARIANT");
-    const int variant = ve ? atoi(ve) : PT_DEFAULT_VARIANT;
+    const int variant = train_stride > 0 ? 3 : (ve ? atoi(ve) : PT_DEFAULT_VARIANT);
+    if (train_stride > 0 && !(W == TILE_W && (H % TILE_H) == 0)) return SRBH_OK;
     if (variant == 2) {
         const int rc2 = ptrunk2_run(d, dense0, dense1, xr, xrr, B, H, W, aux, stream, used, final_cur);
         if (rc2 != SRBH_OK || *used) return rc2;
@@ -1251,8 +1258,10 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
     for (int b0 = 0; b0 < B; b0 += imgs_per_launch) {
         const int nb = (B - b0) < imgs_per_launch ? (B - b0) : imgs_per_launch;
         PParams pp;
+        pp.dense_stride = train_stride;
+        pp.keep_all = pp.out_pixel = train_stride > 0;
         pp.dense[0] = (char*)dense0 + (long)b0 * g.img_b;
-        pp.dense[1] = (char*)dense1 + (long)b0 * g.img_b;
+        pp.dense[1] = (train_stride > 0 ? (char*)dense0 + train_stride : (char*)dense1) + (long)b0 * g.img_b;
         pp.img_b = g.img_b;
         pp.plane_b = g.plane_b;
         pp.row_b = g.row_b;
@@ -1280,7 +1289,7 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
         }
         if (g_trunk_timing && b0 == 0) SRBH_HIP(hipEventRecord(g_trunk_ev[0], stream));
         // variant 3 (RDB-unrolled instruction stream, see srbh_ptrunk3_kernel.h): full 8 x 64 tiles only
-        const bool v3 = variant == 3 && W == TILE_W && (H % TILE_H) == 0 && reg_res;
+        const bool v3 = variant == 3 && W == TILE_W && (H % TILE_H) == 0 && (reg_res || train_stride > 0);
         g_trunk_kernel = v3 ? "ptrunk3_kernel" : "ptrunk_kernel";
         if (v3 && pp.prof)
             hipLaunchKernelGGL((ptrunk3_kernel<1>), dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);

@@ -119,6 +119,11 @@
 // workgroups is bandwidth-bound either way) and the PLAIN epilogue 6.8 k instead of 5.0 k (24 spilled VGPRs at the kernel's pressure peak).
 #define P3_R2LDS 0
 #endif
+#ifndef P3_TRAIN
+// 1: the kernel also runs the SR-stage TRAINING forward (PParams.dense_stride / keep_all / out_pixel: one dense buffer per RDB, whole planes,
+// fp32 output in pixel order); 0 compiles those run-time switches out (A/B aid: what they cost the inference launch)
+#define P3_TRAIN 1
+#endif
 #ifndef P3_PRE_AT
 #define P3_PRE_AT 2
 #endif
@@ -728,7 +733,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     // (x = 0.2 x + x_rrdb, the RRDB-level stream lives in memory): that is a SECOND pass over the registers behind a uniform
     // branch -- as a flag inside one body hipcc if-converted it into 128 selects, as two bodies the 160 live registers met in
     // phis and spilled.  In an RRDB-closing RDB the first pass stores nothing (its fp16 values are not final).
-    auto epi64 = [&](floatx16 (&acc)[2][4], char* obase, const bool r2, const bool r2_pixel, const bool x1_halo_only) {
+    auto epi64 = [&](floatx16 (&acc)[2][4], char* obase, const bool r2, const bool r2_pixel, const bool x1_halo_only, const bool keep, const bool out_px) {
         floatx4 bias4[2][4];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -800,7 +805,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                     tt += bias4[mb][g];
                     xres[mb][i][g] = tt * 0.2f + xres[mb][i][g];
                 }
-                if (!r2) x_row_out(mb, i, obase, (!P3_SEAM && mb == 0) || !x1_halo_only || halo, x1_halo_only);   // (RRDB-closing: the fp16 values are not final yet)
+                if (!r2) x_row_out(mb, i, obase, keep || (!P3_SEAM && mb == 0) || !x1_halo_only || halo, x1_halo_only);   // (RRDB-closing: the fp16 values are not final yet)
             }
         }
         if (r2) {
@@ -811,16 +816,17 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) xres[mb][i][g] = xres[mb][i][g] * 0.2f + a2[slot][mb][g];
-                    x_row_out(mb, i, obase, (!P3_SEAM && mb == 0) || !x1_halo_only || halo, x1_halo_only);
+                    x_row_out(mb, i, obase, keep || (!P3_SEAM && mb == 0) || !x1_halo_only || halo, x1_halo_only);
                 }
                 // the RRDB-level stream goes back to memory (fragment order): private to this workgroup
-                const float* q = pp.xrr + rowb;
-                const unsigned vo = (unsigned)frag_lane * 4u;
+                // (out_px: behind the LAST RDB of a training forward it is the trunk's output: to `xr`, pixel order = NHWC)
+                const float* q = (out_px ? pp.xr : pp.xrr) + rowb;
+                const unsigned vo = out_px ? (unsigned)(X * 64 + hi * 4) * 4u : (unsigned)frag_lane * 4u;
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const unsigned long long sb = uni64((unsigned long long)(q + mb * 1024 + g * 256));
+                        const unsigned long long sb = uni64((unsigned long long)(q + (out_px ? mb * 32 + g * 8 : mb * 1024 + g * 256)));
                         asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(vo), "v"(xres[mb][i][g]), "s"(sb) : "memory");
                     }
             };
@@ -967,7 +973,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             if (P3_LAZYDRAIN) next_bias = bias_request(T[kk + 1].bias, kk == 3 ? 64 : 32);   // (older than the epilogue's stores)
             if (PROF) p2 = __builtin_amdgcn_s_memtime();
             uintx4 kept[4][2];
-            const bool halo_only = P3_SKIPST && P3_S1 && (kk == 0 || (P3_X2REG && kk == 1));
+            const bool halo_only = P3_SKIPST && P3_S1 && (kk == 0 || (P3_X2REG && kk == 1)) && !(P3_TRAIN && pp.keep_all);   // (training forward: whole planes)
             if constexpr (P3_DEFER && decltype(last_nw_tag)::value == 5)     // conv1..3: rows 1, 2 are finished by the next layer's step 0
                 epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept, halo_only, std::true_type{}, A_BIAS_OFF);
             else
@@ -1072,7 +1078,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             }
             const bool r2 = (rdb % 3) == 2;
             if (PROF) p2 = __builtin_amdgcn_s_memtime();
-            epi64(acc, dnxt - (long)Y0 * pp.row_b, r2, rdb == 2, P3_SKIPST && P3_S1 && rdb + 1 < nrdb);   // (the last x goes out whole: conv_body reads it)
+            epi64(acc, dnxt - (long)Y0 * pp.row_b, r2, rdb == 2, P3_SKIPST && P3_S1 && rdb + 1 < nrdb, P3_TRAIN && pp.keep_all != 0,
+                  P3_TRAIN && pp.out_pixel != 0 && rdb + 1 == nrdb);   // (the last x goes out whole: conv_body reads it)
             if (PROF) p3 = __builtin_amdgcn_s_memtime();
             // RDB seam: the next conv1's first chunk is THIS layer's output on the neighbours: publish now, then wait for them
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1100,9 +1107,14 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 unsigned long long* q = pp.prof + ((long)blockIdx.x * pp.nlayers + L) * 6;
                 q[0] = p1; q[1] = p2; q[2] = p3; q[3] = (p1 - p0) | ((unsigned long long)(__builtin_amdgcn_s_memtime() - p3) << 32); q[4] = t_sync; q[5] = t_vm;
             }
-            char* tmp = dcur;
-            dcur = dnxt;
-            dnxt = tmp;
+            if (P3_TRAIN && pp.dense_stride) {      // (training forward: one dense buffer per RDB)
+                dcur = dnxt;
+                dnxt = dnxt + pp.dense_stride;
+            } else {
+                char* tmp = dcur;
+                dcur = dnxt;
+                dnxt = tmp;
+            }
         }
     }
 }

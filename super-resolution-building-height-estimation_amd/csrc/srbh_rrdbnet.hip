@@ -218,6 +218,33 @@ extern "C" int srbh_rrdbnet_trunk_train_forward(const srbh_rrdbnet_desc* d, floa
     return SRBH_OK;
 }
 
+/* The same forward as ONE launch of the persistent trunk kernel (round 5): the inference trunk's ptrunk3_kernel walking a row of dense buffers
+ * (RDB i in dense_all + i * dense_stride) with every plane stored whole, its fp32 output written to xr in pixel order.  Same arithmetic in the
+ * same order as the per-layer sequence above: xr and every saved plane come out bit-identical (tests/test_sr_stage.py).  aux: scratch of
+ * srbh_rrdbnet_trunk_train_aux_bytes(B, H, W) bytes (0 = this geometry is not the kernel's: 64-pixel-wide tiles, H %% 8 == 0).  *used = 0:
+ * nothing was launched, call srbh_rrdbnet_trunk_train_forward.  A halo-exchange timeout (never seen) turns xr into NaN. */
+extern "C" size_t srbh_rrdbnet_trunk_train_aux_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W != TILE_W || (H % TILE_H) != 0) return 0;
+    return ptrunk_aux_bytes(B, (H + TILE_H - 1) / TILE_H);
+}
+extern "C" int srbh_rrdbnet_trunk_train_forward_persistent(const srbh_rrdbnet_desc* d, float* xr, float* xrr, void* dense_all, size_t dense_stride,
+                                                           int B, int H, int W, void* aux, void* stream, int* used) {
+    SRBH_REQUIRE(d && d->rdb && xr && xrr && dense_all && aux && used && B > 0 && H > 0 && W > 0 && dense_stride > 0,
+                 "srbh_rrdbnet_trunk_train_forward_persistent: bad arguments");
+    *used = 0;
+    static const bool off = getenv("SRBH_SR_PTRUNK") && getenv("SRBH_SR_PTRUNK")[0] == '0';
+    if (off || srbh_rrdbnet_trunk_train_aux_bytes(B, H, W) == 0) return SRBH_OK;
+    int rc = srbh_nhwc32_to_act16(xr, dense_all, B, 64, H, W, 6, 0, 1.0f, 0, stream);      // dense buffer 0 <- feat as fp16 planes 0..1 (xr == xrr == feat)
+    if (rc) return rc;
+    int cur = 0;
+    if ((rc = ptrunk_run(d, dense_all, nullptr, xr, xrr, B, H, W, aux, (hipStream_t)stream, used, &cur, (long)dense_stride))) return rc;
+    if (!*used) return SRBH_OK;
+    const int* err_word = (const int*)((const char*)aux + ptrunk_err_offset(B, (H + TILE_H - 1) / TILE_H));
+    hipLaunchKernelGGL(poison_on_error_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, err_word, xr, (size_t)B * H * W * 64);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
 // g_a: gradient of the trunk output on entry (fp32 NHWC64); g_b, g_c: scratch of the same size.  Returns the gradient of the trunk
 // input in *g_out (one of the three).  packs: per RDB `pack_stride` bytes, gradient conv j (dX4, dX3, dX2, dX1, dx) at pack_off[j].
 // dw_all: per RDB 239 616 floats in conv1..conv5 order (OIHW each); db_all: per RDB 192 floats in G order [g5 (64) | g4 | g3 | g2 | g1].

@@ -115,6 +115,8 @@ def _fast_buffers(B, Hh, Ww, n_rdb, dev):
     nb = (nb + 255) // 256 * 256
     ws = {"nb": nb, "D": torch.zeros((n_rdb + 1) * nb, dtype=torch.uint8, device=dev), "G": torch.zeros(2 * nb, dtype=torch.uint8, device=dev),
           "wg": torch.empty(L.srbh_rrdbnet_trunk_wgrad_ws_bytes() // 4, dtype=torch.float32, device=dev), "busy": False, "gen": 0}
+    na = L.srbh_rrdbnet_trunk_train_aux_bytes(B, Hh, Ww)          # scratch of the persistent forward (0: this geometry runs the per-layer sequence)
+    ws["aux"] = torch.zeros(na, dtype=torch.uint8, device=dev) if na else None
     pool.append(ws)
     return ws
 
@@ -180,6 +182,9 @@ def _conv16(a_in, in_chunks, w, bias, cout, B, Hh, Ww, *, lrelu=0, out16=None, o
         _lib.check(L.srbh_conv3x3_f16(C.byref(a), _lib.stream_ptr()), "conv3x3_f16")
 
 
+TRUNK_FWD_PATHS = {"persistent": 0, "per_layer": 0}      # which form the fast training forward took (tests / bench: no silent fallback)
+
+
 def _trunk_fast_forward(net, feat):
     """feat (B,H,W,64) fp32 NHWC -> trunk output (same shape, fp32) + the saved dense buffers.  (The launch loop -- 5 convs per RDB,
     mirroring csrc/srbh_rrdbnet.hip's per-layer inference sequence -- runs behind ONE C-ABI call: at batch 8 the ~350 + ~2 000 launches of
@@ -191,8 +196,15 @@ def _trunk_fast_forward(net, feat):
     _, desc = net._ensure_packed(feat.device)
     lease = _FastLease(ws)
     xr, xrr = feat.clone(), feat.clone()
-    _lib.check(L.srbh_rrdbnet_trunk_train_forward(C.byref(desc), xr.data_ptr(), xrr.data_ptr(), ws["D"].data_ptr(), ws["nb"], B, Hh, Ww,
-                                                  _lib.stream_ptr()), "rrdbnet_trunk_train_forward")
+    used = C.c_int(0)
+    if ws.get("aux") is not None:
+        # the 345 convs as ONE launch of the inference trunk's persistent kernel over the row of dense buffers (bit-identical to the sequence below)
+        _lib.check(L.srbh_rrdbnet_trunk_train_forward_persistent(C.byref(desc), xr.data_ptr(), xrr.data_ptr(), ws["D"].data_ptr(), ws["nb"], B, Hh, Ww,
+                                                                 ws["aux"].data_ptr(), _lib.stream_ptr(), C.byref(used)), "rrdbnet_trunk_train_forward_persistent")
+    if not used.value:
+        _lib.check(L.srbh_rrdbnet_trunk_train_forward(C.byref(desc), xr.data_ptr(), xrr.data_ptr(), ws["D"].data_ptr(), ws["nb"], B, Hh, Ww,
+                                                      _lib.stream_ptr()), "rrdbnet_trunk_train_forward")
+    TRUNK_FWD_PATHS["persistent" if used.value else "per_layer"] += 1
     return xr, lease
 
 

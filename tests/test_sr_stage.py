@@ -305,3 +305,34 @@ def test_fast_mode_two_forwards_before_backward_keep_their_own_saved_planes():
             assert torch.allclose(inter_b[k], alone_b[k], rtol=1e-4, atol=1e-6 * float(alone_b[k].abs().max())), k
     finally:
         RA.set_train_precision("f32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks,B", [(1, 2), (2, 3)])
+def test_persistent_training_forward_equals_the_per_layer_sequence(blocks, B):
+    """SR-stage "fast" training forward of the trunk (SR/rrdbnet_arch.py:136-167 per RDB) as ONE launch of the inference trunk's persistent kernel
+    over a row of dense buffers (srbh_rrdbnet_trunk_train_forward_persistent) against the per-layer sequence: the fp32 output and EVERY saved
+    plane of every RDB (what the backward reads: LeakyReLU masks, weight-gradient operands) bit-identical."""
+    from srbh_amd import rrdbnet_autograd as RA
+    from srbh_amd import synth
+    from srbh_amd.rrdbnet import RRDBNet
+    net = RRDBNet(3, 3, num_block=blocks)
+    net.load_state_dict(synth.rrdbnet_state_dict(num_block=blocks, seed=5, mode="stress"))
+    net = net.to("cuda:0")
+    feat = rand((B, 64, 64, 64), 31).to("cuda:0").contiguous()          # (B, H, W, 64) fp32 NHWC
+    outs = []
+    for persistent in (True, False):
+        RA._FAST_WS.clear()
+        n0 = dict(RA.TRUNK_FWD_PATHS)
+        ws = RA._fast_buffers(B, 64, 64, blocks * 3, feat.device)
+        if not persistent:
+            ws["aux"] = None
+        xr, lease = RA._trunk_fast_forward(net, feat)
+        torch.cuda.synchronize()
+        assert RA.TRUNK_FWD_PATHS["persistent" if persistent else "per_layer"] == n0["persistent" if persistent else "per_layer"] + 1
+        outs.append((xr.clone(), lease.ws["D"].clone()))
+        lease.release()
+    RA._FAST_WS.clear()
+    assert bool(torch.isfinite(outs[0][0]).all())
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
