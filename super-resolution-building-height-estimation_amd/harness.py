@@ -367,16 +367,20 @@ class TrainStep:
         self._static = None
         # pipelined step (see the class docstring): state of the feature prefetch
         self._pf = None              # _Prefetch of the batch the next call is expected to bring
+        self._pipe_h16 = True        # element type of the prefetched features (set per step by _pipe_ok)
         self._next = None            # the batch announced by the running call
         self._trunk_stream = None
         self._pipe_hook = None
         self.pipelined_steps = 0     # steps that consumed prefetched features (bench / tests read it)
 
     def _pipe_ok(self, h16):
-        """the prefetch computes what features_for_head would hand to this head: fp16 channels_last features on the fast trunk path"""
-        return (not self.use_graph and FEATURE_H16 and h16 and os.environ.get("SRBH_TRAIN_PIPELINE", "1") == "1"
-                and os.environ.get("SRBH_PTAIL", "1") != "0" and isinstance(getattr(self.net, "hrfeat", None), self._H.HRfeature)
-                and hasattr(self.net_hr, "_use_strict") and not self.net_hr._use_strict() and not getattr(self.net_hr, "_train_path", False))
+        """the prefetch computes what features_for_head would hand to this head on the fast trunk path: fp16 channels_last features for the
+        fp16-operand head (`self._pipe_h16`), fp32 ones for the exact-fp32 head"""
+        ok = (not self.use_graph and os.environ.get("SRBH_TRAIN_PIPELINE", "1") == "1"
+              and isinstance(getattr(self.net, "hrfeat", None), self._H.HRfeature)
+              and hasattr(self.net_hr, "_use_strict") and not self.net_hr._use_strict() and not getattr(self.net_hr, "_train_path", False))
+        self._pipe_h16 = bool(ok and FEATURE_H16 and h16 and os.environ.get("SRBH_PTAIL", "1") != "0")
+        return ok
 
     def _launch_prefetch(self, nb):
         lr = nb[0]
@@ -392,7 +396,8 @@ class TrainStep:
             B = x3.shape[0]
             cap = pipe_images(dev)
             n = -(-B // cap)
-            fea = torch.empty((B, 64, 4 * x3.shape[2], 4 * x3.shape[3]), dtype=torch.float16, device=dev, memory_format=torch.channels_last)
+            odt = torch.float16 if self._pipe_h16 else torch.float32
+            fea = torch.empty((B, 64, 4 * x3.shape[2], 4 * x3.shape[3]), dtype=odt, device=dev, memory_format=torch.channels_last)
             # even split, in multiples of 8 images where the cap allows (the trunk's tile map keeps the row blocks of an image on one XCD
             # when the launch has a multiple of 8 workgroups per row block index, i.e. whole images per XCD: 64 -> 24, 24, 16 under a cap of 24)
             per = -(-B // n)
@@ -408,7 +413,7 @@ class TrainStep:
                     i = 0
                     while i < B:
                         j = min(B, i + per)
-                        self.net_hr.forward_feature(x3[i:j], out=fea[i:j], out_dtype=torch.float16)
+                        self.net_hr.forward_feature(x3[i:j], out=fea[i:j], out_dtype=odt)
                         i = j
             finally:
                 L.srbh_ptail_wgs_cap(prev)
@@ -520,7 +525,7 @@ class TrainStep:
             self._pipe_hook = first.register_post_accumulate_grad_hook(self._on_head_backward_done)
         if not pipe:
             self._next = None
-        if pf is not None and pipe and pf.matches(lr):
+        if pf is not None and pipe and pf.matches(lr) and pf.fea.dtype == (torch.float16 if self._pipe_h16 else torch.float32):
             hr_fea = pf                       # a handle: the model issues the encoder / decoders first and waits in front of HRfeature
             self.pipelined_steps += 1
         else:

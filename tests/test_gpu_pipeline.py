@@ -79,3 +79,31 @@ def test_pipelined_steps_follow_the_serial_steps(monkeypatch):
     ts2(batches[0])
     l_ref = float(ts2(batches[2])[0])
     assert abs(l_other - l_ref) <= 2e-2 * abs(l_ref)
+
+
+def test_pipelined_step_with_the_exact_fp32_head_prefetches_fp32_features(monkeypatch):
+    """head_precision="f32" (the mode the <= 5e-5 gradient-parity tests pin): the prefetch hands over fp32 features, bit-identical to the inline
+    forward_feature, and the pipelined loss curve follows the serial one"""
+    from srbh_amd import encoders
+    from srbh_amd.harness import TrainStep, synthetic_batch
+    monkeypatch.setattr(encoders, "DROP_CONNECT", 0.0)
+    monkeypatch.setenv("SRBH_PIPE_IMAGES", "3")
+    dev = "cuda:0"
+    batches = [synthetic_batch(4, 200 + i % 2, dev) for i in range(5)]
+    curves = []
+    for pipelined in (False, True):
+        net_hr, net = _nets(dev)
+        ts = TrainStep(net_hr, net, dev, lr=1e-4, status_every=0, head_precision="f32")
+        cur = []
+        for i, b in enumerate(batches):
+            nxt = batches[i + 1] if (pipelined and i + 1 < len(batches)) else None
+            cur.append(float(ts(b, next_batch=nxt)[0]))
+            if pipelined and nxt is not None:
+                assert ts._pf is not None and ts._pf.fea.dtype == torch.float32
+                with torch.no_grad():
+                    want = net_hr.forward_feature(nxt[0].index_select(1, ts._rgb_idx))
+                assert torch.equal(ts._pf(), want)
+        curves.append(cur)
+        assert ts.pipelined_steps == (len(batches) - 1 if pipelined else 0)
+    for i, (a, b) in enumerate(zip(*curves)):
+        assert abs(a - b) <= 2e-2 * abs(a), (i, a, b)
