@@ -75,6 +75,12 @@
 // staging items of such a step.  No LDS word, no barrier; a neighbour that is late makes the wave spin (bounded) where it stands.  A
 // timed-out spin sets the error word and the wave CARRIES ON (uniform control flow, every later spin ends at once on the error word): the
 // launch finishes with garbage that poison_on_error_kernel turns into NaN, as before.  Same arithmetic, same bits.
+// The counted wait is only as good as the count: a VMEM statement whose EXEC mask is EMPTY for a wave never reaches vmcnt, so the window
+// between the polls and the check may hold only statements every wave issues (see `stage_item`: the half-masked fifth weight statement
+// sits behind the check).  With it inside the window waves 2, 3 counted one too many, looked at the second poll (the lower neighbour's --
+// theirs) before it had landed and took whatever the register held: bit-identical in every quiet test and soak, 4 of 300 prefetches
+// wrong (once NaN) when the trunk shared the chip with the training step (profiles/r05bo_soak_pipelined_variants.txt; fixed:
+// profiles/r05bp_soak_fixed.txt, 1 500 of 1 500 identical; tests/test_gpu_pipeline.py keeps a short contended soak).
 #define P3_WFLAGS 1
 #endif
 
@@ -276,12 +282,12 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     };
     auto poll_check = [&](auto k_tag, const int need) {   // k = VMEM instructions this wave issued behind poll_issue()
         constexpr int K = decltype(k_tag)::value;
-        static_assert(K == 0 || K == 5 || K == 9 || K == 12 || K == 16, "vmcnt immediates of poll_check");
+        static_assert(K == 0 || K == 4 || K == 8 || K == 11 || K == 15, "vmcnt immediates of poll_check");
         if constexpr (K == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pq_up), "+v"(pq_dn)::"memory");
-        else if constexpr (K == 5) asm volatile("s_waitcnt vmcnt(5)" : "+v"(pq_up), "+v"(pq_dn)::"memory");
-        else if constexpr (K == 9) asm volatile("s_waitcnt vmcnt(9)" : "+v"(pq_up), "+v"(pq_dn)::"memory");
-        else if constexpr (K == 12) asm volatile("s_waitcnt vmcnt(12)" : "+v"(pq_up), "+v"(pq_dn)::"memory");
-        else asm volatile("s_waitcnt vmcnt(16)" : "+v"(pq_up), "+v"(pq_dn)::"memory");
+        else if constexpr (K == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(pq_up), "+v"(pq_dn)::"memory");
+        else if constexpr (K == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(pq_up), "+v"(pq_dn)::"memory");
+        else if constexpr (K == 11) asm volatile("s_waitcnt vmcnt(11)" : "+v"(pq_up), "+v"(pq_dn)::"memory");
+        else asm volatile("s_waitcnt vmcnt(15)" : "+v"(pq_up), "+v"(pq_dn)::"memory");
         // (branch-free: a missing neighbour polled the workgroup's own word and is "infinitely far ahead")
         f_up = max(__builtin_amdgcn_readfirstlane(pq_up), inf_up);
         f_dn = max(__builtin_amdgcn_readfirstlane(pq_dn), inf_dn);
@@ -479,26 +485,38 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         };
         auto read_item = [&](const int g, const int r, const int set) { read_from(cb_tag, sbi, sbw, g, r, set); };
         auto stage_item = [&](const int d) {
-            if constexpr (FL && IN == 2) {            // weights, the own rows from registers, the border, [check], the neighbours' rows
-                if (d < NW) {
+            // Flagged steps count the VMEM instructions between the polls and the check (poll_check's vmcnt immediate), so
+            // every statement in that window must be one that EVERY wave issues: a statement whose EXEC mask is empty for a
+            // wave (the 5th weight statement for waves 2, 3; the tail input statement) is dropped by the hardware without
+            // touching vmcnt, the wave's count is then one short and the check reads the second poll before it has landed
+            // (found by tools/soak_pipelined.py: rare stale halo rows when the trunk shares the chip).  The last weight
+            // statement therefore goes behind the check, with the statements of the neighbours' rows.
+            if constexpr (FL && IN == 2) {            // weights but the last, the own rows from registers, the border, [check], the last weights, the neighbours' rows
+                if (d < NW - 1) {
                     dma_item(std::integral_constant<int, 0>{}, nw_tag, d, ibase, wbase, din_w, dw_w);
-                } else if (d < NW + 8) {
-                    const int e = d - NW, i = e >> 1, m = e & 1;
+                } else if (d < NW + 7) {
+                    const int e = d - (NW - 1), i = e >> 1, m = e & 1;
                     *(uintx4*)(dst + soff + sswz[m] + i * G::ROW_B) = rsrc[i][m];
-                } else if (d == NW + 8) {
+                } else if (d == NW + 7) {
                     if (lane < 20) *(uintx4*)(dst + boff) = uintx4{0u, 0u, 0u, 0u};
+                } else if (d == NW + 8) {
+                    if (need >= 0) poll_check(std::integral_constant<int, NW - 1>{}, need);
+                    dma_item(std::integral_constant<int, 0>{}, nw_tag, NW - 1, ibase, wbase, din_w, dw_w);
                 } else {
                     const int h = d - NW - 9;
-                    if (h == 0 && need >= 0) poll_check(std::integral_constant<int, NW>{}, need);
                     dma(SC1{}, ibase, hoff[h], din_w + (h ? G::ROWS - 1 : 0) * G::ROW_B + PIX_B);
                 }
                 return;
             }
-            if constexpr (FL && IN == 1) {            // weights, the statements of rows 1..8, [check], the four statements holding rows 0 and 9
-                if (d < NW) {
+            if constexpr (FL && IN == 1) {            // weights but the last, the statements of rows 1..8, [check], the last weights, the four statements holding rows 0 and 9
+                if (d < NW - 1) {
                     dma_item(std::integral_constant<int, 11>{}, nw_tag, d + 11, ibase, wbase, din_w, dw_w);
+                } else if (d < NW + 6) {
+                    dma_item(std::integral_constant<int, 11>{}, nw_tag, d - (NW - 1), ibase, wbase, din_w, dw_w);
+                } else if (d == NW + 6) {
+                    if (need >= 0) poll_check(std::integral_constant<int, NW + 6>{}, need);
+                    dma_item(std::integral_constant<int, 11>{}, nw_tag, NW - 1 + 11, ibase, wbase, din_w, dw_w);
                 } else {
-                    if (d == NW + 7 && need >= 0) poll_check(std::integral_constant<int, NW + 7>{}, need);
                     dma_item(std::integral_constant<int, 11>{}, nw_tag, d - NW, ibase, wbase, din_w, dw_w);
                 }
                 return;

@@ -107,3 +107,32 @@ def test_pipelined_step_with_the_exact_fp32_head_prefetches_fp32_features(monkey
         assert ts.pipelined_steps == (len(batches) - 1 if pipelined else 0)
     for i, (a, b) in enumerate(zip(*curves)):
         assert abs(a - b) <= 2e-2 * abs(a), (i, a, b)
+
+
+def test_prefetch_beside_a_running_step_is_bit_identical_full_depth():
+    """the full 23-RRDB trunk in 16-image launches on the second stream WHILE the step's kernels take and leave CUs: the contended
+    regime in which a neighbour's progress word really is behind when a wave polls it (tools/soak_pipelined.py is the long form; it
+    found the one-short vmcnt window of the per-wave poll, srbh_ptrunk3_kernel.h `stage_item`).  Every second prefetch is compared
+    bit for bit with the inline features of the same batch."""
+    from oracle import synth
+    from srbh_amd import hrfuse as H
+    from srbh_amd.harness import TrainStep, features_for_head, synthetic_batch
+    from srbh_amd.models import SRRegress_Cls_feature
+    from srbh_amd.rrdbnet import RRDBNet
+    dev = "cuda:0"
+    net_hr = RRDBNet(3, 3)
+    net_hr.load_state_dict(synth.rrdbnet_state_dict(seed=1337))
+    torch.manual_seed(0)
+    net = SRRegress_Cls_feature("efficientnet-b4", in_channels=8, super_in=64, super_mid=16, upscale=4, isaggre=True, chans_build=7)
+    ts = TrainStep(net_hr.to(dev), net.to(dev), dev, status_every=0)
+    batches = [synthetic_batch(64, 10 + i, dev) for i in range(2)]
+    with torch.no_grad(), H.head_precision("f16"):
+        want = [features_for_head(net_hr, b[0].index_select(1, ts._rgb_idx), True, model=net).clone() for b in batches]
+    torch.cuda.synchronize()
+    for i in range(80):
+        ts(batches[i % 2], next_batch=batches[(i + 1) % 2])
+        if i % 2:
+            assert torch.equal(ts._pf(), want[(i + 1) % 2]), f"prefetched features of step {i} differ from the inline forward"
+    torch.cuda.synchronize()
+    net_hr.check_status()
+    assert ts.pipelined_steps == 79
