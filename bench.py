@@ -554,7 +554,7 @@ def bench_sr_train(args, rank, world, dev, dist, steps, warmup, batch=8):
                                            "mixed": "f16 / bf16 operands on the head's 16x16x16 kernels", "f32": "exact fp32 matrix cores"}[modes[0]],
             "data": "synthetic tiles, random-init weights",
             "config": {"workload": f"RRDBNet x4 ({args.num_block} RRDB) forward + backward (all parameter gradients), batch {batch}/GPU (SURVEY 8f-4)", "batch": batch, "mode": modes[0],
-                       "trunk_forward_calls": dict(_sr_paths())},      # 'fast' mode: persistent (one launch of the inference trunk's kernel) vs per_layer: no silent fallback
+                       "trunk_forward_calls": dict(_sr_paths()[0]), "trunk_backward_calls": dict(_sr_paths()[1])},      # 'fast' mode: persistent (one launch of the inference trunk's kernel) vs per_layer: no silent fallback
             "roofline": {"bound": "mfma", "achieved": head["achieved_tflops"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(head["achieved_tflops"] / PEAK_F16_TFLOPS, 4), "gflop_per_step": round(gf_tile * batch, 1),
                          "note": "whole fwd+bwd (345 dense-block convs x 3 + the non-trunk convs in 'mixed'), not one kernel"},
@@ -563,7 +563,7 @@ def bench_sr_train(args, rank, world, dev, dist, steps, warmup, batch=8):
 
 def _sr_paths():
     from srbh_amd import rrdbnet_autograd as RA
-    return RA.TRUNK_FWD_PATHS
+    return RA.TRUNK_FWD_PATHS, RA.TRUNK_BWD_PATHS
 
 
 def bench_feature(args, rank, world, dev, dist):

@@ -185,6 +185,8 @@ SIGNATURES = {
     "srbh_rrdbnet_trunk_train_aux_bytes": (_sz, [_i, _i, _i]),
     "srbh_rrdbnet_trunk_train_forward_persistent": (_i, [C.POINTER(RRDBNetDesc), _vp, _vp, _vp, _sz, _i, _i, _i, _vp, _vp, C.POINTER(C.c_int)]),
     "srbh_rrdbnet_trunk_wgrad_ws_bytes": (_sz, []),
+    "srbh_rrdbnet_trunk_train_backward_persistent": (_i, [_i, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp, _vp, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp, _vp, _vp, _i, _i, _i, _vp, _vp,
+                                                          C.POINTER(_i)]),
     "srbh_rrdbnet_trunk_train_backward": (_i, [_i, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srbh_act16_wgrad_b16": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "srbh_conv_first_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -81,7 +81,7 @@ size_t ptrunk_aux_bytes(int B, int tiles_per_img);
 size_t ptrunk_err_offset(int B, int tiles_per_img);
 int ptail_run(const srbh_conv3x3_args* a, hipStream_t stream, int* used);
 int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr, float* xrr, int B, int H, int W,
-               void* aux, hipStream_t stream, int* used, int* final_cur, long train_stride = 0);
+               void* aux, hipStream_t stream, int* used, int* final_cur, long train_stride = 0, const void* mask = nullptr, long mask_stride = 0);
 
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)

@@ -65,6 +65,9 @@ struct PParams {
     long dense_stride;          // > 0: RDB i reads / writes dense[0] + i * dense_stride (its output x goes to RDB i + 1's buffer); 0: the two buffers alternate
     int keep_all;               // 1: every plane is stored whole (the backward reads them), not only the rows a neighbour reads
     int out_pixel;              // 1: the trunk's fp32 output goes to `xr` in pixel order (NHWC) behind the last RDB
+    // BACKWARD of the dense blocks (ptrunk3_kernel<., 1>; srbh_rrdbnet_trunk_train_backward_persistent): the saved forward planes are the LeakyReLU masks
+    const char* mask;           // dense buffer of the forward RDB whose gradient runs first (the LAST forward RDB)
+    long mask_stride;           // bytes from one running RDB's forward buffer to the next one's (negative: the RDBs run in reverse)
 };
 
 constexpr unsigned SPIN_LIMIT = 4u << 20;
@@ -1186,9 +1189,12 @@ static int ptrunk2_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, f
 // returns SRBH_OK and sets *used = 1 when the persistent path ran, *used = 0 when the shape is not eligible
 // train_stride > 0 = the TRAINING forward (srbh_rrdbnet_trunk_train_forward_persistent): dense0 is RDB 0's buffer of a row of buffers train_stride
 // bytes apart (dense1 ignored), every plane is stored whole, and the trunk's fp32 output goes to `xr` in pixel order; variant 3 only.
+// mask != nullptr = the BACKWARD of the dense blocks (srbh_rrdbnet_trunk_train_backward_persistent; needs train_stride > 0): `d` holds the gradient convs'
+// bf16 packs in running (reverse) order, mask / mask_stride walk the saved forward buffers.
 int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr, float* xrr, int B, int H, int W,
-               void* aux, hipStream_t stream, int* used, int* final_cur, long train_stride) {
+               void* aux, hipStream_t stream, int* used, int* final_cur, long train_stride, const void* mask, long mask_stride) {
     *used = 0;
+    if (mask && train_stride <= 0) return SRBH_OK;
     if (W > TILE_W || d->num_block <= 0 || d->num_block > MAX_BLOCKS) return SRBH_OK;
     int dev = 0;
     SRBH_HIP(hipGetDevice(&dev));
@@ -1208,6 +1214,7 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
     SRBH_ONCE_PER_DEVICE({
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
+        SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk3_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
         SRBH_HIP(hipFuncSetAttribute((const void*)ptrunk_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B));
@@ -1260,6 +1267,8 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
         PParams pp;
         pp.dense_stride = train_stride;
         pp.keep_all = pp.out_pixel = train_stride > 0;
+        pp.mask = mask ? (const char*)mask + (long)b0 * g.img_b : nullptr;
+        pp.mask_stride = mask_stride;
         pp.dense[0] = (char*)dense0 + (long)b0 * g.img_b;
         pp.dense[1] = (train_stride > 0 ? (char*)dense0 + train_stride : (char*)dense1) + (long)b0 * g.img_b;
         pp.img_b = g.img_b;
@@ -1291,7 +1300,10 @@ int ptrunk_run(const srbh_rrdbnet_desc* d, void* dense0, void* dense1, float* xr
         // variant 3 (RDB-unrolled instruction stream, see srbh_ptrunk3_kernel.h): full 8 x 64 tiles only
         const bool v3 = variant == 3 && W == TILE_W && (H % TILE_H) == 0 && (reg_res || train_stride > 0);
         g_trunk_kernel = v3 ? "ptrunk3_kernel" : "ptrunk_kernel";
-        if (v3 && pp.prof)
+        if (mask) {
+            SRBH_REQUIRE(v3, "ptrunk_run: the backward form is ptrunk3_kernel's");
+            hipLaunchKernelGGL((ptrunk3_kernel<0, 1>), dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
+        } else if (v3 && pp.prof)
             hipLaunchKernelGGL((ptrunk3_kernel<1>), dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);
         else if (v3)
             hipLaunchKernelGGL((ptrunk3_kernel<0>), dim3(pp.nblocks), dim3(256), LDS_B, stream, pp);

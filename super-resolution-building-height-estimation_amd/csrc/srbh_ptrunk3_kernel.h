@@ -135,7 +135,15 @@
 #endif
 
 // PROF = 1 (developer timeline, SRBH_PT_PROF): s_memtime stamps per layer in ptrunk_kernel's 6-slot format
-template <int PROF>
+// BW = 1 (round 5): the BACKWARD of the dense blocks on the same instruction stream.  The data gradient of an RDB is an RDB run on
+// gradients (csrc/srbh_rrdbnet.hip, srbh_rrdbnet_trunk_train_backward: G = [g5 | g4 | g3 | g2 | g1], transposed + flipped weight slices stacked
+// along K, the shapes of the forward exactly), so the launch walks the RDBs in reverse over a row of G buffers with three differences: bf16
+// operands (v_mfma_f32_32x32x16_bf16: gradients need fp32's exponent range; the 16-bit planes are rounded RNE as the per-layer kernel does),
+// the cout-32 epilogue multiplies by the LeakyReLU derivative read from the SAVED forward plane (y > 0 ? 1 : 0.2; pp.mask + rdb *
+// pp.mask_stride, plane 5 - kk) instead of applying bias + LeakyReLU, and every plane is kept (the weight gradients read them).  The residual
+// recurrences are the forward's own: with the stream held as 0.04 x the gradient, `x = 0.2 conv5 + x` is g5' = 0.2 (dx + cur) and the
+// RRDB-closing `x = 0.2 x + x_rrdb` is the RRDB's skip connection (see srbh_rrdbnet_trunk_train_backward_persistent).
+template <int PROF, int BW = 0>
 __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -557,7 +565,10 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g & 1][dy][mb], P[g & 1][i + dy], acc[mb][i], 0, 0, 0);
+                if constexpr (BW)
+                    acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[g & 1][dy][mb]), __builtin_bit_cast(bf16x8, P[g & 1][i + dy]), acc[mb][i], 0, 0, 0);
+                else
+                    acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g & 1][dy][mb], P[g & 1][i + dy], acc[mb][i], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (P3_SPREAD) {
                     const int k = m / RSTRIDE;
@@ -663,8 +674,21 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         if (tid < nb) ((float*)(smem + bias_lds))[tid] = bias_v;
     };
     // ---- epilogue of a cout-32 layer: bias, leaky ReLU, fp16, straight from the MFMA D layout (see ptrunk_kernel)
-    auto epi32 = [&](floatx16 (&acc)[1][4], char* oplane, uintx4 (&keep)[4][2], const bool halo_only, auto park_tag, const int bias_lds) {
+    auto epi32 = [&](floatx16 (&acc)[1][4], char* oplane, uintx4 (&keep)[4][2], const bool halo_only, auto park_tag, const int bias_lds, const char* mplane = nullptr) {
         constexpr bool PARK = decltype(park_tag)::value;   // rows 1, 2 are parked for the next layer's step 0 (defer_unit)
+        static_assert(!(BW && PARK && P3_DEFER), "the backward form keeps no parked rows");
+        // BW: the saved forward plane's 16-byte records of this lane's four rows (same addresses as the stores below, in the mask buffer): all
+        // eight loads go out in front of the arithmetic (the operand registers of the K loop are dead here)
+        uintx4 mk[4][2];
+        if constexpr (BW) {
+#pragma unroll
+            for (int io = 0; io < 4; ++io) {
+                const int i = io == 0 ? 0 : io == 1 ? 3 : io - 1;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    mk[i][m] = *(const uintx4*)(mplane + (long)(Y0 + wr * 4 + i + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16);
+            }
+        }
         floatx4 bias4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) bias4[g] = *(const floatx4*)((const float*)(smem + bias_lds) + g * 8 + hi * 4);
@@ -685,6 +709,33 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             const int Y = Y0 + wr * 4 + i;
             const bool st = !halo_only || (i == 0 && wr == 0) || (i == 3 && wr == 1);   // (wave-uniform)
             unsigned hp[4][2];
+            if constexpr (BW) {
+                // the mask back in the accumulator's layout (permlane32_swap is its own inverse), then g *= (y > 0 ? 1 : 0.2) and bf16 (RNE)
+                unsigned mq[4][2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    auto u0 = __builtin_amdgcn_permlane32_swap(mk[i][m][0], mk[i][m][2], false, false);
+                    auto u1 = __builtin_amdgcn_permlane32_swap(mk[i][m][1], mk[i][m][3], false, false);
+                    mq[2 * m][0] = u0[0];
+                    mq[2 * m + 1][0] = u0[1];
+                    mq[2 * m][1] = u1[0];
+                    mq[2 * m + 1][1] = u1[1];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const half4 mh = __builtin_bit_cast(half4, uint2{mq[g][0], mq[g][1]});
+                    unsigned r[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float w = acc[0][i][g * 4 + q];
+                        w = (float)mh[q] > 0.f ? w : w * 0.2f;
+                        const unsigned u = __builtin_bit_cast(unsigned, w);
+                        r[q] = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+                    }
+                    hp[g][0] = r[0] | (r[1] << 16);
+                    hp[g][1] = r[2] | (r[3] << 16);
+                }
+            } else {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 floatx4 w;
@@ -700,6 +751,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 const uint2 u = __builtin_bit_cast(uint2, h4);
                 hp[g][0] = u.x;
                 hp[g][1] = u.y;
+            }
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -724,12 +776,24 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         unsigned hp[4][2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            half4 h4;
+            if constexpr (BW) {       // bf16, RNE (as srbh_nhwc32_to_act16's bf16 form)
+                unsigned r[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) h4[q] = (_Float16)xres[mb][i][g][q];
-            const uint2 u = __builtin_bit_cast(uint2, h4);
-            hp[g][0] = u.x;
-            hp[g][1] = u.y;
+                for (int q = 0; q < 4; ++q) {
+                    const float xv = xres[mb][i][g][q];       // (a copy: __builtin_bit_cast applied to the vector ELEMENT read element 0 for every q)
+                    const unsigned u = __builtin_bit_cast(unsigned, xv);
+                    r[q] = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+                }
+                hp[g][0] = r[0] | (r[1] << 16);
+                hp[g][1] = r[2] | (r[3] << 16);
+            } else {
+                half4 h4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h4[q] = (_Float16)xres[mb][i][g][q];
+                const uint2 u = __builtin_bit_cast(uint2, h4);
+                hp[g][0] = u.x;
+                hp[g][1] = u.y;
+            }
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -871,6 +935,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     // ---- prologue of the launch: conv1 of RDB 0 reads conv_first's output (no flag needed)
     char* dcur = pp.dense[0] + tile_off;    // tile origin of plane 0 in the running RDB's dense buffer
     char* dnxt = pp.dense[1] + tile_off;
+    const char* mcur = BW ? pp.mask + tile_off : nullptr;   // the saved forward planes of the RDB whose gradient is running (BW)
     // (P3_SEAM: conv1's step-0 weights live in phase-A stage 0's INPUT area -- step 0 reads the resident plane, not that area -- which is where
     //  conv5's last step can prefetch them at the seam)
     stage_cold(dcur, smem, pp.layers[0].w, smem + stage_off(1, 0) + (P3_SEAM ? 0 : IN_EX), W5{});
@@ -995,7 +1060,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             if constexpr (P3_DEFER && decltype(last_nw_tag)::value == 5)     // conv1..3: rows 1, 2 are finished by the next layer's step 0
                 epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept, halo_only, std::true_type{}, A_BIAS_OFF);
             else
-                epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept, halo_only, std::false_type{}, PL ? A_BIAS_OFF + (kk & 1) * 128 : A_BIAS_OFF);
+                epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept, halo_only, std::false_type{}, PL ? A_BIAS_OFF + (kk & 1) * 128 : A_BIAS_OFF,
+                      BW ? mcur + (long)(5 - kk) * pp.plane_b - (long)Y0 * pp.row_b : nullptr);
             constexpr int NK = (P3_DEFER && decltype(last_nw_tag)::value == 5) ? 2 : 4;     // rows available now: 0 and 3, or all
             if (kk == 0) {
 #pragma unroll
@@ -1125,6 +1191,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 unsigned long long* q = pp.prof + ((long)blockIdx.x * pp.nlayers + L) * 6;
                 q[0] = p1; q[1] = p2; q[2] = p3; q[3] = (p1 - p0) | ((unsigned long long)(__builtin_amdgcn_s_memtime() - p3) << 32); q[4] = t_sync; q[5] = t_vm;
             }
+            if constexpr (BW) mcur += pp.mask_stride;
             if (P3_TRAIN && pp.dense_stride) {      // (training forward: one dense buffer per RDB)
                 dcur = dnxt;
                 dnxt = dnxt + pp.dense_stride;

@@ -362,3 +362,85 @@ extern "C" int srbh_rrdbnet_trunk_train_backward(int num_block, const void* dens
     *g_out = gout;
     return SRBH_OK;
 }
+
+/* The same backward with the 345 data-gradient convs as ONE launch of the persistent trunk kernel (round 5; ptrunk3_kernel<., 1>): the gradient of a
+ * dense block is a dense block on gradients, so the launch walks the RDBs in reverse over a ROW of G buffers (G_all + k * g_stride for the k-th RDB
+ * from the end; n_rdb + 1 buffers, zero borders) with the saved forward buffers as LeakyReLU masks, and the weight / bias gradients of all RDBs
+ * follow on two streams.  The kernel's residual recurrences are the forward's: it runs on x = 0.04 g (g = gradient of the trunk output), where
+ *   x' = 0.2 conv5(G) + x         is  0.2 (dx + cur)  with  x = 0.2 cur  (cur = gradient entering the RDB: `a.skip = cur` above), and
+ *   x  = 0.2 x + x_rrdb           is  the RRDB's skip  (cur + gout) / 25  with  x_rrdb = gout / 25,
+ * so every g5 plane the weight gradients read comes out at its true scale and the result is 25 x the launch's output.  Same operands (bf16, RNE)
+ * and the same accumulation order per conv as the per-layer form; the fp32 streams differ from it in the last bit (0.2 applied to conv5's sum,
+ * not to the stream).  zero_bias: >= 64 zero floats.  wgrad_ws: TWO workspaces of srbh_rrdbnet_trunk_wgrad_ws_bytes().  aux: the scratch of the
+ * persistent forward.  g_a is read, g_b / g_c are scratch; *g_out = the gradient of the trunk input (one of g_b, g_c).  *used = 0: nothing was
+ * launched (geometry not the kernel's, or SRBH_SR_PTRUNK_BWD=0): call srbh_rrdbnet_trunk_train_backward. */
+extern "C" int srbh_rrdbnet_trunk_train_backward_persistent(int num_block, const void* dense_all, size_t dense_stride, const void* packs, size_t pack_stride,
+                                                            const size_t* pack_off, const float* zero_bias, const float* g_a, float* g_b, float* g_c,
+                                                            float** g_out, void* G_all, size_t g_stride, float* dw_all, float* db_all, float* wgrad_ws,
+                                                            int B, int H, int W, void* aux, void* stream, int* used) {
+    SRBH_REQUIRE(num_block > 0 && dense_all && packs && pack_off && zero_bias && g_a && g_b && g_c && g_out && G_all && dw_all && db_all && wgrad_ws && aux && used &&
+                 dense_stride > 0 && g_stride > 0, "srbh_rrdbnet_trunk_train_backward_persistent: bad arguments");
+    *used = 0;
+    static const bool off = getenv("SRBH_SR_PTRUNK_BWD") && getenv("SRBH_SR_PTRUNK_BWD")[0] == '0';
+    if (off || srbh_rrdbnet_trunk_train_aux_bytes(B, H, W) == 0) return SRBH_OK;
+    const long n = (long)B * H * W * 64;
+    const int n_rdb = num_block * 3;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = srbh_axpby_f32(g_b, 0.04f, g_a, 0.f, nullptr, n, stream))) return rc;
+    if ((rc = srbh_axpby_f32(g_c, 0.04f, g_a, 0.f, nullptr, n, stream))) return rc;
+    if ((rc = srbh_nhwc32_to_act16(g_a, G_all, B, 64, H, W, 6, 0, 0.04f, 1, stream))) return rc;      // g5 of the last RDB (bf16)
+    std::vector<srbh_conv_w> cw((size_t)n_rdb * 5);
+    for (int k = 0; k < n_rdb; ++k)
+        for (int j = 0; j < 5; ++j) {
+            cw[(size_t)k * 5 + j] = srbh_conv_w{};
+            cw[(size_t)k * 5 + j].w = (const char*)packs + (size_t)(n_rdb - 1 - k) * pack_stride + pack_off[j];
+            cw[(size_t)k * 5 + j].bias = zero_bias;
+        }
+    srbh_rrdbnet_desc dd = {};
+    dd.num_block = num_block;
+    dd.rdb = cw.data();
+    int cur = 0;
+    if ((rc = ptrunk_run(&dd, G_all, nullptr, g_b, g_c, B, H, W, aux, st, used, &cur, (long)g_stride,
+                         (const char*)dense_all + (size_t)(n_rdb - 1) * dense_stride, -(long)dense_stride))) return rc;
+    if (!*used) return SRBH_OK;
+    const int* err_word = (const int*)((const char*)aux + ptrunk_err_offset(B, (H + TILE_H - 1) / TILE_H));
+    hipLaunchKernelGGL(poison_on_error_kernel, dim3(256), dim3(256), 0, st, err_word, g_b, (size_t)n);
+    SRBH_HIP(hipGetLastError());
+    if ((rc = srbh_axpby_f32(g_c, 25.f, g_b, 0.f, nullptr, n, stream))) return rc;
+    *g_out = g_c;
+    // weight / bias gradients: RDB by RDB, alternating between the caller's stream and the side stream (a weight-gradient launch fills the chip; the
+    // small reduces and plane sums of one RDB run beside the next RDB's)
+    static const int CH0[5] = {160, 128, 96, 64, 0}, COUT[5] = {32, 32, 32, 32, 64}, CIN[5] = {64, 96, 128, 160, 192};
+    static const long DWOFF[5] = {0, 9L * 2048, 9L * (2048 + 3072), 9L * (2048 + 3072 + 4096), 9L * (2048 + 3072 + 4096 + 5120)};
+    constexpr long DW_RDB = 9L * 26624;
+    static const bool overlap = !(getenv("SRBH_SR_OVERLAP") && getenv("SRBH_SR_OVERLAP")[0] == '0');
+    if (overlap) {
+        if ((rc = side_init())) return rc;
+        SRBH_HIP(hipEventRecord(g_side.ready[0], st));
+        SRBH_HIP(hipStreamWaitEvent(g_side.s, g_side.ready[0], 0));
+    }
+    const size_t ws_floats = srbh_rrdbnet_trunk_wgrad_ws_bytes() / sizeof(float);
+    for (int k = 0; k < n_rdb; ++k) {
+        const int i = n_rdb - 1 - k;                 // forward index of the RDB whose gradients sit in G buffer k
+        const bool on_side = overlap && (k & 1);
+        hipStream_t ws_st = on_side ? g_side.s : st;
+        float* ws = wgrad_ws + (on_side ? ws_floats : 0);
+        const char* Gk = (const char*)G_all + (size_t)k * g_stride;
+        const char* D = (const char*)dense_all + (size_t)i * dense_stride;
+        if ((rc = srbh_act16_channel_sum(Gk, B, H, W, 6, 0, 6, 1, db_all + (long)i * 192, ws_st))) return rc;
+        if ((rc = srbh_hwgrad_defer(1))) return rc;
+        size_t woff = 0;
+        for (int c = 0; c < 5; ++c) {
+            rc = srbh_act16_wgrad_b16(D, 6, CIN[c], Gk, 6, CH0[c], COUT[c], B, H, W, dw_all + (long)i * DW_RDB + DWOFF[c], ws + woff, ws_st);
+            if (rc) { srbh_hwgrad_flush(ws_st); return rc; }
+            woff += srbh_hwgrad_ws_bytes(COUT[c], CIN[c], 3) / sizeof(float);
+        }
+        if ((rc = srbh_hwgrad_flush(ws_st))) return rc;
+    }
+    if (overlap) {
+        SRBH_HIP(hipEventRecord(g_side.done[0], g_side.s));
+        SRBH_HIP(hipStreamWaitEvent(st, g_side.done[0], 0));
+    }
+    return SRBH_OK;
+}

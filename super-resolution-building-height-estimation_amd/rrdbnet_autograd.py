@@ -113,10 +113,14 @@ def _fast_buffers(B, Hh, Ww, n_rdb, dev):
     L = _lib.lib()
     nb = L.srbh_act16_bytes(B, 192, Hh, Ww)
     nb = (nb + 255) // 256 * 256
-    ws = {"nb": nb, "D": torch.zeros((n_rdb + 1) * nb, dtype=torch.uint8, device=dev), "G": torch.zeros(2 * nb, dtype=torch.uint8, device=dev),
-          "wg": torch.empty(L.srbh_rrdbnet_trunk_wgrad_ws_bytes() // 4, dtype=torch.float32, device=dev), "busy": False, "gen": 0}
-    na = L.srbh_rrdbnet_trunk_train_aux_bytes(B, Hh, Ww)          # scratch of the persistent forward (0: this geometry runs the per-layer sequence)
+    na = L.srbh_rrdbnet_trunk_train_aux_bytes(B, Hh, Ww)          # scratch of the persistent forward / backward (0: this geometry runs the per-layer sequences)
+    # G: the gradient planes -- a row of n_rdb + 1 buffers for the persistent backward (every RDB's G is kept for the weight gradients that follow
+    # the launch), two (double buffered against the side stream) for the per-layer sequence
+    ws = {"nb": nb, "D": torch.zeros((n_rdb + 1) * nb, dtype=torch.uint8, device=dev),
+          "G": torch.zeros(((n_rdb + 1) if na and BWD_PERSISTENT else 2) * nb, dtype=torch.uint8, device=dev),
+          "wg": torch.empty(2 * (L.srbh_rrdbnet_trunk_wgrad_ws_bytes() // 4), dtype=torch.float32, device=dev), "busy": False, "gen": 0}
     ws["aux"] = torch.zeros(na, dtype=torch.uint8, device=dev) if na else None
+    ws["zero_bias"] = torch.zeros(64, dtype=torch.float32, device=dev)
     pool.append(ws)
     return ws
 
@@ -146,7 +150,9 @@ class _TrunkBwdPacks:
             for sz in sizes:
                 offs.append(tot)
                 tot += (sz + 255) // 256 * 256
-            buf = torch.zeros(n * tot, dtype=torch.uint8, device=dev)
+            buf = getattr(self, "buf", None)          # (rewritten in place: the persistent backward's layer table -- pointers into it -- stays cached)
+            if buf is None or buf.numel() != n * tot or buf.device != dev:
+                buf = torch.zeros(n * tot, dtype=torch.uint8, device=dev)
             for i in range(n):
                 for j, t in enumerate(stacked):
                     _lib.check(L.srbh_pack_conv3x3_b16(t[i].data_ptr(), t.shape[1], t.shape[2], buf.data_ptr() + i * tot + offs[j], st), "pack_conv3x3_b16")
@@ -182,6 +188,8 @@ def _conv16(a_in, in_chunks, w, bias, cout, B, Hh, Ww, *, lrelu=0, out16=None, o
         _lib.check(L.srbh_conv3x3_f16(C.byref(a), _lib.stream_ptr()), "conv3x3_f16")
 
 
+TRUNK_BWD_PATHS = {"persistent": 0, "per_layer": 0}      # ... and the fast training backward
+BWD_PERSISTENT = _os.environ.get("SRBH_SR_PTRUNK_BWD", "1") != "0"
 TRUNK_FWD_PATHS = {"persistent": 0, "per_layer": 0}      # which form the fast training forward took (tests / bench: no silent fallback)
 
 
@@ -227,7 +235,17 @@ def _trunk_fast_backward(net, lease, g, grads):
     db_all = torch.empty(n_rdb * 192, dtype=torch.float32, device=dev)
     offs = (C.c_size_t * 5)(*packs.offs)
     gout = C.c_void_p()
-    _lib.check(L.srbh_rrdbnet_trunk_train_backward(len(net.body), ws["D"].data_ptr(), ws["nb"], packs.buf.data_ptr(), packs.stride, offs,
+    used = C.c_int(0)
+    if BWD_PERSISTENT and ws.get("aux") is not None and ws["G"].numel() >= (n_rdb + 1) * ws["nb"]:
+        # the 345 data-gradient convs as ONE launch of the persistent trunk kernel's bf16 form, the weight gradients of all RDBs behind it
+        _lib.check(L.srbh_rrdbnet_trunk_train_backward_persistent(len(net.body), ws["D"].data_ptr(), ws["nb"], packs.buf.data_ptr(), packs.stride, offs,
+                                                                  ws["zero_bias"].data_ptr(), g.data_ptr(), gb.data_ptr(), gc.data_ptr(), C.byref(gout),
+                                                                  ws["G"].data_ptr(), ws["nb"], dw_all.data_ptr(), db_all.data_ptr(), ws["wg"].data_ptr(),
+                                                                  B, Hh, Ww, ws["aux"].data_ptr(), _lib.stream_ptr(), C.byref(used)),
+                   "rrdbnet_trunk_train_backward_persistent")
+    TRUNK_BWD_PATHS["persistent" if used.value else "per_layer"] += 1
+    if not used.value:
+        _lib.check(L.srbh_rrdbnet_trunk_train_backward(len(net.body), ws["D"].data_ptr(), ws["nb"], packs.buf.data_ptr(), packs.stride, offs,
                                                    g.data_ptr(), gb.data_ptr(), gc.data_ptr(), C.byref(gout), ws["G"].data_ptr(), ws["nb"], dw_all.data_ptr(),
                                                    db_all.data_ptr(), ws["wg"].data_ptr(), B, Hh, Ww, _lib.stream_ptr()), "rrdbnet_trunk_train_backward")
     i = 0

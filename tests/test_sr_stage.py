@@ -336,3 +336,46 @@ def test_persistent_training_forward_equals_the_per_layer_sequence(blocks, B):
     assert bool(torch.isfinite(outs[0][0]).all())
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks,B", [(1, 2), (2, 3)])
+def test_persistent_training_backward_follows_the_per_layer_sequence(blocks, B):
+    """SR-stage "fast" training backward of the trunk (the gradient of SR/rrdbnet_arch.py:136-167 per RDB, SR/rrdbnet_arch.py:538-592's
+    l_g_total.backward()): the data-gradient convs of all RDBs as ONE launch of the persistent kernel's bf16 form
+    (srbh_rrdbnet_trunk_train_backward_persistent) against the per-layer sequence on the SAME saved planes and the same output gradient.  Same bf16
+    operands and summation order per conv; the fp32 gradient streams differ in their last bits (0.2 applied to conv5's sum instead of the stream),
+    which moves a bf16 rounding here and there: input gradient and every weight / bias gradient within 2e-3 rel-L2 (measured ~1e-4)."""
+    from srbh_amd import rrdbnet_autograd as RA
+    from srbh_amd import synth
+    from srbh_amd.rrdbnet import RRDBNet
+    net = RRDBNet(3, 3, num_block=blocks)
+    net.load_state_dict(synth.rrdbnet_state_dict(num_block=blocks, seed=5, mode="stress"))
+    net = net.to("cuda:0")
+    feat = rand((B, 64, 64, 64), 31).to("cuda:0").contiguous()
+    g = rand((B, 64, 64, 64), 32, -1.0, 1.0).to("cuda:0").contiguous()
+    res = []
+    old = RA.BWD_PERSISTENT
+    try:
+        for persistent in (True, False):
+            RA.BWD_PERSISTENT = True          # (both runs on the row of G buffers: only the launch form differs)
+            RA._FAST_WS.clear()
+            xr, lease = RA._trunk_fast_forward(net, feat)
+            RA.BWD_PERSISTENT = persistent
+            n0 = dict(RA.TRUNK_BWD_PATHS)
+            grads = {}
+            gin = RA._trunk_fast_backward(net, lease, g.clone(), grads)
+            torch.cuda.synchronize()
+            key = "persistent" if persistent else "per_layer"
+            assert RA.TRUNK_BWD_PATHS[key] == n0[key] + 1
+            lease.release()
+            named = {n_: grads[id(p)].clone() for n_, p in net.named_parameters() if id(p) in grads}
+            res.append((gin.clone(), named))
+    finally:
+        RA.BWD_PERSISTENT = old
+        RA._FAST_WS.clear()
+    (g0, w0), (g1, w1) = res
+    assert bool(torch.isfinite(g0).all()) and len(w0) == blocks * 3 * 10 and w0.keys() == w1.keys()
+    assert O.rel_l2(g0.cpu(), g1.cpu()) <= 2e-3
+    worst = max(O.rel_l2(w0[k].cpu(), w1[k].cpu()) for k in w0)
+    assert worst <= 2e-3, worst
