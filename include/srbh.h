@@ -194,13 +194,21 @@ int srbh_rrdbnet_trunk_train_backward(int num_block, const void* dense_all, size
 /* the same backward (SR/rrdbnet_arch.py:538-592's l_g_total.backward() through the 69 dense blocks, SR/rrdbnet_arch.py:136-167) with the 345
  * data-gradient convs as ONE launch of the persistent trunk kernel's bf16 form: G_all = a ROW of num_block * 3 + 1 zero-bordered gradient buffers
  * g_stride bytes apart (buffer k = the k-th RDB from the end), the saved forward planes as LeakyReLU masks; the weight / bias gradients follow on
- * two streams (wgrad_ws = TWO workspaces of srbh_rrdbnet_trunk_wgrad_ws_bytes()).  zero_bias = 64 zero floats; aux = the persistent forward's
+ * two streams (wgrad_ws = TWO workspaces of srbh_rrdbnet_trunk_wgrad_ws_bytes()) or, given trunk_wgrad_ws, as one launch (srbh_trunk_wgrad).  zero_bias = 64 zero floats; aux = the persistent forward's
  * scratch.  g_a is only read; *g_out is g_b or g_c.  Same operands and per-conv summation order as the call above, the fp32 streams agree with it
  * to the last bits.  *used = 0: nothing ran, use the call above. */
 int srbh_rrdbnet_trunk_train_backward_persistent(int num_block, const void* dense_all, size_t dense_stride, const void* packs, size_t pack_stride,
                                                  const size_t* pack_off, const float* zero_bias, const float* g_a, float* g_b, float* g_c,
-                                                 float** g_out, void* G_all, size_t g_stride, float* dw_all, float* db_all, float* wgrad_ws, int B,
-                                                 int H, int W, void* aux, void* stream, int* used);
+                                                 float** g_out, void* G_all, size_t g_stride, float* dw_all, float* db_all, float* wgrad_ws,
+                                                 void* trunk_wgrad_ws, int B, int H, int W, void* aux, void* stream, int* used);
+/* Weight and bias gradients of ALL dense blocks in one launch + one reduce (the gradients of SR/rrdbnet_arch.py:136-167's five convs w.r.t. their
+ * parameters, for every RDB): dense_all = the forward's row of saved buffers (fp16 planes), G_all = the backward's row of gradient buffers (bf16
+ * planes, buffer k = the k-th RDB from the end), dw_all / db_all as srbh_rrdbnet_trunk_train_backward; ws = srbh_trunk_wgrad_ws_bytes() bytes
+ * (0: geometry not taken -- 64-pixel-wide images, H % 8 == 0).  bf16 operands (the saved planes rounded RNE while staged), fp32 accumulation,
+ * fixed summation order.  trunk_wgrad_ws above = this workspace (NULL there = the general kernel, RDB by RDB). */
+size_t srbh_trunk_wgrad_ws_bytes(int num_block, int B, int H, int W);
+int srbh_trunk_wgrad(int num_block, const void* dense_all, size_t dense_stride, const void* G_all, size_t g_stride, int B, int H, int W, float* dw_all,
+                     float* db_all, void* ws, void* stream);
 
 /* Synchronises `stream` and returns 0 if the last srbh_rrdbnet_forward on this workspace completed normally, or a
  * negative code if the persistent trunk kernel gave up waiting for a neighbour workgroup (its spins are bounded so a

@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_PATH = os.path.join(_HERE, "libsrbh.so")
 _DEV_LIB = os.environ.get("SRBH_LIB_PATH")      # developer A/B only (tools/ab_variants.sh): load another build of the same ABI
-SOURCES = ["srbh_conv3x3.hip", "srbh_aux.hip", "srbh_rrdbnet.hip", "srbh_ptrunk.hip", "srbh_ptail.hip", "srbh_head.hip", "srbh_head_bwd.hip", "srbh_mosaic.hip", "srbh_loader.hip", "srbh_loss.hip", "srbh_dwconv.hip", "srbh_mbconv.hip", "srbh_pwconv.hip", "srbh_dconv.hip", "srbh_optim.hip"]
+SOURCES = ["srbh_conv3x3.hip", "srbh_aux.hip", "srbh_rrdbnet.hip", "srbh_ptrunk.hip", "srbh_trunk_wgrad.hip", "srbh_ptail.hip", "srbh_head.hip", "srbh_head_bwd.hip", "srbh_mosaic.hip", "srbh_loader.hip", "srbh_loss.hip", "srbh_dwconv.hip", "srbh_mbconv.hip", "srbh_pwconv.hip", "srbh_dconv.hip", "srbh_optim.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # NOTE: `-mllvm -amdgpu-mfma-vgpr-form=1` (accumulators in VGPRs: no v_accvgpr copies at K-loop back-edges).  Round 1 saw the
 # first persistent trunk kernel produce non-deterministic garbage with it; round 3 re-ran it on the current kernel (ptrunk3:
@@ -185,8 +185,10 @@ SIGNATURES = {
     "srbh_rrdbnet_trunk_train_aux_bytes": (_sz, [_i, _i, _i]),
     "srbh_rrdbnet_trunk_train_forward_persistent": (_i, [C.POINTER(RRDBNetDesc), _vp, _vp, _vp, _sz, _i, _i, _i, _vp, _vp, C.POINTER(C.c_int)]),
     "srbh_rrdbnet_trunk_wgrad_ws_bytes": (_sz, []),
-    "srbh_rrdbnet_trunk_train_backward_persistent": (_i, [_i, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp, _vp, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp, _vp, _vp, _i, _i, _i, _vp, _vp,
-                                                          C.POINTER(_i)]),
+    "srbh_rrdbnet_trunk_train_backward_persistent": (_i, [_i, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp, _vp, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
+                                                          _vp, C.POINTER(_i)]),
+    "srbh_trunk_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "srbh_trunk_wgrad": (_i, [_i, _vp, _sz, _vp, _sz, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "srbh_rrdbnet_trunk_train_backward": (_i, [_i, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "srbh_act16_wgrad_b16": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "srbh_conv_first_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -371,13 +371,14 @@ extern "C" int srbh_rrdbnet_trunk_train_backward(int num_block, const void* dens
  *   x  = 0.2 x + x_rrdb           is  the RRDB's skip  (cur + gout) / 25  with  x_rrdb = gout / 25,
  * so every g5 plane the weight gradients read comes out at its true scale and the result is 25 x the launch's output.  Same operands (bf16, RNE)
  * and the same accumulation order per conv as the per-layer form; the fp32 streams differ from it in the last bit (0.2 applied to conv5's sum,
- * not to the stream).  zero_bias: >= 64 zero floats.  wgrad_ws: TWO workspaces of srbh_rrdbnet_trunk_wgrad_ws_bytes().  aux: the scratch of the
+ * not to the stream).  zero_bias: >= 64 zero floats.  wgrad_ws: TWO workspaces of srbh_rrdbnet_trunk_wgrad_ws_bytes(); trunk_wgrad_ws: srbh_trunk_wgrad_ws_bytes()
+ * bytes (the one-launch weight gradients; NULL = the general kernel RDB by RDB through wgrad_ws).  aux: the scratch of the
  * persistent forward.  g_a is read, g_b / g_c are scratch; *g_out = the gradient of the trunk input (one of g_b, g_c).  *used = 0: nothing was
  * launched (geometry not the kernel's, or SRBH_SR_PTRUNK_BWD=0): call srbh_rrdbnet_trunk_train_backward. */
 extern "C" int srbh_rrdbnet_trunk_train_backward_persistent(int num_block, const void* dense_all, size_t dense_stride, const void* packs, size_t pack_stride,
                                                             const size_t* pack_off, const float* zero_bias, const float* g_a, float* g_b, float* g_c,
                                                             float** g_out, void* G_all, size_t g_stride, float* dw_all, float* db_all, float* wgrad_ws,
-                                                            int B, int H, int W, void* aux, void* stream, int* used) {
+                                                            void* trunk_wgrad_ws, int B, int H, int W, void* aux, void* stream, int* used) {
     SRBH_REQUIRE(num_block > 0 && dense_all && packs && pack_off && zero_bias && g_a && g_b && g_c && g_out && G_all && dw_all && db_all && wgrad_ws && aux && used &&
                  dense_stride > 0 && g_stride > 0, "srbh_rrdbnet_trunk_train_backward_persistent: bad arguments");
     *used = 0;
@@ -409,7 +410,10 @@ extern "C" int srbh_rrdbnet_trunk_train_backward_persistent(int num_block, const
     SRBH_HIP(hipGetLastError());
     if ((rc = srbh_axpby_f32(g_c, 25.f, g_b, 0.f, nullptr, n, stream))) return rc;
     *g_out = g_c;
-    // weight / bias gradients: RDB by RDB, alternating between the caller's stream and the side stream (a weight-gradient launch fills the chip; the
+    // weight / bias gradients of all RDBs: one launch over (RDB, plane pair, tile range) + one reduce (srbh_trunk_wgrad.hip) ...
+    static const bool one_launch = !(getenv("SRBH_SR_TRUNK_WGRAD") && getenv("SRBH_SR_TRUNK_WGRAD")[0] == '0');
+    if (trunk_wgrad_ws && one_launch) return srbh_trunk_wgrad(num_block, dense_all, dense_stride, G_all, g_stride, B, H, W, dw_all, db_all, trunk_wgrad_ws, stream);
+    // ... or (no workspace given / SRBH_SR_TRUNK_WGRAD=0) RDB by RDB with the general kernel, alternating between the caller's stream and the side stream (a weight-gradient launch fills the chip; the
     // small reduces and plane sums of one RDB run beside the next RDB's)
     static const int CH0[5] = {160, 128, 96, 64, 0}, COUT[5] = {32, 32, 32, 32, 64}, CIN[5] = {64, 96, 128, 160, 192};
     static const long DWOFF[5] = {0, 9L * 2048, 9L * (2048 + 3072), 9L * (2048 + 3072 + 4096), 9L * (2048 + 3072 + 4096 + 5120)};

@@ -121,6 +121,8 @@ def _fast_buffers(B, Hh, Ww, n_rdb, dev):
           "wg": torch.empty(2 * (L.srbh_rrdbnet_trunk_wgrad_ws_bytes() // 4), dtype=torch.float32, device=dev), "busy": False, "gen": 0}
     ws["aux"] = torch.zeros(na, dtype=torch.uint8, device=dev) if na else None
     ws["zero_bias"] = torch.zeros(64, dtype=torch.float32, device=dev)
+    nt = L.srbh_trunk_wgrad_ws_bytes(n_rdb // 3, B, Hh, Ww) if na and BWD_PERSISTENT else 0      # the one-launch weight gradients behind the persistent backward
+    ws["twg"] = torch.empty(nt, dtype=torch.uint8, device=dev) if nt else None
     pool.append(ws)
     return ws
 
@@ -190,6 +192,7 @@ def _conv16(a_in, in_chunks, w, bias, cout, B, Hh, Ww, *, lrelu=0, out16=None, o
 
 TRUNK_BWD_PATHS = {"persistent": 0, "per_layer": 0}      # ... and the fast training backward
 BWD_PERSISTENT = _os.environ.get("SRBH_SR_PTRUNK_BWD", "1") != "0"
+TRUNK_WGRAD = _os.environ.get("SRBH_SR_TRUNK_WGRAD", "1") != "0"      # weight gradients of all RDBs as one launch (srbh_trunk_wgrad) behind the persistent backward
 TRUNK_FWD_PATHS = {"persistent": 0, "per_layer": 0}      # which form the fast training forward took (tests / bench: no silent fallback)
 
 
@@ -241,6 +244,7 @@ def _trunk_fast_backward(net, lease, g, grads):
         _lib.check(L.srbh_rrdbnet_trunk_train_backward_persistent(len(net.body), ws["D"].data_ptr(), ws["nb"], packs.buf.data_ptr(), packs.stride, offs,
                                                                   ws["zero_bias"].data_ptr(), g.data_ptr(), gb.data_ptr(), gc.data_ptr(), C.byref(gout),
                                                                   ws["G"].data_ptr(), ws["nb"], dw_all.data_ptr(), db_all.data_ptr(), ws["wg"].data_ptr(),
+                                                                  ws["twg"].data_ptr() if (TRUNK_WGRAD and ws.get("twg") is not None) else None,
                                                                   B, Hh, Ww, ws["aux"].data_ptr(), _lib.stream_ptr(), C.byref(used)),
                    "rrdbnet_trunk_train_backward_persistent")
     TRUNK_BWD_PATHS["persistent" if used.value else "per_layer"] += 1

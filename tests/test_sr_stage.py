@@ -379,3 +379,39 @@ def test_persistent_training_backward_follows_the_per_layer_sequence(blocks, B):
     assert O.rel_l2(g0.cpu(), g1.cpu()) <= 2e-3
     worst = max(O.rel_l2(w0[k].cpu(), w1[k].cpu()) for k in w0)
     assert worst <= 2e-3, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks,B", [(1, 2), (2, 5)])
+def test_one_launch_trunk_weight_gradients_equal_the_general_kernel(blocks, B):
+    """srbh_trunk_wgrad (weight + bias gradients of every RDB's five convs, SR/rrdbnet_arch.py:136-167, as one launch over (RDB, plane pair, tile
+    range) + one ordered reduce) against the general 16 x 16-block kernel called RDB by RDB on the SAME saved planes and gradient planes: same bf16
+    operands, fp32 accumulation in a different order -- every gradient within 2e-5 rel-L2 (B = 5: a tile count the four splits do not divide)."""
+    from srbh_amd import rrdbnet_autograd as RA
+    from srbh_amd import synth
+    from srbh_amd.rrdbnet import RRDBNet
+    net = RRDBNet(3, 3, num_block=blocks)
+    net.load_state_dict(synth.rrdbnet_state_dict(num_block=blocks, seed=5, mode="stress"))
+    net = net.to("cuda:0")
+    feat = rand((B, 64, 64, 64), 31).to("cuda:0").contiguous()
+    g = rand((B, 64, 64, 64), 32, -1.0, 1.0).to("cuda:0").contiguous()
+    res = []
+    old = RA.TRUNK_WGRAD
+    try:
+        for one_launch in (True, False):
+            RA._FAST_WS.clear()
+            xr, lease = RA._trunk_fast_forward(net, feat)
+            RA.TRUNK_WGRAD = one_launch
+            grads = {}
+            gin = RA._trunk_fast_backward(net, lease, g.clone(), grads)
+            torch.cuda.synchronize()
+            lease.release()
+            res.append((gin.clone(), {n_: grads[id(p)].clone() for n_, p in net.named_parameters() if id(p) in grads}))
+    finally:
+        RA.TRUNK_WGRAD = old
+        RA._FAST_WS.clear()
+    (g0, w0), (g1, w1) = res
+    assert torch.equal(g0, g1) and len(w0) == blocks * 3 * 10
+    for k in w0:
+        assert bool(torch.isfinite(w0[k]).all()) and float(w0[k].abs().max()) > 0, k
+        assert O.rel_l2(w0[k].cpu(), w1[k].cpu()) <= 2e-5, (k, O.rel_l2(w0[k].cpu(), w1[k].cpu()))
