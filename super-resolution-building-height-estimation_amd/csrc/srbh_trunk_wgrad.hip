@@ -8,13 +8,14 @@
 // channel tensors) gave every workgroup a 16 x 16 block: 345 launches per step, the same D tile staged (fp16 -> bf16, transposed) by cout/16 workgroups
 // and the same G tile by cin/16 of them: 9.2 ms per generator step at batch 8, 25 ms at batch 24 -- 60-80 % of the step.
 //
-// Here a workgroup owns ONE pair and a contiguous range of 8-row tiles.  Per tile the two 32-channel tiles are staged channel-major in LDS (the
-// matrix core wants 8 consecutive PIXELS of one channel per lane: K is the pixel index), x rounded fp16 -> bf16 (RNE) on the way as before, and every
-// wave runs its two rows: 8 K-steps x 9 taps of v_mfma_f32_32x32x16_bf16 (A = g^T: 32 cout x 16 pixels, B = x shifted by the tap: 16 pixels x 32 cin;
-// the three horizontal taps of a row come from one 16-byte read plus its two neighbour dwords and five v_alignbit).  The next tile's global loads are in
-// flight under the MFMAs (registers), the nine 32 x 32 accumulators stay in registers over the whole range, the four waves' sums meet in LDS once, and
-// the partial block goes to the workspace; a second kernel adds the splits in a fixed order and scatters into the OIHW gradients.  The bias gradient
-// (sum of g over pixels) rides along as a tenth accumulator against an all-ones B in the workgroups of D plane 0.
+// Here a workgroup owns ONE pair and a contiguous range of 4-row tiles.  Per tile the two 32-channel tiles are staged channel-major in LDS (the
+// matrix core wants 8 consecutive PIXELS of one channel per lane: K is the pixel index), x rounded fp16 -> bf16 (RNE) on the way as before, and each
+// of the four matrix-core waves runs one row: 4 K-steps x 9 taps of v_mfma_f32_32x32x16_bf16 (A = g^T: 32 cout x 16 pixels, B = x shifted by the tap:
+// 16 pixels x 32 cin; the three horizontal taps of a row come from one 16-byte read plus its two neighbour dwords and five v_alignbit).  Four more
+// waves do the staging one tile ahead into the other LDS stage (see the kernel), the nine 32 x 32 accumulators stay in registers over the whole
+// range, the four waves' sums meet in LDS once, and the partial block goes to the workspace; a second kernel adds the splits in a fixed order and
+// scatters into the OIHW gradients.  The bias gradient (sum of g over pixels) rides along as a tenth accumulator against an all-ones B in the
+// workgroups of D plane 0.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -22,6 +23,10 @@
 #include "srbh_internal.h"
 
 using namespace srbh;
+
+#ifndef TW_ABL
+#define TW_ABL 0      // developer aid (tools/time_trunk_wgrad.py): 1 = no MFMA phase, 2 = no LDS stores, 4 = no global loads (timing only: wrong results)
+#endif
 
 namespace {
 
@@ -31,14 +36,18 @@ typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
 typedef _Float16 half8v __attribute__((ext_vector_type(8)));
 
-constexpr int TW_W = 64, TW_H = 8;              // tile: 8 rows x 64 pixels (the image width)
+constexpr int TW_W = 64, TW_H = 4;              // tile: 4 rows x 64 pixels (the image width); images are H % 8 == 0 tall
 constexpr int RS = 80;                          // staged x row: image column c at position c + 8 (16-byte aligned operand reads), c = -4 .. 67
-constexpr int CSX = 10 * RS * 2 + 16;           // bytes per staged x channel (404 dwords = 20 mod 64: 16 lanes x 4 dwords hit 64 banks)
-constexpr int CSD = TW_H * TW_W * 2 + 16;       // bytes per staged g channel (260 dwords = 4 mod 64)
+constexpr int XROWS = TW_H + 2;
+constexpr int CSX = XROWS * RS * 2 + 16;        // bytes per staged x channel (244 dwords = 52 mod 64: 16 lanes x 4 dwords hit 64 banks)
+constexpr int CSD = TW_H * TW_W * 2 + 16;       // bytes per staged g channel (132 dwords = 4 mod 64)
 constexpr int X_B = 32 * CSX, D_B = 32 * CSD;
-constexpr int TWG_LDS_B = X_B + D_B;            // 84 992 B: one workgroup per CU
+constexpr int STAGE_B = X_B + D_B;              // 48 128 B
+constexpr int TWG_LDS_B = 2 * STAGE_B;          // two stages: 96 256 B, one workgroup of 8 waves per CU
 constexpr int NPAIR = 26;
-static_assert(TWG_LDS_B >= 2 * 9216 * 4, "the cross-wave reduce uses the staging area (two waves' blocks at a time)");
+constexpr int XUNITS = XROWS * 18 * 4, DUNITS = TW_H * 16 * 4;      // 432 / 256 staging units of (4 pixels x 8 channels)
+static_assert(TWG_LDS_B >= 2 * 9216 * 4 + 512, "the cross-wave reduce uses the staging area (two waves' blocks at a time)");
+static_assert(DUNITS == 256 && XUNITS <= 512, "one g unit and up to two x units per producer thread");
 
 struct TWParams {
     const char* dense;        // forward buffers: RDB i at dense + i * dense_stride
@@ -47,7 +56,7 @@ struct TWParams {
     long g_stride;
     long img_b;
     int plane_b, row_b;
-    int n_rdb, H, ntiles, tiles_per_img, tiles_per_split, nsplit;
+    int n_rdb, H, ntiles, tiles_per_img, tiles_per_split, nsplit, per_xcd;
     float* ws;                // [n_rdb][nsplit][26][9216]
     float* wsb;               // [n_rdb][nsplit][6][32]
 };
@@ -61,18 +70,114 @@ __device__ __forceinline__ void pair_planes(int p, int& gp, int& dp) {
     else { gp = 5; dp = p - 24; }
 }
 
-__global__ __launch_bounds__(256, 1) void trunk_wgrad_kernel(const TWParams p) {
+// 512 threads: waves 0..3 are the matrix-core waves (one tile row each: 4 K-steps x 9 taps per tile, the 32 x 32 x 9 accumulators in registers),
+// waves 4..7 the staging waves (global loads one tile ahead in registers, fp16 -> bf16 + 4-pixel transposes, ds_write into the OTHER LDS stage) --
+// one per SIMD of each kind, so a SIMD's staging VALU work runs in the shadow of its MFMAs instead of in front of them (as ONE set of waves doing
+// both in turn the kernel spent 4.4 us per 8-row tile against 1.1 us of matrix-core time).  One barrier per tile.
+__global__ __launch_bounds__(512, 1) void trunk_wgrad_kernel(const TWParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_x = smem;
-    char* s_d = smem + X_B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const bool producer = wave >= 4;
+    const int ptid = tid & 255;
+    // XCD-aware order: workgroup id b runs on XCD b % 8, which owns the contiguous range [x * per_xcd, (x + 1) * per_xcd) of (RDB, tile range, pair)
+    // triples, pair fastest: the 26 workgroups that read the same twelve planes' tiles sit on one XCD at the same time (worth 4 % at batch 8)
+    const int logical = (int)(blockIdx.x & 7) * p.per_xcd + (int)(blockIdx.x >> 3);
+    if (logical >= NPAIR * p.nsplit * p.n_rdb) return;
+    const int pair = logical % NPAIR, split = (logical / NPAIR) % p.nsplit, k = logical / (NPAIR * p.nsplit);
     int gp, dp;
-    pair_planes(blockIdx.x, gp, dp);
-    const int split = blockIdx.y, k = blockIdx.z;
+    pair_planes(pair, gp, dp);
     const char* xpl = p.dense + (long)(p.n_rdb - 1 - k) * p.dense_stride + (long)dp * p.plane_b;
     const char* gpl = p.G + (long)k * p.g_stride + (long)gp * p.plane_b;
     const int t0 = split * p.tiles_per_split, t1 = min(t0 + p.tiles_per_split, p.ntiles);
 
+    const bool with_bias = dp == 0;                 // (uniform)
+    // The two kinds of waves run SEPARATE loops with the same number of barriers (an s_barrier counts waves, not program counters): the
+    // accumulators are live only in the matrix-core branch and the staging registers only in the other, so the 256 registers a wave gets with
+    // eight waves per CU hold 160 of the one or 96 of the other -- as one loop with a role test inside, both were live everywhere (274 spills).
+    if (producer) {
+        // ---- staging waves: x = 6 rows x 18 four-pixel groups x 4 channel octets = 432 units (two per thread, the second partly idle), g = 4 x 16 x 4 = 256.
+        // TWO register sets: a tile's loads are issued two iterations before its LDS stores -- one iteration, ~0.6 us of matrix-core time, did not
+        // cover their latency (1.6 of the kernel's 5.5 ms at batch 24 were these waves waiting: tools/time_trunk_wgrad.py + -DTW_ABL)
+        uintx4 xrA[2][4], drA[4], xrB[2][4], drB[4];
+        auto load_tile = [&](const int t, uintx4 (&xr)[2][4], uintx4 (&dr)[4]) {
+            const int img = t / p.tiles_per_img, Y0 = (t - img * p.tiles_per_img) * TW_H;
+            const char* xb = xpl + (long)img * p.img_b + (long)Y0 * p.row_b;          // padded row Y0 = image row Y0 - 1
+            const char* gb = gpl + (long)img * p.img_b + (long)(Y0 + 1) * p.row_b;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int u = ptid + it * 256;
+                const int c8 = u & 3, qq = u >> 2, r = qq / 18, q = qq - r * 18;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 4 * q - 4 + i;                                      // image column
+                    uintx4 v = {0u, 0u, 0u, 0u};
+                    if (u < XUNITS && c >= -1 && c <= TW_W) v = *(const uintx4*)(xb + (long)r * p.row_b + (c + 1) * 64 + c8 * 16);
+                    xr[it][i] = v;
+                }
+            }
+            {
+                const int c8 = ptid & 3, qq = ptid >> 2, r = qq >> 4, q = qq & 15;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dr[i] = *(const uintx4*)(gb + (long)r * p.row_b + (4 * q + i + 1) * 64 + c8 * 16);
+            }
+        };
+        auto store_tile = [&](char* stage, const uintx4 (&xr)[2][4], const uintx4 (&dr)[4]) {
+            char* s_x = stage;
+            char* s_d = stage + X_B;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int u = ptid + it * 256;
+                if (u < XUNITS) {
+                    const int c8 = u & 3, qq = u >> 2, r = qq / 18, q = qq - r * 18;
+                    half8v h[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) h[i] = __builtin_bit_cast(half8v, xr[it][i]);
+                    char* o = s_x + (c8 * 8) * CSX + (r * RS + 4 * q + 4) * 2;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        *(uintx2*)__builtin_assume_aligned(o + j * CSX, 8) = uintx2{bf16x2_rne((float)h[0][j], (float)h[1][j]), bf16x2_rne((float)h[2][j], (float)h[3][j])};
+                }
+            }
+            {
+                const int c8 = ptid & 3, qq = ptid >> 2, r = qq >> 4, q = qq & 15;
+                char* o = s_d + (c8 * 8) * CSD + (r * TW_W + 4 * q) * 2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;
+                    const unsigned lo = __builtin_amdgcn_perm(dr[1][j >> 1], dr[0][j >> 1], sel);
+                    const unsigned hi2 = __builtin_amdgcn_perm(dr[3][j >> 1], dr[2][j >> 1], sel);
+                    *(uintx2*)__builtin_assume_aligned(o + j * CSD, 8) = uintx2{lo, hi2};
+                }
+            }
+        };
+        if (t0 < t1) {
+            load_tile(t0, xrA, drA);
+            store_tile(smem, xrA, drA);
+            if (t0 + 1 < t1) load_tile(t0 + 1, xrB, drB);
+            if (t0 + 2 < t1) load_tile(t0 + 2, xrA, drA);
+        }
+        __syncthreads();
+        // one tile per barrier; unrolled by two so that the register sets are named statically (tile t0 + r sits in set A for even r, B for odd r)
+        auto step = [&](const int t, uintx4 (&xr)[2][4], uintx4 (&dr)[4]) {      // xr / dr: the set holding tile t + 1
+            char* other = smem + (((t - t0) & 1) ^ 1) * STAGE_B;
+            if (t + 1 < t1) {
+                if (!(TW_ABL & 2)) store_tile(other, xr, dr);                        // tile t + 1 (loaded two iterations ago)
+                if (t + 3 < t1 && !(TW_ABL & 4)) load_tile(t + 3, xr, dr);           // in flight for two iterations
+            }
+            __syncthreads();                                   // the stage the other waves read: read out; other: complete
+        };
+        for (int t = t0; t < t1; t += 2) {
+            step(t, xrB, drB);
+            if (t + 1 < t1) step(t + 1, xrA, drA);
+        }
+        __syncthreads();       // the three barriers of the accumulators' meeting in LDS (below), and the bias gradient's
+        __syncthreads();
+        __syncthreads();
+        if (with_bias) __syncthreads();
+        return;
+    }
+
+    // ---- matrix-core waves: wave w = row w of the tile
     floatx16 acc[9], accb;
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp)
@@ -80,80 +185,18 @@ __global__ __launch_bounds__(256, 1) void trunk_wgrad_kernel(const TWParams p) {
         for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[r] = 0.f;
-    const bool with_bias = dp == 0;                 // (uniform)
     const unsigned one2 = 0x3f803f80u;              // two bf16 ones
     const uintx4 ones = {one2, one2, one2, one2};
-
-    // staging registers: x = 10 rows x 18 four-pixel groups x 4 channel octets = 720 units (3 per thread, the last partly idle), g = 8 x 16 x 4 = 512
-    uintx4 xr[3][4], dr[2][4];
-    auto load_tile = [&](const int t) {
-        const int img = t / p.tiles_per_img, Y0 = (t - img * p.tiles_per_img) * TW_H;
-        const char* xb = xpl + (long)img * p.img_b + (long)Y0 * p.row_b;          // padded row Y0 = image row Y0 - 1
-        const char* gb = gpl + (long)img * p.img_b + (long)(Y0 + 1) * p.row_b;
+    auto mfma_tile = [&](const char* stage) {
+        const char* s_x = stage;
+        const char* s_d = stage + X_B;
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int u = tid + it * 256;
-            const int c8 = u & 3, qq = u >> 2, r = qq / 18, q = qq - r * 18;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = 4 * q - 4 + i;                                      // image column
-                uintx4 v = {0u, 0u, 0u, 0u};
-                if (u < 720 && c >= -1 && c <= TW_W) v = *(const uintx4*)(xb + (long)r * p.row_b + (c + 1) * 64 + c8 * 16);
-                xr[it][i] = v;
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int u = tid + it * 256;
-            const int c8 = u & 3, qq = u >> 2, r = qq >> 4, q = qq & 15;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dr[it][i] = *(const uintx4*)(gb + (long)r * p.row_b + (4 * q + i + 1) * 64 + c8 * 16);
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int u = tid + it * 256;
-            if (u < 720) {
-                const int c8 = u & 3, qq = u >> 2, r = qq / 18, q = qq - r * 18;
-                half8v h[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) h[i] = __builtin_bit_cast(half8v, xr[it][i]);
-                char* o = s_x + (c8 * 8) * CSX + (r * RS + 4 * q + 4) * 2;
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    *(uintx2*)(o + j * CSX) = uintx2{bf16x2_rne((float)h[0][j], (float)h[1][j]), bf16x2_rne((float)h[2][j], (float)h[3][j])};
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int u = tid + it * 256;
-            const int c8 = u & 3, qq = u >> 2, r = qq >> 4, q = qq & 15;
-            char* o = s_d + (c8 * 8) * CSD + (r * TW_W + 4 * q) * 2;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;
-                const unsigned lo = __builtin_amdgcn_perm(dr[it][1][j >> 1], dr[it][0][j >> 1], sel);
-                const unsigned hi2 = __builtin_amdgcn_perm(dr[it][3][j >> 1], dr[it][2][j >> 1], sel);
-                *(uintx2*)(o + j * CSD) = uintx2{lo, hi2};
-            }
-        }
-    };
-
-    if (t0 < t1) load_tile(t0);
-    for (int t = t0; t < t1; ++t) {
-        __syncthreads();                                   // the previous tile's operand reads are done
-        store_tile();
-        __syncthreads();
-        if (t + 1 < t1) load_tile(t + 1);                  // in flight under the MFMAs
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int row = wave * 2 + (ks >> 2), g = ks & 3;
-            const bf16x8 a = __builtin_bit_cast(bf16x8, *(const uintx4*)(s_d + l31 * CSD + (row * TW_W + g * 16 + hi * 8) * 2));
+        for (int g = 0; g < 4; ++g) {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, *(const uintx4*)__builtin_assume_aligned(s_d + l31 * CSD + (wave * TW_W + g * 16 + hi * 8) * 2, 16));
             if (with_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, ones), accb, 0, 0, 0);
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
-                const char* bp = s_x + l31 * CSX + ((row + dy) * RS + g * 16 + hi * 8 + 8) * 2;
+                const char* bp = (const char*)__builtin_assume_aligned(s_x + l31 * CSX + ((wave + dy) * RS + g * 16 + hi * 8 + 8) * 2, 16);
                 const uintx4 cur = *(const uintx4*)bp;
                 const unsigned pv = *(const unsigned*)(bp - 4), nx = *(const unsigned*)(bp + 16);
                 const unsigned m1 = __builtin_amdgcn_alignbit(cur[1], cur[0], 16), m2 = __builtin_amdgcn_alignbit(cur[2], cur[1], 16),
@@ -165,12 +208,16 @@ __global__ __launch_bounds__(256, 1) void trunk_wgrad_kernel(const TWParams p) {
                 acc[dy * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b2), acc[dy * 3 + 2], 0, 0, 0);
             }
         }
+    };
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+        if (!(TW_ABL & 1)) mfma_tile(smem + ((t - t0) & 1) * STAGE_B);
+        __syncthreads();
     }
-    // ---- the four waves' blocks meet in LDS: waves 2, 3 -> LDS, waves 0, 1 add; wave 1 -> LDS, wave 0 adds and writes the partial block
+    // ---- the four matrix-core waves' blocks meet in LDS: waves 2, 3 -> LDS, waves 0, 1 add; wave 1 -> LDS, wave 0 adds and writes the partial block
     // accumulator element r of lane (l31, hi) is (co = 8 (r >> 2) + 4 hi + (r & 3), ci = l31): stored as [tap][co][ci]
     float* red = (float*)smem;
     auto idx = [&](int tp, int r) { return tp * 1024 + (8 * (r >> 2) + 4 * hi + (r & 3)) * 32 + l31; };
-    __syncthreads();
     if (wave >= 2) {
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp)
@@ -193,14 +240,13 @@ __global__ __launch_bounds__(256, 1) void trunk_wgrad_kernel(const TWParams p) {
     }
     __syncthreads();
     if (wave == 0) {
-        float* out = p.ws + (((long)k * p.nsplit + split) * NPAIR + blockIdx.x) * 9216;
+        float* out = p.ws + (((long)k * p.nsplit + split) * NPAIR + pair) * 9216;
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
             for (int r = 0; r < 16; ++r) out[idx(tp, r)] = acc[tp][r] + red[idx(tp, r)];
     }
     if (with_bias) {       // every column of accb holds the same sums: column 0's lanes (l31 == 0) carry them
-        __syncthreads();
         float* rb = (float*)smem + 2 * 9216;                 // (behind what wave 0 may still be reading)
         if (l31 == 0) {
 #pragma unroll
@@ -241,7 +287,7 @@ __global__ __launch_bounds__(256) void trunk_wgrad_reduce_kernel(const float* ws
 }  // namespace
 
 extern "C" size_t srbh_trunk_wgrad_ws_bytes(int num_block, int B, int H, int W) {
-    if (num_block <= 0 || B <= 0 || W != TW_W || H <= 0 || (H % TW_H) != 0) return 0;
+    if (num_block <= 0 || B <= 0 || W != TW_W || H <= 0 || (H % 8) != 0) return 0;
     const int ntiles = B * (H / TW_H);
     const int nsplit = ntiles < 4 ? ntiles : 4;
     return (size_t)num_block * 3 * nsplit * ((size_t)NPAIR * 9216 + 192) * sizeof(float);
@@ -265,7 +311,9 @@ extern "C" int srbh_trunk_wgrad(int num_block, const void* dense_all, size_t den
     p.wsb = (float*)ws + (size_t)p.n_rdb * p.nsplit * NPAIR * 9216;
     hipStream_t st = (hipStream_t)stream;
     SRBH_ONCE_PER_DEVICE(SRBH_HIP(hipFuncSetAttribute((const void*)trunk_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TWG_LDS_B)));
-    hipLaunchKernelGGL(trunk_wgrad_kernel, dim3(NPAIR, p.nsplit, p.n_rdb), dim3(256), TWG_LDS_B, st, p);
+    const int total = NPAIR * p.nsplit * p.n_rdb;
+    p.per_xcd = (total + 7) / 8;
+    hipLaunchKernelGGL(trunk_wgrad_kernel, dim3(p.per_xcd * 8), dim3(512), TWG_LDS_B, st, p);
     SRBH_HIP(hipGetLastError());
     hipLaunchKernelGGL(trunk_wgrad_reduce_kernel, dim3(NPAIR + 1, p.n_rdb), dim3(256), 0, st, p.ws, p.wsb, p.nsplit, p.n_rdb, dw_all, db_all);
     SRBH_HIP(hipGetLastError());
