@@ -286,10 +286,18 @@ __global__ __launch_bounds__(256) void trunk_wgrad_reduce_kernel(const float* ws
 
 }  // namespace
 
+// tile ranges per (RDB, pair): 4 (swept at batch 8 and 24, tools/time_trunk_wgrad.py with SRBH_TWG_SPLITS: every workgroup pays a cold first tile, the
+// meeting of its four accumulator sets in LDS and 37 KB of partial sums)
+static int twg_splits(int ntiles) {
+    static const int want = getenv("SRBH_TWG_SPLITS") ? atoi(getenv("SRBH_TWG_SPLITS")) : 4;
+    const int s = want > 0 ? want : 4;
+    return ntiles < s ? ntiles : s;
+}
+
 extern "C" size_t srbh_trunk_wgrad_ws_bytes(int num_block, int B, int H, int W) {
     if (num_block <= 0 || B <= 0 || W != TW_W || H <= 0 || (H % 8) != 0) return 0;
     const int ntiles = B * (H / TW_H);
-    const int nsplit = ntiles < 4 ? ntiles : 4;
+    const int nsplit = twg_splits(ntiles);
     return (size_t)num_block * 3 * nsplit * ((size_t)NPAIR * 9216 + 192) * sizeof(float);
 }
 
@@ -305,7 +313,7 @@ extern "C" int srbh_trunk_wgrad(int num_block, const void* dense_all, size_t den
     p.n_rdb = num_block * 3; p.H = H;
     p.tiles_per_img = H / TW_H;
     p.ntiles = B * p.tiles_per_img;
-    p.nsplit = p.ntiles < 4 ? p.ntiles : 4;
+    p.nsplit = twg_splits(p.ntiles);
     p.tiles_per_split = (p.ntiles + p.nsplit - 1) / p.nsplit;
     p.ws = (float*)ws;
     p.wsb = (float*)ws + (size_t)p.n_rdb * p.nsplit * NPAIR * 9216;
