@@ -45,7 +45,7 @@ constexpr int X_B = 32 * CSX, D_B = 32 * CSD;
 constexpr int STAGE_B = X_B + D_B;              // 48 128 B
 constexpr int TWG_LDS_B = 2 * STAGE_B;          // two stages: 96 256 B, one workgroup of 8 waves per CU
 constexpr int NPAIR = 26;
-constexpr int XUNITS = XROWS * 18 * 4, DUNITS = TW_H * 16 * 4;      // 432 / 256 staging units of (4 pixels x 8 channels)
+constexpr int XUNITS = XROWS * 16 * 4, DUNITS = TW_H * 16 * 4;      // 384 / 256 staging units of (4 pixels x 8 channels); image columns -1 and 64 are the planes' zero borders: never staged
 static_assert(TWG_LDS_B >= 2 * 9216 * 4 + 512, "the cross-wave reduce uses the staging area (two waves' blocks at a time)");
 static_assert(DUNITS == 256 && XUNITS <= 512, "one g unit and up to two x units per producer thread");
 
@@ -73,7 +73,11 @@ __device__ __forceinline__ void pair_planes(int p, int& gp, int& dp) {
 // 512 threads: waves 0..3 are the matrix-core waves (one tile row each: 4 K-steps x 9 taps per tile, the 32 x 32 x 9 accumulators in registers),
 // waves 4..7 the staging waves (global loads one tile ahead in registers, fp16 -> bf16 + 4-pixel transposes, ds_write into the OTHER LDS stage) --
 // one per SIMD of each kind, so a SIMD's staging VALU work runs in the shadow of its MFMAs instead of in front of them (as ONE set of waves doing
-// both in turn the kernel spent 4.4 us per 8-row tile against 1.1 us of matrix-core time).  One barrier per tile.
+// both in turn the kernel spent 4.4 us per 8-row tile against 1.1 us of matrix-core time).  One barrier per tile.  Where it stands (batch 24,
+// tools/time_trunk_wgrad.py with -DTW_ABL builds): 4.5 ms per call; matrix-core waves alone 2.3 ms, staging waves alone 2.6 ms, nothing 0.47 ms
+// (profiles/r05bv) -- the two kinds share each SIMD's VALU issue (transposes, conversions, operand shifts and swaps are ~350 VALU instructions per
+// tile and SIMD beside 40 MFMAs), so the phases overlap only in part.  Moving the fp16 -> bf16 rounding of x from the staging to the matrix-core
+// waves changed nothing (4.48 -> 4.55 ms; then 2.8 / 2.5 ms alone: profiles/r05ca): built, not kept.
 __global__ __launch_bounds__(512, 1) void trunk_wgrad_kernel(const TWParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(512, 1) void trunk_wgrad_kernel(const TWParams p) {
     // accumulators are live only in the matrix-core branch and the staging registers only in the other, so the 256 registers a wave gets with
     // eight waves per CU hold 160 of the one or 96 of the other -- as one loop with a role test inside, both were live everywhere (274 spills).
     if (producer) {
-        // ---- staging waves: x = 6 rows x 18 four-pixel groups x 4 channel octets = 432 units (two per thread, the second partly idle), g = 4 x 16 x 4 = 256.
+        // ---- staging waves: x = 6 rows x 16 four-pixel groups x 4 channel octets = 384 units (two per thread, the second half idle), g = 4 x 16 x 4 = 256.
         // TWO register sets: a tile's loads are issued two iterations before its LDS stores -- one iteration, ~0.6 us of matrix-core time, did not
         // cover their latency (1.6 of the kernel's 5.5 ms at batch 24 were these waves waiting: tools/time_trunk_wgrad.py + -DTW_ABL)
         uintx4 xrA[2][4], drA[4], xrB[2][4], drB[4];
@@ -106,12 +110,11 @@ __global__ __launch_bounds__(512, 1) void trunk_wgrad_kernel(const TWParams p) {
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int u = ptid + it * 256;
-                const int c8 = u & 3, qq = u >> 2, r = qq / 18, q = qq - r * 18;
+                const int c8 = u & 3, qq = u >> 2, r = qq >> 4, q = qq & 15;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int c = 4 * q - 4 + i;                                      // image column
                     uintx4 v = {0u, 0u, 0u, 0u};
-                    if (u < XUNITS && c >= -1 && c <= TW_W) v = *(const uintx4*)(xb + (long)r * p.row_b + (c + 1) * 64 + c8 * 16);
+                    if (u < XUNITS) v = *(const uintx4*)(xb + (long)r * p.row_b + (4 * q + i + 1) * 64 + c8 * 16);      // image column 4 q + i
                     xr[it][i] = v;
                 }
             }
@@ -128,11 +131,11 @@ __global__ __launch_bounds__(512, 1) void trunk_wgrad_kernel(const TWParams p) {
             for (int it = 0; it < 2; ++it) {
                 const int u = ptid + it * 256;
                 if (u < XUNITS) {
-                    const int c8 = u & 3, qq = u >> 2, r = qq / 18, q = qq - r * 18;
+                    const int c8 = u & 3, qq = u >> 2, r = qq >> 4, q = qq & 15;
                     half8v h[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) h[i] = __builtin_bit_cast(half8v, xr[it][i]);
-                    char* o = s_x + (c8 * 8) * CSX + (r * RS + 4 * q + 4) * 2;
+                    char* o = s_x + (c8 * 8) * CSX + (r * RS + 4 * q + 8) * 2;
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
                         *(uintx2*)__builtin_assume_aligned(o + j * CSX, 8) = uintx2{bf16x2_rne((float)h[0][j], (float)h[1][j]), bf16x2_rne((float)h[2][j], (float)h[3][j])};
@@ -190,22 +193,36 @@ __global__ __launch_bounds__(512, 1) void trunk_wgrad_kernel(const TWParams p) {
     auto mfma_tile = [&](const char* stage) {
         const char* s_x = stage;
         const char* s_d = stage + X_B;
+        bf16x8 a[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const bf16x8 a = __builtin_bit_cast(bf16x8, *(const uintx4*)__builtin_assume_aligned(s_d + l31 * CSD + (wave * TW_W + g * 16 + hi * 8) * 2, 16));
-            if (with_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, ones), accb, 0, 0, 0);
+            a[g] = __builtin_bit_cast(bf16x8, *(const uintx4*)__builtin_assume_aligned(s_d + l31 * CSD + (wave * TW_W + g * 16 + hi * 8) * 2, 16));
+            if (with_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g], __builtin_bit_cast(bf16x8, ones), accb, 0, 0, 0);
+        }
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const char* bp = (const char*)__builtin_assume_aligned(s_x + l31 * CSX + ((wave + dy) * RS + g * 16 + hi * 8 + 8) * 2, 16);
-                const uintx4 cur = *(const uintx4*)bp;
-                const unsigned pv = *(const unsigned*)(bp - 4), nx = *(const unsigned*)(bp + 16);
+        for (int dy = 0; dy < 3; ++dy) {
+            // the row's 64 pixels of this lane's channel: four 16-byte reads.  The pixel in front of / behind a lane's eight sits in the PARTNER
+            // lane of the other half-wave (same channel): v_permlane32_swap + a select, no LDS access -- as `ds_read_b32` of the neighbour dwords
+            // (a per-channel stride of 244 dwords: 8-way bank conflicts) those 24 reads per tile cost as much LDS time as the 16 wide ones.
+            // Image columns -1 and 64 are the planes' zero borders.
+            uintx4 c[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                c[g] = *(const uintx4*)__builtin_assume_aligned(s_x + l31 * CSX + ((wave + dy) * RS + g * 16 + hi * 8 + 8) * 2, 16);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const auto sp = __builtin_amdgcn_permlane32_swap(g > 0 ? c[g - 1][3] : 0u, c[g][3], false, false);      // {(a.lo, b.lo), (a.hi, b.hi)}
+                const auto sn = __builtin_amdgcn_permlane32_swap(c[g][0], g < 3 ? c[g + 1][0] : 0u, false, false);
+                const unsigned pv = hi ? sp[0] : sp[1];       // the dword whose HIGH half is the pixel in front of this lane's eight
+                const unsigned nx = hi ? sn[0] : sn[1];       // the dword whose LOW half is the pixel behind them
+                const uintx4 cur = c[g];
                 const unsigned m1 = __builtin_amdgcn_alignbit(cur[1], cur[0], 16), m2 = __builtin_amdgcn_alignbit(cur[2], cur[1], 16),
                                m3 = __builtin_amdgcn_alignbit(cur[3], cur[2], 16);
                 const uintx4 b0 = {__builtin_amdgcn_alignbit(cur[0], pv, 16), m1, m2, m3};
                 const uintx4 b2 = {m1, m2, m3, __builtin_amdgcn_alignbit(nx, cur[3], 16)};
-                acc[dy * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b0), acc[dy * 3 + 0], 0, 0, 0);
-                acc[dy * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, cur), acc[dy * 3 + 1], 0, 0, 0);
-                acc[dy * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b2), acc[dy * 3 + 2], 0, 0, 0);
+                acc[dy * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g], __builtin_bit_cast(bf16x8, b0), acc[dy * 3 + 0], 0, 0, 0);
+                acc[dy * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g], __builtin_bit_cast(bf16x8, cur), acc[dy * 3 + 1], 0, 0, 0);
+                acc[dy * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g], __builtin_bit_cast(bf16x8, b2), acc[dy * 3 + 2], 0, 0, 0);
             }
         }
     };
