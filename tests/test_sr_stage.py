@@ -382,8 +382,8 @@ def test_persistent_training_backward_follows_the_per_layer_sequence(blocks, B):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("blocks,B", [(1, 2), (2, 5)])
-def test_one_launch_trunk_weight_gradients_equal_the_general_kernel(blocks, B):
+@pytest.mark.parametrize("blocks,B,Hh", [(1, 2, 64), (2, 5, 64), (1, 1, 128)])
+def test_one_launch_trunk_weight_gradients_equal_the_general_kernel(blocks, B, Hh):
     """srbh_trunk_wgrad (weight + bias gradients of every RDB's five convs, SR/rrdbnet_arch.py:136-167, as one launch over (RDB, plane pair, tile
     range) + one ordered reduce) against the general 16 x 16-block kernel called RDB by RDB on the SAME saved planes and gradient planes: same bf16
     operands, fp32 accumulation in a different order -- every gradient within 2e-5 rel-L2 (B = 5: a tile count the four splits do not divide)."""
@@ -393,8 +393,8 @@ def test_one_launch_trunk_weight_gradients_equal_the_general_kernel(blocks, B):
     net = RRDBNet(3, 3, num_block=blocks)
     net.load_state_dict(synth.rrdbnet_state_dict(num_block=blocks, seed=5, mode="stress"))
     net = net.to("cuda:0")
-    feat = rand((B, 64, 64, 64), 31).to("cuda:0").contiguous()
-    g = rand((B, 64, 64, 64), 32, -1.0, 1.0).to("cuda:0").contiguous()
+    feat = rand((B, Hh, 64, 64), 31).to("cuda:0").contiguous()          # (B, H, W, 64): 64 pixels wide, H a multiple of 8
+    g = rand((B, Hh, 64, 64), 32, -1.0, 1.0).to("cuda:0").contiguous()
     res = []
     old = RA.TRUNK_WGRAD
     try:
@@ -410,6 +410,7 @@ def test_one_launch_trunk_weight_gradients_equal_the_general_kernel(blocks, B):
     finally:
         RA.TRUNK_WGRAD = old
         RA._FAST_WS.clear()
+    assert RA.TRUNK_BWD_PATHS["persistent"] >= 2          # (both runs took the persistent data-gradient launch: only the weight gradients differ)
     (g0, w0), (g1, w1) = res
     assert torch.equal(g0, g1) and len(w0) == blocks * 3 * 10
     for k in w0:
