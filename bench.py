@@ -542,6 +542,8 @@ def bench_sr_train(args, rank, world, dev, dist, steps, warmup, batch=8):
         gn = float(sum(p.grad.double().pow(2).sum() for p in net.parameters() if p.grad is not None).sqrt())
         out[mode] = {"ms_per_step": round(ms, 3), "tiles_per_s": round(batch * world / ms * 1e3, 2), "achieved_tflops": round(gf_tile * batch / ms, 2),
                      "steps": n_s, "grad_norm": gn}
+        if mode == "fast" and rank == 0:
+            out[mode]["kernels"] = _sr_trunk_kernels(net, batch, dev, args.num_block)
         del net
         torch.cuda.empty_cache()
     RA.set_train_precision("f32")
@@ -557,8 +559,61 @@ def bench_sr_train(args, rank, world, dev, dist, steps, warmup, batch=8):
                        "trunk_forward_calls": dict(_sr_paths()[0]), "trunk_backward_calls": dict(_sr_paths()[1])},      # 'fast' mode: persistent (one launch of the inference trunk's kernel) vs per_layer: no silent fallback
             "roofline": {"bound": "mfma", "achieved": head["achieved_tflops"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(head["achieved_tflops"] / PEAK_F16_TFLOPS, 4), "gflop_per_step": round(gf_tile * batch, 1),
-                         "note": "whole fwd+bwd (345 dense-block convs x 3 + the non-trunk convs in 'mixed'), not one kernel"},
+                         "note": "whole fwd+bwd (345 dense-block convs x 3 + the non-trunk convs in 'mixed'), not one kernel",
+                         "kernels": head.get("kernels")},
             "modes": out}
+
+
+def _sr_trunk_kernels(net, batch, dev, num_block, reps=10):
+    """the three launches that carry 92 % of the generator step's FLOPs, timed alone with events on the current stream (the stream they are issued
+    on): the persistent trunk forward, its bf16 form for the data gradients, and all dense blocks' weight + bias gradients (+ the ordered reduce).
+    Each does 23 x 3 x 26 624 x 9 x 2 FLOP per pixel = 135.44 GFLOP per 64 x 64 tile."""
+    import ctypes as C
+    from srbh_amd import _lib
+    from srbh_amd import rrdbnet_autograd as RA
+    L = _lib.lib()
+    feat = torch.randn((batch, 64, 64, 64), device=dev) * 0.5
+    g = torch.randn((batch, 64, 64, 64), device=dev) * 1e-3
+    gf = 2.0 * 9 * 26624 * num_block * 3 * batch * 64 * 64 / 1e9
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    lease = [None]
+
+    def fwd():
+        if lease[0] is not None:
+            lease[0].release()
+        _, lease[0] = RA._trunk_fast_forward(net, feat)
+
+    t_f = timed(fwd)
+    if not RA.TRUNK_FWD_PATHS["persistent"]:
+        return None
+    ws = lease[0].ws
+    t_b = timed(lambda: RA._trunk_fast_backward(net, lease[0], g, {}))
+    rows = [{"kernel": "ptrunk3_kernel<0, 0>: forward of the 345 dense-block convs, one launch (+ the fp16 conversion of its input)", "avg_ms": round(t_f, 4)}]
+    if ws.get("twg") is not None and RA.TRUNK_BWD_PATHS["persistent"] and RA.TRUNK_WGRAD:
+        dw = torch.empty(num_block * 3 * 9 * 26624, device=dev)
+        db = torch.empty(num_block * 3 * 192, device=dev)
+        t_w = timed(lambda: _lib.check(L.srbh_trunk_wgrad(num_block, ws["D"].data_ptr(), ws["nb"], ws["G"].data_ptr(), ws["nb"], batch, 64, 64, dw.data_ptr(),
+                                                          db.data_ptr(), ws["twg"].data_ptr(), _lib.stream_ptr()), "trunk_wgrad"))
+        rows.append({"kernel": "ptrunk3_kernel<0, 1>: the 345 data-gradient convs, one launch (+ scaling, conversion, packs cached)", "avg_ms": round(t_b - t_w, 4)})
+        rows.append({"kernel": "trunk_wgrad_kernel + trunk_wgrad_reduce_kernel: weight and bias gradients of all dense blocks", "avg_ms": round(t_w, 4)})
+    else:
+        rows.append({"kernel": "trunk backward (data + weight gradients)", "avg_ms": round(t_b, 4), "gflop": 2 * gf})
+    lease[0].release()
+    for r in rows:
+        f = r.pop("gflop", gf)
+        r.update({"algorithmic_gflop": round(f, 1), "achieved": round(f / r["avg_ms"], 1), "unit": "TFLOP/s", "frac": round(f / r["avg_ms"] / PEAK_F16_TFLOPS, 4)})
+    return rows
 
 
 def _sr_paths():
