@@ -544,6 +544,7 @@ def bench_sr_train(args, rank, world, dev, dist, steps, warmup, batch=8):
                      "steps": n_s, "grad_norm": gn}
         if mode == "fast" and rank == 0:
             out[mode]["kernels"] = _sr_trunk_kernels(net, batch, dev, args.num_block)
+            out[mode]["iteration"] = _sr_iteration(batch, dev, args.num_block, max(3, min(steps, 8)))
         del net
         torch.cuda.empty_cache()
     RA.set_train_precision("f32")
@@ -561,7 +562,34 @@ def bench_sr_train(args, rank, world, dev, dist, steps, warmup, batch=8):
                          "frac": round(head["achieved_tflops"] / PEAK_F16_TFLOPS, 4), "gflop_per_step": round(gf_tile * batch, 1),
                          "note": "whole fwd+bwd (345 dense-block convs x 3 + the non-trunk convs in 'mixed'), not one kernel",
                          "kernels": head.get("kernels")},
+            "iteration": head.get("iteration"),
             "modes": out}
+
+
+def _sr_iteration(batch, dev, num_block, iters):
+    """one WHOLE iteration of the reference's SR-stage trainer (SR/rrdbnet_arch.py:538-592: generator forward, pixel + GAN losses, generator backward +
+    Adam, discriminator forward / backward on real and fake + Adam, EMA) through RealESRGAN(is_train=True).optimize_parameters(): the generator on
+    libsrbh in the mode being measured, discriminator / USM sharpener / losses on stock device ops, every weight pack rebuilt each iteration (the
+    weights move)."""
+    from srbh_amd.rrdbnet import RealESRGAN
+    torch.manual_seed(3)
+    m = RealESRGAN(3, 3, num_block=num_block, device=dev, is_train=True)
+    g = torch.Generator().manual_seed(9)
+    gt = torch.nn.functional.interpolate(torch.rand((batch, 3, 32, 32), generator=g), scale_factor=8, mode="bilinear").to(dev)      # smooth 256 x 256 targets
+    lq = torch.nn.functional.avg_pool2d(gt, 4)                                                                                       # 64 x 64
+    ld = None
+    for _ in range(2):
+        m.feed_data({"lq": lq, "gt": gt})
+        ld = m.optimize_parameters()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        m.feed_data({"lq": lq, "gt": gt})
+        ld = m.optimize_parameters()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return {"what": "RealESRGAN.optimize_parameters(): generator + discriminator forward / backward, both Adam steps, EMA (no perceptual plug-in)",
+            "ms_per_iteration": round(ms, 3), "tiles_per_s": round(batch / ms * 1e3, 2), "iterations": iters, "l_g_pix": float(ld["l_g_pix"])}
 
 
 def _sr_trunk_kernels(net, batch, dev, num_block, reps=10):

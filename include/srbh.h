@@ -120,6 +120,17 @@ int srbh_conv3x3_f16(const srbh_conv3x3_args* a, void* stream);
  * nearest-x2 read in these forms. */
 int srbh_conv3x3_x16(const srbh_conv3x3_args* a, int bf16, const void* mask16, int mask_chunks_total, int mask_chunk0, void* stream);
 int srbh_pack_conv3x3_b16(const float* w_oihw, int cout, int cin, void* packed, void* stream);
+/* the same packs (SR/rrdbnet_arch.py:136-167's conv weights as WPACK16) for MANY convs in ONE launch: table_dev = n descriptors in DEVICE memory;
+ * bias_dst != NULL also copies the conv's cout bias values (the padded bias table of srbh_rrdbnet_desc); max_elems = the largest
+ * srbh_wpack16_bytes(cout, cin) / 2 among them.  (A generator in training repacks every conv each iteration: 351 + 345 launches otherwise.) */
+typedef struct srbh_pack3x3_desc {
+    const float* w;          /* OIHW fp32 [cout][cin][3][3] */
+    void* packed;
+    const float* bias_src;   /* or NULL */
+    float* bias_dst;         /* or NULL */
+    int cout, cin, bf16, pad_;
+} srbh_pack3x3_desc;
+int srbh_pack_conv3x3_many(const srbh_pack3x3_desc* table_dev, int n, long max_elems, void* stream);
 /* NHWC fp32 [B][H][W][C] (C % 32 == 0) * scale -> chunk planes chunk0.. of an ACT16 buffer with chunks_total planes, as fp16 or bf16 */
 int srbh_nhwc32_to_act16(const float* src, void* dst, int B, int C, int H, int W, int chunks_total, int chunk0, float scale, int bf16,
                          void* stream);

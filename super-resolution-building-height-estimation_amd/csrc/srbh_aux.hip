@@ -315,6 +315,37 @@ extern "C" int srbh_pack_conv3x3_b16(const float* w, int cout, int cin, void* pa
     return SRBH_OK;
 }
 
+// ---- the same packs for MANY convs in one launch (a generator whose weights move every iteration: 351 forward packs, 345 gradient packs)
+__global__ __launch_bounds__(256) void pack_w_many_kernel(const srbh_pack3x3_desc* __restrict__ table) {
+    const srbh_pack3x3_desc d = table[blockIdx.y];
+    const int nchunk = (d.cin + 31) / 32, nmb = (d.cout + 31) / 32;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (d.bias_dst && idx < d.cout) d.bias_dst[idx] = d.bias_src[idx];
+    const long total = (long)nchunk * 18 * nmb * 512;
+    if (idx >= total) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63;
+    long f = idx >> 9;
+    const int mb = f % nmb; f /= nmb;
+    const int ks = f & 1; f >>= 1;
+    const int tap = f % 9;
+    const int chunk = (int)(f / 9);
+    const int oc = mb * 32 + (lane & 31), ic = chunk * 32 + ks * 16 + (lane >> 5) * 8 + j;
+    const float v = (oc < d.cout && ic < d.cin) ? d.w[((long)oc * d.cin + ic) * 9 + tap] : 0.f;
+    if (d.bf16) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        ((unsigned short*)d.packed)[idx] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    } else {
+        ((_Float16*)d.packed)[idx] = (_Float16)v;
+    }
+}
+
+extern "C" int srbh_pack_conv3x3_many(const srbh_pack3x3_desc* table_dev, int n, long max_elems, void* stream) {
+    SRBH_REQUIRE(table_dev && n > 0 && max_elems > 0, "srbh_pack_conv3x3_many: bad arguments");
+    hipLaunchKernelGGL(pack_w_many_kernel, dim3((unsigned)((max_elems + 255) / 256), n), dim3(256), 0, (hipStream_t)stream, table_dev);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
 extern "C" int srbh_nhwc32_to_act16(const float* src, void* dst, int B, int C, int H, int W, int chunks_total, int chunk0, float scale,
                                     int bf16, void* stream) {
     SRBH_REQUIRE(src && dst && B > 0 && C > 0 && (C & 31) == 0 && H > 0 && W > 0, "srbh_nhwc32_to_act16: bad arguments (C %% 32 == 0)");

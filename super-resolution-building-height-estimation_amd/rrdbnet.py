@@ -173,6 +173,10 @@ class RRDBNet(nn.Module):
         if not 1 <= num_out_ch <= 32:
             raise NotImplementedError("num_out_ch must be in 1..32")
         convs = self._conv_list()
+        dev = torch.device(device)
+        params = [t for c in convs for t in (c.weight, c.bias) if t is not None] + [self.conv_first.weight, self.conv_first.bias]
+        if all(t.device == dev and t.dtype == torch.float32 and t.is_contiguous() for t in params):
+            return self._pack_in_place(dev, convs, params)
         sizes = [L.srbh_wpack16_bytes(c.out_channels, c.in_channels) for c in convs]
         offs, tot = [], 0
         for s in sizes:
@@ -212,6 +216,55 @@ class RRDBNet(nn.Module):
         d.num_out_ch = num_out_ch
         torch.cuda.current_stream().synchronize()  # `keep` temporaries may be freed after this
         return (wbuf, bbuf, cf_w, cf_b, rdb_arr), d
+
+    def _pack_in_place(self, dev, convs, params):
+        """The usual case -- fp32 parameters living on `dev`: ONE launch (srbh_pack_conv3x3_many) rewrites every pack and the padded bias table IN
+        PLACE from the parameters' own storage.  Buffers, descriptor and job table are built once per set of parameter addresses, so a generator
+        in training (weights move every iteration, SR/rrdbnet_arch.py:538-592) repacks without 351 + 351 launches, fresh allocations, a stream
+        synchronisation -- and the persistent kernels' cached layer tables (pointers into these buffers) stay valid."""
+        import numpy as np
+        L = _lib.lib()
+        key = (str(dev), tuple(t.data_ptr() for t in params))
+        plan = self.__dict__.get("_pack_plan")
+        if plan is None or plan["key"] != key:
+            num_in_ch, num_out_ch, num_feat, num_block, num_grow_ch = self._geom
+            sizes = [L.srbh_wpack16_bytes(c.out_channels, c.in_channels) for c in convs]
+            offs, tot = [], 0
+            for sz in sizes:
+                offs.append(tot)
+                tot += (sz + 255) & ~255
+            wbuf = torch.zeros(tot, dtype=torch.uint8, device=dev)
+            bias_pad = [(c.out_channels + 31) // 32 * 32 for c in convs]
+            bbuf = torch.zeros(sum(bias_pad), dtype=torch.float32, device=dev)
+            boffs, bo = [], 0
+            for bp in bias_pad:
+                boffs.append(bo)
+                bo += bp
+            desc_t = np.dtype([("w", np.uint64), ("packed", np.uint64), ("bias_src", np.uint64), ("bias_dst", np.uint64), ("cout", np.int32), ("cin", np.int32),
+                               ("bf16", np.int32), ("pad", np.int32)])
+            tab = np.zeros(len(convs), dtype=desc_t)
+            for i, c in enumerate(convs):
+                tab[i] = (c.weight.data_ptr(), wbuf.data_ptr() + offs[i], 0 if c.bias is None else c.bias.data_ptr(),
+                          0 if c.bias is None else bbuf.data_ptr() + 4 * boffs[i], c.out_channels, c.in_channels, 0, 0)
+            table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+            n_rdb = num_block * 15
+            rdb_arr = (_lib.ConvW * max(n_rdb, 1))()
+            for i in range(n_rdb):
+                rdb_arr[i].w = wbuf.data_ptr() + offs[i]
+                rdb_arr[i].bias = bbuf.data_ptr() + 4 * boffs[i]
+            d = _lib.RRDBNetDesc()
+            d.num_in_ch = num_in_ch
+            d.num_block = num_block
+            d.conv_first_w = self.conv_first.weight.data_ptr()
+            d.conv_first_b = self.conv_first.bias.data_ptr()
+            d.rdb = C.cast(rdb_arr, C.POINTER(_lib.ConvW))
+            for j, name in enumerate(("conv_body", "conv_up1", "conv_up2", "conv_hr", "conv_last")):
+                setattr(d, name, _lib.ConvW(wbuf.data_ptr() + offs[n_rdb + j], bbuf.data_ptr() + 4 * boffs[n_rdb + j]))
+            d.num_out_ch = num_out_ch
+            plan = self.__dict__["_pack_plan"] = {"key": key, "bufs": (wbuf, bbuf, table, rdb_arr, params), "desc": d, "table": table, "n": len(convs),
+                                                  "max_elems": max(sizes) // 2}
+        _lib.check(L.srbh_pack_conv3x3_many(plan["table"].data_ptr(), plan["n"], plan["max_elems"], _lib.stream_ptr()), "pack_conv3x3_many")
+        return plan["bufs"], plan["desc"]
 
     # workspaces: one per (B, H, W, forward|feature, device), zero-bordered, 0.5 GiB per 32 tiles at 64x64.  Kept while their total
     # stays under WS_BUDGET_BYTES (least recently used dropped first; 288 GB of HBM: the default keeps every tail shape of a tiled
@@ -479,7 +532,11 @@ class RealESRGAN:
         self.cri_perceptual = cri_perceptual
         self.cri_gan = GANLoss("vanilla", loss_weight=0.1).to(device)
         self.net_d_iters, self.net_d_init_iters = 1, 0
-        self.optimizer_g = torch.optim.Adam(self.net_g.parameters(), lr=1e-4, betas=(0.9, 0.99), weight_decay=0)
+        # (the generator's 702 tensors: libsrbh's one-launch Adam -- same constructor, state layout and arithmetic as torch.optim.Adam, optim.py;
+        #  torch's multi-tensor step cost 5.6 ms of host time per iteration, tools/sr_iteration_phases.py)
+        from .optim import Adam as _FusedAdam
+        on_gpu = torch.device(device).type == "cuda"
+        self.optimizer_g = (_FusedAdam if on_gpu else torch.optim.Adam)(self.net_g.parameters(), lr=1e-4, betas=(0.9, 0.99), weight_decay=0)
         self.optimizer_d = torch.optim.Adam(self.net_d.parameters(), lr=1e-4, betas=(0.9, 0.99), weight_decay=0)
         self.optimizers = [self.optimizer_g, self.optimizer_d]
         self.schedulers = [torch.optim.lr_scheduler.MultiStepLR(o, milestones=[400000], gamma=0.5) for o in self.optimizers]
@@ -502,15 +559,20 @@ class RealESRGAN:
 
     @torch.no_grad()
     def model_ema(self, decay=0.999):
-        src = dict(self.net_g.named_parameters())
-        ema = dict(self.net_g_ema.named_parameters())
-        keys = list(ema)
+        cache = self.__dict__.get("_ema_lists")
+        if cache is None or cache[0] is not self.net_g or cache[1] is not self.net_g_ema:
+            src = dict(self.net_g.named_parameters())
+            ema = dict(self.net_g_ema.named_parameters())
+            keys = list(ema)
+            cache = self.__dict__["_ema_lists"] = (self.net_g, self.net_g_ema, [ema[k] for k in keys], [src[k] for k in keys])
+        ema_list, src_list = cache[2], cache[3]
         # (same arithmetic as the reference's `.data.mul_(decay).add_(src, alpha=1-decay)`, SR/rrdbnet_arch.py:533-536, as two
         # multi-tensor launches instead of 2 x 702; `.data` / foreach writes bump no version counter the packed-weight caches
         # see, so the EMA network's parameters are stamped: its next forward repacks)
-        torch._foreach_mul_([ema[k].data for k in keys], decay)
-        torch._foreach_add_([ema[k].data for k in keys], [src[k].data for k in keys], alpha=1 - decay)
-        wcache.stamp(ema.values())
+        ed = [p.data for p in ema_list]
+        torch._foreach_mul_(ed, decay)
+        torch._foreach_add_(ed, [p.data for p in src_list], alpha=1 - decay)
+        wcache.stamp(ema_list)
 
     def optimize_parameters(self):
         """One generator update, then one discriminator update (the protocol of SR/rrdbnet_arch.py:538-592; returns its `loss_dict`).

@@ -141,25 +141,37 @@ class _TrunkBwdPacks:
             st = _lib.stream_ptr()
             n = len(ps) // 5
             dev = ps[0].device
+            plan = getattr(self, "plan", None)
             with torch.no_grad():
                 W = [torch.stack([ps[i * 5 + k].detach().float() for i in range(n)]) for k in range(5)]      # W[k]: (n, cout_k, cin_k, 3, 3)
                 tf = lambda w, lo, hi: w[:, :, lo:hi].permute(0, 2, 1, 3, 4).flip(3, 4)                        # noqa: E731  (n, hi-lo, cout_k, 3, 3)
                 # plane X_m (dense channels lo:hi) is consumed by conv_{m+1}..conv5; G order: g5, g4, g3, g2, g1
                 planes = [(160, 192, [4]), (128, 160, [4, 3]), (96, 128, [4, 3, 2]), (64, 96, [4, 3, 2, 1]), (0, 64, [4, 3, 2, 1, 0])]
-                stacked = [torch.cat([tf(W[k], lo, hi) for k in ks], dim=2).contiguous() for lo, hi, ks in planes]
-            sizes = [L.srbh_wpack16_bytes(t.shape[1], t.shape[2]) for t in stacked]
-            offs, tot = [], 0
-            for sz in sizes:
-                offs.append(tot)
-                tot += (sz + 255) // 256 * 256
-            buf = getattr(self, "buf", None)          # (rewritten in place: the persistent backward's layer table -- pointers into it -- stays cached)
-            if buf is None or buf.numel() != n * tot or buf.device != dev:
-                buf = torch.zeros(n * tot, dtype=torch.uint8, device=dev)
-            for i in range(n):
-                for j, t in enumerate(stacked):
-                    _lib.check(L.srbh_pack_conv3x3_b16(t[i].data_ptr(), t.shape[1], t.shape[2], buf.data_ptr() + i * tot + offs[j], st), "pack_conv3x3_b16")
-            torch.cuda.current_stream().synchronize()          # (`stacked` temporaries may be freed after this)
-            self.key, self.buf, self.offs, self.stride = key, buf, offs, tot
+                if plan is None or plan["n"] != n or plan["dev"] != dev:
+                    # persistent stacked weights + packs + the job table of ONE srbh_pack_conv3x3_many launch (the weights move every iteration:
+                    # 345 pack launches and a stream synchronisation per backward otherwise); rewritten in place, so the persistent backward's
+                    # cached layer table -- pointers into `buf` -- stays valid
+                    import numpy as np
+                    shapes = [(n, hi - lo, sum((32, 32, 32, 32, 64)[k] for k in ks), 3, 3) for lo, hi, ks in planes]
+                    stk = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes]
+                    sizes = [L.srbh_wpack16_bytes(sh[1], sh[2]) for sh in shapes]
+                    offs, tot = [], 0
+                    for sz in sizes:
+                        offs.append(tot)
+                        tot += (sz + 255) // 256 * 256
+                    buf = torch.zeros(n * tot, dtype=torch.uint8, device=dev)
+                    desc_t = np.dtype([("w", np.uint64), ("packed", np.uint64), ("bias_src", np.uint64), ("bias_dst", np.uint64), ("cout", np.int32),
+                                       ("cin", np.int32), ("bf16", np.int32), ("pad", np.int32)])
+                    tab = np.zeros(n * 5, dtype=desc_t)
+                    for i in range(n):
+                        for jj, sh in enumerate(shapes):
+                            tab[i * 5 + jj] = (stk[jj][i].data_ptr(), buf.data_ptr() + i * tot + offs[jj], 0, 0, sh[1], sh[2], 1, 0)
+                    plan = self.plan = {"n": n, "dev": dev, "stk": stk, "buf": buf, "offs": offs, "tot": tot, "max_elems": max(sizes) // 2,
+                                        "table": torch.from_numpy(tab.view(np.uint8).copy()).to(dev)}
+                for jj, (lo, hi, ks) in enumerate(planes):
+                    torch.cat([tf(W[k], lo, hi) for k in ks], dim=2, out=plan["stk"][jj])
+            _lib.check(L.srbh_pack_conv3x3_many(plan["table"].data_ptr(), n * 5, plan["max_elems"], st), "pack_conv3x3_many(bf16)")
+            self.key, self.buf, self.offs, self.stride = key, plan["buf"], plan["offs"], plan["tot"]
         wcache.keep(self.buf)
         return self
 

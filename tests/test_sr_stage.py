@@ -416,3 +416,19 @@ def test_one_launch_trunk_weight_gradients_equal_the_general_kernel(blocks, B, H
     for k in w0:
         assert bool(torch.isfinite(w0[k]).all()) and float(w0[k].abs().max()) > 0, k
         assert O.rel_l2(w0[k].cpu(), w1[k].cpu()) <= 2e-5, (k, O.rel_l2(w0[k].cpu(), w1[k].cpu()))
+
+
+@pytest.mark.gpu
+def test_usm_sharp_on_the_device_is_the_two_dimensional_form():
+    """USMSharp (SR/rrdbnet_arch.py:412-434) on a device tensor applies the 51 x 51 Gaussian as its two 1-D factors; against the 2-D form on the
+    CPU (what the reference fixture pins): the blur itself to fp32 summation order, the sharpened image up to the rare pixel whose residual sits
+    on the threshold (its mask flips and the blurred mask spreads ~1e-3 of it)."""
+    from srbh_amd.srgan import USMSharp, filter2D
+    u = USMSharp()
+    img = torch.nn.functional.interpolate(rand((2, 3, 40, 40), 5, 0.0, 1.0), scale_factor=4, mode="bilinear") + 0.05 * rand((2, 3, 160, 160), 6)
+    img = img.clamp(0, 1)
+    ud = USMSharp().to("cuda:0")
+    blur_d = ud._blur(img.to("cuda:0")).cpu()
+    assert float((blur_d - filter2D(img, u.kernel)).abs().max()) <= 5e-6          # (2 601-term fp32 sums in two orders: measured 2.1e-6)
+    d = (ud(img.to("cuda:0")).cpu() - u(img)).abs()
+    assert float(d.mean()) <= 1e-5 and float((d > 1e-4).float().mean()) <= 2e-3, (float(d.mean()), float(d.max()))
