@@ -15,6 +15,113 @@ from torch.nn.utils import spectral_norm
 __all__ = ["UNetDiscriminatorSN", "filter2D", "USMSharp", "GANLoss"]
 
 
+# ---- the discriminator's 3x3 stride-1 convolutions on libsrbh (round 5) --------------------------------------------------------------------
+# conv0, conv4 .. conv9 of UNetDiscriminatorSN (SR/rrdbnet_arch.py:256-265,285-301) are 3x3 / stride 1 / padding 1: 74 % of the network's FLOPs.
+# They run on the head's convolution kernels (csrc/srbh_head.hip, srbh_head_bwd.hip: forward, data gradient = the forward kernel on transposed +
+# flipped weights, weight gradient as a GEMM over pixels) in slices of <= 64 output channels (the kernels' limit), in the precision of the SR-stage
+# mode: exact fp32, or fp16 forward / bf16 gradient operands with fp32 accumulation (`precision`).  The three 4x4 stride-2 convs, the bilinear
+# up-sampling, LeakyReLU and the skip additions stay stock device ops.  The spectral-norm reparametrisation is torch's own: the hook computes
+# `weight = weight_orig / sigma` (with its power iteration in training), the convolution takes that tensor and returns its gradient.
+# An OPTION (UNetDiscriminatorSN.libsrbh, SRBH_SR_DISC=libsrbh in the trainer), not the default: these kernels are built for the head's 16..64
+# channels; on the discriminator's 64..512 the whole iteration measured slower than with the stock convolutions (profiles/r05cg).
+def _disc_pack(w, cout, cin, transpose, h16, bf16):
+    import ctypes  # noqa: F401
+    from . import _lib
+    L = _lib.lib()
+    if h16:
+        buf = torch.empty(L.srbh_hpack_h16_bytes(cout, cin, 3) // 2, dtype=torch.float16, device=w.device)
+        _lib.check(L.srbh_hpack_conv_h16(w.data_ptr(), cout, cin, 3, int(transpose), int(bf16), buf.data_ptr(), _lib.stream_ptr()), "hpack_conv_h16(disc)")
+    else:
+        buf = torch.empty(L.srbh_hpack_bytes(cout, cin, 3) // 4, dtype=torch.float32, device=w.device)
+        _lib.check(L.srbh_hpack_conv_f32(w.data_ptr(), cout, cin, 3, int(transpose), buf.data_ptr(), _lib.stream_ptr()), "hpack_conv_f32(disc)")
+    return buf
+
+
+def _disc_launch(xn, pack, bias, cout, h16, bf16):
+    """one srbh_hconv call: xn NHWC fp32 (B, c0, H, W) -> (B, cout <= 64, H, W) NHWC fp32"""
+    import ctypes as C
+    from . import _lib
+    from . import hrfuse as H
+    B, c0, Hh, Ww = xn.shape
+    a = _lib.HConvArgs()
+    a.src0, a.c0 = xn.data_ptr(), c0
+    a.w = pack.data_ptr()
+    a.bias = None if bias is None else bias.data_ptr()
+    a.cout, a.ksize = cout, 3
+    a.B, a.H, a.W = B, Hh, Ww
+    out = H.empty_nhwc(B, cout, Hh, Ww, xn.device)
+    a.out = out.data_ptr()
+    L = _lib.lib()
+    if h16:
+        _lib.check(L.srbh_hconv_h16(C.byref(a), int(bf16), _lib.stream_ptr()), "hconv_h16(disc)")
+    else:
+        _lib.check(L.srbh_hconv_f32(C.byref(a), _lib.stream_ptr()), "hconv_f32(disc)")
+    return out
+
+
+class _DiscConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, h16):
+        from . import hrfuse as H
+        xn = H.to_nhwc(x.detach().float())
+        w = weight.detach().float().contiguous()
+        cout, cin = w.shape[:2]
+        outs = []
+        for lo in range(0, cout, 64):
+            n = min(64, cout - lo)
+            b = None
+            if bias is not None:
+                b = torch.zeros((n + 15) // 16 * 16, dtype=torch.float32, device=x.device)
+                b[:n] = bias.detach().float()[lo:lo + n]
+            outs.append(_disc_launch(xn, _disc_pack(w[lo:lo + n].contiguous(), n, cin, False, h16, False), b, n, h16, False))
+        ctx.save_for_backward(xn, w)
+        ctx.h16, ctx.has_bias = bool(h16), bias is not None
+        return outs[0] if len(outs) == 1 else H.to_nhwc(torch.cat(outs, dim=1))
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C
+        from . import _lib
+        from . import hrfuse as H
+        xn, w = ctx.saved_tensors
+        h16 = ctx.h16
+        gn = H.to_nhwc(g.float())
+        cout, cin = w.shape[:2]
+        L = _lib.lib()
+        dx = None
+        if ctx.needs_input_grad[0]:          # conv^T: the forward kernel on transposed + flipped weight slices, <= 64 input channels per launch
+            parts = []
+            for lo in range(0, cin, 64):
+                n = min(64, cin - lo)
+                parts.append(_disc_launch(gn, _disc_pack(w[:, lo:lo + n].contiguous(), n, cout, True, h16, True), None, n, h16, True))
+            dx = parts[0] if len(parts) == 1 else H.to_nhwc(torch.cat(parts, dim=1))
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dws = []
+            for lo in range(0, cout, 64):
+                n = min(64, cout - lo)
+                gs = gn if cout <= 64 else H.to_nhwc(gn[:, lo:lo + n].contiguous(memory_format=torch.channels_last))
+                d = torch.empty((n, cin, 3, 3), dtype=torch.float32, device=g.device)
+                a = _lib.HWGradArgs()
+                a.src0, a.c0 = xn.data_ptr(), cin
+                a.dy, a.cout, a.ksize = gs.data_ptr(), n, 3
+                a.B, a.H, a.W = xn.shape[0], xn.shape[2], xn.shape[3]
+                a.dw = d.data_ptr()
+                ws = torch.empty(L.srbh_hwgrad_ws_bytes(n, cin, 3) // 4, dtype=torch.float32, device=g.device)
+                a.ws = ws.data_ptr()
+                _lib.check((L.srbh_hconv_wgrad_b16 if h16 else L.srbh_hconv_wgrad_f32)(C.byref(a), _lib.stream_ptr()), "hconv_wgrad(disc)")
+                dws.append(d)
+            dw = dws[0] if len(dws) == 1 else torch.cat(dws, dim=0)
+        db = gn.sum(dim=(0, 2, 3)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None
+
+
+def _disc_conv3x3(conv, x, h16):
+    for hook in conv._forward_pre_hooks.values():      # torch's spectral_norm: sets conv.weight = weight_orig / sigma (power iteration in training)
+        hook(conv, (x,))
+    return _DiscConvFn.apply(x, conv.weight, conv.bias, h16)
+
+
 class UNetDiscriminatorSN(nn.Module):
     """U-Net discriminator with spectral normalisation; state_dict keys conv0..conv9 (conv1..conv8 carry weight_orig / weight_u /
     weight_v of torch's spectral_norm) as upstream (SR/rrdbnet_arch.py:244-303)."""
@@ -34,23 +141,30 @@ class UNetDiscriminatorSN(nn.Module):
         self.conv8 = spectral_norm(nn.Conv2d(nf, nf, 3, 1, 1, bias=False))
         self.conv9 = nn.Conv2d(nf, 1, 3, 1, 1)
 
+    libsrbh = None          # None: stock convolutions; "f32" / "f16": the 3x3 stride-1 convs on libsrbh in that operand precision (device tensors only)
+
     def forward(self, x):
         act = lambda t: F.leaky_relu(t, 0.2)
         up = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)
-        x0 = act(self.conv0(x))
+        if self.libsrbh is not None and x.is_cuda:
+            h16 = self.libsrbh == "f16"
+            c3 = lambda conv, t: _disc_conv3x3(conv, t, h16)      # noqa: E731
+        else:
+            c3 = lambda conv, t: conv(t)                           # noqa: E731
+        x0 = act(c3(self.conv0, x))
         x1 = act(self.conv1(x0))
         x2 = act(self.conv2(x1))
         x3 = act(self.conv3(x2))
-        x4 = act(self.conv4(up(x3)))
+        x4 = act(c3(self.conv4, up(x3)))
         if self.skip_connection:
             x4 = x4 + x2
-        x5 = act(self.conv5(up(x4)))
+        x5 = act(c3(self.conv5, up(x4)))
         if self.skip_connection:
             x5 = x5 + x1
-        x6 = act(self.conv6(up(x5)))
+        x6 = act(c3(self.conv6, up(x5)))
         if self.skip_connection:
             x6 = x6 + x0
-        return self.conv9(act(self.conv8(act(self.conv7(x6)))))
+        return c3(self.conv9, act(c3(self.conv8, act(c3(self.conv7, x6)))))
 
 
 def filter2D(img, kernel):

@@ -432,3 +432,44 @@ def test_usm_sharp_on_the_device_is_the_two_dimensional_form():
     assert float((blur_d - filter2D(img, u.kernel)).abs().max()) <= 5e-6          # (2 601-term fp32 sums in two orders: measured 2.1e-6)
     d = (ud(img.to("cuda:0")).cpu() - u(img)).abs()
     assert float(d.mean()) <= 1e-5 and float((d > 1e-4).float().mean()) <= 2e-3, (float(d.mean()), float(d.max()))
+
+
+@pytest.mark.gpu
+def test_discriminator_convs_on_libsrbh_match_the_fixture_and_the_stock_graph(golden_dir):
+    """UNetDiscriminatorSN's 3x3 stride-1 convs (conv0, conv4..conv9, SR/rrdbnet_arch.py:256-265,285-301) on the head's convolution kernels
+    (`libsrbh = "f32"`): the reference's CPU output (g14 `disc_out`) within 2e-5; and, at a width whose convs need output / input slicing
+    (num_feat 32: conv4 is 256 -> 128), forward and EVERY gradient -- input, spectral-norm `weight_orig`s, biases -- against the stock graph
+    from the same state: exact mode <= 1e-4, 16-bit operand mode output <= 5e-3 and gradient cosines >= 0.99."""
+    import copy
+    from srbh_amd.srgan import UNetDiscriminatorSN
+    g = _g14(golden_dir)
+    d = UNetDiscriminatorSN(3, num_feat=8, skip_connection=True).eval()
+    d.load_state_dict({k[len("disc_sd_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("disc_sd_")}, strict=True)
+    d = d.to("cuda:0")
+    d.libsrbh = "f32"
+    with torch.no_grad():
+        y = d(rand((2, 3, 32, 32), 143, 0.0, 1.0).to("cuda:0"))
+    assert O.rel_l2(y.cpu(), torch.from_numpy(g["disc_out"])) <= 2e-5
+    torch.manual_seed(5)
+    base = UNetDiscriminatorSN(3, num_feat=32, skip_connection=True).to("cuda:0").train()
+    x0 = rand((2, 3, 64, 64), 7, 0.0, 1.0).to("cuda:0")
+    wgt = rand((2, 1, 64, 64), 8).to("cuda:0")
+    res = {}
+    for mode in (None, "f32", "f16"):
+        m = copy.deepcopy(base)
+        m.libsrbh = mode
+        x = x0.clone().requires_grad_(True)
+        y = m(x)
+        (y * wgt).sum().backward()
+        res[mode] = (y.detach().cpu(), x.grad.cpu(), {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None})
+    cos = lambda a, b: float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm()).clamp_min(1e-300))   # noqa: E731
+    y0, gx0, g0 = res[None]
+    assert len(g0) == 12
+    y1, gx1, g1 = res["f32"]
+    assert O.rel_l2(y1, y0) <= 1e-4 and O.rel_l2(gx1, gx0) <= 1e-4
+    for k in g0:
+        assert O.rel_l2(g1[k], g0[k]) <= 1e-4, (k, O.rel_l2(g1[k], g0[k]))
+    y2, gx2, g2 = res["f16"]
+    assert O.rel_l2(y2, y0) <= 5e-3 and cos(gx2, gx0) >= 0.99
+    for k in g0:
+        assert cos(g2[k], g0[k]) >= 0.99, (k, cos(g2[k], g0[k]))
