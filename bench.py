@@ -544,7 +544,8 @@ def bench_sr_train(args, rank, world, dev, dist, steps, warmup, batch=8):
                      "steps": n_s, "grad_norm": gn}
         if mode == "fast" and rank == 0:
             out[mode]["kernels"] = _sr_trunk_kernels(net, batch, dev, args.num_block)
-            out[mode]["iteration"] = _sr_iteration(batch, dev, args.num_block, max(3, min(steps, 8)))
+            if os.environ.get("SRBH_SR_BENCH_ITERATION", "1") != "0":      # (the stock discriminator: MIOpen searches its kernels on first use, ~1 min)
+                out[mode]["iteration"] = _sr_iteration(batch, dev, args.num_block, max(3, min(steps, 8)))
         del net
         torch.cuda.empty_cache()
     RA.set_train_precision("f32")
