@@ -439,7 +439,7 @@ def test_discriminator_convs_on_libsrbh_match_the_fixture_and_the_stock_graph(go
     """UNetDiscriminatorSN's 3x3 stride-1 convs (conv0, conv4..conv9, SR/rrdbnet_arch.py:256-265,285-301) on the head's convolution kernels
     (`libsrbh = "f32"`): the reference's CPU output (g14 `disc_out`) within 2e-5; and, at a width whose convs need output / input slicing
     (num_feat 32: conv4 is 256 -> 128), forward and EVERY gradient -- input, spectral-norm `weight_orig`s, biases -- against the stock graph
-    from the same state: exact mode <= 1e-4, 16-bit operand mode output <= 5e-3 and gradient cosines >= 0.99."""
+    in float64 from the same state: exact mode <= 1e-4, 16-bit operand mode output <= 5e-3 and gradient cosines >= 0.99."""
     import copy
     from srbh_amd.srgan import UNetDiscriminatorSN
     g = _g14(golden_dir)
@@ -451,19 +451,28 @@ def test_discriminator_convs_on_libsrbh_match_the_fixture_and_the_stock_graph(go
         y = d(rand((2, 3, 32, 32), 143, 0.0, 1.0).to("cuda:0"))
     assert O.rel_l2(y.cpu(), torch.from_numpy(g["disc_out"])) <= 2e-5
     torch.manual_seed(5)
-    base = UNetDiscriminatorSN(3, num_feat=32, skip_connection=True).to("cuda:0").train()
-    x0 = rand((2, 3, 64, 64), 7, 0.0, 1.0).to("cuda:0")
-    wgt = rand((2, 1, 64, 64), 8).to("cuda:0")
+    base = UNetDiscriminatorSN(3, num_feat=32, skip_connection=True).train()
+    x0 = rand((2, 3, 64, 64), 7, 0.0, 1.0)
+    wgt = rand((2, 1, 64, 64), 8)
     res = {}
-    for mode in (None, "f32", "f16"):
+    # the yardstick is the stock graph in FLOAT64 on the CPU (MIOpen's fp32 convolutions are themselves only ~1e-3 accurate with some of the
+    # solvers it picks on a fresh box: a device-stock-vs-libsrbh comparison at 1e-4 failed one run in four there)
+    for mode in ("cpu64", "f32", "f16"):
         m = copy.deepcopy(base)
-        m.libsrbh = mode
-        x = x0.clone().requires_grad_(True)
+        if mode == "cpu64":
+            m = m.double()
+            x = x0.double().clone().requires_grad_(True)
+            w_ = wgt.double()
+        else:
+            m = m.to("cuda:0")
+            m.libsrbh = mode
+            x = x0.to("cuda:0").clone().requires_grad_(True)
+            w_ = wgt.to("cuda:0")
         y = m(x)
-        (y * wgt).sum().backward()
-        res[mode] = (y.detach().cpu(), x.grad.cpu(), {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None})
+        (y * w_).sum().backward()
+        res[mode] = (y.detach().cpu().float(), x.grad.cpu().float(), {k: p.grad.cpu().float() for k, p in m.named_parameters() if p.grad is not None})
     cos = lambda a, b: float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm()).clamp_min(1e-300))   # noqa: E731
-    y0, gx0, g0 = res[None]
+    y0, gx0, g0 = res["cpu64"]
     assert len(g0) == 12
     y1, gx1, g1 = res["f32"]
     assert O.rel_l2(y1, y0) <= 1e-4 and O.rel_l2(gx1, gx0) <= 1e-4
