@@ -25,7 +25,6 @@ __all__ = ["UNetDiscriminatorSN", "filter2D", "USMSharp", "GANLoss"]
 # An OPTION (UNetDiscriminatorSN.libsrbh, SRBH_SR_DISC=libsrbh in the trainer), not the default: these kernels are built for the head's 16..64
 # channels; on the discriminator's 64..512 the whole iteration measured slower than with the stock convolutions (profiles/r05cg).
 def _disc_pack(w, cout, cin, transpose, h16, bf16):
-    import ctypes  # noqa: F401
     from . import _lib
     L = _lib.lib()
     if h16:
