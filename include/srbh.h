@@ -143,6 +143,11 @@ int srbh_act16_wgrad_b16(const void* x, int x_chunks_total, int cin, const void*
                          int B, int H, int W, float* dw, float* ws, void* stream);
 /* dst = a * x + b * y on fp32 vectors (y may be NULL; dst may alias x or y); n % 4 == 0 */
 int srbh_axpby_f32(float* dst, float a, const float* x, float b, const float* y, long n, void* stream);
+/* g *= (y > 0 ? 1 : slope), in place: the backward of F.leaky_relu (SR/rrdbnet_arch.py:234-239's activations) from the saved OUTPUT y; n % 4 == 0 */
+int srbh_lrelu_bwd_f32(float* g, const float* y, float slope, long n, void* stream);
+/* the adjoint of F.interpolate(scale_factor=2, mode='nearest') (SR/rrdbnet_arch.py:236-237) on an NHWC fp32 tensor: g [B][2Ho][2Wo][C] -> out [B][Ho][Wo][C],
+ * the sum of each 2 x 2 block ((a + b) + (c + d)); C % 4 == 0 */
+int srbh_up2_bwd_nhwc_f32(const float* g, float* out, int B, int Ho, int Wo, int C, void* stream);
 
 /* conv_first (SR/rrdbnet_arch.py:197,232): 3x3 conv on the NCHW fp32 network input with few input
  * channels (3, 12 or 48), computed in fp32 on the vector ALUs.  Writes the 64-channel result to up to

@@ -187,6 +187,8 @@ SIGNATURES = {
     "srbh_rrdbnet_trunk_wgrad_ws_bytes": (_sz, []),
     "srbh_rrdbnet_trunk_train_backward_persistent": (_i, [_i, _vp, _sz, _vp, _sz, C.POINTER(_sz), _vp, _vp, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
                                                           _vp, C.POINTER(_i)]),
+    "srbh_lrelu_bwd_f32": (_i, [_vp, _vp, C.c_float, C.c_long, _vp]),
+    "srbh_up2_bwd_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_pack_conv3x3_many": (_i, [_vp, _i, C.c_long, _vp]),
     "srbh_trunk_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "srbh_trunk_wgrad": (_i, [_i, _vp, _sz, _vp, _sz, _i, _i, _i, _vp, _vp, _vp, _vp]),

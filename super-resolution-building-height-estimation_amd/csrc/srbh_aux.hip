@@ -380,6 +380,50 @@ extern "C" int srbh_axpby_f32(float* dst, float a, const float* x, float b, cons
     return SRBH_OK;
 }
 
+// g *= (y > 0 ? 1 : slope): the backward of y = leaky_relu(z) from the SAVED output (y > 0 <=> z > 0; torch's slope at z <= 0), in place, one pass
+__global__ void lrelu_bwd_kernel(float4* __restrict__ g, const float4* __restrict__ y, float slope, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = g[i];
+        const float4 w = y[i];
+        v.x *= w.x > 0.f ? 1.f : slope; v.y *= w.y > 0.f ? 1.f : slope; v.z *= w.z > 0.f ? 1.f : slope; v.w *= w.w > 0.f ? 1.f : slope;
+        g[i] = v;
+    }
+}
+
+// adjoint of nearest-neighbour x2 on an NHWC fp32 tensor: out[b][y][x][c] = sum of the 2 x 2 block of g; one thread per 4 output channels
+__global__ void up2_bwd_nhwc_kernel(const float4* __restrict__ g, float4* __restrict__ out, long n4, int Ho, int Wo, int C4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long r = i / C4;
+        const int x = (int)(r % Wo);
+        r /= Wo;
+        const int y = (int)(r % Ho);
+        const long b = r / Ho;
+        const long row = (long)2 * Wo * C4;
+        const float4* q = g + ((b * 2 * Ho + 2 * y) * 2 * Wo + 2 * x) * C4 + c;
+        const float4 a0 = q[0], a1 = q[C4], a2 = q[row], a3 = q[row + C4];
+        out[i] = float4{(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w)};
+    }
+}
+
+extern "C" int srbh_up2_bwd_nhwc_f32(const float* g, float* out, int B, int Ho, int Wo, int C, void* stream) {
+    SRBH_REQUIRE(g && out && B > 0 && Ho > 0 && Wo > 0 && C > 0 && (C & 3) == 0, "srbh_up2_bwd_nhwc_f32: bad arguments (C %% 4 == 0)");
+    const long n4 = (long)B * Ho * Wo * (C / 4);
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(up2_bwd_nhwc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)g, (float4*)out, n4, Ho, Wo, C / 4);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_lrelu_bwd_f32(float* g, const float* y, float slope, long n, void* stream) {
+    SRBH_REQUIRE(g && y && n > 0 && (n & 3) == 0, "srbh_lrelu_bwd_f32: bad arguments");
+    const long n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)g, (const float4*)y, slope, n4);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
 extern "C" int srbh_act16_channel_sum(const void* src, int B, int H, int W, int chunks_total, int chunk0, int nchunk, int bf16, float* out,
                                       void* stream) {
     SRBH_REQUIRE(src && out && B > 0 && H > 0 && W > 0 && nchunk > 0 && chunk0 >= 0 && chunk0 + nchunk <= chunks_total, "srbh_act16_channel_sum: bad arguments");

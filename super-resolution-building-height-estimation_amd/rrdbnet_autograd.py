@@ -374,10 +374,26 @@ def _up2(t):
 
 def _up2_bwd(g):            # adjoint of nearest x2: the sum over each 2x2 block
     Bn, Hn, Wn, Cn = g.shape
+    if g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and Cn % 4 == 0:
+        o = torch.empty((Bn, Hn // 2, Wn // 2, Cn), dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().srbh_up2_bwd_nhwc_f32(g.data_ptr(), o.data_ptr(), Bn, Hn // 2, Wn // 2, Cn, _lib.stream_ptr()), "up2_bwd_nhwc_f32")
+        return o
     return g.reshape(Bn, Hn // 2, 2, Wn // 2, 2, Cn).sum(dim=(2, 4))
 
 
+def _bias_grad(g):          # (B,H,W,C) -> (C,): the head's plane-sum kernels (fp64 partial sums) for the 64-channel gradients
+    if g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.shape[3] % 16 == 0:
+        from . import hrfuse_autograd as HA
+        return HA.channel_sum(g.permute(0, 3, 1, 2))
+    return g.sum(dim=(0, 1, 2))
+
+
 def _lrelu_mask_(g, y):     # g *= d lrelu(z)/dz with y = lrelu(z): y > 0 <=> z > 0 (torch: slope at z <= 0)
+    if (g.is_cuda and g.dtype == torch.float32 and y.dtype == torch.float32 and g.is_contiguous() and y.is_contiguous() and g.shape == y.shape
+            and g.numel() % 4 == 0):
+        # one pass (srbh_lrelu_bwd_f32) instead of three stock element-wise kernels over 256 x 256 x 64 fp32 tensors
+        _lib.check(_lib.lib().srbh_lrelu_bwd_f32(g.data_ptr(), y.data_ptr(), 0.2, g.numel(), _lib.stream_ptr()), "lrelu_bwd_f32")
+        return g
     return g.mul_(torch.where(y > 0, 1.0, 0.2))
 
 
@@ -442,7 +458,7 @@ class _RRDBNetFn(torch.autograd.Function):
             p = _packs(mod)
             cout = mod.out_channels
             grads[id(mod.weight)] = _wgrad(src, c0, ld0, g, cout)
-            grads[id(mod.bias)] = g.sum(dim=(0, 1, 2))
+            grads[id(mod.bias)] = _bias_grad(g)
             if not need_dx:
                 return None
             if dst is None:
