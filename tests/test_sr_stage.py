@@ -339,7 +339,7 @@ def test_persistent_training_forward_equals_the_per_layer_sequence(blocks, B):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("blocks,B", [(1, 2), (2, 3)])
+@pytest.mark.parametrize("blocks,B", [(1, 2), (2, 3), (1, 33)])          # (33 images: two launches of the persistent kernel, one workgroup per CU)
 def test_persistent_training_backward_follows_the_per_layer_sequence(blocks, B):
     """SR-stage "fast" training backward of the trunk (the gradient of SR/rrdbnet_arch.py:136-167 per RDB, SR/rrdbnet_arch.py:538-592's
     l_g_total.backward()): the data-gradient convs of all RDBs as ONE launch of the persistent kernel's bf16 form
