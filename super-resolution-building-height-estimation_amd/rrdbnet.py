@@ -581,14 +581,17 @@ class RealESRGAN:
         perceptual plug-in, the GAN term through the FROZEN discriminator; discriminator terms: real target, then the detached output."""
         from collections import OrderedDict
         log = OrderedDict()
-        # SRBH_SR_DISC=libsrbh: the discriminator's 3x3 stride-1 convs (74 % of its FLOPs) on libsrbh in the generator's operand precision
-        # (srgan._DiscConvFn; parity: tests/test_sr_stage.py).  OFF by default: the head's kernels these convs would run on are built for 16..64
-        # channels, and at 64..512 channels with a layout change at every stock neighbour the iteration measured SLOWER than with MIOpen's
-        # convs (65.2 against 57.7 ms at batch 8, profiles/r05cg) -- the discriminator wants kernels of the trunk's family, not these.
+        # The discriminator's 3x3 stride-1 convs (conv0, conv4..conv9: 74 % of its FLOPs) run on libsrbh (srgan._DiscConvFn; parity:
+        # tests/test_sr_stage.py) when the generator trains with 16-bit operands ("mixed" / "fast": fp16 forward, bf16 gradients, fp32
+        # accumulation -- the same policy): 57.5 -> 52.2 ms per iteration at batch 8 (profiles/r05cs; a first measurement that said "slower"
+        # had timed MIOpen's first-use kernel search for the new tensor layouts).  Exact-fp32 mode: stock convs (the exact-fp32 kernels are
+        # slow at 64..512 channels).  SRBH_SR_DISC=stock / libsrbh overrides.
         import os
         from . import rrdbnet_autograd as RA
         on_gpu = torch.device(self.device).type == "cuda"
-        self.net_d.libsrbh = ("f16" if RA._mixed() else "f32") if (on_gpu and os.environ.get("SRBH_SR_DISC", "") == "libsrbh") else None
+        sel = os.environ.get("SRBH_SR_DISC", "")
+        use = on_gpu and (sel == "libsrbh" or (sel != "stock" and RA._mixed()))
+        self.net_d.libsrbh = ("f16" if RA._mixed() else "f32") if use else None
 
         def update(optimizer, train_d, groups):
             self.net_d.requires_grad_(train_d)

@@ -22,8 +22,8 @@ __all__ = ["UNetDiscriminatorSN", "filter2D", "USMSharp", "GANLoss"]
 # mode: exact fp32, or fp16 forward / bf16 gradient operands with fp32 accumulation (`precision`).  The three 4x4 stride-2 convs, the bilinear
 # up-sampling, LeakyReLU and the skip additions stay stock device ops.  The spectral-norm reparametrisation is torch's own: the hook computes
 # `weight = weight_orig / sigma` (with its power iteration in training), the convolution takes that tensor and returns its gradient.
-# An OPTION (UNetDiscriminatorSN.libsrbh, SRBH_SR_DISC=libsrbh in the trainer), not the default: these kernels are built for the head's 16..64
-# channels; on the discriminator's 64..512 the whole iteration measured slower than with the stock convolutions (profiles/r05cg).
+# UNetDiscriminatorSN.libsrbh selects it; the trainer turns it on with the generator's 16-bit operand modes (RealESRGAN.optimize_parameters: 57.5 ->
+# 52.2 ms per iteration at batch 8, profiles/r05cs).  Restricting it to the <= 64-channel convs (one launch each) gained nothing.
 def _disc_pack(w, cout, cin, transpose, h16, bf16):
     from . import _lib
     L = _lib.lib()
