@@ -148,6 +148,10 @@ int srbh_lrelu_bwd_f32(float* g, const float* y, float slope, long n, void* stre
 /* the adjoint of F.interpolate(scale_factor=2, mode='nearest') (SR/rrdbnet_arch.py:236-237) on an NHWC fp32 tensor: g [B][2Ho][2Wo][C] -> out [B][Ho][Wo][C],
  * the sum of each 2 x 2 block ((a + b) + (c + d)); C % 4 == 0 */
 int srbh_up2_bwd_nhwc_f32(const float* g, float* out, int B, int Ho, int Wo, int C, void* stream);
+/* F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) on an NHWC fp32 tensor (UNetDiscriminatorSN, SR/rrdbnet_arch.py:285-297):
+ * backward == 0: x [B][H][W][C] -> out [B][2H][2W][C]; backward != 0: x = the gradient [B][2H][2W][C] -> out = its adjoint [B][H][W][C] (a gather:
+ * no atomics, fixed summation order).  C % 4 == 0. */
+int srbh_bilinear2x_nhwc_f32(const float* x, float* out, int B, int H, int W, int C, int backward, void* stream);
 
 /* conv_first (SR/rrdbnet_arch.py:197,232): 3x3 conv on the NCHW fp32 network input with few input
  * channels (3, 12 or 48), computed in fp32 on the vector ALUs.  Writes the 64-channel result to up to

@@ -189,6 +189,7 @@ SIGNATURES = {
                                                           _vp, C.POINTER(_i)]),
     "srbh_lrelu_bwd_f32": (_i, [_vp, _vp, C.c_float, C.c_long, _vp]),
     "srbh_up2_bwd_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "srbh_bilinear2x_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "srbh_pack_conv3x3_many": (_i, [_vp, _i, C.c_long, _vp]),
     "srbh_trunk_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "srbh_trunk_wgrad": (_i, [_i, _vp, _sz, _vp, _sz, _i, _i, _i, _vp, _vp, _vp, _vp]),

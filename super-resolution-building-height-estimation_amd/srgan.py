@@ -121,6 +121,31 @@ def _disc_conv3x3(conv, x, h16):
     return _DiscConvFn.apply(x, conv.weight, conv.bias, h16)
 
 
+class _Bilinear2xFn(torch.autograd.Function):
+    """F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) on a device tensor through srbh_bilinear2x_nhwc_f32 (the stock backward
+    scatters with atomics: 4.5 ms of a 52 ms trainer iteration at batch 8)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        from . import _lib
+        from . import hrfuse as H
+        xn = H.to_nhwc(x.detach().float())
+        B, Cc, Hh, Ww = xn.shape
+        out = H.empty_nhwc(B, Cc, 2 * Hh, 2 * Ww, x.device)
+        _lib.check(_lib.lib().srbh_bilinear2x_nhwc_f32(xn.data_ptr(), out.data_ptr(), B, Hh, Ww, Cc, 0, _lib.stream_ptr()), "bilinear2x(fwd)")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        from . import hrfuse as H
+        gn = H.to_nhwc(g.float())
+        B, Cc, H2, W2 = gn.shape
+        dx = H.empty_nhwc(B, Cc, H2 // 2, W2 // 2, g.device)
+        _lib.check(_lib.lib().srbh_bilinear2x_nhwc_f32(gn.data_ptr(), dx.data_ptr(), B, H2 // 2, W2 // 2, Cc, 1, _lib.stream_ptr()), "bilinear2x(bwd)")
+        return dx
+
+
 class UNetDiscriminatorSN(nn.Module):
     """U-Net discriminator with spectral normalisation; state_dict keys conv0..conv9 (conv1..conv8 carry weight_orig / weight_u /
     weight_v of torch's spectral_norm) as upstream (SR/rrdbnet_arch.py:244-303)."""
@@ -148,6 +173,7 @@ class UNetDiscriminatorSN(nn.Module):
         if self.libsrbh is not None and x.is_cuda:
             h16 = self.libsrbh == "f16"
             c3 = lambda conv, t: _disc_conv3x3(conv, t, h16)      # noqa: E731
+            up = lambda t: _Bilinear2xFn.apply(t) if t.shape[1] % 4 == 0 else F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)      # noqa: E731
         else:
             c3 = lambda conv, t: conv(t)                           # noqa: E731
         x0 = act(c3(self.conv0, x))

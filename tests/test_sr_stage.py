@@ -482,3 +482,21 @@ def test_discriminator_convs_on_libsrbh_match_the_fixture_and_the_stock_graph(go
     assert O.rel_l2(y2, y0) <= 5e-3 and cos(gx2, gx0) >= 0.99
     for k in g0:
         assert cos(g2[k], g0[k]) >= 0.99, (k, cos(g2[k], g0[k]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 8, 5, 7), (1, 64, 16, 16), (3, 4, 1, 1)])
+def test_bilinear_x2_kernels_equal_interpolate(shape):
+    """srbh_bilinear2x_nhwc_f32 (UNetDiscriminatorSN's up-sampling, SR/rrdbnet_arch.py:285-297) and its gather-form adjoint against
+    F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) and its autograd, borders and a 1 x 1 plane included: <= 1e-6."""
+    from srbh_amd.srgan import _Bilinear2xFn
+    x = rand(shape, 21).to("cuda:0")
+    w = rand((shape[0], shape[1], 2 * shape[2], 2 * shape[3]), 22).to("cuda:0")
+    outs = []
+    for fn in (lambda t: torch.nn.functional.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False), _Bilinear2xFn.apply):
+        xx = x.clone().requires_grad_(True)
+        y = fn(xx)
+        (y * w).sum().backward()
+        outs.append((y.detach().cpu(), xx.grad.cpu()))
+    assert outs[0][0].shape == outs[1][0].shape
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-6 and float((outs[0][1] - outs[1][1]).abs().max()) <= 2e-6
