@@ -273,11 +273,18 @@ class _Prefetch:
     """RRDBNet features of a batch, being computed on the trunk stream: calling it makes the current stream wait for them"""
 
     def __init__(self, lr, fea, done):
-        self.key = (lr.data_ptr(), lr._version, tuple(lr.shape))
+        # the announced tensor ITSELF is held: its storage cannot be freed and handed out again at the same address with version 0
+        # (a pointer + version + shape key would then match a DIFFERENT batch and serve it the wrong features, round-5 ADVICE)
+        self.lr, self.version = lr, lr._version
         self.fea, self.done = fea, done
 
     def matches(self, lr):
-        return self.key == (lr.data_ptr(), lr._version, tuple(lr.shape))
+        return lr is self.lr and lr._version == self.version
+
+    def abandon(self):
+        """the features will not be used: the current stream still has to wait for the launches that compute them, because an inline
+        forward_feature that follows shares the RRDBNet's workspace and progress flags (keyed by geometry, not by stream)"""
+        torch.cuda.current_stream(self.fea.device).wait_event(self.done)
 
     def __call__(self):
         cur = torch.cuda.current_stream(self.fea.device)
@@ -529,6 +536,8 @@ class TrainStep:
             hr_fea = pf                       # a handle: the model issues the encoder / decoders first and waits in front of HRfeature
             self.pipelined_steps += 1
         else:
+            if pf is not None and not in_graph:
+                pf.abandon()
             with torch.no_grad():
                 hr_fea = features_for_head(self.net_hr, lr.index_select(1, self._rgb_idx), h16, model=self.net)
         height_pred, build_pred, height_pred_aggre = self.net(lr, hr_fea)

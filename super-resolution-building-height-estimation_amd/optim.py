@@ -62,7 +62,9 @@ class Adam(torch.optim.Optimizer):
                 ma.copy_(st["exp_avg"])
                 va.copy_(st["exp_avg_sq"])
             st["exp_avg"], st["exp_avg_sq"] = ma, va
-            st["step"] = float(st["step"]) if "step" in st else float(self._t)
+            # a parameter without state starts at step 0 as in torch/optim/adam.py (one added by add_param_group, or unfrozen, in the
+            # middle of training has its OWN bias corrections; `_t` only picks the ring slot)
+            st["step"] = float(st["step"]) if "step" in st else 0.0
         chunk = _lib.lib().srbh_adam_chunk()
         chunks = np.array([(i, s) for i, p in enumerate(ps) for s in range((p.numel() + chunk - 1) // chunk)], dtype=np.int32)
         # the pointer table goes to the device with an asynchronous copy from pinned memory; the host may be a whole step ahead of the

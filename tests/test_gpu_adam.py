@@ -68,3 +68,28 @@ def test_state_dict_round_trip_with_torch_adam():
     torch.cuda.synchronize()
     for x, y in zip(pa, pb):
         assert _rel(x, y) <= 5e-6
+
+
+def test_param_group_added_mid_training_starts_at_step_zero_like_torch():
+    """round-5 ADVICE: a parameter that joins after t steps has its OWN bias corrections (step 1 at its first update), as in torch"""
+    from srbh_amd.optim import Adam
+    pa, pb = _params(4), _params(4)
+    la, lb = torch.nn.Parameter(torch.ones(5, device=DEV)), torch.nn.Parameter(torch.ones(5, device=DEV))
+    oa, ob = Adam(pa, lr=1e-3), torch.optim.Adam(pb, lr=1e-3)
+    g = torch.Generator().manual_seed(5)
+
+    def sweep(xs, ys):
+        for x, y in zip(xs, ys):
+            gr = torch.randn(x.shape, generator=g).to(DEV)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+
+    for _ in range(5):
+        sweep(pa, pb)
+    oa.add_param_group({"params": [la]})
+    ob.add_param_group({"params": [lb]})
+    for _ in range(3):
+        sweep(pa + [la], pb + [lb])
+    torch.cuda.synchronize()
+    assert float(oa.state[la]["step"]) == float(ob.state[lb]["step"]) == 3.0
+    assert _rel(la, lb) <= 2e-6 and _rel(pa[0], pb[0]) <= 2e-6

@@ -136,3 +136,29 @@ def test_prefetch_beside_a_running_step_is_bit_identical_full_depth():
     torch.cuda.synchronize()
     net_hr.check_status()
     assert ts.pipelined_steps == 79
+
+
+def test_a_new_batch_at_a_recycled_address_is_not_served_the_old_prefetch():
+    """round-5 ADVICE: the announced batch is dropped by the caller and ANOTHER batch of the same shape is allocated -- the caching
+    allocator hands out the same address with version 0.  The prefetch holds the announced tensor itself (identity, not address), so
+    the new batch is computed inline; the abandoned launches are waited for before the inline forward touches the shared workspace."""
+    from srbh_amd.harness import TrainStep, synthetic_batch
+    dev = "cuda:0"
+    net_hr, net = _nets(dev, blocks=2)
+    ts = TrainStep(net_hr, net, dev, lr=1e-4, status_every=0)
+    b0 = synthetic_batch(4, 300, dev)
+    b1 = list(synthetic_batch(4, 301, dev))
+    ts(b0, next_batch=tuple(b1))
+    assert ts._pf is not None
+    other = synthetic_batch(4, 302, dev)
+    stale = ts._pf
+    lr_new = torch.empty_like(b1[0])
+    lr_new.copy_(other[0])
+    assert not stale.matches(lr_new)
+    # same storage, same version, same shape as the announced tensor but another Python object standing for "a recycled address"
+    alias = b1[0].view_as(b1[0])
+    assert alias.data_ptr() == b1[0].data_ptr() and not stale.matches(alias)
+    loss = float(ts((lr_new,) + tuple(other[1:]))[0])
+    assert ts.pipelined_steps == 0 and loss == loss
+    torch.cuda.synchronize()
+    net_hr.check_status()
