@@ -206,19 +206,6 @@ def _dist_info(dist):
     return {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "rccl_version": ver}
 
 
-def _recorded_301():
-    """the builder's own full-size configs[4] run (all 301 cities), newest file under profiles/: a RECORDED figure, named as such"""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_predict_301cities.json.log")))
-    for f in reversed(files):
-        try:
-            rec = json.loads([ln for ln in open(f).read().splitlines() if ln.startswith("{")][-1])
-            return {"file": "profiles/" + os.path.basename(f), "tiles_per_s": rec.get("value"),
-                    "p50_city_latency_ms": rec.get("p50_city_latency_ms"), "note": "RECORDED builder run, not measured in this run"}
-        except Exception:
-            continue
-    return None
-
-
 def _max_over_ranks(vals, dev, dist):
     if dist is None:
         return vals
@@ -276,12 +263,20 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
     elapsed = time.perf_counter() - t0
     (elapsed,) = _max_over_ranks([elapsed], dev, dist)
     net_hr.check_status()
+    # how many of the timed steps consumed prefetched features, on the slowest and the fastest rank (a rank whose prefetch never hits
+    # runs the serial step and drags the job: must be visible in an N-GPU line)
+    hits = ts.pipelined_steps - p0
+    hit_lo, hit_hi = hits, hits
+    if dist is not None:
+        hh = torch.tensor([float(hits), -float(hits)], dtype=torch.float64, device=dev)
+        dist.all_reduce(hh, op=dist.ReduceOp.MAX)
+        hit_hi, hit_lo = int(hh[0]), int(-hh[1])
     comm = None
     if ts.reducer is not None:
         ex = [a.elapsed_time(b) for a, b in exposed] or [0.0]
         iso = ts.reducer.isolated_comm_ms()
         ex_max, iso_max = _max_over_ranks([sum(ex) / len(ex), iso], dev, dist)
-        comm = {"buckets": ts.reducer.n_buckets, "grad_bytes": int(sum(b["flat"].numel() * 4 for b in ts.reducer.plan)),
+        comm = {"prefetch_hits_per_rank": {"min": hit_lo, "max": hit_hi, "of_steps": steps}, "buckets": ts.reducer.n_buckets, "grad_bytes": int(sum(b["flat"].numel() * 4 for b in ts.reducer.plan)),
                 "comm_ms": round(iso_max, 3), "exposed_comm_ms": round(ex_max, 3),
                 "note": "comm_ms = the step's bucketed all-reduces on their own; exposed_comm_ms = device time between the "
                         "end of backward and the last bucket landing (max over ranks)"}
@@ -869,6 +864,29 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # self-validation on first contact with a multi-GPU node (round-5 VERDICT item 8): the numbers of an N-GPU line must come from
+        # N ranks on N devices over RCCL -- anything else ends the run with a non-zero exit status instead of a plausible line
+        info = _dist_info(dist)
+        hooked = os.environ.get("SRBH_BENCH_BACKEND") is not None or os.environ.get("SRBH_BENCH_SHARED_DEVICE", "0") == "1"
+        problems = []
+        if info["world_size_seen"] != args.gpus:
+            problems.append(f"the process group has {info['world_size_seen']} ranks, --gpus says {args.gpus}")
+        if not hooked:
+            if info["backend"] != "nccl":
+                problems.append(f"backend is {info['backend']!r}, not 'nccl' (RCCL)")
+            if info["rccl_version"] is None:
+                problems.append("torch.cuda.nccl.version() is unavailable: no RCCL behind the 'nccl' backend")
+            if torch.cuda.device_count() < world:
+                problems.append(f"{world} ranks but only {torch.cuda.device_count()} visible devices (one rank per GPU)")
+            else:
+                # one all-reduce over RCCL right now: every rank contributes its rank + 1
+                probe = torch.full((1024,), float(rank + 1), device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if float(probe[0]) != world * (world + 1) / 2 or float(probe[-1]) != world * (world + 1) / 2:
+                    problems.append(f"a probe all-reduce returned {float(probe[0])}, expected {world * (world + 1) / 2}")
+        if problems:
+            sys.exit(f"bench.py --gpus {args.gpus} (rank {rank}): " + "; ".join(problems))
 
     tb = args.batch if args.batch != 32 else 64
     pb = args.batch if args.batch != 32 else 128
@@ -888,7 +906,7 @@ def main():
             extras = {}
             for key, fn in (("train_step", lambda: bench_train(args, rank, world, dev, dist, 20, 8, batch=64,      # (8 warm-up + 20 timed steps: the pipelined step needs a few steps to settle; 5 + 10 read 1.8 ms above the 40-step figure)
                                                                 with_cpu=not args.no_cpu_baseline)),
-                            ("predict", lambda: bench_predict(args, rank, world, dev, dist, int(os.environ.get("SRBH_BENCH_PREDICT_CITIES", "30")), 1, batch=128))):
+                            ("predict", lambda: bench_predict(args, rank, world, dev, dist, int(os.environ.get("SRBH_BENCH_PREDICT_CITIES", "301")), 1, batch=128))):   # configs[4] at its stated size: all 301 cities (~225 s on one GPU)
                 try:
                     extras[key] = _compact(fn())
                 except Exception as e:          # the headline must survive a failing extra (and say so)
@@ -913,16 +931,18 @@ def main():
                         "encdec_libsrbh_ms": (t.get("encdec_kernels") or {}).get("ms_per_step"),
                         "encdec_stock_op_calls_2steps": ((t.get("encdec_kernels") or {}).get("stock_ops") or {}).get("calls"),
                         "cpu_baseline_tiles_per_s": (t.get("cpu_baseline") or {}).get("value")},
-                    "predict_30_of_301_cities": {"error": p_["error"]} if "error" in p_ else {
+                    "predict_cities": {"error": p_["error"]} if "error" in p_ else {
+                        "cities": (p_.get("config") or {}).get("cities"), "of": 301, "tiles": (p_.get("config") or {}).get("tiles"),
                         "tiles_per_s": p_.get("value"), "p50_city_latency_ms": p_.get("p50_city_latency_ms"),
-                        "frac_mfma_peak_per_gpu": (p_.get("roofline") or {}).get("frac"),
-                        "all_301_cities_source": _recorded_301()},
+                        "p95_city_latency_ms": p_.get("p95_city_latency_ms"), "max_city_latency_ms": p_.get("max_city_latency_ms"),
+                        "frac_mfma_peak_per_gpu": (p_.get("roofline") or {}).get("frac")},
                     # the fwd+bwd curve of BASELINE's metric at THIS N (configs[2] at N=1, configs[3]'s step at N>1) and what the process
                     # group was: a SCALE record carries the gradient all-reduce whatever the headline workload is
                     "dp_train": {"error": t["error"]} if "error" in t else dict(
                         {"tiles_per_s": t.get("value"), "ms_per_step": t.get("ms_per_step"), "n_gpus": world,
                          "comm_ms": (t.get("comm") or {}).get("comm_ms"), "exposed_comm_ms": (t.get("comm") or {}).get("exposed_comm_ms"),
-                         "buckets": (t.get("comm") or {}).get("buckets"), "grad_bytes": (t.get("comm") or {}).get("grad_bytes")},
+                         "buckets": (t.get("comm") or {}).get("buckets"), "grad_bytes": (t.get("comm") or {}).get("grad_bytes"),
+                         "prefetch_hits_per_rank": (t.get("comm") or {}).get("prefetch_hits_per_rank")},
                         **_dist_info(dist)),
                 }
     if rank == 0:
