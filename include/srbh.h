@@ -628,14 +628,6 @@ int srbh_pwconv_bwd_data_res(const float* dy, const float* w, const float* res, 
 size_t srbh_pwconv_bwd_weight_ws_floats(int B, int Cin, int Cout, int HW);
 int srbh_pwconv_bwd_weight(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int Cout, int HW, void* stream);
 
-/* Deferred 1x1 weight gradients (round 5; harness.TrainStep around loss.backward()).  The reference obtains these from torch autograd
- * (train.py:254-256) and reads them only in optimizer.step(): between srbh_pwconv_wgrad_defer(1) and srbh_pwconv_wgrad_flush every
- * srbh_pwconv_bwd_weight call -- from any host thread: autograd runs backward on its own -- only QUEUES its job; the flush runs all queued jobs
- * of one kernel form as ONE launch (and every ordered reduce as one more) on `stream` and ends the deferral.  The caller keeps x / dy / dw /
- * ws of every queued job alive, and dw unread, until the flush.  Bit-identical to the immediate calls. */
-int srbh_pwconv_wgrad_defer(int on);
-int srbh_pwconv_wgrad_flush(void* stream);
-
 /* ---- inference epilogue: quantise + integer mosaic (predict_realesanet_feature_globe.py:172-204) ------------------
  * accumulate: height [B][th][tw] fp32 (model output, C=1), build logits NHWC [B][th][tw][C] fp32, pos [B][4] int32
  *   = (xoff, yoff, xcount, ycount) already multiplied by 4 (predict...py:182); adds round(max(h,0)*10) and

@@ -271,8 +271,6 @@ SIGNATURES = {
     "srbh_pwconv_bwd_data_res": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_pwconv_bwd_weight_ws_floats": (_sz, [_i, _i, _i, _i]),
     "srbh_pwconv_bwd_weight": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "srbh_pwconv_wgrad_defer": (_i, [_i]),
-    "srbh_pwconv_wgrad_flush": (_i, [_vp]),
     "srbh_dwconv_fwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "srbh_dwconv_bwd_data": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp]),
     "srbh_dwconv_bwd_weight_splits": (_i, [_i, _i]),

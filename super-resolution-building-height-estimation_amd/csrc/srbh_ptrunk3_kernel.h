@@ -17,9 +17,6 @@
 // predication in the epilogues).  Same arithmetic in the same order as ptrunk_kernel: bit-identical results.
 #pragma once
 
-#ifndef P3_READS_PER_SHADOW
-#define P3_READS_PER_SHADOW 2   // LDS reads of the next group per MFMA shadow
-#endif
 #ifndef P3_S1
 #define P3_S1 1                 // 1: x's second chunk and X1 are staged from registers; 0: every plane by LDS-DMA (A/B aid)
 #endif
@@ -28,15 +25,6 @@
 #endif
 #ifndef P3_SKIPST
 #define P3_SKIPST 1             // 1: a register-resident plane is stored to memory only where a neighbour reads it (its halo rows)
-#endif
-#ifndef P3_DEFER
-#define P3_DEFER 0               // 1: rows 1, 2 of a cout-32 epilogue run in the empty MFMA shadows of the next layer's step 0 (measured neutral: see DESIGN.md 5.0)
-#endif
-#ifndef P3_ABL
-#define P3_ABL 0                // developer ablations (WRONG RESULTS): 1 no weight DMA, 2 no input/halo DMA, 4 no register staging stores
-#endif
-#ifndef P3_DMA_FIRST
-#define P3_DMA_FIRST 1          // 1: a group's DMA statements sit behind its FIRST MFMAs, the LDS reads behind the later ones
 #endif
 #ifndef P3_LAZYDRAIN
 // 1 (round 3): a layer prologue waits only for what the layer's step 0 READS (the LDS-DMA issued during the previous layer's last
@@ -47,15 +35,11 @@
 // it waits for layer L, so the exchange cannot deadlock.
 #define P3_LAZYDRAIN 1
 #endif
-#ifndef P3_SPREAD
-// 1 (round 3): the next group's LDS reads are spread EVENLY over the group's MFMA shadows (one read behind every MFMA of a
-// cout-32 group, every second MFMA of conv5's) in the order of their FIRST USE, and the staging items share those shadows
-// (LDS and VMEM are separate issue paths).  The r02 schedule packed a group's 9 (12) reads, two per shadow, behind its LAST 5 (6)
-// MFMAs: all four waves march in lock-step, so every group boundary put 36 (48) ds_read_b128 = 288 (384) cycles of LDS
-// pipe into a 160 (192)-cycle window, with the fragment the next group's FIRST MFMA needs (A[dy=0]) issued 7th -- the matrix
-// core waited ~100 cycles at each of the 6 group boundaries of a step, and 7 reads deep after every step barrier.
-#define P3_SPREAD 1
-#endif
+// The next group's LDS reads are spread EVENLY over the group's MFMA shadows (round 3: one read behind every MFMA of a cout-32 group, every
+// second MFMA of conv5's) in the order of their FIRST USE, and the staging items share those shadows (LDS and VMEM are separate issue
+// paths).  The r02 schedule packed a group's 9 (12) reads, two per shadow, behind its LAST 5 (6) MFMAs: all four waves march in lock-step,
+// so every group boundary put 36 (48) ds_read_b128 into a 160 (192)-cycle window with the fragment the next group's FIRST MFMA needs
+// issued 7th.
 
 #ifndef P3_SEAM
 // 1 (round 5): the RDB seam without a cold stage.  conv5's epilogue ALSO ds_writes the own rows of the new x's first chunk into the resident
@@ -66,23 +50,20 @@
 #define P3_SEAM 1
 #endif
 
-#ifndef P3_WFLAGS
-// 1 (round 5): the neighbour-progress check is a property of the WAVE, inside the step that fetches the halo rows.  It used to be thread 0
-// polling the two progress words between two steps (an L2 round trip with the matrix core idle), an LDS word and two extra barriers, five
-// times per RDB.  Every wave issues a slice of each halo DMA statement, so every wave can check for itself: the two polls go out at the top
+// The neighbour-progress check is a property of the WAVE, inside the step that fetches the halo rows (round 5; it used to be thread 0
+// polling the two progress words between two steps -- an L2 round trip with the matrix core idle, an LDS word and two extra barriers, five
+// times per RDB).  Every wave issues a slice of each halo DMA statement, so every wave can check for itself: the two polls go out at the top
 // of the step as untracked loads, the step's other staging items (weights, the register-staged rows) and their MFMAs run, and the wave
 // looks at the result -- `s_waitcnt vmcnt(<DMA statements issued since>)` -- only in front of the halo statements, which are the LAST
 // staging items of such a step.  No LDS word, no barrier; a neighbour that is late makes the wave spin (bounded) where it stands.  A
 // timed-out spin sets the error word and the wave CARRIES ON (uniform control flow, every later spin ends at once on the error word): the
-// launch finishes with garbage that poison_on_error_kernel turns into NaN, as before.  Same arithmetic, same bits.
+// launch finishes with garbage that poison_on_error_kernel turns into NaN.
 // The counted wait is only as good as the count: a VMEM statement whose EXEC mask is EMPTY for a wave never reaches vmcnt, so the window
 // between the polls and the check may hold only statements every wave issues (see `stage_item`: the half-masked fifth weight statement
 // sits behind the check).  With it inside the window waves 2, 3 counted one too many, looked at the second poll (the lower neighbour's --
 // theirs) before it had landed and took whatever the register held: bit-identical in every quiet test and soak, 4 of 300 prefetches
 // wrong (once NaN) when the trunk shared the chip with the training step (profiles/r05bo_soak_pipelined_variants.txt; fixed:
 // profiles/r05bp_soak_fixed.txt, 1 500 of 1 500 identical; tests/test_gpu_pipeline.py keeps a short contended soak).
-#define P3_WFLAGS 1
-#endif
 
 #ifndef P3_PREREAD
 // 1 (round 5): the step barrier sits INSIDE the step, in front of the MFMA P3_PRE_AT of its last group, and the LDS reads of the NEXT step's
@@ -90,40 +71,8 @@
 // ds_read_b128 per wave, four waves at once on a 128 B/clk port) in front of an idle matrix core.  At the barrier every wave has drained its
 // own LDS-DMA (vmcnt(0)) and its LDS reads (lgkmcnt(0): the last group's operands are in registers), so the stage the next step reads is
 // complete and the stage this step read is free for the next step's staging items -- the two facts the top-of-step barrier established.
-// Steps of one layer only (the epilogue separates layers).  Needs P3_WFLAGS (nothing may sit between two steps) and P3_SPREAD.
+// Steps of one layer only (the epilogue separates layers).
 #define P3_PREREAD 1
-#endif
-#ifndef P3_PRELAYER
-// 1 (round 5): the same hand-over across a LAYER boundary inside an RDB (conv1 -> 2 -> 3 -> 4 -> 5).  A layer's last step holds a barrier in its
-// last group as well and reads the next layer's first operands (resident plane + the weights it has just fetched) behind it; they stay in
-// registers over the epilogue.  The layer prologue then has nothing left to wait for with a barrier: the stage the next step 0 overwrites was
-// last read before that barrier, and the bias goes into the OTHER of two LDS buffers (even / odd layer: the epilogue of the layer before may
-// still be reading its own), a barrier earlier than the epilogue that reads it.  conv5's bias area lies in phase A's stage 1, which conv4's
-// last step reads: it is written behind that step's barrier.  (The RDB seam keeps its barrier: conv1's step 0 reads the neighbours' rows.)
-// 2 = among the cout-32 layers only (1 also conv4 -> conv5: one VGPR spills).  MEASURED SLOWER, default off: same-box 3.740 / 3.726 ms
-// without, 3.753 / 3.757 with (2), 3.769 / 3.755 with (1) (profiles/r05v_ab_prelayer.txt) -- 36 more registers live across each epilogue
-// and the layer's last weight DMA has to land three groups earlier; bit-identical either way.
-#define P3_PRELAYER 0
-#endif
-#ifndef P3_CTAP
-// 1 (round 5): the centre-tap pixel fragments of a register-resident plane come from the registers.  For dx = 1 the B operand of the wave's own
-// rows (fragments 1..4 of the six) is exactly the 16 bytes per lane that x1p / X1r / X2r hold (the bytes the epilogue stored and the staging
-// wrote to LDS), so 8 of a step's 54 (72) ds_read_b128 disappear in the 12 of 20 steps that read chunk 1, X1 or X2.  A cout-32 step keeps the
-// LDS port busy for ~2.1 k of its 2.3 k MFMA cycles (54 reads x 29 cycles + 60 KB of LDS-DMA) -- but it does not pace it.  MEASURED NEUTRAL,
-// default off (it costs a second body for conv5's chunk-3 / chunk-4 steps): same-box 3.796 / 3.775 ms with, 3.765 / 3.806 without
-// (profiles/r05x_ab_ctap.txt); the ISA has the 96 reads less and 8 more v_mov; bit-identical.
-#define P3_CTAP 0
-#endif
-#ifndef P3_R2LDS
-// 1 (round 5): the RRDB-closing epilogue (every third RDB: x = 0.2 x + x_rrdb, the RRDB-level fp32 stream lives in memory, 128 KiB per
-// workgroup) fetches three of its four rows by LDS-DMA at the START of the epilogue into LDS nobody reads at that point (the stage the last
-// step read + the unused tail of the other one: 96 KiB of [IN_EX + 18 KiB, B_BIAS_OFF) and one 1 KiB unit behind the bias), the fourth into
-// registers as before: all 32 KiB x 4 are in flight at once under the first pass instead of two rows ahead with two exposed latencies
-// (12.5 k cycles per RRDB-closing epilogue against 4.9 k for a plain one).  Costs one more workgroup barrier per RRDB.  Same arithmetic.
-// MEASURED SLOWER, default off (profiles/r05an_ab_r2lds.txt): 3.743 / 3.746 ms without, 3.803 / 3.819 with -- the RRDB-closing epilogue
-// takes 16.6 k cycles instead of 12.6 k (one wait for 32 KiB x 4 in flight is not shorter than two rows ahead: the burst of all 256
-// workgroups is bandwidth-bound either way) and the PLAIN epilogue 6.8 k instead of 5.0 k (24 spilled VGPRs at the kernel's pressure peak).
-#define P3_R2LDS 0
 #endif
 #ifndef P3_TRAIN
 // 1: the kernel also runs the SR-stage TRAINING forward (PParams.dense_stride / keep_all / out_pixel: one dense buffer per RDB, whole planes,
@@ -241,31 +190,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
 
     // ---- neighbour progress (as ptrunk_kernel)
     int f_up = up < 0 ? 0x7fffffff : 0, f_dn = dn < 0 ? 0x7fffffff : 0;
-    bool aborted = false;
-    auto ensure_flags = [&](int need) {
-        auto* word = (__attribute__((address_space(3))) int*)(smem + P_WORD_OFF);
-        if (tid == 0) {
-            int bad = 0;
-            unsigned spins = 0;
-            while (f_up < need || f_dn < need) {
-                if (up >= 0) f_up = __hip_atomic_load(pp.prog + up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (dn >= 0) f_dn = __hip_atomic_load(pp.prog + dn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (f_up >= need && f_dn >= need) break;
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > SPIN_LIMIT || __hip_atomic_load(pp.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    bad = 1;
-                    break;
-                }
-            }
-            if (bad) __hip_atomic_store(pp.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *word = bad;
-        }
-        __syncthreads();
-        const int bad = *word;
-        __syncthreads();
-        if (bad) aborted = true;
-    };
-    // P3_WFLAGS: per-wave form (f_up / f_dn are then wave-uniform copies kept by every wave)
+    // per-wave progress check (f_up / f_dn are wave-uniform copies kept by every wave)
     int pq_up = 0, pq_dn = 0;
     const int inf_up = up < 0 ? 0x7fffffff : 0, inf_dn = dn < 0 ? 0x7fffffff : 0;
     auto poll_issue = [&]() {
@@ -381,45 +306,6 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         for (int m = 0; m < 2; ++m)
             x1p[i][m] = *(const uintx4*)(pp.dense[0] + tile_off + (long)pp.plane_b + (long)(wr * 4 + i + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16);
 
-    // ---- deferred half of a cout-32 epilogue (P3_DEFER).  Groups 3-5 of a step carry neither LDS reads nor staging items: ~20
-    // MFMA shadows of 28 cycles with nothing in them, while an epilogue is 350 VALU instructions with the matrix core idle.
-    // So conv1..3 finish only the rows a neighbour may read (0 and 3: halo rows, stored and published as before) right away and
-    // park the accumulators of rows 1, 2 (32 registers + 16 of bias); the next layer's step 0 works them off, one unit of ~6
-    // VALU instructions per empty shadow: 16 units (row, channel group, half) bias + leaky ReLU + fp16, 4 units (row, k-step)
-    // permlane + (store).  Their results are needed one step later at the earliest (staging of X1 / X2 from registers, the own
-    // DMA of X3), and no neighbour ever reads these rows.  Same arithmetic, same bits.
-    float pend[2][16];
-    floatx4 pbias[4];
-    unsigned php[2][4][2];
-    uintx4 pk[2][2];
-    char* poplane = nullptr;
-    bool pst = false;
-    auto defer_unit = [&](const int u) {
-        if (u < 16) {
-            const int r = u >> 3, g = (u >> 1) & 3, hh = u & 1;
-            float w0 = pend[r][g * 4 + 2 * hh] + pbias[g][2 * hh], w1 = pend[r][g * 4 + 2 * hh + 1] + pbias[g][2 * hh + 1];
-            const float s0 = w0 * 0.2f, s1 = w1 * 0.2f;
-            asm("v_max_f32 %0, %1, %2" : "=v"(w0) : "v"(w0), "v"(s0));
-            asm("v_max_f32 %0, %1, %2" : "=v"(w1) : "v"(w1), "v"(s1));
-            typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-            const half2v h2 = {(_Float16)w0, (_Float16)w1};
-            php[r][g][hh] = __builtin_bit_cast(unsigned, h2);
-        } else {
-            const int r = (u - 16) >> 1, m = (u - 16) & 1, i = 1 + r;
-            auto s0 = __builtin_amdgcn_permlane32_swap(php[r][2 * m][0], php[r][2 * m + 1][0], false, false);
-            auto s1 = __builtin_amdgcn_permlane32_swap(php[r][2 * m][1], php[r][2 * m + 1][1], false, false);
-            const uintx4 raw = {s0[0], s1[0], s0[1], s1[1]};
-            pk[r][m] = raw;
-            if (pst) {
-                char* o = poplane + (long)(Y0 + wr * 4 + i + 1) * pp.row_b + (X + 1) * PIX_B + m * 32 + hi * 16;
-                if (wt)
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
-                else
-                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(o), "v"(raw) : "memory");
-            }
-        }
-    };
-
     auto publish_pending = [&]() {
         if (pending_pub) {
             publish(pub_val);
@@ -439,59 +325,49 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         }
     };
 
-    half8 Pq[2][G::NP], Aq[2][3][2];   // operand fragments of two MFMA groups (kernel scope: P3_PREREAD hands group 0's over a step boundary)
+    half8 Pq[2][G::NP], Aq[2][3][2];   // operand fragments of two MFMA groups (kernel scope: group 0's are handed over a step boundary)
     // ---- one K step.  CB = cout/32 of the running layer.  What is staged for the NEXT step is a compile-time property:
     //   IN: 0 no input plane | 1 input plane by LDS-DMA (11 statements) | 2 input plane from registers (8 ds_write_b128 + 1
     //   border write + 2 halo DMA statements);   NW: weight DMA statements per wave (0 | 5 = 18 fragments | 9 = 36 fragments)
     auto run_step = [&](auto cb_tag, auto in_tag, auto nw_tag, floatx16 (&acc)[decltype(cb_tag)::value][4], const char* sbi, const char* sbw,
-                        const char* nsrc, const char* nw, char* dst, const uintx4 (&rsrc)[4][2], auto defer_tag, auto flag_tag, const int need,
-                        auto pre_tag, auto nxt_tag, auto rc_tag, const uintx4 (&rcur)[4][2]) {
+                        const char* nsrc, const char* nw, char* dst, const uintx4 (&rsrc)[4][2], auto flag_tag, const int need,
+                        auto pre_tag, auto nxt_tag) {
         constexpr int CB = decltype(cb_tag)::value, IN = decltype(in_tag)::value, NW = decltype(nw_tag)::value;
-        // FL (P3_WFLAGS): this step fetches rows of a neighbour (the plane it stages is new on them): polls at the top, the check in front
-        // of the statements that carry those rows, which are then the LAST staging items of the step (need < 0: no check this time)
-        constexpr bool FL = P3_WFLAGS && decltype(flag_tag)::value != 0;
+        // FL: this step fetches rows of a neighbour (the plane it stages is new on them): polls at the top, the check in front of the
+        // statements that carry those rows, which are then the LAST staging items of the step (need < 0: no check this time)
+        constexpr bool FL = decltype(flag_tag)::value != 0;
         static_assert(!FL || IN != 0, "a flagged step stages an input plane");
-        constexpr bool DEFER = decltype(defer_tag)::value;   // also work off the parked half of the previous layer's epilogue
         constexpr int NRD = G::NP + 3 * CB, NMF = 12 * CB;
         constexpr int NH = 2;                                           // halo DMA statements of a register-staged plane
         constexpr int NDMA = (IN == 1 ? 11 : IN == 2 ? NH : 0) + NW;    // DMA statements
         constexpr int ND = NDMA + (IN == 2 ? 9 : 0);                    // + LDS stores of a register-staged plane
-        constexpr int RSH = (NRD + P3_READS_PER_SHADOW - 1) / P3_READS_PER_SHADOW;   // MFMA shadows of a group that carry LDS reads
-        constexpr int DPG = NMF - RSH;                                                 // ... that can carry a staging item
-        static_assert(ND + (DEFER ? 20 : 0) <= 6 * (P3_SPREAD ? 12 : DPG), "the staging items (and deferred epilogue units) of a step must fit its MFMA shadows");
+        static_assert(ND <= 6 * 12, "the staging items of a step must fit its MFMA shadows");
         // LDS reads of a group in the order of their first use by the MFMA sequence below (m = dy-major, then row, then channel block):
         // r < NP: pixel-row fragment P[r]; r = NP + dy * CB + mb: weight fragment A[dy][mb]
         constexpr int ORD1[9] = {6, 0, 1, 2, 3, 7, 4, 8, 5};                   // CB = 1: A0 P0 P1 P2 P3 A1 P4 A2 P5
         constexpr int ORD2[12] = {6, 0, 7, 1, 2, 3, 8, 9, 4, 10, 11, 5};       // CB = 2: A00 P0 A01 P1 P2 P3 A10 A11 P4 A20 A21 P5
         static_assert(G::NP == 6, "read order tables are written for 6 pixel-row fragments");
-        constexpr int RSTRIDE = NMF / NRD;                                      // shadows per read when spread: 1 (CB = 1), 2 (CB = 2)
+        constexpr int RSTRIDE = NMF / NRD;                                      // shadows per read: 1 (CB = 1), 2 (CB = 2)
         const unsigned long long ibase = uni64((unsigned long long)nsrc);
         const unsigned long long wbase = uni64((unsigned long long)(nw + wave * 1024));
         const unsigned din_w = __builtin_amdgcn_readfirstlane(lds_addr(dst) + wave * 1024);
         const unsigned dw_w = din_w + IN_EX;
-        constexpr bool PRE = P3_PREREAD && decltype(pre_tag)::value != 0;   // group 0's operands were read by the previous step
-        constexpr int NXV = P3_PREREAD ? decltype(nxt_tag)::value : 0;       // 1: next step of this layer; 2 / 3: step 0 of the next layer (cout 32 / 64)
-        constexpr bool NXT = NXV != 0;                                        // this step holds the barrier and reads the next step's group 0
-        constexpr int NCB = NXV == 3 ? 2 : NXV == 2 ? 1 : CB;                 // cout / 32 of the step those reads belong to
-        constexpr int NRDN = G::NP + 3 * NCB;
-        constexpr int AT = P3_PRE_AT < NMF - NRDN ? P3_PRE_AT : NMF - NRDN;   // MFMA of the last group the barrier sits in front of
-        static_assert(!P3_PREREAD || (P3_WFLAGS && P3_SPREAD), "P3_PREREAD needs P3_WFLAGS and P3_SPREAD");
+        constexpr bool PRE = decltype(pre_tag)::value != 0;    // group 0's operands were read by the previous step
+        constexpr bool NXT = decltype(nxt_tag)::value != 0;    // this step holds the barrier and reads the next step's group 0 (same layer)
+        constexpr int AT = P3_PRE_AT < NMF - NRD ? P3_PRE_AT : NMF - NRD;   // MFMA of the last group the barrier sits in front of
         static_assert(AT >= 0, "the next step's first reads must fit behind the barrier");
         half8 (&P)[2][G::NP] = Pq;
         half8 (&A)[2][3][2] = Aq;
-        auto read_from = [&](auto rcb_tag, const char* bi, const char* bw, const int g, const int r, const int set) {   // LDS read r (0..NRD-1) of group g
-            constexpr int RCB = decltype(rcb_tag)::value;
+        auto read_from = [&](const char* bi, const char* bw, const int g, const int r, const int set) {   // LDS read r (0..NRD-1) of group g
             const int ks = g / 3, dx = g - ks * 3;
-            if (P3_CTAP && decltype(rc_tag)::value != 0 && bi == sbi && dx == 1 && r >= 1 && r <= 4) {
-                P[set][r] = __builtin_bit_cast(half8, rcur[r - 1][ks]);     // (P3_CTAP: the lane's own pixel of an own row)
-            } else if (r < G::NP) {
+            if (r < G::NP) {
                 P[set][r] = *(const half8*)(bi + aoff[dx][ks] + r * G::ROW_B);
             } else {
-                const int q = r - G::NP, dy = q / RCB, mb = q - dy * RCB;
-                A[set][dy][mb] = *(const half8*)(bw + woff + ((((dy * 3 + dx) * 2 + ks) * RCB + mb) << 10));
+                const int q = r - G::NP, dy = q / CB, mb = q - dy * CB;
+                A[set][dy][mb] = *(const half8*)(bw + woff + ((((dy * 3 + dx) * 2 + ks) * CB + mb) << 10));
             }
         };
-        auto read_item = [&](const int g, const int r, const int set) { read_from(cb_tag, sbi, sbw, g, r, set); };
+        auto read_item = [&](const int g, const int r, const int set) { read_from(sbi, sbw, g, r, set); };
         auto stage_item = [&](const int d) {
             // Flagged steps count the VMEM instructions between the polls and the check (poll_check's vmcnt immediate), so
             // every statement in that window must be one that EVERY wave issues: a statement whose EXEC mask is empty for a
@@ -529,9 +405,6 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 }
                 return;
             }
-            if ((P3_ABL & 1) && d >= (IN == 1 ? 11 : IN == 2 ? NH : 0) && d < NDMA) return;
-            if ((P3_ABL & 2) && d < (IN == 1 ? 11 : IN == 2 ? NH : 0)) return;
-            if ((P3_ABL & 4) && d >= NDMA) return;
             if constexpr (IN == 2) {
                 if (d < NH) {           // the neighbours' rows
                     dma(SC1{}, ibase, hoff[d], din_w + (d ? G::ROWS - 1 : 0) * G::ROW_B + PIX_B);
@@ -550,7 +423,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         if constexpr (FL) poll_issue();
         if constexpr (!PRE) {
 #pragma unroll
-            for (int r = 0; r < NRD; ++r) read_item(0, P3_SPREAD ? (CB == 1 ? ORD1[r % 9] : ORD2[r % 12]) : r, 0);
+            for (int r = 0; r < NRD; ++r) read_item(0, CB == 1 ? ORD1[r % 9] : ORD2[r % 12], 0);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -561,7 +434,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 if constexpr (NXT) {
                     if (g == 5 && m == AT) {             // the step barrier (see P3_PREREAD)
                         step_sync();
-                        if constexpr (NXV == 1) publish_pending();   // (the layer's first barrier carries the lazy publication of the previous layer's output)
+                        publish_pending();               // (the layer's first barrier carries the lazy publication of the previous layer's output)
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -570,44 +443,19 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 else
                     acc[mb][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[g & 1][dy][mb], P[g & 1][i + dy], acc[mb][i], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (P3_SPREAD) {
-                    const int k = m / RSTRIDE;
-                    if (g + 1 < 6 && m % RSTRIDE == 0 && k < NRD) read_item(g + 1, CB == 1 ? ORD1[k % 9] : ORD2[k % 12], (g + 1) & 1);
-                    if constexpr (NXT) {                 // the next step's group 0 (it reads what this step staged: dst, dst + IN_EX), one read per shadow
-                        const int k2 = m - AT;
-                        // (a next LAYER's step 0 reads the resident plane -- phase B's stage 0 starts at the same address -- and the weights this step fetched)
-                        if (g == 5 && k2 >= 0 && k2 < NRDN)
-                            read_from(std::integral_constant<int, NCB>{}, NXV == 1 ? dst : smem, dst + IN_EX, 0, NCB == 1 ? ORD1[k2 % 9] : ORD2[k2 % 12], 0);
-                    }
-                    // staging: one item per shadow for a cout-32 group (12), every other shadow of conv5's (the ones without a read)
-                    const int sm = CB == 1 ? m : (m % 2 ? m / 2 : -1);
-                    if (sm >= 0) {
-                        const int d = g * 12 + sm;
-                        if (d < ND) stage_item(d);
-                        else if (DEFER && d - ND < 20) defer_unit(d - ND);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    continue;
+                const int k = m / RSTRIDE;
+                if (g + 1 < 6 && m % RSTRIDE == 0 && k < NRD) read_item(g + 1, CB == 1 ? ORD1[k % 9] : ORD2[k % 12], (g + 1) & 1);
+                if constexpr (NXT) {                 // the next step's group 0 (it reads what this step staged: dst, dst + IN_EX), one read per shadow
+                    const int k2 = m - AT;
+                    if (g == 5 && k2 >= 0 && k2 < NRD) read_from(dst, dst + IN_EX, 0, CB == 1 ? ORD1[k2 % 9] : ORD2[k2 % 12], 0);
                 }
-                const int mr = P3_DMA_FIRST ? m - DPG : m;          // shadow index among the read-carrying ones
-                const int md = P3_DMA_FIRST ? m : m - RSH;          // ... among the staging ones
-                if (mr >= 0 && mr < RSH) {
-                    if (g + 1 < 6) {
-#pragma unroll
-                        for (int q = 0; q < P3_READS_PER_SHADOW; ++q)
-                            if (mr * P3_READS_PER_SHADOW + q < NRD) read_item(g + 1, mr * P3_READS_PER_SHADOW + q, (g + 1) & 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else {
-                    const int d = g * DPG + md;
-                    if (d < ND) {
-                        stage_item(d);
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else if (DEFER && d - ND < 20) {
-                        defer_unit(d - ND);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                // staging: one item per shadow for a cout-32 group (12), every other shadow of conv5's (the ones without a read)
+                const int sm = CB == 1 ? m : (m % 2 ? m / 2 : -1);
+                if (sm >= 0) {
+                    const int d = g * 12 + sm;
+                    if (d < ND) stage_item(d);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -621,31 +469,22 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     using W0 = std::integral_constant<int, 0>;   // NW: weight DMA statements per wave
     using W5 = std::integral_constant<int, 5>;
     using W9 = std::integral_constant<int, 9>;
-    using NODEFER = std::false_type;
-    using DODEFER = std::true_type;
     using F0 = std::integral_constant<int, 0>;   // flag_tag: no neighbour rows in what the step stages / the step checks the neighbours' progress
     using F1 = std::integral_constant<int, 1>;
-    using Q0 = std::integral_constant<int, 0>;   // pre_tag / nxt_tag (P3_PREREAD)
+    using Q0 = std::integral_constant<int, 0>;   // pre_tag / nxt_tag
     using Q1 = std::integral_constant<int, 1>;
-    using Q2 = std::integral_constant<int, 2>;
-    using Q3 = std::integral_constant<int, 3>;
-    using R0 = std::integral_constant<int, 0>;   // rc_tag: the plane the step READS has a register copy (rcur)
-    using R1 = std::integral_constant<int, P3_S1 ? 1 : 0>;
-    using R1X = std::integral_constant<int, (P3_S1 && P3_X2REG) ? 1 : 0>;
-    constexpr bool PR = P3_PREREAD != 0;
-    constexpr bool PL = PR && P3_PRELAYER != 0 && P3_LAZYDRAIN != 0 && !P3_DEFER;
-    constexpr bool PL5 = PL && P3_PRELAYER == 1;      // ... also conv4 -> conv5 (P3_PRELAYER = 2: the cout-32 layers among themselves only)
-    // P3_PRELAYER: no barrier -- the wait leaves the epilogue's NST stores in flight and covers the bias load in front of them
-    auto bias_commit = [&](auto nst_tag, const float bias_v, const int nb, const int bias_lds) {
-        constexpr int NST = decltype(nst_tag)::value;
-        if constexpr (NST == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid < nb) ((float*)(smem + bias_lds))[tid] = bias_v;
-    };
 
-    // ---- layer prologue: drain the own DMA / stores, barrier, bias into LDS, lazy publish
-    auto prologue = [&](const float* bias, const int nb, const int bias_lds) {
+    // The next layer's bias is requested BEFORE the epilogue's stores (an asm load: the compiler's own wait for a load it tracks would be
+    // vmcnt(0) -- it does not count the asm stores issued behind it), so that `vmcnt(NST)` in the prologue covers it together with the
+    // step-0 DMA and leaves exactly the epilogue's NST stores in flight
+    auto bias_request = [&](const float* bias, const int nb) {
+        float v;
+        const float* q = bias + (tid < nb ? tid : 0);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(q) : "memory");
+        return v;
+    };
+    // ---- layer prologue: wait for what step 0 reads, barrier, bias into LDS (the first layer of an RDB: everything has drained at the seam)
+    auto prologue_cold = [&](const float* bias, const int nb, const int bias_lds) {
         float bias_v = 0.f;
         if (tid < nb) bias_v = bias[tid];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -656,16 +495,7 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             pending_pub = false;
         }
     };
-    // P3_LAZYDRAIN: the next layer's bias is requested BEFORE the epilogue's stores (an asm load: the compiler's own wait for a load
-    // it tracks would be vmcnt(0) -- it does not count the asm stores issued behind it), so that `vmcnt(NST)` in the prologue
-    // covers it together with the step-0 DMA and leaves exactly the epilogue's NST stores in flight
-    auto bias_request = [&](const float* bias, const int nb) {
-        float v;
-        const float* q = bias + (tid < nb ? tid : 0);
-        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(q) : "memory");
-        return v;
-    };
-    auto prologue_lazy = [&](auto nst_tag, const float bias_v, const int nb, const int bias_lds) {
+    auto prologue = [&](auto nst_tag, const float bias_v, const int nb, const int bias_lds) {
         constexpr int NST = decltype(nst_tag)::value;
         if constexpr (NST == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -673,10 +503,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         __syncthreads();
         if (tid < nb) ((float*)(smem + bias_lds))[tid] = bias_v;
     };
-    // ---- epilogue of a cout-32 layer: bias, leaky ReLU, fp16, straight from the MFMA D layout (see ptrunk_kernel)
-    auto epi32 = [&](floatx16 (&acc)[1][4], char* oplane, uintx4 (&keep)[4][2], const bool halo_only, auto park_tag, const int bias_lds, const char* mplane = nullptr) {
-        constexpr bool PARK = decltype(park_tag)::value;   // rows 1, 2 are parked for the next layer's step 0 (defer_unit)
-        static_assert(!(BW && PARK && P3_DEFER), "the backward form keeps no parked rows");
+    // ---- epilogue of a cout-32 layer: bias, leaky ReLU, fp16, straight from the MFMA D layout
+    auto epi32 = [&](floatx16 (&acc)[1][4], char* oplane, uintx4 (&keep)[4][2], const bool halo_only, const char* mplane = nullptr) {
         // BW: the saved forward plane's 16-byte records of this lane's four rows (same addresses as the stores below, in the mask buffer): all
         // eight loads go out in front of the arithmetic (the operand registers of the K loop are dead here)
         uintx4 mk[4][2];
@@ -691,20 +519,10 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         }
         floatx4 bias4[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bias4[g] = *(const floatx4*)((const float*)(smem + bias_lds) + g * 8 + hi * 4);
+        for (int g = 0; g < 4; ++g) bias4[g] = *(const floatx4*)((const float*)(smem + A_BIAS_OFF) + g * 8 + hi * 4);
         // rows 0 and 3 first: one of them is the row a neighbour reads (its store is the one the publication waits for)
-        if constexpr (PARK) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) pend[r][q] = acc[0][1 + r][q];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) pbias[g] = bias4[g];
-            poplane = oplane;
-            pst = !halo_only;
-        }
-#pragma unroll
-        for (int io = 0; io < (PARK ? 2 : 4); ++io) {
+        for (int io = 0; io < 4; ++io) {
             const int i = io == 0 ? 0 : io == 1 ? 3 : io - 1;
             const int Y = Y0 + wr * 4 + i;
             const bool st = !halo_only || (i == 0 && wr == 0) || (i == 3 && wr == 1);   // (wave-uniform)
@@ -769,8 +587,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             }
         }
     };
-    // ---- epilogue of conv5: x = 0.2 (acc + bias) + x in registers (+ the RRDB-level stream every third RDB), fp16 copy out
-    // one row of x (channel block mb) -> fp16 fragments, kept (mb == 1) and stored where somebody reads them from memory
+    // one row of x (channel block mb) -> 16-bit fragments, kept (mb == 1), written into the next RDB's resident plane (mb == 0, to_lds) and
+    // stored where somebody reads them from memory
     auto x_row_out = [&](const int mb, const int i, char* obase, const bool st, const bool to_lds = false) {
         const int Y = Y0 + wr * 4 + i;
         unsigned hp[4][2];
@@ -825,40 +643,9 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         // The RRDB-level stream of an RRDB-closing RDB: its 8 loads per row are issued TWO ROWS AHEAD of their use (two register
         // slots of 32): rows 0 and 3 during the first pass -- they land under its arithmetic -- and rows 1, 2 as the slots free
         // up.  (Loading each row pair right before its use cost 17 k cycles per RRDB-closing epilogue against 3.6 k for a plain
-        // one: two fully exposed memory latencies plus a wasted fp16 pass.)
+        // one: two fully exposed memory latencies plus a wasted fp16 pass.  All four rows at once by LDS-DMA into the idle stage
+        // was built and is slower -- the burst of all 256 workgroups is bandwidth-bound either way: profiles/r05an_ab_r2lds.txt.)
         floatx4 a2[2][2][4];
-        // P3_R2LDS: where the 1 KiB unit k (= instruction (mb, g)) of row slot s of THIS wave sits in LDS
-        constexpr int R2_BASE = IN_EX + 18 * 1024, R2_UNITS = (B_BIAS_OFF - R2_BASE) / 1024, R2_SPILL = B_BIAS_OFF + 256;
-        static_assert(R2_UNITS == 95 && R2_SPILL + 1024 <= A_BIAS_OFF, "P3_R2LDS: three rows of the RRDB-level stream = 96 units: 95 in front of the bias, one behind it");
-        auto r2_off = [&](const int s_, const int k) {
-            const int L = (s_ * 4 + wave) * 8 + k;
-            return L < R2_UNITS ? R2_BASE + L * 1024 : R2_SPILL + (L - R2_UNITS) * 1024;
-        };
-        const bool r2lds = P3_R2LDS && r2 && !r2_pixel;       // (the first closing reads conv_first's pixel-order output: the register path)
-        if (r2lds) {
-            __syncthreads();                                  // every wave is past the last step's LDS reads (the rows land in that stage)
-            // rows 0, 3, 1: the order they are closed in; row 2 comes through registers (below).  A ROLLED loop over the rows: unrolled, the 24
-            // statements' scalar bases cost 50 more SGPR spills and 9 VGPR spills
-#pragma unroll 1
-            for (int s_ = 0; s_ < 3; ++s_) {
-                const int row = s_ == 0 ? 0 : s_ == 1 ? 3 : 1;
-                const long rowb = ((long)img * pp.H + Y0 + wr * 4 + row) * pp.W * 64;
-                const unsigned long long rb = uni64((unsigned long long)(pp.xrr + rowb + wc * 2048));
-                const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr(smem) + R2_BASE + (s_ * 4 + wave) * 8 * 1024);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    unsigned lo = lb + k * 1024;
-                    if (k == 7) lo = (s_ * 4 + wave) * 8 + 7 < R2_UNITS ? lo : (unsigned)__builtin_amdgcn_readfirstlane(lds_addr(smem) + R2_SPILL);   // (the one unit that does not fit)
-                    dma(NOSC{}, rb + k * 1024, woff, lo);
-                }
-            }
-        }
-        auto fetch_a2 = [&](const int slot, const int s_) {   // a row slot from LDS (this wave's own units)
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) a2[slot][mb][g] = *(const floatx4*)(smem + r2_off(s_, mb * 4 + g) + lane * 16);
-        };
         auto load_a2 = [&](const int slot, const int i) {
             const long rowb = ((long)img * pp.H + Y0 + wr * 4 + i) * pp.W * 64;
             const float* q2 = pp.xrr + rowb + (r2_pixel ? X * 64 + hi * 4 : frag_lane);
@@ -874,8 +661,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             const int i = io == 0 ? 0 : io == 1 ? 3 : io - 1;
             // (a slot's loads go out right behind the first pass of its row: the row's 32 accumulator registers are dead by then,
             //  so the prefetch costs no registers at the kernel's pressure peak; they land under the first pass of rows 1, 2)
-            if (r2 && io == 1) load_a2(0, r2lds ? 2 : 0);
-            if (r2 && io == 2 && !r2lds) load_a2(1, 3);
+            if (r2 && io == 1) load_a2(0, 0);
+            if (r2 && io == 2) load_a2(1, 3);
             const bool halo = (i == 0 && wr == 0) || (i == 3 && wr == 1);   // (wave-uniform)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
@@ -912,23 +699,12 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                         asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(vo), "v"(xres[mb][i][g]), "s"(sb) : "memory");
                     }
             };
-            if (r2lds) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the 24 LDS-DMA statements (and row 2's loads): all went out before the first pass
-                fetch_a2(1, 0);
-                close_row(1, 0);
-                fetch_a2(1, 1);
-                close_row(1, 3);
-                fetch_a2(1, 2);
-                close_row(1, 1);
-                close_row(0, 2);
-            } else {
-                close_row(0, 0);
-                load_a2(0, 1);
-                close_row(1, 3);
-                load_a2(1, 2);
-                close_row(0, 1);
-                close_row(1, 2);
-            }
+            close_row(0, 0);
+            load_a2(0, 1);
+            close_row(1, 3);
+            load_a2(1, 2);
+            close_row(0, 1);
+            close_row(1, 2);
         }
     };
 
@@ -940,17 +716,15 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
     //  conv5's last step can prefetch them at the seam)
     stage_cold(dcur, smem, pp.layers[0].w, smem + stage_off(1, 0) + (P3_SEAM ? 0 : IN_EX), W5{});
     const int nrdb = pp.nlayers / 5;
-    for (int rdb = 0; rdb < nrdb && !aborted; ++rdb) {
+    for (int rdb = 0; rdb < nrdb; ++rdb) {
         const PLayer* T = pp.layers + rdb * 5;
         const int L0 = rdb * 5;
         int gs = 0;
-        // ---------------- conv1..conv4 (cout 32, plane 0 resident, stages of IN_EX + 18 KiB).  One body for conv1..3 and one
-        // for conv4 (their last steps stage different things: compiling them as two variants of ONE layer body made the
-        // accumulators of the two last-step variants meet in a phi, i.e. 64 v_accvgpr_mov per layer)
-        float next_bias = 0.f;   // P3_LAZYDRAIN: the next layer's bias element of this thread, requested ahead of the epilogue
+        // ---------------- conv1..conv4 (cout 32, plane 0 resident, stages of IN_EX + 18 KiB).  One body per layer (kk is a compile-time
+        // constant; conv1..3 and conv4 stage different things in their last steps: compiled as two variants of ONE layer body the
+        // accumulators of the two last-step variants met in a phi, i.e. 64 v_accvgpr_mov per layer)
+        float next_bias = 0.f;   // the next layer's bias element of this thread, requested ahead of the epilogue
         auto layerA = [&](auto kk_tag, auto last_nw_tag) {
-            // (kk is a compile-time constant: four bodies per RDB instead of two, but the parked epilogue registers of P3_DEFER are
-            //  then provably dead outside conv1..3 -> conv2..4; as a run-time loop variable they were live across conv5: 217 spills)
             constexpr int kk = decltype(kk_tag)::value;
             const int L = L0 + kk, n = kk + 2;
             const char* wl = T[kk].w;
@@ -959,10 +733,9 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             if (P3_LAZYDRAIN && kk > 0) {
                 // stores of the previous layer's epilogue still in flight per wave: X1 / X2 go out as one halo row (2 x 16 B), X3 whole (8)
                 constexpr bool prev_halo_only = P3_SKIPST && P3_S1 && (kk - 1 == 0 || (P3_X2REG && kk - 1 == 1));
-                if constexpr (PL) bias_commit(std::integral_constant<int, prev_halo_only ? 2 : 8>{}, next_bias, 32, A_BIAS_OFF + (kk & 1) * 128);
-                else prologue_lazy(std::integral_constant<int, prev_halo_only ? 2 : 8>{}, next_bias, 32, A_BIAS_OFF);
+                prologue(std::integral_constant<int, prev_halo_only ? 2 : 8>{}, next_bias, 32, A_BIAS_OFF);
             } else {
-                prologue(T[kk].bias, 32, A_BIAS_OFF);
+                prologue_cold(T[kk].bias, 32, A_BIAS_OFF);
             }
             if (PROF) p1 = __builtin_amdgcn_s_memtime();
             t_sync = 0;
@@ -972,108 +745,58 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][i][r] = 0.f;
-            // step 0: resident plane 0; stages chunk 1 (x's second half) from registers
-            if (P3_DEFER && kk > 0) {   // ... and works off rows 1, 2 of the previous layer's epilogue in its empty MFMA shadows
-                run_step(C1{}, I2{}, W5{}, acc, smem, smem + stage_off(1, gs & 1) + IN_EX, dcur + (long)pp.plane_b, wl + 18 * 1024,
-                         smem + stage_off(1, (gs + 1) & 1), x1p, DODEFER{}, F0{}, 0, Q0{}, Q1{}, R0{}, x1p);
-                if (kk == 1) {
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) X1r[1 + r][m] = pk[r][m];
-                }
-                if (kk == 2) {
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) X2r[1 + r][m] = pk[r][m];
-                }
-            } else {
-                run_step(C1{}, I2{}, W5{}, acc, smem, smem + stage_off(1, gs & 1) + ((P3_SEAM && kk == 0) ? 0 : IN_EX), dcur + (long)pp.plane_b, wl + 18 * 1024,
-                         smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{}, F0{}, 0, std::integral_constant<int, (PL && kk > 0) ? 1 : 0>{}, Q1{}, R0{}, x1p);
-            }
+            // step 0: resident plane 0; stages chunk 1 (x's second half) from registers.  Its barrier (inside its last MFMA group) is the
+            // layer's FIRST: it carries the lazy publication of the previous layer's output (its vmcnt(0) covers the epilogue stores that
+            // drained under step 0), in front of any neighbour check of this layer
+            run_step(C1{}, I2{}, W5{}, acc, smem, smem + stage_off(1, gs & 1) + ((P3_SEAM && kk == 0) ? 0 : IN_EX), dcur + (long)pp.plane_b, wl + 18 * 1024,
+                     smem + stage_off(1, (gs + 1) & 1), x1p, F0{}, 0, Q0{}, Q1{});
             ++gs;
-            // the layer's FIRST top-of-step barrier (P3_LAZYDRAIN: it carries the lazy publication of the previous layer's output:
-            // its vmcnt(0) covers the epilogue stores that drained under step 0), in front of any neighbour check
-            bool synced = PR;         // (P3_PREREAD: every step but a layer's last holds the barrier itself)
-            if (P3_LAZYDRAIN && !PR) {
-                step_sync();
-                publish_pending();
-                synced = true;
-            }
-            // The only NEW input plane of conv2..4 is the last chunk (index kk + 1): its halo rows are fetched during step kk, so
-            // the neighbours' progress is checked right in front of that step (conv1's inputs were verified at the seam).
-            if (!P3_WFLAGS && kk == 1) {
-                ensure_flags(L);
-                if (aborted) return;
-            }
+            // The only NEW input plane of conv2..4 is the last chunk (index kk + 1): its halo rows are fetched during step kk, which checks
+            // the neighbours' progress itself (conv1's inputs were verified at the seam).
             if (n >= 3) {      // step 1: chunk 1; stages chunk 2 (X1) from registers
-                if (!synced) step_sync();
-                synced = PR;
                 const char* st = smem + stage_off(1, gs & 1);
                 run_step(C1{}, I2{}, W5{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (18 * 1024),
-                         smem + stage_off(1, (gs + 1) & 1), X1r, NODEFER{}, std::integral_constant<int, kk == 1>{}, L, Q1{}, Q1{}, R1{}, x1p);
+                         smem + stage_off(1, (gs + 1) & 1), X1r, std::integral_constant<int, kk == 1>{}, L, Q1{}, Q1{});
                 ++gs;
             }
             if (n >= 4) {      // step 2: chunk 2; stages chunk 3 (X2) from registers
-                if (!P3_WFLAGS && kk == 2) {
-                    ensure_flags(L);
-                    if (aborted) return;
-                }
-                if (!PR) step_sync();
                 const char* st = smem + stage_off(1, gs & 1);
                 run_step(C1{}, I2X{}, W5{}, acc, st, st + IN_EX, dcur + 3l * pp.plane_b, wl + 3 * (18 * 1024),
-                         smem + stage_off(1, (gs + 1) & 1), X2r, NODEFER{}, std::integral_constant<int, kk == 2>{}, L, Q1{}, Q1{}, R1{}, X1r);
+                         smem + stage_off(1, (gs + 1) & 1), X2r, std::integral_constant<int, kk == 2>{}, L, Q1{}, Q1{});
                 ++gs;
             }
             if (n >= 5) {      // step 3 (conv4): chunk 3; stages chunk 4 (X3) by DMA
-                if (!P3_WFLAGS) {
-                    ensure_flags(L);
-                    if (aborted) return;
-                }
-                if (!PR) step_sync();
                 const char* st = smem + stage_off(1, gs & 1);
                 run_step(C1{}, I1{}, W5{}, acc, st, st + IN_EX, dcur + 4l * pp.plane_b, wl + 4 * (18 * 1024),
-                         smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{}, F1{}, L, Q1{}, Q1{}, R1X{}, X2r);
+                         smem + stage_off(1, (gs + 1) & 1), x1p, F1{}, L, Q1{}, Q1{});
                 ++gs;
             }
-            if (!synced) step_sync();
             {
                 const char* st = smem + stage_off(1, gs & 1);
                 // (the last step reads chunk kk + 1: x's second half, X1, X2 -- register-resident -- or X3)
-                const auto& rlast = [&]() -> const uintx4 (&)[4][2] {
-                    if constexpr (kk == 0) return x1p;
-                    else if constexpr (kk == 1) return X1r;
-                    else return X2r;
-                }();
                 if constexpr (decltype(last_nw_tag)::value == 5)   // conv1..3: the next layer's step 0 reads the resident plane: weights only
-                    run_step(C1{}, I0{}, W5{}, acc, st, st + IN_EX, nullptr, T[kk + 1].w, smem + stage_off(1, (gs + 1) & 1), x1p, NODEFER{}, F0{}, 0, Q1{}, std::integral_constant<int, PL ? 2 : 0>{},
-                             std::integral_constant<int, kk == 2 ? R1X::value : R1::value>{}, rlast);
+                    run_step(C1{}, I0{}, W5{}, acc, st, st + IN_EX, nullptr, T[kk + 1].w, smem + stage_off(1, (gs + 1) & 1), x1p, F0{}, 0, Q1{}, Q0{});
                 else              // conv4: conv5's chunk 0 IS the resident plane (phase-B stage 0 starts at the same address): 36 KiB of weights
-                    run_step(C1{}, I0{}, W9{}, acc, st, st + IN_EX, nullptr, T[4].w, smem + stage_off(2, 0), x1p, NODEFER{}, F0{}, 0, Q1{}, std::integral_constant<int, PL5 ? 3 : 0>{}, R0{}, x1p);
+                    run_step(C1{}, I0{}, W9{}, acc, st, st + IN_EX, nullptr, T[4].w, smem + stage_off(2, 0), x1p, F0{}, 0, Q1{}, Q0{});
                 ++gs;
             }
             if (P3_LAZYDRAIN) next_bias = bias_request(T[kk + 1].bias, kk == 3 ? 64 : 32);   // (older than the epilogue's stores)
             if (PROF) p2 = __builtin_amdgcn_s_memtime();
             uintx4 kept[4][2];
             const bool halo_only = P3_SKIPST && P3_S1 && (kk == 0 || (P3_X2REG && kk == 1)) && !(P3_TRAIN && pp.keep_all);   // (training forward: whole planes)
-            if constexpr (P3_DEFER && decltype(last_nw_tag)::value == 5)     // conv1..3: rows 1, 2 are finished by the next layer's step 0
-                epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept, halo_only, std::true_type{}, A_BIAS_OFF);
-            else
-                epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept, halo_only, std::false_type{}, PL ? A_BIAS_OFF + (kk & 1) * 128 : A_BIAS_OFF,
-                      BW ? mcur + (long)(5 - kk) * pp.plane_b - (long)Y0 * pp.row_b : nullptr);
-            constexpr int NK = (P3_DEFER && decltype(last_nw_tag)::value == 5) ? 2 : 4;     // rows available now: 0 and 3, or all
+            epi32(acc, dcur + (long)(2 + kk) * pp.plane_b - (long)Y0 * pp.row_b, kept, halo_only,
+                  BW ? mcur + (long)(5 - kk) * pp.plane_b - (long)Y0 * pp.row_b : nullptr);
             if (kk == 0) {
 #pragma unroll
-                for (int io = 0; io < NK; ++io)
+                for (int io = 0; io < 4; ++io)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) X1r[NK == 2 ? 3 * io : io][m] = kept[NK == 2 ? 3 * io : io][m];
+                    for (int m = 0; m < 2; ++m) X1r[io][m] = kept[io][m];
             }
             if (kk == 1) {
 #pragma unroll
-                for (int io = 0; io < NK; ++io)
+                for (int io = 0; io < 4; ++io)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) X2r[NK == 2 ? 3 * io : io][m] = kept[NK == 2 ? 3 * io : io][m];
+                    for (int m = 0; m < 2; ++m) X2r[io][m] = kept[io][m];
             }
             pending_pub = true;   // published behind the next top-of-step barrier (whose vmcnt(0) covers these stores)
             pub_val = L + 1;
@@ -1083,19 +806,20 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             }
         };
         layerA(std::integral_constant<int, 0>{}, W5{});
-        if (!aborted) layerA(std::integral_constant<int, 1>{}, W5{});
-        if (!aborted) layerA(std::integral_constant<int, 2>{}, W5{});
-        if (!aborted) layerA(std::integral_constant<int, 3>{}, W9{});
-        if (aborted) break;
+        layerA(std::integral_constant<int, 1>{}, W5{});
+        layerA(std::integral_constant<int, 2>{}, W5{});
+        layerA(std::integral_constant<int, 3>{}, W9{});
         // ---------------- conv5 (cout 64, stages of IN_EX + 36 KiB, residual epilogue)
         {
             const int L = L0 + 4;
             const char* wl = T[4].w;
             unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;
             if (PROF) p0 = __builtin_amdgcn_s_memtime();
-            if constexpr (PL5) bias_commit(std::integral_constant<int, 8>{}, next_bias, 64, B_BIAS_OFF);
-            else if (P3_LAZYDRAIN) prologue_lazy(std::integral_constant<int, 8>{}, next_bias, 64, B_BIAS_OFF);   // (X4 went out whole: 8 stores per wave)
-            else prologue(T[4].bias, 64, B_BIAS_OFF);
+            if (P3_LAZYDRAIN) {
+                prologue(std::integral_constant<int, 8>{}, next_bias, 64, B_BIAS_OFF);   // (X4 went out whole: 8 stores per wave)
+            } else {
+                prologue_cold(T[4].bias, 64, B_BIAS_OFF);
+            }
             if (PROF) p1 = __builtin_amdgcn_s_memtime();
             t_sync = 0;
             t_vm = 0;
@@ -1108,56 +832,33 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                     for (int r = 0; r < 16; ++r) acc[mb][i][r] = 0.f;
             {   // chunk 0 = the resident plane (in place: phase-B stage 0); stages chunk 1 from registers
                 const char* st = smem + stage_off(2, 0);
-                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + (long)pp.plane_b, wl + 36 * 1024, smem + stage_off(2, 1), x1p, NODEFER{}, F0{}, 0, std::integral_constant<int, PL5 ? 1 : 0>{}, Q1{}, R0{}, x1p);
+                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + (long)pp.plane_b, wl + 36 * 1024, smem + stage_off(2, 1), x1p, F0{}, 0, Q0{}, Q1{});
             }
-            if (!PR) step_sync();
-            if (P3_LAZYDRAIN && !PR) publish_pending();       // conv4's output: its stores drained under step 0
             {   // chunk 1; stages chunk 2 (X1) from registers
                 const char* st = smem + stage_off(2, 1);
-                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (36 * 1024), smem + stage_off(2, 0), X1r, NODEFER{}, F0{}, 0, Q1{}, Q1{}, R1{}, x1p);
+                run_step(C2{}, I2{}, W9{}, acc, st, st + IN_EX, dcur + 2l * pp.plane_b, wl + 2 * (36 * 1024), smem + stage_off(2, 0), X1r, F0{}, 0, Q1{}, Q1{});
             }
-            if (!PR) step_sync();
             {   // chunk 2; stages chunk 3 (X2) from registers
                 const char* st = smem + stage_off(2, 0);
-                run_step(C2{}, I2X{}, W9{}, acc, st, st + IN_EX, dcur + 3l * pp.plane_b, wl + 3 * (36 * 1024), smem + stage_off(2, 1), X2r, NODEFER{}, F0{}, 0, Q1{}, Q1{}, R1{}, X1r);
+                run_step(C2{}, I2X{}, W9{}, acc, st, st + IN_EX, dcur + 3l * pp.plane_b, wl + 3 * (36 * 1024), smem + stage_off(2, 1), X2r, F0{}, 0, Q1{}, Q1{});
             }
-            if constexpr (P3_CTAP && P3_S1 && P3_X2REG && P3_WFLAGS) {
-                // two bodies: chunk 3 (X2) has a register copy and its step fetches nothing new from the neighbours; chunk 4 (X3) has none and its
-                // step fetches X4, conv4's output on the neighbours
-                {
-                    if (!PR) step_sync();
-                    const char* st = smem + stage_off(2, 1);
-                    run_step(C2{}, I1{}, W9{}, acc, st, st + IN_EX, dcur + 4l * pp.plane_b, wl + 4l * (36 * 1024),
-                             smem + stage_off(2, 0), x1p, NODEFER{}, F0{}, 0, Q1{}, Q1{}, R1X{}, X2r);
-                }
-                {
-                    if (!PR) step_sync();
-                    const char* st = smem + stage_off(2, 0);
-                    run_step(C2{}, I1{}, W9{}, acc, st, st + IN_EX, dcur + 5l * pp.plane_b, wl + 5l * (36 * 1024),
-                             smem + stage_off(2, 1), x1p, NODEFER{}, F1{}, L, Q1{}, Q1{}, R0{}, x1p);
-                }
-            } else
-            for (int c = 3; c < 5; ++c) {      // chunks 3, 4; stage X3, X4 by DMA
-                if (!P3_WFLAGS && c == 4) {      // X4 (chunk 5) is conv4's output on the neighbours: checked in front of the step that fetches it
-                    ensure_flags(L);
-                    if (aborted) break;
-                }
-                if (!PR) step_sync();
-                const char* st = smem + stage_off(2, c & 1);
-                run_step(C2{}, I1{}, W9{}, acc, st, st + IN_EX, dcur + (long)(c + 1) * pp.plane_b, wl + (long)(c + 1) * (36 * 1024),
-                         smem + stage_off(2, (c + 1) & 1), x1p, NODEFER{}, F1{}, c == 4 ? L : -1, Q1{}, Q1{}, R0{}, x1p);
+            {   // chunk 3; stages chunk 4 (X3) by DMA
+                const char* st = smem + stage_off(2, 1);
+                run_step(C2{}, I1{}, W9{}, acc, st, st + IN_EX, dcur + 4l * pp.plane_b, wl + 4l * (36 * 1024), smem + stage_off(2, 0), x1p, F1{}, -1, Q1{}, Q1{});
             }
-            if (aborted) break;
-            if (!PR) step_sync();
+            {   // chunk 4; stages chunk 5 (X4) by DMA: conv4's output on the neighbours, checked by this step
+                const char* st = smem + stage_off(2, 0);
+                run_step(C2{}, I1{}, W9{}, acc, st, st + IN_EX, dcur + 5l * pp.plane_b, wl + 5l * (36 * 1024), smem + stage_off(2, 1), x1p, F1{}, L, Q1{}, Q1{});
+            }
             {
                 const char* st = smem + stage_off(2, 1);
                 if constexpr (P3_SEAM) {
                     // the next conv1's first weight chunk -> smem + IN_EX (dst = smem: run_step puts weights at dst + IN_EX); the last RDB has no
                     // successor: it prefetches its own first chunk again (a select, not a branch: one step body), nobody reads it
                     const char* nw5 = rdb + 1 < nrdb ? T[5].w : T[0].w;
-                    run_step(C2{}, I0{}, W5{}, acc, st, st + IN_EX, nullptr, nw5, smem, x1p, NODEFER{}, F0{}, 0, Q1{}, Q0{}, R0{}, x1p);
+                    run_step(C2{}, I0{}, W5{}, acc, st, st + IN_EX, nullptr, nw5, smem, x1p, F0{}, 0, Q1{}, Q0{});
                 } else {
-                    run_step(C2{}, I0{}, W0{}, acc, st, st + IN_EX, nullptr, nullptr, smem, x1p, NODEFER{}, F0{}, 0, Q1{}, Q0{}, R0{}, x1p);
+                    run_step(C2{}, I0{}, W0{}, acc, st, st + IN_EX, nullptr, nullptr, smem, x1p, F0{}, 0, Q1{}, Q0{});
                 }
             }
             const bool r2 = (rdb % 3) == 2;
@@ -1170,13 +871,8 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
             __syncthreads();
             publish(L + 1);
             if (rdb + 1 < nrdb) {
-                if constexpr (P3_WFLAGS) {
-                    poll_issue();
-                    poll_check(std::integral_constant<int, 0>{}, L + 1);
-                } else {
-                    ensure_flags(L + 1);
-                    if (aborted) break;
-                }
+                poll_issue();
+                poll_check(std::integral_constant<int, 0>{}, L + 1);
                 if constexpr (P3_SEAM) {
                     // own rows: written by the epilogue; weights: prefetched by the last step; left: the neighbours' two rows
                     const unsigned long long ib = uni64((unsigned long long)dnxt);

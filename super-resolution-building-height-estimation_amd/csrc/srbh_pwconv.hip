@@ -230,46 +230,6 @@ __global__ __launch_bounds__(KW == 16 ? 1024 : 256) void pw_wgrad_kernel(const f
     pw_wgrad_body<VEC, KW>(dY, X, out, M, N, HW, B, S, tiles_n, blockIdx.x, blockIdx.y, red);
 }
 
-// ---- SEVERAL weight gradients in one launch (round 5).  The 62 expand / project weight gradients of a training step are each a 12-19 us
-// latency chain on a few hundred waves, one behind the other in the backward's dependency chain although nothing reads dW before the
-// optimizer.  Under srbh_pwconv_wgrad_defer they are queued, and srbh_pwconv_wgrad_flush runs all jobs of one kernel form (plane size x
-// waves per tile) as ONE launch -- a linear block index finds its job in a by-value table -- followed by one launch for every ordered reduce.
-// Same kernel body, same split plan per job: every dW bit-identical to the immediate call.
-struct PwJob {
-    const float* dY; const float* X; float* out;
-    int M, N, HW, B, S, tiles_n, blk0, tiles;       // blk0: first linear block of the job; tiles = tiles_m * tiles_n (blocks per split)
-};
-constexpr int PW_MANY_MAX = 40;
-struct PwMany { PwJob j[PW_MANY_MAX]; int n; };
-template <int VEC, int KW>
-__global__ __launch_bounds__(KW == 16 ? 1024 : 256) void pw_wgrad_many_kernel(const PwMany m) {
-    extern __shared__ __attribute__((aligned(16))) float red[];
-    const int b = blockIdx.x;
-    int k = 0;
-    while (k + 1 < m.n && b >= m.j[k + 1].blk0) ++k;
-    const PwJob& J = m.j[k];
-    const int local = b - J.blk0, by = local / J.tiles, bx = local - by * J.tiles;
-    pw_wgrad_body<VEC, KW>(J.dY, J.X, J.out, J.M, J.N, J.HW, J.B, J.S, J.tiles_n, bx, by, red);
-}
-struct PwRedJob { const float* part; float* dw; long n; int S, blk0; };
-struct PwRedMany { PwRedJob j[PW_MANY_MAX]; int n; };
-__global__ __launch_bounds__(256) void pw_wgrad_reduce_many_kernel(const PwRedMany m) {
-    const int b = blockIdx.x;
-    int k = 0;
-    while (k + 1 < m.n && b >= m.j[k + 1].blk0) ++k;
-    const PwRedJob& J = m.j[k];
-    const long i = (long)(b - J.blk0) * 256 + threadIdx.x;
-    if (i >= J.n) return;
-    float a0 = 0.f, a1 = 0.f;
-    int s = 0;
-    for (; s + 1 < J.S; s += 2) {
-        a0 += J.part[(long)s * J.n + i];
-        a1 += J.part[(long)(s + 1) * J.n + i];
-    }
-    if (s < J.S) a0 += J.part[(long)s * J.n + i];
-    J.dw[i] = a0 + a1;
-}
-
 __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long n, int S) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -434,91 +394,12 @@ extern "C" size_t srbh_pwconv_bwd_weight_ws_floats(int B, int Cin, int Cout, int
     return p.S > 1 ? (size_t)p.S * Cout * Cin : 0;
 }
 
-namespace {
-struct PwQueued { const float* x; const float* dy; float* dw; float* ws; int B, Cin, Cout, HW; WgradPlan p; };
-std::mutex g_pw_mu;                 // (the queue is filled by autograd's device thread and flushed by the thread that called backward)
-bool g_pw_defer = false;
-std::vector<PwQueued> g_pw_queue;
-
-template <int VEC, int KW>
-int pw_flush_form(const std::vector<PwQueued>& q, hipStream_t st) {
-    PwMany m = {};
-    int blk = 0;
-    auto launch = [&]() {
-        if (m.n == 0) return;
-        hipLaunchKernelGGL((pw_wgrad_many_kernel<VEC, KW>), dim3((unsigned)blk), dim3(64 * KW), KW * 4 * 64 * 4, st, m);
-        m.n = 0;
-        blk = 0;
-    };
-    for (const PwQueued& e : q) {
-        if ((e.HW == 4 ? 1 : 4) != VEC || e.p.KW != KW) continue;
-        const int tm = (e.Cout + 15) / 16, tn = (e.Cin + 15) / 16;
-        PwJob& J = m.j[m.n++];
-        J.dY = e.dy; J.X = e.x; J.out = e.p.S > 1 ? e.ws : e.dw;
-        J.M = e.Cout; J.N = e.Cin; J.HW = e.HW; J.B = e.B; J.S = e.p.S; J.tiles_n = tn; J.blk0 = blk; J.tiles = tm * tn;
-        blk += tm * tn * e.p.S;
-        if (m.n == PW_MANY_MAX) launch();
-    }
-    launch();
-    SRBH_HIP(hipGetLastError());
-    return SRBH_OK;
-}
-}  // namespace
-
-/* Between srbh_pwconv_wgrad_defer(1) and srbh_pwconv_wgrad_flush every srbh_pwconv_bwd_weight call (any host thread) only QUEUES its job;
- * the flush runs the queued jobs of each kernel form as one launch and every ordered reduce as one more, on `stream`, and ends the deferral.
- * The caller keeps x / dy / dw / ws of every queued job alive (and unread) until the flush.  Results equal the immediate calls bit for bit. */
-extern "C" int srbh_pwconv_wgrad_defer(int on) {
-    std::lock_guard<std::mutex> lk(g_pw_mu);
-    SRBH_REQUIRE(on || g_pw_queue.empty(), "srbh_pwconv_wgrad_defer(0) with queued jobs: call srbh_pwconv_wgrad_flush");
-    g_pw_defer = on != 0;
-    return SRBH_OK;
-}
-extern "C" int srbh_pwconv_wgrad_flush(void* stream) {
-    std::vector<PwQueued> q;
-    {
-        std::lock_guard<std::mutex> lk(g_pw_mu);
-        g_pw_defer = false;
-        q.swap(g_pw_queue);
-    }
-    hipStream_t st = (hipStream_t)stream;
-    if (int rc = pw_flush_form<1, 4>(q, st)) return rc;
-    if (int rc = pw_flush_form<1, 16>(q, st)) return rc;
-    if (int rc = pw_flush_form<4, 4>(q, st)) return rc;
-    if (int rc = pw_flush_form<4, 16>(q, st)) return rc;
-    PwRedMany r = {};
-    int blk = 0;
-    auto launch = [&]() {
-        if (r.n == 0) return;
-        hipLaunchKernelGGL(pw_wgrad_reduce_many_kernel, dim3((unsigned)blk), dim3(256), 0, st, r);
-        r.n = 0;
-        blk = 0;
-    };
-    for (const PwQueued& e : q) {
-        if (e.p.S <= 1) continue;
-        PwRedJob& J = r.j[r.n++];
-        J.part = e.ws; J.dw = e.dw; J.n = (long)e.Cout * e.Cin; J.S = e.p.S; J.blk0 = blk;
-        blk += (int)((J.n + 255) / 256);
-        if (r.n == PW_MANY_MAX) launch();
-    }
-    launch();
-    SRBH_HIP(hipGetLastError());
-    return SRBH_OK;
-}
-
 extern "C" int srbh_pwconv_bwd_weight(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int Cout, int HW, void* stream) {
     SRBH_REQUIRE(x && dy && dw, "srbh_pwconv_bwd_weight: null pointer");
     SRBH_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && HW > 0, "srbh_pwconv_bwd_weight: bad shape");
     SRBH_REQUIRE(HW == 4 || (HW & 15) == 0, "srbh_pwconv_bwd_weight: planes of 4 or a multiple of 16 elements (HW = %d)", HW);
     const WgradPlan p = wgrad_plan(Cout, Cin, B, HW);
     SRBH_REQUIRE(p.S == 1 || ws, "srbh_pwconv_bwd_weight: this shape needs the workspace (srbh_pwconv_bwd_weight_ws_floats)");
-    {
-        std::lock_guard<std::mutex> lk(g_pw_mu);
-        if (g_pw_defer) {
-            g_pw_queue.push_back(PwQueued{x, dy, dw, ws, B, Cin, Cout, HW, p});
-            return SRBH_OK;
-        }
-    }
     float* out = p.S > 1 ? ws : dw;
     const int tm = (Cout + 15) / 16, tn = (Cin + 15) / 16;
     const dim3 grid((unsigned)(tm * tn), p.S);

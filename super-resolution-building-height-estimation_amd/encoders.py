@@ -22,7 +22,7 @@ import os
 
 import torch
 import torch.nn.functional as F
-from . import sidework, wcache
+from . import wcache
 from torch import nn
 
 # (width, depth, resolution, dropout) -- EfficientNet paper table / efficientnet_pytorch.utils.efficientnet_params
@@ -118,47 +118,13 @@ class _DepthwiseConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             ws = torch.empty(_lib.lib().srbh_dwconv_bwd_weight_splits(B, C) * C * K * K, dtype=torch.float32, device=x.device)
-            with sidework.side(x, dy, dw, ws):         # a leaf of the graph: next to the data-gradient chain, not in it
-                _lib.check(_lib.lib().srbh_dwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, C, H, W, K,
-                                                             stride, pt, pl, OH, OW, _lib.stream_ptr()), "dwconv_bwd_weight")
+            _lib.check(_lib.lib().srbh_dwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, C, H, W, K,
+                                                         stride, pt, pl, OH, OW, _lib.stream_ptr()), "dwconv_bwd_weight")
         return dx, dw, None, None
 
 
-# ---- deferred 1x1 weight gradients (srbh_pwconv_wgrad_defer / _flush, include/srbh.h).  Inside `deferred_pointwise_wgrads()` -- harness.TrainStep
-# puts it around loss.backward() on one GPU -- every expand / project weight gradient is only queued, and leaving the block runs them all in a
-# handful of launches: 62 launches of 12-19 us (+ 19 reduces) leave the backward's dependency chain.  The returned dW tensors are NOT valid
-# before the block is left (nothing may read a gradient inside it: no gradient all-reduce hooks, no accumulation into an existing .grad);
-# the operands of queued jobs are kept alive here.  MEASURED SMALL, default off (SRBH_PW_WGRAD_DEFER=1 turns it on): serial step 30.65 ->
-# 30.50 ms, pipelined step unchanged (profiles/r05as_ab_pw_wgrad_defer.txt) -- each of these launches already fills the chip with waves (the
-# split plan asks for ~4 600), so batching them saves their launch gaps, not their time; not worth a gradient that is invalid inside backward.
-PW_WGRAD_DEFER = os.environ.get("SRBH_PW_WGRAD_DEFER", "0") == "1"
 # the skip connection of an MBConv block taken through its expand conv's autograd node (see _PointwiseConvFn.forward); SRBH_SKIP_EXPAND=0: autograd's add
 SKIP_THROUGH_EXPAND = os.environ.get("SRBH_SKIP_EXPAND", "1") == "1"
-_PW_KEEP = []
-_PW_ON = [False]
-
-
-class deferred_pointwise_wgrads:
-    def __init__(self, enable=True):
-        self.enable = bool(enable) and PW_WGRAD_DEFER and not _PW_ON[0]
-
-    def __enter__(self):
-        if self.enable:
-            from . import _lib
-            _lib.check(_lib.lib().srbh_pwconv_wgrad_defer(1), "pwconv_wgrad_defer")
-            _PW_ON[0] = True
-        return self
-
-    def __exit__(self, *exc):
-        if self.enable:
-            from . import _lib
-            _PW_ON[0] = False
-            try:
-                _lib.check(_lib.lib().srbh_pwconv_wgrad_flush(_lib.stream_ptr()), "pwconv_wgrad_flush")
-            finally:
-                _PW_KEEP.clear()
-        return False
-
 
 class _PointwiseConvFn(torch.autograd.Function):
     """1x1 convolution without bias (MBConv expand / project) on libsrbh (csrc/srbh_pwconv.hip): one fp32-MFMA launch forward, one for
@@ -207,11 +173,8 @@ class _PointwiseConvFn(torch.autograd.Function):
             dw = torch.empty_like(weight)
             n = L.srbh_pwconv_bwd_weight_ws_floats(B, Cin, Cout, H * W)
             ws = torch.empty(n, dtype=torch.float32, device=x.device) if n else None
-            if _PW_ON[0]:          # queued (deferred_pointwise_wgrads): the operands must outlive this call.  NOT dw: autograd takes the
-                _PW_KEEP.append((x, dy, ws))       # returned tensor as .grad only while it holds the sole reference -- otherwise it CLONES it (now)
-            with sidework.side(x, dy, dw, ws):
-                _lib.check(L.srbh_pwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr() if n else None, B, Cin, Cout, H * W,
-                                                    _lib.stream_ptr()), "pwconv_bwd_weight")
+            _lib.check(L.srbh_pwconv_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr() if n else None, B, Cin, Cout, H * W,
+                                                _lib.stream_ptr()), "pwconv_bwd_weight")
         return dx, dw, None, None
 
 
@@ -754,9 +717,8 @@ class _DecoderConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             ws = torch.empty(L.srbh_dconv_wgrad_ws_floats(B, Cin, Cout, H, W), dtype=torch.float32, device=x.device)
-            with sidework.side(x, dy, dw, ws):
-                _lib.check(L.srbh_dconv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, Cin, Cout, H, W, _lib.stream_ptr()),
-                           "dconv_wgrad")
+            _lib.check(L.srbh_dconv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, Cin, Cout, H, W, _lib.stream_ptr()),
+                       "dconv_wgrad")
         return dx, dw, None
 
 

@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import _lib, sidework, wcache
+from . import _lib, wcache
 
 HIR = (0, 3, 12, 21, 30, 60, 90, 256)                       # train.py:55
 # hierweight(bh_stats_globe, HIR) as probed on the reference data; synthetic labels reuse it
@@ -138,7 +138,6 @@ class GradReducer:
 
     def _launch(self, b):
         flat = b["flat"]
-        sidework.join()           # weight gradients computed on the side stream (sidework.py): final before this bucket is packed
         torch._foreach_copy_([flat[o:o + n].view_as(q.grad) for q, o, n in b["items"]], [q.grad for q, _, _ in b["items"]])
         self._work.append((b, self.dist.all_reduce(flat, async_op=True)))
 
@@ -545,15 +544,10 @@ class TrainStep:
                 + self.criterion[1](height_pred_aggre.squeeze(1), height_aggre, weight_aggre)
                 + self.criterion[2](build_pred, build, weight))
         self.optimizer.zero_grad(set_to_none=True)
-        # one GPU: the encoder's 1x1 weight gradients are queued during backward and run as a handful of launches behind it (with a gradient
-        # all-reduce its hooks would read them too early; gradients are fresh tensors after zero_grad(set_to_none=True): nothing accumulates)
-        from .encoders import deferred_pointwise_wgrads
-        with deferred_pointwise_wgrads(self.world == 1 and not in_graph):
-            loss.backward()
+        loss.backward()
         if self._next is not None and self._pf is None:      # (the hook did not fire: no gradient reached HRfeature's first weight)
             self._pf = self._launch_prefetch(self._next)
         self._next = None
-        sidework.join()           # (the end-of-backward callback already did: a no-op unless that callback was skipped)
         if in_graph and self.world > 1:
             return loss.detach(), height_pred.detach()      # (the collectives and Adam follow each replay: _reduce_and_update)
         self._reduce_and_update()

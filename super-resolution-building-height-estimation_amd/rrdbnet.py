@@ -592,7 +592,6 @@ class RealESRGAN:
         sel = os.environ.get("SRBH_SR_DISC", "")
         use = on_gpu and (sel == "libsrbh" or (sel != "stock" and RA._mixed()))
         self.net_d.libsrbh = ("f16" if RA._mixed() else "f32") if use else None
-        self.net_d.libsrbh_s2 = use and os.environ.get("SRBH_SR_DISC_S2", "0") == "1"      # conv1..conv3 (4x4 stride 2) on the same kernels (srgan._disc_conv4x4s2)
 
         def update(optimizer, train_d, groups):
             self.net_d.requires_grad_(train_d)

@@ -116,52 +116,17 @@ class _DiscConvFn(torch.autograd.Function):
 
 
 def _disc_conv3x3(conv, x, h16):
-    for hook in conv._forward_pre_hooks.values():      # torch's spectral_norm: sets conv.weight = weight_orig / sigma (power iteration in training)
+    """conv(x) of a 3x3 stride-1 discriminator conv on libsrbh.  torch's spectral_norm is a forward PRE-hook that sets conv.weight =
+    weight_orig / sigma (one power iteration in training): it is the only hook this path knows how to honour, so it is called by hand and a
+    module carrying ANY other hook (forward hooks, foreign pre-hooks, hooks with kwargs) takes the stock `conv(x)` with the full hook protocol."""
+    from torch.nn.utils.spectral_norm import SpectralNorm
+    pre = list(conv._forward_pre_hooks.values())
+    if (any(not isinstance(h, SpectralNorm) for h in pre) or conv._forward_hooks or conv._backward_hooks or conv._backward_pre_hooks
+            or getattr(conv, "_forward_pre_hooks_with_kwargs", None) or getattr(conv, "_forward_hooks_with_kwargs", None)):
+        return conv(x)
+    for hook in pre:
         hook(conv, (x,))
     return _DiscConvFn.apply(x, conv.weight, conv.bias, h16)
-
-
-def _s2_tap_table():
-    """Index table of the 4x4 / stride 2 / pad 1 -> 3x3 / stride 1 / pad 1 rewrite: input row 2 y - 1 + k of tap k is row y + t - 1, phase p of the
-    pixel-unshuffled tensor with (t, p) = (0, 1), (1, 0), (1, 1), (2, 0) for k = 0..3; the two (t, p) pairs no tap reaches stay zero."""
-    k_of = {(0, 1): 0, (1, 0): 1, (1, 1): 2, (2, 0): 3}
-    idx, mask = [], []
-    for py in range(2):
-        for px in range(2):
-            for ty in range(3):
-                for tx in range(3):
-                    ky, kx = k_of.get((ty, py)), k_of.get((tx, px))
-                    idx.append(0 if ky is None or kx is None else ky * 4 + kx)
-                    mask.append(0.0 if ky is None or kx is None else 1.0)
-    return torch.tensor(idx, dtype=torch.long), torch.tensor(mask, dtype=torch.float32)
-
-
-_S2_TABLE = {}
-
-
-def _s2_as_s1_weight(w):
-    """(cout, cin, 4, 4) kernel of a stride-2 pad-1 conv -> the (cout, 4 cin, 3, 3) kernel of the SAME conv written as stride 1, pad 1 over
-    F.pixel_unshuffle(x, 2) (channel c * 4 + py * 2 + px): 16 of the 36 taps per input channel carry a weight, the others are zero.
-    Differentiable (a gather and a mask), so the 3x3 kernels' weight gradient lands on the 4x4 tensor through autograd."""
-    key = (w.device, w.dtype)
-    if key not in _S2_TABLE:
-        idx, mask = _s2_tap_table()
-        _S2_TABLE[key] = (idx.to(w.device), mask.to(device=w.device, dtype=w.dtype))
-    idx, mask = _S2_TABLE[key]
-    cout, cin = w.shape[:2]
-    return (w.reshape(cout, cin, 16).index_select(2, idx) * mask).reshape(cout, cin * 4, 3, 3)
-
-
-def _disc_conv4x4s2(conv, x, h16):
-    """UNetDiscriminatorSN.conv1..conv3 (SR/rrdbnet_arch.py:257-259: 4x4, stride 2, pad 1, no bias) as a 3x3 stride-1 conv over the
-    pixel-unshuffled input on the same libsrbh kernels as the other convs (2.25 x the multiply-adds, on the 16-bit matrix-core forms instead of
-    the stock fp32 implicit GEMMs).  Exact (tests/test_sr_stage.py) and measured SLOWER: one trainer iteration at batch 8 45.6-45.9 -> 81.6-82.8 ms
-    (profiles/r05de) -- at 256..1024 input channels the head's <= 64-output-channel kernels re-read the input once per slice and walk 36 taps
-    per channel for 16 weights.  OFF by default (SRBH_SR_DISC_S2=1): kept as the parity-tested statement of the rewrite a 64..512-channel
-    kernel of the trunk's family would use."""
-    for hook in conv._forward_pre_hooks.values():
-        hook(conv, (x,))
-    return _DiscConvFn.apply(F.pixel_unshuffle(x, 2), _s2_as_s1_weight(conv.weight), None, h16)
 
 
 class _Bilinear2xFn(torch.autograd.Function):
@@ -209,7 +174,6 @@ class UNetDiscriminatorSN(nn.Module):
         self.conv9 = nn.Conv2d(nf, 1, 3, 1, 1)
 
     libsrbh = None          # None: stock convolutions; "f32" / "f16": the 3x3 stride-1 convs on libsrbh in that operand precision (device tensors only)
-    libsrbh_s2 = False      # with libsrbh: conv1..conv3 (4x4, stride 2) as 3x3 stride-1 convs over the pixel-unshuffled input on the same kernels
 
     def forward(self, x):
         act = lambda t: F.leaky_relu(t, 0.2)
@@ -220,9 +184,7 @@ class UNetDiscriminatorSN(nn.Module):
             up = lambda t: _Bilinear2xFn.apply(t) if t.shape[1] % 4 == 0 else F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)      # noqa: E731
         else:
             c3 = lambda conv, t: conv(t)                           # noqa: E731
-        s2 = lambda conv, t: conv(t)                               # noqa: E731
-        if self.libsrbh is not None and self.libsrbh_s2 and x.is_cuda and x.shape[-1] % 16 == 0 and x.shape[-2] % 16 == 0:
-            s2 = lambda conv, t: _disc_conv4x4s2(conv, t, self.libsrbh == "f16")      # noqa: E731
+        s2 = lambda conv, t: conv(t)                               # noqa: E731  (4x4 stride 2: stock convolutions)
         x0 = act(c3(self.conv0, x))
         x1 = act(s2(self.conv1, x0))
         x2 = act(s2(self.conv2, x1))

@@ -288,36 +288,6 @@ def _graph_fns(fn, seen=None):
     return seen
 
 
-def test_deferred_pointwise_weight_gradients_equal_the_immediate_ones(monkeypatch):
-    """srbh_pwconv_wgrad_defer / _flush (harness.TrainStep puts them around loss.backward()): the 1x1 weight gradients of several shapes --
-    every kernel form: 2x2 planes and larger ones, 4 and 16 waves per tile, with and without the split-over-images reduce -- queued from
-    autograd's backward thread and run as a handful of launches behind it: every dW (and the untouched dX) bit-identical to the immediate
-    calls; nothing is queued outside the block."""
-    import torch
-    from srbh_amd import encoders as E
-    monkeypatch.setattr(E, "PW_WGRAD_DEFER", True)          # (off by default: measured small)
-    dev = "cuda:0"
-    g = torch.Generator().manual_seed(3)
-    shapes = [(8, 24, 144, 32), (8, 144, 24, 32), (8, 56, 336, 8), (8, 960, 160, 4), (8, 1632, 272, 2), (8, 272, 1632, 2), (8, 448, 2688, 2), (4, 48, 24, 32)]
-    xs = [torch.randn((B, ci, hw, hw), generator=g).to(dev).requires_grad_(True) for B, ci, co, hw in shapes]
-    ws = [(torch.randn((co, ci, 1, 1), generator=g) * 0.05).to(dev).requires_grad_(True) for B, ci, co, hw in shapes]
-
-    def run(defer):
-        for t in xs + ws:
-            t.grad = None
-        with E.deferred_pointwise_wgrads(defer):
-            loss = sum(E._PointwiseConvFn.apply(x, w).square().sum() for x, w in zip(xs, ws))
-            loss.backward()
-        torch.cuda.synchronize()
-        return [w.grad.clone() for w in ws], [x.grad.clone() for x in xs]
-
-    w0, x0 = run(False)
-    w1, x1 = run(True)
-    assert not E._PW_KEEP and not E._PW_ON[0]
-    for a, b in zip(w0 + x0, w1 + x1):
-        assert bool(torch.isfinite(b).all()) and torch.equal(a, b)
-
-
 def test_skip_gradient_through_the_expand_conv_node():
     """an MBConv block's skip connection routed through its expand conv's autograd node (_pointwise_with_skip): the gradient arriving over the
     skip and the conv's input gradient meet inside srbh_pwconv_bwd_data_res instead of in an add launched by autograd -- same dX / dW as the

@@ -131,23 +131,6 @@ def test_persistent_and_per_layer_paths_agree(monkeypatch):
         assert torch.equal(y0, y1), (B, hw)
 
 
-def test_two_workgroups_per_cu_variant_is_bit_identical(monkeypatch):
-    """SRBH_PT_VARIANT=2 (4-row tiles, half-chunk pipeline, two workgroups per CU; kept as a measured alternative, see
-    DESIGN.md 5) runs the same arithmetic in the same order as the default persistent kernel."""
-    sd = synth.rrdbnet_state_dict(num_block=3, seed=21, mode="stress")
-    net = build(sd, num_block=3)
-    for B, hw in ((3, 64), (70, 64), (2, 40)):
-        x = synth.tiles(B, 3, hw, seed=23).to(DEV)
-        with torch.no_grad():
-            monkeypatch.setenv("SRBH_PT_VARIANT", "2")
-            y2 = net.forward_feature(x)
-            net.check_status()
-            monkeypatch.setenv("SRBH_PT_VARIANT", "1")
-            y1 = net.forward_feature(x)
-            net.check_status()
-        assert torch.equal(y1, y2), (B, hw)
-
-
 def test_strict_fp32_path_matches_reference_and_bounds_the_fast_path(golden_dir):
     """precision='f32': exact-fp32 matrix-core convs -> agrees with the fp32 reference to rounding (1e-5), and is the
     on-device yardstick for the default fp16-operand path (<= 1e-3)."""

@@ -59,23 +59,6 @@ def test_usm_sharp_gaussian_kernel_known_answers():
     assert y.shape == x.shape and float(y.min()) >= -1e-6 and float(y.max()) <= 1 + 1e-6
 
 
-def test_stride2_conv_as_stride1_over_the_unshuffled_input_is_exact():
-    """srgan._s2_as_s1_weight: the discriminator's 4x4 / stride 2 / pad 1 convs (SR/rrdbnet_arch.py:257-259) written as 3x3 / stride 1 / pad 1
-    over F.pixel_unshuffle(x, 2) -- output, input gradient and the gradient of the 4x4 weight (through the gather) equal in float64."""
-    import torch.nn.functional as F
-    from srbh_amd.srgan import _s2_as_s1_weight
-    x = rand((2, 5, 16, 24), 31).double().requires_grad_(True)
-    w = rand((7, 5, 4, 4), 32).double().requires_grad_(True)
-    y0 = F.conv2d(x, w, None, 2, 1)
-    w3 = _s2_as_s1_weight(w)
-    assert w3.shape == (7, 20, 3, 3) and int((w3 != 0).sum()) == 7 * 5 * 16
-    y1 = F.conv2d(F.pixel_unshuffle(x, 2), w3, None, 1, 1)
-    g = rand(tuple(y0.shape), 33).double()
-    a = torch.autograd.grad((y0 * g).sum(), (x, w))
-    b = torch.autograd.grad((y1 * g).sum(), (x, w))
-    assert float((y0 - y1).abs().max()) <= 1e-12 and float((a[0] - b[0]).abs().max()) <= 1e-12 and float((a[1] - b[1]).abs().max()) <= 1e-12
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["fw", "ft"])
 def test_rrdbnet_backward_matches_reference_autograd(golden_dir, tag):
@@ -474,7 +457,7 @@ def test_discriminator_convs_on_libsrbh_match_the_fixture_and_the_stock_graph(go
     res = {}
     # the yardstick is the stock graph in FLOAT64 on the CPU (MIOpen's fp32 convolutions are themselves only ~1e-3 accurate with some of the
     # solvers it picks on a fresh box: a device-stock-vs-libsrbh comparison at 1e-4 failed one run in four there)
-    for mode in ("cpu64", "f32", "f16", "f32+s2", "f16+s2"):      # (+s2: conv1..conv3, 4x4 stride 2, as 3x3 convs over the pixel-unshuffled input)
+    for mode in ("cpu64", "f32", "f16"):
         m = copy.deepcopy(base)
         if mode == "cpu64":
             m = m.double()
@@ -482,7 +465,7 @@ def test_discriminator_convs_on_libsrbh_match_the_fixture_and_the_stock_graph(go
             w_ = wgt.double()
         else:
             m = m.to("cuda:0")
-            m.libsrbh, m.libsrbh_s2 = mode[:3], mode.endswith("+s2")
+            m.libsrbh = mode
             x = x0.to("cuda:0").clone().requires_grad_(True)
             w_ = wgt.to("cuda:0")
         y = m(x)
@@ -499,14 +482,6 @@ def test_discriminator_convs_on_libsrbh_match_the_fixture_and_the_stock_graph(go
     assert O.rel_l2(y2, y0) <= 5e-3 and cos(gx2, gx0) >= 0.99
     for k in g0:
         assert cos(g2[k], g0[k]) >= 0.99, (k, cos(g2[k], g0[k]))
-    y3, gx3, g3 = res["f32+s2"]
-    assert O.rel_l2(y3, y0) <= 1e-4 and O.rel_l2(gx3, gx0) <= 1e-4
-    for k in g0:
-        assert O.rel_l2(g3[k], g0[k]) <= 1e-4, (k, O.rel_l2(g3[k], g0[k]))
-    y4, gx4, g4 = res["f16+s2"]
-    assert O.rel_l2(y4, y0) <= 5e-3 and cos(gx4, gx0) >= 0.99
-    for k in g0:
-        assert cos(g4[k], g0[k]) >= 0.99, (k, cos(g4[k], g0[k]))
 
 
 @pytest.mark.gpu
