@@ -420,7 +420,9 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 dma_item(std::integral_constant<int, IN == 1 ? 11 : 0>{}, nw_tag, d, ibase, wbase, din_w, dw_w);
             }
         };
-        if constexpr (FL) poll_issue();
+        if constexpr (FL) {
+            if (need >= 0) poll_issue();          // (never a poll in flight that no wait covers: its late landing would hit a reallocated register)
+        }
         if constexpr (!PRE) {
 #pragma unroll
             for (int r = 0; r < NRD; ++r) read_item(0, CB == 1 ? ORD1[r % 9] : ORD2[r % 12], 0);
@@ -842,13 +844,14 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
                 const char* st = smem + stage_off(2, 0);
                 run_step(C2{}, I2X{}, W9{}, acc, st, st + IN_EX, dcur + 3l * pp.plane_b, wl + 3 * (36 * 1024), smem + stage_off(2, 1), X2r, F0{}, 0, Q1{}, Q1{});
             }
-            {   // chunk 3; stages chunk 4 (X3) by DMA
-                const char* st = smem + stage_off(2, 1);
-                run_step(C2{}, I1{}, W9{}, acc, st, st + IN_EX, dcur + 4l * pp.plane_b, wl + 4l * (36 * 1024), smem + stage_off(2, 0), x1p, F1{}, -1, Q1{}, Q1{});
-            }
-            {   // chunk 4; stages chunk 5 (X4) by DMA: conv4's output on the neighbours, checked by this step
-                const char* st = smem + stage_off(2, 0);
-                run_step(C2{}, I1{}, W9{}, acc, st, st + IN_EX, dcur + 5l * pp.plane_b, wl + 5l * (36 * 1024), smem + stage_off(2, 1), x1p, F1{}, L, Q1{}, Q1{});
+            {   // chunks 3, 4; stage X3, X4 by DMA (X4 is conv4's output on the neighbours: checked by the step that fetches it).  ONE step body run
+                // twice, as a do-while: the `for` form and two explicit bodies both cost 30 spilled VGPRs (and the two bodies 144 more MFMAs of code)
+                int c = 3;
+                do {
+                    const char* st = smem + stage_off(2, c & 1);
+                    run_step(C2{}, I1{}, W9{}, acc, st, st + IN_EX, dcur + (long)(c + 1) * pp.plane_b, wl + (long)(c + 1) * (36 * 1024),
+                             smem + stage_off(2, (c + 1) & 1), x1p, F1{}, c == 4 ? L : -1, Q1{}, Q1{});
+                } while (++c < 5);
             }
             {
                 const char* st = smem + stage_off(2, 1);
