@@ -321,7 +321,7 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
         line["strict_f32_head"] = {"ms_per_step": round(strict_ms, 3), "value": round(batch / strict_ms * 1e3, 2), "unit": "tiles/s",
                                    "note": "same step, head convolutions + their gradients on exact-fp32 matrix cores (head_precision='f32': "
                                            "the mode the <=5e-5 gradient-parity tests pin); the headline's 'f16' mode keeps outputs <= 1e-3 but "
-                                           "its gradients are only direction-accurate (cos >= 0.99, median rel 3e-2 vs the exact graph)"}
+                                           "its parameter gradients are compared with this mode's in `parity` (heads <= 4e-3, upstream groups direction-accurate)"}
     if comm:
         comm.update(_dist_info(dist))
         line["comm"] = comm
@@ -395,6 +395,15 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
         tot2["note"] = ("libsrbh encoder / decoder calls of the step, HIP events around each call; top 5 entry points (all: --details); "
                         "planes are 2x2 .. 64x64: latency chains, the HBM fraction is not their roofline (DESIGN.md 3.10)")
         line["encdec_kernels"] = tot2
+    if with_kernels and world == 1 and not epoch_tiles:
+        # the mixed mode's parameter gradients against the exact-fp32 graph of the SAME step (weights as they stand after the timed steps, the
+        # fixed batch, lr 0): measured in this run, with the stated per-group tolerance (srbh_amd/gradcheck.py, tests/test_gpu_grad_parity.py)
+        from srbh_amd import gradcheck
+        try:
+            line["parity"] = gradcheck.mixed_vs_exact(net_hr, net, fixed, dev)
+        except Exception as e:
+            line["parity"] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
     if with_cpu and world == 1:
         line["cpu_baseline"] = cpu_baseline_train(sd)
     return line
@@ -741,10 +750,10 @@ def bench_feature(args, rank, world, dev, dist):
                      "traffic_source": ((f"{traffic_src} (RECORDED: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                          "command, FETCH doubled per the guide; not measured in this run)") if traffic is not None else traffic_src),
                      "power_capped_peak": None if strict else {
-                         "what": "tools/mfma_ceiling.hip on this package (RECORDED, profiles/r04k_mfma_ceiling.txt): v_mfma_f32_32x32x16_f16 back to back, one wave "
+                         "what": "tools/mfma_ceiling.hip on this package (RECORDED at this round's HEAD, profiles/r06d_mfma_ceiling.txt + r06d_mfma_ceiling_smi_summary.txt; package at 1 372 W of 1 400 W under the trunk itself, profiles/r06c_trunk_power_probe.txt): v_mfma_f32_32x32x16_f16 back to back, one wave "
                                  "per SIMD, 256 CUs, real trunk operands, seconds-long runs: MFMA only / + the trunk's LDS read mix / + its weight LDS-DMA stream",
-                         "tflops": [1659.6, 1563.3, 1516.1], "frac_of_2500": [0.664, 0.625, 0.606], "sclk_mhz": [1640, 1557, 1561],
-                         "frac_of_measured_ceiling": round(trunk_tflops / 1516.1, 4) if trunk_tflops else None},
+                         "tflops": [1680.7, 1591.6, 1545.0], "frac_of_2500": [0.672, 0.637, 0.618], "sclk_mhz": [1653, 1582, 1586],
+                         "frac_of_measured_ceiling": round(trunk_tflops / 1545.0, 4) if trunk_tflops else None},
                      "kernel": ("hconv_f32_kernel per conv (strict fp32: no single dominant kernel; see whole_forward)" if strict else
                                 f"{kname} (persistent trunk: 345 dense-block 3x3 convs in one launch)"),
                      "avg_launch_ms": round(trunk_ms, 4) if trunk_ms else None,
@@ -807,6 +816,8 @@ def _compact(d, drop=("higher_is_better", "vs_baseline", "warmup", "unit", "scal
     if not d:
         return d
     out = {k: v for k, v in d.items() if k not in drop}
+    if isinstance(out.get("parity"), dict):
+        out["parity"] = {kk: vv for kk, vv in out["parity"].items() if kk != "what"}
     for k in ("head_roofline", "encdec_kernels", "strict_f32_head", "comm"):
         if isinstance(out.get(k), dict):
             out[k] = {kk: vv for kk, vv in out[k].items() if kk != "note"}
@@ -925,7 +936,10 @@ def main():
                     "train_step_b64": {"error": t["error"]} if "error" in t else {
                         "credited_strict_f32_head": {"ms_per_step": (t.get("strict_f32_head") or {}).get("ms_per_step"),
                                                      "tiles_per_s": (t.get("strict_f32_head") or {}).get("value")},
-                        "fast_mode_f16_head": {"ms_per_step": t.get("ms_per_step"), "tiles_per_s": t.get("value")},
+                        "fast_mode_f16_head": {"ms_per_step": t.get("ms_per_step"), "tiles_per_s": t.get("value"),
+                                               "gradient_parity_vs_exact": {k: (t.get("parity") or {}).get(k) for k in
+                                                                            ("whole_gradient", "heads_max_rel_l2", "within_tolerance", "tolerance", "error")
+                                                                            if (t.get("parity") or {}).get(k) is not None}},
                         "head_frac_hbm_peak": (t.get("head_roofline") or {}).get("frac_hbm_peak"),
                         "head_ms": (t.get("head_roofline") or {}).get("ms_per_step"),
                         "encdec_libsrbh_ms": (t.get("encdec_kernels") or {}).get("ms_per_step"),

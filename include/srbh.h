@@ -52,6 +52,7 @@ const char* srbh_last_error(void);
 #define SRBH_PATH_WGRAD_ENTRY_FUSED 7   /* srbh_hconv_wgrad_entry_b16 -> one pass */
 #define SRBH_PATH_WGRAD_ENTRY_SPLIT 8
 #define SRBH_PATH_HCONV_UP 9             /* srbh_hconv_h16, pixelshuffle2 == 2 -> persistent Upsampler 16 -> 64 kernel */
+#define SRBH_PATH_HBLOCK16 11            /* srbh_hblock16_eval: a plain BasicBlock of the inference head in one pass */
 #define SRBH_PATH_HBWD16 10              /* srbh_hbwd16: BatchNorm apply + weight gradient + data gradient of a 16 -> 16 conv in one pass */
 int srbh_path_counters(unsigned long long* out, int n, int reset);
 
@@ -442,6 +443,22 @@ typedef struct srbh_hbwd16_args {
 } srbh_hbwd16_args;
 int srbh_hbwd16_supported(int H, int W);
 int srbh_hbwd16(const srbh_hbwd16_args* a, void* stream);
+
+/* A whole PLAIN BasicBlock of the inference head in one pass (round 6; reference: SR/HRfuse.py:142-159 in eval mode):
+ *     out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x),   conv1 / conv2 = 3x3, 16 -> 16, no bias; bn folded to (scale, shift) per channel
+ * with fp16 operands and the fp16 intermediate of the two-launch chain (srbh_hconv_h16 x 2: post_scale / post_relu / out fp16, then res1 = x)
+ * kept inside the compute unit: 32 bytes read and 32 (out_h16) / 64 written per pixel instead of 160.  Bit-identical to that chain.
+ * x: fp16 NHWC [B][H][W][16];  w1 / w2: srbh_hpack_conv_h16(ksize 3, transpose_flip 0, bf16 0);  out: fp16 (out_h16) or fp32 NHWC.
+ * W % 64 == 0, H % 4 == 0 (srbh_hblock16_supported); 8-byte aligned x / fp16 out, 16-byte aligned fp32 out and packs. */
+typedef struct srbh_hblock16_args {
+    const void* x;
+    const void* w1; const void* w2;
+    const float* scale1; const float* shift1; const float* scale2; const float* shift2;
+    void* out; int out_h16;
+    int B, H, W;
+} srbh_hblock16_args;
+int srbh_hblock16_supported(int H, int W);
+int srbh_hblock16_eval(const srbh_hblock16_args* a, void* stream);
 
 /* Deferred weight-gradient reduces (round 5; hrfuse_autograd._BlockChainFn.backward).  The reference gets dW from torch autograd
  * (train.py:254-256); nothing reads it before the optimizer / the gradient all-reduce, so the ordered reduce of the per-workgroup partial sums

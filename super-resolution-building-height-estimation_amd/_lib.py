@@ -56,7 +56,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 PATH_NAMES = ("hconv16", "hconv_template", "entry_fused", "entry_split", "wgrad16", "wgrad_b16_generic", "wgrad_f32", "wgrad_entry_fused",
-              "wgrad_entry_split", "hconv_up", "hbwd16")
+              "wgrad_entry_split", "hconv_up", "hbwd16", "hblock16")
 
 
 def path_counters(reset=False):
@@ -106,6 +106,11 @@ class HBwd16Args(C.Structure):
                  ("dx", C.c_void_p), ("dx_b16", C.c_int), ("res", C.c_void_p), ("bstat_c", C.c_void_p), ("bstat_mean", C.c_void_p),
                  ("bstat_invstd", C.c_void_p), ("bstat_ms", C.c_void_p), ("bstat_mh", C.c_void_p), ("stats", C.c_void_p), ("stats_clean", C.c_int),
                  ("dw", C.c_void_p), ("ws", C.c_void_p), ("relu_bits", C.c_void_p)])
+
+
+class HBlock16Args(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w1", C.c_void_p), ("w2", C.c_void_p), ("scale1", C.c_void_p), ("shift1", C.c_void_p),
+                ("scale2", C.c_void_p), ("shift2", C.c_void_p), ("out", C.c_void_p), ("out_h16", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int)]
 
 
 class HWGradArgs(C.Structure):
@@ -223,6 +228,8 @@ SIGNATURES = {
     "srbh_adam_step": (_i, [_vp, _vp, _i, C.c_double, C.c_double, C.c_double, _vp]),
     "srbh_hbwd16_supported": (_i, [_i, _i]),
     "srbh_hbwd16": (_i, [C.POINTER(HBwd16Args), _vp]),
+    "srbh_hblock16_supported": (_i, [_i, _i]),
+    "srbh_hblock16_eval": (_i, [C.POINTER(HBlock16Args), _vp]),
     "srbh_hwgrad_defer": (_i, [_i]),
     "srbh_hwgrad_flush": (_i, [_vp]),
     "srbh_relu_mask_mul": (_i, [_vp, _vp, _vp, C.c_long, _vp]),

@@ -654,6 +654,7 @@ __global__ void nearest2x_kernel(const floatx4* __restrict__ src, floatx4* __res
 #include "srbh_hconv16_kernel.h"
 #include "srbh_hconv_entry_kernel.h"
 #include "srbh_hconv_up_kernel.h"
+#include "srbh_hblock16_kernel.h"
 
 template <int NOB, int KS, int RPW, int OPT = 0>
 int launch_hconv(HParams& p, int B, int H, int W, hipStream_t st) {
@@ -985,6 +986,38 @@ extern "C" int srbh_hconv_entry_h16(const srbh_hconv_args* c1, const srbh_hconv_
     else if (bf16) hipLaunchKernelGGL((hconv_entry_kernel<2, 0>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);
     else if (eo16) hipLaunchKernelGGL((hconv_entry_kernel<1, 1>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);
     else hipLaunchKernelGGL((hconv_entry_kernel<1, 0>), dim3(per_xcd * 8), dim3(256), lds_b, st, e);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_hblock16_supported(int H, int W) { return H > 0 && W > 0 && (W & 63) == 0 && (H & 3) == 0; }
+
+/* A plain BasicBlock of the inference head (eval mode, fp16 chain) as one pass: srbh_hblock16_kernel.h */
+extern "C" int srbh_hblock16_eval(const srbh_hblock16_args* a, void* stream) {
+    SRBH_REQUIRE(a && a->x && a->w1 && a->w2 && a->scale1 && a->shift1 && a->scale2 && a->shift2 && a->out, "srbh_hblock16_eval: null pointer");
+    SRBH_REQUIRE(a->B > 0 && srbh_hblock16_supported(a->H, a->W), "srbh_hblock16_eval: W %% 64 == 0 and H %% 4 == 0 (srbh_hblock16_supported)");
+    SRBH_REQUIRE(((uintptr_t)a->x & 7) == 0 && (((uintptr_t)a->w1 | (uintptr_t)a->w2) & 7) == 0 && ((uintptr_t)a->out & (a->out_h16 ? 7 : 15)) == 0 &&
+                 (((uintptr_t)a->scale1 | (uintptr_t)a->shift1 | (uintptr_t)a->scale2 | (uintptr_t)a->shift2) & 15) == 0, "srbh_hblock16_eval: misaligned tensor");
+    static const int wgs = getenv("SRBH_HBLOCK16_WGS") ? atoi(getenv("SRBH_HBLOCK16_WGS")) : 768;
+    HBlkParams p;
+    p.x = a->x; p.w1 = a->w1; p.w2 = a->w2; p.s1 = a->scale1; p.h1 = a->shift1; p.s2 = a->scale2; p.h2 = a->shift2; p.out = a->out;
+    p.B = a->B; p.H = a->H; p.W = a->W;
+    p.tiles_x = a->W / 64;
+    p.tiles_per_img = p.tiles_x * (a->H / 4);
+    p.ntiles = p.tiles_per_img * a->B;
+    p.tiles_per_xcd = (p.ntiles + 7) / 8;
+    const int per_xcd = p.tiles_per_xcd < wgs / 8 ? p.tiles_per_xcd : (wgs >= 8 ? wgs / 8 : 1);
+    constexpr int LDS_B = 2 * 8 * 68 * 32 + 6 * 66 * 32;
+    hipStream_t st = (hipStream_t)stream;
+    count_path(PATH_HBLOCK16);
+    static const int wpc = getenv("SRBH_HBLOCK16_WPC") ? atoi(getenv("SRBH_HBLOCK16_WPC")) : 3;      // (A/B aid while the kernel is tuned)
+    if (wpc == 2) {
+        if (a->out_h16) hipLaunchKernelGGL((hblock16_kernel<1, 2>), dim3(per_xcd * 8), dim3(256), LDS_B, st, p);
+        else hipLaunchKernelGGL((hblock16_kernel<0, 2>), dim3(per_xcd * 8), dim3(256), LDS_B, st, p);
+    } else {
+        if (a->out_h16) hipLaunchKernelGGL((hblock16_kernel<1>), dim3(per_xcd * 8), dim3(256), LDS_B, st, p);
+        else hipLaunchKernelGGL((hblock16_kernel<0>), dim3(per_xcd * 8), dim3(256), LDS_B, st, p);
+    }
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }

@@ -20,7 +20,7 @@ void set_error(const char* fmt, ...);
 // sliding back to the slow form shows as a count, not only as time.  (Round 4: the fp16 feature hand-off had sent the inference
 // chain's 64-channel block entry back to two template launches -- found only in a kernel trace.)
 enum PathCounter { PATH_HCONV16 = 0, PATH_HCONV_TEMPLATE, PATH_ENTRY_FUSED, PATH_ENTRY_SPLIT, PATH_WGRAD16, PATH_WGRAD_B16_GENERIC,
-                   PATH_WGRAD_F32, PATH_WGRAD_ENTRY_FUSED, PATH_WGRAD_ENTRY_SPLIT, PATH_HCONV_UP, PATH_HBWD16, PATH_N };
+                   PATH_WGRAD_F32, PATH_WGRAD_ENTRY_FUSED, PATH_WGRAD_ENTRY_SPLIT, PATH_HCONV_UP, PATH_HBWD16, PATH_HBLOCK16, PATH_N };
 extern unsigned long long g_path_counters[PATH_N];
 inline void count_path(int i) { ++g_path_counters[i]; }
 // Stream-ordered zero fill of `bytes` (a multiple of 4) by a KERNEL.  Not hipMemsetAsync: captured into a HIP graph, a memset node is

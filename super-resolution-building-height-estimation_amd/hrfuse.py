@@ -375,6 +375,26 @@ def hconv(srcs, conv: nn.Conv2d, packed: _PackedConv, pre=None, ps2=False, want_
     return out, stats
 
 
+# a plain BasicBlock of the fp16 inference chain as one libsrbh pass (csrc/srbh_hblock16_kernel.h); SRBH_HBLOCK16=0: conv1 and conv2 as two launches (A/B aid)
+HBLOCK16 = _os.environ.get("SRBH_HBLOCK16", "1") == "1"
+
+
+def hblock16(x, blk, bn1, bn2, out_h16):
+    """relu(bn2(conv2(relu(bn1(conv1(x))))) + x) for a 16-channel fp16 NHWC `x`, folded BatchNorms bn1 / bn2 = (scale, shift)"""
+    L = _lib.lib()
+    B, _, H, W = x.shape
+    w1, _ = blk._p1.get(blk.conv1, True, False)
+    w2, _ = blk._p2.get(blk.conv2, True, False)
+    a = _lib.HBlock16Args()
+    a.x, a.w1, a.w2 = x.data_ptr(), w1.data_ptr(), w2.data_ptr()
+    a.scale1, a.shift1, a.scale2, a.shift2 = bn1[0].data_ptr(), bn1[1].data_ptr(), bn2[0].data_ptr(), bn2[1].data_ptr()
+    out = empty_nhwc(B, 16, H, W, x.device, torch.float16 if out_h16 else torch.float32)
+    a.out, a.out_h16 = out.data_ptr(), int(out_h16)
+    a.B, a.H, a.W = B, H, W
+    _lib.check(L.srbh_hblock16_eval(C.byref(a), _lib.stream_ptr()), "hblock16_eval")
+    return out
+
+
 def hconv_entry(srcs, conv1, packed1, convd, packedd, want_stats=False, postd=None, post1=None, post1_relu=False, out_h16=False):
     """The entry of a BasicBlock with a downsample branch: conv1 (3x3) and downsample[0] (1x1) over the same cat(srcs) in ONE
     libsrbh call (srbh_hconv_entry_h16: one fused pass over the input when the shapes allow, else the two launches; 16-bit operand
@@ -628,10 +648,15 @@ class BasicBlock(nn.Module):
                 sd, hd, _, _ = bn_scale_shift(self.downsample[1], None, n, False)
                 idt, _ = hconv(srcs, self.downsample[0], self._pd, post=(sd, hd), out_h16=True)
             else:
-                a1, _ = hconv(srcs, self.conv1, self._p1, post=(s1, h1), post_relu=True, out_h16=True)
                 if len(srcs) != 1:
                     raise ValueError("identity path needs a single source")
-                idt = srcs[0]
+                x0 = srcs[0]
+                if (HBLOCK16 and x0.dtype == torch.float16 and x0.shape[1] == 16 and self.bn1.num_features == 16 and self.bn2.num_features == 16
+                        and _lib.lib().srbh_hblock16_supported(H, W)):
+                    # the whole plain block as ONE pass (srbh_hblock16_eval): a1 never leaves the compute unit; same bits as the two launches below
+                    return hblock16(x0, self, (s1, h1), (s2, h2), out_h16)
+                a1, _ = hconv(srcs, self.conv1, self._p1, post=(s1, h1), post_relu=True, out_h16=True)
+                idt = x0
             out, _ = hconv([a1], self.conv2, self._p2, post=(s2, h2), res=idt, post_relu=True, out_h16=out_h16)
             return out
         if any(t.dtype != torch.float32 for t in srcs):
