@@ -244,6 +244,8 @@ SIGNATURES = {
     "srbh_hwgrad_ws_bytes": (_sz, [_i, _i, _i]),
     "srbh_ps2_inverse": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_affine_act_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "srbh_stem_conv_eval_supported": (_i, [_i, _i, _i]),
+    "srbh_stem_conv_eval": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "srbh_affine_act_add_nchw": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_affine_act_pool_nchw": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "srbh_se_hidden": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

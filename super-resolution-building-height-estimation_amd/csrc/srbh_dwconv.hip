@@ -390,6 +390,59 @@ __global__ __launch_bounds__(256) void affine_act_nchw_kernel(const float* __res
     }
 }
 
+// ---- the encoder's STEM at inference (round 6): conv3x3 stride 2 (static "same" padding) Cin <= 16 -> Cout <= 64 + the folded BatchNorm + SiLU in
+// one pass on NCHW fp32 (smp EfficientNetEncoder.forward through mymodels.py:276: `_swish(_bn0(_conv_stem(x)))`).  MIOpen's solver search
+// (benchmark mode of the tiled-inference path) settles on an asm kernel that takes ~0.6 ms per 128-tile batch for this 0.9-GFLOP layer
+// (profiles/r05cd_predict_steady_kernel_stats.txt), followed by the affine pass.  Here: one thread per output pixel, all Cout accumulators
+// in registers, the weights transposed into LDS as [ci][tap][co] and read as wave-uniform ds_read_b128 broadcasts, input taps straight from
+// L1 (a 64 x 64 plane is 16 KB), outputs written plane by plane (coalesced along x).
+template <int CO4>
+__global__ __launch_bounds__(256) void stem_conv_eval_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ y, int B, int Cin, int H, int W,
+                                                            int stride, int pt, int pl, int OH, int OW, int act) {
+    constexpr int CO = CO4 * 4;
+    extern __shared__ __attribute__((aligned(16))) float wl[];          // [Cin][9][CO]
+    const int Cout = CO;
+    for (int i = threadIdx.x; i < Cout * Cin * 9; i += 256) {
+        const int co = i / (Cin * 9), r = i - co * Cin * 9;             // OIHW: r = ci * 9 + tap
+        wl[r * CO + co] = w[i];
+    }
+    __syncthreads();
+    const long total = (long)B * OH * OW;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ox = (int)(idx % OW);
+    const long t = idx / OW;
+    const int oy = (int)(t % OH), b = (int)(t / OH);
+    floatx4 acc[CO4];
+#pragma unroll
+    for (int q = 0; q < CO4; ++q) acc[q] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int iy0 = oy * stride - pt, ix0 = ox * stride - pl;
+    const float* xb = x + (long)b * Cin * H * W;
+    for (int ci = 0; ci < Cin; ++ci) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int iy = iy0 + tap / 3, ix = ix0 + tap % 3;
+            float v = 0.f;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xb[((long)ci * H + iy) * W + ix];
+            const floatx4* wq = (const floatx4*)(wl + (ci * 9 + tap) * CO);
+#pragma unroll
+            for (int q = 0; q < CO4; ++q) acc[q] += wq[q] * v;
+        }
+    }
+    float* yb = y + ((long)b * Cout * OH + oy) * OW + ox;
+#pragma unroll
+    for (int q = 0; q < CO4; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = q * 4 + j;
+            float u = fmaf(acc[q][j], scale[co], shift[co]);
+            if (act == 1) u = u / (1.f + __expf(-u));
+            else if (act == 2) u = fmaxf(u, 0.f);
+            yb[(long)co * OH * OW] = u;
+        }
+}
+
 // ---- squeeze-and-excitation of an MBConv block at inference (efficientnet_pytorch MBConvBlock.forward: avg-pool -> 1x1
 // reduce -> swish -> 1x1 expand -> sigmoid -> scale), three launches instead of ~11 stock-op ones per block:
 //  (1) inference BatchNorm + SiLU of the depthwise output WITH the per-plane mean (one wave per (b, c) plane, <= 1024 px)
@@ -686,6 +739,25 @@ static int affine_act_impl(const float* x, const float* scale, const float* shif
         hipLaunchKernelGGL(affine_act_nchw_kernel<4>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, scale, shift, res, y, planes, C, HW, act);
     else
         hipLaunchKernelGGL(affine_act_nchw_kernel<1>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, scale, shift, res, y, planes, C, HW, act);
+    SRBH_HIP(hipGetLastError());
+    return SRBH_OK;
+}
+
+extern "C" int srbh_stem_conv_eval_supported(int Cin, int Cout, int K) { return K == 3 && Cin > 0 && Cin <= 16 && (Cout == 32 || Cout == 40 || Cout == 48 || Cout == 56 || Cout == 64); }
+
+/* act(conv3x3(x, w, stride, static padding top = pt / left = pl, zeros beyond) * scale[c] + shift[c]) on NCHW fp32; w: OIHW; act 0 none / 1 SiLU / 2 ReLU */
+extern "C" int srbh_stem_conv_eval(const float* x, const float* w, const float* scale, const float* shift, float* y, int B, int Cin, int H, int W,
+                                   int Cout, int stride, int pt, int pl, int OH, int OW, int act, void* stream) {
+    SRBH_REQUIRE(x && w && scale && shift && y, "srbh_stem_conv_eval: null pointer");
+    SRBH_REQUIRE(B > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && stride >= 1 && pt >= 0 && pl >= 0 && act >= 0 && act <= 2 && srbh_stem_conv_eval_supported(Cin, Cout, 3),
+                 "srbh_stem_conv_eval: bad arguments (3x3, Cin <= 16, Cout in {32, 40, 48, 56, 64})");
+    const long total = (long)B * OH * OW;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    const size_t lds = (size_t)Cin * 9 * Cout * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+#define SRBH_STEM(C4_) hipLaunchKernelGGL((stem_conv_eval_kernel<C4_>), grid, dim3(256), lds, st, x, w, scale, shift, y, B, Cin, H, W, stride, pt, pl, OH, OW, act)
+    switch (Cout) { case 32: SRBH_STEM(8); break; case 40: SRBH_STEM(10); break; case 48: SRBH_STEM(12); break; case 56: SRBH_STEM(14); break; default: SRBH_STEM(16); }
+#undef SRBH_STEM
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }

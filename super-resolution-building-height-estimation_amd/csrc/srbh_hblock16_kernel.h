@@ -25,8 +25,10 @@ struct HBlkParams {
     int B, H, W, tiles_x, tiles_per_img, ntiles, tiles_per_xcd;
 };
 
-template <int O16, int WPC = 3>
-__global__ __launch_bounds__(256, WPC) void hblock16_kernel(const HBlkParams p) {
+// Two workgroups per CU (256 registers): at three (168) the kernel spills ~39 registers, and scratch reloads count in vmcnt like any load --
+// every one of them turns a counted wait into a wait for the prefetch.
+template <int O16>
+__global__ __launch_bounds__(256, 2) void hblock16_kernel(const HBlkParams p) {
     constexpr int XR = 8, XC = 68, AR = 6, AC = 66;
     constexpr int NIT = (XR * XC * 4 + 255) / 256;                  // 9 staging units per thread (8-byte quads; the last one partial)
     constexpr int XSTAGE_B = XR * XC * 32;                          // 17 408 bytes
@@ -87,15 +89,23 @@ __global__ __launch_bounds__(256, WPC) void hblock16_kernel(const HBlkParams p) 
     const int a_se = h16_off(e_row, e_col, kk, AC);
     const int idt = h16_off(wave + 2, 2 + l15, kk, XC);                        // + i * 16 * 32 (16 columns: the swizzle bit flips with bit 3 of the column)
 
+    // The loads of a tile are UNCONDITIONAL (a unit outside the image reads the tile's own first pixel and is zeroed when it goes to LDS): a
+    // load behind a branch makes the number of memory operations in flight unknown to the compiler, and every wait for the OLDER slot then
+    // becomes s_waitcnt vmcnt(0) -- i.e. a wait for the prefetch issued a moment ago as well (the first version of this kernel ran at the
+    // speed of the two launches it replaces for exactly that reason).
     typedef float2v ldv_t;
     ldv_t ld[2][NIT];
+    unsigned okmask[2] = {0u, 0u};
     auto issue = [&](auto slot_tag, const int t) {
         constexpr int SL = decltype(slot_tag)::value;
         const int img = t / p.tiles_per_img;
         const int trem = t - img * p.tiles_per_img;
         const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
         const int Y0 = ty * 4, X0 = tx * 64;
-        const char* tp = (const char*)p.x + (((long)img * p.H + (Y0 - 2)) * p.W + (X0 - 2)) * 32;
+        const long org = (((long)img * p.H + (Y0 - 2)) * p.W + (X0 - 2)) * 32;
+        const char* tp = (const char*)p.x + org;
+        const int safe = (2 * p.W + 2) * 32 + cg * 8;                              // the tile's pixel (Y0, X0): always inside the image
+        unsigned m = 0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int r = (urow >> (3 * it)) & 7;
@@ -103,20 +113,29 @@ __global__ __launch_bounds__(256, WPC) void hblock16_kernel(const HBlkParams p) 
             if ((uleft >> it) & 1) ok = ok && X0 > 0;
             if ((uright >> it) & 1) ok = ok && X0 + 64 < p.W;
             if (it == NIT - 1) ok = ok && last_unit;
-            ld[SL][it] = float2v{0.f, 0.f};
-            if (ok) ld[SL][it] = *(const ldv_t*)(tp + uoff[it]);
+            ld[SL][it] = *(const ldv_t*)(tp + (ok ? uoff[it] : safe));
+            m |= ok ? 1u << it : 0u;
         }
+        okmask[SL] = m;
     };
     auto commit = [&](auto slot_tag, char* stage) {
         constexpr int SL = decltype(slot_tag)::value;
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
-            if (it < NIT - 1 || last_unit) *(float2v*)(stage + ulds[it]) = ld[SL][it];      // (zero padding = zero bits)
+            if (it < NIT - 1 || last_unit)
+                *(float2v*)(stage + ulds[it]) = ((okmask[SL] >> it) & 1) ? ld[SL][it] : float2v{0.f, 0.f};      // (zero padding = zero bits)
     };
     using SL0 = std::integral_constant<int, 0>;
     using SL1 = std::integral_constant<int, 1>;
-    if (t_first < t_end) issue(SL0{}, t_first);
-    if (t_first + t_step < t_end) issue(SL1{}, t_first + t_step);
+    // everything loaded once (weights, folded BatchNorms) is CONSUMED here, in front of the walk: a value whose first use sits inside the
+    // loop makes the compiler wait with vmcnt(0) at that use in EVERY iteration (it cannot order the pre-loop load against the loop's
+    // prefetches), which again waits for the prefetch issued a moment ago
+    asm volatile("" ::"v"(sc1), "v"(sh1), "v"(sc2), "v"(sh2));
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) asm volatile("" ::"v"(wa1[tap]), "v"(wa2[tap]));
+    if (t_first >= t_end) return;
+    issue(SL0{}, t_first);
+    issue(SL1{}, t_first + t_step < t_end ? t_first + t_step : t_first);
 
     auto mfma = [&](const short4v a, const short4v b, floatx4& acc) {
         acc = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, a), __builtin_bit_cast(half4, b), acc, 0, 0, 0);
@@ -139,7 +158,9 @@ __global__ __launch_bounds__(256, WPC) void hblock16_kernel(const HBlkParams p) 
         const int trem = t - img * p.tiles_per_img;
         const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
         const int Y0 = ty * 4, X0 = tx * 64;
-        if (t + 2 * t_step < t_end) issue(slot_tag, t + 2 * t_step);          // (into the registers `commit` has just emptied)
+        // (into the registers `commit` has just emptied; ALWAYS issued -- behind the range's end the tile is loaded again and never used -- so that
+        //  the number of memory operations between a slot's loads and their use is a compile-time constant: see `issue`)
+        issue(slot_tag, t + 2 * t_step < t_end ? t + 2 * t_step : t);
         __syncthreads();           // the x stage is complete; every wave is past phase 2 of the tile before (it read the a1 window and the other x stage)
         // ---- phase 1: a1 = relu(bn1(conv1(x))) on the 6 x 66 window
         {

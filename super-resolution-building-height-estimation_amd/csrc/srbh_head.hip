@@ -998,7 +998,7 @@ extern "C" int srbh_hblock16_eval(const srbh_hblock16_args* a, void* stream) {
     SRBH_REQUIRE(a->B > 0 && srbh_hblock16_supported(a->H, a->W), "srbh_hblock16_eval: W %% 64 == 0 and H %% 4 == 0 (srbh_hblock16_supported)");
     SRBH_REQUIRE(((uintptr_t)a->x & 7) == 0 && (((uintptr_t)a->w1 | (uintptr_t)a->w2) & 7) == 0 && ((uintptr_t)a->out & (a->out_h16 ? 7 : 15)) == 0 &&
                  (((uintptr_t)a->scale1 | (uintptr_t)a->shift1 | (uintptr_t)a->scale2 | (uintptr_t)a->shift2) & 15) == 0, "srbh_hblock16_eval: misaligned tensor");
-    static const int wgs = getenv("SRBH_HBLOCK16_WGS") ? atoi(getenv("SRBH_HBLOCK16_WGS")) : 768;
+    static const int wgs = getenv("SRBH_HBLOCK16_WGS") ? atoi(getenv("SRBH_HBLOCK16_WGS")) : 512;      // two per CU
     HBlkParams p;
     p.x = a->x; p.w1 = a->w1; p.w2 = a->w2; p.s1 = a->scale1; p.h1 = a->shift1; p.s2 = a->scale2; p.h2 = a->shift2; p.out = a->out;
     p.B = a->B; p.H = a->H; p.W = a->W;
@@ -1010,14 +1010,8 @@ extern "C" int srbh_hblock16_eval(const srbh_hblock16_args* a, void* stream) {
     constexpr int LDS_B = 2 * 8 * 68 * 32 + 6 * 66 * 32;
     hipStream_t st = (hipStream_t)stream;
     count_path(PATH_HBLOCK16);
-    static const int wpc = getenv("SRBH_HBLOCK16_WPC") ? atoi(getenv("SRBH_HBLOCK16_WPC")) : 3;      // (A/B aid while the kernel is tuned)
-    if (wpc == 2) {
-        if (a->out_h16) hipLaunchKernelGGL((hblock16_kernel<1, 2>), dim3(per_xcd * 8), dim3(256), LDS_B, st, p);
-        else hipLaunchKernelGGL((hblock16_kernel<0, 2>), dim3(per_xcd * 8), dim3(256), LDS_B, st, p);
-    } else {
-        if (a->out_h16) hipLaunchKernelGGL((hblock16_kernel<1>), dim3(per_xcd * 8), dim3(256), LDS_B, st, p);
-        else hipLaunchKernelGGL((hblock16_kernel<0>), dim3(per_xcd * 8), dim3(256), LDS_B, st, p);
-    }
+    if (a->out_h16) hipLaunchKernelGGL((hblock16_kernel<1>), dim3(per_xcd * 8), dim3(256), LDS_B, st, p);
+    else hipLaunchKernelGGL((hblock16_kernel<0>), dim3(per_xcd * 8), dim3(256), LDS_B, st, p);
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
 }

@@ -299,6 +299,33 @@ def _fused_eval_ok(bn, x):
             and not torch.is_grad_enabled())
 
 
+# the stem at inference as one libsrbh pass (conv3x3 stride 2 + folded BatchNorm + SiLU: srbh_stem_conv_eval); SRBH_STEM_EVAL=0: MIOpen's conv + the affine pass
+STEM_EVAL = os.environ.get("SRBH_STEM_EVAL", "1") == "1"
+
+
+def _stem_eval_ok(conv, bn, x):
+    if not (STEM_EVAL and _fused_eval_ok(bn, x) and x.dim() == 4 and conv.bias is None and conv.groups == 1 and conv.weight.dtype == torch.float32
+            and conv.kernel_size == (3, 3) and conv.stride[0] == conv.stride[1] and conv.dilation == (1, 1)):
+        return False
+    from . import _lib
+    return bool(_lib.lib().srbh_stem_conv_eval_supported(conv.in_channels, conv.out_channels, 3))
+
+
+def _stem_eval(conv, bn, x):
+    from . import _lib
+    scale, shift = _bn_affine(bn, x.device)
+    x = x.contiguous()
+    B, Cin, H, W = x.shape
+    pl, pr, pt, pb = conv._pad
+    st = conv.stride[0]
+    OH, OW = (H + pt + pb - 3) // st + 1, (W + pl + pr - 3) // st + 1
+    y = torch.empty((B, conv.out_channels, OH, OW), dtype=torch.float32, device=x.device)
+    w = conv.weight.detach().contiguous()
+    _lib.check(_lib.lib().srbh_stem_conv_eval(x.data_ptr(), w.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, Cin, H, W,
+                                              conv.out_channels, st, pt, pl, OH, OW, _ACT["silu"], _lib.stream_ptr()), "stem_conv_eval")
+    return y
+
+
 def bn_swish_se(bn, x, se_reduce, se_expand):
     """MBConv middle at inference: swish(bn(x)) followed by squeeze-and-excitation, as THREE libsrbh launches
     (csrc/srbh_dwconv.hip) instead of ~11 stock-op ones per block: the encoder is bound by its launch count."""
@@ -553,7 +580,7 @@ class EfficientNetEncoder(nn.Module):
                 pt = self.__dict__["_srbh_pwt"] = PointwiseTransposes(
                     m for m in self.modules() if isinstance(m, SamePadConv2d) and m._pointwise and m is not self._conv_head)
             pt.refresh(x.device)
-        x = bn_act(self._bn0, self._conv_stem(x), "silu")
+        x = _stem_eval(self._conv_stem, self._bn0, x) if _stem_eval_ok(self._conv_stem, self._bn0, x) else bn_act(self._bn0, self._conv_stem(x), "silu")
         feats.append(x)
         n = len(self._blocks)
         bounds = list(self._stage_idxs[:3]) + [n]
