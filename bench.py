@@ -238,10 +238,16 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
     # small-kernel phases.  Every timed step still contains one full trunk pass (that of the batch the following step consumes; the last
     # one is computed and never used), and the final synchronize covers the second stream.  SRBH_TRAIN_PIPELINE=0: the serial step.
     pipe = os.environ.get("SRBH_TRAIN_PIPELINE", "1") == "1" and not use_graph
-    for _ in range(max(warmup, 5 if use_graph else 2)):          # (world > 1: step 1 records the bucket plan; graph: 3 eager steps, then the capture; pipeline: step 1 fills it)
-        ts(fixed, next_batch=fixed if pipe else None)
+    # the timed steps alternate between TWO batches (round-5 VERDICT, hygiene): the announced next batch is then a different tensor from the
+    # running one, as in an epoch (graph mode replays one static batch)
+    other = fixed if use_graph else synthetic_batch(batch, 7331 + rank, dev)
+    pair = (fixed, other)
+    nw = max(warmup, 5 if use_graph else 2)
+    for i in range(nw):          # (world > 1: step 1 records the bucket plan; graph: 3 eager steps, then the capture; pipeline: step 1 fills it)
+        ts(pair[i % 2], next_batch=pair[(i + 1) % 2] if pipe else None)
     if use_graph:
         fixed = ts.static_batch()
+        pair = (fixed, fixed)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -252,8 +258,8 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
     if epoch_tiles:
         steps, tiles, loss = train_epoch(ts, epoch_tiles, batch, rank, world, dev)
     else:
-        for _ in range(steps):
-            loss, _ = ts(fixed, next_batch=fixed if pipe else None)
+        for i in range(nw, nw + steps):
+            loss, _ = ts(pair[i % 2], next_batch=pair[(i + 1) % 2] if pipe else None)
             if ts.reducer is not None:
                 exposed.append(ts.reducer._last_events)
         tiles = batch * world * steps
@@ -304,7 +310,7 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
         "metric": "tiles/sec (64x64x8ch->256x256 height) fwd+bwd", "value": round(tiles / elapsed, 2), "unit": "tiles/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": f"f16 operands/f32 acc (RRDB), head convs: {ts.head_precision} (f16 = forward fp16 operands, data and weight gradients bf16 operands, fp32 accumulation; BN + losses + Adam fp32)",
-        "data": "synthetic" + (" (batches drawn on the device each step)" if epoch_tiles else " (one fixed batch)"),
+        "data": "synthetic" + (" (batches drawn on the device each step)" if epoch_tiles else (" (one static batch: graph replay)" if use_graph else " (two alternating batches)")),
         "config": {"workload": (f"one data-parallel pass over {epoch_tiles} synthetic train tiles (BASELINE.json configs[3]), " if epoch_tiles else "")
                                + f"full train step: RRDBNet fwd (no grad) + SRRegress_Cls_feature fwd/bwd + Adam, batch {batch}/GPU "
                                "(BASELINE.json configs[2])", "batch": batch, "global_batch": batch * world,

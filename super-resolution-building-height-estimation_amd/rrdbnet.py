@@ -495,7 +495,7 @@ class RealESRGAN:
     term is skipped and ``loss_dict`` has no 'l_g_percep'."""
 
     def __init__(self, in_ch=3, out_ch=3, num_block=23, device="cuda", scale=4, ema_decay=0.999,
-                 pretrain_g_path=None, pretrain_d_path=None, is_train=False, cri_perceptual=None):
+                 pretrain_g_path=None, pretrain_d_path=None, is_train=False, cri_perceptual=None, vgg19_weights=None):
         self.device = device
         self.scale = scale
         self.ema_decay = ema_decay
@@ -508,7 +508,11 @@ class RealESRGAN:
                 if isinstance(ckpt, dict) and k in ckpt:
                     ckpt = ckpt[k]
                     break
-            weights = ckpt
+            weights = dict(ckpt)
+            if in_ch == 1:      # SR/rrdbnet_arch.py:451-455,470-474: a 3-band checkpoint averaged over its bands for a 1-band generator
+                weights["conv_first.weight"] = torch.mean(weights["conv_first.weight"], dim=1, keepdim=True)
+                weights["conv_last.weight"] = torch.mean(weights["conv_last.weight"], dim=0, keepdim=True)
+                weights["conv_last.bias"] = torch.mean(weights["conv_last.bias"], dim=0, keepdim=True)
             self.net_g.load_state_dict(weights, strict=True)
         if not self.is_train:
             self.net_g.eval()
@@ -525,10 +529,19 @@ class RealESRGAN:
                 p.requires_grad = False
         self.net_d = UNetDiscriminatorSN(num_in_ch=out_ch, num_feat=64, skip_connection=True).to(device)
         if pretrain_d_path is not None:
-            self.net_d.load_state_dict(torch.load(pretrain_d_path, map_location="cpu")["params"])
+            wd = dict(torch.load(pretrain_d_path, map_location="cpu")["params"])
+            if in_ch == 1:      # SR/rrdbnet_arch.py:486-487
+                wd["conv0.weight"] = torch.mean(wd["conv0.weight"], dim=1, keepdim=True)
+            self.net_d.load_state_dict(wd)
         self.net_g.train().enable_training_path(True)
         self.net_d.train()
         self.cri_pix = nn.L1Loss().to(device)
+        # the VGG19 perceptual term (SR/rrdbnet_arch.py:496-498): a ready module, or torchvision's vgg19 weights (a state_dict or a path to one:
+        # no download offline) for srgan.PerceptualLoss; neither -> the term is skipped and loss_dict has no 'l_g_percep'
+        if cri_perceptual is None and vgg19_weights is not None:
+            from .srgan import PerceptualLoss
+            sd_v = torch.load(vgg19_weights, map_location="cpu") if isinstance(vgg19_weights, (str, bytes)) else vgg19_weights
+            cri_perceptual = PerceptualLoss(loss_weight=1.0, use_input_norm=True, use_range_norm=False, state_dict=sd_v).to(device)
         self.cri_perceptual = cri_perceptual
         self.cri_gan = GANLoss("vanilla", loss_weight=0.1).to(device)
         self.net_d_iters, self.net_d_init_iters = 1, 0

@@ -256,6 +256,96 @@ class USMSharp(nn.Module):
         return soft_mask * sharp + (1 - soft_mask) * img
 
 
+# ---- VGG19 perceptual loss (SR/srloss.py:61-143; wired at SR/rrdbnet_arch.py:496-498, used at :559-562) -------------------------------
+# The reference builds `torchvision.models.vgg19(weights="IMAGENET1K_V1").features` and downloads its weights.  Neither torchvision nor a
+# network exists offline, so the feature stack is restated from the layer table the reference itself prints (SR/srloss.py:8-48: configuration
+# "E": 2 x 64, pool, 2 x 128, pool, 4 x 256, pool, 4 x 512, pool, 4 x 512, pool; every conv 3x3 / pad 1 + ReLU, max-pool 2 / 2) and takes the
+# weights as a state_dict with torchvision's keys (`features.<i>.weight` / `.bias`, or the bare `<i>.weight` of the `features` module).
+# Without one the convolutions keep their random initialisation -- a structure test, not a perceptual metric; RealESRGAN(is_train=True) only
+# adds the term when it is handed weights or a ready module.
+VGG19_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M")
+
+
+def vgg19_features():
+    """torchvision.models.vgg19().features: indices 0..36 as listed in SR/srloss.py:8-48"""
+    layers, cin = [], 3
+    for v in VGG19_CFG:
+        if v == "M":
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    return nn.Sequential(*layers)
+
+
+class VGGFeatureExtractor(nn.Module):
+    """SR/srloss.py:61-105: the VGG19 feature stack cut behind `feature_layer` (a list: one nn.Sequential child per cut, keys
+    `features.child<i>.<j>.*` as upstream; an int: a single stack), optional ImageNet input normalisation / [-1, 1] -> [0, 1] range map,
+    parameters frozen.  state_dict: torchvision's vgg19 weights (see above)."""
+
+    def __init__(self, feature_layer=(2, 7, 16, 25, 34), use_input_norm=True, use_range_norm=False, state_dict=None):
+        super().__init__()
+        feats = vgg19_features()
+        if state_dict is not None:
+            sd = {(k[len("features."):] if k.startswith("features.") else k): v for k, v in state_dict.items()
+                  if k.startswith("features.") or k.split(".")[0].isdigit()}
+            feats.load_state_dict(sd, strict=True)
+        self.use_input_norm = use_input_norm
+        self.use_range_norm = use_range_norm
+        if self.use_input_norm:
+            self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
+            self.register_buffer("std", torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
+        self.list_outputs = isinstance(feature_layer, (list, tuple))
+        children = list(feats.children())
+        if self.list_outputs:
+            self.features = nn.Sequential()
+            cuts = [-1] + list(feature_layer)
+            for i in range(len(cuts) - 1):
+                self.features.add_module("child" + str(i), nn.Sequential(*children[cuts[i] + 1:cuts[i + 1] + 1]))
+        else:
+            self.features = nn.Sequential(*children[:feature_layer + 1])
+        for v in self.features.parameters():
+            v.requires_grad = False
+
+    def forward(self, x):
+        if self.use_range_norm:
+            x = (x + 1.0) / 2.0
+        if self.use_input_norm:
+            x = (x - self.mean) / self.std
+        if self.list_outputs:
+            out = []
+            for child in self.features.children():
+                x = child(x)
+                out.append(x.clone())      # (the next child starts with an in-place ReLU)
+            return out
+        return self.features(x)
+
+
+class PerceptualLoss(nn.Module):
+    """SR/srloss.py:108-143: sum_i weights[i] * L1|MSE(vgg_i(x), vgg_i(gt.detach())) -- times `self.loss_weight`, which upstream pins to 1.0
+    whatever the argument says (srloss.py:123: kept, it is the arithmetic the checkpoints were trained with)."""
+
+    def __init__(self, feature_layer=(2, 7, 16, 25, 34), weights=(0.1, 0.1, 1.0, 1.0, 1.0), lossfn_type="l1", use_input_norm=True,
+                 use_range_norm=False, loss_weight=1.0, state_dict=None):
+        super().__init__()
+        self.vgg = VGGFeatureExtractor(feature_layer=feature_layer, use_input_norm=use_input_norm, use_range_norm=use_range_norm,
+                                       state_dict=state_dict)
+        self.lossfn_type = lossfn_type
+        self.weights = list(weights)
+        self.lossfn = nn.L1Loss() if lossfn_type == "l1" else nn.MSELoss()
+        self.loss_weight = 1.0
+
+    def forward(self, x, gt):
+        x_vgg, gt_vgg = self.vgg(x), self.vgg(gt.detach())
+        loss = 0.0
+        if isinstance(x_vgg, list):
+            for i in range(len(x_vgg)):
+                loss = loss + self.weights[i] * self.lossfn(x_vgg[i], gt_vgg[i])
+        else:
+            loss = loss + self.lossfn(x_vgg, gt_vgg.detach())
+        return loss * self.loss_weight
+
+
 class GANLoss(nn.Module):
     """SR/srloss.py:144-249: 'vanilla' (BCE with logits), 'lsgan', 'wgan', 'wgan_softplus', 'hinge'; loss_weight applies to the
     generator only."""

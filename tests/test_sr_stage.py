@@ -144,6 +144,81 @@ def test_discriminator_on_the_device_matches_the_reference_fixture(golden_dir):
     assert O.rel_l2(y.cpu(), torch.from_numpy(g["disc_out"])) <= 1e-5
 
 
+def _vgg19_seeded_state_dict():
+    """the weights tools/make_golden.py gave the reference's feature stack (torch.manual_seed(1905), default init x 3), torchvision's keys"""
+    from srbh_amd import srgan
+    torch.manual_seed(1905)
+    f = srgan.vgg19_features()
+    with torch.no_grad():
+        for p_ in f.parameters():
+            p_.mul_(3.0)
+    return {"features." + k: v.clone() for k, v in f.state_dict().items()}
+
+
+def test_perceptual_loss_matches_the_reference_fixture(golden_dir):
+    """srgan.VGGFeatureExtractor / PerceptualLoss (SR/srloss.py:61-143) against fixture g15: the reference's own PerceptualLoss executed on a VGG19
+    feature stack built from its layer table with seeded weights (torchvision is absent offline) -- the list form with the default cuts
+    [2, 7, 16, 25, 34] / weights / ImageNet input norm / L1, and the single-cut MSE form with the range map: loss values, input gradients,
+    feature shapes and norms; parameter keys as upstream; frozen parameters."""
+    from srbh_amd.srgan import PerceptualLoss
+    g = np.load(os.path.join(golden_dir, "g15_perceptual.npz"))
+    sd = _vgg19_seeded_state_dict()
+    x = rand((2, 3, 48, 40), 150, 0.0, 1.0).requires_grad_(True)
+    gt = rand((2, 3, 48, 40), 151, 0.0, 1.0)
+    pl = PerceptualLoss(loss_weight=1.0, use_input_norm=True, use_range_norm=False, state_dict=sd)
+    assert not any(p_.requires_grad for p_ in pl.parameters())
+    assert [k for k, _ in pl.vgg.features.named_parameters()][:3] == ["child0.0.weight", "child0.0.bias", "child0.2.weight"]
+    l = pl(x, gt)
+    l.backward()
+    assert abs(float(l) - float(g["l1_list_loss"])) <= 1e-5 * abs(float(g["l1_list_loss"]))
+    assert O.rel_l2(x.grad, torch.from_numpy(g["l1_list_gx"])) <= 1e-5
+    feats = pl.vgg(x.detach())
+    assert [list(f.shape) for f in feats] == g["feat_shapes"].tolist()
+    assert np.allclose([float(f.double().norm()) for f in feats], g["feat_norms"], rtol=1e-5)
+    x.grad = None
+    pm = PerceptualLoss(feature_layer=7, lossfn_type="l2", use_input_norm=False, use_range_norm=True, loss_weight=0.5, state_dict=sd)
+    assert pm.loss_weight == 1.0          # (pinned upstream, srloss.py:123)
+    l2 = pm(x * 2 - 1, gt * 2 - 1)
+    l2.backward()
+    assert abs(float(l2) - float(g["mse_single_loss"])) <= 1e-5 * abs(float(g["mse_single_loss"]))
+    assert O.rel_l2(x.grad, torch.from_numpy(g["mse_single_gx"])) <= 1e-5
+
+
+def test_one_band_generator_takes_a_three_band_checkpoint_averaged(tmp_path):
+    """SR/rrdbnet_arch.py:451-455,470-474: in_ch == 1 -> conv_first.weight averaged over its input bands, conv_last.weight / .bias over its output
+    bands, before load_state_dict"""
+    from srbh_amd.rrdbnet import RRDBNet, RealESRGAN
+    torch.manual_seed(4)
+    src = RRDBNet(3, 3, num_block=1)
+    path = os.path.join(tmp_path, "net_g.tar")
+    torch.save({"params_ema": src.state_dict()}, path)
+    m = RealESRGAN(in_ch=1, out_ch=1, num_block=1, device="cpu", pretrain_g_path=path, is_train=False)
+    sd, got = src.state_dict(), m.net_g.state_dict()
+    assert tuple(got["conv_first.weight"].shape) == (64, 1, 3, 3) and tuple(got["conv_last.weight"].shape) == (1, 64, 3, 3)
+    assert torch.equal(got["conv_first.weight"], sd["conv_first.weight"].mean(dim=1, keepdim=True))
+    assert torch.equal(got["conv_last.weight"], sd["conv_last.weight"].mean(dim=0, keepdim=True))
+    assert torch.equal(got["conv_last.bias"], sd["conv_last.bias"].mean(dim=0, keepdim=True))
+    assert torch.equal(got["body.0.rdb1.conv1.weight"], sd["body.0.rdb1.conv1.weight"])
+
+
+@pytest.mark.gpu
+def test_realesrgan_training_step_with_the_perceptual_term():
+    """RealESRGAN(is_train=True, vgg19_weights=<state_dict>): the VGG19 perceptual term joins the generator's loss (SR/rrdbnet_arch.py:559-562),
+    loss_dict carries the reference's keys in its order, gradients reach the generator through the frozen VGG stack"""
+    from srbh_amd.rrdbnet import RealESRGAN
+    torch.manual_seed(3)
+    m = RealESRGAN(3, 3, num_block=1, device="cuda:0", is_train=True, vgg19_weights=_vgg19_seeded_state_dict())
+    gt = torch.nn.functional.interpolate(rand((2, 3, 16, 16), 9, 0.0, 1.0), scale_factor=8, mode="bilinear")
+    lq = torch.nn.functional.avg_pool2d(gt, 4)
+    vals = []
+    for it in range(4):
+        m.feed_data({"lq": lq, "gt": gt})
+        ld = m.optimize_parameters()
+        assert list(ld) == ["l_g_pix", "l_g_percep", "l_g_gan", "l_d_real", "out_d_real", "l_d_fake", "out_d_fake"]
+        vals.append(ld["l_g_percep"])
+    assert all(v == v and v > 0 for v in vals) and vals[-1] < vals[0], vals
+
+
 @pytest.mark.gpu
 def test_realesrgan_training_step_runs_and_learns():
     """RealESRGAN(is_train=True) (reference SR/rrdbnet_arch.py:437-592): feed_data -> optimize_parameters for a few iterations on

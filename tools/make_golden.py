@@ -522,7 +522,61 @@ def g_sr_stage():
     save("g14_sr_stage", **out)
 
 
+# ---- G15: VGG19 perceptual loss (SR/srloss.py:61-143).  torchvision is absent: the reference's `torchvision.models.vgg19(...)` call is served
+# by a factory that builds the feature stack from the layer table the reference itself documents (SR/srloss.py:8-48) with SEEDED weights (no
+# pretrained network offline); everything else -- the cuts, the input normalisation, the weighted L1 over the five feature maps, the pinned
+# loss_weight -- is the reference's own code, executed.
+def g_perceptual():
+    import torch.nn as nn
+    import SR.srloss as ref_loss
+    from srbh_amd import srgan
+
+    class _VGG(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.features = srgan.vgg19_features()
+
+    def vgg19(weights=None):
+        torch.manual_seed(1905)
+        m = _VGG()
+        with torch.no_grad():
+            for p_ in m.parameters():
+                p_.mul_(3.0)          # (default init shrinks activations by ~0.6 per layer: keep the deep features away from zero)
+        return m
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    sys.modules["torchvision.models"].vgg19 = vgg19
+    ref_loss.torchvision = sys.modules["torchvision"]
+    import contextlib, io
+    out = {}
+    x = rand((2, 3, 48, 40), 150, 0.0, 1.0).requires_grad_(True)
+    gt = rand((2, 3, 48, 40), 151, 0.0, 1.0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = ref_loss.PerceptualLoss(loss_weight=1.0, use_input_norm=True, use_range_norm=False)
+        ref_mse = ref_loss.PerceptualLoss(feature_layer=7, lossfn_type="l2", use_input_norm=False, use_range_norm=True, loss_weight=0.5)
+    sd = {"features." + k: v for k, v in vgg19().features.state_dict().items()}
+    l = ref(x, gt)
+    l.backward()
+    out["l1_list_loss"], out["l1_list_gx"] = l.detach(), x.grad.clone()
+    feats = ref.vgg(x.detach())
+    out["feat_shapes"] = np.array([list(f.shape) for f in feats])
+    out["feat_norms"] = torch.tensor([float(f.double().norm()) for f in feats])
+    x.grad = None
+    l2 = ref_mse(x * 2 - 1, gt * 2 - 1)
+    l2.backward()
+    out["mse_single_loss"], out["mse_single_gx"] = l2.detach(), x.grad.clone()
+    # the restatement on the same weights (state_dict with torchvision's keys)
+    mine = srgan.PerceptualLoss(state_dict=sd)
+    x2 = x.detach().clone().requires_grad_(True)
+    lm = mine(x2, gt)
+    lm.backward()
+    check("G15 perceptual loss", lm.detach().reshape(1), l.detach().reshape(1))
+    check("G15 perceptual grad", x2.grad, out["l1_list_gx"])
+    assert [k for k, _ in mine.vgg.features.named_parameters()] == [k for k, _ in ref.vgg.features.named_parameters()]
+    save("g15_perceptual", **out)
+
+
 if __name__ == "__main__":
+    g_perceptual()
     g_sr_stage()
     g_mosaic()
     g_loader()
