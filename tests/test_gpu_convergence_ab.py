@@ -31,10 +31,13 @@ def test_mixed_head_trains_like_strict_head():
         assert r["heldout_eval_height_rmse"][-1][1] < 0.8 * r["heldout_eval_height_rmse"][0][1]
     # Training is chaotic: two runs of the exact-fp32 step that differ only in their drop-connect draws end 10-20 % apart (the
     # control), so "same curve" can only mean "inside that band".  One-sided: the mixed mode must not train WORSE than the strict
-    # mode by more than the larger of 25 % and twice the control's gap (it may train better: first run here, 300 steps at B=64:
+    # mode by more than the larger of 50 % and twice the control's gap (it may train better: first run here, 300 steps at B=64:
     # loss tail 5.94 vs 6.88, held-out RMSE 4.91 vs 5.80 -- noise in its favour).
+    # (round 6, profiles/r06l_convergence_ab_repeats.txt: six repeats of exactly this test body -- the strict-vs-strict control gap of the loss tail
+    #  ranged 0.05 ... 0.44, the mixed / strict ratio 0.83 ... 1.19: ONE control sample underestimates the band one run in ~ten, which is how
+    #  this test failed once inside a full-suite run.  The floor is therefore the largest control gap seen, 0.5, not 0.25.)
     noise = s["seed_noise_control"]
     m = s["mixed_over_strict"]
-    assert m["loss_tail"] <= 1.0 + max(0.25, 2 * noise["loss_tail_rel_gap"]), s
-    assert m["train_rmse_tail"] <= 1.0 + max(0.25, 2 * noise["train_rmse_tail_rel_gap"]), s
-    assert m["heldout_rmse_final"] <= 1.0 + max(0.25, 2 * noise["heldout_rmse_final_rel_gap"]), s
+    assert m["loss_tail"] <= 1.0 + max(0.5, 2 * noise["loss_tail_rel_gap"]), s
+    assert m["train_rmse_tail"] <= 1.0 + max(0.5, 2 * noise["train_rmse_tail_rel_gap"]), s
+    assert m["heldout_rmse_final"] <= 1.0 + max(0.5, 2 * noise["heldout_rmse_final_rel_gap"]), s

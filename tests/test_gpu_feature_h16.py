@@ -139,7 +139,8 @@ def test_no_head_entry_point_falls_back_to_its_slow_form(monkeypatch):
         net(x, harness.features_for_head(net_hr, x[:, :3].contiguous()))
     c = _lib.path_counters(reset=True)
     assert c["entry_fused"] == 3 and c["entry_split"] == 0, c                  # hrfeat.0, reg.fuse.0, seg.fuse.0
-    assert c["hconv16"] >= 14, c                                               # conv2 of 9 blocks + conv1 of 6 + the two conv_last
+    assert c["hblock16"] == 6, c                                               # the 6 plain blocks: one pass each (round 6, srbh_hblock16_eval)
+    assert c["hconv16"] >= 5, c                                                # conv2 of the 3 entry blocks + the two conv_last
     assert c["hconv_up"] == 4, c                                               # the two Upsampler convs of reg and seg: counted, not silent
     ts = harness.TrainStep(net_hr, net, DEV, lr=1e-4, status_every=0)
     batch = harness.synthetic_batch(2, 3, DEV)

@@ -1,0 +1,52 @@
+"""Register-allocation inventory of the hot kernels (round-5 VERDICT item 2: "private_segment_fixed_size as a CPU test beside test_isa_hazards.py").
+The units are compiled to ISA text and the kernel descriptors' scratch sizes / spill counts are read from the metadata:
+  * the kernels that must not touch scratch at all -- the persistent trunk (a scratch reload inside its pinned instruction stream is a stall with
+    the matrix core idle; two explicit step bodies once cost 30 spilled VGPRs, csrc/srbh_ptrunk3_kernel.h), the fused inference BasicBlock
+    (scratch reloads count in vmcnt and turn its counted waits into waits for the prefetch, csrc/srbh_hblock16_kernel.h) -- are pinned at 0;
+  * the head kernels that DO spill at their launch bounds (a measured trade: three workgroups per CU with 6-24 spilled registers beat two
+    without, DESIGN.md 5.0b / srbh_hconv_entry_kernel.h) are listed with their present budget, so that a change that makes it worse -- or a new
+    spilling kernel -- fails here instead of showing up as a slower step."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "super-resolution-building-height-estimation_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# scratch bytes allowed per kernel family (regex on the demangled name); anything not listed: 0
+BUDGET = [(r"hconv16_kernel<", 68), (r"hconv_entry_kernel<", 100), (r"hbwd16_kernel<", 72)]
+ZERO = [r"ptrunk3_kernel<0, 0>", r"ptrunk3_kernel<0, 1>", r"hblock16_kernel<", r"hconv_entry64_kernel<", r"hconv_up_kernel<", r"hwgrad16_kernel<"]
+
+
+def _kernels(src, tmp_path):
+    out = str(tmp_path / (src + ".s"))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-inline-asm", "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+           "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, src)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    txt = open(out).read()
+    rows = re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.sgpr_spill_count:\s+(\d+)\n(?:.*\n)*?"
+                      r"\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", txt)
+    names = subprocess.run(["c++filt"], input="\n".join(r_[0] for r_ in rows), capture_output=True, text=True).stdout.splitlines()
+    return [(n, int(r_[1]), int(r_[4])) for n, r_ in zip(names, rows)]
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="no hipcc")
+@pytest.mark.parametrize("src", ["srbh_ptrunk.hip", "srbh_head.hip", "srbh_head_bwd.hip"])
+def test_scratch_budget_of_the_hot_kernels(src, tmp_path):
+    ks = _kernels(src, tmp_path)
+    assert ks, "no kernel descriptors found"
+    bad = []
+    for name, scratch, vspill in ks:
+        allowed = 0
+        for pat, b in BUDGET:
+            if re.search(pat, name):
+                allowed = b
+        if any(re.search(z, name) for z in ZERO):
+            allowed = 0
+        if scratch > allowed:
+            bad.append((name[:100], scratch, vspill, allowed))
+    assert not bad, bad

@@ -37,6 +37,8 @@ bench_leg $O/${TAG}_bench_sr_train_b8.json.log --workload sr_train --steps 6 --w
 SRBH_SR_BENCH_MODES=fast,mixed bench_leg $O/${TAG}_bench_sr_train_b24.json.log --workload sr_train --steps 6 --warmup 2 --batch 24
 leg 'timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- python bench.py --no-cpu-baseline --no-extras > $O/${TAG}_stats.log 2>&1'
 leg 'cp $(find $O/${TAG}_stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_feature_b32_kernel_stats.csv'
+# (the stats CSV averages EVERY launch of a kernel, the one-tile parity forwards included: the batch-32 launches on their own)
+leg 'python tools/trunk_launch_stats.py $O/${TAG}_stats > $O/${TAG}_trunk_launches_by_grid.txt'
 leg 'timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_pmc_fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/${TAG}_pmc_fetch.log 2>&1'
 leg 'timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_pmc_write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/${TAG}_pmc_write.log 2>&1'
 leg 'python tools/pmc_traffic.py $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_hbm_traffic.json'
