@@ -5,5 +5,5 @@ run() { timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/d
 for r in 1 2; do
 cp $P/libsrbh_old.so.keep $P/libsrbh.so; run old
 cp /tmp/new.so $P/libsrbh.so; run new
-SRBH_PT_REGRES=0 run new_regres0
+
 done
