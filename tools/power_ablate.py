@@ -1,3 +1,4 @@
+# NOTE (round 6): the -DP3_ABL ablation knob this script was written for was removed from csrc/srbh_ptrunk3_kernel.h with the other dead knobs; kept as the record of how profiles/r04c / r05y were produced.
 """developer aid: trunk launch time + package power + shader clock for ONE library build (SRBH_LIB_PATH: tools/build_variant.py
 -DP3_ABL=... variants give WRONG results by construction; only time / power / clock are read).  Loops forward_feature(B=32) for
 ~5 s with rocm-smi sampled beside it.    usage: SRBH_LIB_PATH=build/variants/libsrbh_x.so python tools/power_ablate.py <label>"""

@@ -1,3 +1,4 @@
+# NOTE (round 6): the -DP3_ABL ablation knob this script was written for was removed from csrc/srbh_ptrunk3_kernel.h with the other dead knobs; kept as the record of how profiles/r04c / r05y were produced.
 """developer aid: trunk launch time (HIP events inside libsrbh) without any correctness check -- for ABLATED variants (tools/build_variant.py
 -DP3_ABL=..., wrong results by construction) loaded through SRBH_LIB_PATH.  usage: time_trunk.py [reps]"""
 import ctypes, sys
