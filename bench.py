@@ -415,7 +415,7 @@ def bench_train(args, rank, world, dev, dist, steps, warmup, batch=64, epoch_til
     return line
 
 
-def bench_predict(args, rank, world, dev, dist, n_cities, warmup, batch=128, small=False):
+def bench_predict(args, rank, world, dev, dist, n_cities, warmup, batch=256, small=False):
     """BASELINE configs[4]: urban-centre tiled inference.  A "step" is ONE synthetic city: its grid cells (64x64x8 LR tiles,
     stride 48 as in the reference's grid loader) are sharded over the ranks, each rank runs RRDBNet features -> eval head ->
     quantise + integer mosaic on the device, the integer mosaics are summed over ranks (bit-identical to the serial
@@ -906,7 +906,7 @@ def main():
             sys.exit(f"bench.py --gpus {args.gpus} (rank {rank}): " + "; ".join(problems))
 
     tb = args.batch if args.batch != 32 else 64
-    pb = args.batch if args.batch != 32 else 128
+    pb = args.batch if args.batch != 32 else 256      # (256 tiles per batch: +3.7 % over 128 on three interleaved repeats, profiles/r06m_predict_batch_repeats.txt)
     if args.workload == "train":
         line = bench_train(args, rank, world, dev, dist, args.steps, args.warmup, batch=tb, with_kernels=not args.no_extras,
                            with_cpu=not (args.no_extras or args.no_cpu_baseline))
@@ -923,7 +923,7 @@ def main():
             extras = {}
             for key, fn in (("train_step", lambda: bench_train(args, rank, world, dev, dist, 20, 8, batch=64,      # (8 warm-up + 20 timed steps: the pipelined step needs a few steps to settle; 5 + 10 read 1.8 ms above the 40-step figure)
                                                                 with_cpu=not args.no_cpu_baseline)),
-                            ("predict", lambda: bench_predict(args, rank, world, dev, dist, int(os.environ.get("SRBH_BENCH_PREDICT_CITIES", "301")), 1, batch=128))):   # configs[4] at its stated size: all 301 cities (~225 s on one GPU)
+                            ("predict", lambda: bench_predict(args, rank, world, dev, dist, int(os.environ.get("SRBH_BENCH_PREDICT_CITIES", "301")), 1, batch=256))):   # configs[4] at its stated size: all 301 cities (~225 s on one GPU)
                 try:
                     extras[key] = _compact(fn())
                 except Exception as e:          # the headline must survive a failing extra (and say so)
