@@ -54,7 +54,9 @@ struct HBParams {
 //         bit pattern, written as bf16 and summed for bn2' (sum dz', sum dz' xhat2' over the rounded values) -- exactly what that block's
 //         srbh_bn_bwd_reduce_io(SRBH_BN_REF_BITS | SRBH_BN_OUT_B16) pass would compute from the fp32 tensor this kernel then never writes
 // MK: 1 = g is masked with c*ms + mh > 0
-template <int BS, int MK>
+// RES: the forms that may carry a skip gradient (conv1's uses: BS 0 and 2; conv2's use, BS 1, has none) ALWAYS load four quads for it -- from `g`
+// when no `res` is given, and then do not add them: a run-time `if (p.res) load` would hide the number of loads in flight from the compiler
+template <int BS, int MK, int RES = (BS != 1)>
 __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
     extern __shared__ __attribute__((aligned(16))) float hbsm[];
     using G = HB16;
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
         pmlds[it] = 16 * SX + 16 * SD;                                     // dword offset of the pixel-major area (pixel offsets added per i)
     }
     const bool x1_valid = tid + 256 < 6 * QX * 4;
+    const int xsafe = (p.W + 4) * 16 + cg * 4;        // element offset of the tile's first own quad (row Y0, columns X0 .. X0 + 3) from the window origin
 
     floatx4 accw[9];
 #pragma unroll
@@ -139,21 +142,18 @@ __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
             if (xq[it] == 0) ok = ok && X0 > 0;
             if (xq[it] == QX - 1) ok = ok && X0 + 64 < p.W;
             if (it == 1) ok = ok && x1_valid;
+            // UNCONDITIONAL loads (an item outside the image reads the tile's own first quad; `commit` zeroes it): a load behind a branch hides the
+            // number of memory operations in flight from the compiler, and every later counted wait -- the epilogue's wait for THIS tile's c / skip
+            // gradient, issued in front of the next tile's 24 window loads -- becomes s_waitcnt vmcnt(0), i.e. a wait for that prefetch
+            // (csrc/srbh_hblock16_kernel.h has the measurement of what that costs)
+            const int xo = ok ? xoff[it] : xsafe;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                lg[it][i] = float2w{0.f, 0.f};
-                lc[it][i] = floatx4{0.f, 0.f, 0.f, 0.f};
-                lx[it][i] = floatx4{0.f, 0.f, 0.f, 0.f};
+                lg[it][i] = *(const float2w*)(gp + (long)(xo + i * 16) * 2);
+                lc[it][i] = *(const floatx4*)(cp + xo + i * 16);
+                lx[it][i] = *(const floatx4*)(xp + xo + i * 16);
             }
-            if (ok) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    lg[it][i] = *(const float2w*)(gp + (long)(xoff[it] + i * 16) * 2);
-                    lc[it][i] = *(const floatx4*)(cp + xoff[it] + i * 16);
-                    lx[it][i] = *(const floatx4*)(xp + xoff[it] + i * 16);
-                }
-                okx |= 1u << it;
-            }
+            okx |= ok ? 1u << it : 0u;
         }
     };
     auto commit = [&](unsigned* stage) {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
         const long pix0 = ((long)img * p.H + ty * 4 + wave) * p.W + tx * 64 + l15;
         // epilogue operands of THIS tile first (c of the statistics / the skip gradient), then the next tile's window
         floatx4 rres[BS != 0 ? 4 : 1];
-        float2w rraw[BS != 1 ? 4 : 1];           // (the skip gradient: raw bf16 quads, widened in the epilogue)
+        float2w rraw[RES ? 4 : 1];                // (the skip gradient: raw bf16 quads, widened in the epilogue)
         // HB16_LATE (BS = 2 only, where both are needed: 24 registers across the MFMAs cost 16 spills): 1 = the skip gradient, 2 = the skip
         // gradient and c' are requested BEHIND the MFMAs (their latency is then covered by the other wave of the SIMD only)
         auto load_c = [&]() {
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
             for (int i = 0; i < 4; ++i) rres[i] = *(const floatx4*)(rp + i * 16 * 16);
         };
         auto load_res = [&]() {
-            const char* rp = (const char*)p.res + (pix0 * 16 + kk * 4) * 2;
+            const char* rp = (const char*)(p.res ? p.res : p.g) + (pix0 * 16 + kk * 4) * 2;
 #pragma unroll
             for (int i = 0; i < 4; ++i) rraw[i] = *(const float2w*)(rp + (long)i * 16 * 16 * 2);
         };
@@ -244,8 +244,8 @@ __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
         unsigned bitsv = 0;
         if constexpr (BS == 2 && HB16_BITS_VEC) bitsv = ((const unsigned*)(p.relu_bits + ((pix0 - l15) >> 4) * 4))[lane & 31];
         if constexpr (BS != 0 && LATE < 2) load_c();
-        if constexpr (BS != 1 && LATE < 1) { if (p.res) load_res(); }
-        if (t + t_step < t_end) issue(t + t_step);
+        if constexpr (RES && LATE < 1) load_res();
+        issue(t + t_step < t_end ? t + t_step : t);          // (ALWAYS: behind the range's end the tile is loaded again and never used -- a constant count)
         __syncthreads();           // stage `buf` complete; every wave is past the MFMAs of the tile before (other stage)
         // ---- weight gradient: 4 pixel groups x 3 rows x 3 shifts (hwgrad16_kernel's loop)
 #pragma unroll
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
         }
         // ---- epilogue of the data gradient
         if constexpr (BS != 0 && LATE >= 2) load_c();
-        if constexpr (BS != 1 && LATE >= 1) { if (p.res) load_res(); }
+        if constexpr (RES && LATE >= 1) load_res();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             floatx4 v = acc[i];
@@ -322,8 +322,8 @@ __global__ __launch_bounds__(256, 2) void hbwd16_kernel(const HBParams p) {
                     ssq[q] = fmaf(dzr[q], (rres[i][q] - b_mean[q]) * b_inv[q], ssq[q]);
                 }
                 continue;
-            } else if (p.res) {
-                v = v + widen_b4(rraw[i]);
+            } else if constexpr (RES) {
+                if (p.res) v = v + widen_b4(rraw[i]);
             }
             if (p.dx_b16) *(float2w*)((char*)p.dx + ((pix0 + i * 16) * 16 + kk * 4) * 2) = narrow_b4(v);
             else *(floatx4*)((float*)p.dx + (pix0 + i * 16) * 16 + kk * 4) = v;

@@ -76,6 +76,8 @@ __global__ __launch_bounds__(256, SRBH_ENTRY_WGS_PER_CU) void hconv_entry_kernel
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f}, dsum[4] = {0.f, 0.f, 0.f, 0.f}, dsq[4] = {0.f, 0.f, 0.f, 0.f};
     typedef typename std::conditional<S16 != 0, short4v, floatx4>::type ld_t;
     ld_t ld[NIT];
+    unsigned okmask = 0;
+    const int usafe = p.W + 1;          // window pixel offset of the tile's pixel (Y0, X0): always inside the image
     auto issue = [&](const int t, const int c) {
         const int img = t / p.tiles_per_img;
         const int trem = t - img * p.tiles_per_img;
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(256, SRBH_ENTRY_WGS_PER_CU) void hconv_entry_kernel
         const long eoff = (((long)img * p.H + (Y0 - 1)) * p.W + (X0 - 1)) * ldp + cg * 4 + (in0 ? c * 16 : c * 16 - p.c0);      // in elements
         const float* tp = (in0 ? p.src0 : p.src1) + eoff;
         const short* tp16 = (const short*)(in0 ? p.src0 : p.src1) + eoff;
+        unsigned m = 0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int r = (urow >> (3 * it)) & 7;
@@ -93,29 +96,33 @@ __global__ __launch_bounds__(256, SRBH_ENTRY_WGS_PER_CU) void hconv_entry_kernel
             if ((ucol1 >> it) & 1) ok = ok && X0 > 0;
             if ((ucol1 >> (8 + it)) & 1) ok = ok && X0 + 64 < p.W;
             if (it == NIT - 1) ok = ok && last_unit;
-            if constexpr (S16 != 0) {
-                ld[it] = short4v{0, 0, 0, 0};
-                if (ok) ld[it] = *(const short4v*)(tp16 + upix[it] * ldp);
-            } else {
-                ld[it] = floatx4{0.f, 0.f, 0.f, 0.f};
-                if (ok) ld[it] = *(const floatx4*)(tp + upix[it] * ldp);
-            }
+            // UNCONDITIONAL loads (a unit outside the image reads the tile's own first pixel; `commit` zeroes it): a load behind a branch hides the
+            // number of memory operations in flight from the compiler and turns every later counted wait into s_waitcnt vmcnt(0)
+            // (csrc/srbh_hblock16_kernel.h); it also cost this kernel 24 spilled registers at its launch bound
+            const int po = ok ? upix[it] : usafe;
+            if constexpr (S16 != 0) ld[it] = *(const short4v*)(tp16 + po * ldp);
+            else ld[it] = *(const floatx4*)(tp + po * ldp);
+            m |= ok ? 1u << it : 0u;
         }
+        okmask = m;
     };
     auto commit = [&](char* stage) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (it < NIT - 1 || last_unit) {
+                const bool uok = (okmask >> it) & 1;
                 if constexpr (S16 != 0) {
-                    *(short4v*)(stage + ulds[it]) = ld[it];
+                    *(short4v*)(stage + ulds[it]) = uok ? ld[it] : short4v{0, 0, 0, 0};
                 } else {
                     const float t4[4] = {ld[it][0], ld[it][1], ld[it][2], ld[it][3]};
-                    *(short4v*)(stage + ulds[it]) = round4<OPT>(t4);
+                    *(short4v*)(stage + ulds[it]) = uok ? round4<OPT>(t4) : short4v{0, 0, 0, 0};
                 }
             }
         }
     };
 
+    // (values loaded once are consumed in front of the walk; the prefetch below is issued ALWAYS: constant counts -> counted waits)
+    asm volatile("" ::"v"(e_bias), "v"(e_sc), "v"(e_sh), "v"(d_bias), "v"(d_sc), "v"(d_sh));
     if (t_first < t_end) issue(t_first, 0);
     __syncthreads();                   // the weights are in LDS
     int buf = 0;
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(256, SRBH_ENTRY_WGS_PER_CU) void hconv_entry_kernel
             char* const stage = s_base + buf * STAGE_B;
             commit(stage);
             if (c + 1 < nchunk) issue(t, c + 1);
-            else if (t + t_step < t_end) issue(t + t_step, 0);
+            else issue(t + t_step < t_end ? t + t_step : t, 0);          // (behind the range's end: the tile again, never used)
             __syncthreads();           // stage `buf` complete; every wave is past the MFMAs of the unit before (other stage)
             const char* wc = s_w + ((long)c * 640 + lane) * 8;
 #pragma unroll

@@ -582,6 +582,7 @@ __global__ void bn_add_relu_kernel(const void* __restrict__ a, const float* sa, 
                                    long n4, int C, unsigned long long* __restrict__ bits = nullptr) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long stride = (long)gridDim.x * blockDim.x;
+    // (one unit per trip: four units per trip with all eight loads in front measured SLOWER, 179-183 against 166-170 us, profiles/r06q_ab_bar_unroll.txt)
     for (; i < n4; i += stride) {
         int c = (int)((i * 4) % C);
         floatx4 av, d;

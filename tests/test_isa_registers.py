@@ -3,8 +3,8 @@ The units are compiled to ISA text and the kernel descriptors' scratch sizes / s
   * the kernels that must not touch scratch at all -- the persistent trunk (a scratch reload inside its pinned instruction stream is a stall with
     the matrix core idle; two explicit step bodies once cost 30 spilled VGPRs, csrc/srbh_ptrunk3_kernel.h), the fused inference BasicBlock
     (scratch reloads count in vmcnt and turn its counted waits into waits for the prefetch, csrc/srbh_hblock16_kernel.h) -- are pinned at 0;
-  * the head kernels that DO spill at their launch bounds (a measured trade: three workgroups per CU with 6-24 spilled registers beat two
-    without, DESIGN.md 5.0b / srbh_hconv_entry_kernel.h) are listed with their present budget, so that a change that makes it worse -- or a new
+  * the head kernels that DO spill at their launch bounds (hconv16_kernel's statistics / narrow-input forms: a measured trade, three workgroups
+    per CU with 6-16 spilled registers beat two without) are listed with their present budget, so that a change that makes it worse -- or a new
     spilling kernel -- fails here instead of showing up as a slower step."""
 import os
 import re
@@ -17,8 +17,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "super-resolution-building-height-estimation_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # scratch bytes allowed per kernel family (regex on the demangled name); anything not listed: 0
-BUDGET = [(r"hconv16_kernel<", 68), (r"hconv_entry_kernel<", 100), (r"hbwd16_kernel<", 72)]
-ZERO = [r"ptrunk3_kernel<0, 0>", r"ptrunk3_kernel<0, 1>", r"hblock16_kernel<", r"hconv_entry64_kernel<", r"hconv_up_kernel<", r"hwgrad16_kernel<"]
+# (round 6: hbwd16_kernel 8-72 B -> 0 in all six forms and hconv_entry_kernel 100 B -> 0 -- 20 B left in its bf16 / 16-bit-output form, which no
+#  caller of the training step or the inference chain uses -- by making their loads unconditional and their prefetch issue constant)
+BUDGET = [(r"hconv16_kernel<", 68), (r"hconv_entry_kernel<2, 1, 0>", 20)]
+ZERO = [r"ptrunk3_kernel<0, 0>", r"ptrunk3_kernel<0, 1>", r"hblock16_kernel<", r"hconv_entry64_kernel<", r"hconv_up_kernel<", r"hwgrad16_kernel<",
+        r"hbwd16_kernel<", r"hconv_entry_kernel<1,", r"hconv_entry_kernel<2, 0"]
 
 
 def _kernels(src, tmp_path):
