@@ -524,7 +524,7 @@ int srbh_dwconv_bwd_weight(const float* x, const float* dy, float* dw, float* ws
 /* The encoder's stem at inference (round 6; smp EfficientNetEncoder.forward behind mymodels.py:276: _swish(_bn0(_conv_stem(x)))): a 3x3 conv with
  * stride `stride` and the static "same" zero padding (pt rows on top, pl columns on the left; whatever the window needs beyond the image on the
  * other sides is zero as well) + the folded BatchNorm (scale, shift per output channel) + activation (0 none, 1 SiLU, 2 ReLU) in ONE pass over
- * NCHW fp32 tensors.  w: OIHW fp32.  Cin <= 16, Cout in {32, 40, 48, 56, 64} (srbh_stem_conv_eval_supported: the stems of efficientnet-b0..b7). */
+ * NCHW fp32 tensors.  w: OIHW fp32.  Cin <= 16, Cout in {32, 40, 48} (srbh_stem_conv_eval_supported: the stems of efficientnet-b0..b5; wider stems keep the stock conv). */
 int srbh_stem_conv_eval_supported(int Cin, int Cout, int K);
 int srbh_stem_conv_eval(const float* x, const float* w, const float* scale, const float* shift, float* y, int B, int Cin, int H, int W,
                         int Cout, int stride, int pt, int pl, int OH, int OW, int act, void* stream);

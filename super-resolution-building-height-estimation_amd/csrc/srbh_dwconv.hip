@@ -743,20 +743,21 @@ static int affine_act_impl(const float* x, const float* scale, const float* shif
     return SRBH_OK;
 }
 
-extern "C" int srbh_stem_conv_eval_supported(int Cin, int Cout, int K) { return K == 3 && Cin > 0 && Cin <= 16 && (Cout == 32 || Cout == 40 || Cout == 48 || Cout == 56 || Cout == 64); }
+// (56 / 64 output channels -- the stems of efficientnet-b6 / b7 -- would need a second accumulator pass: one thread holding 64 accumulators spills)
+extern "C" int srbh_stem_conv_eval_supported(int Cin, int Cout, int K) { return K == 3 && Cin > 0 && Cin <= 16 && (Cout == 32 || Cout == 40 || Cout == 48); }
 
 /* act(conv3x3(x, w, stride, static padding top = pt / left = pl, zeros beyond) * scale[c] + shift[c]) on NCHW fp32; w: OIHW; act 0 none / 1 SiLU / 2 ReLU */
 extern "C" int srbh_stem_conv_eval(const float* x, const float* w, const float* scale, const float* shift, float* y, int B, int Cin, int H, int W,
                                    int Cout, int stride, int pt, int pl, int OH, int OW, int act, void* stream) {
     SRBH_REQUIRE(x && w && scale && shift && y, "srbh_stem_conv_eval: null pointer");
     SRBH_REQUIRE(B > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && stride >= 1 && pt >= 0 && pl >= 0 && act >= 0 && act <= 2 && srbh_stem_conv_eval_supported(Cin, Cout, 3),
-                 "srbh_stem_conv_eval: bad arguments (3x3, Cin <= 16, Cout in {32, 40, 48, 56, 64})");
+                 "srbh_stem_conv_eval: bad arguments (3x3, Cin <= 16, Cout in {32, 40, 48})");
     const long total = (long)B * OH * OW;
     const dim3 grid((unsigned)((total + 255) / 256));
     const size_t lds = (size_t)Cin * 9 * Cout * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
 #define SRBH_STEM(C4_) hipLaunchKernelGGL((stem_conv_eval_kernel<C4_>), grid, dim3(256), lds, st, x, w, scale, shift, y, B, Cin, H, W, stride, pt, pl, OH, OW, act)
-    switch (Cout) { case 32: SRBH_STEM(8); break; case 40: SRBH_STEM(10); break; case 48: SRBH_STEM(12); break; case 56: SRBH_STEM(14); break; default: SRBH_STEM(16); }
+    switch (Cout) { case 32: SRBH_STEM(8); break; case 40: SRBH_STEM(10); break; default: SRBH_STEM(12); }
 #undef SRBH_STEM
     SRBH_HIP(hipGetLastError());
     return SRBH_OK;
