@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256, 1) void ptail_kernel(const TParams p) {
                       j < G::NJ - 1 ? ~0ull : tail_mask);
     };
 
+    // epilogue stores per wave and tile when every tile is full (no store predicated off): see the wait at the top of the tile loop
+    const int nst = ((p.H & (TILE_H - 1)) == 0 && (p.W & (TILE_W - 1)) == 0) ? (p.out32 ? 32 : 0) + (p.out16 ? 16 : 0) : 0;
     const int t0 = blockIdx.x * p.tiles_per_wg;
     const int t1 = (t0 + p.tiles_per_wg < p.ntiles) ? t0 + p.tiles_per_wg : p.ntiles;
     if (t0 >= t1) return;
@@ -112,7 +114,13 @@ __global__ __launch_bounds__(256, 1) void ptail_kernel(const TParams p) {
     for (int t = t0; t < t1; ++t) {
         int img, Y0, X0;
         tile_origin(t, img, Y0, X0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's inputs (and, first time, the weights) landed ...
+        // this tile's inputs (and, first time, the weights) landed ...  From the second tile on the only operations YOUNGER than that DMA are the
+        // previous tile's epilogue stores (issued behind stage_inputs): full tiles issue a fixed number of them per wave -- 32 (fp32 output) and /
+        // or 16 (16-bit output) -- so the wait leaves exactly those in flight instead of waiting for their acknowledgement as well
+        if (t == t0 || nst == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nst == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (nst == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
         __syncthreads();                                    // ... on every wave
         floatx16 acc[CB][4];
 #pragma unroll

@@ -646,7 +646,10 @@ __global__ __launch_bounds__(256, 1) void ptrunk3_kernel(const PParams pp) {
         // slots of 32): rows 0 and 3 during the first pass -- they land under its arithmetic -- and rows 1, 2 as the slots free
         // up.  (Loading each row pair right before its use cost 17 k cycles per RRDB-closing epilogue against 3.6 k for a plain
         // one: two fully exposed memory latencies plus a wasted fp16 pass.  All four rows at once by LDS-DMA into the idle stage
-        // was built and is slower -- the burst of all 256 workgroups is bandwidth-bound either way: profiles/r05an_ab_r2lds.txt.)
+        // was built and is slower -- the burst of all 256 workgroups is bandwidth-bound either way: profiles/r05an_ab_r2lds.txt.  Round 6: the
+        // compiler's waits for these slots come out as vmcnt(1) / vmcnt(0) because the asm stores in between are invisible to it; asm loads with
+        // manual counted waits (vmcnt(8) / (16)) shortened this epilogue by ~800 cycles and lengthened the seam by as much -- the stores have to
+        // be acknowledged before the publication anyway: 3.727 vs 3.736 ms over four interleaved runs, profiles/r06s_*; not kept.)
         floatx4 a2[2][2][4];
         auto load_a2 = [&](const int slot, const int i) {
             const long rowb = ((long)img * pp.H + Y0 + wr * 4 + i) * pp.W * 64;
