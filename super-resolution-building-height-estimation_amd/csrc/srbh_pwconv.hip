@@ -18,6 +18,7 @@
 // quarter [kq K/4, (kq+1) K/4): every lane then walks its own row / plane sequentially.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 #include "srbh.h"
@@ -319,9 +320,13 @@ int gemm_launch_epi_kw(int kw, const float* W, const float* In, float* Out, int 
     return SRBH_OK;
 }
 
+#include "srbh_pwgemm_lds_kernel.h"      // the LDS-tiled form for wide products (the tiled prediction's batches)
+
 template <int TRANS_A>
 int gemm_launch_epi(const float* W, const float* In, float* Out, int M, int K, int HW, int B, const PwEpi& ep, hipStream_t st) {
     const long ncols = (long)B * HW, m16 = (M + 15) / 16, n16 = (ncols + 15) / 16;
+    const PwLdsPlan lp = pw_lds_plan(M, K, HW, ncols);
+    if (lp.form) return pw_lds_launch<TRANS_A, 1>(lp, W, In, Out, M, K, HW, ncols, ep, st);
     const int t = pick_tile(m16, n16);
     const int MI = t == 2 ? 2 : 1, NI = t >= 1 ? 2 : 1;
     const int tm = (int)((m16 + MI - 1) / MI), tn = (int)((n16 + NI - 1) / NI);
@@ -334,6 +339,8 @@ int gemm_launch_epi(const float* W, const float* In, float* Out, int M, int K, i
 template <int TRANS_A>
 int gemm_launch(const float* W, const float* In, float* Out, int M, int K, int HW, int B, hipStream_t st) {
     const long ncols = (long)B * HW, m16 = (M + 15) / 16, n16 = (ncols + 15) / 16;
+    const PwLdsPlan lp = pw_lds_plan(M, K, HW, ncols);
+    if (lp.form) return pw_lds_launch<TRANS_A, 0>(lp, W, In, Out, M, K, HW, ncols, PwEpi{}, st);
     const int t = pick_tile(m16, n16);
     const int MI = t == 2 ? 2 : 1, NI = t >= 1 ? 2 : 1;
     const int tm = (int)((m16 + MI - 1) / MI), tn = (int)((n16 + NI - 1) / NI);

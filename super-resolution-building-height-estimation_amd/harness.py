@@ -643,6 +643,11 @@ def train_epoch(ts, n_tiles, batch, rank, world, device, seed=1337, max_steps=No
 
 PREDICT_GRAPH = os.environ.get("SRBH_PREDICT_GRAPH", "1") == "1"
 PREDICT_SPLIT = os.environ.get("SRBH_PREDICT_SPLIT", "1") == "1"      # encoder / decoders as their own graph on a second stream (0: one graph, A/B aid)
+# the encoder / decoders of batch k + 1 run BEHIND batch k's trunk (beside its tail convs / HRfeature / reg / seg) instead of beside batch
+# k + 1's trunk (round 6; 0: the round-4 arrangement, A/B aid).  Measured (tools/predict_parts.py, profiles/r06x_*): the persistent trunk
+# owns every CU, so the encoder's ~190 launches beside it are not hidden -- a batch takes the SUM of its three graphs -- and each one that
+# slips in between two trunk launches delays a whole launch: 44.65 ms per 256 tiles against 43.7 with the encoder kept off the trunk.
+PREDICT_AHEAD = os.environ.get("SRBH_PREDICT_AHEAD", "1") == "1"
 
 
 class _PredictGraph:
@@ -673,7 +678,33 @@ class _PredictGraph:
             # same chains on one stream); separate graph launches on separate streams do.  The persistent trunk owns every CU
             # while it runs, so the encoder fills in around it (before, between its launches, under HRfeature).
             self.split = PREDICT_SPLIT and all(hasattr(model, n) for n in ("forward_lr", "forward_hr", "forward_fuse"))
-            if self.split:
+            self.ahead = self.split and PREDICT_AHEAD
+            if self.ahead:
+                # FIVE graphs + two sets of encoder buffers: trunk (its own 3-channel input), HRfeature, and per parity of the batch
+                # number the encoder / decoders (own 8-channel input) and reg / seg reading that parity's decoder outputs
+                self.side = side
+                self.x3 = torch.zeros((batch, 3, 64, 64), device=dev)
+                self.x_lr = [torch.zeros((batch, chans, 64, 64), device=dev) for _ in range(2)]
+                self.g_trunk, self.g_hrfeat = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                self.g_lr2 = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
+                self.g_fuse2 = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
+                with torch.cuda.graph(self.g_trunk):
+                    self.fea = features_for_head(net_hr, self.x3, model=model)
+                with torch.cuda.graph(self.g_hrfeat):
+                    self.hr_out = model.forward_hr(self.fea)
+                self.lr_out2, self.out2 = [], []
+                for p in range(2):
+                    with torch.cuda.graph(self.g_lr2[p]):
+                        self.lr_out2.append(model.forward_lr(self.x_lr[p]))
+                    with torch.cuda.graph(self.g_fuse2[p]):
+                        height, build = model.forward_fuse(self.lr_out2[p][0], self.lr_out2[p][1], self.hr_out)
+                    self.out2.append((height, build) + ((self.lr_out2[p][2],) if self.lr_out2[p][2] is not None else ()))
+                self.ev_lr = [torch.cuda.Event(), torch.cuda.Event()]
+                self.ev_trunk = torch.cuda.Event()
+                self.pending = [False, False]          # parity p's encoder / decoders were launched ahead (for the batch that comes next)
+                self.out = self.out2[0]
+                self.n = 0
+            elif self.split:
                 self.side = side
                 self.g_lr, self.g_hr, self.g_fuse = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.g_lr):
@@ -697,7 +728,42 @@ class _PredictGraph:
                   for m in (net_hr, model) for t in list(m.parameters()) + list(m.buffers()))
         return (k, batch, str(dev), wcache.gen(), _H._HEAD_PRECISION["mode"])
 
-    def __call__(self, x_src, k):
+    def reset(self):
+        """forget an encoder pass launched ahead (a city loop that ended early): the next call stages its own"""
+        if self.ahead and any(self.pending):
+            torch.cuda.current_stream(self.x.device).wait_stream(self.side)
+            self.pending = [False, False]
+
+    def _call_ahead(self, x_src, nxt_src):
+        cur = torch.cuda.current_stream(self.x.device)
+        p = self.n & 1
+        if not self.pending[p]:                        # first batch of a run: this batch's encoder / decoders now, beside its trunk
+            self.x_lr[p].copy_(x_src, non_blocking=True)
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                self.g_lr2[p].replay()
+                self.ev_lr[p].record(self.side)
+        self.x3.copy_(x_src[:, :3], non_blocking=True)
+        self.g_trunk.replay()
+        if nxt_src is not None:                        # the next batch's encoder / decoders: behind this trunk, beside what follows it
+            self.ev_trunk.record(cur)                  # (also behind reg / seg of batch k - 1, the last readers of that parity's buffers)
+            self.side.wait_event(self.ev_trunk)
+            with torch.cuda.stream(self.side):
+                self.x_lr[1 - p].copy_(nxt_src, non_blocking=True)
+                self.g_lr2[1 - p].replay()
+                self.ev_lr[1 - p].record(self.side)
+            self.pending[1 - p] = True
+        self.g_hrfeat.replay()
+        cur.wait_event(self.ev_lr[p])
+        self.g_fuse2[p].replay()
+        self.pending[p] = False
+        self.n += 1
+        return self.out2[p]
+
+    def __call__(self, x_src, k, nxt_src=None):
+        """one full batch; `nxt_src`: the tiles of the NEXT full batch of the same run (None: there is none)"""
+        if self.ahead:
+            return self._call_ahead(x_src, nxt_src)
         self.x[:k].copy_(x_src, non_blocking=True)
         if k < self.x.shape[0]:
             self.x[k:].zero_()
@@ -732,11 +798,13 @@ def predict_tiles(net_hr, model, tiles, posall, mosaic, batch=32, rank=0, world=
         if pg is None or pg.key != _PredictGraph.weights_key(net_hr, model, batch, dev):
             pg = model.__dict__["_srbh_predict_graph"] = None      # (drop the old graph's memory pool first)
             pg = model.__dict__["_srbh_predict_graph"] = _PredictGraph(net_hr, model, batch, dev, tiles.shape[1])
+    if pg is not None:
+        pg.reset()
     for s in range(lo, hi, batch):
         e = min(s + batch, hi)
         k = e - s
         if pg is not None and k == batch:
-            out = pg(tiles[s:e], k)
+            out = pg(tiles[s:e], k, tiles[e:e + batch] if e + batch <= hi else None)
             mosaic.add(out[0], out[1], posall[s:e])
             continue
         x = tiles[s:e].to(dev, non_blocking=True)

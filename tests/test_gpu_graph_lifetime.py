@@ -97,17 +97,22 @@ def test_predict_graph_split_over_two_streams_equals_the_single_graph(monkeypatc
     from srbh_amd import harness
     net_hr, model = _nets(isaggre=True)
     model.eval()
-    sizes = [3 * 128, 128 + 40, 2 * 128]
+    sizes = [3 * 128, 128 + 40, 2 * 128, 5 * 128 + 7]
     res = {}
-    for split in (True, False, True):
+    # (round 6) harness.PREDICT_AHEAD: batch k + 1's encoder / decoders launched behind batch k's trunk, two sets of buffers by the parity of
+    # the batch number -- 3, 1, 2 and 5 full batches per city: both parities, a city that ends on either, a pass launched ahead for every batch
+    # but a city's first
+    for split, ahead in ((True, True), (True, False), (False, False), (True, True)):
         monkeypatch.setattr(harness, "PREDICT_SPLIT", split)
+        monkeypatch.setattr(harness, "PREDICT_AHEAD", ahead)
         model.__dict__["_srbh_predict_graph"] = None
         got = _run_cities(net_hr, model, sizes, graph=True)
         pg = model.__dict__["_srbh_predict_graph"]
-        assert pg is not None and pg.split == split and len(pg.out) == 3
-        res.setdefault(split, []).append(got)
+        assert pg is not None and pg.split == split and pg.ahead == (split and ahead) and len(pg.out) == 3
+        assert not pg.ahead or (pg.n == 11 and not any(pg.pending))
+        res.setdefault((split, ahead), []).append(got)
     model.__dict__["_srbh_predict_graph"] = None
-    for a, b in ((res[True][0], res[False][0]), (res[True][0], res[True][1])):
+    for a, b in ((res[(True, True)][0], res[(False, False)][0]), (res[(True, False)][0], res[(False, False)][0]), (res[(True, True)][0], res[(True, True)][1])):
         for i, (g, w) in enumerate(zip(a, b)):
             for u, v in zip(g, w):
                 assert torch.equal(u, v), f"city {i}"

@@ -201,7 +201,7 @@ def test_up2_cat_matches_interpolate_and_cat_bit_exact_forward(B, Cx, Cs, H, W):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H", [(64, 272, 1632, 2), (5, 24, 144, 16), (3, 1632, 272, 2), (64, 32, 192, 16), (7, 56, 336, 8), (2, 960, 160, 4),
-                                          (9, 19, 37, 4), (64, 2688, 448, 2), (3, 48, 24, 32)])
+                                          (9, 19, 37, 4), (64, 2688, 448, 2), (3, 48, 24, 32), (256, 160, 960, 4), (256, 272, 1632, 2), (200, 336, 56, 8)])
 def test_pointwise_conv_matches_stock_conv(B, Cin, Cout, H):
     """1x1 convolution kernels (csrc/srbh_pwconv.hip, fp32 MFMA) against F.conv2d evaluated in fp64: forward, input gradient, weight gradient"""
     from srbh_amd.encoders import _PointwiseConvFn

@@ -8,5 +8,5 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
             agg[(r["Kernel_Name"].replace("(anonymous namespace)::", "")[:48], int(r.get("Grid_Size_X", r.get("Grid_Size", 0))), int(r.get("Workgroup_Size_X", 0)))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 tot = sum(sum(v) for v in agg.values())
 print("total", round(tot / 1e3), "us over the run")
-for (k, g, w), v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:40]:
+for (k, g, w), v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:int(sys.argv[3]) if len(sys.argv) > 3 else 40]:
     print(f"{k:50s} grid {g:8d} wg {w:5d} x{len(v):4d}  {sum(v) / len(v) / 1e3:7.1f} us")

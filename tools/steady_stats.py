@@ -26,10 +26,11 @@ print("steps %d | kernel time %.2f ms/step | wall %.2f ms/step | %d launches/ste
 bycalls = len(sys.argv) > 4 and sys.argv[4] != "--stock"
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0 if bycalls else 1])[:top]:
     print("%7.3f ms/step %5.1f %% %6d calls/step  %s" % (v[1] / steps / 1e6, 100.0 * v[1] / tot, v[0] // steps, k))
-GROUPS = (("RRDBNet (trunk, first/tail convs)", ("ptrunk", "ptail", "conv_first", "rrdb", "poison", "upconv", "tail_")),
-          ("encoder / decoders: libsrbh depthwise, 1x1 and decoder 3x3 convs, SE, training BatchNorm, upsample+concat", ("dw_fwd", "dw_bwd", "dw_reduce", "dw_lds", "dconv", "mbconv_mid", "se_train", "se_hidden", "se_gate", "se_bwd", "affine_act", "bn_act_train", "bn_large", "up2_cat", "pw_gemm", "pw_wgrad", "transpose_many")),
-          ("head (libsrbh hconv / hwgrad / BN / elementwise)", ("hconv", "hwgrad", "hbwd16", "hpack", "bn_", "relu_mask", "nchw_to_nhwc", "nhwc_to_nchw", "ps2_", "add_inplace", "aggregate", "chan_sum", "bias_grad")),
-          ("optimizer (multi_tensor_apply)", ("multi_tensor_apply",)),
+GROUPS = (("RRDBNet (trunk, first/tail convs)", ("ptrunk", "ptail", "conv_first", "rrdb", "poison", "upconv", "tail_", "conv3x3_f16")),
+          ("encoder / decoders: libsrbh depthwise, 1x1 and decoder 3x3 convs, SE, training BatchNorm, upsample+concat", ("dw_fwd", "dw_bwd", "dw_reduce", "dw_lds", "dconv", "mbconv_mid", "se_train", "se_hidden", "se_gate", "se_bwd", "affine_act", "bn_act_train", "bn_large", "up2_cat", "pw_gemm", "pw_wgrad", "transpose_many", "stem_conv", "bn_eval")),
+          ("head (libsrbh hconv / hwgrad / BN / elementwise)", ("hconv", "hwgrad", "hbwd16", "hblock16", "hpack", "bn_", "relu_mask", "nchw_to_nhwc", "nhwc_to_nchw", "ps2_", "add_inplace", "aggregate", "chan_sum", "bias_grad")),
+          ("optimizer (libsrbh Adam; multi_tensor_apply)", ("multi_tensor_apply", "adam_kernel")),
+          ("tiled prediction: mosaic accumulate / finalize", ("mosaic_",)),
           ("losses (libsrbh)", ("wmse_", "cedice_")))
 gs = collections.OrderedDict((g[0], [0, 0]) for g in GROUPS)
 gs["encoder / decoders / losses: stock ops (MIOpen, rocBLAS, ATen)"] = [0, 0]
