@@ -11,10 +11,16 @@
 //     columns of all six rows: lanes address LDS individually, so 12 scattered pixels make one MFMA group), bn1 + ReLU + fp16 rounding
 //     in the epilogue, ZERO outside the image (conv2's padding is the padding of a1, not conv1 of a padded x), written to LDS;
 //   * phase 2: conv2 from that window, bn2, + the identity read from the staged x window (it is the tile's own input), ReLU, one store.
-// 32 bytes read + 32 (fp16) / 64 (fp32) written per pixel; 1.56 x the matrix-core work of the two launches (225 + 144 instead of 2 x 144
-// MFMAs per tile: the halo ring of a1 is recomputed), which an HBM-bound kernel has to spare.
-// Same operand rounding and the same MFMA order per output element as the two-launch chain (taps 0..8, one 16-channel K step each; the
-// epilogues are hconv16_kernel's expressions): bit-identical outputs (tests/test_gpu_hblock16.py).
+// 32 bytes read + 32 (fp16) / 64 (fp32) written per pixel; the halo ring of a1 is recomputed (1.29 x conv1's work).
+// Same operand rounding and the same epilogue expressions as the two-launch chain.  The matrix instruction is v_mfma_f32_16x16x32_f16 with TWO
+// taps per instruction (K = 2 x 16 channels): the legacy 16x16x16 form issues in the same 8 passes (tools/mfma_rate.hip), and with
+// 90-99 of them per tile and wave this kernel kept the matrix pipe 70 % busy -- its bound, not HBM.  Lane group kk = lane >> 4 holds channels
+// 8 (kk & 1) .. + 7 of the pair's first (kk < 2) or second (kk >= 2) tap -- a 16-byte half of the pixel record (the record's swizzle exchanges
+// its two halves as wholes).  conv1 pairs the taps (dy 0, dy 1) of a dx and leaves dy 2 as a half-empty instruction (zero weights in the upper
+// lane groups): the upper groups then simply read one window row further down, so a fragment row is still read from LDS once and used by two
+// output rows -- 6 x 6 instead of 6 x 9 instructions; conv2 and the gathered edge unit have no such reuse and pair taps (0,1) (2,3) (4,5) (6,7)
+// (8,-): 5 instead of 9.  The sum over a pixel's 144 products is the same set of products in another order: the outputs equal the
+// two-launch chain's up to the last fp16 bit on a small fraction of the elements (tests/test_gpu_hblock16.py), no longer bit for bit.
 // The walk, the XCD-contiguous tile ranges and the two-tiles-ahead loads are hconv16_kernel's.
 // Restrictions (host: srbh_hblock16_supported): 16 channels, fp16 NHWC input, W % 64 == 0, H % 4 == 0.
 struct HBlkParams {
@@ -43,13 +49,26 @@ __global__ __launch_bounds__(256, 2) void hblock16_kernel(const HBlkParams p) {
     const int t_first = (blockIdx.x & 7) * p.tiles_per_xcd + (blockIdx.x >> 3), t_step = gridDim.x >> 3;
 
     // ---- per-thread constants
-    short4v wa1[9], wa2[9];
-    {
-        const short4v* q1 = (const short4v*)p.w1 + lane;
-        const short4v* q2 = (const short4v*)p.w2 + lane;
+    // A operands: lane (oc = l15, kk) holds input channels 8 (kk & 1) .. + 7 of tap tA (kk < 2) / tB (kk >= 2, zero when the pair has no
+    // second tap), gathered from the one-tap-per-instruction pack (lane (q << 4 | oc) of a tap = input channels 4 q .. 4 q + 3)
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    typedef short short8v __attribute__((ext_vector_type(8)));
+    const int hi = kk >> 1, oct = kk & 1;
+    auto pair_w = [&](const void* w, const int tA, const int tB) {
+        const short4v* q = (const short4v*)w;
+        const int tap = hi ? tB : tA;
+        short8v r = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (tap >= 0) {
+            const short4v lo4 = q[tap * 64 + ((2 * oct) << 4 | l15)], hi4 = q[tap * 64 + ((2 * oct + 1) << 4 | l15)];
+            r = short8v{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        }
+        return r;
+    };
+    short8v wp1[3], ws1[3], we1[5], wa2[5];       // conv1: (dy 0, dy 1) pairs and dy 2 singles per dx; the edge unit's and conv2's five pairs
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) { wa1[tap] = q1[tap * 64]; wa2[tap] = q2[tap * 64]; }
-    }
+    for (int dx = 0; dx < 3; ++dx) { wp1[dx] = pair_w(p.w1, dx, 3 + dx); ws1[dx] = pair_w(p.w1, 6 + dx, -1); }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { we1[q] = pair_w(p.w1, 2 * q, q < 4 ? 2 * q + 1 : -1); wa2[q] = pair_w(p.w2, 2 * q, q < 4 ? 2 * q + 1 : -1); }
     const floatx4 sc1 = *(const floatx4*)(p.s1 + kk * 4), sh1 = *(const floatx4*)(p.h1 + kk * 4);
     const floatx4 sc2 = *(const floatx4*)(p.s2 + kk * 4), sh2 = *(const floatx4*)(p.h2 + kk * 4);
     // staging unit `it`: window pixel (tid >> 2) + 64 it = (row, col) of the 8 x 68 window, quad cg; tile-independent
@@ -70,20 +89,27 @@ __global__ __launch_bounds__(256, 2) void hblock16_kernel(const HBlkParams p) {
         }
     }
     const bool last_unit = tid + (NIT - 1) * 256 < XR * XC * 4;
-    // phase 1 (conv1): wave w computes a1 columns 16 w .. 16 w + 15 of all six rows; B fragment of tap (dy, dx) for a1 row r: x window
-    // (r + dy, 16 w + l15 + dx).  The swizzle bit depends on the column only: one base per dx, rows are immediate offsets.
-    int b1[3];
+    // 16-byte half `o` of the record of window pixel (r, col): the swizzle exchanges the halves with bit 3 of the column
+    auto off16 = [](const int r, const int col, const int o, const int cols) { return (r * cols + col) * 32 + ((o ^ ((col >> 3) & 1)) << 4); };
+    // phase 1 (conv1): wave w computes a1 columns 16 w .. 16 w + 15 of all six rows.  Fragment (xr, dx): lane groups kk < 2 read x window pixel
+    // (xr, 16 w + l15 + dx), groups kk >= 2 the pixel one row below (b1); the last window row has no row below: every group reads it (b1u;
+    // it only feeds the half-empty dy 2 instructions, whose upper weights are zero -- but zero times whatever LDS holds behind the stage is not)
+    int b1[3], b1u[3];
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) b1[dx] = h16_off(0, wave * 16 + l15 + dx, kk, XC);
+    for (int dx = 0; dx < 3; ++dx) {
+        b1[dx] = off16(hi, wave * 16 + l15 + dx, oct, XC);
+        b1u[dx] = off16(0, wave * 16 + l15 + dx, oct, XC);
+    }
     // the edge unit (wave 3): lane l15 < 12 holds a1 (row l15 >> 1, column 64 + (l15 & 1)); the other lanes repeat lane 0's addresses
     const int e_row = l15 < 12 ? (l15 >> 1) : 0, e_col = l15 < 12 ? 64 + (l15 & 1) : 64;
-    int be[3];
+    int be[5], b2[5];
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) be[dx] = h16_off(e_row, e_col + dx, kk, XC);
-    // phase 2 (conv2): wave w = output row w; B fragment of tap (dy, dx), column group i: a1 window (w + dy, 16 i + l15 + dx)
-    int b2[3];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) b2[dx] = h16_off(wave, l15 + dx, kk, AC);
+    for (int q = 0; q < 5; ++q) {
+        const int tap = (hi && q < 4) ? 2 * q + 1 : 2 * q, dy = tap / 3, dx = tap - dy * 3;      // (the single tap 8: both halves read its pixel)
+        be[q] = off16(e_row + dy, e_col + dx, oct, XC);
+        // phase 2 (conv2): wave w = output row w; column group i adds 16 i columns (the swizzle bit does not change with 16 columns)
+        b2[q] = off16(wave + dy, l15 + dx, oct, AC);
+    }
     // a1 stores of phase 1 and the identity reads of phase 2 (swizzle bit 3 of the column: constant over 16 i for the identity, per unit below)
     const int a_st = h16_off(0, wave * 16 + l15, kk, AC);                      // + r * AC * 32
     const int a_se = h16_off(e_row, e_col, kk, AC);
@@ -132,13 +158,15 @@ __global__ __launch_bounds__(256, 2) void hblock16_kernel(const HBlkParams p) {
     // prefetches), which again waits for the prefetch issued a moment ago
     asm volatile("" ::"v"(sc1), "v"(sh1), "v"(sc2), "v"(sh2));
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) asm volatile("" ::"v"(wa1[tap]), "v"(wa2[tap]));
+    for (int dx = 0; dx < 3; ++dx) asm volatile("" ::"v"(wp1[dx]), "v"(ws1[dx]));
+#pragma unroll
+    for (int q = 0; q < 5; ++q) asm volatile("" ::"v"(we1[q]), "v"(wa2[q]));
     if (t_first >= t_end) return;
     issue(SL0{}, t_first);
     issue(SL1{}, t_first + t_step < t_end ? t_first + t_step : t_first);
 
-    auto mfma = [&](const short4v a, const short4v b, floatx4& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4, a), __builtin_bit_cast(half4, b), acc, 0, 0, 0);
+    auto mfma = [&](const short8v a, const short8v b, floatx4& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), acc, 0, 0, 0);
     };
     // bn1 + ReLU + fp16 of one a1 unit (hconv16_kernel's epilogue expressions: post_scale, post_relu, out16), zero outside the image
     auto a1_store = [&](const floatx4 acc, const bool inside, const int off) {
@@ -168,17 +196,17 @@ __global__ __launch_bounds__(256, 2) void hblock16_kernel(const HBlkParams p) {
 #pragma unroll
             for (int r = 0; r < AR; ++r) acc[r] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int xr = 0; xr < XR; ++xr) {          // x window row xr feeds a1 rows xr - dy (dy = 0..2): each fragment is read once
-                short4v b[3];
+            for (int xr = 0; xr < XR; ++xr) {          // fragment row xr = x window rows (xr | xr + 1): taps (dy 0 | dy 1) of a1 row xr, tap dy 2 of a1 row xr - 2
+                short8v b[3];
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) b[dx] = *(const short4v*)(sx + b1[dx] + xr * XC * 32);
+                for (int dx = 0; dx < 3; ++dx) b[dx] = *(const short8v*)(sx + (xr < XR - 1 ? b1[dx] : b1u[dx]) + xr * XC * 32);
+                if (xr < AR) {
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int r = xr - dy;
-                    if (r >= 0 && r < AR) {
+                    for (int dx = 0; dx < 3; ++dx) mfma(wp1[dx], b[dx], acc[xr]);
+                }
+                if (xr >= 2) {
 #pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) mfma(wa1[dy * 3 + dx], b[dx], acc[r]);
-                    }
+                    for (int dx = 0; dx < 3; ++dx) mfma(ws1[dx], b[dx], acc[xr - 2]);
                 }
             }
             const int Xc = X0 - 1 + wave * 16 + l15;          // image column of this lane's a1 pixel
@@ -188,10 +216,7 @@ __global__ __launch_bounds__(256, 2) void hblock16_kernel(const HBlkParams p) {
             if (wave == 3) {       // the two right-most columns of the six rows as one gathered unit
                 floatx4 ae = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int dy = tap / 3, dx = tap - dy * 3;
-                    mfma(wa1[tap], *(const short4v*)(sx + be[dx] + dy * XC * 32), ae);
-                }
+                for (int q = 0; q < 5; ++q) mfma(we1[q], *(const short8v*)(sx + be[q]), ae);
                 if (l15 < 12)
                     a1_store(ae, (unsigned)(X0 - 1 + e_col) < (unsigned)p.W && (unsigned)(Y0 - 1 + e_row) < (unsigned)p.H, a_se);
             }
@@ -203,10 +228,9 @@ __global__ __launch_bounds__(256, 2) void hblock16_kernel(const HBlkParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dy = tap / 3, dx = tap - dy * 3;
+            for (int q = 0; q < 5; ++q) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) mfma(wa2[tap], *(const short4v*)(s_a + b2[dx] + (dy * AC + i * 16) * 32), acc[i]);
+                for (int i = 0; i < 4; ++i) mfma(wa2[q], *(const short8v*)(s_a + b2[q] + i * 16 * 32), acc[i]);
             }
             const long pix0 = ((long)img * p.H + Y0 + wave) * p.W + X0 + l15;
 #pragma unroll

@@ -229,6 +229,10 @@ __global__ __launch_bounds__(256, SRBH_ENTRY_WGS_PER_CU) void hconv_entry_kernel
 // flight under 4 x 40 MFMAs.  Same staging layout per chunk (h16_off swizzle: a 16-byte unit is the granule pair the swizzle moves as a whole),
 // same fragment reads, same MFMA order (chunk 0..3, tap 0..8) and epilogue as hconv_entry_kernel: bit-identical outputs; BatchNorm partial
 // sums differ only by their order of addition (other grid).
+// (Round 6: two chunks per v_mfma_f32_16x16x32_f16 -- 2 x 40 instead of 4 x 40 instructions per wave and tile -- was built and measured: this
+//  kernel 1.21 -> ~1.0 ms per 256 tiles, tiled prediction +0.5 %, training step unchanged (profiles/r06aa_*).  NOT kept: the other summation
+//  order ends the bit-identity with hconv_entry_kernel, i.e. of the fp16 feature hand-off with the fp32 one (tests/test_gpu_feature_h16.py),
+//  which is worth more than 0.5 %.)
 template <int O16>
 __global__ __launch_bounds__(256, 1) void hconv_entry64_kernel(const EParams e) {
     const HParams& p = e.a;

@@ -1,7 +1,8 @@
 """GPU: a plain BasicBlock of the fp16 inference chain as ONE libsrbh pass (srbh_hblock16_eval, csrc/srbh_hblock16_kernel.h; reference:
-SR/HRfuse.py:142-159 in eval mode) against (1) the two-launch chain it replaces -- same operand rounding, same MFMA order: bit-identical, at
-every tile position of an image (corners, edges, interior), fp16 and fp32 outputs -- and (2) the float64 torch graph of the block on the
-fp16-rounded operands (<= 2e-3: two fp16 roundings of activations on the way)."""
+SR/HRfuse.py:142-159 in eval mode) against (1) the two-launch chain it replaces -- same operand rounding and epilogues; since the kernel packs
+two taps into one 16x16x32 matrix instruction the 144 products of an output are summed in another order, so the results agree up to the last
+fp16 bit on a small fraction of the elements (they were bit-identical with one tap per instruction) -- at every tile position of an image
+(corners, edges, interior), fp16 and fp32 outputs -- and (2) the float64 torch graph of the block on the fp16-rounded operands."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -45,7 +46,13 @@ def test_fused_block_equals_the_two_launch_chain(B, Hh, Ww, out_h16):
             assert y.dtype == (torch.float16 if out_h16 else torch.float32)
             outs.append(y.float().cpu())
     assert bool(torch.isfinite(outs[0]).all())
-    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    d = (outs[0] - outs[1]).abs()
+    # a different summation order moves an fp32 sum by ~1e-7; where that crosses an fp16 rounding boundary (of the intermediate a1 or of the
+    # output) an element moves by one fp16 step: 2^-10 relative, allow two
+    assert bool((d <= 2.0 ** -9 * outs[1].abs().clamp_min(1.0)).all()), float(d.max())
+    assert float(d.norm() / outs[1].norm()) <= 1e-4
+    if out_h16:
+        assert float((d > 0).float().mean()) <= 0.02, float((d > 0).float().mean())
 
 
 def test_fused_block_against_the_float64_graph():
