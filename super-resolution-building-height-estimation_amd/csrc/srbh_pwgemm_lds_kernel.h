@@ -8,10 +8,8 @@
 // cores work on the other stage -> LDS), and its four waves run v_mfma_f32_32x32x2_f32 on them: lane l feeds A[m = l & 31][k = l >> 5] and
 // B[k = l >> 5][n = l & 31] (one ds_read_b32 each, conflict-free along m / n).  Exact fp32 (the instruction is an fmaf chain over k), K walked
 // in order.
-//   forms: WM x WN x WK waves -- 2x2x1 (64x64 tile, 64x128 with TN = 2): the expand convs, M large and K small;
-//                                1x1x8 (32x32 tile, EIGHT waves split every 128-wide K block and fold through LDS): the project convs, whose
-//                                M of 56 ... 448 and N of 1 024 ... 4 096 would otherwise leave most of the chip idle on K = 336 ... 2 688;
-//                                1x4x1 (32x128): M <= 32.
+//   forms: WM x WN x WK waves -- 2x2x1 (64x64 tile, 64x128 with TN = 2): the expand convs, M large and K small; 1x4x1 (32x128): M <= 32.
+//   (WK > 1 -- waves splitting every K block and folding through LDS -- is supported by the template; no such form is instantiated, see pw_lds_plan.)
 // Layouts as pw_gemm_kernel: In [B][K][HW], Out [B][M][HW], W [M][K] or, TRANS_A, [K][M]; M, K, HW multiples of 4 (every MBConv width is a
 // multiple of 8, planes are 4 ... 1 024 pixels), so every global access is a 16-byte one: a column quad n .. n + 3 lies in one image.  Planes of
 // 4 pixels walk K fastest in the operand loads and M fastest in the stores (a plane is one 16-byte item; consecutive channels are contiguous).
@@ -196,7 +194,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void pw_gemm_lds_kernel(const fl
 }
 
 // which form takes a product (0: none -- pw_gemm_kernel keeps it)
-struct PwLdsPlan { int form, tiles_m, tiles_n; };      // form 1: 64x64, 2: 64x128, 3: 32x32 with split K, 4: 32x128
+struct PwLdsPlan { int form, tiles_m, tiles_n; };      // form 1: 64x64, 2: 64x128, 4: 32x128
 inline PwLdsPlan pw_lds_plan(int M, int K, int HW, long ncols) {
     static const int enabled = getenv("SRBH_PW_LDS") ? atoi(getenv("SRBH_PW_LDS")) : 1;              // 0: always pw_gemm_kernel (A/B aid)
     static const long min_cols = getenv("SRBH_PW_LDS_MINN") ? atol(getenv("SRBH_PW_LDS_MINN")) : 1024;
@@ -206,7 +204,9 @@ inline PwLdsPlan pw_lds_plan(int M, int K, int HW, long ncols) {
     if (M <= 32) p = PwLdsPlan{4, 1, (int)cdiv(ncols, 128)};
     else if (cdiv(M, 64) * cdiv(ncols, 128) >= 1024) p = PwLdsPlan{2, (int)cdiv(M, 64), (int)cdiv(ncols, 128)};
     else if (cdiv(M, 64) * cdiv(ncols, 64) >= 384 || K < 128) p = PwLdsPlan{1, (int)cdiv(M, 64), (int)cdiv(ncols, 64)};
-    else p = PwLdsPlan{3, (int)cdiv(M, 32), (int)cdiv(ncols, 32)};
+    // (else: few tiles and a deep K -- the project convs at 2x2 / 4x4 planes.  A 32x32 form whose eight waves split every 128-wide K block
+    //  was built: 20-30 % faster alone (profiles/r06w_time_pwconv.txt), but its 74 KB of LDS per workgroup beside the head's kernels cost the
+    //  tiled prediction 1.5-7 % depending on the box (profiles/r06ac_ab_pw_lds_forms.txt); pw_gemm_kernel's 16x16 tiles with split K keep them)
     return p;
 }
 
@@ -232,7 +232,6 @@ int pw_lds_launch(const PwLdsPlan& p, const float* W, const float* In, float* Ou
     switch (p.form) {
         case 1: return pw_lds_launch_form<2, 2, 1, 1, 1, TRANS_A, EPI>(p, W, In, Out, M, K, HW, ncols, ep, st);
         case 2: return pw_lds_launch_form<2, 2, 1, 1, 2, TRANS_A, EPI>(p, W, In, Out, M, K, HW, ncols, ep, st);
-        case 3: return pw_lds_launch_form<1, 1, 8, 1, 1, TRANS_A, EPI>(p, W, In, Out, M, K, HW, ncols, ep, st);
         default: return pw_lds_launch_form<1, 4, 1, 1, 1, TRANS_A, EPI>(p, W, In, Out, M, K, HW, ncols, ep, st);
     }
 }

@@ -138,8 +138,8 @@ def test_fused_inference_depthwise_bn_swish_pool_kernel(B, C, H, K, stride, pre)
 
 
 # (the second row: products wide enough for the LDS-tiled forms of csrc/srbh_pwgemm_lds_kernel.h -- 32x128, 64x128, 64x64 incl. K = 56 (not a
-#  multiple of the 16-wide K block) and a ragged last column tile, 32x32 with split K at 2x2 and 4x4 planes incl. M = 112 / 272 and K = 1632,
-#  neither a multiple of its tile)
+#  multiple of the 16-wide K block), a ragged last column tile and 2x2 planes (M = 2688) -- and wide products with few tiles and a deep K, which
+#  stay on pw_gemm_kernel's split-K form)
 @pytest.mark.parametrize("B,Cin,Cout,HW", [(3, 144, 24, 1024), (2, 240, 40, 256), (5, 672, 112, 16), (7, 2688, 448, 4), (128, 960, 160, 16), (1, 24, 24, 64),
                                            (67, 144, 32, 256), (256, 24, 144, 1024), (255, 160, 960, 16), (130, 56, 336, 64), (256, 1632, 272, 4),
                                            (250, 672, 112, 16), (256, 448, 2688, 4)])
