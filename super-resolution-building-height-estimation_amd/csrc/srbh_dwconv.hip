@@ -581,6 +581,8 @@ constexpr size_t DW_LDS_MAX = 60 * 1024;
 #ifndef DW_LDS_FORMS
 #define DW_LDS_FORMS 1          // (0: the one-thread-per-output kernels, for same-box A/B builds)
 #endif
+// (round 6: up to 8 rounds of planes per workgroup at the tiled prediction's 49 152 planes -- fewer, longer workgroups -- measured: the encoder
+//  graph 4.67 ms at one round, 4.57 at two, 4.61 at four, 4.76 at eight (profiles/r06ae_predict_parts.txt): not kept)
 int lds_planes(int out_px) {     // planes a workgroup stages per round: ~256 outputs
     int P = 256 / (out_px > 0 ? out_px : 1);
     return P < 1 ? 1 : (P > 64 ? 64 : P);
