@@ -10,6 +10,13 @@
 //   * the epilogue stores straight from the MFMA D layout (v_permlane32_swap -> 16 B per lane, no LDS), which leaves
 //     LDS free: the input tiles of the NEXT tile are DMA'd while the epilogue of the current one drains.
 // Same arithmetic, same accumulation order as conv3x3_f16_kernel<2, UPS> (bit-identical results).
+// (Round 6: the three phases of a tile run one after the other here -- ablation builds, profiles/r06ag_ptail_ablation.txt: of the 0.34 ms the
+//  three tail convs take per 32 tiles the MFMAs are 0.11, the epilogue (800 VALU instructions + 48 KB of stores per wave) 0.12, the exposed part
+//  of the input DMA 0.045.  A fully pipelined form was built: two accumulator sets, the epilogue of tile t - 1 interleaved unit by unit with the
+//  MFMA groups of tile t's second chunk in one basic block, the input chunks requested half a tile ahead, counted waits; bit-identical, 45 tests.
+//  It is 0.4 % faster on forward_feature and 0.6 % slower in the tiled prediction (profiles/r06ah_ab_ptail_pipe.txt): with the phases
+//  overlapped the launch draws more power at once and the package clocks down -- the tail convs are energy-bound like the trunk,
+//  not latency-bound.  Not kept.)
 #include <stdlib.h>
 #include "srbh_conv3x3_kernel.h"
 
