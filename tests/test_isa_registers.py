@@ -19,9 +19,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # scratch bytes allowed per kernel family (regex on the demangled name); anything not listed: 0
 # (round 6: hbwd16_kernel 8-72 B -> 0 in all six forms and hconv_entry_kernel 100 B -> 0 -- 20 B left in its bf16 / 16-bit-output form, which no
 #  caller of the training step or the inference chain uses -- by making their loads unconditional and their prefetch issue constant)
-BUDGET = [(r"hconv16_kernel<", 68), (r"hconv_entry_kernel<2, 1, 0>", 20)]
+BUDGET = [(r"hconv16_kernel<", 68), (r"hconv_entry_kernel<2, 1, 0>", 20), (r"pw_gemm_kernel<2, 2, 1, 16, 1>", 12)]     # (the last: a 1 024-thread form no product of the model selects)
 ZERO = [r"ptrunk3_kernel<0, 0>", r"ptrunk3_kernel<0, 1>", r"hblock16_kernel<", r"hconv_entry64_kernel<", r"hconv_up_kernel<", r"hwgrad16_kernel<",
-        r"hbwd16_kernel<", r"hconv_entry_kernel<1,", r"hconv_entry_kernel<2, 0"]
+        r"hbwd16_kernel<", r"hconv_entry_kernel<1,", r"hconv_entry_kernel<2, 0", r"pw_gemm_lds_kernel<", r"ptail_kernel<"]
 
 
 def _kernels(src, tmp_path):
@@ -38,7 +38,7 @@ def _kernels(src, tmp_path):
 
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="no hipcc")
-@pytest.mark.parametrize("src", ["srbh_ptrunk.hip", "srbh_head.hip", "srbh_head_bwd.hip"])
+@pytest.mark.parametrize("src", ["srbh_ptrunk.hip", "srbh_head.hip", "srbh_head_bwd.hip", "srbh_ptail.hip", "srbh_pwconv.hip"])
 def test_scratch_budget_of_the_hot_kernels(src, tmp_path):
     ks = _kernels(src, tmp_path)
     assert ks, "no kernel descriptors found"
