@@ -622,6 +622,13 @@ class _BlockChainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         subs = ctx.subs
+        if subs is None:
+            raise RuntimeError("srbh BasicBlock chain: backward a second time through the same graph -- the saved activations were released "
+                               "after the first one (as autograd releases saved tensors; retain_graph=True is not supported here: run the "
+                               "forward again, or SRBH_BLOCK_CHAIN=0 for one autograd node per block)")
+        # (the blocks' saved tensors live in plain attributes, not in ctx.save_for_backward -- a chain of bodies shares one node --, so they are
+        #  released HERE: otherwise ~1 GB of activations per head stayed referenced until the graph node itself died)
+        ctx.subs = None
         pgrads = [None] * len(subs)
         handoff, dx0, dx1 = None, None, None
         with deferred_wgrad_reduces():           # the ~7 weight gradients of the chain reduce their partial sums in one pair of launches at the end

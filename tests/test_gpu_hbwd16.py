@@ -157,6 +157,24 @@ def test_block_chain_handoff_equals_one_node_per_block(monkeypatch):
     assert torch.equal(out["chain"][0], out["nodes"][0])          # the forward is the same launches
 
 
+def test_block_chain_releases_its_activations_after_backward():
+    """the chain keeps its blocks' saved tensors in plain attributes of one autograd node (round-5 advice): they are dropped when its backward has
+    run -- as autograd drops saved tensors -- and a second backward through the same graph says so instead of computing on freed state"""
+    import pytest
+    from srbh_amd import hrfuse as H
+    from srbh_amd import hrfuse_autograd as HA
+    torch.manual_seed(3)
+    blocks = [H.BasicBlock(16, 16).to(DEV).train(), H.BasicBlock(16, 16).to(DEV).train()]
+    x = torch.randn((2, 16, 8, 64), device=DEV, requires_grad=True)
+    with H.head_precision("f16"):
+        y = HA.blocks_forward(blocks, [x])
+        node = y.grad_fn
+        y.sum().backward(retain_graph=True)
+        assert node.subs is None and x.grad is not None
+        with pytest.raises(RuntimeError, match="second time"):
+            y.sum().backward()
+
+
 def test_deferred_weight_gradient_reduces_equal_the_immediate_ones():
     """srbh_hwgrad_defer / srbh_hwgrad_flush: several weight gradients (the generic bf16 kernel at 3x3 and 1x1, the fused entry pair,
     srbh_hbwd16) queue their ordered reduce and ONE pair of launches does them all: every dW bit-identical to the call that reduces at once
