@@ -477,6 +477,28 @@ def bench_predict(args, rank, world, dev, dist, n_cities, warmup, batch=256, sma
     lat = [city(n, 2024 + i) for i, n in enumerate(todo)]
     head_paths = _L.path_counters()          # (graph replays launch without passing the C entry points: these are the eager tail batches + captures)
     torch.backends.cudnn.benchmark = False
+    # where a full batch spends its time (rank 0, outside the timed region): each HIP graph of harness._PredictGraph alone, and the batch as
+    # predict_tiles schedules it -- the sum of the parts against the whole says what the second stream hides (nothing)
+    parts = None
+    pg = model.__dict__.get("_srbh_predict_graph")
+    if rank == 0 and pg is not None and getattr(pg, "ahead", False):
+        def _t(fn, n=10):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return round((time.perf_counter() - t0) / n * 1e3, 3)
+        with torch.no_grad():
+            xb = torch.randn((batch, 8, 64, 64), device=dev) * 0.25 + 0.35
+            parts = {"trunk_first_tail_convs_graph": _t(pg.g_trunk.replay), "hrfeature_graph": _t(pg.g_hrfeat.replay),
+                     "encoder_decoders_graph": _t(pg.g_lr2[0].replay), "reg_seg_graph": _t(pg.g_fuse2[0].replay)}
+            parts["sum_of_parts"] = round(sum(parts.values()), 3)
+            parts["batch_as_scheduled"] = _t(lambda: pg(xb, batch, xb))
+            pg.reset()
+            parts["unit"] = f"ms per batch of {batch} tiles, graphs only (no mosaic, no ragged tail)"
     if rank != 0:
         return None
     total, elapsed = sum(todo), sum(lat)
@@ -503,6 +525,7 @@ def bench_predict(args, rank, world, dev, dist, n_cities, warmup, batch=256, sma
                      "note": "whole predict path PER GPU (RRDBNet forward_feature 146.63 + eval head 8.12 + encoder/decoders 0.9 GFLOP per tile, "
                              "SURVEY 8d) incl. tile generation hand-off, quantise and mosaic: not one kernel; the trunk kernel's own fraction is the headline's `roofline`"},
         "dist": _dist_info(dist),
+        "batch_parts_ms": parts,
         "head_paths_eager_calls": {k: v for k, v in head_paths.items() if v}}
 
 
