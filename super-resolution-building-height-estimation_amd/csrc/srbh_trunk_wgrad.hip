@@ -78,6 +78,9 @@ __device__ __forceinline__ void pair_planes(int p, int& gp, int& dp) {
 // (profiles/r05bv) -- the two kinds share each SIMD's VALU issue (transposes, conversions, operand shifts and swaps are ~350 VALU instructions per
 // tile and SIMD beside 40 MFMAs), so the phases overlap only in part.  Moving the fp16 -> bf16 rounding of x from the staging to the matrix-core
 // waves changed nothing (4.48 -> 4.55 ms; then 2.8 / 2.5 ms alone: profiles/r05ca): built, not kept.
+// (Round 6: the staging stores are 2-way bank-conflicted -- a 16-lane pass holds channel octets 0 and 2 of four pixel groups, 8 CSX = 32 banks
+//  apart twice; walking the pixel group fastest over the lanes makes them conflict-free and the global loads of a lane quad 256 B apart instead of
+//  adjacent: 4.42-4.56 -> 4.61-4.67 ms at batch 24, 1.685 -> 1.75 at batch 8 (profiles/r06an_trunk_wgrad_remap.txt): not kept.)
 __global__ __launch_bounds__(512, 1) void trunk_wgrad_kernel(const TWParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
